@@ -1,0 +1,163 @@
+"""CPU oracle for the cascaded-DDPM sampling loop (TEST INFRASTRUCTURE — see oracle/unet_oracle.py header).
+
+Restates, in fp32 torch on CPU, the continuous-time Gaussian diffusion helpers
+(ip.py:212-318) and the ancestral sampler `Imagen.p_mean_variance / p_sample /
+p_sample_loop / sample` (ip.py:2042-2498) for the options the BASELINE configs use:
+noise-prediction objective, dynamic thresholding, classifier-free guidance, low-res
+noise-conditioning augmentation.  Inpainting / init_images / skip_steps / video are
+out of scope.
+
+All Gaussian noise is drawn through an injectable `noise_fn(tag, shape)` so the HIP
+path and the reference can be fed identical tensors (CPU and GPU RNG streams differ,
+SURVEY §7.3-8).  Tags: ("init", stage), ("lowres", stage), ("step", stage, step_index).
+
+Parity status: pinned against the live reference in tests/test_oracle_vs_reference.py
+(container only) and tests/golden/sample_*.pt (travels).
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Dict, List, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from .unet_oracle import unet_forward_with_cond_scale
+
+Tensor = torch.Tensor
+
+
+# ---------------------------------------------------------------- schedules (ip.py:212-221)
+
+def log_snr_linear(t: Tensor) -> Tensor:
+    """ip.py:212-214."""
+    return -torch.log(torch.special.expm1(1e-4 + 10 * (t ** 2)))
+
+
+def log_snr_cosine(t: Tensor, s: float = 0.008) -> Tensor:
+    """ip.py:216-218 (log() there clamps at eps=1e-5)."""
+    return -torch.log(((torch.cos((t + s) / (1 + s) * math.pi * 0.5) ** -2) - 1).clamp(min=1e-5))
+
+
+SCHEDULES = {"linear": log_snr_linear, "cosine": log_snr_cosine}
+
+
+def alpha_sigma(log_snr: Tensor):
+    """ip.py:220-221."""
+    return torch.sqrt(torch.sigmoid(log_snr)), torch.sqrt(torch.sigmoid(-log_snr))
+
+
+def sampling_time_pairs(num_timesteps: int) -> List[tuple]:
+    """ip.py:245-250 — consecutive pairs of linspace(1, 0, T+1) as python floats held in fp32."""
+    times = torch.linspace(1.0, 0.0, num_timesteps + 1)
+    return [(times[i], times[i + 1]) for i in range(num_timesteps)]
+
+
+def default_noise_schedules(num_unets: int, given="cosine") -> List[str]:
+    """ip.py:1853-1855 — pad to ('cosine','cosine') then 'linear' for the rest."""
+    g = list(given) if isinstance(given, (list, tuple)) else [given]
+    while len(g) < 2:
+        g.append("cosine")
+    while len(g) < num_unets:
+        g.append("linear")
+    return g[:num_unets] if len(g) > num_unets else g
+
+
+# ---------------------------------------------------------------- one DDPM step (ip.py:2042-2165)
+
+def dynamic_threshold(x0: Tensor, percentile: float = 0.95) -> Tensor:
+    """ip.py:2094-2105."""
+    s = torch.quantile(x0.reshape(x0.shape[0], -1).abs(), percentile, dim=-1).clamp(min=1.0)
+    s = s.reshape(-1, *([1] * (x0.ndim - 1)))
+    return x0.clamp(-s, s) / s
+
+
+def ddpm_step(x: Tensor, pred_noise: Tensor, t: Tensor, t_next: Tensor, noise: Tensor, schedule: str,
+              dynamic_thresholding: bool = True, percentile: float = 0.95):
+    """x_t, eps_hat -> x_{t_next}.  t, t_next: (B,) fp32.  ip.py:314-318, 2094-2109, 252-270, 2160-2164."""
+    fn = SCHEDULES[schedule]
+    pad = lambda v: v.reshape(-1, *([1] * (x.ndim - 1)))
+    log_snr, log_snr_next = pad(fn(t)), pad(fn(t_next))
+    alpha, sigma = alpha_sigma(log_snr)
+    alpha_next, sigma_next = alpha_sigma(log_snr_next)
+    x0 = (x - sigma * pred_noise) / alpha.clamp(min=1e-8)
+    x0 = dynamic_threshold(x0, percentile) if dynamic_thresholding else x0.clamp(-1.0, 1.0)
+    c = -torch.special.expm1(log_snr - log_snr_next)
+    mean = alpha_next * (x * (1 - c) / alpha + c * x0)
+    var = (sigma_next ** 2) * c
+    log_var = torch.log(var.clamp(min=1e-20))
+    nonzero = pad(1.0 - (t_next == 0).float())
+    return mean + nonzero * (0.5 * log_var).exp() * noise, x0
+
+
+# ---------------------------------------------------------------- loops (ip.py:2167-2289, 2291-2498)
+
+def p_sample_loop(denoise: Callable[[Tensor, Tensor], Tensor], shape, *, schedule: str, num_timesteps: int,
+                  noise_fn: Callable, stage: int, dynamic_thresholding: bool = True, percentile: float = 0.95,
+                  max_steps: Optional[int] = None, trace: Optional[list] = None) -> Tensor:
+    """denoise(x_t, log_snr(t)) -> guided eps_hat.  Returns the un-normalised image in [0, 1] (ip.py:2281-2289)."""
+    b = shape[0]
+    img = noise_fn(("init", stage), shape)
+    fn = SCHEDULES[schedule]
+    pairs = sampling_time_pairs(num_timesteps)
+    if max_steps is not None:
+        pairs = pairs[:max_steps]
+    for i, (tt, tn) in enumerate(pairs):
+        t = tt.expand(b).clone()
+        t_next = tn.expand(b).clone()
+        pred = denoise(img, fn(t))
+        img, _ = ddpm_step(img, pred, t, t_next, noise_fn(("step", stage, i), shape), schedule,
+                           dynamic_thresholding, percentile)
+        if trace is not None:
+            trace.append(img.clone())
+    return (img.clamp(-1.0, 1.0) + 1) * 0.5
+
+
+def imagen_sample(
+    unets: Sequence[tuple],           # [(state_dict, ctor_kwargs), ...] — kwargs already carry lowres_cond etc.
+    image_sizes: Sequence[int],
+    text_embeds: Tensor,
+    *,
+    timesteps=1000,
+    cond_scale=1.0,
+    noise_schedules="cosine",
+    lowres_noise_schedule: str = "linear",
+    lowres_sample_noise_level: float = 0.2,
+    dynamic_thresholding: bool = True,
+    percentile: float = 0.95,
+    channels: int = 3,
+    text_masks: Optional[Tensor] = None,
+    noise_fn: Optional[Callable] = None,
+    max_steps: Optional[int] = None,
+    return_all: bool = False,
+):
+    """ip.py:2291-2498 for text_embeds-conditioned image sampling (no inpainting/init images/video)."""
+    n = len(unets)
+    timesteps = timesteps if isinstance(timesteps, (list, tuple)) else (timesteps,) * n
+    cond_scale = cond_scale if isinstance(cond_scale, (list, tuple)) else (cond_scale,) * n
+    schedules = default_noise_schedules(n, noise_schedules)
+    if noise_fn is None:
+        noise_fn = lambda tag, shape: torch.randn(shape)
+    if text_masks is None:
+        text_masks = torch.any(text_embeds != 0.0, dim=-1)  # ip.py:2337
+    b = text_embeds.shape[0]
+    outputs, img = [], None
+    for stage, ((sd, kw), size, T, cs, sched) in enumerate(zip(unets, image_sizes, timesteps, cond_scale, schedules)):
+        lowres_img = lowres_times = None
+        if kw.get("lowres_cond", False):
+            lowres_times = torch.full((b,), lowres_sample_noise_level, dtype=torch.float32)
+            up = img if img.shape[-1] == size else F.interpolate(img, size, mode="nearest")  # ip.py:152-168
+            up = up * 2 - 1
+            a, s = alpha_sigma(SCHEDULES[lowres_noise_schedule](lowres_times).reshape(-1, 1, 1, 1))
+            lowres_img = a * up + s * noise_fn(("lowres", stage), up.shape)       # ip.py:272-284, 2449
+            lowres_logsnr = SCHEDULES[lowres_noise_schedule](lowres_times)       # ip.py:2081
+
+        def denoise(x, log_snr, _sd=sd, _kw=kw, _cs=cs, _li=lowres_img, _lt=(lowres_logsnr if lowres_img is not None else None)):
+            return unet_forward_with_cond_scale(_sd, _kw, x, log_snr, cond_scale=_cs, text_embeds=text_embeds,
+                                                text_mask=text_masks, lowres_cond_img=_li, lowres_noise_times=_lt)
+
+        img = p_sample_loop(denoise, (b, channels, size, size), schedule=sched, num_timesteps=T, noise_fn=noise_fn,
+                            stage=stage, dynamic_thresholding=dynamic_thresholding, percentile=percentile,
+                            max_steps=max_steps)
+        outputs.append(img)
+    return outputs if return_all else outputs[-1]
