@@ -1,0 +1,156 @@
+// attention.hip — flash-style cosine-similarity attention for the Imagen denoiser on CDNA4 MFMA.
+// Replaces the materialised (b, h, n, n+39) fp32 similarity + softmax + AV of ip.py:559-590 (self attention,
+// ONE k/v head shared by all 8 query heads), ip.py:812-833 (cross attention, per-head k/v, 39|41 keys) and
+// PerceiverAttention ip.py:424-444.
+//
+// Inputs are prepared by QNORM / KV_PREP: q rows already l2-normalised * q_scale * 8 * log2(e) (so softmax
+// is exp2 of the raw dot product), k rows l2-normalised * k_scale, V stored transposed (V^T[d][key]) and both
+// K / V^T zero-padded to a multiple of 32 keys.  For the shared-k/v self attention the host passes
+// heads = 1 and rows = n*8: the (token, head) pairs are just 8n query rows over one key set.
+//
+// Workgroup = 4 wave64 = 128 query rows of one (batch, head); wave = 32 query rows.  Per 32-key tile:
+//   S^T[key][q]  = mfma_32x32x16(A = K tile rows (LDS, ds_read_b128), B = Q (registers))      4 MFMA
+//   online softmax in registers: lane = query column, 16 keys per lane + 1 cross-half shuffle
+//   O^T[d][q]   += mfma_32x32x16(A = V^T rows (LDS, 2x ds_read_b64), B = P (registers, fp16))  4 MFMA
+// The key order of the PV contraction is chosen to match the S^T accumulator layout, so P never moves
+// between lanes.  K / V^T tiles are register-prefetched one tile ahead and double-buffered in LDS.
+#include "common.h"
+
+namespace {
+
+constexpr int KT = 32;        // keys per tile
+constexpr int KSTR = 144;     // LDS bytes per K row   (128 + 16: conflict-free ds_read_b128)
+constexpr int VSTR = 72;      // LDS bytes per V^T row (64 + 8: conflict-free ds_read_b64)
+constexpr int KBYTES = KT * KSTR;
+constexpr int VBYTES = 64 * VSTR;
+
+__global__ __launch_bounds__(256) void attention_kernel(const ImagenAttentionParams p) {
+  __shared__ __attribute__((aligned(16))) char smem[2 * (KBYTES + VBYTES)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int row = blockIdx.x * 128 + wave * 32 + l31;
+  const int row_c = row < p.rows ? row : p.rows - 1;
+
+  const f16* q = reinterpret_cast<const f16*>(p.q) + (size_t)b * p.q_bs + (size_t)hd * p.q_hs + (size_t)row_c * p.q_rs;
+  f16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const f16x8*>(q + 16 * s + 8 * half);
+
+  const f16* kg = reinterpret_cast<const f16*>(p.k) + (size_t)b * p.k_bs + (size_t)hd * p.k_hs;
+  const f16* vg = reinterpret_cast<const f16*>(p.vt) + (size_t)b * p.vt_bs + (size_t)hd * p.vt_hs;
+  // staging roles: K tile 32 keys x 8 groups of 8 dims; V^T tile 64 dims x 4 groups of 8 keys
+  const int sk_key = tid >> 3, sk_dg = tid & 7;
+  const int sv_d = tid >> 2, sv_kg = tid & 3;
+
+  uint4 k_stage, v_stage;
+  auto tile_load = [&](int kt0) {
+    k_stage = *reinterpret_cast<const uint4*>(kg + (size_t)(kt0 + sk_key) * p.k_rs + sk_dg * 8);
+    v_stage = *reinterpret_cast<const uint4*>(vg + (size_t)sv_d * p.vt_ds + kt0 + sv_kg * 8);
+  };
+  auto tile_store = [&](char* buf) {
+    *reinterpret_cast<uint4*>(buf + sk_key * KSTR + sk_dg * 16) = k_stage;
+    uint2* vd = reinterpret_cast<uint2*>(buf + KBYTES + sv_d * VSTR + sv_kg * 16);
+    vd[0] = make_uint2(v_stage.x, v_stage.y);
+    vd[1] = make_uint2(v_stage.z, v_stage.w);
+  };
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
+  float m_run = -1.0e30f, l_run = 0.f;
+
+  const int ntiles = (p.J + KT - 1) / KT;
+  tile_load(0);
+  tile_store(smem);
+  __syncthreads();
+  int cur = 0;
+  for (int t = 0; t < ntiles; ++t) {
+    const bool more = t + 1 < ntiles;
+    if (more) tile_load((t + 1) * KT);
+    const char* kb = smem + cur * (KBYTES + VBYTES);
+    const char* vb = kb + KBYTES;
+
+    // ---- S^T = K . Q^T
+    f32x16 sacc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const f16x8 kf = *reinterpret_cast<const f16x8*>(kb + l31 * KSTR + (16 * s + 8 * half) * 2);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc, 0, 0, 0);
+    }
+    // ---- mask the ragged last tile, online softmax (lane = query; this lane holds 16 of the tile's 32 keys)
+    const int kbase = t * KT + 4 * half;
+    float mx = -1.0e30f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = kbase + (r & 3) + 8 * (r >> 2);
+      if (key >= p.J) sacc[r] = -1.0e30f;
+      mx = fmaxf(mx, sacc[r]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    const float m_new = fmaxf(m_run, mx);
+    const float alpha = exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+    f16x8 pf[2];
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const float e = exp2f(sacc[r] - m_new);
+      psum += e;
+      pf[r >> 3][r & 7] = (f16)e;
+    }
+    l_run = l_run * alpha + psum;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+
+    // ---- O^T += V^T . P^T   (k-step s covers the keys of accumulator registers 8s..8s+7)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) {
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const char* vrow = vb + (32 * db + l31) * VSTR + (16 * s + 4 * half) * 2;
+        const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
+        const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16);
+        uint4 packed = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        const f16x8 vf = *reinterpret_cast<const f16x8*>(&packed);
+        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], oacc[db], 0, 0, 0);
+      }
+    }
+
+    if (more) tile_store(smem + (cur ^ 1) * (KBYTES + VBYTES));
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  if (row < p.rows) {
+    f16* o = reinterpret_cast<f16*>(p.o) + (size_t)b * p.o_bs + (size_t)hd * p.o_hs + (size_t)row * p.o_rs;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        f16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (f16)(oacc[db][4 * qd + e] * inv);
+        *reinterpret_cast<f16x4*>(o + 32 * db + 8 * qd + 4 * half) = v;
+      }
+  }
+}
+
+}  // namespace
+
+int launch_attention(const ImagenAttentionParams* p, hipStream_t s) {
+  IMAGEN_CHECK(p->rows > 0 && p->J > 0 && p->B > 0 && p->heads > 0, "attention: empty problem");
+  IMAGEN_CHECK(p->q_rs % 8 == 0 && p->k_rs % 8 == 0 && p->vt_ds % 8 == 0 && p->o_rs % 4 == 0,
+               "attention: strides must keep 16B alignment");
+  dim3 grid((p->rows + 127) / 128, p->heads, p->B);
+  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, s, *p);
+  return imagen_hip_status("attention");
+}

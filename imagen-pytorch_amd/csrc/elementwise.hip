@@ -1,0 +1,458 @@
+// elementwise.hip — the HBM-bound glue of the Imagen denoiser (statistics, gates, residuals, token
+// assembly, embeddings).  All kernels move 16 B per lane (8 fp16) with consecutive lanes on consecutive
+// addresses; reductions over a row use a power-of-two sub-group of the wave64 and __shfl_xor.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ int lanes_per_row(int groups) {  // smallest power of two >= groups, capped at 64
+  int l = 1;
+  while (l < groups && l < 64) l <<= 1;
+  return l;
+}
+
+__device__ __forceinline__ float group_sum(float v, int lpr) {
+  for (int off = lpr >> 1; off > 0; off >>= 1) v += __shfl_xor(v, off);
+  return v;
+}
+
+// ------------------------------------------------------------------------------------------------ rowstat
+__global__ __launch_bounds__(256) void rowstat_kernel(const ImagenRowstatParams p, int lpr) {
+  const int rows_per_block = 256 / lpr;
+  const int sub = threadIdx.x / lpr, li = threadIdx.x % lpr;
+  const int r = blockIdx.x * rows_per_block + sub;
+  if (r >= p.rows) return;  // whole sub-group exits together
+  const int b = r / p.rows_per_batch, rr = r - b * p.rows_per_batch;
+  const f16* x1 = reinterpret_cast<const f16*>(p.x1) + (size_t)b * p.bs1 + (size_t)rr * p.ld1;
+  const f16* x2 = p.x2 ? reinterpret_cast<const f16*>(p.x2) + (size_t)b * p.bs2 + (size_t)rr * p.ld2 : nullptr;
+  const int g1 = p.C1 >> 3, g2 = p.x2 ? (p.C2 >> 3) : 0;
+  if (p.mode == 0) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int g = li; g < g1; g += lpr) {
+      const f16x8 v = *reinterpret_cast<const f16x8*>(x1 + g * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s1 += (float)v[j] * (float)v[j];
+    }
+    for (int g = li; g < g2; g += lpr) {
+      const f16x8 v = *reinterpret_cast<const f16x8*>(x2 + g * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s2 += (float)v[j] * (float)v[j];
+    }
+    const float tot = group_sum(s1 + p.w2 * s2, lpr);
+    if (li == 0) p.rs[r] = 1.0f / fmaxf(sqrtf(tot), 1e-12f);
+  } else {
+    const int C = p.C1 + (p.x2 ? p.C2 : 0);
+    float s = 0.f;
+    for (int g = li; g < g1; g += lpr) {
+      const f16x8 v = *reinterpret_cast<const f16x8*>(x1 + g * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (float)v[j];
+    }
+    for (int g = li; g < g2; g += lpr) {
+      const f16x8 v = *reinterpret_cast<const f16x8*>(x2 + g * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += (float)v[j];
+    }
+    const float mean = group_sum(s, lpr) / (float)C;
+    float q = 0.f;
+    for (int g = li; g < g1; g += lpr) {
+      const f16x8 v = *reinterpret_cast<const f16x8*>(x1 + g * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = (float)v[j] - mean; q += d * d; }
+    }
+    for (int g = li; g < g2; g += lpr) {
+      const f16x8 v = *reinterpret_cast<const f16x8*>(x2 + g * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = (float)v[j] - mean; q += d * d; }
+    }
+    const float var = group_sum(q, lpr) / (float)C;
+    if (li == 0) {
+      p.mu[r] = mean;
+      p.rs[r] = rsqrtf(var + p.eps);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ gate_residual
+__global__ __launch_bounds__(256) void gate_residual_kernel(const ImagenGateResidualParams p, int lpr) {
+  const int rows_per_block = 256 / lpr;
+  const int sub = threadIdx.x / lpr, li = threadIdx.x % lpr;
+  const int r = blockIdx.x * rows_per_block + sub;
+  if (r >= p.rows) return;
+  const int b = r / p.rows_per_batch;
+  const f16* h = reinterpret_cast<const f16*>(p.h) + (size_t)r * p.ld_h;
+  const f16* res = reinterpret_cast<const f16*>(p.res) + (size_t)r * p.ld_res;
+  f16* out = reinterpret_cast<f16*>(p.out) + (size_t)r * p.ld_out;
+  const int groups = p.C >> 3;
+  float ssq = 0.f;
+  for (int g = li; g < groups; g += lpr) {
+    const f16x8 hv = *reinterpret_cast<const f16x8*>(h + g * 8);
+    const f16x8 rv = *reinterpret_cast<const f16x8*>(res + g * 8);
+    float gt[8];
+    if (p.gate) {
+      const float4* gp = reinterpret_cast<const float4*>(p.gate + (size_t)b * p.C + g * 8);
+      const float4 g0 = gp[0], g1 = gp[1];
+      gt[0] = g0.x; gt[1] = g0.y; gt[2] = g0.z; gt[3] = g0.w; gt[4] = g1.x; gt[5] = g1.y; gt[6] = g1.z; gt[7] = g1.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) gt[j] = 1.0f;
+    }
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const float v = (float)hv[j] * gt[j] + (float)rv[j];
+      o[j] = (f16)v;
+      const float vr = (float)o[j];  // statistics of the value the consumer will actually read
+      ssq += vr * vr;
+    }
+    *reinterpret_cast<f16x8*>(out + g * 8) = o;
+  }
+  if (p.rs_out) {
+    const float tot = group_sum(ssq, lpr);
+    if (li == 0) p.rs_out[r] = 1.0f / fmaxf(sqrtf(tot), 1e-12f);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ ln_residual
+__global__ __launch_bounds__(256) void ln_residual_kernel(const ImagenLnResidualParams p, int lpr) {
+  const int rows_per_block = 256 / lpr;
+  const int sub = threadIdx.x / lpr, li = threadIdx.x % lpr;
+  const int r = blockIdx.x * rows_per_block + sub;
+  if (r >= p.rows) return;
+  const f16* y = reinterpret_cast<const f16*>(p.y) + (size_t)r * p.ld_y;
+  const f16* res = p.res ? reinterpret_cast<const f16*>(p.res) + (size_t)r * p.ld_res : nullptr;
+  f16* out = reinterpret_cast<f16*>(p.out) + (size_t)r * p.ld_out;
+  const int groups = p.C >> 3;
+  float s = 0.f;
+  for (int g = li; g < groups; g += lpr) {
+    const f16x8 v = *reinterpret_cast<const f16x8*>(y + g * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s += (float)v[j];
+  }
+  const float mean = group_sum(s, lpr) / (float)p.C;
+  float q = 0.f;
+  for (int g = li; g < groups; g += lpr) {
+    const f16x8 v = *reinterpret_cast<const f16x8*>(y + g * 8);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { const float d = (float)v[j] - mean; q += d * d; }
+  }
+  const float rstd = rsqrtf(group_sum(q, lpr) / (float)p.C + p.eps);
+  for (int g = li; g < groups; g += lpr) {
+    const f16x8 v = *reinterpret_cast<const f16x8*>(y + g * 8);
+    f16x8 rv;
+    if (res) rv = *reinterpret_cast<const f16x8*>(res + g * 8);
+    f16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      float t = ((float)v[j] - mean) * rstd * p.g[g * 8 + j];
+      if (p.beta) t += p.beta[g * 8 + j];
+      if (res) t += (float)rv[j];
+      o[j] = (f16)t;
+    }
+    *reinterpret_cast<f16x8*>(out + g * 8) = o;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ q / kv preparation
+// 8 lanes per 64-wide head row; each lane owns 8 consecutive dims.
+__global__ __launch_bounds__(256) void qnorm_kernel(const ImagenQnormParams p) {
+  const int item = blockIdx.x * 32 + (threadIdx.x >> 3);  // (row, head)
+  const int dg = threadIdx.x & 7;
+  if (item >= p.rows * p.heads) return;
+  const int row = item / p.heads, hd = item - row * p.heads;
+  f16* q = reinterpret_cast<f16*>(p.q) + (size_t)row * p.ld + hd * 64 + dg * 8;
+  const f16x8 v = *reinterpret_cast<const f16x8*>(q);
+  float ssq = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ssq += (float)v[j] * (float)v[j];
+  ssq = group_sum(ssq, 8);
+  const float inv = p.mult / fmaxf(sqrtf(ssq), 1e-12f);
+  f16x8 o;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (f16)((float)v[j] * inv * p.q_scale[dg * 8 + j]);
+  *reinterpret_cast<f16x8*>(q) = o;
+}
+
+__global__ __launch_bounds__(256) void kv_prep_kernel(const ImagenKvPrepParams p) {
+  const int bh = blockIdx.y;
+  const int b = bh / p.heads, hd = bh - b * p.heads;
+  const int row = blockIdx.x * 32 + (threadIdx.x >> 3);
+  const int dg = threadIdx.x & 7;
+  if (row >= p.rows) return;
+  const size_t soff = (size_t)b * p.src_bs + (size_t)row * p.src_rs + (size_t)hd * p.src_hs + dg * 8;
+  float kv[8], vv[8];
+  if (p.src_is_f32) {
+    const float* ks = reinterpret_cast<const float*>(p.k_src) + soff;
+    const float* vs = reinterpret_cast<const float*>(p.v_src) + soff;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { kv[j] = ks[j]; vv[j] = vs[j]; }
+  } else {
+    const f16x8 k8 = *reinterpret_cast<const f16x8*>(reinterpret_cast<const f16*>(p.k_src) + soff);
+    const f16x8 v8 = *reinterpret_cast<const f16x8*>(reinterpret_cast<const f16*>(p.v_src) + soff);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { kv[j] = (float)k8[j]; vv[j] = (float)v8[j]; }
+  }
+  float ssq = 0.f;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ssq += kv[j] * kv[j];
+  ssq = group_sum(ssq, 8);
+  const float inv = 1.0f / fmaxf(sqrtf(ssq), 1e-12f);
+  f16x8 ko;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ko[j] = (f16)(kv[j] * inv * p.k_scale[dg * 8 + j]);
+  f16* kh = reinterpret_cast<f16*>(p.khat) + (size_t)b * p.k_bs + (size_t)hd * p.k_hs + (size_t)(p.r0 + row) * p.k_rs + dg * 8;
+  *reinterpret_cast<f16x8*>(kh) = ko;
+  f16* vt = reinterpret_cast<f16*>(p.vt) + (size_t)b * p.vt_bs + (size_t)hd * p.vt_hs + (p.r0 + row);
+#pragma unroll
+  for (int j = 0; j < 8; ++j) vt[(size_t)(dg * 8 + j) * p.vt_ds] = (f16)vv[j];
+}
+
+// ------------------------------------------------------------------------------------------------ global context
+// Block = one chunk of pixels of one image.  Phase 1: logits -> LDS, block max.  Phase 2: thread (pixel-lane,
+// 8-channel group) accumulates exp(logit - max) * h over its pixels; cross-lane reduction through LDS.
+constexpr int kGcaMaxChunk = 1024;
+
+__global__ __launch_bounds__(256) void gca_partial_kernel(const ImagenGcaPartialParams p, int chunk_px) {
+  __shared__ float s_logit[kGcaMaxChunk];
+  __shared__ float s_red[256];
+  __shared__ float s_acc[256 * 8];
+  const int b = blockIdx.y, ch = blockIdx.x;
+  const int p0 = ch * chunk_px;
+  const int npx = min(chunk_px, p.HW - p0);
+  const f16* h = reinterpret_cast<const f16*>(p.h) + ((size_t)b * p.HW + p0) * p.ld;
+  const int groups = p.C >> 3;
+  const int lpr = lanes_per_row(groups);
+  const int ppb = 256 / lpr;
+  const int sub = threadIdx.x / lpr, li = threadIdx.x % lpr;
+  // phase 1
+  float lmax = -3.0e38f;
+  for (int px = sub; px < npx; px += ppb) {
+    float d = 0.f;
+    for (int g = li; g < groups; g += lpr) {
+      const f16x8 v = *reinterpret_cast<const f16x8*>(h + (size_t)px * p.ld + g * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) d += (float)v[j] * p.wk[g * 8 + j];
+    }
+    d = group_sum(d, lpr) + p.bk;
+    if (li == 0) s_logit[px] = d;
+    lmax = fmaxf(lmax, d);
+  }
+  s_red[threadIdx.x] = lmax;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) s_red[threadIdx.x] = fmaxf(s_red[threadIdx.x], s_red[threadIdx.x + off]);
+    __syncthreads();
+  }
+  const float m = s_red[0];
+  __syncthreads();
+  // phase 2: thread -> (pixel lane pl, channel group cg)
+  const int npl = 256 / groups;  // pixel lanes (threads beyond npl*groups idle)
+  const int pl = threadIdx.x / groups, cg = threadIdx.x - pl * groups;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  float se = 0.f;
+  if (pl < npl) {
+    for (int px = pl; px < npx; px += npl) {
+      const float e = __expf(s_logit[px] - m);
+      const f16x8 v = *reinterpret_cast<const f16x8*>(h + (size_t)px * p.ld + cg * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += e * (float)v[j];
+      if (cg == 0) se += e;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s_acc[threadIdx.x * 8 + j] = acc[j];
+  s_red[threadIdx.x] = se;
+  __syncthreads();
+  float* out = p.part + ((size_t)b * p.chunks + ch) * (p.C + 2);
+  if (threadIdx.x < groups) {  // reduce over pixel lanes for channel group threadIdx.x
+    float tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    for (int q = 0; q < npl; ++q) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) tot[j] += s_acc[(q * groups + threadIdx.x) * 8 + j];
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[2 + threadIdx.x * 8 + j] = tot[j];
+  }
+  if (threadIdx.x == 0) {
+    float tot = 0.f;
+    for (int q = 0; q < npl; ++q) tot += s_red[q * groups];
+    out[0] = m;
+    out[1] = tot;
+  }
+}
+
+__global__ __launch_bounds__(256) void gca_final_kernel(const ImagenGcaFinalParams p) {
+  extern __shared__ float sm[];  // ctx[C] | hid[hidden]
+  float* ctx = sm;
+  float* hid = sm + p.C;
+  const int b = blockIdx.x;
+  const float* part = p.part + (size_t)b * p.chunks * (p.C + 2);
+  float M = -3.0e38f;
+  for (int i = 0; i < p.chunks; ++i) M = fmaxf(M, part[(size_t)i * (p.C + 2)]);
+  float S = 0.f;
+  for (int i = 0; i < p.chunks; ++i) S += part[(size_t)i * (p.C + 2) + 1] * __expf(part[(size_t)i * (p.C + 2)] - M);
+  for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+    float a = 0.f;
+    for (int i = 0; i < p.chunks; ++i) a += part[(size_t)i * (p.C + 2) + 2 + c] * __expf(part[(size_t)i * (p.C + 2)] - M);
+    ctx[c] = a / S;
+  }
+  __syncthreads();
+  for (int j = threadIdx.x; j < p.hidden; j += blockDim.x) {
+    float a = p.b1[j];
+    for (int c = 0; c < p.C; ++c) a += p.w1[(size_t)j * p.C + c] * ctx[c];
+    hid[j] = silu_f(a);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+    float a = p.b2[c];
+    for (int j = 0; j < p.hidden; ++j) a += p.w2[(size_t)c * p.hidden + j] * hid[j];
+    p.gate[(size_t)b * p.C + c] = sigmoid_f(a);
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ embeddings / affine
+__global__ __launch_bounds__(256) void time_embed_kernel(const ImagenTimeEmbedParams p) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.B * p.out_dim) return;
+  const int b = i / p.out_dim, o = i - b * p.out_dim;
+  const float x = p.step_ptr ? p.coef[(size_t)(*p.step_ptr) * 8 + 6] : p.times[b];
+  const int nf = 2 * p.half_dim + 1;
+  const float* w = p.w + (size_t)o * nf;
+  float a = p.bias[o] + w[0] * x;
+  for (int k = 0; k < p.half_dim; ++k) {
+    const float f = x * p.freqs[k] * 6.283185307179586f;
+    a += w[1 + k] * sinf(f) + w[1 + p.half_dim + k] * cosf(f);
+  }
+  reinterpret_cast<f16*>(p.hid)[(size_t)b * p.ld_hid + o] = (f16)silu_f(a);
+}
+
+__global__ __launch_bounds__(256) void scale_shift_kernel(const ImagenScaleShiftParams p) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.B * p.total_c) return;
+  const int b = i / p.total_c, c = i - b * p.total_c;
+  const f16* ss = reinterpret_cast<const f16*>(p.ss) + (size_t)b * p.ld_ss;
+  p.pa[i] = p.gamma_s[c] * ((float)ss[p.idx_scale[c]] + 1.0f);
+  p.ps[i] = (float)ss[p.idx_shift[c]];
+}
+
+__global__ __launch_bounds__(256) void pack_image_kernel(const ImagenPackImageParams p) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  const int HW = p.H * p.W;
+  if (i >= p.B * p.Brep * HW) return;
+  const int bo = i / HW, px = i - bo * HW;
+  const int bs = bo % p.B;
+  f16* out = reinterpret_cast<f16*>(p.out) + (size_t)i * p.Cpad;
+  for (int c = 0; c < p.Cpad; ++c) {
+    float v = 0.f;
+    if (c < p.Ca) v = p.a[((size_t)bs * p.Ca + c) * HW + px];
+    else if (c - p.Ca < p.Cb) v = p.b[((size_t)bs * p.Cb + (c - p.Ca)) * HW + px];
+    out[c] = (f16)v;
+  }
+}
+
+__global__ __launch_bounds__(256) void rows_copy_kernel(const ImagenRowsCopyParams p) {
+  const int groups = p.C >> 3;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.B * p.rows * groups) return;
+  const int g = i % groups;
+  const int r = (i / groups) % p.rows;
+  const int b = i / (groups * p.rows);
+  const f16* s = reinterpret_cast<const f16*>(p.src) + (size_t)b * p.src_bs + (size_t)r * p.src_rs + g * 8;
+  f16* d = reinterpret_cast<f16*>(p.dst) + (size_t)b * p.dst_bs + (size_t)r * p.dst_rs + g * 8;
+  *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(s);
+}
+
+__global__ __launch_bounds__(256) void memset32_kernel(uint32_t* dst, uint32_t value, int count) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i < count) dst[i] = value;
+}
+
+int host_lpr(int groups) {
+  int l = 1;
+  while (l < groups && l < 64) l <<= 1;
+  return l;
+}
+
+}  // namespace
+
+int launch_rowstat(const ImagenRowstatParams* p, hipStream_t s) {
+  IMAGEN_CHECK(p->C1 % 8 == 0 && p->C2 % 8 == 0 && p->ld1 % 8 == 0, "rowstat: channels/stride must be multiples of 8");
+  IMAGEN_CHECK(p->rows > 0 && p->rows_per_batch > 0, "rowstat: empty");
+  const int lpr = host_lpr((p->C1 + (p->x2 ? p->C2 : 0)) / 8);
+  const int rpb = 256 / lpr;
+  hipLaunchKernelGGL(rowstat_kernel, dim3((p->rows + rpb - 1) / rpb), dim3(256), 0, s, *p, lpr);
+  return imagen_hip_status("rowstat");
+}
+
+int launch_gate_residual(const ImagenGateResidualParams* p, hipStream_t s) {
+  IMAGEN_CHECK(p->C % 8 == 0, "gate_residual: C %% 8");
+  const int lpr = host_lpr(p->C / 8);
+  const int rpb = 256 / lpr;
+  hipLaunchKernelGGL(gate_residual_kernel, dim3((p->rows + rpb - 1) / rpb), dim3(256), 0, s, *p, lpr);
+  return imagen_hip_status("gate_residual");
+}
+
+int launch_ln_residual(const ImagenLnResidualParams* p, hipStream_t s) {
+  IMAGEN_CHECK(p->C % 8 == 0, "ln_residual: C %% 8");
+  const int lpr = host_lpr(p->C / 8);
+  const int rpb = 256 / lpr;
+  hipLaunchKernelGGL(ln_residual_kernel, dim3((p->rows + rpb - 1) / rpb), dim3(256), 0, s, *p, lpr);
+  return imagen_hip_status("ln_residual");
+}
+
+int launch_qnorm(const ImagenQnormParams* p, hipStream_t s) {
+  const int items = p->rows * p->heads;
+  hipLaunchKernelGGL(qnorm_kernel, dim3((items + 31) / 32), dim3(256), 0, s, *p);
+  return imagen_hip_status("qnorm");
+}
+
+int launch_kv_prep(const ImagenKvPrepParams* p, hipStream_t s) {
+  IMAGEN_CHECK(p->rows > 0, "kv_prep: empty");
+  hipLaunchKernelGGL(kv_prep_kernel, dim3((p->rows + 31) / 32, p->B * p->heads), dim3(256), 0, s, *p);
+  return imagen_hip_status("kv_prep");
+}
+
+int launch_gca_partial(const ImagenGcaPartialParams* p, hipStream_t s) {
+  IMAGEN_CHECK(p->C % 8 == 0 && p->C / 8 <= 256, "gca: unsupported C %d", p->C);
+  const int chunk_px = (p->HW + p->chunks - 1) / p->chunks;
+  IMAGEN_CHECK(chunk_px <= kGcaMaxChunk, "gca: chunk of %d pixels too large", chunk_px);
+  hipLaunchKernelGGL(gca_partial_kernel, dim3(p->chunks, p->B), dim3(256), 0, s, *p, chunk_px);
+  return imagen_hip_status("gca_partial");
+}
+
+int launch_gca_final(const ImagenGcaFinalParams* p, hipStream_t s) {
+  const size_t sm = (size_t)(p->C + p->hidden) * sizeof(float);
+  hipLaunchKernelGGL(gca_final_kernel, dim3(p->B), dim3(256), sm, s, *p);
+  return imagen_hip_status("gca_final");
+}
+
+int launch_time_embed(const ImagenTimeEmbedParams* p, hipStream_t s) {
+  const int n = p->B * p->out_dim;
+  hipLaunchKernelGGL(time_embed_kernel, dim3((n + 255) / 256), dim3(256), 0, s, *p);
+  return imagen_hip_status("time_embed");
+}
+
+int launch_scale_shift(const ImagenScaleShiftParams* p, hipStream_t s) {
+  const int n = p->B * p->total_c;
+  hipLaunchKernelGGL(scale_shift_kernel, dim3((n + 255) / 256), dim3(256), 0, s, *p);
+  return imagen_hip_status("scale_shift");
+}
+
+int launch_pack_image(const ImagenPackImageParams* p, hipStream_t s) {
+  const int n = p->B * p->Brep * p->H * p->W;
+  hipLaunchKernelGGL(pack_image_kernel, dim3((n + 255) / 256), dim3(256), 0, s, *p);
+  return imagen_hip_status("pack_image");
+}
+
+int launch_rows_copy(const ImagenRowsCopyParams* p, hipStream_t s) {
+  IMAGEN_CHECK(p->C % 8 == 0, "rows_copy: C %% 8");
+  const int n = p->B * p->rows * (p->C / 8);
+  hipLaunchKernelGGL(rows_copy_kernel, dim3((n + 255) / 256), dim3(256), 0, s, *p);
+  return imagen_hip_status("rows_copy");
+}
+
+int launch_memset32(const ImagenMemset32Params* p, hipStream_t s) {
+  hipLaunchKernelGGL(memset32_kernel, dim3((p->count + 255) / 256), dim3(256), 0, s, reinterpret_cast<uint32_t*>(p->dst), p->value,
+                     p->count);
+  return imagen_hip_status("memset32");
+}

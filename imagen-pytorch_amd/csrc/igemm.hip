@@ -1,0 +1,404 @@
+// igemm.hip — implicit-GEMM convolution / linear layer on CDNA4 MFMA (v_mfma_f32_32x32x16_f16) with the
+// Imagen block prologue (ChanRMSNorm / LayerNorm statistics + per-(batch,channel) affine + SiLU) fused into
+// the activation staging and bias / activation / gate*addend / residual / pixel-shuffle fused into the
+// epilogue.  Replaces the ATen sequences cited at ImagenIgemmParams in include/imagen_hip.h.
+//
+// Data flow per workgroup (256 threads = 4 wave64, one output tile of TP pixels x BN output channels):
+//   HBM (NHWC fp16) --16B/lane loads--> VGPR --prologue in fp32--> LDS halo tile [pixels][8*G ch], padded rows
+//   LDS --ds_read_b128 per (tap, 8-channel group)--> MFMA B operand (pixels are the N/lane dimension)
+//   packed weights (L2-resident, fragment order) --16B/lane loads--> MFMA A operand (output channels = rows)
+//   accumulators D[cout][pixel]: lane = pixel, 4 consecutive couts per register quad -> 8B NHWC stores.
+// The k dimension runs over channel chunks of 8*G channels; inside a chunk over (tap, 8-channel group) pairs;
+// two consecutive groups (lane>>5 selects) feed one K=16 MFMA.  Staging of chunk c+1 (global loads issued
+// before, LDS writes after the MFMAs of chunk c) overlaps the matrix work of chunk c.
+#include "common.h"
+
+namespace {
+
+struct TileCfg { int MI, NI, WM, WN, G; };
+constexpr int kMaxItems = 6;  // 16B staging items per thread per chunk
+
+constexpr TileCfg kCfgs[] = {
+    {2, 1, 4, 1, 4},  // 0: 256 px x  32 co, 32-ch chunks   (C_out = 32 layers, 256^2/128^2 levels)
+    {2, 2, 2, 2, 4},  // 1: 128 px x 128 co
+    {2, 2, 4, 1, 4},  // 2: 256 px x  64 co
+    {1, 2, 2, 2, 4},  // 3:  64 px x 128 co                (small feature maps, token GEMMs)
+    {1, 1, 4, 1, 4},  // 4: 128 px x  32 co
+    {2, 1, 4, 1, 1},  // 5: 256 px x  32 co,  8-ch chunks   (15x15 cross-embed conv, C_in = 3|6 padded to 8)
+    {1, 1, 2, 2, 4},  // 6:  64 px x  64 co
+    {1, 2, 2, 2, 1},  // 7:  64 px x 128 co,  8-ch chunks   (channel counts that are only multiples of 8)
+    {1, 1, 2, 2, 1},  // 8:  64 px x  64 co,  8-ch chunks
+    {1, 1, 4, 1, 1},  // 9: 128 px x  32 co,  8-ch chunks
+};
+constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
+template <int G> struct Geo {
+  static constexpr int KC = 8 * G;                          // channels per chunk
+  static constexpr int PS = (G == 1) ? 16 : (G * 16 + 16);  // LDS bytes per staged pixel (16B pad: conflict-free ds_read_b128)
+};
+
+template <int MI, int NI, int WM, int WN, int G>
+__global__ __launch_bounds__(256) void igemm_kernel(const ImagenIgemmParams p) {
+  static_assert(WM * WN == 4, "4 waves per workgroup");
+  constexpr int BN = 32 * NI * WN;
+  constexpr int KC = Geo<G>::KC;
+  constexpr int PS = Geo<G>::PS;
+  constexpr int LOG2G = (G == 1) ? 0 : (G == 2 ? 1 : 2);
+
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave / WN, wn = wave % WN;
+
+  // ---- which output tile
+  const int tilesX = (p.OW + p.TW - 1) / p.TW;
+  const int tilesY = (p.OH + p.TH - 1) / p.TH;
+  int t = blockIdx.x;
+  const int tile_x = t % tilesX;
+  t /= tilesX;
+  const int tile_y = t % tilesY;
+  const int b = t / tilesY;
+  const int oy0 = tile_y * p.TH, ox0 = tile_x * p.TW;
+  const int n0 = blockIdx.y * BN;
+
+  const int ITW = (p.TW - 1) * p.stride + p.KW;
+  const int ITH = (p.TH - 1) * p.stride + p.KH;
+  const int IT = ITH * ITW;
+  const int items = IT << LOG2G;
+  const float inv_itw = 1.0f / (float)ITW;
+  const int iy0 = oy0 * p.stride - p.pad, ix0 = ox0 * p.stride - p.pad;
+  const int buf_bytes = IT * PS;
+
+  const int ntap = p.KH * p.KW;
+  const int KG = ntap * G;            // 8-channel groups per chunk
+  const int KS = (KG + 1) >> 1;       // K=16 MFMA steps per chunk (odd KG: last half-step is zero weights)
+  const int NC = p.Cin_pad / KC;      // chunks
+
+  // ---- per-lane output pixel coordinates (lane = pixel in the MFMA N dimension)
+  int a_base[MI];
+  int opix_y[MI], opix_x[MI];
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int tp = (wm * MI + mi) * 32 + l31;
+    const int py = tp / p.TW, px = tp - py * p.TW;
+    opix_y[mi] = oy0 + py;
+    opix_x[mi] = ox0 + px;
+    a_base[mi] = ((py * p.stride) * ITW + px * p.stride) * PS;
+  }
+
+  // ---- weights: packed [chunk*KGP + kg][Cout_pad] x (8 halves); this lane's rows
+  const int KGP = KS * 2;
+  const f16x8* wbase = reinterpret_cast<const f16x8*>(p.w) + (size_t)half * p.Cout_pad + n0 + wn * (NI * 32) + l31;
+  const size_t wstep = (size_t)2 * p.Cout_pad;  // one K=16 step
+  (void)KGP;
+
+  f32x16 acc[NI][MI];
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.0f;
+
+  // ---- staging state
+  uint4 raw[kMaxItems];
+  float st_rs[kMaxItems], st_mu[kMaxItems];
+  unsigned inb_mask = 0;
+
+  const f16* x1 = reinterpret_cast<const f16*>(p.x1);
+  const f16* x2 = reinterpret_cast<const f16*>(p.x2);
+
+  auto stage_load = [&](int chunk) {
+    inb_mask = 0;
+#pragma unroll
+    for (int it = 0; it < kMaxItems; ++it) {
+      const int idx = tid + it * 256;
+      raw[it] = make_uint4(0, 0, 0, 0);
+      st_rs[it] = 1.0f;
+      st_mu[it] = 0.0f;
+      if (idx < items) {
+        const int pix = idx >> LOG2G, cg = idx & (G - 1);
+        const int iy = (int)(((float)pix + 0.5f) * inv_itw);
+        const int ix = pix - iy * ITW;
+        const int gy = iy0 + iy, gx = ix0 + ix;
+        const int c = chunk * KC + cg * 8;
+        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+          const int gp = gy * p.W + gx;
+          const f16* src = nullptr;
+          if (c < p.C1) src = x1 + (size_t)b * p.bs1 + (size_t)gp * p.ld1 + c;
+          else if (c - p.C1 < p.C2) src = x2 + (size_t)b * p.bs2 + (size_t)gp * p.ld2 + (c - p.C1);
+          if (src) {
+            raw[it] = *reinterpret_cast<const uint4*>(src);
+            inb_mask |= 1u << it;
+            const int sp = b * (p.H * p.W) + gp;
+            if (p.rs) st_rs[it] = p.rs[sp];
+            if (p.mu) st_mu[it] = p.mu[sp];
+          }
+        }
+      }
+    }
+  };
+
+  auto stage_write = [&](int chunk, char* buf) {
+#pragma unroll
+    for (int it = 0; it < kMaxItems; ++it) {
+      const int idx = tid + it * 256;
+      if (idx < items) {
+        const int pix = idx >> LOG2G, cg = idx & (G - 1);
+        f16x8 out;
+        if (inb_mask & (1u << it)) {
+          const f16x8 in = *reinterpret_cast<const f16x8*>(&raw[it]);
+          const int c = chunk * KC + cg * 8;
+          float a[8], s[8];
+          if (p.pa) {
+            const float4* q = reinterpret_cast<const float4*>(p.pa + (size_t)b * p.pstride + c);
+            const float4 q0 = q[0], q1 = q[1];
+            a[0] = q0.x; a[1] = q0.y; a[2] = q0.z; a[3] = q0.w; a[4] = q1.x; a[5] = q1.y; a[6] = q1.z; a[7] = q1.w;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) a[j] = 1.0f;
+          }
+          if (p.ps) {
+            const float4* q = reinterpret_cast<const float4*>(p.ps + (size_t)b * p.pstride + c);
+            const float4 q0 = q[0], q1 = q[1];
+            s[0] = q0.x; s[1] = q0.y; s[2] = q0.z; s[3] = q0.w; s[4] = q1.x; s[5] = q1.y; s[6] = q1.z; s[7] = q1.w;
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s[j] = 0.0f;
+          }
+          const float rs = st_rs[it], mu = st_mu[it];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            float v = ((float)in[j] - mu) * rs * a[j] + s[j];
+            if (p.act_in == IMAGEN_ACT_SILU) v = silu_f(v);
+            out[j] = (f16)v;
+          }
+        } else {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) out[j] = (f16)0.0f;
+        }
+        *reinterpret_cast<f16x8*>(buf + pix * PS + cg * 16) = out;
+      }
+    }
+  };
+
+  // ---- weight fragment pipeline (continuous over chunks)
+  f16x8 wcur[NI], wnxt[NI];
+  const f16x8* wptr = wbase;
+  const int total_steps = NC * KS;
+#pragma unroll
+  for (int ni = 0; ni < NI; ++ni) wcur[ni] = wptr[ni * 32];
+  int gstep = 0;
+
+  auto compute = [&](const char* buf) {
+    // (dy, dx, group) walk of this lane's 8-channel group: kg = 2*ks + half
+    int dy = 0, dx = 0, cgp = 0;  // G >= 2: uniform walk, group = 2*cgp + half
+    int tap_l = half;             // G == 1: per-lane tap walk (tap = 2*ks + half), kept as (ty_l, tx_l) incrementally
+    int ty_l = half / p.KW, tx_l = half - ty_l * p.KW;
+    for (int ks = 0; ks < KS; ++ks) {
+      // prefetch next step's weight fragments
+      ++gstep;
+      wptr += wstep;
+      if (gstep < total_steps) {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) wnxt[ni] = wptr[ni * 32];
+      }
+      int aoff;
+      if (G == 1) {
+        // padded half-step (tap_l == ntap): any valid address works, its weights are zero
+        aoff = tap_l < ntap ? (ty_l * ITW + tx_l) * PS : 0;
+        tap_l += 2;
+        tx_l += 2;
+        while (tx_l >= p.KW) { tx_l -= p.KW; ++ty_l; }
+      } else {
+        aoff = (dy * ITW + dx) * PS + (2 * cgp + half) * 16;
+        if (++cgp == G / 2) {
+          cgp = 0;
+          if (++dx == p.KW) { dx = 0; ++dy; }
+        }
+      }
+      f16x8 afrag[MI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) afrag[mi] = *reinterpret_cast<const f16x8*>(buf + a_base[mi] + aoff);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wcur[ni], afrag[mi], acc[ni][mi], 0, 0, 0);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wcur[ni] = wnxt[ni];
+    }
+  };
+
+  // ---- main loop over channel chunks (double-buffered LDS)
+  stage_load(0);
+  stage_write(0, smem);
+  __syncthreads();
+  int cur = 0;
+  for (int chunk = 0; chunk < NC; ++chunk) {
+    const bool more = chunk + 1 < NC;
+    if (more) stage_load(chunk + 1);
+    compute(smem + cur * buf_bytes);
+    if (more) stage_write(chunk + 1, smem + (cur ^ 1) * buf_bytes);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  // ---- epilogue: lane = pixel; register quad q holds couts 8q + 4*half + {0..3} of each 32-cout fragment
+  const f16* addend = reinterpret_cast<const f16*>(p.addend);
+  const f16* res = reinterpret_cast<const f16*>(p.res);
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int oy = opix_y[mi], ox = opix_x[mi];
+    if (oy >= p.OH || ox >= p.OW) continue;
+    const int op = oy * p.OW + ox;
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
+        if (co >= p.Cout) continue;
+        float v[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float x = acc[ni][mi][4 * q + e];
+          if (p.bias) x += p.bias[co + e];  // bias is padded to Cout_pad by the host
+          if (p.act_out == IMAGEN_ACT_SILU) x = silu_f(x);
+          else if (p.act_out == IMAGEN_ACT_GELU) x = gelu_f(x);
+          v[e] = x;
+        }
+        if (p.out_mode == IMAGEN_OUT_NCHW_F32) {
+          float* y = reinterpret_cast<float*>(p.y);
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (co + e < p.Cout) y[((size_t)b * p.Cout + co + e) * (p.OH * p.OW) + op] = v[e];
+          continue;
+        }
+        if (addend) {
+          const f16x4 ad = *reinterpret_cast<const f16x4*>(addend + (size_t)b * p.bs_add + (size_t)op * p.ld_add + co);
+          const float4 g = *reinterpret_cast<const float4*>(p.gate + (size_t)b * p.gate_stride + co);
+          v[0] += (float)ad[0] * g.x; v[1] += (float)ad[1] * g.y; v[2] += (float)ad[2] * g.z; v[3] += (float)ad[3] * g.w;
+        }
+        if (res) {
+          const f16x4 rr = *reinterpret_cast<const f16x4*>(res + (size_t)b * p.bs_res + (size_t)op * p.ld_res + co);
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+        }
+        f16x4 o;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o[e] = (f16)v[e];
+        f16* y = reinterpret_cast<f16*>(p.y);
+        if (p.out_mode == IMAGEN_OUT_PIXEL_SHUFFLE) {
+          // output channels are packed (s1, s2, c): cout = (2*s1 + s2) * Cq + c   (PixelShuffle(2), ip.py:616)
+          const int Cq = p.Cout >> 2;
+          const int sub = co / Cq, c = co - sub * Cq;
+          const int yy = 2 * oy + (sub >> 1), xx = 2 * ox + (sub & 1);
+          *reinterpret_cast<f16x4*>(y + (size_t)b * p.bsy + ((size_t)yy * (2 * p.OW) + xx) * p.ldy + c) = o;
+        } else {
+          *reinterpret_cast<f16x4*>(y + (size_t)b * p.bsy + (size_t)op * p.ldy + co) = o;
+        }
+      }
+    }
+  }
+}
+
+template <int MI, int NI, int WM, int WN, int G>
+int launch_cfg(const ImagenIgemmParams& p, hipStream_t s) {
+  constexpr int TP = 32 * MI * WM, BN = 32 * NI * WN;
+  const int ITW = (p.TW - 1) * p.stride + p.KW, ITH = (p.TH - 1) * p.stride + p.KH;
+  const int IT = ITH * ITW;
+  IMAGEN_CHECK(p.TH * p.TW == TP, "igemm: tile %dx%d does not match cfg %d (%d pixels)", p.TH, p.TW, p.cfg, TP);
+  IMAGEN_CHECK(IT * G <= kMaxItems * 256, "igemm: halo tile too large (%d px x %d groups)", IT, G);
+  IMAGEN_CHECK(p.Cout_pad % BN == 0, "igemm: Cout_pad %d not a multiple of %d", p.Cout_pad, BN);
+  IMAGEN_CHECK(p.Cin_pad % (8 * G) == 0, "igemm: Cin_pad %d not a multiple of %d", p.Cin_pad, 8 * G);
+  IMAGEN_CHECK(p.C1 % 8 == 0 && p.C2 % 8 == 0 && p.ld1 % 8 == 0 && (p.x2 == nullptr || p.ld2 % 8 == 0),
+               "igemm: channel counts / strides must be multiples of 8 (C1=%d C2=%d ld1=%d ld2=%d)", p.C1, p.C2, p.ld1, p.ld2);
+  IMAGEN_CHECK(p.out_mode == IMAGEN_OUT_NCHW_F32 || p.Cout % 4 == 0, "igemm: Cout %d must be a multiple of 4", p.Cout);
+  IMAGEN_CHECK(p.out_mode != IMAGEN_OUT_PIXEL_SHUFFLE || p.Cout % 16 == 0, "igemm: pixel-shuffle needs Cout %% 16 == 0");
+  const size_t lds = (size_t)2 * IT * Geo<G>::PS;
+  IMAGEN_CHECK(lds <= 160 * 1024, "igemm: LDS tile %zu bytes too large", lds);
+  auto kern = igemm_kernel<MI, NI, WM, WN, G>;
+  static bool attr_done = false;
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { imagen_set_error("igemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    attr_done = true;
+  }
+  const int tilesX = (p.OW + p.TW - 1) / p.TW, tilesY = (p.OH + p.TH - 1) / p.TH;
+  dim3 grid(p.B * tilesX * tilesY, (p.Cout + BN - 1) / BN);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+  return imagen_hip_status("igemm launch");
+}
+
+}  // namespace
+
+int launch_igemm(const ImagenIgemmParams* pp, hipStream_t s) {
+  const ImagenIgemmParams& p = *pp;
+  IMAGEN_CHECK(p.cfg >= 0 && p.cfg < kNumCfgs, "igemm: bad cfg %d", p.cfg);
+  IMAGEN_CHECK(p.x1 && p.w && p.y, "igemm: null x1/w/y");
+  IMAGEN_CHECK(!p.addend || p.gate, "igemm: addend requires gate");
+  switch (p.cfg) {
+    case 0: return launch_cfg<2, 1, 4, 1, 4>(p, s);
+    case 1: return launch_cfg<2, 2, 2, 2, 4>(p, s);
+    case 2: return launch_cfg<2, 2, 4, 1, 4>(p, s);
+    case 3: return launch_cfg<1, 2, 2, 2, 4>(p, s);
+    case 4: return launch_cfg<1, 1, 4, 1, 4>(p, s);
+    case 5: return launch_cfg<2, 1, 4, 1, 1>(p, s);
+    case 6: return launch_cfg<1, 1, 2, 2, 4>(p, s);
+    case 7: return launch_cfg<1, 2, 2, 2, 1>(p, s);
+    case 8: return launch_cfg<1, 1, 2, 2, 1>(p, s);
+    case 9: return launch_cfg<1, 1, 4, 1, 1>(p, s);
+  }
+  return -1;
+}
+
+extern "C" int imagen_igemm_num_configs(void) { return kNumCfgs; }
+
+extern "C" int imagen_igemm_config_info(int cfg, int* tile_pixels, int* tile_cout, int* kgroups) {
+  if (cfg < 0 || cfg >= kNumCfgs) return -1;
+  const TileCfg& c = kCfgs[cfg];
+  if (tile_pixels) *tile_pixels = 32 * c.MI * c.WM;
+  if (tile_cout) *tile_cout = 32 * c.NI * c.WN;
+  if (kgroups) *kgroups = c.G;
+  return 0;
+}
+
+static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+
+extern "C" size_t imagen_igemm_packed_elems(int G, int Cin, int Cout_pad, int KH, int KW) {
+  if (G != 1 && G != 2 && G != 4) return 0;
+  const int KC = 8 * G;
+  const int NC = round_up(Cin, KC) / KC;
+  const int KGP = ((KH * KW * G + 1) / 2) * 2;
+  return (size_t)NC * KGP * Cout_pad * 8;
+}
+
+// Host-side packing into MFMA A-operand fragment order: element (chunk, tap, group cg, cout, j) holds
+// W[cout][chunk*KC + cg*8 + j][tap] (* in_scale[c]) at ((chunk*KGP + tap*G + cg) * Cout_pad + cout) * 8 + j.
+// The layout depends only on G (8-channel groups per k-chunk) and Cout_pad, not on the tile configuration.
+extern "C" int imagen_pack_igemm_weights(int G, const float* w_in, const float* in_scale, int Cin, int Cout, int Cout_pad,
+                                         int KH, int KW, uint16_t* w_out) {
+  if (G != 1 && G != 2 && G != 4) { imagen_set_error("pack: bad G %d", G); return -1; }
+  if (Cout_pad < Cout || Cout_pad % 32) { imagen_set_error("pack: bad Cout_pad %d", Cout_pad); return -1; }
+  const int KC = 8 * G;
+  const int Cin_pad = round_up(Cin, KC);
+  const int NC = Cin_pad / KC, ntap = KH * KW;
+  const int KGP = ((ntap * G + 1) / 2) * 2;
+  const size_t total = (size_t)NC * KGP * Cout_pad * 8;
+  f16* out = reinterpret_cast<f16*>(w_out);
+  for (size_t i = 0; i < total; ++i) out[i] = (f16)0.0f;
+  for (int chunk = 0; chunk < NC; ++chunk)
+    for (int tap = 0; tap < ntap; ++tap)
+      for (int cg = 0; cg < G; ++cg)
+        for (int co = 0; co < Cout; ++co)
+          for (int j = 0; j < 8; ++j) {
+            const int ci = chunk * KC + cg * 8 + j;
+            if (ci >= Cin) continue;
+            float v = w_in[((size_t)co * Cin + ci) * ntap + tap];
+            if (in_scale) v *= in_scale[ci];
+            out[((size_t)(chunk * KGP + tap * G + cg) * Cout_pad + co) * 8 + j] = (f16)v;
+          }
+  return 0;
+}

@@ -1,0 +1,230 @@
+// sampler.hip — the per-timestep DDPM epilogue of Imagen.p_sample (ip.py:2042-2165) as graph-capturable
+// kernels: classifier-free-guidance combine + x0 prediction, exact per-sample 0.95-quantile of |x0|
+// (torch.quantile semantics: fp32 rank, linear interpolation), dynamic thresholding, posterior mean /
+// variance and ancestral noise (injected tensor for parity runs, counter-based Philox4x32-10 otherwise).
+// Every kernel reads the current step from a device counter so one captured graph replays for all T steps.
+#include "common.h"
+
+namespace {
+
+// coef row layout (host-built, fp32): [alpha, sigma, alpha_next, sigma_next, c, nonzero, log_snr, 0]
+constexpr int kCoefStride = 8;
+
+__global__ __launch_bounds__(256) void cfg_x0_kernel(const ImagenCfgX0Params p) {
+  const size_t n = (size_t)p.B * p.n_per_sample;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const float* cf = p.coef + (size_t)(*p.step_ptr) * kCoefStride;
+  const float alpha = cf[0], sigma = cf[1];
+  float eps;
+  if (p.cfg) {
+    const float cond = p.pred[i], nul = p.pred[n + i];
+    eps = nul + (cond - nul) * p.cond_scale;  // ip.py:1522
+  } else {
+    eps = p.pred[i];
+  }
+  const float x0 = (p.x[i] - sigma * eps) / fmaxf(alpha, 1e-8f);  // ip.py:314-318
+  p.x0[i] = x0;
+  p.absx0[i] = fabsf(x0);
+}
+
+// ---- exact quantile: 4 x 8-bit MSB-first radix select on the (non-negative) float bit patterns ------------
+// scratch per sample (uint32): hist[4][256] | cnt_le | min_gt | unused...
+constexpr int kScratch = IMAGEN_QUANTILE_SCRATCH_WORDS;
+
+struct Narrow { uint32_t prefix; uint32_t k; };
+
+// Re-derive (prefix, remaining rank) from the histograms of the passes already done.
+__device__ Narrow narrow_from_hist(const uint32_t* hist, int passes_done, uint32_t k) {
+  Narrow nr{0u, k};
+  for (int ps = 0; ps < passes_done; ++ps) {
+    const uint32_t* h = hist + ps * 256;
+    uint32_t cum = 0;
+    int bin = 0;
+    for (; bin < 256; ++bin) {
+      const uint32_t c = h[bin];
+      if (cum + c > nr.k) break;
+      cum += c;
+    }
+    if (bin > 255) bin = 255;
+    nr.prefix |= (uint32_t)bin << (24 - 8 * ps);
+    nr.k -= cum;
+  }
+  return nr;
+}
+
+__device__ __forceinline__ uint32_t rank_below(int n, float q) {
+  const float rank = q * (float)(n - 1);  // fp32 rank, as torch.quantile computes it
+  return (uint32_t)floorf(rank);
+}
+
+__global__ __launch_bounds__(256) void quantile_hist_kernel(const ImagenQuantileParams p, int pass, int blocks_per_sample) {
+  __shared__ uint32_t s_hist[256];
+  __shared__ Narrow s_nr;
+  const int b = blockIdx.x / blocks_per_sample, blk = blockIdx.x % blocks_per_sample;
+  uint32_t* scratch = p.scratch + (size_t)b * kScratch;
+  s_hist[threadIdx.x] = 0;
+  if (threadIdx.x == 0) s_nr = narrow_from_hist(scratch, pass, rank_below(p.n, p.q));
+  __syncthreads();
+  const uint32_t prefix = s_nr.prefix;
+  const uint32_t himask = pass == 0 ? 0u : (0xFFFFFFFFu << (32 - 8 * pass));
+  const int shift = 24 - 8 * pass;
+  const uint32_t* keys = reinterpret_cast<const uint32_t*>(p.absx0) + (size_t)b * p.n;
+  for (int i = blk * 256 + threadIdx.x; i < p.n; i += blocks_per_sample * 256) {
+    const uint32_t key = keys[i];
+    if ((key & himask) == (prefix & himask)) atomicAdd(&s_hist[(key >> shift) & 255u], 1u);
+  }
+  __syncthreads();
+  const uint32_t c = s_hist[threadIdx.x];
+  if (c) atomicAdd(&scratch[pass * 256 + threadIdx.x], c);
+}
+
+// After 4 passes the rank-k key is fully known; count keys <= it and find the smallest key above it.
+__global__ __launch_bounds__(256) void quantile_tail_kernel(const ImagenQuantileParams p, int blocks_per_sample) {
+  __shared__ Narrow s_nr;
+  __shared__ uint32_t s_cnt, s_min;
+  const int b = blockIdx.x / blocks_per_sample, blk = blockIdx.x % blocks_per_sample;
+  uint32_t* scratch = p.scratch + (size_t)b * kScratch;
+  if (threadIdx.x == 0) {
+    s_nr = narrow_from_hist(scratch, 4, rank_below(p.n, p.q));
+    s_cnt = 0;
+    s_min = 0xFFFFFFFFu;
+  }
+  __syncthreads();
+  const uint32_t vlo = s_nr.prefix;
+  const uint32_t* keys = reinterpret_cast<const uint32_t*>(p.absx0) + (size_t)b * p.n;
+  uint32_t cnt = 0, mn = 0xFFFFFFFFu;
+  for (int i = blk * 256 + threadIdx.x; i < p.n; i += blocks_per_sample * 256) {
+    const uint32_t key = keys[i];
+    if (key <= vlo) ++cnt;
+    else mn = min(mn, key);
+  }
+  atomicAdd(&s_cnt, cnt);
+  atomicMin(&s_min, mn);
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    atomicAdd(&scratch[1024], s_cnt);
+    atomicMin(&scratch[1025], s_min);
+  }
+}
+
+__global__ void quantile_final_kernel(const ImagenQuantileParams p) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= p.B) return;
+  const uint32_t* scratch = p.scratch + (size_t)b * kScratch;
+  const float rank = p.q * (float)(p.n - 1);
+  const uint32_t k = (uint32_t)floorf(rank);
+  const float w = rank - floorf(rank);
+  const Narrow nr = narrow_from_hist(scratch, 4, k);
+  const uint32_t cnt_le = scratch[1024];
+  const uint32_t hi_key = (cnt_le >= k + 2u || scratch[1025] == 0xFFFFFFFFu) ? nr.prefix : scratch[1025];
+  const float lo = __uint_as_float(nr.prefix), hi = __uint_as_float(hi_key);
+  // torch lerp: w < 0.5 ? a + w*(b-a) : b - (b-a)*(1-w)
+  const float d = hi - lo;
+  p.out[b] = (w < 0.5f) ? (lo + w * d) : (hi - d * (1.0f - w));
+}
+
+__global__ __launch_bounds__(256) void memset_u32_kernel(uint32_t* dst, int count, int stride_words, int min_slot) {
+  // zero the histograms and counters; the "min" slot starts at 0xFFFFFFFF
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= count) return;
+  dst[i] = ((i % stride_words) == min_slot) ? 0xFFFFFFFFu : 0u;
+}
+
+// ---- Philox4x32-10 + Box-Muller ------------------------------------------------------------------------
+__device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_t& c2, uint32_t& c3, uint32_t k0, uint32_t k1) {
+  const uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+  const uint32_t hi0 = __umulhi(M0, c0), lo0 = M0 * c0;
+  const uint32_t hi1 = __umulhi(M1, c2), lo1 = M1 * c2;
+  const uint32_t n0 = hi1 ^ c1 ^ k0, n1 = lo1, n2 = hi0 ^ c3 ^ k1, n3 = lo0;
+  c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+}
+
+__device__ __forceinline__ void philox_normal4(uint32_t ctr0, uint32_t ctr1, uint32_t ctr2, uint32_t seed_lo, uint32_t seed_hi, float out[4]) {
+  uint32_t c0 = ctr0, c1 = ctr1, c2 = ctr2, c3 = 0u, k0 = seed_lo, k1 = seed_hi;
+#pragma unroll
+  for (int r = 0; r < 10; ++r) {
+    philox_round(c0, c1, c2, c3, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  const float inv = 2.3283064365386963e-10f;  // 2^-32
+  const float u0 = ((float)c0 + 0.5f) * inv, u1 = ((float)c1 + 0.5f) * inv;
+  const float u2 = ((float)c2 + 0.5f) * inv, u3 = ((float)c3 + 0.5f) * inv;
+  const float r0 = sqrtf(-2.0f * __logf(fmaxf(u0, 1e-12f))), r1 = sqrtf(-2.0f * __logf(fmaxf(u2, 1e-12f)));
+  float s0, c0f, s1, c1f;
+  __sincosf(6.283185307179586f * u1, &s0, &c0f);
+  __sincosf(6.283185307179586f * u3, &s1, &c1f);
+  out[0] = r0 * c0f; out[1] = r0 * s0; out[2] = r1 * c1f; out[3] = r1 * s1;
+}
+
+__global__ __launch_bounds__(256) void ddpm_update_kernel(const ImagenDdpmUpdateParams p) {
+  const size_t n = (size_t)p.B * p.n_per_sample;
+  const size_t i4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  const int step = *p.step_ptr;
+  const float* cf = p.coef + (size_t)step * kCoefStride;
+  const float alpha = cf[0], alpha_next = cf[2], sigma_next = cf[3], c = cf[4], nonzero = cf[5];
+  const float var = sigma_next * sigma_next * c;                // ip.py:268
+  const float stdev = sqrtf(fmaxf(var, 1e-20f));                 // = exp(0.5*log(clamp(var,1e-20))), ip.py:269, 2164
+  float z[4];
+  if (p.noise) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) z[e] = (i4 + e < n) ? p.noise[i4 + e] : 0.f;
+  } else {
+    philox_normal4((uint32_t)(i4 >> 2), (uint32_t)step, p.stream_id, p.seed_lo, p.seed_hi, z);
+  }
+  const bool last = step + 1 >= p.total_steps;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const size_t i = i4 + e;
+    if (i >= n) break;
+    const int b = (int)(i / p.n_per_sample);
+    float x0 = p.x0[i];
+    if (p.dynamic_threshold) {
+      const float s = fmaxf(p.quant[b], 1.0f);                  // ip.py:2103
+      x0 = fminf(fmaxf(x0, -s), s) / s;                         // ip.py:2105
+    } else {
+      x0 = fminf(fmaxf(x0, -1.0f), 1.0f);                       // ip.py:2107
+    }
+    const float xt = p.x[i];
+    const float mean = alpha_next * (xt * (1.0f - c) / alpha + c * x0);  // ip.py:265
+    const float xn = mean + nonzero * stdev * z[e];                       // ip.py:2164
+    p.x[i] = xn;
+    if (last && p.final_out) p.final_out[i] = (fminf(fmaxf(xn, -1.0f), 1.0f) + 1.0f) * 0.5f;  // ip.py:2281-2288
+  }
+}
+
+__global__ void step_advance_kernel(int32_t* step_ptr) { *step_ptr += 1; }
+
+}  // namespace
+
+int launch_cfg_x0(const ImagenCfgX0Params* p, hipStream_t s) {
+  IMAGEN_CHECK(p->step_ptr && p->coef, "cfg_x0: coef table / step counter required");
+  const size_t n = (size_t)p->B * p->n_per_sample;
+  hipLaunchKernelGGL(cfg_x0_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, *p);
+  return imagen_hip_status("cfg_x0");
+}
+
+int launch_quantile(const ImagenQuantileParams* p, hipStream_t s) {
+  IMAGEN_CHECK(p->n >= 2 && p->B > 0, "quantile: need n >= 2");
+  int bps = (p->n + 8191) / 8192;  // blocks per sample: ~8k keys each
+  if (bps < 1) bps = 1;
+  if (bps > 64) bps = 64;
+  const int words = p->B * kScratch;
+  hipLaunchKernelGGL(memset_u32_kernel, dim3((words + 255) / 256), dim3(256), 0, s, p->scratch, words, kScratch, 1025);
+  for (int pass = 0; pass < 4; ++pass)
+    hipLaunchKernelGGL(quantile_hist_kernel, dim3(p->B * bps), dim3(256), 0, s, *p, pass, bps);
+  hipLaunchKernelGGL(quantile_tail_kernel, dim3(p->B * bps), dim3(256), 0, s, *p, bps);
+  hipLaunchKernelGGL(quantile_final_kernel, dim3((p->B + 63) / 64), dim3(64), 0, s, *p);
+  return imagen_hip_status("quantile");
+}
+
+int launch_ddpm_update(const ImagenDdpmUpdateParams* p, hipStream_t s) {
+  IMAGEN_CHECK(p->step_ptr && p->coef, "ddpm_update: coef table / step counter required");
+  IMAGEN_CHECK(!p->dynamic_threshold || p->quant, "ddpm_update: dynamic thresholding needs the quantile");
+  const size_t n4 = ((size_t)p->B * p->n_per_sample + 3) / 4;
+  hipLaunchKernelGGL(ddpm_update_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, *p);
+  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, p->step_ptr);
+  return imagen_hip_status("ddpm_update");
+}

@@ -1,0 +1,471 @@
+"""Host-side op builders: torch tensors (device memory only) -> C-ABI params structs -> launch / plan.
+
+Nothing here computes: every function fills an `Imagen*Params` struct (include/imagen_hip.h) with raw
+device pointers and sizes and appends it to a `Plan`.  A plan is executed by ONE call into
+`imagen_plan_run` (native loop over the ops) on a given HIP stream, and can be captured into a hipGraph.
+"""
+from __future__ import annotations
+
+import ctypes
+import math
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _abi
+from ._abi import ENUMS, STRUCTS, OpRef, check, load_library
+
+ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+OUT_NHWC, OUT_PIXEL_SHUFFLE, OUT_NCHW_F32 = 0, 1, 2
+LOG2E = 1.4426950408889634
+
+# tile configurations of the igemm kernel: cfg id -> (tile pixels, tile couts, G)
+_CFG_TABLE = None
+
+
+def cfg_table():
+    global _CFG_TABLE
+    if _CFG_TABLE is None:
+        lib = load_library()
+        tab = []
+        for i in range(lib.imagen_igemm_num_configs()):
+            tp, bn, g = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
+            lib.imagen_igemm_config_info(i, ctypes.byref(tp), ctypes.byref(bn), ctypes.byref(g))
+            tab.append((tp.value, bn.value, g.value))
+        _CFG_TABLE = tab
+    return _CFG_TABLE
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def current_stream_handle() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+# ------------------------------------------------------------------------------------------------ plan
+
+class Plan:
+    """Ordered list of kernel launches with their params structs (kept alive here)."""
+
+    def __init__(self, name: str = ""):
+        self.name = name
+        self.ops: List[tuple] = []   # (kind, struct, label)
+        self.keep: List[object] = []  # tensors referenced by raw pointer
+        self._arr = None
+
+    def add(self, struct, label: str = "", keep: Sequence = ()):
+        kind = _abi.STRUCT_KIND[type(struct)]
+        self.ops.append((kind, struct, label))
+        self.keep.extend(k for k in keep if k is not None)
+        self._arr = None
+        return struct
+
+    def extend(self, other: "Plan"):
+        self.ops.extend(other.ops)
+        self.keep.extend(other.keep)
+        self._arr = None
+
+    def __len__(self):
+        return len(self.ops)
+
+    def _array(self):
+        if self._arr is None:
+            arr = (OpRef * len(self.ops))()
+            for i, (kind, st, _) in enumerate(self.ops):
+                arr[i].kind = kind
+                arr[i].params = ctypes.addressof(st)
+            self._arr = arr
+        return self._arr
+
+    def run(self, stream: Optional[int] = None):
+        if not self.ops:
+            return
+        lib = load_library()
+        s = current_stream_handle() if stream is None else stream
+        check(lib.imagen_plan_run(ctypes.cast(self._array(), ctypes.c_void_p), len(self.ops), s), f"plan '{self.name}'")
+
+    def run_stepwise(self, stream: Optional[int] = None, sync_each: bool = False):
+        """Debug: launch op by op (optionally synchronising) so a faulting kernel is attributable."""
+        lib = load_library()
+        s = current_stream_handle() if stream is None else stream
+        for kind, st, label in self.ops:
+            check(lib.imagen_launch(kind, ctypes.addressof(st), s), f"op {label or kind}")
+            if sync_each:
+                torch.cuda.synchronize()
+
+
+class Graph:
+    """hipGraph capture of a plan (per-timestep graph)."""
+
+    def __init__(self, plan: Plan, stream: torch.cuda.Stream):
+        self.plan, self.stream = plan, stream
+        lib = load_library()
+        self._exec = ctypes.c_void_p()
+        h = stream.cuda_stream
+        check(lib.imagen_graph_begin(h), "graph begin")
+        try:
+            plan.run(h)
+        finally:
+            rc = lib.imagen_graph_end(h, ctypes.byref(self._exec))
+        check(rc, "graph end")
+
+    def launch(self):
+        check(load_library().imagen_graph_launch(self._exec, self.stream.cuda_stream), "graph launch")
+
+    def __del__(self):
+        try:
+            if self._exec:
+                load_library().imagen_graph_destroy(self._exec)
+        except Exception:
+            pass
+
+
+# ------------------------------------------------------------------------------------------------ tensors
+
+@dataclass
+class Act:
+    """fp16 NHWC activation view: element (b, y, x, c) at b*bs + (y*W + x)*ld + c (elements)."""
+    t: torch.Tensor          # owning storage (kept alive)
+    B: int
+    H: int
+    W: int
+    C: int
+    ld: int
+    bs: int
+    off: int = 0             # element offset into t
+
+    @property
+    def ptr(self) -> int:
+        return self.t.data_ptr() + 2 * self.off
+
+    @property
+    def rows(self) -> int:
+        return self.B * self.H * self.W
+
+    def tokens(self) -> "Act":
+        """Same memory seen as (B, 1, H*W, C)."""
+        return Act(self.t, self.B, 1, self.H * self.W, self.C, self.ld, self.bs, self.off)
+
+
+def new_act(B, H, W, C, device, zero: bool = False) -> Act:
+    t = (torch.zeros if zero else torch.empty)((B, H, W, C), dtype=torch.float16, device=device)
+    return Act(t, B, H, W, C, C, H * W * C)
+
+
+def act_from_nchw(x: torch.Tensor) -> Act:
+    """fp32/fp16 NCHW torch tensor -> fp16 NHWC Act (test helper; plumbing, not on the hot path)."""
+    B, C, H, W = x.shape
+    t = x.permute(0, 2, 3, 1).contiguous().to(torch.float16)
+    return Act(t, B, H, W, C, C, H * W * C)
+
+
+def act_to_nchw(a: Act) -> torch.Tensor:
+    assert a.ld == a.C and a.off == 0
+    return a.t.reshape(a.B, a.H, a.W, a.C).permute(0, 3, 1, 2).float()
+
+
+# ------------------------------------------------------------------------------------------------ weights
+
+def _round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+@dataclass
+class PackedWeight:
+    w: torch.Tensor           # packed fp16, device
+    bias: Optional[torch.Tensor]  # fp32 [Cout_pad], device
+    Cin: int
+    Cout: int
+    KH: int
+    KW: int
+    G: int
+    Cin_pad: int
+    Cout_pad: int
+
+
+def choose_G(Cin: int) -> int:
+    if Cin % 32 == 0:
+        return 4
+    return 1
+
+
+def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], device, in_scale: Optional[torch.Tensor] = None,
+                G: Optional[int] = None) -> PackedWeight:
+    """w: fp32 [Cout, Cin, KH, KW] or [Cout, Cin] (Linear).  Packs on the host through the C packer, uploads once."""
+    lib = load_library()
+    w = w.detach().float().cpu()
+    if w.ndim == 2:
+        w = w[:, :, None, None]
+    w = w.contiguous()
+    Cout, Cin, KH, KW = w.shape
+    G = G or choose_G(Cin)
+    KC = 8 * G
+    Cin_pad = _round_up(Cin, KC)
+    Cout_pad = _round_up(Cout, 128)
+    n = lib.imagen_igemm_packed_elems(G, Cin, Cout_pad, KH, KW)
+    out = torch.empty(n, dtype=torch.float16)
+    sc = None if in_scale is None else in_scale.detach().float().cpu().contiguous()
+    check(lib.imagen_pack_igemm_weights(G, w.data_ptr(), None if sc is None else sc.data_ptr(), Cin, Cout, Cout_pad, KH, KW,
+                                        out.data_ptr()), "pack weights")
+    b = None
+    if bias is not None:
+        b = torch.zeros(Cout_pad, dtype=torch.float32)
+        b[:Cout] = bias.detach().float().cpu()
+        b = b.to(device)
+    return PackedWeight(out.to(device), b, Cin, Cout, KH, KW, G, Cin_pad, Cout_pad)
+
+
+# ------------------------------------------------------------------------------------------------ igemm
+
+MAX_STAGE_ITEMS = 6 * 256      # kMaxItems * threads in igemm.hip
+MAX_LDS_BYTES = 160 * 1024
+
+
+def _tile_shapes(tp: int, OH: int, OW: int):
+    if OH == 1:
+        return [(1, tp)]
+    return [(tp // tw, tw) for tw in (8, 16, 32, 64) if tp % tw == 0 and tp // tw >= 1]
+
+
+def pick_cfg(G: int, Cout: int, OH: int, OW: int, B: int, KH: int = 1, KW: int = 1, stride: int = 1):
+    """Choose (cfg, TH, TW): output-channel tile closest to Cout, then the largest pixel tile that still fills
+    the 256 CUs (smallest one otherwise), then the tile shape staging the fewest input pixels (halo)."""
+    tab = cfg_table()
+    img_px = OH * OW
+    want_bn = 32 if Cout <= 32 else (64 if Cout <= 64 else 128)
+    ps = 16 if G == 1 else G * 16 + 16
+    best = None
+    for i, (tp, bn, g) in enumerate(tab):
+        if g != G:
+            continue
+        for th, tw in _tile_shapes(tp, OH, OW):
+            it = ((th - 1) * stride + KH) * ((tw - 1) * stride + KW)
+            if it * G > MAX_STAGE_ITEMS or 2 * it * ps > MAX_LDS_BYTES:
+                continue
+            tiles = math.ceil(OH / th) * math.ceil(OW / tw)
+            nb = B * tiles * math.ceil(Cout / bn)
+            waste = tiles * tp / img_px            # padded-pixel overhead (tiles hanging over the image)
+            fill = nb >= 256
+            score = (abs(bn - want_bn), waste > 1.5, not fill, -tp if fill else tp, tiles * it)
+            if best is None or score < best[0]:
+                best = (score, i, th, tw)
+    if best is None:
+        raise ValueError(f"no igemm tile configuration for G={G} Cout={Cout} {OH}x{OW} k{KH}x{KW} s{stride}")
+    return best[1], best[2], best[3]
+
+
+def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None, mu=None, rs=None, pa=None, ps=None,
+          pstride: int = 0, act_in: int = ACT_NONE, act_out: int = ACT_NONE, addend: Optional[Act] = None, gate=None,
+          res: Optional[Act] = None, out_mode: int = OUT_NHWC, stride: int = 1, pad: Optional[int] = None,
+          cfg: Optional[tuple] = None, label: str = ""):
+    """Append one implicit-GEMM launch.  y: Act (NHWC / pixel-shuffle target) or fp32 NCHW tensor (OUT_NCHW_F32)."""
+    KH, KW = pw.KH, pw.KW
+    if pad is None:
+        pad = (KH - 1) // 2 if stride == 1 else 0
+    H, W = x1.H, x1.W
+    OH = (H + 2 * pad - KH) // stride + 1
+    OW = (W + 2 * pad - KW) // stride + 1
+    C2 = x2.C if x2 is not None else 0
+    assert x1.C + C2 == pw.Cin, f"{label}: input channels {x1.C}+{C2} != weight Cin {pw.Cin}"
+    if cfg is None:
+        cfg = pick_cfg(pw.G, pw.Cout, OH, OW, x1.B, KH, KW, stride)
+    cid, th, tw = cfg
+    p = STRUCTS["ImagenIgemmParams"]()
+    p.x1, p.C1, p.ld1, p.bs1 = x1.ptr, x1.C, x1.ld, x1.bs
+    if x2 is not None:
+        assert (x2.B, x2.H, x2.W) == (x1.B, x1.H, x1.W)
+        p.x2, p.C2, p.ld2, p.bs2 = x2.ptr, x2.C, x2.ld, x2.bs
+    p.mu, p.rs, p.pa, p.ps = ptr(mu), ptr(rs), ptr(pa), ptr(ps)
+    p.w, p.bias = pw.w.data_ptr(), ptr(pw.bias)
+    p.B, p.H, p.W = x1.B, H, W
+    p.KH, p.KW, p.stride, p.pad = KH, KW, stride, pad
+    p.OH, p.OW = OH, OW
+    p.Cin_pad, p.Cout, p.Cout_pad = pw.Cin_pad, pw.Cout, pw.Cout_pad
+    p.pstride = pstride
+    p.act_in, p.act_out = act_in, act_out
+    if addend is not None:
+        assert gate is not None and (addend.H, addend.W) == (OH, OW)
+        p.addend, p.ld_add, p.bs_add = addend.ptr, addend.ld, addend.bs
+        p.gate, p.gate_stride = gate.data_ptr(), pw.Cout
+    if res is not None:
+        assert (res.H, res.W, res.C) == (OH, OW, pw.Cout), f"{label}: residual shape"
+        p.res, p.ld_res, p.bs_res = res.ptr, res.ld, res.bs
+    p.out_mode = out_mode
+    keep = [x1.t, x2.t if x2 is not None else None, mu, rs, pa, ps, pw.w, pw.bias, gate,
+            addend.t if addend is not None else None, res.t if res is not None else None]
+    if out_mode == OUT_NCHW_F32:
+        assert isinstance(y, torch.Tensor) and y.dtype == torch.float32 and tuple(y.shape) == (x1.B, pw.Cout, OH, OW)
+        p.y = y.data_ptr()
+        keep.append(y)
+    else:
+        assert isinstance(y, Act)
+        if out_mode == OUT_PIXEL_SHUFFLE:
+            assert (y.H, y.W, y.C) == (2 * OH, 2 * OW, pw.Cout // 4), f"{label}: pixel-shuffle target shape"
+        else:
+            assert (y.H, y.W) == (OH, OW) and y.C >= pw.Cout or (y.H * y.W == OH * OW and y.C >= pw.Cout), f"{label}: output shape"
+        p.y, p.ldy, p.bsy = y.ptr, y.ld, y.bs
+        keep.append(y.t)
+    p.TH, p.TW, p.cfg = th, tw, cid
+    plan.add(p, label or "igemm", keep)
+    return p
+
+
+# ------------------------------------------------------------------------------------------------ small ops
+
+def rowstat(plan: Plan, x1: Act, *, mode: int, rs: torch.Tensor, mu: Optional[torch.Tensor] = None, x2: Optional[Act] = None,
+            w2: float = 1.0, eps: float = 1e-5, label: str = ""):
+    p = STRUCTS["ImagenRowstatParams"]()
+    p.x1, p.C1, p.ld1, p.bs1 = x1.ptr, x1.C, x1.ld, x1.bs
+    if x2 is not None:
+        p.x2, p.C2, p.ld2, p.bs2 = x2.ptr, x2.C, x2.ld, x2.bs
+    p.mu, p.rs = ptr(mu), rs.data_ptr()
+    p.rows, p.rows_per_batch, p.mode = x1.rows, x1.H * x1.W, mode
+    p.w2, p.eps = w2, eps
+    plan.add(p, label or "rowstat", [x1.t, x2.t if x2 is not None else None, mu, rs])
+    return p
+
+
+def attention(plan: Plan, q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, o: torch.Tensor, *, B, heads, rows, J,
+              q_strides, k_strides, vt_strides, o_strides, label: str = ""):
+    p = STRUCTS["ImagenAttentionParams"]()
+    p.q, p.k, p.vt, p.o = q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr()
+    p.B, p.heads, p.rows, p.J = B, heads, rows, J
+    p.q_bs, p.q_hs, p.q_rs = q_strides
+    p.k_bs, p.k_hs, p.k_rs = k_strides
+    p.vt_bs, p.vt_hs, p.vt_ds = vt_strides
+    p.o_bs, p.o_hs, p.o_rs = o_strides
+    plan.add(p, label or "attention", [q, k, vt, o])
+    return p
+
+
+def kv_prep(plan: Plan, k_src: torch.Tensor, v_src: torch.Tensor, k_scale: torch.Tensor, khat: torch.Tensor, vt: torch.Tensor, *,
+            B, heads, rows, r0, src_strides, k_strides, vt_strides, k_off: int = 0, v_off: int = 0, label: str = ""):
+    """k_off / v_off: element offsets of the k and v columns inside the source rows."""
+    p = STRUCTS["ImagenKvPrepParams"]()
+    es = k_src.element_size()
+    p.k_src, p.v_src = k_src.data_ptr() + k_off * es, v_src.data_ptr() + v_off * es
+    p.k_scale, p.khat, p.vt = k_scale.data_ptr(), khat.data_ptr(), vt.data_ptr()
+    p.B, p.heads, p.rows, p.r0 = B, heads, rows, r0
+    p.src_bs, p.src_rs, p.src_hs = src_strides
+    p.k_bs, p.k_hs, p.k_rs = k_strides
+    p.vt_bs, p.vt_hs, p.vt_ds = vt_strides
+    p.src_is_f32 = 1 if k_src.dtype == torch.float32 else 0
+    plan.add(p, label or "kv_prep", [k_src, v_src, k_scale, khat, vt])
+    return p
+
+
+def qnorm(plan: Plan, q: torch.Tensor, q_scale: torch.Tensor, *, rows, heads, ld, mult, label: str = ""):
+    p = STRUCTS["ImagenQnormParams"]()
+    p.q, p.q_scale, p.rows, p.heads, p.ld, p.mult = q.data_ptr(), q_scale.data_ptr(), rows, heads, ld, mult
+    plan.add(p, label or "qnorm", [q, q_scale])
+    return p
+
+
+def gca(plan: Plan, h: Act, wk, bk: float, w1, b1, w2, b2, part: torch.Tensor, gate: torch.Tensor, chunks: int, label: str = ""):
+    C = h.C
+    p = STRUCTS["ImagenGcaPartialParams"]()
+    p.h, p.wk, p.part = h.ptr, wk.data_ptr(), part.data_ptr()
+    p.B, p.HW, p.C, p.ld, p.chunks, p.bk = h.B, h.H * h.W, C, h.ld, chunks, bk
+    plan.add(p, (label or "gca") + ".partial", [h.t, wk, part])
+    f = STRUCTS["ImagenGcaFinalParams"]()
+    f.part, f.w1, f.b1, f.w2, f.b2, f.gate = part.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), gate.data_ptr()
+    f.B, f.C, f.hidden, f.chunks = h.B, C, w1.shape[0], chunks
+    plan.add(f, (label or "gca") + ".final", [part, w1, b1, w2, b2, gate])
+
+
+def gca_chunks(HW: int) -> int:
+    c = max(1, math.ceil(HW / 1024))
+    return c
+
+
+def gate_residual(plan: Plan, h: Act, gate: Optional[torch.Tensor], res: Act, out: Act, rs_out: Optional[torch.Tensor] = None,
+                  label: str = ""):
+    assert h.ld * h.H * h.W == h.bs and res.ld * res.H * res.W == res.bs and out.ld * out.H * out.W == out.bs
+    p = STRUCTS["ImagenGateResidualParams"]()
+    p.h, p.gate, p.res, p.out, p.rs_out = h.ptr, ptr(gate), res.ptr, out.ptr, ptr(rs_out)
+    p.rows, p.rows_per_batch, p.C = h.rows, h.H * h.W, h.C
+    p.ld_h, p.ld_res, p.ld_out = h.ld, res.ld, out.ld
+    plan.add(p, label or "gate_residual", [h.t, gate, res.t, out.t, rs_out])
+    return p
+
+
+def ln_residual(plan: Plan, y: Act, g: torch.Tensor, out: Act, *, beta=None, res: Optional[Act] = None, eps: float = 1e-5,
+                label: str = ""):
+    p = STRUCTS["ImagenLnResidualParams"]()
+    p.y, p.g, p.beta, p.res, p.out = y.ptr, g.data_ptr(), ptr(beta), (res.ptr if res is not None else None), out.ptr
+    p.rows, p.C, p.ld_y, p.ld_res, p.ld_out, p.eps = y.rows, y.C, y.ld, (res.ld if res is not None else 0), out.ld, eps
+    plan.add(p, label or "ln_residual", [y.t, g, beta, res.t if res is not None else None, out.t])
+    return p
+
+
+def time_embed(plan: Plan, *, times, coef, step_ptr, freqs, w, bias, hid: Act, label: str = ""):
+    p = STRUCTS["ImagenTimeEmbedParams"]()
+    p.times, p.coef, p.step_ptr = ptr(times), ptr(coef), ptr(step_ptr)
+    p.freqs, p.w, p.bias, p.hid = freqs.data_ptr(), w.data_ptr(), bias.data_ptr(), hid.ptr
+    p.B, p.half_dim, p.out_dim, p.ld_hid = hid.B * hid.H * hid.W, freqs.numel(), hid.C, hid.ld
+    plan.add(p, label or "time_embed", [times, coef, step_ptr, freqs, w, bias, hid.t])
+    return p
+
+
+def scale_shift(plan: Plan, ss: Act, gamma_s, idx_scale, idx_shift, pa, ps, label: str = ""):
+    p = STRUCTS["ImagenScaleShiftParams"]()
+    p.ss, p.gamma_s, p.idx_scale, p.idx_shift, p.pa, p.ps = ss.ptr, gamma_s.data_ptr(), idx_scale.data_ptr(), idx_shift.data_ptr(), pa.data_ptr(), ps.data_ptr()
+    p.B, p.total_c, p.ld_ss = ss.rows, gamma_s.numel(), ss.ld
+    plan.add(p, label or "scale_shift", [ss.t, gamma_s, idx_scale, idx_shift, pa, ps])
+    return p
+
+
+def pack_image(plan: Plan, a: torch.Tensor, b: Optional[torch.Tensor], out: Act, brep: int, label: str = ""):
+    p = STRUCTS["ImagenPackImageParams"]()
+    B, Ca, H, W = a.shape
+    p.a, p.b, p.out = a.data_ptr(), ptr(b), out.ptr
+    p.B, p.Brep, p.H, p.W, p.Ca, p.Cb, p.Cpad = B, brep, H, W, Ca, (b.shape[1] if b is not None else 0), out.C
+    assert out.B == B * brep and out.ld == out.C
+    plan.add(p, label or "pack_image", [a, b, out.t])
+    return p
+
+
+def rows_copy(plan: Plan, src: torch.Tensor, dst: torch.Tensor, *, B, rows, C, src_bs, src_rs, dst_bs, dst_rs, src_off=0, dst_off=0,
+              label: str = ""):
+    p = STRUCTS["ImagenRowsCopyParams"]()
+    p.src, p.dst = src.data_ptr() + 2 * src_off, dst.data_ptr() + 2 * dst_off
+    p.B, p.rows, p.C, p.src_bs, p.src_rs, p.dst_bs, p.dst_rs = B, rows, C, src_bs, src_rs, dst_bs, dst_rs
+    plan.add(p, label or "rows_copy", [src, dst])
+    return p
+
+
+def memset32(plan: Plan, dst: torch.Tensor, value: int, count: Optional[int] = None, label: str = ""):
+    p = STRUCTS["ImagenMemset32Params"]()
+    p.dst, p.value, p.count = dst.data_ptr(), value, count if count is not None else dst.numel()
+    plan.add(p, label or "memset32", [dst])
+    return p
+
+
+def cfg_x0(plan: Plan, x, pred, coef, step_ptr, x0, absx0, *, B, n_per_sample, cfg: bool, cond_scale: float, label: str = ""):
+    p = STRUCTS["ImagenCfgX0Params"]()
+    p.x, p.pred, p.coef, p.step_ptr, p.x0, p.absx0 = x.data_ptr(), pred.data_ptr(), coef.data_ptr(), step_ptr.data_ptr(), x0.data_ptr(), absx0.data_ptr()
+    p.B, p.n_per_sample, p.cfg, p.cond_scale = B, n_per_sample, int(cfg), cond_scale
+    plan.add(p, label or "cfg_x0", [x, pred, coef, step_ptr, x0, absx0])
+    return p
+
+
+def quantile(plan: Plan, absx0, out, scratch, *, B, n, q: float, label: str = ""):
+    p = STRUCTS["ImagenQuantileParams"]()
+    p.absx0, p.out, p.scratch, p.B, p.n, p.q = absx0.data_ptr(), out.data_ptr(), scratch.data_ptr(), B, n, q
+    assert scratch.numel() >= B * ENUMS["IMAGEN_QUANTILE_SCRATCH_WORDS"]
+    plan.add(p, label or "quantile", [absx0, out, scratch])
+    return p
+
+
+def ddpm_update(plan: Plan, x, x0, quant, coef, noise, final_out, step_ptr, *, B, n_per_sample, dynamic_threshold: bool,
+                total_steps: int, seed: int, stream_id: int, label: str = ""):
+    p = STRUCTS["ImagenDdpmUpdateParams"]()
+    p.x, p.x0, p.quant, p.coef, p.noise, p.final_out, p.step_ptr = (x.data_ptr(), x0.data_ptr(), ptr(quant), coef.data_ptr(), ptr(noise),
+                                                                   ptr(final_out), step_ptr.data_ptr())
+    p.B, p.n_per_sample, p.dynamic_threshold, p.total_steps = B, n_per_sample, int(dynamic_threshold), total_steps
+    p.seed_lo, p.seed_hi, p.stream_id = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, stream_id
+    plan.add(p, label or "ddpm_update", [x, x0, quant, coef, noise, final_out, step_ptr])
+    return p

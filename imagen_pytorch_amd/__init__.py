@@ -1,0 +1,8 @@
+"""Importable alias of the `imagen-pytorch_amd/` package directory (a hyphen cannot appear in an import name)."""
+import os as _os
+
+_real = _os.path.join(_os.path.dirname(_os.path.dirname(_os.path.abspath(__file__))), "imagen-pytorch_amd")
+__path__ = [_real]
+with open(_os.path.join(_real, "__init__.py")) as _f:
+    exec(compile(_f.read(), _os.path.join(_real, "__init__.py"), "exec"))
+del _f

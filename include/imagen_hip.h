@@ -1,0 +1,266 @@
+/*
+ * imagen_hip.h — C ABI of libimagen_hip.so, the gfx950 (MI355X / CDNA4) kernel library behind the
+ * Imagen cascaded-DDPM sampling path.
+ *
+ * The reference (lucidrains/imagen-pytorch v2, pure Python) has no FFI of its own: the "operator API"
+ * of this path is the Python class surface (Unet.forward / Imagen.sample).  This header is the inner
+ * boundary our Python drop-in classes call through: flat extern "C" entry points,
+ * raw device pointers + sizes + a hipStream_t, no C++/torch types.  Each op below names the reference
+ * lines (imagen_pytorch/imagen_pytorch.py = "ip.py") whose ATen sequence it replaces.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (torch tensors kept alive by Python);
+ *   - nothing allocates, frees or synchronises; every launch goes to the passed stream, so a whole
+ *     denoiser step is capturable into a hipGraph;
+ *   - activations are fp16 ("h") NHWC: element (b, y, x, c) at  b*bstride + (y*W + x)*ld + c;
+ *     token tensors (b, n, c) are the same layout with H = 1, W = n;
+ *   - statistics, biases, affine vectors, sampler state are fp32 ("f");
+ *   - return value: 0 on success, otherwise a hipError_t / negative library code;
+ *     imagen_last_error() returns a thread-local message.
+ *
+ * Every params struct is plain-old-data laid out as: pointers, then int32, then float — mirrored 1:1 by
+ * ctypes.Structure classes in imagen-pytorch_amd/_abi.py; imagen_sizeof(kind) lets the host verify it.
+ */
+#ifndef IMAGEN_HIP_H
+#define IMAGEN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define IMAGEN_ABI_VERSION 1
+
+typedef void* imagen_stream_t; /* hipStream_t */
+
+enum ImagenOpKind {
+  IMAGEN_OP_IGEMM = 1,         /* implicit-GEMM conv / linear on MFMA with fused prologue + epilogue   */
+  IMAGEN_OP_ROWSTAT = 2,       /* per-pixel RMS / LayerNorm statistics                                 */
+  IMAGEN_OP_ATTENTION = 3,     /* flash-style cosine-sim attention                                     */
+  IMAGEN_OP_KV_PREP = 4,       /* l2norm*scale of k rows + transposed v into the attention K / V^T buffers */
+  IMAGEN_OP_QNORM = 5,         /* in-place l2norm*scale of q rows                                      */
+  IMAGEN_OP_GCA_PARTIAL = 6,   /* GlobalContext: per-block softmax-pool partials                       */
+  IMAGEN_OP_GCA_FINAL = 7,     /* GlobalContext: combine partials + squeeze MLP -> gate                */
+  IMAGEN_OP_GATE_RESIDUAL = 8, /* out = h*gate + res                                                   */
+  IMAGEN_OP_LN_RESIDUAL = 9,   /* out = LayerNorm(y)*g (+beta) (+ res)                                 */
+  IMAGEN_OP_TIME_EMBED = 10,   /* learned sinusoidal embedding + Linear + SiLU                         */
+  IMAGEN_OP_SCALE_SHIFT = 11,  /* time-MLP output -> per-(batch,channel) prologue affine              */
+  IMAGEN_OP_PACK_IMAGE = 12,   /* fp32 NCHW image(s) -> fp16 NHWC, zero-padded channels                */
+  IMAGEN_OP_CFG_X0 = 13,       /* CFG combine + x0-from-noise + |x0| keys for the quantile             */
+  IMAGEN_OP_QUANTILE = 14,     /* exact per-sample quantile (radix select + lerp)                      */
+  IMAGEN_OP_DDPM_UPDATE = 15,  /* dynamic threshold + posterior mean/var + Philox noise                */
+  IMAGEN_OP_ROWS_COPY = 16,    /* strided fp16 row copy / broadcast (token assembly)                   */
+  IMAGEN_OP_MEMSET32 = 17,     /* fill fp32/int32 words                                                */
+  IMAGEN_OP_KIND_COUNT = 18
+};
+
+/* ------------------------------------------------------------------------------------------------
+ * IGEMM — replaces: Block (ChanRMSNorm -> scale/shift -> SiLU -> Conv2d 3x3) ip.py:671-691;
+ * CrossEmbedLayer ip.py:1051-1076; Downsample ip.py:633-640; PixelShuffleUpsample ip.py:603-631;
+ * res_conv ip.py:732; final_conv ip.py:1436,1725; every nn.Linear on the path (ip.py:521-532,
+ * 738-741, 782-791, 972-980, 1213-1228, 1260, 1283-1287).
+ *
+ *   in(p, c)  = concat(x1[.., :C1], x2[.., :C2])                       (x2 optional)
+ *   a(p, c)   = act_in( (in - mu[p]) * rs[p] * pa[b, c] + ps[b, c] )   (each factor optional), 0 outside the image
+ *   acc(q, o) = sum_{ky,kx,c} a(q*stride - pad + (ky,kx), c) * W[o][ky][kx][c]
+ *   v         = act_out(acc + bias[o]);  v += addend(q,o) * gate[b,o];  v += res(q,o)
+ *   y         = v   (NHWC fp16 | pixel-shuffle NHWC fp16 | NCHW fp32)
+ *
+ * Weights are pre-packed by imagen_pack_igemm_weights() into MFMA-fragment order.
+ */
+enum { IMAGEN_ACT_NONE = 0, IMAGEN_ACT_SILU = 1, IMAGEN_ACT_GELU = 2 };
+enum { IMAGEN_OUT_NHWC = 0, IMAGEN_OUT_PIXEL_SHUFFLE = 1, IMAGEN_OUT_NCHW_F32 = 2 };
+
+typedef struct ImagenIgemmParams {
+  const void* x1;      /* fp16 */
+  const void* x2;      /* fp16 or NULL */
+  const float* mu;     /* [B*H*W] or NULL */
+  const float* rs;     /* [B*H*W] or NULL */
+  const float* pa;     /* [B or 1][Cin] or NULL */
+  const float* ps;     /* [B or 1][Cin] or NULL */
+  const void* w;       /* packed fp16 */
+  const float* bias;   /* [Cout] or NULL */
+  const void* addend;  /* fp16 NHWC at output resolution or NULL */
+  const float* gate;   /* [B][Cout] (required with addend) */
+  const void* res;     /* fp16 NHWC at output resolution or NULL */
+  void* y;             /* fp16 NHWC / fp32 NCHW */
+  int32_t B, H, W;     /* input batch / spatial dims */
+  int32_t C1, ld1, bs1; /* channels, pixel stride, batch stride (elements) of x1 */
+  int32_t C2, ld2, bs2;
+  int32_t KH, KW, stride, pad;
+  int32_t OH, OW;
+  int32_t Cin_pad;     /* C1+C2 rounded up to the k-chunk (8*G) */
+  int32_t Cout, Cout_pad; /* Cout_pad = multiple of 32*NI*WN of the chosen tile */
+  int32_t pstride;     /* batch stride of pa/ps in floats (0 = shared) */
+  int32_t act_in, act_out;
+  int32_t ld_add, bs_add, ld_res, bs_res;
+  int32_t gate_stride;
+  int32_t ldy, bsy;    /* output pixel / batch strides (elements) */
+  int32_t out_mode;
+  int32_t TH, TW;      /* output tile (TH*TW must equal the tile's pixel count) */
+  int32_t cfg;         /* tile configuration id, see imagen_igemm_pick_config */
+} ImagenIgemmParams;
+
+/* ROWSTAT — replaces the reductions inside ChanRMSNorm (ip.py:322-329) and LayerNorm (ip.py:331-349,
+ * nn.LayerNorm).  mode 0: rs = 1/max(sqrt(ssq1 + w2*ssq2), 1e-12), mu untouched.
+ * mode 1: mu = mean, rs = rsqrt(var + eps) (biased variance, two-pass). */
+typedef struct ImagenRowstatParams {
+  const void* x1; const void* x2; float* mu; float* rs;
+  int32_t rows, C1, ld1, C2, ld2, mode;
+  int32_t rows_per_batch, bs1, bs2; /* batch strides (elements); rows_per_batch = rows if contiguous */
+  float w2, eps;
+} ImagenRowstatParams;
+
+/* ATTENTION — replaces ip.py:559-590 (self, shared k/v head) and ip.py:812-833 (cross, per-head k/v),
+ * also PerceiverAttention ip.py:424-444.  q rows are pre-normalised/scaled (QNORM) and include the
+ * similarity scale * log2(e); K rows pre-normalised (KV_PREP); VT is V transposed [d][key].
+ *   o[r] = softmax_j(q[r] . k[j]) @ v   for r in rows, j in [0, J)
+ * Addressing: q/o row r of (batch b, head h): base + b*q_bs + h*q_hs + r*q_rs ; k: b*k_bs + h*k_hs + j*k_rs ;
+ * vt: b*vt_bs + h*vt_hs + d*vt_ds + j.   Head dim is fixed at 64. */
+typedef struct ImagenAttentionParams {
+  const void* q; const void* k; const void* vt; void* o;
+  int32_t B, heads, rows, J;
+  int32_t q_bs, q_hs, q_rs;
+  int32_t k_bs, k_hs, k_rs;
+  int32_t vt_bs, vt_hs, vt_ds;
+  int32_t o_bs, o_hs, o_rs;
+} ImagenAttentionParams;
+
+/* KV_PREP — k/v rows -> attention operand buffers (null_kv, context kv, self kv; ip.py:545-561, 805-814).
+ *   khat[b, h, r0 + r, :] = l2norm(k_src row) * k_scale ;  vt[b, h, :, r0 + r] = v_src row
+ * src row r of batch b, head h at  b*src_bs + r*src_rs + h*src_hs (+ k_off / v_off);  src_bs = 0 broadcasts. */
+typedef struct ImagenKvPrepParams {
+  const void* k_src; const void* v_src; const float* k_scale; void* khat; void* vt;
+  int32_t B, heads, rows, r0;
+  int32_t src_bs, src_rs, src_hs;
+  int32_t k_bs, k_hs, k_rs;
+  int32_t vt_bs, vt_hs, vt_ds;
+  int32_t src_is_f32; /* null_kv parameters are fp32 */
+} ImagenKvPrepParams;
+
+/* QNORM — q[r, h, :] = l2norm(q[r, h, :]) * q_scale * mult   in place (ip.py:559-560, 812-813). */
+typedef struct ImagenQnormParams {
+  void* q; const float* q_scale;
+  int32_t rows, heads, ld; /* row stride in elements; head h at column h*64 */
+  float mult;
+} ImagenQnormParams;
+
+/* GCA_PARTIAL / GCA_FINAL — GlobalContext ip.py:945-970 on h (NHWC fp16):
+ *   logit[p] = h[p,:].wk + bk ; per-chunk (max, sum exp, sum exp*h[p,:]) -> part[b][chunk][C+2]
+ *   final: ctx = softmax-pooled mean; gate = sigmoid(W2 silu(W1 ctx + b1) + b2)   -> gate[b][C] */
+typedef struct ImagenGcaPartialParams {
+  const void* h; const float* wk; float* part;
+  int32_t B, HW, C, ld, chunks; float bk;
+} ImagenGcaPartialParams;
+typedef struct ImagenGcaFinalParams {
+  const float* part; const float* w1; const float* b1; const float* w2; const float* b2; float* gate;
+  int32_t B, C, hidden, chunks;
+} ImagenGcaFinalParams;
+
+/* GATE_RESIDUAL — ResnetBlock tail ip.py:755-757 with identity residual: out = h*gate[b,c] + res
+ * (gate NULL -> 1).  Optionally emits rs_out = 1/max(||out||,1e-12) per pixel for the next ChanRMSNorm. */
+typedef struct ImagenGateResidualParams {
+  const void* h; const float* gate; const void* res; void* out; float* rs_out;
+  int32_t rows, rows_per_batch, C, ld_h, ld_res, ld_out;
+} ImagenGateResidualParams;
+
+/* LN_RESIDUAL — to_out LayerNorm + residual ip.py:529-532,1017 / nn.LayerNorm ip.py:1252:
+ *   out = (y - mean)*rsqrt(var+eps)*g (+ beta) (+ res) */
+typedef struct ImagenLnResidualParams {
+  const void* y; const float* g; const float* beta; const void* res; void* out;
+  int32_t rows, C, ld_y, ld_res, ld_out; float eps;
+} ImagenLnResidualParams;
+
+/* TIME_EMBED — LearnedSinusoidalPosEmb + Linear + SiLU ip.py:654-669, 1213-1217:
+ *   hid[b,:] = silu(W [x, sin(2 pi x w), cos(2 pi x w)] + bias),  x = log-SNR condition of batch element b:
+ *   x = times[b], or (step_ptr != NULL) the current step's log-SNR  coef[*step_ptr * 8 + 6]  (graph replay). */
+typedef struct ImagenTimeEmbedParams {
+  const float* times; const float* coef; const int32_t* step_ptr;
+  const float* freqs; const float* w; const float* bias; void* hid;
+  int32_t B, half_dim, out_dim, ld_hid;
+} ImagenTimeEmbedParams;
+
+/* SCALE_SHIFT — ResnetBlock time_mlp tail ip.py:738-741 folded with block2's ChanRMSNorm gain, for every
+ * ResnetBlock of the network at once (their time-MLPs are batched into one GEMM):
+ *   pa[b,i] = gamma_s[i] * (ss[b, idx_scale[i]] + 1) ;  ps[b,i] = ss[b, idx_shift[i]]      i in [0, total_c)
+ * gamma_s = block2.norm.gamma * sqrt(C) laid out block after block. */
+typedef struct ImagenScaleShiftParams {
+  const void* ss; const float* gamma_s; const int32_t* idx_scale; const int32_t* idx_shift;
+  float* pa; float* ps;
+  int32_t B, total_c, ld_ss;
+} ImagenScaleShiftParams;
+
+/* PACK_IMAGE — x (+ lowres_cond_img) fp32 NCHW -> fp16 NHWC [B,H,W,Cpad] (ip.py:1550-1551 concat). */
+typedef struct ImagenPackImageParams {
+  const float* a; const float* b; void* out;
+  int32_t B, Brep, H, W, Ca, Cb, Cpad;
+} ImagenPackImageParams;
+
+/* CFG_X0 — ip.py:1522 + 314-318: eps = null + (cond-null)*s ; x0 = (x - sigma*eps)/max(alpha,1e-8);
+ * writes x0 and |x0| (for the quantile).  pred is [2B,...] (cond first) when cfg != 0, else [B,...]. */
+typedef struct ImagenCfgX0Params {
+  const float* x; const float* pred; const float* coef; const int32_t* step_ptr; float* x0; float* absx0;
+  int32_t B, n_per_sample, cfg; float cond_scale;
+} ImagenCfgX0Params;
+
+/* QUANTILE — torch.quantile(|x0| per sample, q) ip.py:2097-2101 (linear interpolation), exact. */
+typedef struct ImagenQuantileParams {
+  const float* absx0; float* out; uint32_t* scratch; /* scratch: B * IMAGEN_QUANTILE_SCRATCH_WORDS uint32, zeroed by the op */
+  int32_t B, n; float q;
+} ImagenQuantileParams;
+#define IMAGEN_QUANTILE_SCRATCH_WORDS (4 * 256 + 8)
+
+/* DDPM_UPDATE — ip.py:2103-2105, 252-270, 2160-2164 and final clamp/unnormalise ip.py:2281-2289.
+ * coef table row (per step): [alpha, sigma, alpha_next, sigma_next, c, nonzero, log_snr, pad]. */
+typedef struct ImagenDdpmUpdateParams {
+  float* x; const float* x0; const float* quant; const float* coef; const float* noise; float* final_out;
+  int32_t* step_ptr; /* device step counter: read by every sampler kernel of the step, incremented at the end */
+  int32_t B, n_per_sample, dynamic_threshold, total_steps;
+  uint32_t seed_lo, seed_hi, stream_id;
+} ImagenDdpmUpdateParams;
+
+/* ROWS_COPY — dst[b, r0 + r, :C] = src[b (or 0), r, :C]  (fp16). */
+typedef struct ImagenRowsCopyParams {
+  const void* src; void* dst;
+  int32_t B, rows, C, src_bs, src_rs, dst_bs, dst_rs;
+} ImagenRowsCopyParams;
+
+typedef struct ImagenMemset32Params { void* dst; uint32_t value; int32_t count; } ImagenMemset32Params;
+
+typedef struct ImagenOpRef { int32_t kind; int32_t reserved; const void* params; } ImagenOpRef;
+
+/* ---- entry points ------------------------------------------------------------------------------ */
+int imagen_abi_version(void);
+const char* imagen_last_error(void);
+size_t imagen_sizeof(int kind);                       /* sizeof the params struct of an op kind */
+int imagen_launch(int kind, const void* params, imagen_stream_t stream);
+int imagen_plan_run(const ImagenOpRef* ops, int n, imagen_stream_t stream);
+
+/* igemm tile selection + packing.  cfg ids are stable; *_tile_* describe a cfg. */
+int imagen_igemm_num_configs(void);
+int imagen_igemm_config_info(int cfg, int* tile_pixels, int* tile_cout, int* kgroups /* G: 8-channel groups per k-chunk */);
+/* Host-side pack: w_in fp32 [Cout][Cin][KH][KW] (Conv2d / Linear layout, HOST memory) -> packed fp16 (HOST memory)
+ * in MFMA fragment order.  G = 8-channel groups per k-chunk (1, 2 or 4; must match the tile cfg used at launch),
+ * Cout_pad = multiple of 128 (any tile cfg can then consume it).  in_scale (optional, [Cin]) is folded into W. */
+size_t imagen_igemm_packed_elems(int G, int Cin, int Cout_pad, int KH, int KW);
+int imagen_pack_igemm_weights(int G, const float* w_in, const float* in_scale, int Cin, int Cout, int Cout_pad, int KH, int KW,
+                              uint16_t* w_out /* fp16 bits */);
+
+/* hipGraph helpers (per-timestep capture). */
+int imagen_graph_begin(imagen_stream_t stream);
+int imagen_graph_end(imagen_stream_t stream, void** graph_exec_out);
+int imagen_graph_launch(void* graph_exec, imagen_stream_t stream);
+int imagen_graph_destroy(void* graph_exec);
+
+/* HIP-event timing on an explicit stream (bench.py roofline leg). */
+int imagen_event_create(void** ev);
+int imagen_event_record(void* ev, imagen_stream_t stream);
+int imagen_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);
+int imagen_event_destroy(void* ev);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* IMAGEN_HIP_H */
