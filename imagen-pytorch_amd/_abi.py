@@ -20,6 +20,7 @@ LIB_PATH = os.path.join(HERE, "libimagen_hip.so")
 _CTYPE = {
     "int32_t": ctypes.c_int32,
     "uint32_t": ctypes.c_uint32,
+    "uint8_t": ctypes.c_uint8,
     "float": ctypes.c_float,
 }
 
@@ -96,6 +97,10 @@ OP_STRUCT = {
     ENUMS["IMAGEN_OP_DDPM_UPDATE"]: STRUCTS["ImagenDdpmUpdateParams"],
     ENUMS["IMAGEN_OP_ROWS_COPY"]: STRUCTS["ImagenRowsCopyParams"],
     ENUMS["IMAGEN_OP_MEMSET32"]: STRUCTS["ImagenMemset32Params"],
+    ENUMS["IMAGEN_OP_SELECT_ROWS"]: STRUCTS["ImagenSelectRowsParams"],
+    ENUMS["IMAGEN_OP_MEAN_ROWS"]: STRUCTS["ImagenMeanRowsParams"],
+    ENUMS["IMAGEN_OP_RANDN"]: STRUCTS["ImagenRandnParams"],
+    ENUMS["IMAGEN_OP_LOWRES_PREP"]: STRUCTS["ImagenLowresPrepParams"],
 }
 STRUCT_KIND = {v: k for k, v in OP_STRUCT.items()}
 

@@ -37,6 +37,10 @@ extern "C" size_t imagen_sizeof(int kind) {
     case IMAGEN_OP_DDPM_UPDATE: return sizeof(ImagenDdpmUpdateParams);
     case IMAGEN_OP_ROWS_COPY: return sizeof(ImagenRowsCopyParams);
     case IMAGEN_OP_MEMSET32: return sizeof(ImagenMemset32Params);
+    case IMAGEN_OP_SELECT_ROWS: return sizeof(ImagenSelectRowsParams);
+    case IMAGEN_OP_MEAN_ROWS: return sizeof(ImagenMeanRowsParams);
+    case IMAGEN_OP_RANDN: return sizeof(ImagenRandnParams);
+    case IMAGEN_OP_LOWRES_PREP: return sizeof(ImagenLowresPrepParams);
     default: return 0;
   }
 }
@@ -62,6 +66,10 @@ extern "C" int imagen_launch(int kind, const void* params, imagen_stream_t strea
     case IMAGEN_OP_DDPM_UPDATE: return launch_ddpm_update(static_cast<const ImagenDdpmUpdateParams*>(params), s);
     case IMAGEN_OP_ROWS_COPY: return launch_rows_copy(static_cast<const ImagenRowsCopyParams*>(params), s);
     case IMAGEN_OP_MEMSET32: return launch_memset32(static_cast<const ImagenMemset32Params*>(params), s);
+    case IMAGEN_OP_SELECT_ROWS: return launch_select_rows(static_cast<const ImagenSelectRowsParams*>(params), s);
+    case IMAGEN_OP_MEAN_ROWS: return launch_mean_rows(static_cast<const ImagenMeanRowsParams*>(params), s);
+    case IMAGEN_OP_RANDN: return launch_randn(static_cast<const ImagenRandnParams*>(params), s);
+    case IMAGEN_OP_LOWRES_PREP: return launch_lowres_prep(static_cast<const ImagenLowresPrepParams*>(params), s);
     default: imagen_set_error("imagen_launch: unknown op kind %d", kind); return -1;
   }
 }

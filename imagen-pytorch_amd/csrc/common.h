@@ -54,3 +54,7 @@ int launch_quantile(const ImagenQuantileParams* p, hipStream_t s);
 int launch_ddpm_update(const ImagenDdpmUpdateParams* p, hipStream_t s);
 int launch_rows_copy(const ImagenRowsCopyParams* p, hipStream_t s);
 int launch_memset32(const ImagenMemset32Params* p, hipStream_t s);
+int launch_select_rows(const ImagenSelectRowsParams* p, hipStream_t s);
+int launch_mean_rows(const ImagenMeanRowsParams* p, hipStream_t s);
+int launch_randn(const ImagenRandnParams* p, hipStream_t s);
+int launch_lowres_prep(const ImagenLowresPrepParams* p, hipStream_t s);

@@ -119,9 +119,10 @@ __global__ __launch_bounds__(256) void ln_residual_kernel(const ImagenLnResidual
   const int sub = threadIdx.x / lpr, li = threadIdx.x % lpr;
   const int r = blockIdx.x * rows_per_block + sub;
   if (r >= p.rows) return;
-  const f16* y = reinterpret_cast<const f16*>(p.y) + (size_t)r * p.ld_y;
-  const f16* res = p.res ? reinterpret_cast<const f16*>(p.res) + (size_t)r * p.ld_res : nullptr;
-  f16* out = reinterpret_cast<f16*>(p.out) + (size_t)r * p.ld_out;
+  const int bb = r / p.rows_per_batch, rr = r - bb * p.rows_per_batch;
+  const f16* y = reinterpret_cast<const f16*>(p.y) + (size_t)bb * p.bs_y + (size_t)rr * p.ld_y;
+  const f16* res = p.res ? reinterpret_cast<const f16*>(p.res) + (size_t)bb * p.bs_res + (size_t)rr * p.ld_res : nullptr;
+  f16* out = reinterpret_cast<f16*>(p.out) + (size_t)bb * p.bs_out + (size_t)rr * p.ld_out;
   const int groups = p.C >> 3;
   float s = 0.f;
   for (int g = li; g < groups; g += lpr) {
@@ -362,6 +363,39 @@ __global__ __launch_bounds__(256) void rows_copy_kernel(const ImagenRowsCopyPara
   *reinterpret_cast<uint4*>(d) = *reinterpret_cast<const uint4*>(s);
 }
 
+__global__ __launch_bounds__(256) void select_rows_kernel(const ImagenSelectRowsParams p) {
+  const int groups = p.C >> 3;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.R * p.L * groups) return;
+  const int g = i % groups;
+  const int l = (i / groups) % p.L;
+  const int r = i / (groups * p.L);
+  const int sb = p.src[r];
+  const bool take = p.keep[r] && (p.mask == nullptr || p.mask[(size_t)sb * p.L + l]);
+  const f16* s = take ? reinterpret_cast<const f16*>(p.a) + ((size_t)sb * p.L + l) * p.C + g * 8
+                      : reinterpret_cast<const f16*>(p.nul) + (size_t)l * p.C + g * 8;
+  *reinterpret_cast<uint4*>(reinterpret_cast<f16*>(p.dst) + ((size_t)r * p.L + l) * p.C + g * 8) = *reinterpret_cast<const uint4*>(s);
+}
+
+__global__ __launch_bounds__(256) void mean_rows_kernel(const ImagenMeanRowsParams p) {
+  const int groups = p.C >> 3;
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= p.B * groups) return;
+  const int b = i / groups, g = i - b * groups;
+  const f16* x = reinterpret_cast<const f16*>(p.x) + (size_t)b * p.bs_x + g * 8;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int r = 0; r < p.rows; ++r) {
+    const f16x8 v = *reinterpret_cast<const f16x8*>(x + (size_t)r * p.ld_x);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] += (float)v[j];
+  }
+  f16x8 o;
+  const float inv = 1.0f / (float)p.rows;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) o[j] = (f16)(acc[j] * inv);
+  *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(p.out) + (size_t)b * p.ld_out + g * 8) = o;
+}
+
 __global__ __launch_bounds__(256) void memset32_kernel(uint32_t* dst, uint32_t value, int count) {
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i < count) dst[i] = value;
@@ -449,6 +483,20 @@ int launch_rows_copy(const ImagenRowsCopyParams* p, hipStream_t s) {
   const int n = p->B * p->rows * (p->C / 8);
   hipLaunchKernelGGL(rows_copy_kernel, dim3((n + 255) / 256), dim3(256), 0, s, *p);
   return imagen_hip_status("rows_copy");
+}
+
+int launch_select_rows(const ImagenSelectRowsParams* p, hipStream_t s) {
+  IMAGEN_CHECK(p->C % 8 == 0, "select_rows: C %% 8");
+  const int n = p->R * p->L * (p->C / 8);
+  hipLaunchKernelGGL(select_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, s, *p);
+  return imagen_hip_status("select_rows");
+}
+
+int launch_mean_rows(const ImagenMeanRowsParams* p, hipStream_t s) {
+  IMAGEN_CHECK(p->C % 8 == 0 && p->rows > 0, "mean_rows: bad shape");
+  const int n = p->B * (p->C / 8);
+  hipLaunchKernelGGL(mean_rows_kernel, dim3((n + 255) / 256), dim3(256), 0, s, *p);
+  return imagen_hip_status("mean_rows");
 }
 
 int launch_memset32(const ImagenMemset32Params* p, hipStream_t s) {

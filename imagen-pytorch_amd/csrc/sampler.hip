@@ -23,7 +23,10 @@ __global__ __launch_bounds__(256) void cfg_x0_kernel(const ImagenCfgX0Params p) 
   } else {
     eps = p.pred[i];
   }
-  const float x0 = (p.x[i] - sigma * eps) / fmaxf(alpha, 1e-8f);  // ip.py:314-318
+  float x0;
+  if (p.objective == 0) x0 = (p.x[i] - sigma * eps) / fmaxf(alpha, 1e-8f);  // noise, ip.py:314-318
+  else if (p.objective == 1) x0 = eps;                                      // x_start, ip.py:2087-2088
+  else x0 = alpha * p.x[i] - sigma * eps;                                   // v, ip.py:308-312
   p.x0[i] = x0;
   p.absx0[i] = fabsf(x0);
 }
@@ -140,8 +143,9 @@ __device__ __forceinline__ void philox_round(uint32_t& c0, uint32_t& c1, uint32_
   c0 = n0; c1 = n1; c2 = n2; c3 = n3;
 }
 
-__device__ __forceinline__ void philox_normal4(uint32_t ctr0, uint32_t ctr1, uint32_t ctr2, uint32_t seed_lo, uint32_t seed_hi, float out[4]) {
-  uint32_t c0 = ctr0, c1 = ctr1, c2 = ctr2, c3 = 0u, k0 = seed_lo, k1 = seed_hi;
+__device__ __forceinline__ void philox_normal4(uint32_t ctr0, uint32_t ctr1, uint32_t ctr2, uint32_t ctr3, uint32_t seed_lo, uint32_t seed_hi,
+                                               float out[4]) {
+  uint32_t c0 = ctr0, c1 = ctr1, c2 = ctr2, c3 = ctr3, k0 = seed_lo, k1 = seed_hi;
 #pragma unroll
   for (int r = 0; r < 10; ++r) {
     philox_round(c0, c1, c2, c3, k0, k1);
@@ -159,6 +163,7 @@ __device__ __forceinline__ void philox_normal4(uint32_t ctr0, uint32_t ctr1, uin
 }
 
 __global__ __launch_bounds__(256) void ddpm_update_kernel(const ImagenDdpmUpdateParams p) {
+  // n_per_sample % 4 == 0 (checked at launch): a 4-element group never straddles two samples
   const size_t n = (size_t)p.B * p.n_per_sample;
   const size_t i4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
   if (i4 >= n) return;
@@ -172,7 +177,10 @@ __global__ __launch_bounds__(256) void ddpm_update_kernel(const ImagenDdpmUpdate
 #pragma unroll
     for (int e = 0; e < 4; ++e) z[e] = (i4 + e < n) ? p.noise[i4 + e] : 0.f;
   } else {
-    philox_normal4((uint32_t)(i4 >> 2), (uint32_t)step, p.stream_id, p.seed_lo, p.seed_hi, z);
+    const int bs = (int)(i4 / p.n_per_sample);
+    const uint32_t within = (uint32_t)((i4 - (size_t)bs * p.n_per_sample) >> 2);
+    const uint32_t k0 = p.seed_ptr ? p.seed_ptr[0] : p.seed_lo, k1 = p.seed_ptr ? p.seed_ptr[1] : p.seed_hi;
+    philox_normal4(within, (uint32_t)step, p.stream_id, (uint32_t)(p.sample_offset + bs), k0, k1, z);
   }
   const bool last = step + 1 >= p.total_steps;
 #pragma unroll
@@ -197,6 +205,32 @@ __global__ __launch_bounds__(256) void ddpm_update_kernel(const ImagenDdpmUpdate
 
 __global__ void step_advance_kernel(int32_t* step_ptr) { *step_ptr += 1; }
 
+__global__ __launch_bounds__(256) void randn_kernel(const ImagenRandnParams p) {
+  const size_t n = (size_t)p.B * p.n_per_sample;
+  const size_t i4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  const int bs = (int)(i4 / p.n_per_sample);
+  const uint32_t within = (uint32_t)((i4 - (size_t)bs * p.n_per_sample) >> 2);
+  float z[4];
+  philox_normal4(within, p.tag, p.stream_id, (uint32_t)(p.sample_offset + bs), p.seed_lo, p.seed_hi, z);
+#pragma unroll
+  for (int e = 0; e < 4; ++e) p.out[i4 + e] = z[e];
+}
+
+__global__ __launch_bounds__(256) void lowres_prep_kernel(const ImagenLowresPrepParams p) {
+  const size_t n = (size_t)p.B * p.C * p.Hout * p.Wout;
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const int xo = (int)(i % p.Wout);
+  const int yo = (int)((i / p.Wout) % p.Hout);
+  const size_t bc = i / ((size_t)p.Wout * p.Hout);
+  // F.interpolate(mode='nearest'): src = floor(dst * in/out)
+  const int ys = min((int)floorf((float)yo * ((float)p.Hin / (float)p.Hout)), p.Hin - 1);
+  const int xs = min((int)floorf((float)xo * ((float)p.Win / (float)p.Wout)), p.Win - 1);
+  const float v = p.img[(bc * p.Hin + ys) * p.Win + xs] * 2.0f - 1.0f;
+  p.out[i] = p.alpha * v + p.sigma * p.noise[i];
+}
+
 }  // namespace
 
 int launch_cfg_x0(const ImagenCfgX0Params* p, hipStream_t s) {
@@ -220,8 +254,22 @@ int launch_quantile(const ImagenQuantileParams* p, hipStream_t s) {
   return imagen_hip_status("quantile");
 }
 
+int launch_randn(const ImagenRandnParams* p, hipStream_t s) {
+  IMAGEN_CHECK(p->n_per_sample % 4 == 0, "randn: n_per_sample must be a multiple of 4");
+  const size_t n4 = ((size_t)p->B * p->n_per_sample) / 4;
+  hipLaunchKernelGGL(randn_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, *p);
+  return imagen_hip_status("randn");
+}
+
+int launch_lowres_prep(const ImagenLowresPrepParams* p, hipStream_t s) {
+  const size_t n = (size_t)p->B * p->C * p->Hout * p->Wout;
+  hipLaunchKernelGGL(lowres_prep_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, s, *p);
+  return imagen_hip_status("lowres_prep");
+}
+
 int launch_ddpm_update(const ImagenDdpmUpdateParams* p, hipStream_t s) {
   IMAGEN_CHECK(p->step_ptr && p->coef, "ddpm_update: coef table / step counter required");
+  IMAGEN_CHECK(p->n_per_sample % 4 == 0, "ddpm_update: n_per_sample must be a multiple of 4");
   IMAGEN_CHECK(!p->dynamic_threshold || p->quant, "ddpm_update: dynamic thresholding needs the quantile");
   const size_t n4 = ((size_t)p->B * p->n_per_sample + 3) / 4;
   hipLaunchKernelGGL(ddpm_update_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, *p);

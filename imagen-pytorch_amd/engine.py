@@ -1,0 +1,746 @@
+"""UnetEngine — the host-side planner that turns a drop-in `Unet` (parameters only) into a static list of
+HIP kernel launches for a fixed (rows, image_size): the MI355X replacement of `Unet.forward`
+(ip.py:1524-1725).  Three plans are built:
+
+  * static plan   — everything that does not change over the T timesteps of a sample() call: text projection,
+                    null-embedding select, PerceiverResampler, text hiddens, low-res noise-level embedding,
+                    norm_cond of the static tokens and their K/V rows for every attention block
+                    (results-preserving because norm_cond / to_kv are per-token);
+  * step plan     — one denoiser evaluation: time embedding -> batched time-MLPs -> U-net traversal;
+  * (sampler ops are appended by imagen.py to form the per-timestep graph).
+
+Row convention: `rows` = B (plain forward) or 2B (classifier-free guidance: rows [0,B) conditional,
+rows [B,2B) with the null text conditioning — ip.py:1510-1522 evaluated as ONE batch).  Row r reads image
+`r % src_batch`.
+
+Nothing here computes with torch: torch only owns device buffers.  `dry=True` builds the plan on CPU memory
+without ever launching (host-logic tests).
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from .modules import AttentionP, CrossAttentionP, CrossEmbedP, ParallelP, PixelShuffleUpsampleP, ResnetBlockP, TransformerBlockP
+from .ops import ACT_GELU, ACT_NONE, ACT_SILU, LOG2E, OUT_NCHW_F32, OUT_PIXEL_SHUFFLE, Act, Plan
+
+SIM_SCALE = 8.0  # cosine-sim attention scale (ip.py:510, 768, 386)
+
+
+def _f32(t, dev):
+    return t.detach().float().contiguous().to(dev)
+
+
+def _f16(t, dev):
+    return t.detach().to(torch.float16).contiguous().to(dev)
+
+
+def _pad_vec(v: torch.Tensor, n: int) -> torch.Tensor:
+    out = torch.zeros(n, dtype=torch.float32)
+    out[: v.numel()] = v.detach().float().flatten().cpu()
+    return out
+
+
+class Weights:
+    """Device-resident packed parameters of one Unet (shared by all engines of that unet on a device)."""
+
+    def __init__(self, unet, device):
+        self.dev = device
+        self.cache: Dict[str, object] = {}
+        self.unet = unet
+
+    def get(self, key, make):
+        if key not in self.cache:
+            self.cache[key] = make()
+        return self.cache[key]
+
+    def conv(self, key, mod: nn.Module, in_scale=None, G=None, cin_pad_to=None, out_perm=None):
+        def make():
+            w, b = mod.weight.detach().float(), (mod.bias.detach().float() if mod.bias is not None else None)
+            if w.ndim == 2:
+                w = w[:, :, None, None]
+            if out_perm is not None:
+                w, b = w[out_perm], (b[out_perm] if b is not None else None)
+            if cin_pad_to is not None and cin_pad_to > w.shape[1]:
+                wp = torch.zeros(w.shape[0], cin_pad_to, *w.shape[2:])
+                wp[:, : w.shape[1]] = w
+                w = wp
+            sc = None
+            if in_scale is not None:
+                sc = torch.ones(w.shape[1])
+                sc[: in_scale.numel()] = in_scale
+            return ops.pack_weight(w, b, self.dev, in_scale=sc, G=G)
+        return self.get(key, make)
+
+    def raw(self, key, w, b, G=None):
+        return self.get(key, lambda: ops.pack_weight(w, b, self.dev, G=G))
+
+    def f32(self, key, t_fn):
+        return self.get(key, lambda: _f32(t_fn(), self.dev))
+
+    def f16(self, key, t_fn):
+        return self.get(key, lambda: _f16(t_fn(), self.dev))
+
+
+def _fingerprint(unet) -> tuple:
+    return tuple(p._version for p in unet.parameters()) + tuple(p.data_ptr() for p in unet.parameters())
+
+
+class UnetEngine:
+    def __init__(self, unet, rows: int, src_batch: int, size: int, device, with_text: bool = True, dry: bool = False):
+        assert rows % src_batch == 0
+        self.unet, self.R, self.S, self.dev, self.dry = unet, rows, size, torch.device(device), dry
+        self.src_batch = src_batch
+        self.fp = _fingerprint(unet)
+        wkey = (str(self.dev),)
+        cache = getattr(unet, "_weight_cache", None)
+        if cache is None or cache[0] != self.fp or cache[1] != wkey:
+            cache = (self.fp, wkey, Weights(unet, self.dev))
+            unet._weight_cache = cache
+        self.W: Weights = cache[2]
+        self.lc = unet._layer_cfg
+        self.cond_dim, self.Tc = unet.cond_dim, unet.time_cond_dim
+        self.ntt = unet.num_time_tokens
+        self.lowres = unet.lowres_cond
+        self.has_text = bool(unet.cond_on_text and with_text)
+        self.NTX = 0
+        if self.has_text:
+            self.NTX = (unet.attn_pool.latents.shape[0] + unet.attn_pool.num_latents_mean_pooled) if unet.attn_pool is not None else unet.max_text_len
+        self.NS = (self.ntt if self.lowres else 0) + self.NTX          # static conditioning tokens
+        self.NT = self.ntt + self.NS                                    # all conditioning tokens
+        self.attn_sites: List[dict] = []   # attention K/V buffers + how to fill their conditioning rows
+        self.taps: Dict[str, Act] = {}     # named intermediates (persistent buffers) for per-stage parity checks
+        self._static_plans: Dict[int, tuple] = {}   # n_tok -> (plan, te16, mask_u8)
+        self._cond_ready = False
+        self._alloc_io()
+        self.step_plan = self._build_step_plan()
+
+    # ------------------------------------------------------------------------------------------ helpers
+    def stale(self) -> bool:
+        return _fingerprint(self.unet) != self.fp
+
+    def new(self, B, H, W, C, zero=False) -> Act:
+        return ops.new_act(B, H, W, C, self.dev, zero=zero)
+
+    def f32buf(self, *shape, zero=False):
+        return (torch.zeros if zero else torch.empty)(*shape, dtype=torch.float32, device=self.dev)
+
+    def _alloc_io(self):
+        R, S, u = self.R, self.S, self.unet
+        self.x_in = self.f32buf(self.src_batch, u.channels, S, S, zero=True)      # fp32 NCHW staging (or the sampler's state)
+        self.lowres_in = self.f32buf(self.src_batch, u.channels, S, S, zero=True) if self.lowres else None
+        self.times = self.f32buf(R, zero=True)          # log-SNR per row (plain forward mode)
+        self.lowres_times = self.f32buf(R, zero=True)
+        self.out = self.f32buf(R, u.channels_out, S, S)
+        self.coef = None
+        self.step_ptr = None
+        # per-row conditioning produced by the static plan, consumed by the step plan
+        self.t_const = self.new(1, 1, R, self.Tc, zero=True)               # text hiddens (+ lowres t)
+        self.keep_u8 = torch.ones(R, dtype=torch.uint8, device=self.dev)
+        self.src_idx = torch.zeros(R, dtype=torch.int32, device=self.dev)
+        self.arange_idx = torch.arange(R, dtype=torch.int32, device=self.dev)
+
+    # ------------------------------------------------------------------------------------------ weights
+    def _time_mlp_tables(self, blocks: List[ResnetBlockP]):
+        """Concatenate every ResnetBlock's time_mlp Linear (ip.py:711-714) into one GEMM; build the gather
+        tables turning its output into block2's per-(row, channel) affine (ImagenScaleShiftParams)."""
+        ws, bs, gam, idx_scale, idx_shift, offs = [], [], [], [], [], []
+        col, coff = 0, 0
+        for rb in blocks:
+            lin = rb.time_mlp[1]
+            C = rb.dim_out
+            ws.append(lin.weight.detach().float().cpu())
+            bs.append(lin.bias.detach().float().cpu())
+            gam.append(rb.block2.norm.gamma.detach().float().flatten().cpu() * math.sqrt(C))
+            idx_scale.append(torch.arange(col, col + C))
+            idx_shift.append(torch.arange(col + C, col + 2 * C))
+            offs.append(coff)
+            col += 2 * C
+            coff += C
+        return torch.cat(ws), torch.cat(bs), torch.cat(gam), torch.cat(idx_scale).int(), torch.cat(idx_shift).int(), offs, coff
+
+    # ------------------------------------------------------------------------------------------ step plan
+    def _all_resnet_blocks(self) -> List[ResnetBlockP]:
+        u = self.unet
+        out = []
+        if u.init_resnet_block is not None:
+            out.append(u.init_resnet_block)
+        for lvl in u.downs:
+            out.append(lvl[1])
+            out.extend(lvl[2])
+        out += [u.mid_block1, u.mid_block2]
+        for lvl in u.ups:
+            out.append(lvl[0])
+            out.extend(lvl[1])
+        if u.final_res_block is not None:
+            out.append(u.final_res_block)
+        return out
+
+    def _build_step_plan(self) -> Plan:
+        u, R, S, W = self.unet, self.R, self.S, self.W
+        plan = Plan("unet-step")
+        self._plan = plan
+        # ---- input image (+ low-res conditioning image) -> fp16 NHWC, 8 channels
+        cin = u.channels * (2 if self.lowres else 1)
+        assert cin <= 8, "init conv packs the input image into 8 channels"
+        self.img = self.new(R, S, S, 8)
+        self._pack_op = ops.pack_image(plan, self.x_in, self.lowres_in, self.img, brep=R // self.src_batch, label="pack_image")
+
+        # ---- time conditioning (ip.py:1573-1578)
+        self.hid = self.new(1, 1, R, self.Tc)
+        self._time_embed_op = ops.time_embed(
+            plan, times=self.times, coef=None, step_ptr=None,
+            freqs=W.f32("time.freqs", lambda: u.to_time_hiddens[0].weights), w=W.f32("time.w", lambda: u.to_time_hiddens[1].weight),
+            bias=W.f32("time.b", lambda: u.to_time_hiddens[1].bias), hid=self.hid, label="time_embed")
+        self.t = self.new(1, 1, R, self.Tc)
+        ops.igemm(plan, self.hid, W.conv("time.cond", u.to_time_cond[0]), self.t, res=self.t_const, label="to_time_cond")
+        # time tokens -> norm_cond (ip.py:1577, 1660)
+        tok_raw = self.new(1, 1, R, self.ntt * self.cond_dim)
+        ops.igemm(plan, self.hid, W.conv("time.tokens", u.to_time_tokens[0]), tok_raw, label="to_time_tokens")
+        self.c_time = self.new(1, 1, R * self.ntt, self.cond_dim)
+        tok_rows = Act(tok_raw.t, 1, 1, R * self.ntt, self.cond_dim, self.cond_dim, R * self.ntt * self.cond_dim)
+        ops.ln_residual(plan, tok_rows, W.f32("norm_cond.w", lambda: u.norm_cond.weight), self.c_time,
+                        beta=W.f32("norm_cond.b", lambda: u.norm_cond.bias), eps=1e-5, label="norm_cond(time)")
+
+        # ---- all ResnetBlock time-MLPs in one GEMM + scale/shift tables (ip.py:738-741)
+        blocks = self._all_resnet_blocks()
+        self._blk_index = {id(rb): i for i, rb in enumerate(blocks)}
+        tw, tb, gam, isc, ish, self._blk_off, total_c = W.get("timemlp.tables", lambda: self._time_mlp_tables(blocks))
+        self.total_c = total_c
+        ss = self.new(1, 1, R, tw.shape[0])
+        ops.igemm(plan, self.t, W.raw("timemlp.w", tw, tb), ss, act_in=ACT_SILU, label="time_mlps")
+        self.pa2 = self.f32buf(R, total_c)
+        self.ps2 = self.f32buf(R, total_c)
+        ops.scale_shift(plan, ss, W.f32("timemlp.gam", lambda: gam), W.get("timemlp.isc", lambda: isc.to(self.dev)),
+                        W.get("timemlp.ish", lambda: ish.to(self.dev)), self.pa2, self.ps2)
+
+        # ---- conditioning K/V rows that depend on the timestep (filled after the traversal registers the sites)
+        self._kv_dynamic_anchor = len(plan.ops)
+
+        # ---- U-net traversal
+        x = self.new(R, S, S, self.lc["init_dim"])
+        self._init_conv(plan, x)
+        self.taps['init_conv'] = x
+        if u.init_resnet_block is not None:
+            x = self._resnet(plan, x, None, u.init_resnet_block, "init_resnet", with_cond=False)
+        hiddens: List[Act] = []
+        n_levels = len(self.lc["in_out"])
+        mem_eff = self.lc["memory_efficient"]
+        for i, lvl in enumerate(u.downs):
+            pre, init_block, res_blocks, attn_block, post = lvl
+            if pre is not None:
+                x = self._downsample(plan, x, pre, f"downs.{i}.0")
+            x = self._resnet(plan, x, None, init_block, f"downs.{i}.1", with_cond=True)
+            for j, rb in enumerate(res_blocks):
+                x = self._resnet(plan, x, None, rb, f"downs.{i}.2.{j}", with_cond=False)
+                hiddens.append(x)
+            if isinstance(attn_block, TransformerBlockP):
+                x = self._transformer(plan, x, attn_block, f"downs.{i}.3", with_context=True)
+            hiddens.append(x)
+            self.taps[f'down{i}'] = x
+            if post is not None:
+                x = self._downsample(plan, x, post, f"downs.{i}.4")
+        x = self._resnet(plan, x, None, u.mid_block1, "mid_block1", with_cond=True)
+        if u.mid_attn is not None:
+            x = self._transformer(plan, x, u.mid_attn, "mid_attn", with_context=False)
+        x = self._resnet(plan, x, None, u.mid_block2, "mid_block2", with_cond=True)
+        self.taps['mid'] = x
+        for i, lvl in enumerate(u.ups):
+            init_block, res_blocks, attn_block, upsample = lvl
+            x = self._resnet(plan, x, hiddens.pop(), init_block, f"ups.{i}.0", with_cond=True)
+            for j, rb in enumerate(res_blocks):
+                x = self._resnet(plan, x, hiddens.pop(), rb, f"ups.{i}.1.{j}", with_cond=False)
+            if isinstance(attn_block, TransformerBlockP):
+                x = self._transformer(plan, x, attn_block, f"ups.{i}.2", with_context=True)
+            if isinstance(upsample, PixelShuffleUpsampleP):
+                x = self._upsample(plan, x, upsample, f"ups.{i}.3")
+            self.taps[f'up{i}'] = x
+        assert not hiddens
+        if u.final_res_block is not None:
+            x = self._resnet(plan, x, None, u.final_res_block, "final_res_block", with_cond=False)
+        self.taps['final_res'] = x
+        self._final_conv(plan, x)
+
+        # ---- now that every attention site is known: the per-step conditioning K/V ops, spliced in before the traversal
+        dyn = Plan("kv-dynamic")
+        self._emit_context_kv(dyn, self.c_time, rows_per_batch=self.ntt, k_row0_self=0, k_row0_cross=1, tag="dyn")
+        plan.ops[self._kv_dynamic_anchor:self._kv_dynamic_anchor] = dyn.ops
+        plan.keep.extend(dyn.keep)
+        plan._arr = None
+        return plan
+
+    # ---- init / final convs
+    def _init_conv(self, plan, out: Act):
+        """CrossEmbedLayer (ip.py:1051-1076, stride 1) as ONE kmax x kmax conv with the smaller kernels zero-embedded;
+        or the plain init conv (ip.py:1198)."""
+        u = self.unet
+
+        def make():
+            if isinstance(u.init_conv, CrossEmbedP):
+                kmax = max(u.init_conv.kernel_sizes)
+                ws, bs = [], []
+                for conv, k in zip(u.init_conv.convs, u.init_conv.kernel_sizes):
+                    w = torch.zeros(conv.weight.shape[0], 8, kmax, kmax)
+                    p = (kmax - k) // 2
+                    w[:, : conv.weight.shape[1], p:p + k, p:p + k] = conv.weight.detach().float()
+                    ws.append(w)
+                    bs.append(conv.bias.detach().float())
+                return ops.pack_weight(torch.cat(ws), torch.cat(bs), self.dev, G=1)
+            conv = u.init_conv
+            w = torch.zeros(conv.weight.shape[0], 8, *conv.weight.shape[2:])
+            w[:, : conv.weight.shape[1]] = conv.weight.detach().float()
+            return ops.pack_weight(w, conv.bias.detach().float(), self.dev, G=1)
+
+        ops.igemm(plan, self.img, self.W.get("init_conv", make), out, label="init_conv")
+
+    def _final_conv(self, plan, x: Act):
+        """final_conv over cat(x, lowres_cond_img) (ip.py:1722-1725) -> fp32 NCHW."""
+        u = self.unet
+        extra = self.img if self.lowres else None  # channels [C, 2C) of the packed image are the low-res image
+
+        def make():
+            w = u.final_conv.weight.detach().float()
+            co, ci, kh, kw = w.shape
+            if extra is None:
+                return ops.pack_weight(w, u.final_conv.bias.detach().float(), self.dev)
+            wp = torch.zeros(co, x.C + 8, kh, kw)
+            wp[:, : x.C] = w[:, : x.C]
+            # packed image channel layout: [x (C) | lowres (C) | zero pad]; the reference concatenates lowres after the features
+            wp[:, x.C + u.channels: x.C + 2 * u.channels] = w[:, x.C:]
+            return ops.pack_weight(wp, u.final_conv.bias.detach().float(), self.dev)
+
+        ops.igemm(plan, x, self.W.get("final_conv", make), self.out, x2=extra, out_mode=OUT_NCHW_F32, label="final_conv")
+
+    # ---- ResnetBlock (ip.py:693-757)
+    def _resnet(self, plan, x: Act, skip: Optional[Act], rb: ResnetBlockP, name: str, with_cond: bool) -> Act:
+        W, R = self.W, self.R
+        C1, C2 = x.C, (skip.C if skip is not None else 0)
+        Cin, Cout = C1 + C2, rb.dim_out
+        assert Cin == rb.dim, f"{name}: {Cin} input channels, block expects {rb.dim}"
+        s = self.unet.skip_connect_scale
+        H, Wd = x.H, x.W
+        in_scale = None
+        if skip is not None:
+            in_scale = torch.ones(Cin)
+            in_scale[C1:] = s
+        # block1: ChanRMSNorm over the (scaled) concat -> SiLU -> conv3x3
+        rs1 = self.f32buf(R * H * Wd)
+        ops.rowstat(plan, x, mode=0, rs=rs1, x2=skip, w2=s * s, label=name + ".block1.stat")
+        w1 = W.conv(name + ".block1", rb.block1.project)
+        pa1 = W.f32(name + ".block1.pa", lambda: _pad_vec(rb.block1.norm.gamma.detach().float().flatten().cpu() * math.sqrt(Cin)
+                                                         * (in_scale if in_scale is not None else 1.0), w1.Cin_pad))
+        h1 = self.new(R, H, Wd, Cout)
+        ops.igemm(plan, x, w1, h1, x2=skip, rs=rs1, pa=pa1, pstride=0, act_in=ACT_SILU, label=name + ".block1")
+        if rb.cross_attn is not None:
+            assert with_cond
+            h1 = self._cross_attn(plan, h1, rb.cross_attn, name + ".cross_attn")
+        # block2: ChanRMSNorm -> (scale+1, shift) from the time MLP -> SiLU -> conv3x3
+        rs2 = self.f32buf(R * H * Wd)
+        ops.rowstat(plan, h1, mode=0, rs=rs2, label=name + ".block2.stat")
+        off = self._blk_off[self._blk_index[id(rb)]]
+        pa2 = self.pa2[:, off:]
+        ps2 = self.ps2[:, off:]
+        h2 = self.new(R, H, Wd, Cout)
+        ops.igemm(plan, h1, W.conv(name + ".block2", rb.block2.project), h2, rs=rs2, pa=pa2, ps=ps2, pstride=self.total_c,
+                  act_in=ACT_SILU, label=name + ".block2")
+        gate = None
+        if rb.gca is not None:
+            g = rb.gca
+            chunks = ops.gca_chunks(H * Wd)
+            part = self.f32buf(R, chunks, Cout + 2)
+            gate = self.f32buf(R, Cout)
+            hidden = g.net[0].weight.shape[0]
+            ops.gca(plan, h2, W.f32(name + ".gca.wk", lambda: g.to_k.weight.reshape(-1)), float(g.to_k.bias.detach().float().item()),
+                    W.f32(name + ".gca.w1", lambda: g.net[0].weight.reshape(hidden, Cout)), W.f32(name + ".gca.b1", lambda: g.net[0].bias),
+                    W.f32(name + ".gca.w2", lambda: g.net[2].weight.reshape(Cout, hidden)), W.f32(name + ".gca.b2", lambda: g.net[2].bias),
+                    part, gate, chunks, label=name + ".gca")
+        out = self.new(R, H, Wd, Cout)
+        if rb.res_conv is not None:
+            wr = W.conv(name + ".res_conv", rb.res_conv, in_scale=in_scale)
+            if gate is not None:
+                ops.igemm(plan, x, wr, out, x2=skip, addend=h2, gate=gate, label=name + ".res_conv")
+            else:
+                ops.igemm(plan, x, wr, out, x2=skip, res=h2, label=name + ".res_conv")
+        else:
+            assert skip is None
+            ops.gate_residual(plan, h2, gate, x, out, label=name + ".tail")
+        return out
+
+    # ---- CrossAttention inside a ResnetBlock (ip.py:745-751, 759-834)
+    def _cross_attn(self, plan, h: Act, ca: CrossAttentionP, name: str) -> Act:
+        W, R = self.W, self.R
+        N, C = h.H * h.W, h.C
+        heads, dh = ca.heads, ca.dim_head
+        inner = heads * dh
+        tok = h.tokens()
+        mu, rs = self.f32buf(R * N), self.f32buf(R * N)
+        ops.rowstat(plan, tok, mode=1, rs=rs, mu=mu, eps=1e-5, label=name + ".norm")
+        q = self.new(R, 1, N, inner)
+        wq = W.conv(name + ".to_q", ca.to_q)
+        ops.igemm(plan, tok, wq, q, mu=mu, rs=rs, pa=W.f32(name + ".norm.g", lambda: _pad_vec(ca.norm.g, wq.Cin_pad)), label=name + ".to_q")
+        ops.qnorm(plan, q.t, W.f32(name + ".q_scale", lambda: ca.q_scale), rows=R * N, heads=heads, ld=inner, mult=SIM_SCALE * LOG2E,
+                  label=name + ".qnorm")
+        J = self.NT + 1
+        Jp = ops._round_up(J, 32)
+        khat = torch.zeros(R, heads, Jp, dh, dtype=torch.float16, device=self.dev)
+        vt = torch.zeros(R, heads, dh, Jp, dtype=torch.float16, device=self.dev)
+        site = dict(kind="cross", name=name, mod=ca, khat=khat, vt=vt, heads=heads, Jp=Jp,
+                    k_strides=(heads * Jp * dh, Jp * dh, dh), vt_strides=(heads * dh * Jp, dh * Jp, Jp))
+        self.attn_sites.append(site)
+        o = self.new(R, 1, N, inner)
+        ops.attention(plan, q.t, khat, vt, o.t, B=R, heads=heads, rows=N, J=J, q_strides=(N * inner, dh, inner),
+                      k_strides=site["k_strides"], vt_strides=site["vt_strides"], o_strides=(N * inner, dh, inner), label=name + ".attn")
+        y = self.new(R, 1, N, C)
+        ops.igemm(plan, o, W.conv(name + ".to_out", ca.to_out[0]), y, label=name + ".to_out")
+        out = self.new(R, h.H, h.W, C)
+        ops.ln_residual(plan, y, W.f32(name + ".out_g", lambda: ca.to_out[1].g), out.tokens(), res=tok, eps=1e-5, label=name + ".out_norm")
+        return out
+
+    # ---- TransformerBlock (ip.py:992-1022): depth x [multi-query self attention + FeedForward]
+    def _transformer(self, plan, x: Act, tb: TransformerBlockP, name: str, with_context: bool) -> Act:
+        W, R = self.W, self.R
+        N, C = x.H * x.W, x.C
+        cur = x
+        for d, (attn, ff) in enumerate(tb.layers):
+            nm = f"{name}.layers.{d}"
+            heads, dh = attn.heads, attn.dim_head
+            inner = heads * dh
+            tok = cur.tokens()
+            mu, rs = self.f32buf(R * N), self.f32buf(R * N)
+            ops.rowstat(plan, tok, mode=1, rs=rs, mu=mu, eps=1e-5, label=nm + ".norm")
+            # q | k | v from ONE GEMM (to_q and to_kv are both bias-free on the same normalised input, ip.py:539)
+            wqkv = W.raw(nm + ".qkv", torch.cat((attn.to_q.weight.detach().float(), attn.to_kv.weight.detach().float())), None)
+            qkv = self.new(R, 1, N, inner + 2 * dh)
+            ops.igemm(plan, tok, wqkv, qkv, mu=mu, rs=rs, pa=W.f32(nm + ".norm.g", lambda: _pad_vec(attn.norm.g, wqkv.Cin_pad)),
+                      label=nm + ".qkv")
+            ld = inner + 2 * dh
+            ops.qnorm(plan, qkv.t, W.f32(nm + ".q_scale", lambda: attn.q_scale), rows=R * N, heads=heads, ld=ld, mult=SIM_SCALE * LOG2E,
+                      label=nm + ".qnorm")
+            n_ctx = self.NT if (with_context and attn.to_context is not None) else 0
+            J = n_ctx + 1 + N
+            Jp = ops._round_up(J, 32)
+            khat = torch.zeros(R, Jp, dh, dtype=torch.float16, device=self.dev)
+            vt = torch.zeros(R, dh, Jp, dtype=torch.float16, device=self.dev)
+            k_strides, vt_strides = (Jp * dh, 0, dh), (dh * Jp, 0, Jp)
+            site = dict(kind="self", name=nm, mod=attn, khat=khat, vt=vt, heads=1, Jp=Jp, n_ctx=n_ctx, k_strides=k_strides, vt_strides=vt_strides)
+            self.attn_sites.append(site)
+            ops.kv_prep(plan, qkv.t, qkv.t, W.f32(nm + ".k_scale", lambda: attn.k_scale), khat, vt, B=R, heads=1, rows=N, r0=n_ctx + 1,
+                        src_strides=(N * ld, ld, 0), k_strides=k_strides, vt_strides=vt_strides, k_off=inner, v_off=inner + dh,
+                        label=nm + ".kv_self")
+            o = self.new(R, 1, N, inner)
+            ops.attention(plan, qkv.t, khat, vt, o.t, B=R, heads=heads, rows=N, J=J, q_strides=(N * ld, dh, ld), k_strides=k_strides,
+                          vt_strides=vt_strides, o_strides=(N * inner, dh, inner), label=nm + ".attn")
+            y = self.new(R, 1, N, C)
+            ops.igemm(plan, o, W.conv(nm + ".to_out", attn.to_out[0]), y, label=nm + ".to_out")
+            x1 = self.new(R, 1, N, C)
+            ops.ln_residual(plan, y, W.f32(nm + ".out_g", lambda: attn.to_out[1].g), x1, res=tok, eps=1e-5, label=nm + ".out_norm")
+            cur = Act(self._feed_forward(plan, x1, ff, nm + ".ff").t, R, x.H, x.W, C, C, N * C)
+        return cur
+
+    def _feed_forward(self, plan, x: Act, ff: nn.Sequential, name: str) -> Act:
+        """ip.py:972-980 + residual (ip.py:1018): LN -> Linear -> GELU -> LN -> Linear, + x."""
+        W = self.W
+        rows = x.rows
+        hidden = ff[1].weight.shape[0]
+        mu, rs = self.f32buf(rows), self.f32buf(rows)
+        ops.rowstat(plan, x, mode=1, rs=rs, mu=mu, eps=1e-5, label=name + ".ln0")
+        w1 = W.conv(name + ".w1", ff[1])
+        hid = self.new(x.B, x.H, x.W, hidden)
+        ops.igemm(plan, x, w1, hid, mu=mu, rs=rs, pa=W.f32(name + ".g0", lambda: _pad_vec(ff[0].g, w1.Cin_pad)), act_out=ACT_GELU,
+                  label=name + ".lin1")
+        mu2, rs2 = self.f32buf(rows), self.f32buf(rows)
+        ops.rowstat(plan, hid, mode=1, rs=rs2, mu=mu2, eps=1e-5, label=name + ".ln1")
+        w2 = W.conv(name + ".w2", ff[4])
+        out = self.new(x.B, x.H, x.W, x.C)
+        ops.igemm(plan, hid, w2, out, mu=mu2, rs=rs2, pa=W.f32(name + ".g1", lambda: _pad_vec(ff[3].g, w2.Cin_pad)), res=x, label=name + ".lin2")
+        return out
+
+    # ---- resampling
+    def _downsample(self, plan, x: Act, mod, name: str) -> Act:
+        R = self.R
+        if isinstance(mod, ParallelP):  # last level (ip.py:1366): conv3x3 + conv1x1 summed == one 3x3 conv with the 1x1 folded into its centre tap
+            def make():
+                w3 = mod.fns[0].weight.detach().float().clone()
+                w3[:, :, 1, 1] += mod.fns[1].weight.detach().float()[:, :, 0, 0]
+                return ops.pack_weight(w3, mod.fns[0].bias.detach().float() + mod.fns[1].bias.detach().float(), self.dev)
+            w = self.W.get(name, make)
+            out = self.new(R, x.H, x.W, w.Cout)
+            ops.igemm(plan, x, w, out, label=name)
+            return out
+        conv = mod[1]  # pixel-unshuffle + 1x1 conv (ip.py:633-640) == 2x2 stride-2 conv
+        def make():
+            w = conv.weight.detach().float()
+            return ops.pack_weight(w.view(w.shape[0], x.C, 2, 2), conv.bias.detach().float(), self.dev)
+        w = self.W.get(name, make)
+        out = self.new(R, x.H // 2, x.W // 2, w.Cout)
+        ops.igemm(plan, x, w, out, stride=2, pad=0, label=name)
+        return out
+
+    def _upsample(self, plan, x: Act, mod: PixelShuffleUpsampleP, name: str) -> Act:
+        conv = mod.net[0]
+        c4 = conv.weight.shape[0]
+        cq = c4 // 4
+        perm = torch.arange(c4).view(cq, 4).t().reshape(-1)  # PixelShuffle channel c*4 + s -> packed order (s, c)
+        w = self.W.conv(name, conv, out_perm=perm)
+        out = self.new(self.R, 2 * x.H, 2 * x.W, cq)
+        ops.igemm(plan, x, w, out, act_out=ACT_SILU, out_mode=OUT_PIXEL_SHUFFLE, label=name)
+        return out
+
+    # ------------------------------------------------------------------------------------------ conditioning K/V
+    def _ctx_weights(self):
+        """Batched projections of the conditioning tokens for every attention site:
+        self-attention `to_context` = LayerNorm(affine) + Linear (ip.py:527): the LN affine is folded into the Linear, so all
+        sites share one normalised input; cross-attention `to_kv` (ip.py:783) consumes c directly."""
+        selfs = [s for s in self.attn_sites if s["kind"] == "self" and s["n_ctx"] > 0]
+        crosses = [s for s in self.attn_sites if s["kind"] == "cross"]
+
+        def make_self():
+            ws, bs = [], []
+            for s in selfs:
+                ln, lin = s["mod"].to_context[0], s["mod"].to_context[1]
+                w = lin.weight.detach().float()
+                ws.append(w * ln.weight.detach().float()[None, :])
+                bs.append(lin.bias.detach().float() + w @ ln.bias.detach().float())
+            return ops.pack_weight(torch.cat(ws), torch.cat(bs), self.dev)
+
+        def make_cross():
+            return ops.pack_weight(torch.cat([s["mod"].to_kv.weight.detach().float() for s in crosses]), None, self.dev)
+
+        ws = self.W.get("ctx.self", make_self) if selfs else None
+        wc = self.W.get("ctx.cross", make_cross) if crosses else None
+        return selfs, crosses, ws, wc
+
+    def _emit_context_kv(self, plan, c_rows: Act, rows_per_batch: int, k_row0_self: int, k_row0_cross: int, tag: str):
+        """Project `c_rows` ([1,1,R*rpb,cond], already norm_cond'ed) for every site and write its K^/V^T rows."""
+        R, W = self.R, self.W
+        selfs, crosses, ws, wc = self._ctx_weights()
+        n = rows_per_batch
+        if selfs:
+            mu, rs = self.f32buf(R * n), self.f32buf(R * n)
+            ops.rowstat(plan, c_rows, mode=1, rs=rs, mu=mu, eps=1e-5, label=f"ctx.{tag}.ln")
+            st = self.new(1, 1, R * n, ws.Cout)
+            ops.igemm(plan, c_rows, ws, st, mu=mu, rs=rs, label=f"ctx.{tag}.self")
+            for i, s in enumerate(selfs):
+                ops.kv_prep(plan, st.t, st.t, W.f32(s["name"] + ".k_scale", lambda s=s: s["mod"].k_scale), s["khat"], s["vt"], B=R, heads=1,
+                            rows=n, r0=k_row0_self, src_strides=(n * ws.Cout, ws.Cout, 0), k_strides=s["k_strides"], vt_strides=s["vt_strides"],
+                            k_off=i * 128, v_off=i * 128 + 64, label=f"{s['name']}.kv_ctx.{tag}")
+        if crosses:
+            st = self.new(1, 1, R * n, wc.Cout)
+            ops.igemm(plan, c_rows, wc, st, label=f"ctx.{tag}.cross")
+            col = 0  # sites differ in head count (the mid blocks are always 8 x 64, ip.py:1380-1382): cumulative column offsets
+            for s in crosses:
+                inner = s["heads"] * 64
+                ops.kv_prep(plan, st.t, st.t, W.f32(s["name"] + ".k_scale", lambda s=s: s["mod"].k_scale), s["khat"], s["vt"], B=R,
+                            heads=s["heads"], rows=n, r0=k_row0_cross, src_strides=(n * wc.Cout, wc.Cout, 64), k_strides=s["k_strides"],
+                            vt_strides=s["vt_strides"], k_off=col, v_off=col + inner, label=f"{s['name']}.kv_ctx.{tag}")
+                col += 2 * inner
+            assert col == wc.Cout
+
+    def _emit_null_kv(self, plan):
+        """learned null key/value (ip.py:545-547 self: after the context; ip.py:805-808 cross: first)."""
+        R, W = self.R, self.W
+        for s in self.attn_sites:
+            nk = W.f32(s["name"] + ".null_kv", lambda s=s: s["mod"].null_kv)
+            r0 = s["n_ctx"] if s["kind"] == "self" else 0
+            ops.kv_prep(plan, nk, nk, W.f32(s["name"] + ".k_scale", lambda s=s: s["mod"].k_scale), s["khat"], s["vt"], B=R, heads=s["heads"],
+                        rows=1, r0=r0, src_strides=(0, 0, 0), k_strides=s["k_strides"], vt_strides=s["vt_strides"], k_off=0, v_off=64,
+                        label=s["name"] + ".kv_null")
+
+    # ------------------------------------------------------------------------------------------ static plan
+    def _build_static_plan(self, n_tok: int):
+        """Timestep-invariant conditioning (ip.py:1583-1660 minus the time tokens)."""
+        u, R, W, cd, Tc = self.unet, self.R, self.W, self.cond_dim, self.Tc
+        plan = Plan("unet-static")
+        L = u.max_text_len
+        src_batch = self.src_batch
+        te16 = mask_u8 = None
+        t_parts: List[Act] = []
+        static_tokens: List[Act] = []   # pieces of c after the time tokens: [lowres time tokens][text tokens]
+        # ---- low-res noise-level conditioning (ip.py:1583-1589)
+        if self.lowres:
+            hid_l = self.new(1, 1, R, Tc)
+            ops.time_embed(plan, times=self.lowres_times, coef=None, step_ptr=None,
+                           freqs=W.f32("ltime.freqs", lambda: u.to_lowres_time_hiddens[0].weights),
+                           w=W.f32("ltime.w", lambda: u.to_lowres_time_hiddens[1].weight),
+                           bias=W.f32("ltime.b", lambda: u.to_lowres_time_hiddens[1].bias), hid=hid_l, label="lowres_time_embed")
+            t_l = self.new(1, 1, R, Tc)
+            ops.igemm(plan, hid_l, W.conv("ltime.cond", u.to_lowres_time_cond[0]), t_l, label="to_lowres_time_cond")
+            t_parts.append(t_l)
+            tok_l = self.new(1, 1, R, self.ntt * cd)
+            ops.igemm(plan, hid_l, W.conv("ltime.tokens", u.to_lowres_time_tokens[0]), tok_l, label="to_lowres_time_tokens")
+            static_tokens.append(Act(tok_l.t, R, 1, self.ntt, cd, cd, self.ntt * cd))
+        # ---- text conditioning (ip.py:1595-1652)
+        if self.has_text:
+            assert n_tok > 0
+            ted = u.text_to_cond.weight.shape[1]
+            te16 = torch.zeros(src_batch, n_tok, ted, dtype=torch.float16, device=self.dev)
+            mask_u8 = torch.ones(src_batch, L, dtype=torch.uint8, device=self.dev)
+            tok = self.new(src_batch, 1, L, cd, zero=True)          # rows >= n_tok stay zero (F.pad, ip.py:1617)
+            te = Act(te16, src_batch, 1, n_tok, ted, ted, n_tok * ted)
+            tok_head = Act(tok.t, src_batch, 1, n_tok, cd, cd, L * cd)
+            ops.igemm(plan, te, W.conv("text_to_cond", u.text_to_cond), tok_head, label="text_to_cond")
+            xt = self.new(R, 1, L, cd)
+            ops.select_rows(plan, tok.t, W.f16("null_text_embed", lambda: u.null_text_embed[0]), mask_u8, self.src_idx, self.keep_u8, xt.t,
+                            R=R, L=L, C=cd, label="text_keep_select")
+            text_tokens = self._perceiver(plan, xt, u.attn_pool) if u.attn_pool is not None else xt
+            static_tokens.append(text_tokens)
+            pooled = self.new(1, 1, R, cd)
+            ops.mean_rows(plan, text_tokens, pooled, label="text_mean_pool")
+            nc = u.to_text_non_attn_cond
+            mu, rs = self.f32buf(R), self.f32buf(R)
+            ops.rowstat(plan, pooled, mode=1, rs=rs, mu=mu, eps=1e-5, label="text_hidden.ln")
+            w1 = W.conv("text_hidden.w1", nc[1])
+            h1 = self.new(1, 1, R, Tc)
+            ops.igemm(plan, pooled, w1, h1, mu=mu, rs=rs, pa=W.f32("text_hidden.lnw", lambda: _pad_vec(nc[0].weight, w1.Cin_pad)),
+                      ps=W.f32("text_hidden.lnb", lambda: _pad_vec(nc[0].bias, w1.Cin_pad)), act_out=ACT_SILU, label="text_hidden.lin1")
+            h2 = self.new(1, 1, R, Tc)
+            ops.igemm(plan, h1, W.conv("text_hidden.w2", nc[3]), h2, label="text_hidden.lin2")
+            th = self.new(1, 1, R, Tc)
+            ops.select_rows(plan, h2.t, W.f16("null_text_hidden", lambda: u.null_text_hidden), None, self.arange_idx, self.keep_u8, th.t,
+                            R=R, L=1, C=Tc, label="text_hidden_select")
+            t_parts.append(th)
+        # ---- t_const = text hiddens + lowres t  (added to to_time_cond(hid) each step, ip.py:1588, 1652)
+        if len(t_parts) == 2:
+            ops.gate_residual(plan, t_parts[0], None, t_parts[1], self.t_const, label="t_const")
+        elif len(t_parts) == 1:
+            ops.rows_copy(plan, t_parts[0].t, self.t_const.t, B=1, rows=R, C=Tc, src_bs=0, src_rs=Tc, dst_bs=0, dst_rs=Tc, label="t_const")
+        else:
+            ops.memset32(plan, self.t_const.t.view(torch.int32), 0, label="t_const=0")
+        # ---- static part of c: norm_cond per token (ip.py:1656-1660), then K/V rows for every attention site
+        ns = sum(a.W * a.H for a in static_tokens)
+        assert ns == self.NS, f"static conditioning tokens: built {ns}, planned {self.NS}"
+        if ns > 0:
+            c_static = self.new(R, 1, ns, cd)
+            r0 = 0
+            for a in static_tokens:
+                n = a.H * a.W
+                dst = Act(c_static.t, R, 1, n, cd, cd, ns * cd, off=r0 * cd)
+                ops.ln_residual(plan, Act(a.t, R, 1, n, cd, a.ld, a.bs, a.off), W.f32("norm_cond.w", lambda: u.norm_cond.weight), dst,
+                                beta=W.f32("norm_cond.b", lambda: u.norm_cond.bias), eps=1e-5, label="norm_cond(static)")
+                r0 += n
+            flat = Act(c_static.t, 1, 1, R * ns, cd, cd, R * ns * cd)
+            self._emit_context_kv(plan, flat, rows_per_batch=ns, k_row0_self=self.ntt, k_row0_cross=1 + self.ntt, tag="static")
+        self._emit_null_kv(plan)
+        return plan, te16, mask_u8
+
+    def _perceiver(self, plan, xt: Act, pr) -> Act:
+        """PerceiverResampler (ip.py:447-498), depth x [PerceiverAttention (ip.py:408-445) + FeedForward(mult 4)]."""
+        R, W, cd = self.R, self.W, self.cond_dim
+        L = xt.W
+        nl, nm = pr.latents.shape[0], pr.num_latents_mean_pooled
+        NL = nl + nm
+        # x + positional embedding
+        posb = self.new(R, 1, L, cd)
+        ops.rows_copy(plan, W.f16("attn_pool.pos", lambda: pr.pos_emb.weight[:L]), posb.t, B=R, rows=L, C=cd, src_bs=0, src_rs=cd,
+                      dst_bs=L * cd, dst_rs=cd, label="attn_pool.pos_bcast")
+        xpos = self.new(R, 1, L, cd)
+        flat = lambda a: Act(a.t, 1, 1, a.B * a.H * a.W, a.C, a.ld, a.B * a.bs, a.off)
+        ops.gate_residual(plan, flat(xt), None, flat(posb), flat(xpos), label="attn_pool.x_plus_pos")
+        lat = self.new(R, 1, NL, cd)
+        if nm > 0:
+            pooled = self.new(1, 1, R, cd)
+            ops.mean_rows(plan, xt, pooled, label="attn_pool.mean_pool")
+            seq = pr.to_latents_from_mean_pooled_seq
+            mu, rs = self.f32buf(R), self.f32buf(R)
+            ops.rowstat(plan, pooled, mode=1, rs=rs, mu=mu, eps=1e-5, label="attn_pool.mp.ln")
+            wm = W.conv("attn_pool.mp", seq[1])
+            dst = Act(lat.t, R, 1, 1, nm * cd, NL * cd, NL * cd)  # (R, nm*cd) written as the first nm rows of each row's latents
+            src = Act(pooled.t, R, 1, 1, cd, cd, cd)
+            ops.igemm(plan, src, wm, dst, mu=mu, rs=rs, pa=W.f32("attn_pool.mp.g", lambda: _pad_vec(seq[0].g, wm.Cin_pad)), label="attn_pool.mp.lin")
+        ops.rows_copy(plan, W.f16("attn_pool.latents", lambda: pr.latents), lat.t, B=R, rows=nl, C=cd, src_bs=0, src_rs=cd, dst_bs=NL * cd,
+                      dst_rs=cd, dst_off=nm * cd, label="attn_pool.latents")
+        Jk = L + NL
+        Jp = ops._round_up(Jk, 32)
+        for i, (pa, ff) in enumerate(pr.layers):
+            nm_ = f"attn_pool.layers.{i}"
+            heads, dh = pa.heads, pa.dim_head
+            inner = heads * dh
+            kv = self.new(R, 1, Jk, 2 * inner)
+            wkv = W.conv(nm_ + ".to_kv", pa.to_kv)
+            # k/v of the normalised sequence ...
+            mu, rs = self.f32buf(R * L), self.f32buf(R * L)
+            ops.rowstat(plan, xpos, mode=1, rs=rs, mu=mu, eps=1e-5, label=nm_ + ".norm")
+            ops.igemm(plan, xpos, wkv, Act(kv.t, R, 1, L, 2 * inner, 2 * inner, Jk * 2 * inner), mu=mu, rs=rs,
+                      pa=W.f32(nm_ + ".norm.w", lambda pa=pa: _pad_vec(pa.norm.weight, wkv.Cin_pad)),
+                      ps=W.f32(nm_ + ".norm.b", lambda pa=pa: _pad_vec(pa.norm.bias, wkv.Cin_pad)), label=nm_ + ".kv_x")
+            # ... and of the normalised latents (ip.py:417-418), which also give q
+            mul, rsl = self.f32buf(R * NL), self.f32buf(R * NL)
+            ops.rowstat(plan, lat, mode=1, rs=rsl, mu=mul, eps=1e-5, label=nm_ + ".norm_latents")
+            lnw = W.f32(nm_ + ".norml.w", lambda pa=pa: _pad_vec(pa.norm_latents.weight, wkv.Cin_pad))
+            lnb = W.f32(nm_ + ".norml.b", lambda pa=pa: _pad_vec(pa.norm_latents.bias, wkv.Cin_pad))
+            ops.igemm(plan, lat, wkv, Act(kv.t, R, 1, NL, 2 * inner, 2 * inner, Jk * 2 * inner, off=L * 2 * inner), mu=mul, rs=rsl, pa=lnw, ps=lnb,
+                      label=nm_ + ".kv_lat")
+            q = self.new(R, 1, NL, inner)
+            ops.igemm(plan, lat, W.conv(nm_ + ".to_q", pa.to_q), q, mu=mul, rs=rsl, pa=lnw, ps=lnb, label=nm_ + ".to_q")
+            ops.qnorm(plan, q.t, W.f32(nm_ + ".q_scale", lambda pa=pa: pa.q_scale), rows=R * NL, heads=heads, ld=inner, mult=SIM_SCALE * LOG2E,
+                      label=nm_ + ".qnorm")
+            khat = torch.zeros(R, heads, Jp, dh, dtype=torch.float16, device=self.dev)
+            vt = torch.zeros(R, heads, dh, Jp, dtype=torch.float16, device=self.dev)
+            ks, vs = (heads * Jp * dh, Jp * dh, dh), (heads * dh * Jp, dh * Jp, Jp)
+            ops.kv_prep(plan, kv.t, kv.t, W.f32(nm_ + ".k_scale", lambda pa=pa: pa.k_scale), khat, vt, B=R, heads=heads, rows=Jk, r0=0,
+                        src_strides=(Jk * 2 * inner, 2 * inner, dh), k_strides=ks, vt_strides=vs, k_off=0, v_off=inner, label=nm_ + ".kv_prep")
+            o = self.new(R, 1, NL, inner)
+            ops.attention(plan, q.t, khat, vt, o.t, B=R, heads=heads, rows=NL, J=Jk, q_strides=(NL * inner, dh, inner), k_strides=ks,
+                          vt_strides=vs, o_strides=(NL * inner, dh, inner), label=nm_ + ".attn")
+            y = self.new(R, 1, NL, cd)
+            ops.igemm(plan, o, W.conv(nm_ + ".to_out", pa.to_out[0]), y, label=nm_ + ".to_out")
+            lat2 = self.new(R, 1, NL, cd)
+            ops.ln_residual(plan, y, W.f32(nm_ + ".out.w", lambda pa=pa: pa.to_out[1].weight), lat2,
+                            beta=W.f32(nm_ + ".out.b", lambda pa=pa: pa.to_out[1].bias), res=lat, eps=1e-5, label=nm_ + ".out_norm")
+            lat = self._feed_forward(plan, lat2, ff, nm_ + ".ff")
+        return lat
+
+    # ------------------------------------------------------------------------------------------ run-time API
+    def set_conditioning(self, *, text_embeds, text_mask, keep, lowres_noise_times):
+        """Stage the timestep-invariant inputs and run the static plan.  `keep`: bool [R] (True = conditional row)."""
+        R, u, src_batch = self.R, self.unet, self.src_batch
+        n_tok = 0
+        if self.has_text:
+            assert text_embeds is not None, "this engine was planned with text conditioning"
+            text_embeds = text_embeds[:, : u.max_text_len]
+            n_tok = text_embeds.shape[1]
+            assert text_embeds.shape[0] == src_batch
+        if n_tok not in self._static_plans:
+            self._static_plans[n_tok] = self._build_static_plan(n_tok)
+        plan, te16, mask_u8 = self._static_plans[n_tok]
+        self.keep_u8.copy_(keep.to(torch.uint8))
+        self.src_idx.copy_(torch.arange(R, dtype=torch.int32) % src_batch)
+        if self.lowres:
+            assert lowres_noise_times is not None
+            lt = lowres_noise_times.float().reshape(-1)
+            self.lowres_times.copy_(lt.repeat(R // lt.numel()))
+        if self.has_text:
+            te16.copy_(text_embeds.to(torch.float16))
+            L = u.max_text_len
+            m = torch.zeros(src_batch, L, dtype=torch.uint8)
+            if text_mask is not None:
+                tm = text_mask[:, :L].to(torch.uint8).cpu()
+                m[:, : tm.shape[1]] = tm
+            else:
+                m[:, :n_tok] = 1
+            mask_u8.copy_(m)
+        if not self.dry:
+            plan.run()
+        self._cond_ready = True
+
+    def bind_step_counter(self, coef: torch.Tensor, step_ptr: torch.Tensor):
+        """Sampler mode: the time embedding reads log-SNR of the current step from the coef table (graph replay)."""
+        p = self._time_embed_op
+        p.times, p.coef, p.step_ptr = None, coef.data_ptr(), step_ptr.data_ptr()
+        self.coef, self.step_ptr = coef, step_ptr
+
+    def forward(self, x: torch.Tensor, time: torch.Tensor, lowres_cond_img: Optional[torch.Tensor] = None) -> torch.Tensor:
+        assert self._cond_ready, "set_conditioning() first"
+        R = self.R
+        self.x_in.copy_(x)
+        if self.lowres:
+            self.lowres_in.copy_(lowres_cond_img)
+        t = time.float().reshape(-1)
+        self.times.copy_(t.repeat(R // t.numel()))
+        if not self.dry:
+            self.step_plan.run()
+        return self.out

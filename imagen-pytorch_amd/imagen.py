@@ -1,0 +1,407 @@
+"""Drop-in `Imagen` (cascaded DDPM): constructor and `.sample()` signature of the reference
+(imagen_pytorch/imagen_pytorch.py:1787-2498 = "ip.py"), sampling half only.
+
+Each cascade stage runs T timesteps; one timestep = [denoiser plan of the stage's UnetEngine (both CFG branches
+as one 2B-row batch)] + [CFG combine / x0 / exact 0.95-quantile / dynamic threshold / posterior / noise kernels],
+captured ONCE into a hipGraph and replayed T times — the step index lives in a device counter that every
+sampler kernel (and the time embedding) reads, so replay needs no host-side parameter patching.
+
+Training (`forward`, p_losses), T5 text encoding (`texts=`), video, inpainting, init_images / skip_steps are
+outside the hot-path scope and raise.
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, List, Optional
+
+import torch
+from torch import nn
+
+from . import ops
+from .ops import Plan
+from .schedules import GaussianDiffusionContinuousTimes
+from .unet import NullUnet, Unet
+
+T5_DIMS = {  # d_model of the encoders the reference accepts by name (t5.py:47-58 reads it from the HF config)
+    't5-small': 512, 't5-base': 768, 't5-large': 1024, 't5-3b': 1024, 't5-11b': 1024,
+    'google/t5-v1_1-small': 512, 'google/t5-v1_1-base': 768, 'google/t5-v1_1-large': 1024,
+    'google/t5-v1_1-xl': 2048, 'google/t5-v1_1-xxl': 4096,
+}
+DEFAULT_T5_NAME = 'google/t5-v1_1-base'
+
+TAG_INIT, TAG_LOWRES = 0x7FFF0001, 0x7FFF0002  # RANDN counter tags (step noise uses the step index)
+
+
+def _cast_tuple(val, length=None):
+    if isinstance(val, list):
+        val = tuple(val)
+    out = val if isinstance(val, tuple) else ((val,) * (length or 1))
+    if length is not None:
+        assert len(out) == length
+    return out
+
+
+def _pad_tuple(t, length, fill):
+    return t if len(t) >= length else (*t, *((fill,) * (length - len(t))))
+
+
+def _out_of_scope(what):
+    raise NotImplementedError(f"{what} is outside the MI355X sampling hot path of this build (SURVEY.md §2 / §8)")
+
+
+class Imagen(nn.Module):
+    def __init__(
+        self,
+        unets,
+        *,
+        image_sizes,
+        text_encoder_name=DEFAULT_T5_NAME,
+        text_embed_dim=None,
+        channels=3,
+        timesteps=1000,
+        cond_drop_prob=0.1,
+        loss_type='l2',
+        noise_schedules='cosine',
+        pred_objectives='noise',
+        random_crop_sizes=None,
+        lowres_noise_schedule='linear',
+        lowres_sample_noise_level=0.2,
+        per_sample_random_aug_noise_level=False,
+        condition_on_text=True,
+        auto_normalize_img=True,
+        dynamic_thresholding=True,
+        dynamic_thresholding_percentile=0.95,
+        only_train_unet_number=None,
+        temporal_downsample_factor=1,
+        resize_cond_video_frames=True,
+        resize_mode='nearest',
+        min_snr_loss_weight=True,
+        min_snr_gamma=5,
+    ):
+        super().__init__()
+        if loss_type not in ('l1', 'l2', 'huber'):
+            raise NotImplementedError()
+        self.loss_type = loss_type
+        self.condition_on_text = condition_on_text
+        self.unconditional = not condition_on_text
+        self.channels = channels
+
+        unets = _cast_tuple(unets)
+        num_unets = len(unets)
+        timesteps = _cast_tuple(timesteps, num_unets)
+
+        # 'cosine', 'cosine', then 'linear' for further super-resolution stages (ip.py:1853-1855)
+        noise_schedules = _pad_tuple(_pad_tuple(_cast_tuple(noise_schedules), 2, 'cosine'), num_unets, 'linear')
+        self.noise_schedulers = nn.ModuleList([GaussianDiffusionContinuousTimes(noise_schedule=s, timesteps=t)
+                                               for t, s in zip(timesteps, noise_schedules)])
+        self.random_crop_sizes = _cast_tuple(random_crop_sizes, num_unets)
+        self.lowres_noise_schedule = GaussianDiffusionContinuousTimes(noise_schedule=lowres_noise_schedule)
+        self.pred_objectives = _cast_tuple(pred_objectives, num_unets)
+
+        self.text_encoder_name = text_encoder_name
+        if text_embed_dim is None:
+            if text_encoder_name not in T5_DIMS:
+                raise ValueError(f"unknown text encoder '{text_encoder_name}': pass text_embed_dim explicitly")
+            text_embed_dim = T5_DIMS[text_encoder_name]
+        self.text_embed_dim = text_embed_dim
+
+        self.unets = nn.ModuleList([])
+        self.unet_being_trained_index = -1
+        self.only_train_unet_number = only_train_unet_number
+        for ind, one_unet in enumerate(unets):
+            assert isinstance(one_unet, (Unet, NullUnet))
+            one_unet = one_unet.cast_model_parameters(
+                lowres_cond=ind > 0, cond_on_text=self.condition_on_text,
+                text_embed_dim=self.text_embed_dim if self.condition_on_text else None,
+                channels=self.channels, channels_out=self.channels)   # ip.py:1897-1903 (may re-instantiate with fresh weights)
+            self.unets.append(one_unet)
+
+        image_sizes = _cast_tuple(image_sizes)
+        self.image_sizes = image_sizes
+        assert num_unets == len(image_sizes), f'you did not supply the correct number of u-nets ({len(unets)}) for resolutions {image_sizes}'
+        self.sample_channels = _cast_tuple(self.channels, num_unets)
+        self.is_video = False
+        self.resize_mode = resize_mode
+        if resize_mode != 'nearest':
+            _out_of_scope(f"resize_mode='{resize_mode}'")
+        self.temporal_downsample_factor = _cast_tuple(temporal_downsample_factor, num_unets)
+
+        lowres_conditions = tuple(u.lowres_cond for u in self.unets)
+        assert lowres_conditions == (False, *((True,) * (num_unets - 1))), \
+            'the first unet must be unconditioned (by low resolution image), and the rest of the unets must have `lowres_cond` set to True'
+
+        self.lowres_sample_noise_level = lowres_sample_noise_level
+        self.per_sample_random_aug_noise_level = per_sample_random_aug_noise_level
+        self.cond_drop_prob = cond_drop_prob
+        self.can_classifier_guidance = cond_drop_prob > 0.
+        self.auto_normalize_img = auto_normalize_img
+        self.input_image_range = (0. if auto_normalize_img else -1., 1.)
+        self.dynamic_thresholding = _cast_tuple(dynamic_thresholding, num_unets)
+        self.dynamic_thresholding_percentile = dynamic_thresholding_percentile
+        min_snr_loss_weight = _cast_tuple(min_snr_loss_weight, num_unets)
+        min_snr_gamma = _cast_tuple(min_snr_gamma, num_unets)
+        self.min_snr_gamma = tuple((g if use else None) for use, g in zip(min_snr_loss_weight, min_snr_gamma))
+
+        self.register_buffer('_temp', torch.tensor([0.]), persistent=False)
+        self.to(next(self.unets.parameters()).device)
+        self._stages = {}
+        self._stream = None
+        self._call_counter = 0
+
+    # ---- device bookkeeping (API parity; weights stay resident as packed copies, nothing is shuffled over PCIe) ----
+    @property
+    def device(self):
+        return self._temp.device
+
+    def force_unconditional_(self):
+        self.condition_on_text = False
+        self.unconditional = True
+        for unet in self.unets:
+            unet.cond_on_text = False
+
+    def get_unet(self, unet_number):
+        assert 0 < unet_number <= len(self.unets)
+        return self.unets[unet_number - 1]
+
+    def reset_unets_all_one_device(self, device=None):
+        device = device if device is not None else self.device
+        self.unets.to(device)
+        self.unet_being_trained_index = -1
+
+    def state_dict(self, *args, **kwargs):
+        return super().state_dict(*args, **kwargs)
+
+    def load_state_dict(self, *args, **kwargs):
+        return super().load_state_dict(*args, **kwargs)
+
+    def forward(self, *args, **kwargs):
+        _out_of_scope("Imagen.forward (training loss, ip.py:2500-2734)")
+
+    # ---- one cascade stage -------------------------------------------------------------------------------------
+    def _stage(self, idx: int, B: int, device, *, cond_scale: float, with_text: bool, inject_noise: bool, sample_offset: int):
+        """Build (or fetch) the per-timestep plan + graph of stage `idx` for batch B."""
+        unet = self.unets[idx]
+        S = self.image_sizes[idx]
+        sched = self.noise_schedulers[idx]
+        T = sched.num_timesteps
+        cfg = cond_scale != 1.
+        key = (idx, B, S, str(device), float(cond_scale), with_text, inject_noise, sample_offset, self.dynamic_thresholding[idx],
+               self.pred_objectives[idx], self.dynamic_thresholding_percentile)
+        st = self._stages.get(key)
+        if st is not None and not st['eng'].stale():
+            return st
+        rows = 2 * B if cfg else B
+        from .engine import UnetEngine
+        eng = UnetEngine(unet, rows, B, S, device, with_text=with_text)
+        n = self.channels * S * S
+        dev = device
+        coef = sched.step_coefficients().to(dev)
+        step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
+        seed_dev = torch.zeros(2, dtype=torch.int32, device=dev)
+        eng.bind_step_counter(coef, step_ptr)
+        x0 = torch.empty(B, n, device=dev)
+        absx0 = torch.empty(B, n, device=dev)
+        quant = torch.empty(B, device=dev)
+        scratch = torch.empty(B * ops.ENUMS["IMAGEN_QUANTILE_SCRATCH_WORDS"], dtype=torch.int32, device=dev)
+        noise = torch.empty(B, self.channels, S, S, device=dev) if inject_noise else None
+        final = torch.empty(B, self.channels, S, S, device=dev)
+        plan = Plan(f"stage{idx}-step")
+        plan.extend(eng.step_plan)
+        ops.cfg_x0(plan, eng.x_in, eng.out, coef, step_ptr, x0, absx0, B=B, n_per_sample=n, cfg=cfg, cond_scale=float(cond_scale),
+                   objective=self.pred_objectives[idx])
+        dyn = bool(self.dynamic_thresholding[idx])
+        if dyn:
+            ops.quantile(plan, absx0, quant, scratch, B=B, n=n, q=float(self.dynamic_thresholding_percentile))
+        ops.ddpm_update(plan, eng.x_in, x0, quant if dyn else None, coef, noise, final, step_ptr, B=B, n_per_sample=n,
+                        dynamic_threshold=dyn, total_steps=T, seed=0, stream_id=idx, sample_offset=sample_offset, seed_ptr=seed_dev)
+        st = dict(eng=eng, plan=plan, graph=None, coef=coef, step_ptr=step_ptr, seed_dev=seed_dev, noise=noise, final=final, T=T, S=S,
+                  quant=quant, x0=x0)
+        self._stages[key] = st
+        return st
+
+    @torch.no_grad()
+    def p_sample_loop(self, st, *, noise_fn: Optional[Callable], stage: int, seed: int, use_graph: bool = True, use_tqdm: bool = False,
+                      max_steps: Optional[int] = None, trace: Optional[list] = None):
+        """ip.py:2167-2289 for one stage: x_T ~ N(0, I), T ancestral steps, clamp + unnormalise (done by the last step's kernel)."""
+        eng, plan, T = st['eng'], st['plan'], st['T']
+        B, S = eng.src_batch, st['S']
+        stream = torch.cuda.current_stream()
+        if noise_fn is not None:
+            eng.x_in.copy_(noise_fn(("init", stage), tuple(eng.x_in.shape)))
+        else:
+            init = Plan("init-noise")
+            ops.randn(init, eng.x_in, seed=seed, stream_id=stage, tag=TAG_INIT, sample_offset=st.get('sample_offset', 0))
+            init.run()
+        st['step_ptr'].zero_()
+        st['seed_dev'].copy_(torch.tensor([seed & 0x7FFFFFFF, (seed >> 31) & 0x7FFFFFFF], dtype=torch.int32))
+        steps = T if max_steps is None else min(T, max_steps)
+        if use_graph and st['graph'] is None:
+            plan.run()                                   # warm-up outside capture (sets kernel attributes), then rewind
+            st['step_ptr'].zero_()
+            if noise_fn is not None:
+                eng.x_in.copy_(noise_fn(("init", stage), tuple(eng.x_in.shape)))
+            else:
+                init.run()
+            torch.cuda.synchronize()
+            st['graph'] = ops.Graph(plan, stream)
+        it = range(steps)
+        if use_tqdm:
+            try:
+                from tqdm.auto import tqdm
+                it = tqdm(it, desc='sampling loop time step', total=steps)
+            except ImportError:
+                pass
+        for i in it:
+            if noise_fn is not None:
+                st['noise'].copy_(noise_fn(("step", stage, i), tuple(st['noise'].shape)))
+            if use_graph:
+                st['graph'].launch()
+            else:
+                plan.run()
+            if trace is not None:
+                trace.append(eng.x_in.clone())
+        if steps == T:
+            return st['final']
+        return (eng.x_in.clamp(-1., 1.) + 1) * 0.5  # truncated loop (tests): same epilogue as ip.py:2281-2288
+
+    # ---- public sampling API (ip.py:2291-2498) ------------------------------------------------------------------
+    @torch.no_grad()
+    def sample(
+        self,
+        texts: Optional[List[str]] = None,
+        text_masks=None,
+        text_embeds=None,
+        video_frames=None,
+        cond_images=None,
+        cond_video_frames=None,
+        post_cond_video_frames=None,
+        inpaint_videos=None,
+        inpaint_images=None,
+        inpaint_masks=None,
+        inpaint_resample_times=5,
+        init_images=None,
+        skip_steps=None,
+        batch_size=1,
+        cond_scale=1.,
+        lowres_sample_noise_level=None,
+        start_at_unet_number=1,
+        start_image_or_video=None,
+        stop_at_unet_number=None,
+        return_all_unet_outputs=False,
+        return_pil_images=False,
+        device=None,
+        use_tqdm=True,
+        use_one_unet_in_gpu=True,
+        *,
+        noise_fn: Optional[Callable] = None,   # extension: injectable Gaussian noise (parity tests), tags as in oracle/sampler_oracle.py
+        seed: Optional[int] = None,            # extension: Philox seed of this call
+        sample_offset: int = 0,                # extension: global index of sample 0 (batch sharding)
+        use_graph: bool = True,
+        max_steps: Optional[int] = None,
+    ):
+        was_training = self.training
+        self.eval()
+        try:
+            return self._sample(texts, text_masks, text_embeds, video_frames, cond_images, cond_video_frames, post_cond_video_frames,
+                                inpaint_videos, inpaint_images, inpaint_masks, init_images, skip_steps, batch_size, cond_scale,
+                                lowres_sample_noise_level, start_at_unet_number, start_image_or_video, stop_at_unet_number,
+                                return_all_unet_outputs, return_pil_images, device, use_tqdm, noise_fn, seed, sample_offset, use_graph,
+                                max_steps)
+        finally:
+            self.train(was_training)
+
+    def _sample(self, texts, text_masks, text_embeds, video_frames, cond_images, cond_video_frames, post_cond_video_frames,
+                inpaint_videos, inpaint_images, inpaint_masks, init_images, skip_steps, batch_size, cond_scale,
+                lowres_sample_noise_level, start_at_unet_number, start_image_or_video, stop_at_unet_number, return_all_unet_outputs,
+                return_pil_images, device, use_tqdm, noise_fn, seed, sample_offset, use_graph, max_steps):
+        device = torch.device(device) if device is not None else self.device
+        if device.type != 'cuda':
+            raise RuntimeError("imagen_pytorch_amd.Imagen.sample runs on MI355X only (move the module to 'cuda'); there is no CPU path")
+        self.reset_unets_all_one_device(device)
+        if texts is not None and text_embeds is None and not self.unconditional:
+            _out_of_scope("T5 text encoding (`texts=`): pass precomputed `text_embeds=`")
+        for name, val in (('video_frames', video_frames), ('cond_images', cond_images), ('cond_video_frames', cond_video_frames),
+                          ('post_cond_video_frames', post_cond_video_frames), ('inpaint_videos', inpaint_videos),
+                          ('inpaint_images', inpaint_images), ('inpaint_masks', inpaint_masks), ('skip_steps', skip_steps)):
+            if val is not None:
+                _out_of_scope(f"sample({name}=...)")
+        if init_images is not None and any(i is not None for i in _cast_tuple(init_images)):
+            _out_of_scope("sample(init_images=...)")
+        if return_pil_images:
+            _out_of_scope("return_pil_images (torchvision is not part of this stack)")
+
+        if not self.unconditional:
+            assert text_embeds is not None, 'text must be passed in if the network was not trained without text `condition_on_text` must be set to `False` when training'
+            text_embeds = text_embeds.to(device)
+            if text_masks is None:
+                text_masks = torch.any(text_embeds != 0., dim=-1)    # ip.py:2337
+            batch_size = text_embeds.shape[0]
+        assert not (self.condition_on_text and text_embeds is None), 'text or text encodings must be passed into imagen if specified'
+        assert not (not self.condition_on_text and text_embeds is not None), 'imagen specified not to be conditioned on text, yet it is presented'
+        assert not (text_embeds is not None and text_embeds.shape[-1] != self.text_embed_dim), \
+            f'invalid text embedding dimension being passed in (should be {self.text_embed_dim})'
+
+        num_unets = len(self.unets)
+        level = lowres_sample_noise_level if lowres_sample_noise_level is not None else self.lowres_sample_noise_level
+        cond_scale = _cast_tuple(cond_scale, num_unets)
+        if seed is None:
+            self._call_counter += 1
+            seed = (int(torch.initial_seed()) * 1000003 + self._call_counter) & ((1 << 62) - 1)
+
+        img = None
+        if start_at_unet_number > 1:
+            assert start_at_unet_number <= num_unets, 'must start a unet that is less than the total number of unets'
+            assert stop_at_unet_number is None or start_at_unet_number <= stop_at_unet_number
+            assert start_image_or_video is not None, 'starting image or video must be supplied if only doing upscaling'
+            img = start_image_or_video.to(device).float().contiguous()
+
+        if self._stream is None or self._stream.device != device:
+            self._stream = torch.cuda.Stream(device=device)
+        outputs = []
+        torch.cuda.synchronize(device)
+        with torch.cuda.device(device), torch.cuda.stream(self._stream):
+            for idx in range(num_unets):
+                unet_number = idx + 1
+                if unet_number < start_at_unet_number:
+                    continue
+                unet = self.unets[idx]
+                assert not isinstance(unet, NullUnet), 'one cannot sample from null / placeholder unets'
+                cs = cond_scale[idx]
+                assert not (cs != 1. and not self.can_classifier_guidance), \
+                    'imagen was not trained with conditional dropout, and thus one cannot use classifier free guidance (cond_scale anything other than 1)'
+                with_text = text_embeds is not None and unet.cond_on_text
+                st = self._stage(idx, batch_size, device, cond_scale=cs, with_text=with_text, inject_noise=noise_fn is not None,
+                                 sample_offset=sample_offset)
+                st['sample_offset'] = sample_offset
+                eng = st['eng']
+                S = self.image_sizes[idx]
+                lowres_logsnr = None
+                if unet.lowres_cond:
+                    assert img is not None
+                    a, s, lsnr = self.lowres_noise_schedule.q_sample_coefficients(level)
+                    lowres_logsnr = torch.full((batch_size,), lsnr, dtype=torch.float32)
+                    aug = torch.empty(batch_size, self.channels, S, S, device=device)
+                    if noise_fn is not None:
+                        aug.copy_(noise_fn(("lowres", idx), tuple(aug.shape)))
+                    prep = Plan("lowres-prep")
+                    if noise_fn is None:
+                        ops.randn(prep, aug, seed=seed, stream_id=idx, tag=TAG_LOWRES, sample_offset=sample_offset)
+                    src = img if self.auto_normalize_img else (img + 1) * 0.5   # kernel normalises [0,1] -> [-1,1]
+                    ops.lowres_prep(prep, src.contiguous(), aug, eng.lowres_in, alpha=a, sigma=s)
+                    prep.run()
+                rows = eng.R
+                keep = torch.ones(rows, dtype=torch.bool)
+                if rows == 2 * batch_size:
+                    keep[batch_size:] = False            # second half = null-conditioned CFG branch (cond_drop_prob = 1, ip.py:1521)
+                eng.set_conditioning(text_embeds=text_embeds if with_text else None, text_mask=text_masks if with_text else None,
+                                     keep=keep, lowres_noise_times=lowres_logsnr)
+                out = self.p_sample_loop(st, noise_fn=noise_fn, stage=idx, seed=seed, use_graph=use_graph, use_tqdm=use_tqdm,
+                                         max_steps=max_steps)
+                img = out.clone()
+                if not self.auto_normalize_img:
+                    img = img * 2 - 1
+                outputs.append(img)
+                if stop_at_unet_number is not None and stop_at_unet_number == unet_number:
+                    break
+        self._stream.synchronize()
+        return outputs if return_all_unet_outputs else outputs[-1]

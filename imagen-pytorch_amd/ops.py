@@ -397,7 +397,30 @@ def ln_residual(plan: Plan, y: Act, g: torch.Tensor, out: Act, *, beta=None, res
     p = STRUCTS["ImagenLnResidualParams"]()
     p.y, p.g, p.beta, p.res, p.out = y.ptr, g.data_ptr(), ptr(beta), (res.ptr if res is not None else None), out.ptr
     p.rows, p.C, p.ld_y, p.ld_res, p.ld_out, p.eps = y.rows, y.C, y.ld, (res.ld if res is not None else 0), out.ld, eps
+    p.rows_per_batch = y.H * y.W
+    p.bs_y, p.bs_res, p.bs_out = y.bs, (res.bs if res is not None else 0), out.bs
+    assert out.H * out.W == y.H * y.W and out.B == y.B
     plan.add(p, label or "ln_residual", [y.t, g, beta, res.t if res is not None else None, out.t])
+    return p
+
+
+def select_rows(plan: Plan, a: torch.Tensor, nul: torch.Tensor, mask: Optional[torch.Tensor], src: torch.Tensor, keep: torch.Tensor,
+                dst: torch.Tensor, *, R, L, C, label: str = ""):
+    """dst[r,l,:] = keep[r] & mask[src[r],l] ? a[src[r],l,:] : nul[l,:]   (mask/keep uint8, src int32)."""
+    p = STRUCTS["ImagenSelectRowsParams"]()
+    p.a, p.nul, p.mask, p.src, p.keep, p.dst = a.data_ptr(), nul.data_ptr(), ptr(mask), src.data_ptr(), keep.data_ptr(), dst.data_ptr()
+    p.R, p.L, p.C = R, L, C
+    plan.add(p, label or "select_rows", [a, nul, mask, src, keep, dst])
+    return p
+
+
+def mean_rows(plan: Plan, x: Act, out: Act, label: str = ""):
+    """out[b,:] = mean over the H*W rows of x[b]."""
+    p = STRUCTS["ImagenMeanRowsParams"]()
+    p.x, p.out = x.ptr, out.ptr
+    p.B, p.rows, p.C, p.bs_x, p.ld_x, p.ld_out = x.B, x.H * x.W, x.C, x.bs, x.ld, out.ld
+    assert out.rows == x.B and out.C == x.C
+    plan.add(p, label or "mean_rows", [x.t, out.t])
     return p
 
 
@@ -444,10 +467,14 @@ def memset32(plan: Plan, dst: torch.Tensor, value: int, count: Optional[int] = N
     return p
 
 
-def cfg_x0(plan: Plan, x, pred, coef, step_ptr, x0, absx0, *, B, n_per_sample, cfg: bool, cond_scale: float, label: str = ""):
+OBJECTIVES = {"noise": 0, "x_start": 1, "v": 2}
+
+
+def cfg_x0(plan: Plan, x, pred, coef, step_ptr, x0, absx0, *, B, n_per_sample, cfg: bool, cond_scale: float, objective: str = "noise",
+           label: str = ""):
     p = STRUCTS["ImagenCfgX0Params"]()
     p.x, p.pred, p.coef, p.step_ptr, p.x0, p.absx0 = x.data_ptr(), pred.data_ptr(), coef.data_ptr(), step_ptr.data_ptr(), x0.data_ptr(), absx0.data_ptr()
-    p.B, p.n_per_sample, p.cfg, p.cond_scale = B, n_per_sample, int(cfg), cond_scale
+    p.B, p.n_per_sample, p.cfg, p.cond_scale, p.objective = B, n_per_sample, int(cfg), cond_scale, OBJECTIVES[objective]
     plan.add(p, label or "cfg_x0", [x, pred, coef, step_ptr, x0, absx0])
     return p
 
@@ -461,11 +488,34 @@ def quantile(plan: Plan, absx0, out, scratch, *, B, n, q: float, label: str = ""
 
 
 def ddpm_update(plan: Plan, x, x0, quant, coef, noise, final_out, step_ptr, *, B, n_per_sample, dynamic_threshold: bool,
-                total_steps: int, seed: int, stream_id: int, label: str = ""):
+                total_steps: int, seed: int, stream_id: int, sample_offset: int = 0, seed_ptr: Optional[torch.Tensor] = None,
+                label: str = ""):
     p = STRUCTS["ImagenDdpmUpdateParams"]()
     p.x, p.x0, p.quant, p.coef, p.noise, p.final_out, p.step_ptr = (x.data_ptr(), x0.data_ptr(), ptr(quant), coef.data_ptr(), ptr(noise),
                                                                    ptr(final_out), step_ptr.data_ptr())
     p.B, p.n_per_sample, p.dynamic_threshold, p.total_steps = B, n_per_sample, int(dynamic_threshold), total_steps
+    p.sample_offset = sample_offset
+    p.seed_ptr = ptr(seed_ptr)
+    if seed_ptr is not None:
+        plan.keep.append(seed_ptr)
     p.seed_lo, p.seed_hi, p.stream_id = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, stream_id
     plan.add(p, label or "ddpm_update", [x, x0, quant, coef, noise, final_out, step_ptr])
+    return p
+
+
+def randn(plan: Plan, out: torch.Tensor, *, seed: int, stream_id: int, tag: int, sample_offset: int = 0, label: str = ""):
+    """out: fp32 [B, ...]; per-sample counter streams keyed by the GLOBAL sample index (shard-invariant noise)."""
+    p = STRUCTS["ImagenRandnParams"]()
+    p.out, p.B, p.n_per_sample, p.sample_offset = out.data_ptr(), out.shape[0], out[0].numel(), sample_offset
+    p.seed_lo, p.seed_hi, p.stream_id, p.tag = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, stream_id, tag
+    plan.add(p, label or "randn", [out])
+    return p
+
+
+def lowres_prep(plan: Plan, img: torch.Tensor, noise: torch.Tensor, out: torch.Tensor, *, alpha: float, sigma: float, label: str = ""):
+    p = STRUCTS["ImagenLowresPrepParams"]()
+    B, C, Hin, Win = img.shape
+    p.img, p.noise, p.out = img.data_ptr(), noise.data_ptr(), out.data_ptr()
+    p.B, p.C, p.Hin, p.Win, p.Hout, p.Wout, p.alpha, p.sigma = B, C, Hin, Win, out.shape[2], out.shape[3], alpha, sigma
+    plan.add(p, label or "lowres_prep", [img, noise, out])
     return p

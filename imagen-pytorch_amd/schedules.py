@@ -1,0 +1,74 @@
+"""Continuous-time Gaussian diffusion schedules (host side).
+
+Mirror of the reference's `GaussianDiffusionContinuousTimes` (ip.py:212-318) for the sampling path: the
+log-SNR schedules and the per-step scalar coefficients of the DDPM posterior.  These are O(T) scalars per
+stage — they are evaluated once on the host (fp32 torch on CPU, exactly the reference's formulas) and
+uploaded as a `[T, 8]` table that the sampler kernels index with the device step counter
+("precompute per-step scalar table on host").
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+from torch import nn
+
+
+def beta_linear_log_snr(t: torch.Tensor) -> torch.Tensor:
+    """ip.py:212-214."""
+    return -torch.log(torch.special.expm1(1e-4 + 10 * (t ** 2)))
+
+
+def alpha_cosine_log_snr(t: torch.Tensor, s: float = 0.008) -> torch.Tensor:
+    """ip.py:216-218 (its log() clamps at 1e-5)."""
+    return -torch.log(((torch.cos((t + s) / (1 + s) * math.pi * 0.5) ** -2) - 1).clamp(min=1e-5))
+
+
+def log_snr_to_alpha_sigma(log_snr: torch.Tensor):
+    """ip.py:220-221."""
+    return torch.sqrt(torch.sigmoid(log_snr)), torch.sqrt(torch.sigmoid(-log_snr))
+
+
+COEF_COLS = 8  # [alpha, sigma, alpha_next, sigma_next, c, nonzero, log_snr, 0] — layout shared with csrc/sampler.hip
+
+
+class GaussianDiffusionContinuousTimes(nn.Module):
+    def __init__(self, *, noise_schedule, timesteps=1000):
+        super().__init__()
+        if noise_schedule == "linear":
+            self.log_snr = beta_linear_log_snr
+        elif noise_schedule == "cosine":
+            self.log_snr = alpha_cosine_log_snr
+        else:
+            raise ValueError(f'invalid noise schedule {noise_schedule}')
+        self.noise_schedule = noise_schedule
+        self.num_timesteps = timesteps
+
+    def get_times(self, batch_size, noise_level, *, device=None):
+        return torch.full((batch_size,), noise_level, device=device, dtype=torch.float32)
+
+    def get_condition(self, times):
+        return None if times is None else self.log_snr(times)
+
+    def get_sampling_timesteps(self, batch=None, *, device=None):
+        """ip.py:245-250: T consecutive (t, t_next) pairs of linspace(1, 0, T+1), as fp32 scalars."""
+        times = torch.linspace(1., 0., self.num_timesteps + 1)
+        return [(times[i], times[i + 1]) for i in range(self.num_timesteps)]
+
+    def step_coefficients(self) -> torch.Tensor:
+        """[T, 8] fp32 table for the sampler kernels: ip.py:256-268 (posterior), 315-318 (x0), 2162-2163 (nonzero mask)."""
+        rows = []
+        for t, t_next in self.get_sampling_timesteps():
+            l, ln = self.log_snr(t), self.log_snr(t_next)
+            alpha, sigma = log_snr_to_alpha_sigma(l)
+            alpha_n, sigma_n = log_snr_to_alpha_sigma(ln)
+            c = -torch.special.expm1(l - ln)
+            nonzero = 0.0 if float(t_next) == 0.0 else 1.0
+            rows.append(torch.stack([alpha, sigma, alpha_n, sigma_n, c, torch.tensor(nonzero), l, torch.tensor(0.0)]))
+        return torch.stack(rows).float().contiguous()
+
+    def q_sample_coefficients(self, t: float):
+        """alpha, sigma of q(x_t | x_0) at noise level t (ip.py:272-284) as python floats (fp32-rounded)."""
+        l = self.log_snr(torch.tensor(t, dtype=torch.float32))
+        a, s = log_snr_to_alpha_sigma(l)
+        return float(a), float(s), float(l)

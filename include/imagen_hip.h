@@ -53,7 +53,11 @@ enum ImagenOpKind {
   IMAGEN_OP_DDPM_UPDATE = 15,  /* dynamic threshold + posterior mean/var + Philox noise                */
   IMAGEN_OP_ROWS_COPY = 16,    /* strided fp16 row copy / broadcast (token assembly)                   */
   IMAGEN_OP_MEMSET32 = 17,     /* fill fp32/int32 words                                                */
-  IMAGEN_OP_KIND_COUNT = 18
+  IMAGEN_OP_SELECT_ROWS = 18,  /* per-(row, token) select between text tokens and null_text_embed      */
+  IMAGEN_OP_MEAN_ROWS = 19,    /* mean over the token axis                                             */
+  IMAGEN_OP_RANDN = 20,        /* counter-based (Philox4x32-10) standard normal fill, keyed by global sample index */
+  IMAGEN_OP_LOWRES_PREP = 21,  /* nearest resize + normalise + noise-augment the previous stage's image  */
+  IMAGEN_OP_KIND_COUNT = 22
 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -170,7 +174,9 @@ typedef struct ImagenGateResidualParams {
  *   out = (y - mean)*rsqrt(var+eps)*g (+ beta) (+ res) */
 typedef struct ImagenLnResidualParams {
   const void* y; const float* g; const float* beta; const void* res; void* out;
-  int32_t rows, C, ld_y, ld_res, ld_out; float eps;
+  int32_t rows, C, ld_y, ld_res, ld_out;
+  int32_t rows_per_batch, bs_y, bs_res, bs_out; /* row r = (b, rr): address b*bs + rr*ld (rows_per_batch = rows if flat) */
+  float eps;
 } ImagenLnResidualParams;
 
 /* TIME_EMBED — LearnedSinusoidalPosEmb + Linear + SiLU ip.py:654-669, 1213-1217:
@@ -198,11 +204,12 @@ typedef struct ImagenPackImageParams {
   int32_t B, Brep, H, W, Ca, Cb, Cpad;
 } ImagenPackImageParams;
 
-/* CFG_X0 — ip.py:1522 + 314-318: eps = null + (cond-null)*s ; x0 = (x - sigma*eps)/max(alpha,1e-8);
+/* CFG_X0 — ip.py:1522 + 2085-2092: out = null + (cond-null)*s ; x0 = (x - sigma*out)/max(alpha,1e-8) (objective 0 = noise,
+ * ip.py:314-318) | out (1 = x_start) | alpha*x - sigma*out (2 = v, ip.py:308-312);
  * writes x0 and |x0| (for the quantile).  pred is [2B,...] (cond first) when cfg != 0, else [B,...]. */
 typedef struct ImagenCfgX0Params {
   const float* x; const float* pred; const float* coef; const int32_t* step_ptr; float* x0; float* absx0;
-  int32_t B, n_per_sample, cfg; float cond_scale;
+  int32_t B, n_per_sample, cfg, objective; float cond_scale;
 } ImagenCfgX0Params;
 
 /* QUANTILE — torch.quantile(|x0| per sample, q) ip.py:2097-2101 (linear interpolation), exact. */
@@ -217,15 +224,45 @@ typedef struct ImagenQuantileParams {
 typedef struct ImagenDdpmUpdateParams {
   float* x; const float* x0; const float* quant; const float* coef; const float* noise; float* final_out;
   int32_t* step_ptr; /* device step counter: read by every sampler kernel of the step, incremented at the end */
+  const uint32_t* seed_ptr; /* optional device [2] Philox key (overrides seed_lo/hi): lets one captured graph serve every sample() call */
   int32_t B, n_per_sample, dynamic_threshold, total_steps;
+  int32_t sample_offset; /* global index of local sample 0 (batch sharding: noise is keyed by the global sample index) */
   uint32_t seed_lo, seed_hi, stream_id;
 } ImagenDdpmUpdateParams;
+
+/* RANDN — out[b, i] ~ N(0,1), Philox4x32-10 counter (i/4, tag, stream_id, sample_offset + b), key = seed.
+ * Replaces torch.randn at ip.py:2195 (initial image) and ip.py:2449 (low-res augmentation noise). */
+typedef struct ImagenRandnParams {
+  float* out;
+  int32_t B, n_per_sample, sample_offset;
+  uint32_t seed_lo, seed_hi, stream_id, tag;
+} ImagenRandnParams;
+
+/* LOWRES_PREP — ip.py:2446-2449: nearest-neighbour resize (F.interpolate 'nearest') of the previous stage's [0,1] image,
+ * normalise to [-1,1], noise-augment: out = alpha * (2*img - 1) + sigma * noise   (fp32 NCHW). */
+typedef struct ImagenLowresPrepParams {
+  const float* img; const float* noise; float* out;
+  int32_t B, C, Hin, Win, Hout, Wout; float alpha, sigma;
+} ImagenLowresPrepParams;
 
 /* ROWS_COPY — dst[b, r0 + r, :C] = src[b (or 0), r, :C]  (fp16). */
 typedef struct ImagenRowsCopyParams {
   const void* src; void* dst;
   int32_t B, rows, C, src_bs, src_rs, dst_bs, dst_rs;
 } ImagenRowsCopyParams;
+
+/* SELECT_ROWS — text keep-mask select ip.py:1599-1632:
+ *   dst[r, l, :] = (keep[r] && (mask == NULL || mask[src[r], l])) ? a[src[r], l, :] : nul[l, :]      (fp16 rows of C) */
+typedef struct ImagenSelectRowsParams {
+  const void* a; const void* nul; const uint8_t* mask; const int32_t* src; const uint8_t* keep; void* dst;
+  int32_t R, L, C;
+} ImagenSelectRowsParams;
+
+/* MEAN_ROWS — out[b, :] = mean_r x[b, r, :]  (masked_mean with an all-true mask ip.py:490; text_tokens.mean ip.py:1640). */
+typedef struct ImagenMeanRowsParams {
+  const void* x; void* out;
+  int32_t B, rows, C, bs_x, ld_x, ld_out;
+} ImagenMeanRowsParams;
 
 typedef struct ImagenMemset32Params { void* dst; uint32_t value; int32_t count; } ImagenMemset32Params;
 

@@ -1,0 +1,117 @@
+"""Generate the golden fixtures under tests/golden/ from the LIVE REFERENCE (build container only).
+
+    python -m oracle.make_golden
+
+The reference (lucidrains/imagen-pytorch at /root/reference) ships no golden vectors for the sampling path
+(SURVEY.md §4), and it cannot travel to the GPU box, so this script imports it through oracle/ref_shim.py,
+runs its own `Unet.forward`, `Unet.forward_with_cond_scale` and `Imagen.sample` on small seeded problems and
+records inputs, weights (state_dict), every Gaussian draw and the outputs.  The fixtures pin
+  * oracle/unet_oracle.py + oracle/sampler_oracle.py  (tests/test_oracle_golden.py, CPU), and
+  * the HIP path                                       (tests/test_model_gpu.py, MI355X)
+to the reference's actual numbers.  Nothing from the reference's sources is copied; only tensors are stored.
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle.ref_shim import load_reference  # noqa: E402
+
+GOLDEN = os.path.join(ROOT, "tests", "golden")
+
+TINY_BASE = dict(dim=8, cond_dim=32, text_embed_dim=32, dim_mults=(1, 2), num_resnet_blocks=1, layer_attns=(False, True),
+                 layer_cross_attns=(False, True), attn_heads=2, attn_dim_head=64, max_text_len=16, attn_pool_num_latents=8)
+TINY_SR = dict(dim=8, cond_dim=32, text_embed_dim=32, dim_mults=(1, 2), num_resnet_blocks=(1, 2), layer_attns=(False, True),
+               layer_cross_attns=(False, True), attn_heads=2, attn_dim_head=64, max_text_len=16, attn_pool_num_latents=8, lowres_cond=True)
+
+
+def _derandomise(unet):
+    """final_conv is zero-initialised in the reference (ip.py:1438): a fresh Unet outputs exact zeros. Give it weights."""
+    torch.nn.init.normal_(unet.final_conv.weight, std=0.3)
+    torch.nn.init.normal_(unet.final_conv.bias, std=0.3)
+
+
+def make_unet_fixture(ip, kwargs, size, seed, path):
+    torch.manual_seed(seed)
+    unet = ip.Unet(**kwargs).eval()
+    _derandomise(unet)
+    B = 2
+    x = torch.randn(B, 3, size, size)
+    time = torch.tensor([0.7, -2.3])                      # log-SNR conditions
+    text_embeds = torch.randn(B, 11, kwargs["text_embed_dim"])
+    text_mask = torch.ones(B, 11, dtype=torch.bool)
+    text_mask[1, 7:] = False
+    extra = {}
+    if kwargs.get("lowres_cond"):
+        extra = dict(lowres_cond_img=torch.randn(B, 3, size, size), lowres_noise_times=torch.tensor([1.1, 1.1]))
+    with torch.no_grad():
+        out_cond = unet(x, time, text_embeds=text_embeds, text_mask=text_mask, **extra)
+        out_null = unet(x, time, text_embeds=text_embeds, text_mask=text_mask, cond_drop_prob=1., **extra)
+        out_cfg = unet.forward_with_cond_scale(x, time, text_embeds=text_embeds, text_mask=text_mask, cond_scale=3., **extra)
+    torch.save(dict(kwargs=kwargs, state_dict={k: v.clone() for k, v in unet.state_dict().items()}, x=x, time=time,
+                    text_embeds=text_embeds, text_mask=text_mask, extra=extra, out_cond=out_cond, out_null=out_null, out_cfg=out_cfg,
+                    generator="oracle/make_golden.py", reference="lucidrains/imagen-pytorch v2.0.0 Unet.forward (ip.py:1524-1725)"), path)
+    print(f"wrote {path}: |out_cond| = {out_cond.abs().mean():.4f}")
+
+
+def make_sample_fixture(ip, path, seed=7, T=3):
+    torch.manual_seed(seed)
+    u1, u2 = ip.Unet(**TINY_BASE), ip.Unet(**{k: v for k, v in TINY_SR.items() if k != "lowres_cond"})
+    imagen = ip.Imagen((u1, u2), image_sizes=(16, 32), timesteps=T, text_embed_dim=32, cond_drop_prob=0.1).eval()
+    for u in imagen.unets:
+        _derandomise(u)
+    text_embeds = torch.randn(2, 9, 32)
+    # record every Gaussian draw of the reference, in order
+    draws = []
+    real_randn, real_randn_like = torch.randn, torch.randn_like
+
+    def rec_randn(*a, **k):
+        t = real_randn(*a, **k)
+        draws.append(t.clone())
+        return t
+
+    def rec_randn_like(x, **k):
+        t = real_randn_like(x, **k)
+        draws.append(t.clone())
+        return t
+
+    torch.randn, torch.randn_like = rec_randn, rec_randn_like
+    try:
+        outs = imagen.sample(text_embeds=text_embeds, cond_scale=3., use_tqdm=False, return_all_unet_outputs=True)
+    finally:
+        torch.randn, torch.randn_like = real_randn, real_randn_like
+    # order of draws (ip.py:2449, 2195, 2160): stage 0: init, T steps; stage 1: lowres aug, init, T steps
+    noise = {}
+    it = iter(draws)
+    for stage in range(2):
+        if stage > 0:
+            noise[("lowres", stage)] = next(it)
+        noise[("init", stage)] = next(it)
+        for i in range(T):
+            noise[("step", stage, i)] = next(it)
+    assert next(it, None) is None
+    unets = []
+    for i, (u, kw) in enumerate(zip(imagen.unets, (TINY_BASE, TINY_SR))):
+        unets.append(dict(kwargs={**{k: v for k, v in kw.items() if k != "lowres_cond"}, "lowres_cond": i > 0},
+                          state_dict={k: v.clone() for k, v in u.state_dict().items()}))
+    torch.save(dict(unets=unets, image_sizes=(16, 32), timesteps=T, cond_scale=3., text_embeds=text_embeds, noise=noise,
+                    outputs=[o.clone() for o in outs], generator="oracle/make_golden.py",
+                    reference="lucidrains/imagen-pytorch v2.0.0 Imagen.sample (ip.py:2291-2498)"), path)
+    print(f"wrote {path}: out std {outs[-1].std():.4f}")
+
+
+def main():
+    ip = load_reference()
+    os.makedirs(GOLDEN, exist_ok=True)
+    make_unet_fixture(ip, TINY_BASE, 16, 11, os.path.join(GOLDEN, "unet_tiny_base.pt"))
+    make_unet_fixture(ip, TINY_SR, 32, 12, os.path.join(GOLDEN, "unet_tiny_sr.pt"))
+    make_sample_fixture(ip, os.path.join(GOLDEN, "sample_tiny_cascade.pt"))
+
+
+if __name__ == "__main__":
+    main()

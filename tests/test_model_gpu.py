@@ -1,0 +1,160 @@
+"""MI355X: the whole HIP denoiser / sampler (through the C ABI) against
+  (a) golden fixtures recorded from the live reference (tests/golden/, oracle/make_golden.py), and
+  (b) the CPU oracle (oracle/) on README-sized unets with identical weights and inputs.
+
+Tolerances (normwise relative error ||y - y_ref|| / ||y_ref||, fp16 storage / fp32 accumulate):
+  * whole Unet forward:  <= 5e-3.  The reference's own fp16-autocast forward sits 2.5e-3 from its fp32 forward
+    (SURVEY.md §8c calibration); per-kernel parity on identical inputs is held to 1e-3 in test_kernels_gpu.py.
+  * sampler epilogue on identical inputs: 1e-5 (fp32 math), quantile exact.
+"""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+UNET_TOL = 5e-3
+
+
+def nerr(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / b.norm().clamp(min=1e-12)).item()
+
+
+def _load(name):
+    return torch.load(os.path.join(GOLDEN, name), weights_only=False)
+
+
+def _build(kwargs, state_dict, dev):
+    from imagen_pytorch_amd import Unet
+
+    u = Unet(**kwargs).eval()
+    u.load_state_dict(state_dict)
+    return u.to(dev)
+
+
+def _tap_report(eng, taps_ref):
+    """Per-stage normwise errors of the engine's persistent intermediates vs the oracle's taps (cond rows only)."""
+    from imagen_pytorch_amd import ops
+
+    rep = {}
+    for name, act in eng.taps.items():
+        if name in taps_ref:
+            ref = taps_ref[name]
+            got = ops.act_to_nchw(act)[: ref.shape[0]]
+            rep[name] = nerr(got, ref)
+    return rep
+
+
+@pytest.mark.parametrize("name", ["unet_tiny_base.pt", "unet_tiny_sr.pt"])
+def test_unet_forward_vs_reference_fixture(name):
+    dev = torch.device("cuda:0")
+    g = _load(name)
+    u = _build(g["kwargs"], g["state_dict"], dev)
+    ex = {k: v.to(dev) for k, v in g["extra"].items()}
+    kw = dict(text_embeds=g["text_embeds"].to(dev), text_mask=g["text_mask"].to(dev), **ex)
+    x, t = g["x"].to(dev), g["time"].to(dev)
+    cond = u(x, t, **kw)
+    null = u(x, t, cond_drop_prob=1.0, **kw)
+    cfg = u.forward_with_cond_scale(x, t, cond_scale=3.0, **kw)
+    errs = dict(cond=nerr(cond, g["out_cond"]), null=nerr(null, g["out_null"]), cfg=nerr(cfg, g["out_cfg"]))
+    print(name, errs)
+    assert max(errs.values()) < UNET_TOL, errs
+
+
+README_U1 = dict(dim=32, cond_dim=512, dim_mults=(1, 2, 4, 8), num_resnet_blocks=3, layer_attns=(False, True, True, True),
+                 layer_cross_attns=(False, True, True, True))
+README_U2 = dict(dim=32, cond_dim=512, dim_mults=(1, 2, 4, 8), num_resnet_blocks=(2, 4, 8, 8), layer_attns=(False, False, False, True),
+                 layer_cross_attns=(False, False, False, True), lowres_cond=True)
+MEMEFF = dict(dim=32, cond_dim=64, dim_mults=(1, 2, 4), num_resnet_blocks=(1, 2, 2), layer_attns=(False, False, True),
+              layer_cross_attns=(False, True, True), memory_efficient=True, lowres_cond=True, attn_heads=4)
+
+
+@pytest.mark.parametrize("kw,S", [(README_U1, 64), (README_U2, 64), (MEMEFF, 32)], ids=["readme-unet1@64", "readme-unet2@64", "memory-efficient@32"])
+def test_unet_forward_vs_oracle(kw, S):
+    """README-sized unets (32-channel-chunk MFMA paths, 1024-token attention) vs the fp32 CPU oracle, stage by stage."""
+    from imagen_pytorch_amd import Unet
+    from oracle import unet_oracle as uo
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    u = Unet(**kw).eval()
+    torch.nn.init.normal_(u.final_conv.weight, std=0.05)
+    torch.nn.init.normal_(u.final_conv.bias, std=0.05)
+    sd = {k: v.clone() for k, v in u.state_dict().items()}
+    B = 2
+    x, t = torch.randn(B, 3, S, S), torch.tensor([0.3, -1.2])
+    te = torch.randn(B, 24, kw.get("text_embed_dim", 768))
+    mask = torch.ones(B, 24, dtype=torch.bool)
+    mask[1, 18:] = False
+    extra = dict(lowres_cond_img=torch.randn(B, 3, S, S), lowres_noise_times=torch.tensor([0.5, 0.5])) if kw.get("lowres_cond") else {}
+    taps = {}
+    with torch.no_grad():
+        ref = uo.unet_forward(sd, kw, x, t, text_embeds=te, text_mask=mask, taps=taps, **extra)
+        ref_null = uo.unet_forward(sd, kw, x, t, text_embeds=te, text_mask=mask, cond_drop_prob=1.0, **extra)
+    u = u.to(dev)
+    exd = {k: v.to(dev) for k, v in extra.items()}
+    got = u(x.to(dev), t.to(dev), text_embeds=te.to(dev), text_mask=mask.to(dev), **exd)
+    eng = next(iter(u._engines.values()))
+    rep = _tap_report(eng, taps)
+    print("per-stage normwise error:", {k: f"{v:.1e}" for k, v in rep.items()})
+    e = nerr(got, ref)
+    got_null = u(x.to(dev), t.to(dev), text_embeds=te.to(dev), text_mask=mask.to(dev), cond_drop_prob=1.0, **exd)
+    e_null = nerr(got_null, ref_null)
+    print(f"forward normwise error cond {e:.2e} null {e_null:.2e}")
+    assert e < UNET_TOL and e_null < UNET_TOL, (e, e_null, rep)
+    # the CFG batch (2B rows in one plan) must agree with the two separate evaluations
+    cfg = u.forward_with_cond_scale(x.to(dev), t.to(dev), text_embeds=te.to(dev), text_mask=mask.to(dev), cond_scale=3.0, **exd)
+    ref_cfg = ref_null + (ref - ref_null) * 3.0
+    assert nerr(cfg, ref_cfg) < 2 * UNET_TOL
+
+
+def test_sample_vs_reference_fixture():
+    """Imagen.sample (2-stage cascade, CFG 3, dynamic thresholding) fed the reference's recorded Gaussian draws."""
+    from imagen_pytorch_amd import Imagen, Unet
+
+    dev = torch.device("cuda:0")
+    g = _load("sample_tiny_cascade.pt")
+    unets = []
+    for spec in g["unets"]:
+        kw = {k: v for k, v in spec["kwargs"].items()}
+        u = Unet(**kw).eval()
+        u.load_state_dict(spec["state_dict"])
+        unets.append(u)
+    imagen = Imagen(unets, image_sizes=g["image_sizes"], timesteps=g["timesteps"], text_embed_dim=32, cond_drop_prob=0.1).to(dev)
+    for u, spec in zip(imagen.unets, g["unets"]):   # cast_model_parameters may have re-instantiated: reload
+        u.load_state_dict(spec["state_dict"])
+    noise_fn = lambda tag, shape: g["noise"][tag].to(dev)
+    results = {}
+    for use_graph in (False, True):
+        outs = imagen.sample(text_embeds=g["text_embeds"].to(dev), cond_scale=g["cond_scale"], use_tqdm=False, return_all_unet_outputs=True,
+                             noise_fn=noise_fn, use_graph=use_graph)
+        errs = [nerr(o, r) for o, r in zip(outs, g["outputs"])]
+        print("graph" if use_graph else "eager", errs)
+        results[use_graph] = outs
+        assert max(errs) < 2e-2, errs   # T steps of an fp16 denoiser through a chaotic sampler; per-step parity is checked above
+    for a, b in zip(results[False], results[True]):
+        assert torch.equal(a, b), "hipGraph replay must be bit-identical to eager launches"
+
+
+def test_sample_philox_determinism_and_sharding():
+    """In-kernel Philox noise: same seed -> identical images; noise is keyed by the GLOBAL sample index, so a batch
+    shard (sample_offset) reproduces the corresponding rows of the unsharded run (SURVEY.md §8e parity test)."""
+    from imagen_pytorch_amd import Imagen, Unet
+
+    dev = torch.device("cuda:0")
+    g = _load("sample_tiny_cascade.pt")
+    unets = [Unet(**spec["kwargs"]).eval() for spec in g["unets"]]
+    imagen = Imagen(unets, image_sizes=g["image_sizes"], timesteps=4, text_embed_dim=32, cond_drop_prob=0.1).to(dev)
+    for u, spec in zip(imagen.unets, g["unets"]):
+        u.load_state_dict(spec["state_dict"])
+    te = torch.randn(4, 9, 32, device=dev)
+    a = imagen.sample(text_embeds=te, cond_scale=3.0, use_tqdm=False, seed=99)
+    b = imagen.sample(text_embeds=te, cond_scale=3.0, use_tqdm=False, seed=99)
+    c = imagen.sample(text_embeds=te, cond_scale=3.0, use_tqdm=False, seed=100)
+    assert torch.equal(a, b) and not torch.equal(a, c)
+    assert a.shape == (4, 3, 32, 32) and a.min() >= 0 and a.max() <= 1 and torch.isfinite(a).all()
+    hi = imagen.sample(text_embeds=te[2:], cond_scale=3.0, use_tqdm=False, seed=99, sample_offset=2)
+    assert nerr(hi, a[2:]) < 1e-5

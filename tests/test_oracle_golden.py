@@ -1,0 +1,56 @@
+"""CPU: the oracle restatement (oracle/) against the golden fixtures generated from the live reference by
+oracle/make_golden.py.  These fixtures travel to the GPU box, so the oracle is pinned there too."""
+import os
+
+import pytest
+import torch
+
+from oracle import sampler_oracle as so
+from oracle import unet_oracle as uo
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def _load(name):
+    return torch.load(os.path.join(GOLDEN, name), weights_only=False)
+
+
+@pytest.mark.parametrize("name", ["unet_tiny_base.pt", "unet_tiny_sr.pt"])
+def test_unet_oracle_matches_reference_fixture(name):
+    g = _load(name)
+    kw = dict(text_embeds=g["text_embeds"], text_mask=g["text_mask"], **g["extra"])
+    with torch.no_grad():
+        cond = uo.unet_forward(g["state_dict"], g["kwargs"], g["x"], g["time"], **kw)
+        null = uo.unet_forward(g["state_dict"], g["kwargs"], g["x"], g["time"], cond_drop_prob=1.0, **kw)
+        cfg = uo.unet_forward_with_cond_scale(g["state_dict"], g["kwargs"], g["x"], g["time"], cond_scale=3.0, **kw)
+    for got, ref in ((cond, g["out_cond"]), (null, g["out_null"]), (cfg, g["out_cfg"])):
+        assert ref.abs().mean() > 0.05, "vacuous fixture (zero-initialised final_conv?)"
+        assert torch.allclose(got, ref, atol=2e-5, rtol=1e-5), (got - ref).abs().max()
+
+
+def test_sampler_oracle_matches_reference_fixture():
+    g = _load("sample_tiny_cascade.pt")
+    unets = [(u["state_dict"], u["kwargs"]) for u in g["unets"]]
+    noise_fn = lambda tag, shape: g["noise"][tag]
+    with torch.no_grad():
+        outs = so.imagen_sample(unets, g["image_sizes"], g["text_embeds"], timesteps=g["timesteps"], cond_scale=g["cond_scale"],
+                                noise_fn=noise_fn, return_all=True)
+    for got, ref in zip(outs, g["outputs"]):
+        assert got.shape == ref.shape
+        assert torch.allclose(got, ref, atol=2e-4), (got - ref).abs().max()
+
+
+def test_schedule_tables_match_oracle():
+    """Host coefficient table (imagen-pytorch_amd/schedules.py) vs the oracle's per-step formulas."""
+    from imagen_pytorch_amd.schedules import GaussianDiffusionContinuousTimes
+
+    for sched in ("cosine", "linear"):
+        T = 17
+        tab = GaussianDiffusionContinuousTimes(noise_schedule=sched, timesteps=T).step_coefficients()
+        pairs = so.sampling_time_pairs(T)
+        for i, (t, tn) in enumerate(pairs):
+            l, ln = so.SCHEDULES[sched](t), so.SCHEDULES[sched](tn)
+            a, s = so.alpha_sigma(l)
+            an, sn = so.alpha_sigma(ln)
+            ref = torch.stack([a, s, an, sn, -torch.special.expm1(l - ln), torch.tensor(0.0 if tn == 0 else 1.0), l])
+            assert torch.equal(tab[i, :7], ref)

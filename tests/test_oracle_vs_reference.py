@@ -1,0 +1,68 @@
+"""Build-container only: the oracle restatement against the LIVE reference (imported through oracle/ref_shim.py)
+on README-sized unets.  Skipped wherever /root/reference is absent (e.g. the GPU box)."""
+import pytest
+import torch
+
+from oracle import ref_shim
+from oracle import sampler_oracle as so
+from oracle import unet_oracle as uo
+
+pytestmark = [pytest.mark.reference, pytest.mark.skipif(not ref_shim.reference_available(), reason="reference tree not present")]
+
+U1 = dict(dim=32, cond_dim=512, dim_mults=(1, 2, 4, 8), num_resnet_blocks=3, layer_attns=(False, True, True, True),
+          layer_cross_attns=(False, True, True, True))
+U2 = dict(dim=32, cond_dim=512, dim_mults=(1, 2, 4, 8), num_resnet_blocks=(2, 4, 8, 8), layer_attns=(False, False, False, True),
+          layer_cross_attns=(False, False, False, True), lowres_cond=True)
+
+
+def _dezero(u):
+    torch.nn.init.normal_(u.final_conv.weight, std=0.05)
+    torch.nn.init.normal_(u.final_conv.bias, std=0.05)
+
+
+@pytest.mark.parametrize("kw", [U1, U2], ids=["readme-unet1", "readme-unet2"])
+def test_unet_forward(kw):
+    ip = ref_shim.load_reference()
+    torch.manual_seed(0)
+    u = ip.Unet(**kw).eval()
+    _dezero(u)
+    B, S = 1, 32
+    x, t = torch.randn(B, 3, S, S), torch.tensor([0.3])
+    te = torch.randn(B, 20, 768)
+    extra = dict(lowres_cond_img=torch.randn(B, 3, S, S), lowres_noise_times=torch.tensor([0.5])) if kw.get("lowres_cond") else {}
+    with torch.no_grad():
+        for cdp in (0.0, 1.0):
+            r = u(x, t, text_embeds=te, cond_drop_prob=cdp, **extra)
+            o = uo.unet_forward(u.state_dict(), kw, x, t, text_embeds=te, cond_drop_prob=cdp, **extra)
+            assert torch.allclose(r, o, atol=1e-5), (r - o).abs().max()
+
+
+def test_state_dict_layout_is_interchangeable():
+    """The drop-in Unet must load a reference state_dict strictly (same keys, shapes, order)."""
+    from imagen_pytorch_amd.unet import Unet
+
+    ip = ref_shim.load_reference()
+    for kw in (U1, U2, dict(dim=16, dim_mults=(1, 2), memory_efficient=True, lowres_cond=True, attn_heads=2)):
+        ref = ip.Unet(**kw)
+        ours = Unet(**kw)
+        assert list(ref.state_dict().keys()) == list(ours.state_dict().keys())
+        ours.load_state_dict(ref.state_dict())
+
+
+def test_sampler_small_cascade():
+    ip = ref_shim.load_reference()
+    torch.manual_seed(0)
+    k1 = dict(dim=8, cond_dim=32, dim_mults=(1, 2), num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True), attn_heads=2)
+    k2 = dict(dim=8, cond_dim=32, dim_mults=(1, 2), num_resnet_blocks=(1, 2), layer_attns=(False, True), layer_cross_attns=(False, True),
+              attn_heads=2, memory_efficient=True)
+    im = ip.Imagen((ip.Unet(**k1), ip.Unet(**k2)), image_sizes=(16, 32), timesteps=4, text_embed_dim=768, cond_drop_prob=0.1)
+    for u in im.unets:
+        _dezero(u)
+    te = torch.randn(2, 7, 768)
+    torch.manual_seed(123)
+    ref = im.sample(text_embeds=te, cond_scale=3., use_tqdm=False, return_all_unet_outputs=True)
+    torch.manual_seed(123)  # identical CPU RNG stream: the oracle draws in the reference's order
+    unets = [(u.state_dict(), {**kw, "lowres_cond": i > 0}) for i, (u, kw) in enumerate(zip(im.unets, (k1, k2)))]
+    got = so.imagen_sample(unets, (16, 32), te, timesteps=4, cond_scale=3., return_all=True)
+    for a, b in zip(ref, got):
+        assert torch.allclose(a, b, atol=5e-4), (a - b).abs().max()
