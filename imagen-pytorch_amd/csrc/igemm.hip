@@ -20,9 +20,11 @@ constexpr int kMaxItems = 6;  // 16B staging items per thread per chunk
 
 constexpr TileCfg kCfgs[] = {
     {2, 1, 4, 1, 4},  // 0: 256 px x  32 co, 32-ch chunks   (C_out = 32 layers, 256^2/128^2 levels)
-    {2, 2, 2, 2, 4},  // 1: 128 px x 128 co
-    {2, 2, 4, 1, 4},  // 2: 256 px x  64 co
-    {1, 2, 2, 2, 4},  // 3:  64 px x 128 co                (small feature maps, token GEMMs)
+    // wave tilings put ALL pixels of the tile on every wave and split the output channels across waves where possible:
+    // a weight fragment (streamed from L2, 16 B/lane) then feeds MI MFMAs and no two waves fetch the same one
+    {4, 1, 1, 4, 4},  // 1: 128 px x 128 co
+    {4, 1, 2, 2, 4},  // 2: 256 px x  64 co
+    {2, 1, 1, 4, 4},  // 3:  64 px x 128 co                (small feature maps, token GEMMs)
     {1, 1, 4, 1, 4},  // 4: 128 px x  32 co
     {2, 1, 4, 1, 1},  // 5: 256 px x  32 co,  8-ch chunks   (15x15 cross-embed conv, C_in = 3|6 padded to 8)
     {1, 1, 2, 2, 4},  // 6:  64 px x  64 co
@@ -37,7 +39,10 @@ template <int G> struct Geo {
   static constexpr int PS = (G == 1) ? 16 : (G * 16 + 16);  // LDS bytes per staged pixel (16B pad: conflict-free ds_read_b128)
 };
 
-template <int MI, int NI, int WM, int WN, int G>
+// KSC > 0: the number of K=16 steps per channel chunk is a compile-time constant (18 for 3x3 convs with 32-channel
+// chunks, 2 for 1x1 / linear, 8 for the 2x2 stride-2 downsample): the k-loop is fully unrolled so the weight-fragment ring is
+// statically indexed (no register copies of in-flight loads, which would force a vmcnt wait every step).  KSC == 0: generic loop.
+template <int MI, int NI, int WM, int WN, int G, int KSC>
 __global__ __launch_bounds__(256) void igemm_kernel(const ImagenIgemmParams p) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr int BN = 32 * NI * WN;
@@ -73,7 +78,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ImagenIgemmParams p) {
 
   const int ntap = p.KH * p.KW;
   const int KG = ntap * G;            // 8-channel groups per chunk
-  const int KS = (KG + 1) >> 1;       // K=16 MFMA steps per chunk (odd KG: last half-step is zero weights)
+  const int KS = KSC > 0 ? KSC : (KG + 1) >> 1;  // K=16 MFMA steps per chunk (odd KG: last half-step is zero weights)
   const int NC = p.Cin_pad / KC;      // chunks
 
   // ---- per-lane output pixel coordinates (lane = pixel in the MFMA N dimension)
@@ -185,26 +190,24 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ImagenIgemmParams p) {
   };
 
   // ---- weight fragment pipeline (continuous over chunks)
-  f16x8 wcur[NI], wnxt[NI];
+  // wq[j] holds the fragments of K=16 step (gstep + j); wptr always points at step (gstep + kLookAhead)
+  constexpr int kLookAhead = KSC == 0 ? 1 : (KSC >= 6 ? 6 : KSC);
+  f16x8 wq[kLookAhead][NI];
   const f16x8* wptr = wbase;
-  const int total_steps = NC * KS;
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni) wcur[ni] = wptr[ni * 32];
-  int gstep = 0;
+  for (int j = 0; j < kLookAhead; ++j) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) wq[j][ni] = wptr[ni * 32];
+    wptr += wstep;
+  }
+  static_assert(kLookAhead <= 8, "packed weights carry a zero tail of 8 steps");
 
   auto compute = [&](const char* buf) {
     // (dy, dx, group) walk of this lane's 8-channel group: kg = 2*ks + half
     int dy = 0, dx = 0, cgp = 0;  // G >= 2: uniform walk, group = 2*cgp + half
     int tap_l = half;             // G == 1: per-lane tap walk (tap = 2*ks + half), kept as (ty_l, tx_l) incrementally
     int ty_l = half / p.KW, tx_l = half - ty_l * p.KW;
-    for (int ks = 0; ks < KS; ++ks) {
-      // prefetch next step's weight fragments
-      ++gstep;
-      wptr += wstep;
-      if (gstep < total_steps) {
-#pragma unroll
-        for (int ni = 0; ni < NI; ++ni) wnxt[ni] = wptr[ni * 32];
-      }
+    auto next_aoff = [&]() -> int {  // LDS offset of this lane's fragment for the next K=16 step, advancing the walk
       int aoff;
       if (G == 1) {
         // padded half-step (tap_l == ntap): any valid address works, its weights are zero
@@ -219,16 +222,46 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ImagenIgemmParams p) {
           if (++dx == p.KW) { dx = 0; ++dy; }
         }
       }
-      f16x8 afrag[MI];
+      return aoff;
+    };
+    // activation fragments are register-prefetched one step ahead: the ds_read latency of step k+1 hides under the MFMAs of k
+    f16x8 afrag[MI], anext[MI];
+    {
+      const int a0 = next_aoff();
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) afrag[mi] = *reinterpret_cast<const f16x8*>(buf + a_base[mi] + aoff);
+      for (int mi = 0; mi < MI; ++mi) afrag[mi] = *reinterpret_cast<const f16x8*>(buf + a_base[mi] + a0);
+    }
+    auto do_step = [&](int ks) {
+      // prefetch the weight fragments kLookAhead steps ahead (L2 latency ~ 2-3 MFMA groups)
+      // (unconditional: the packed buffer carries a zero tail of kTailSteps steps, so reads past the last step stay in bounds)
+      f16x8 wnew[NI];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wnew[ni] = wptr[ni * 32];
+      wptr += wstep;
+      if (ks + 1 < KS) {
+        const int a1 = next_aoff();
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) anext[mi] = *reinterpret_cast<const f16x8*>(buf + a_base[mi] + a1);
+      }
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wcur[ni], afrag[mi], acc[ni][mi], 0, 0, 0);
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[0][ni], afrag[mi], acc[ni][mi], 0, 0, 0);
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) wcur[ni] = wnxt[ni];
+      for (int mi = 0; mi < MI; ++mi) afrag[mi] = anext[mi];
+#pragma unroll
+      for (int j = 0; j + 1 < kLookAhead; ++j)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) wq[j][ni] = wq[j + 1][ni];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wq[kLookAhead - 1][ni] = wnew[ni];
+    };
+    if constexpr (KSC > 0) {
+#pragma unroll
+      for (int ks = 0; ks < KSC; ++ks) do_step(ks);
+    } else {
+      for (int ks = 0; ks < KS; ++ks) do_step(ks);
     }
   };
 
@@ -239,9 +272,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ImagenIgemmParams p) {
   int cur = 0;
   for (int chunk = 0; chunk < NC; ++chunk) {
     const bool more = chunk + 1 < NC;
-    if (more) stage_load(chunk + 1);
-    compute(smem + cur * buf_bytes);
-    if (more) stage_write(chunk + 1, smem + (cur ^ 1) * buf_bytes);
+    const bool restage = more && !(p.dbg & 1);
+    if (restage) stage_load(chunk + 1);
+    if (!(p.dbg & 2)) compute(smem + cur * buf_bytes);
+    if (restage) stage_write(chunk + 1, smem + (cur ^ 1) * buf_bytes);
     __syncthreads();
     cur ^= 1;
   }
@@ -304,8 +338,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ImagenIgemmParams p) {
   }
 }
 
-template <int MI, int NI, int WM, int WN, int G>
-int launch_cfg(const ImagenIgemmParams& p, hipStream_t s) {
+template <int MI, int NI, int WM, int WN, int G, int KSC>
+int launch_ksc(const ImagenIgemmParams& p, hipStream_t s) {
   constexpr int TP = 32 * MI * WM, BN = 32 * NI * WN;
   const int ITW = (p.TW - 1) * p.stride + p.KW, ITH = (p.TH - 1) * p.stride + p.KH;
   const int IT = ITH * ITW;
@@ -319,7 +353,7 @@ int launch_cfg(const ImagenIgemmParams& p, hipStream_t s) {
   IMAGEN_CHECK(p.out_mode != IMAGEN_OUT_PIXEL_SHUFFLE || p.Cout % 16 == 0, "igemm: pixel-shuffle needs Cout %% 16 == 0");
   const size_t lds = (size_t)2 * IT * Geo<G>::PS;
   IMAGEN_CHECK(lds <= 160 * 1024, "igemm: LDS tile %zu bytes too large", lds);
-  auto kern = igemm_kernel<MI, NI, WM, WN, G>;
+  auto kern = igemm_kernel<MI, NI, WM, WN, G, KSC>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -332,6 +366,17 @@ int launch_cfg(const ImagenIgemmParams& p, hipStream_t s) {
   return imagen_hip_status("igemm launch");
 }
 
+template <int MI, int NI, int WM, int WN, int G>
+int launch_cfg(const ImagenIgemmParams& p, hipStream_t s) {
+  const int ks = (p.KH * p.KW * G + 1) / 2;
+  if (G == 4) {
+    if (ks == 18) return launch_ksc<MI, NI, WM, WN, G, (G == 4 ? 18 : 0)>(p, s);
+    if (ks == 2) return launch_ksc<MI, NI, WM, WN, G, (G == 4 ? 2 : 0)>(p, s);
+    if (ks == 8) return launch_ksc<MI, NI, WM, WN, G, (G == 4 ? 8 : 0)>(p, s);
+  }
+  return launch_ksc<MI, NI, WM, WN, G, 0>(p, s);
+}
+
 }  // namespace
 
 int launch_igemm(const ImagenIgemmParams* pp, hipStream_t s) {
@@ -341,9 +386,9 @@ int launch_igemm(const ImagenIgemmParams* pp, hipStream_t s) {
   IMAGEN_CHECK(!p.addend || p.gate, "igemm: addend requires gate");
   switch (p.cfg) {
     case 0: return launch_cfg<2, 1, 4, 1, 4>(p, s);
-    case 1: return launch_cfg<2, 2, 2, 2, 4>(p, s);
-    case 2: return launch_cfg<2, 2, 4, 1, 4>(p, s);
-    case 3: return launch_cfg<1, 2, 2, 2, 4>(p, s);
+    case 1: return launch_cfg<4, 1, 1, 4, 4>(p, s);
+    case 2: return launch_cfg<4, 1, 2, 2, 4>(p, s);
+    case 3: return launch_cfg<2, 1, 1, 4, 4>(p, s);
     case 4: return launch_cfg<1, 1, 4, 1, 4>(p, s);
     case 5: return launch_cfg<2, 1, 4, 1, 1>(p, s);
     case 6: return launch_cfg<1, 1, 2, 2, 4>(p, s);
@@ -366,13 +411,14 @@ extern "C" int imagen_igemm_config_info(int cfg, int* tile_pixels, int* tile_cou
 }
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
+constexpr int kTailSteps = 8;  // >= the kernel's weight look-ahead
 
 extern "C" size_t imagen_igemm_packed_elems(int G, int Cin, int Cout_pad, int KH, int KW) {
   if (G != 1 && G != 2 && G != 4) return 0;
   const int KC = 8 * G;
   const int NC = round_up(Cin, KC) / KC;
   const int KGP = ((KH * KW * G + 1) / 2) * 2;
-  return (size_t)NC * KGP * Cout_pad * 8;
+  return (size_t)(NC * KGP + kTailSteps * 2) * Cout_pad * 8;  // + zero tail: the kernel prefetches up to kTailSteps K=16 steps past the end
 }
 
 // Host-side packing into MFMA A-operand fragment order: element (chunk, tap, group cg, cout, j) holds
@@ -386,7 +432,7 @@ extern "C" int imagen_pack_igemm_weights(int G, const float* w_in, const float* 
   const int Cin_pad = round_up(Cin, KC);
   const int NC = Cin_pad / KC, ntap = KH * KW;
   const int KGP = ((ntap * G + 1) / 2) * 2;
-  const size_t total = (size_t)NC * KGP * Cout_pad * 8;
+  const size_t total = (size_t)(NC * KGP + kTailSteps * 2) * Cout_pad * 8;
   f16* out = reinterpret_cast<f16*>(w_out);
   for (size_t i = 0; i < total; ++i) out[i] = (f16)0.0f;
   for (int chunk = 0; chunk < NC; ++chunk)

@@ -395,8 +395,20 @@ class Imagen(nn.Module):
                     keep[batch_size:] = False            # second half = null-conditioned CFG branch (cond_drop_prob = 1, ip.py:1521)
                 eng.set_conditioning(text_embeds=text_embeds if with_text else None, text_mask=text_masks if with_text else None,
                                      keep=keep, lowres_noise_times=lowres_logsnr)
+                timing = os.environ.get("IMAGEN_TIMING")
+                if timing:
+                    self._stream.synchronize()
+                    import time as _time
+                    t_stage = _time.perf_counter()
                 out = self.p_sample_loop(st, noise_fn=noise_fn, stage=idx, seed=seed, use_graph=use_graph, use_tqdm=use_tqdm,
                                          max_steps=max_steps)
+                if timing:
+                    self._stream.synchronize()
+                    dt = _time.perf_counter() - t_stage
+                    self.last_stage_seconds = getattr(self, "last_stage_seconds", {})
+                    self.last_stage_seconds[idx] = dt
+                    print(f"[imagen] stage {idx} ({S}x{S}, rows {eng.R}): {dt * 1e3:.1f} ms for {st['T'] if max_steps is None else min(st['T'], max_steps)} steps "
+                          f"({len(st['plan'])} launches/step)", flush=True, file=__import__('sys').stderr)
                 img = out.clone()
                 if not self.auto_normalize_img:
                     img = img * 2 - 1

@@ -220,6 +220,9 @@ def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], device, in_scale:
 
 # ------------------------------------------------------------------------------------------------ igemm
 
+import os as _os
+
+FILL_BLOCKS = int(_os.environ.get("IMAGEN_FILL_BLOCKS", "512"))   # workgroups wanted before growing the tile (2 per CU on 256 CUs)
 MAX_STAGE_ITEMS = 6 * 256      # kMaxItems * threads in igemm.hip
 MAX_LDS_BYTES = 160 * 1024
 
@@ -248,7 +251,7 @@ def pick_cfg(G: int, Cout: int, OH: int, OW: int, B: int, KH: int = 1, KW: int =
             tiles = math.ceil(OH / th) * math.ceil(OW / tw)
             nb = B * tiles * math.ceil(Cout / bn)
             waste = tiles * tp / img_px            # padded-pixel overhead (tiles hanging over the image)
-            fill = nb >= 256
+            fill = nb >= FILL_BLOCKS
             score = (abs(bn - want_bn), waste > 1.5, not fill, -tp if fill else tp, tiles * it)
             if best is None or score < best[0]:
                 best = (score, i, th, tw)

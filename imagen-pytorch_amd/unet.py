@@ -92,7 +92,8 @@ class Unet(nn.Module):
         assert attn_heads > 1, 'you need to have more than 1 attention head, ideally at least 4 or 8'
         if dim < 128 and not _printed_dim_hint:
             _printed_dim_hint = True
-            print('The base dimension of your u-net should ideally be no smaller than 128 (reference hint, ip.py:1168)')
+            import sys as _sys
+            print('The base dimension of your u-net should ideally be no smaller than 128 (reference hint, ip.py:1168)', file=_sys.stderr)
 
         # constructor kwargs are kept for cast_model_parameters / persistence (ip.py:1173-1175)
         ctor_kwargs = dict(locals())

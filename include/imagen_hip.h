@@ -104,7 +104,8 @@ typedef struct ImagenIgemmParams {
   int32_t ldy, bsy;    /* output pixel / batch strides (elements) */
   int32_t out_mode;
   int32_t TH, TW;      /* output tile (TH*TW must equal the tile's pixel count) */
-  int32_t cfg;         /* tile configuration id, see imagen_igemm_pick_config */
+  int32_t cfg;         /* tile configuration id, see imagen_igemm_config_info */
+  int32_t dbg;         /* ablation switches for tools/igemm_probe.py (0 in production): 1 = skip restaging after chunk 0, 2 = skip MFMAs */
 } ImagenIgemmParams;
 
 /* ROWSTAT — replaces the reductions inside ChanRMSNorm (ip.py:322-329) and LayerNorm (ip.py:331-349,
