@@ -11,6 +11,8 @@
 // The k dimension runs over channel chunks of 8*G channels; inside a chunk over (tap, 8-channel group) pairs;
 // two consecutive groups (lane>>5 selects) feed one K=16 MFMA.  Staging of chunk c+1 (global loads issued
 // before, LDS writes after the MFMAs of chunk c) overlaps the matrix work of chunk c.
+#include <type_traits>
+#include <utility>
 #include "common.h"
 
 namespace {
@@ -33,6 +35,16 @@ constexpr TileCfg kCfgs[] = {
     {1, 1, 4, 1, 1},  // 9: 128 px x  32 co,  8-ch chunks
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
+
+// compile-time loop: f(std::integral_constant<int, I>) for I in [0, N) — keeps every register-array index static
+template <class F, int... I>
+__device__ __forceinline__ void static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+  static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
 
 template <int G> struct Geo {
   static constexpr int KC = 8 * G;                          // channels per chunk
@@ -115,8 +127,30 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ImagenIgemmParams p) {
   const f16* x1 = reinterpret_cast<const f16*>(p.x1);
   const f16* x2 = reinterpret_cast<const f16*>(p.x2);
 
-  auto stage_load = [&](int chunk) {
+  // per-chunk prologue affine of THIS thread's 8-channel group: every item of a thread has the same group (256 % G == 0) and
+  // the tile lies in one batch row, so the 8 + 8 floats are loaded once per chunk, together with the activations
+  float st_a[8], st_s[8];
+  const int my_cg = tid & (G - 1);
+
+  auto stage_load = [&](int chunk) __attribute__((always_inline)) {
     inb_mask = 0;
+    const int cc = chunk * KC + my_cg * 8;
+    if (p.pa) {
+      const float4* q = reinterpret_cast<const float4*>(p.pa + (size_t)b * p.pstride + cc);
+      const float4 q0 = q[0], q1 = q[1];
+      st_a[0] = q0.x; st_a[1] = q0.y; st_a[2] = q0.z; st_a[3] = q0.w; st_a[4] = q1.x; st_a[5] = q1.y; st_a[6] = q1.z; st_a[7] = q1.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) st_a[j] = 1.0f;
+    }
+    if (p.ps) {
+      const float4* q = reinterpret_cast<const float4*>(p.ps + (size_t)b * p.pstride + cc);
+      const float4 q0 = q[0], q1 = q[1];
+      st_s[0] = q0.x; st_s[1] = q0.y; st_s[2] = q0.z; st_s[3] = q0.w; st_s[4] = q1.x; st_s[5] = q1.y; st_s[6] = q1.z; st_s[7] = q1.w;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) st_s[j] = 0.0f;
+    }
 #pragma unroll
     for (int it = 0; it < kMaxItems; ++it) {
       const int idx = tid + it * 256;
@@ -124,16 +158,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ImagenIgemmParams p) {
       st_rs[it] = 1.0f;
       st_mu[it] = 0.0f;
       if (idx < items) {
-        const int pix = idx >> LOG2G, cg = idx & (G - 1);
+        const int pix = idx >> LOG2G;
         const int iy = (int)(((float)pix + 0.5f) * inv_itw);
         const int ix = pix - iy * ITW;
         const int gy = iy0 + iy, gx = ix0 + ix;
-        const int c = chunk * KC + cg * 8;
         if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
           const int gp = gy * p.W + gx;
           const f16* src = nullptr;
-          if (c < p.C1) src = x1 + (size_t)b * p.bs1 + (size_t)gp * p.ld1 + c;
-          else if (c - p.C1 < p.C2) src = x2 + (size_t)b * p.bs2 + (size_t)gp * p.ld2 + (c - p.C1);
+          if (cc < p.C1) src = x1 + (size_t)b * p.bs1 + (size_t)gp * p.ld1 + cc;
+          else if (cc - p.C1 < p.C2) src = x2 + (size_t)b * p.bs2 + (size_t)gp * p.ld2 + (cc - p.C1);
           if (src) {
             raw[it] = *reinterpret_cast<const uint4*>(src);
             inb_mask |= 1u << it;
@@ -146,47 +179,31 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ImagenIgemmParams p) {
     }
   };
 
-  auto stage_write = [&](int chunk, char* buf) {
+  // transform + LDS write of ONE staged item (it is a compile-time index at every call site)
+  auto stage_write_item = [&](int it, char* buf) __attribute__((always_inline)) {
+    const int idx = tid + it * 256;
+    if (idx < items) {
+      const int pix = idx >> LOG2G;
+      f16x8 out;
+      if (inb_mask & (1u << it)) {
+        const f16x8 in = *reinterpret_cast<const f16x8*>(&raw[it]);
+        const float rs = st_rs[it], mu = st_mu[it];
 #pragma unroll
-    for (int it = 0; it < kMaxItems; ++it) {
-      const int idx = tid + it * 256;
-      if (idx < items) {
-        const int pix = idx >> LOG2G, cg = idx & (G - 1);
-        f16x8 out;
-        if (inb_mask & (1u << it)) {
-          const f16x8 in = *reinterpret_cast<const f16x8*>(&raw[it]);
-          const int c = chunk * KC + cg * 8;
-          float a[8], s[8];
-          if (p.pa) {
-            const float4* q = reinterpret_cast<const float4*>(p.pa + (size_t)b * p.pstride + c);
-            const float4 q0 = q[0], q1 = q[1];
-            a[0] = q0.x; a[1] = q0.y; a[2] = q0.z; a[3] = q0.w; a[4] = q1.x; a[5] = q1.y; a[6] = q1.z; a[7] = q1.w;
-          } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) a[j] = 1.0f;
-          }
-          if (p.ps) {
-            const float4* q = reinterpret_cast<const float4*>(p.ps + (size_t)b * p.pstride + c);
-            const float4 q0 = q[0], q1 = q[1];
-            s[0] = q0.x; s[1] = q0.y; s[2] = q0.z; s[3] = q0.w; s[4] = q1.x; s[5] = q1.y; s[6] = q1.z; s[7] = q1.w;
-          } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) s[j] = 0.0f;
-          }
-          const float rs = st_rs[it], mu = st_mu[it];
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            float v = ((float)in[j] - mu) * rs * a[j] + s[j];
-            if (p.act_in == IMAGEN_ACT_SILU) v = silu_f(v);
-            out[j] = (f16)v;
-          }
-        } else {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) out[j] = (f16)0.0f;
+        for (int j = 0; j < 8; ++j) {
+          float v = ((float)in[j] - mu) * rs * st_a[j] + st_s[j];
+          if (p.act_in == IMAGEN_ACT_SILU) v = silu_f(v);
+          out[j] = (f16)v;
         }
-        *reinterpret_cast<f16x8*>(buf + pix * PS + cg * 16) = out;
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) out[j] = (f16)0.0f;
       }
+      *reinterpret_cast<f16x8*>(buf + pix * PS + my_cg * 16) = out;
     }
+  };
+
+  auto stage_write = [&](char* buf) __attribute__((always_inline)) {
+    static_for<kMaxItems>([&](auto ic) __attribute__((always_inline)) { stage_write_item(decltype(ic)::value, buf); });
   };
 
   // ---- weight fragment pipeline (continuous over chunks)
@@ -202,12 +219,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ImagenIgemmParams p) {
   }
   static_assert(kLookAhead <= 8, "packed weights carry a zero tail of 8 steps");
 
-  auto compute = [&](const char* buf) {
+  // wbuf != nullptr: the LDS writes of the NEXT chunk's staged items are interleaved with the last kMaxItems MFMA steps, so the
+  // prologue VALU work runs under the matrix pipe instead of serialising behind it (only when the k-loop is unrolled)
+  auto compute = [&](const char* buf, char* wbuf) __attribute__((always_inline)) {
     // (dy, dx, group) walk of this lane's 8-channel group: kg = 2*ks + half
     int dy = 0, dx = 0, cgp = 0;  // G >= 2: uniform walk, group = 2*cgp + half
     int tap_l = half;             // G == 1: per-lane tap walk (tap = 2*ks + half), kept as (ty_l, tx_l) incrementally
     int ty_l = half / p.KW, tx_l = half - ty_l * p.KW;
-    auto next_aoff = [&]() -> int {  // LDS offset of this lane's fragment for the next K=16 step, advancing the walk
+    auto next_aoff = [&]() __attribute__((always_inline)) -> int {  // LDS offset of this lane's fragment for the next K=16 step, advancing the walk
       int aoff;
       if (G == 1) {
         // padded half-step (tap_l == ntap): any valid address works, its weights are zero
@@ -231,7 +250,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ImagenIgemmParams p) {
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) afrag[mi] = *reinterpret_cast<const f16x8*>(buf + a_base[mi] + a0);
     }
-    auto do_step = [&](int ks) {
+    auto do_step = [&](int ks) __attribute__((always_inline)) {
       // prefetch the weight fragments kLookAhead steps ahead (L2 latency ~ 2-3 MFMA groups)
       // (unconditional: the packed buffer carries a zero tail of kTailSteps steps, so reads past the last step stay in bounds)
       f16x8 wnew[NI];
@@ -258,8 +277,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ImagenIgemmParams p) {
       for (int ni = 0; ni < NI; ++ni) wq[kLookAhead - 1][ni] = wnew[ni];
     };
     if constexpr (KSC > 0) {
-#pragma unroll
-      for (int ks = 0; ks < KSC; ++ks) do_step(ks);
+      static_for<KSC>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int ks = decltype(ic)::value;
+        do_step(ks);
+        if constexpr (KSC >= kMaxItems && ks >= KSC - kMaxItems) {
+          if (wbuf != nullptr) stage_write_item(ks - (KSC - kMaxItems), wbuf);
+        }
+      });
     } else {
       for (int ks = 0; ks < KS; ++ks) do_step(ks);
     }
@@ -267,15 +291,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ImagenIgemmParams p) {
 
   // ---- main loop over channel chunks (double-buffered LDS)
   stage_load(0);
-  stage_write(0, smem);
+  stage_write(smem);
   __syncthreads();
   int cur = 0;
   for (int chunk = 0; chunk < NC; ++chunk) {
     const bool more = chunk + 1 < NC;
     const bool restage = more && !(p.dbg & 1);
+    char* nbuf = smem + (cur ^ 1) * buf_bytes;
+    constexpr bool kInterleave = KSC >= kMaxItems;
     if (restage) stage_load(chunk + 1);
-    if (!(p.dbg & 2)) compute(smem + cur * buf_bytes);
-    if (restage) stage_write(chunk + 1, smem + (cur ^ 1) * buf_bytes);
+    if (!(p.dbg & 2)) compute(smem + cur * buf_bytes, (kInterleave && restage) ? nbuf : nullptr);
+    if (restage && (!kInterleave || (p.dbg & 2))) stage_write(nbuf);
     __syncthreads();
     cur ^= 1;
   }
