@@ -15,7 +15,7 @@ from typing import Dict
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 HEADER = os.path.join(ROOT, "include", "imagen_hip.h")
-LIB_PATH = os.path.join(HERE, "libimagen_hip.so")
+LIB_PATH = os.environ.get("IMAGEN_LIB_PATH") or os.path.join(HERE, "libimagen_hip.so")   # override: A/B builds of the kernel library
 
 _CTYPE = {
     "int32_t": ctypes.c_int32,

@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void rowstat_kernel(const ImagenRowstatParams 
   const f16* x1 = reinterpret_cast<const f16*>(p.x1) + (size_t)b * p.bs1 + (size_t)rr * p.ld1;
   const f16* x2 = p.x2 ? reinterpret_cast<const f16*>(p.x2) + (size_t)b * p.bs2 + (size_t)rr * p.ld2 : nullptr;
   const int g1 = p.C1 >> 3, g2 = p.x2 ? (p.C2 >> 3) : 0;
-  if (p.mode == 0) {
+  if (p.mode == 0 || p.mode == 2) {
     float s1 = 0.f, s2 = 0.f;
     for (int g = li; g < g1; g += lpr) {
       const f16x8 v = *reinterpret_cast<const f16x8*>(x1 + g * 8);
@@ -39,7 +39,7 @@ __global__ __launch_bounds__(256) void rowstat_kernel(const ImagenRowstatParams 
       for (int j = 0; j < 8; ++j) s2 += (float)v[j] * (float)v[j];
     }
     const float tot = group_sum(s1 + p.w2 * s2, lpr);
-    if (li == 0) p.rs[r] = 1.0f / fmaxf(sqrtf(tot), 1e-12f);
+    if (li == 0) p.rs[r] = p.mode == 2 ? tot : 1.0f / fmaxf(sqrtf(tot), 1e-12f);
   } else {
     const int C = p.C1 + (p.x2 ? p.C2 : 0);
     float s = 0.f;
@@ -109,7 +109,7 @@ __global__ __launch_bounds__(256) void gate_residual_kernel(const ImagenGateResi
   }
   if (p.rs_out) {
     const float tot = group_sum(ssq, lpr);
-    if (li == 0) p.rs_out[r] = 1.0f / fmaxf(sqrtf(tot), 1e-12f);
+    if (li == 0) p.rs_out[r] = p.raw_ssq ? tot : 1.0f / fmaxf(sqrtf(tot), 1e-12f);
   }
 }
 
@@ -138,6 +138,7 @@ __global__ __launch_bounds__(256) void ln_residual_kernel(const ImagenLnResidual
     for (int j = 0; j < 8; ++j) { const float d = (float)v[j] - mean; q += d * d; }
   }
   const float rstd = rsqrtf(group_sum(q, lpr) / (float)p.C + p.eps);
+  float ssq = 0.f;
   for (int g = li; g < groups; g += lpr) {
     const f16x8 v = *reinterpret_cast<const f16x8*>(y + g * 8);
     f16x8 rv;
@@ -149,8 +150,14 @@ __global__ __launch_bounds__(256) void ln_residual_kernel(const ImagenLnResidual
       if (p.beta) t += p.beta[g * 8 + j];
       if (res) t += (float)rv[j];
       o[j] = (f16)t;
+      const float tr = (float)o[j];
+      ssq += tr * tr;
     }
     *reinterpret_cast<f16x8*>(out + g * 8) = o;
+  }
+  if (p.ssq_out) {
+    const float tot = group_sum(ssq, lpr);
+    if (li == 0) p.ssq_out[r] = tot;
   }
 }
 
@@ -282,31 +289,113 @@ __global__ __launch_bounds__(256) void gca_partial_kernel(const ImagenGcaPartial
   }
 }
 
+// Single-pass variant (power-of-two C/8): thread = (pixel lane, 8-channel group); the `groups` consecutive lanes of a pixel
+// reduce the logit with __shfl_xor, then every thread folds exp(logit - m) * h into its 8 accumulators with an online
+// (running-max) rescale, so h is read ONCE.  Pixel lanes are merged through LDS at the end.
+__global__ __launch_bounds__(256) void gca_partial_online_kernel(const ImagenGcaPartialParams p, int chunk_px) {
+  __shared__ float s_m[256];
+  __shared__ float s_se[256];
+  __shared__ float s_acc[256 * 8];
+  const int b = blockIdx.y, ch = blockIdx.x;
+  const int p0 = ch * chunk_px;
+  const int npx = min(chunk_px, p.HW - p0);
+  const f16* h = reinterpret_cast<const f16*>(p.h) + ((size_t)b * p.HW + p0) * p.ld;
+  const int groups = p.C >> 3;           // power of two <= 64
+  const int npl = 256 / groups;          // pixel lanes
+  const int pl = threadIdx.x / groups, cg = threadIdx.x & (groups - 1);
+  float wk[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) wk[j] = p.wk[cg * 8 + j];
+  float m = -3.0e38f, se = 0.f;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  for (int px = pl; px < npx; px += npl) {   // uniform trip count within each `groups`-lane team
+    const f16x8 v = *reinterpret_cast<const f16x8*>(h + (size_t)px * p.ld + cg * 8);
+    float d = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) d += (float)v[j] * wk[j];
+    d = group_sum(d, groups) + p.bk;
+    const float mn = fmaxf(m, d);
+    const float sc = __expf(m - mn), e = __expf(d - mn);
+    m = mn;
+    se = se * sc + e;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = acc[j] * sc + e * (float)v[j];
+  }
+  s_m[threadIdx.x] = m;
+  s_se[threadIdx.x] = se;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) s_acc[threadIdx.x * 8 + j] = acc[j];
+  __syncthreads();
+  float* out = p.part + ((size_t)b * p.chunks + ch) * (p.C + 2);
+  if (threadIdx.x < groups) {  // merge the pixel lanes of channel group threadIdx.x
+    float M = -3.0e38f;
+    for (int q = 0; q < npl; ++q) M = fmaxf(M, s_m[q * groups]);
+    float tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    float S = 0.f;
+    for (int q = 0; q < npl; ++q) {
+      const float w = __expf(s_m[q * groups] - M);   // lanes that saw no pixel carry m = -3e38 -> weight 0
+      S += s_se[q * groups] * w;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) tot[j] += s_acc[(q * groups + threadIdx.x) * 8 + j] * w;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) out[2 + threadIdx.x * 8 + j] = tot[j];
+    if (threadIdx.x == 0) {
+      out[0] = M;
+      out[1] = S;
+    }
+  }
+}
+
+// One workgroup per image: merge the chunk partials (weights exp(m_i - M) shared through LDS), then the squeeze MLP with
+// transposed weights so consecutive threads read consecutive addresses.
 __global__ __launch_bounds__(256) void gca_final_kernel(const ImagenGcaFinalParams p) {
-  extern __shared__ float sm[];  // ctx[C] | hid[hidden]
+  extern __shared__ float sm[];  // ctx[C] | hid[hidden] | wgt[chunks]
   float* ctx = sm;
   float* hid = sm + p.C;
+  float* wgt = hid + p.hidden;
+  __shared__ float s_red[256];
   const int b = blockIdx.x;
-  const float* part = p.part + (size_t)b * p.chunks * (p.C + 2);
-  float M = -3.0e38f;
-  for (int i = 0; i < p.chunks; ++i) M = fmaxf(M, part[(size_t)i * (p.C + 2)]);
-  float S = 0.f;
-  for (int i = 0; i < p.chunks; ++i) S += part[(size_t)i * (p.C + 2) + 1] * __expf(part[(size_t)i * (p.C + 2)] - M);
-  for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+  const int stride = p.C + 2;
+  const float* part = p.part + (size_t)b * p.chunks * stride;
+  float lm = -3.0e38f;
+  for (int i = threadIdx.x; i < p.chunks; i += 256) lm = fmaxf(lm, part[(size_t)i * stride]);
+  s_red[threadIdx.x] = lm;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) s_red[threadIdx.x] = fmaxf(s_red[threadIdx.x], s_red[threadIdx.x + off]);
+    __syncthreads();
+  }
+  const float M = s_red[0];
+  __syncthreads();
+  float ls = 0.f;
+  for (int i = threadIdx.x; i < p.chunks; i += 256) {
+    const float w = __expf(part[(size_t)i * stride] - M);
+    wgt[i] = w;
+    ls += part[(size_t)i * stride + 1] * w;
+  }
+  s_red[threadIdx.x] = ls;
+  __syncthreads();
+  for (int off = 128; off > 0; off >>= 1) {
+    if (threadIdx.x < off) s_red[threadIdx.x] += s_red[threadIdx.x + off];
+    __syncthreads();
+  }
+  const float S = s_red[0];
+  for (int c = threadIdx.x; c < p.C; c += 256) {
     float a = 0.f;
-    for (int i = 0; i < p.chunks; ++i) a += part[(size_t)i * (p.C + 2) + 2 + c] * __expf(part[(size_t)i * (p.C + 2)] - M);
+    for (int i = 0; i < p.chunks; ++i) a += part[(size_t)i * stride + 2 + c] * wgt[i];
     ctx[c] = a / S;
   }
   __syncthreads();
-  for (int j = threadIdx.x; j < p.hidden; j += blockDim.x) {
+  for (int j = threadIdx.x; j < p.hidden; j += 256) {
     float a = p.b1[j];
-    for (int c = 0; c < p.C; ++c) a += p.w1[(size_t)j * p.C + c] * ctx[c];
+    for (int c = 0; c < p.C; ++c) a += p.w1t[(size_t)c * p.hidden + j] * ctx[c];
     hid[j] = silu_f(a);
   }
   __syncthreads();
-  for (int c = threadIdx.x; c < p.C; c += blockDim.x) {
+  for (int c = threadIdx.x; c < p.C; c += 256) {
     float a = p.b2[c];
-    for (int j = 0; j < p.hidden; ++j) a += p.w2[(size_t)c * p.hidden + j] * hid[j];
+    for (int j = 0; j < p.hidden; ++j) a += p.w2t[(size_t)j * p.C + c] * hid[j];
     p.gate[(size_t)b * p.C + c] = sigmoid_f(a);
   }
 }
@@ -449,13 +538,18 @@ int launch_kv_prep(const ImagenKvPrepParams* p, hipStream_t s) {
 int launch_gca_partial(const ImagenGcaPartialParams* p, hipStream_t s) {
   IMAGEN_CHECK(p->C % 8 == 0 && p->C / 8 <= 256, "gca: unsupported C %d", p->C);
   const int chunk_px = (p->HW + p->chunks - 1) / p->chunks;
+  const int groups = p->C / 8;
+  if ((groups & (groups - 1)) == 0 && groups <= 64) {
+    hipLaunchKernelGGL(gca_partial_online_kernel, dim3(p->chunks, p->B), dim3(256), 0, s, *p, chunk_px);
+    return imagen_hip_status("gca_partial");
+  }
   IMAGEN_CHECK(chunk_px <= kGcaMaxChunk, "gca: chunk of %d pixels too large", chunk_px);
   hipLaunchKernelGGL(gca_partial_kernel, dim3(p->chunks, p->B), dim3(256), 0, s, *p, chunk_px);
   return imagen_hip_status("gca_partial");
 }
 
 int launch_gca_final(const ImagenGcaFinalParams* p, hipStream_t s) {
-  const size_t sm = (size_t)(p->C + p->hidden) * sizeof(float);
+  const size_t sm = (size_t)(p->C + p->hidden + p->chunks) * sizeof(float);
   hipLaunchKernelGGL(gca_final_kernel, dim3(p->B), dim3(256), sm, s, *p);
   return imagen_hip_status("gca_final");
 }

@@ -54,8 +54,9 @@ template <int G> struct Geo {
 // KSC > 0: the number of K=16 steps per channel chunk is a compile-time constant (18 for 3x3 convs with 32-channel
 // chunks, 2 for 1x1 / linear, 8 for the 2x2 stride-2 downsample): the k-loop is fully unrolled so the weight-fragment ring is
 // statically indexed (no register copies of in-flight loads, which would force a vmcnt wait every step).  KSC == 0: generic loop.
+// occupancy target (waves per SIMD): 2 for the 64-pixel-per-wave tilings (<= 256 VGPR+AGPR), 1 for the 128-pixel ones
 template <int MI, int NI, int WM, int WN, int G, int KSC>
-__global__ __launch_bounds__(256) void igemm_kernel(const ImagenIgemmParams p) {
+__global__ __launch_bounds__(256, (MI * NI <= 2 ? 2 : 1)) void igemm_kernel(const ImagenIgemmParams p) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   constexpr int BN = 32 * NI * WN;
   constexpr int KC = Geo<G>::KC;
@@ -172,6 +173,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ImagenIgemmParams p) {
             inb_mask |= 1u << it;
             const int sp = b * (p.H * p.W) + gp;
             if (p.rs) st_rs[it] = p.rs[sp];
+            else if (p.ssq_a) {  // ChanRMSNorm statistics straight from the producers' per-pixel sums of squares
+              float q = p.ssq_a[sp];
+              if (p.ssq_b) q += p.ssq_wb * p.ssq_b[sp];
+              st_rs[it] = 1.0f / fmaxf(sqrtf(q), 1e-12f);
+            }
             if (p.mu) st_mu[it] = p.mu[sp];
           }
         }
@@ -309,8 +315,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ImagenIgemmParams p) {
   // ---- epilogue: lane = pixel; register quad q holds couts 8q + 4*half + {0..3} of each 32-cout fragment
   const f16* addend = reinterpret_cast<const f16*>(p.addend);
   const f16* res = reinterpret_cast<const f16*>(p.res);
+  float ssq_px[MI];  // per-pixel sum of squares of this wave's stored channels (for the consumer's ChanRMSNorm)
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
+    ssq_px[mi] = 0.0f;
     const int oy = opix_y[mi], ox = opix_x[mi];
     if (oy >= p.OH || ox >= p.OW) continue;
     const int op = oy * p.OW + ox;
@@ -348,7 +356,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ImagenIgemmParams p) {
         }
         f16x4 o;
 #pragma unroll
-        for (int e = 0; e < 4; ++e) o[e] = (f16)v[e];
+        for (int e = 0; e < 4; ++e) {
+          o[e] = (f16)v[e];
+          const float r = (float)o[e];  // statistics of the value the consumer will read back
+          ssq_px[mi] += r * r;
+        }
         f16* y = reinterpret_cast<f16*>(p.y);
         if (p.out_mode == IMAGEN_OUT_PIXEL_SHUFFLE) {
           // output channels are packed (s1, s2, c): cout = (2*s1 + s2) * Cq + c   (PixelShuffle(2), ip.py:616)
@@ -358,6 +370,35 @@ __global__ __launch_bounds__(256) void igemm_kernel(const ImagenIgemmParams p) {
           *reinterpret_cast<f16x4*>(y + (size_t)b * p.bsy + ((size_t)yy * (2 * p.OW) + xx) * p.ldy + c) = o;
         } else {
           *reinterpret_cast<f16x4*>(y + (size_t)b * p.bsy + (size_t)op * p.ldy + co) = o;
+        }
+      }
+    }
+  }
+  // ---- optional: emit the per-pixel sum of squares (launcher guarantees one workgroup covers all Cout: gridDim.y == 1)
+  if (p.ssq_out) {
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) ssq_px[mi] += __shfl_xor(ssq_px[mi], 32);  // both lane halves hold disjoint channel quads
+    if (WN == 1) {
+      if (half == 0) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          if (opix_y[mi] < p.OH && opix_x[mi] < p.OW) p.ssq_out[(size_t)b * (p.OH * p.OW) + opix_y[mi] * p.OW + opix_x[mi]] = ssq_px[mi];
+      }
+    } else {
+      float* red = reinterpret_cast<float*>(smem);  // [WN][pixels of this wave row]; LDS is free after the main loop's last barrier
+      constexpr int PXW = 32 * MI;                  // pixels per wave
+      if (half == 0) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) red[(wm * WN + wn) * PXW + mi * 32 + l31] = ssq_px[mi];
+      }
+      __syncthreads();
+      if (wn == 0 && half == 0) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          float tot = 0.0f;
+#pragma unroll
+          for (int w = 0; w < WN; ++w) tot += red[(wm * WN + w) * PXW + mi * 32 + l31];
+          if (opix_y[mi] < p.OH && opix_x[mi] < p.OW) p.ssq_out[(size_t)b * (p.OH * p.OW) + opix_y[mi] * p.OW + opix_x[mi]] = tot;
         }
       }
     }
@@ -377,6 +418,8 @@ int launch_ksc(const ImagenIgemmParams& p, hipStream_t s) {
                "igemm: channel counts / strides must be multiples of 8 (C1=%d C2=%d ld1=%d ld2=%d)", p.C1, p.C2, p.ld1, p.ld2);
   IMAGEN_CHECK(p.out_mode == IMAGEN_OUT_NCHW_F32 || p.Cout % 4 == 0, "igemm: Cout %d must be a multiple of 4", p.Cout);
   IMAGEN_CHECK(p.out_mode != IMAGEN_OUT_PIXEL_SHUFFLE || p.Cout % 16 == 0, "igemm: pixel-shuffle needs Cout %% 16 == 0");
+  IMAGEN_CHECK(!p.ssq_out || (p.out_mode == IMAGEN_OUT_NHWC && p.Cout <= BN),
+               "igemm: ssq_out needs NHWC output and one workgroup covering all %d output channels (tile has %d)", p.Cout, BN);
   const size_t lds = (size_t)2 * IT * Geo<G>::PS;
   IMAGEN_CHECK(lds <= 160 * 1024, "igemm: LDS tile %zu bytes too large", lds);
   auto kern = igemm_kernel<MI, NI, WM, WN, G, KSC>;

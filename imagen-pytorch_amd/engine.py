@@ -295,7 +295,10 @@ class UnetEngine:
             w[:, : conv.weight.shape[1]] = conv.weight.detach().float()
             return ops.pack_weight(w, conv.bias.detach().float(), self.dev, G=1)
 
-        ops.igemm(plan, self.img, self.W.get("init_conv", make), out, label="init_conv")
+        out.ssq = self.f32buf(out.rows)
+        op = ops.igemm(plan, self.img, self.W.get("init_conv", make), out, ssq_out=out.ssq, label="init_conv")
+        if not op.ssq_emitted:
+            out.ssq = None
 
     def _final_conv(self, plan, x: Act):
         """final_conv over cat(x, lowres_cond_img) (ip.py:1722-1725) -> fp32 NCHW."""
@@ -327,25 +330,29 @@ class UnetEngine:
         if skip is not None:
             in_scale = torch.ones(Cin)
             in_scale[C1:] = s
-        # block1: ChanRMSNorm over the (scaled) concat -> SiLU -> conv3x3
-        rs1 = self.f32buf(R * H * Wd)
-        ops.rowstat(plan, x, mode=0, rs=rs1, x2=skip, w2=s * s, label=name + ".block1.stat")
+        # block1: ChanRMSNorm over the (scaled) concat -> SiLU -> conv3x3.  The norm statistics come from the per-pixel sums of
+        # squares the producers of x / skip emitted in their epilogues (a ROWSTAT pass only where a producer could not).
+        sx = self._ssq_of(plan, x, name + ".block1.stat_x")
+        ss = self._ssq_of(plan, skip, name + ".block1.stat_skip") if skip is not None else None
         w1 = W.conv(name + ".block1", rb.block1.project)
         pa1 = W.f32(name + ".block1.pa", lambda: _pad_vec(rb.block1.norm.gamma.detach().float().flatten().cpu() * math.sqrt(Cin)
                                                          * (in_scale if in_scale is not None else 1.0), w1.Cin_pad))
         h1 = self.new(R, H, Wd, Cout)
-        ops.igemm(plan, x, w1, h1, x2=skip, rs=rs1, pa=pa1, pstride=0, act_in=ACT_SILU, label=name + ".block1")
+        h1.ssq = self.f32buf(R * H * Wd)
+        op = ops.igemm(plan, x, w1, h1, x2=skip, ssq_a=sx, ssq_b=ss, ssq_wb=s * s, pa=pa1, pstride=0, act_in=ACT_SILU, ssq_out=h1.ssq,
+                       label=name + ".block1")
+        if not op.ssq_emitted:
+            h1.ssq = None
         if rb.cross_attn is not None:
             assert with_cond
             h1 = self._cross_attn(plan, h1, rb.cross_attn, name + ".cross_attn")
         # block2: ChanRMSNorm -> (scale+1, shift) from the time MLP -> SiLU -> conv3x3
-        rs2 = self.f32buf(R * H * Wd)
-        ops.rowstat(plan, h1, mode=0, rs=rs2, label=name + ".block2.stat")
+        s1 = self._ssq_of(plan, h1, name + ".block2.stat")
         off = self._blk_off[self._blk_index[id(rb)]]
         pa2 = self.pa2[:, off:]
         ps2 = self.ps2[:, off:]
         h2 = self.new(R, H, Wd, Cout)
-        ops.igemm(plan, h1, W.conv(name + ".block2", rb.block2.project), h2, rs=rs2, pa=pa2, ps=ps2, pstride=self.total_c,
+        ops.igemm(plan, h1, W.conv(name + ".block2", rb.block2.project), h2, ssq_a=s1, pa=pa2, ps=ps2, pstride=self.total_c,
                   act_in=ACT_SILU, label=name + ".block2")
         gate = None
         if rb.gca is not None:
@@ -355,20 +362,30 @@ class UnetEngine:
             gate = self.f32buf(R, Cout)
             hidden = g.net[0].weight.shape[0]
             ops.gca(plan, h2, W.f32(name + ".gca.wk", lambda: g.to_k.weight.reshape(-1)), float(g.to_k.bias.detach().float().item()),
-                    W.f32(name + ".gca.w1", lambda: g.net[0].weight.reshape(hidden, Cout)), W.f32(name + ".gca.b1", lambda: g.net[0].bias),
-                    W.f32(name + ".gca.w2", lambda: g.net[2].weight.reshape(Cout, hidden)), W.f32(name + ".gca.b2", lambda: g.net[2].bias),
+                    W.f32(name + ".gca.w1t", lambda: g.net[0].weight.reshape(hidden, Cout).t()), W.f32(name + ".gca.b1", lambda: g.net[0].bias),
+                    W.f32(name + ".gca.w2t", lambda: g.net[2].weight.reshape(Cout, hidden).t()), W.f32(name + ".gca.b2", lambda: g.net[2].bias),
                     part, gate, chunks, label=name + ".gca")
         out = self.new(R, H, Wd, Cout)
+        out.ssq = self.f32buf(R * H * Wd)
         if rb.res_conv is not None:
             wr = W.conv(name + ".res_conv", rb.res_conv, in_scale=in_scale)
             if gate is not None:
-                ops.igemm(plan, x, wr, out, x2=skip, addend=h2, gate=gate, label=name + ".res_conv")
+                op = ops.igemm(plan, x, wr, out, x2=skip, addend=h2, gate=gate, ssq_out=out.ssq, label=name + ".res_conv")
             else:
-                ops.igemm(plan, x, wr, out, x2=skip, res=h2, label=name + ".res_conv")
+                op = ops.igemm(plan, x, wr, out, x2=skip, res=h2, ssq_out=out.ssq, label=name + ".res_conv")
+            if not op.ssq_emitted:
+                out.ssq = None
         else:
             assert skip is None
-            ops.gate_residual(plan, h2, gate, x, out, label=name + ".tail")
+            ops.gate_residual(plan, h2, gate, x, out, rs_out=out.ssq, raw_ssq=True, label=name + ".tail")
         return out
+
+    def _ssq_of(self, plan, a: Act, label: str) -> torch.Tensor:
+        """Per-pixel sum of squares of `a`: the producer's epilogue output if it emitted one, else one ROWSTAT (mode 2) pass."""
+        if a.ssq is None:
+            a.ssq = self.f32buf(a.rows)
+            ops.rowstat(plan, a, mode=2, rs=a.ssq, label=label)
+        return a.ssq
 
     # ---- CrossAttention inside a ResnetBlock (ip.py:745-751, 759-834)
     def _cross_attn(self, plan, h: Act, ca: CrossAttentionP, name: str) -> Act:
@@ -397,7 +414,9 @@ class UnetEngine:
         y = self.new(R, 1, N, C)
         ops.igemm(plan, o, W.conv(name + ".to_out", ca.to_out[0]), y, label=name + ".to_out")
         out = self.new(R, h.H, h.W, C)
-        ops.ln_residual(plan, y, W.f32(name + ".out_g", lambda: ca.to_out[1].g), out.tokens(), res=tok, eps=1e-5, label=name + ".out_norm")
+        out.ssq = self.f32buf(R * N)
+        ops.ln_residual(plan, y, W.f32(name + ".out_g", lambda: ca.to_out[1].g), out.tokens(), res=tok, eps=1e-5, ssq_out=out.ssq,
+                        label=name + ".out_norm")
         return out
 
     # ---- TransformerBlock (ip.py:992-1022): depth x [multi-query self attention + FeedForward]
@@ -438,7 +457,8 @@ class UnetEngine:
             ops.igemm(plan, o, W.conv(nm + ".to_out", attn.to_out[0]), y, label=nm + ".to_out")
             x1 = self.new(R, 1, N, C)
             ops.ln_residual(plan, y, W.f32(nm + ".out_g", lambda: attn.to_out[1].g), x1, res=tok, eps=1e-5, label=nm + ".out_norm")
-            cur = Act(self._feed_forward(plan, x1, ff, nm + ".ff").t, R, x.H, x.W, C, C, N * C)
+            ffo = self._feed_forward(plan, x1, ff, nm + ".ff")
+            cur = Act(ffo.t, R, x.H, x.W, C, C, N * C, ssq=ffo.ssq)
         return cur
 
     def _feed_forward(self, plan, x: Act, ff: nn.Sequential, name: str) -> Act:
@@ -456,7 +476,11 @@ class UnetEngine:
         ops.rowstat(plan, hid, mode=1, rs=rs2, mu=mu2, eps=1e-5, label=name + ".ln1")
         w2 = W.conv(name + ".w2", ff[4])
         out = self.new(x.B, x.H, x.W, x.C)
-        ops.igemm(plan, hid, w2, out, mu=mu2, rs=rs2, pa=W.f32(name + ".g1", lambda: _pad_vec(ff[3].g, w2.Cin_pad)), res=x, label=name + ".lin2")
+        out.ssq = self.f32buf(rows)
+        op = ops.igemm(plan, hid, w2, out, mu=mu2, rs=rs2, pa=W.f32(name + ".g1", lambda: _pad_vec(ff[3].g, w2.Cin_pad)), res=x,
+                       ssq_out=out.ssq, label=name + ".lin2")
+        if not op.ssq_emitted:
+            out.ssq = None
         return out
 
     # ---- resampling
@@ -469,7 +493,9 @@ class UnetEngine:
                 return ops.pack_weight(w3, mod.fns[0].bias.detach().float() + mod.fns[1].bias.detach().float(), self.dev)
             w = self.W.get(name, make)
             out = self.new(R, x.H, x.W, w.Cout)
-            ops.igemm(plan, x, w, out, label=name)
+            out.ssq = self.f32buf(out.rows)
+            if not ops.igemm(plan, x, w, out, ssq_out=out.ssq, label=name).ssq_emitted:
+                out.ssq = None
             return out
         conv = mod[1]  # pixel-unshuffle + 1x1 conv (ip.py:633-640) == 2x2 stride-2 conv
         def make():
@@ -477,7 +503,9 @@ class UnetEngine:
             return ops.pack_weight(w.view(w.shape[0], x.C, 2, 2), conv.bias.detach().float(), self.dev)
         w = self.W.get(name, make)
         out = self.new(R, x.H // 2, x.W // 2, w.Cout)
-        ops.igemm(plan, x, w, out, stride=2, pad=0, label=name)
+        out.ssq = self.f32buf(out.rows)
+        if not ops.igemm(plan, x, w, out, stride=2, pad=0, ssq_out=out.ssq, label=name).ssq_emitted:
+            out.ssq = None
         return out
 
     def _upsample(self, plan, x: Act, mod: PixelShuffleUpsampleP, name: str) -> Act:

@@ -136,6 +136,7 @@ class Act:
     ld: int
     bs: int
     off: int = 0             # element offset into t
+    ssq: Optional[torch.Tensor] = None   # fp32 [rows]: per-pixel sum of squares emitted by the producer (ChanRMSNorm statistics)
 
     @property
     def ptr(self) -> int:
@@ -222,6 +223,7 @@ def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], device, in_scale:
 
 import os as _os
 
+IGEMM_DBG = int(_os.environ.get("IMAGEN_IGEMM_DBG", "0"))          # kernel A/B switches (see ImagenIgemmParams.dbg); 0 in production
 FILL_BLOCKS = int(_os.environ.get("IMAGEN_FILL_BLOCKS", "512"))   # workgroups wanted before growing the tile (2 per CU on 256 CUs)
 MAX_STAGE_ITEMS = 6 * 256      # kMaxItems * threads in igemm.hip
 MAX_LDS_BYTES = 160 * 1024
@@ -263,7 +265,10 @@ def pick_cfg(G: int, Cout: int, OH: int, OW: int, B: int, KH: int = 1, KW: int =
 def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None, mu=None, rs=None, pa=None, ps=None,
           pstride: int = 0, act_in: int = ACT_NONE, act_out: int = ACT_NONE, addend: Optional[Act] = None, gate=None,
           res: Optional[Act] = None, out_mode: int = OUT_NHWC, stride: int = 1, pad: Optional[int] = None,
-          cfg: Optional[tuple] = None, label: str = ""):
+          cfg: Optional[tuple] = None, ssq_a=None, ssq_b=None, ssq_wb: float = 1.0, ssq_out=None, label: str = ""):
+    """... ssq_a / ssq_b: producers' per-pixel sums of squares of x1 / x2 (ChanRMSNorm statistics without a separate pass);
+    ssq_out: emit the per-pixel sum of squares of the output — honoured only when the chosen tile covers all Cout
+    (`p.ssq_emitted` tells the caller, who otherwise falls back to a ROWSTAT op)."""
     """Append one implicit-GEMM launch.  y: Act (NHWC / pixel-shuffle target) or fp32 NCHW tensor (OUT_NCHW_F32)."""
     KH, KW = pw.KH, pw.KW
     if pad is None:
@@ -312,7 +317,17 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
         p.y, p.ldy, p.bsy = y.ptr, y.ld, y.bs
         keep.append(y.t)
     p.TH, p.TW, p.cfg = th, tw, cid
+    p.dbg = IGEMM_DBG
+    if ssq_a is not None:
+        p.ssq_a, p.ssq_b, p.ssq_wb = ssq_a.data_ptr(), ptr(ssq_b), ssq_wb
+        keep += [ssq_a, ssq_b]
+    emitted = False
+    if ssq_out is not None and out_mode == OUT_NHWC and pw.Cout <= cfg_table()[cid][1]:
+        p.ssq_out = ssq_out.data_ptr()
+        keep.append(ssq_out)
+        emitted = True
     plan.add(p, label or "igemm", keep)
+    p.ssq_emitted = emitted
     return p
 
 
@@ -367,16 +382,18 @@ def qnorm(plan: Plan, q: torch.Tensor, q_scale: torch.Tensor, *, rows, heads, ld
     return p
 
 
-def gca(plan: Plan, h: Act, wk, bk: float, w1, b1, w2, b2, part: torch.Tensor, gate: torch.Tensor, chunks: int, label: str = ""):
+def gca(plan: Plan, h: Act, wk, bk: float, w1t, b1, w2t, b2, part: torch.Tensor, gate: torch.Tensor, chunks: int, label: str = ""):
+    """w1t: [C, hidden] (net.0.weight transposed), w2t: [hidden, C] (net.2.weight transposed), fp32 device tensors."""
     C = h.C
     p = STRUCTS["ImagenGcaPartialParams"]()
     p.h, p.wk, p.part = h.ptr, wk.data_ptr(), part.data_ptr()
     p.B, p.HW, p.C, p.ld, p.chunks, p.bk = h.B, h.H * h.W, C, h.ld, chunks, bk
     plan.add(p, (label or "gca") + ".partial", [h.t, wk, part])
     f = STRUCTS["ImagenGcaFinalParams"]()
-    f.part, f.w1, f.b1, f.w2, f.b2, f.gate = part.data_ptr(), w1.data_ptr(), b1.data_ptr(), w2.data_ptr(), b2.data_ptr(), gate.data_ptr()
-    f.B, f.C, f.hidden, f.chunks = h.B, C, w1.shape[0], chunks
-    plan.add(f, (label or "gca") + ".final", [part, w1, b1, w2, b2, gate])
+    assert tuple(w1t.shape) == (C, w2t.shape[0]) and w2t.shape[1] == C
+    f.part, f.w1t, f.b1, f.w2t, f.b2, f.gate = part.data_ptr(), w1t.data_ptr(), b1.data_ptr(), w2t.data_ptr(), b2.data_ptr(), gate.data_ptr()
+    f.B, f.C, f.hidden, f.chunks = h.B, C, w1t.shape[1], chunks
+    plan.add(f, (label or "gca") + ".final", [part, w1t, b1, w2t, b2, gate])
 
 
 def gca_chunks(HW: int) -> int:
@@ -385,25 +402,27 @@ def gca_chunks(HW: int) -> int:
 
 
 def gate_residual(plan: Plan, h: Act, gate: Optional[torch.Tensor], res: Act, out: Act, rs_out: Optional[torch.Tensor] = None,
-                  label: str = ""):
+                  raw_ssq: bool = False, label: str = ""):
     assert h.ld * h.H * h.W == h.bs and res.ld * res.H * res.W == res.bs and out.ld * out.H * out.W == out.bs
     p = STRUCTS["ImagenGateResidualParams"]()
     p.h, p.gate, p.res, p.out, p.rs_out = h.ptr, ptr(gate), res.ptr, out.ptr, ptr(rs_out)
     p.rows, p.rows_per_batch, p.C = h.rows, h.H * h.W, h.C
     p.ld_h, p.ld_res, p.ld_out = h.ld, res.ld, out.ld
+    p.raw_ssq = int(raw_ssq)
     plan.add(p, label or "gate_residual", [h.t, gate, res.t, out.t, rs_out])
     return p
 
 
 def ln_residual(plan: Plan, y: Act, g: torch.Tensor, out: Act, *, beta=None, res: Optional[Act] = None, eps: float = 1e-5,
-                label: str = ""):
+                ssq_out: Optional[torch.Tensor] = None, label: str = ""):
     p = STRUCTS["ImagenLnResidualParams"]()
     p.y, p.g, p.beta, p.res, p.out = y.ptr, g.data_ptr(), ptr(beta), (res.ptr if res is not None else None), out.ptr
     p.rows, p.C, p.ld_y, p.ld_res, p.ld_out, p.eps = y.rows, y.C, y.ld, (res.ld if res is not None else 0), out.ld, eps
     p.rows_per_batch = y.H * y.W
     p.bs_y, p.bs_res, p.bs_out = y.bs, (res.bs if res is not None else 0), out.bs
     assert out.H * out.W == y.H * y.W and out.B == y.B
-    plan.add(p, label or "ln_residual", [y.t, g, beta, res.t if res is not None else None, out.t])
+    p.ssq_out = ptr(ssq_out)
+    plan.add(p, label or "ln_residual", [y.t, g, beta, res.t if res is not None else None, out.t, ssq_out])
     return p
 
 

@@ -90,6 +90,9 @@ typedef struct ImagenIgemmParams {
   const float* gate;   /* [B][Cout] (required with addend) */
   const void* res;     /* fp16 NHWC at output resolution or NULL */
   void* y;             /* fp16 NHWC / fp32 NCHW */
+  const float* ssq_a;  /* optional per-input-pixel sum of squares of x1 (emitted by its producer): when set (and rs == NULL) */
+  const float* ssq_b;  /*   rs = 1/max(sqrt(ssq_a + ssq_wb*ssq_b), 1e-12) — ChanRMSNorm statistics without a separate pass   */
+  float* ssq_out;      /* optional per-output-pixel sum of squares of the stored fp16 output (NHWC mode, Cout <= tile couts) */
   int32_t B, H, W;     /* input batch / spatial dims */
   int32_t C1, ld1, bs1; /* channels, pixel stride, batch stride (elements) of x1 */
   int32_t C2, ld2, bs2;
@@ -106,11 +109,13 @@ typedef struct ImagenIgemmParams {
   int32_t TH, TW;      /* output tile (TH*TW must equal the tile's pixel count) */
   int32_t cfg;         /* tile configuration id, see imagen_igemm_config_info */
   int32_t dbg;         /* ablation switches for tools/igemm_probe.py (0 in production): 1 = skip restaging after chunk 0, 2 = skip MFMAs */
+  float ssq_wb;        /* weight of ssq_b (skip_connect_scale^2 for the concatenated skip tensor) */
 } ImagenIgemmParams;
 
 /* ROWSTAT — replaces the reductions inside ChanRMSNorm (ip.py:322-329) and LayerNorm (ip.py:331-349,
  * nn.LayerNorm).  mode 0: rs = 1/max(sqrt(ssq1 + w2*ssq2), 1e-12), mu untouched.
- * mode 1: mu = mean, rs = rsqrt(var + eps) (biased variance, two-pass). */
+ * mode 1: mu = mean, rs = rsqrt(var + eps) (biased variance, two-pass).
+ * mode 2: rs = ssq1 + w2*ssq2 (raw sum of squares, the form IGEMM's ssq_a/ssq_b consume). */
 typedef struct ImagenRowstatParams {
   const void* x1; const void* x2; float* mu; float* rs;
   int32_t rows, C1, ld1, C2, ld2, mode;
@@ -160,8 +165,8 @@ typedef struct ImagenGcaPartialParams {
   int32_t B, HW, C, ld, chunks; float bk;
 } ImagenGcaPartialParams;
 typedef struct ImagenGcaFinalParams {
-  const float* part; const float* w1; const float* b1; const float* w2; const float* b2; float* gate;
-  int32_t B, C, hidden, chunks;
+  const float* part; const float* w1t; const float* b1; const float* w2t; const float* b2; float* gate;
+  int32_t B, C, hidden, chunks; /* w1t: [C][hidden] (= net.0.weight transposed), w2t: [hidden][C] (= net.2.weight transposed) */
 } ImagenGcaFinalParams;
 
 /* GATE_RESIDUAL — ResnetBlock tail ip.py:755-757 with identity residual: out = h*gate[b,c] + res
@@ -169,12 +174,14 @@ typedef struct ImagenGcaFinalParams {
 typedef struct ImagenGateResidualParams {
   const void* h; const float* gate; const void* res; void* out; float* rs_out;
   int32_t rows, rows_per_batch, C, ld_h, ld_res, ld_out;
+  int32_t raw_ssq; /* 1: rs_out receives the raw per-pixel sum of squares instead of 1/max(||out||, 1e-12) */
 } ImagenGateResidualParams;
 
 /* LN_RESIDUAL — to_out LayerNorm + residual ip.py:529-532,1017 / nn.LayerNorm ip.py:1252:
  *   out = (y - mean)*rsqrt(var+eps)*g (+ beta) (+ res) */
 typedef struct ImagenLnResidualParams {
   const void* y; const float* g; const float* beta; const void* res; void* out;
+  float* ssq_out; /* optional raw per-row sum of squares of the stored output (feeds a following ChanRMSNorm) */
   int32_t rows, C, ld_y, ld_res, ld_out;
   int32_t rows_per_batch, bs_y, bs_res, bs_out; /* row r = (b, rr): address b*bs + rr*ld (rows_per_batch = rows if flat) */
   float eps;

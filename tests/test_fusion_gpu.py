@@ -1,0 +1,92 @@
+"""MI355X: epilogue-emitted ChanRMSNorm statistics (ssq_out -> ssq_a / ssq_b) give the same Block output as the
+separate ROWSTAT pass, for every tile family (cross-wave LDS reduction included), and the fused tails emit the right sums."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def insc_ref(C, C1, sk):
+    v = torch.ones(1, C, 1, 1)
+    v[:, C1:] = sk
+    return v
+
+
+def nerr(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / b.norm().clamp(min=1e-12)).item()
+
+
+@pytest.mark.parametrize("B,H,W,C1,C2,Cmid,Cout", [(2, 32, 32, 32, 32, 32, 32), (2, 16, 16, 64, 64, 128, 128), (1, 64, 64, 64, 0, 64, 64),
+                                                   (2, 8, 8, 128, 0, 128, 256), (1, 24, 24, 16, 8, 24, 16)])
+def test_ssq_chain(B, H, W, C1, C2, Cmid, Cout):
+    """conv_a emits ssq of its output; conv_b consumes (ssq_a, ssq_b over a concat) instead of a ROWSTAT pass."""
+    from imagen_pytorch_amd import ops
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    sk = 2 ** -0.5
+    x1 = torch.randn(B, C1, H, W).half().float()
+    x2 = torch.randn(B, C2, H, W).half().float() if C2 else None
+    C = C1 + C2
+    wa = torch.randn(Cmid, C, 3, 3) / math.sqrt(9 * C)
+    wb = torch.randn(Cout, Cmid + C1, 3, 3) / math.sqrt(9 * (Cmid + C1))
+    # reference: y = conv_a(cat(x1, x2*sk)) ; z = conv_b(silu(rms(cat(y, x1*sk))))
+    xin = x1 if x2 is None else torch.cat((x1, x2 * sk), 1)
+    y = F.conv2d(x1 if x2 is None else torch.cat((x1, x2), 1), (wa * insc_ref(C, C1, sk)).half().float(), None, padding=1)
+    y16 = y.half().float()
+    cat = torch.cat((y16, x1 * sk), 1)
+    hn = F.silu(F.normalize(cat, dim=1) * math.sqrt(Cmid + C1))
+    z = F.conv2d(hn, wb.half().float(), None, padding=1)
+
+    a1 = ops.act_from_nchw(x1.to(dev))
+    a2 = ops.act_from_nchw(x2.to(dev)) if x2 is not None else None
+    insc = torch.ones(C)
+    insc[C1:] = sk
+    pwa, pwb = ops.pack_weight(wa, None, dev, in_scale=insc), ops.pack_weight(wb, None, dev)
+    ya = ops.new_act(B, H, W, Cmid, dev)
+    ssq_y = torch.full((B * H * W,), -1.0, device=dev)
+    ssq_x1 = torch.empty(B * H * W, device=dev)
+    plan = ops.Plan()
+    op = ops.igemm(plan, a1, pwa, ya, x2=a2, ssq_out=ssq_y)
+    if not op.ssq_emitted:   # tile narrower than Cout: the planner's fallback
+        ops.rowstat(plan, ya, mode=2, rs=ssq_y)
+    ops.rowstat(plan, a1, mode=2, rs=ssq_x1)
+    pa = torch.ones(pwb.Cin_pad, device=dev) * math.sqrt(Cmid + C1)
+    pa[Cmid:Cmid + C1] *= sk
+    zb = ops.new_act(B, H, W, Cout, dev)
+    ops.igemm(plan, ya, pwb, zb, x2=a1, ssq_a=ssq_y, ssq_b=ssq_x1, ssq_wb=sk * sk, pa=pa, act_in=ops.ACT_SILU)
+    plan.run()
+    torch.cuda.synchronize()
+    ref_ssq = (y16 ** 2).sum(1).reshape(-1)
+    assert nerr(ssq_y, ref_ssq) < 2e-3, "epilogue sum of squares"
+    assert nerr(ops.act_to_nchw(ya), y) < 1e-3
+    assert nerr(ops.act_to_nchw(zb), z) < 2e-3
+
+
+def test_tail_kernels_emit_raw_ssq():
+    from imagen_pytorch_amd import ops
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(1)
+    B, H, W, C = 2, 16, 16, 64
+    h = torch.randn(B, C, H, W).half().float()
+    x = torch.randn(B, C, H, W).half().float()
+    gate = torch.rand(B, C)
+    out = ops.new_act(B, H, W, C, dev)
+    ssq = torch.empty(B * H * W, device=dev)
+    plan = ops.Plan()
+    ops.gate_residual(plan, ops.act_from_nchw(h.to(dev)), gate.to(dev), ops.act_from_nchw(x.to(dev)), out, rs_out=ssq, raw_ssq=True)
+    g = 1 + 0.1 * torch.randn(C)
+    out2 = ops.new_act(B, H, W, C, dev)
+    ssq2 = torch.empty(B * H * W, device=dev)
+    ops.ln_residual(plan, ops.act_from_nchw(h.to(dev)), g.to(dev), out2, res=ops.act_from_nchw(x.to(dev)), ssq_out=ssq2)
+    plan.run()
+    torch.cuda.synchronize()
+    o = ops.act_to_nchw(out).cpu()
+    assert nerr(ssq, (o ** 2).sum(1).reshape(-1)) < 1e-5
+    o2 = ops.act_to_nchw(out2).cpu()
+    assert nerr(ssq2, (o2 ** 2).sum(1).reshape(-1)) < 1e-5

@@ -332,8 +332,8 @@ def test_global_context(ops, dev, B, HW, C):
     part = torch.empty(B, chunks, C + 2, device=dev)
     gate = torch.empty(B, C, device=dev)
     plan = ops.Plan()
-    ops.gca(plan, a, wk.reshape(C).to(dev), float(bk), w1.reshape(hidden, C).contiguous().to(dev), b1.to(dev),
-            w2.reshape(C, hidden).contiguous().to(dev), b2.to(dev), part, gate, chunks)
+    ops.gca(plan, a, wk.reshape(C).to(dev), float(bk), w1.reshape(hidden, C).t().contiguous().to(dev), b1.to(dev),
+            w2.reshape(C, hidden).t().contiguous().to(dev), b2.to(dev), part, gate, chunks)
     _run(plan)
     assert nerr(gate, ref) < 1e-4
 
