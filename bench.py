@@ -52,6 +52,12 @@ def build_imagen(timesteps: int, device):
     return imagen.to(device).eval()
 
 
+# igemm tile configuration id -> template arguments <MI, NI, WM, WN, G> (csrc/igemm.hip kCfgs), to match rocprof kernel names
+CFG_TEMPLATE = {0: (2, 1, 4, 1, 4), 1: (4, 1, 1, 4, 4), 2: (4, 1, 2, 2, 4), 3: (2, 1, 1, 4, 4), 4: (1, 1, 4, 1, 4), 5: (2, 1, 4, 1, 1),
+                6: (1, 1, 2, 2, 4), 7: (1, 2, 2, 2, 1), 8: (1, 1, 2, 2, 1), 9: (1, 1, 4, 1, 1), 10: (2, 1, 1, 4, 16), 11: (4, 1, 1, 4, 8),
+                12: (1, 1, 2, 2, 16), 13: (1, 1, 4, 1, 8), 14: (2, 1, 1, 4, 8), 15: (1, 1, 2, 2, 8)}
+
+
 def igemm_flops(p) -> float:
     """Algorithmic FLOPs of one igemm launch: 2 * output pixels * Cout * (KH*KW*Cin)."""
     return 2.0 * p.B * p.OH * p.OW * p.Cout * p.KH * p.KW * (p.C1 + p.C2)
@@ -96,11 +102,27 @@ def roofline_leg(imagen, batch: int, device):
     cfg, (n, fl, sec) = max(per_cfg.items(), key=lambda kv: kv[1][2])
     tab = ops.cfg_table()
     achieved = fl / sec / 1e12
+    # HBM traffic per launch of that symbol from the committed PMC summaries (separate FETCH_SIZE / WRITE_SIZE passes of
+    # `rocprofv3 --pmc`, tools/pmc_summary.py); KiB units, FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B)
+    traffic = None
+    try:
+        fetch = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch.json")))
+        write = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_write.json")))
+        mi, ni, wm, wn, g = CFG_TEMPLATE[cfg]
+        pat = f"igemm_kernel<{mi}, {ni}, {wm}, {wn}, {g},"
+        fs = [(v["launches"], v.get("FETCH_SIZE", 0.0)) for k, v in fetch.items() if pat in k]
+        ws = [(v["launches"], v.get("WRITE_SIZE", 0.0)) for k, v in write.items() if pat in k]
+        if fs and ws:
+            favg = sum(a * b for a, b in fs) / sum(a for a, _ in fs)
+            wavg = sum(a * b for a, b in ws) / sum(a for a, _ in ws)
+            traffic = round((2.0 * favg + wavg) * 1024.0)
+    except (OSError, ValueError, KeyError):
+        pass
     summary = {str(c): {"launches": v[0], "tflops": round(v[1] / max(v[2], 1e-12) / 1e12, 1), "ms_total": round(v[2] * 1e3, 3)}
                for c, v in sorted(per_cfg.items())}
     return {
         "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-        "traffic": None,
+        "traffic": traffic,
         "kernel": f"igemm_kernel cfg {cfg} ({tab[cfg][0]} px x {tab[cfg][1]} cout tile, G={tab[cfg][2]})",
         "launches_per_denoiser_step_pair": n, "avg_launch_us": round(sec / n * 1e6, 2), "avg_launch_gflop": round(fl / n / 1e9, 3),
         "per_cfg": summary,

@@ -32,9 +32,11 @@ static inline int imagen_hip_status(const char* what) {
   return 0;
 }
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+// v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division: the staging prologue of the C=32 layers is VALU-bound
+// (tools/igemm_probe.py ablations), and SiLU runs once per staged element.  exp2 with the log2(e) fold saves the v_mul of __expf.
+__device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)); }
 __device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
-__device__ __forceinline__ float sigmoid_f(float v) { return 1.0f / (1.0f + __expf(-v)); }
+__device__ __forceinline__ float sigmoid_f(float v) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)); }
 
 // op launchers (one per translation unit)
 int launch_igemm(const ImagenIgemmParams* p, hipStream_t s);

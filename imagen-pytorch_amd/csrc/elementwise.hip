@@ -2,6 +2,7 @@
 // assembly, embeddings).  All kernels move 16 B per lane (8 fp16) with consecutive lanes on consecutive
 // addresses; reductions over a row use a power-of-two sub-group of the wave64 and __shfl_xor.
 #include "common.h"
+#include "gca_device.h"
 
 namespace {
 
@@ -347,57 +348,11 @@ __global__ __launch_bounds__(256) void gca_partial_online_kernel(const ImagenGca
   }
 }
 
-// One workgroup per image: merge the chunk partials (weights exp(m_i - M) shared through LDS), then the squeeze MLP with
-// transposed weights so consecutive threads read consecutive addresses.
+// One workgroup per image: merge the chunk partials and run the squeeze MLP (gca_device.h, shared with the fused igemm epilogue).
 __global__ __launch_bounds__(256) void gca_final_kernel(const ImagenGcaFinalParams p) {
-  extern __shared__ float sm[];  // ctx[C] | hid[hidden] | wgt[chunks]
-  float* ctx = sm;
-  float* hid = sm + p.C;
-  float* wgt = hid + p.hidden;
-  __shared__ float s_red[256];
+  extern __shared__ float sm[];  // C + hidden + chunks + 256 floats
   const int b = blockIdx.x;
-  const int stride = p.C + 2;
-  const float* part = p.part + (size_t)b * p.chunks * stride;
-  float lm = -3.0e38f;
-  for (int i = threadIdx.x; i < p.chunks; i += 256) lm = fmaxf(lm, part[(size_t)i * stride]);
-  s_red[threadIdx.x] = lm;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (threadIdx.x < off) s_red[threadIdx.x] = fmaxf(s_red[threadIdx.x], s_red[threadIdx.x + off]);
-    __syncthreads();
-  }
-  const float M = s_red[0];
-  __syncthreads();
-  float ls = 0.f;
-  for (int i = threadIdx.x; i < p.chunks; i += 256) {
-    const float w = __expf(part[(size_t)i * stride] - M);
-    wgt[i] = w;
-    ls += part[(size_t)i * stride + 1] * w;
-  }
-  s_red[threadIdx.x] = ls;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (threadIdx.x < off) s_red[threadIdx.x] += s_red[threadIdx.x + off];
-    __syncthreads();
-  }
-  const float S = s_red[0];
-  for (int c = threadIdx.x; c < p.C; c += 256) {
-    float a = 0.f;
-    for (int i = 0; i < p.chunks; ++i) a += part[(size_t)i * stride + 2 + c] * wgt[i];
-    ctx[c] = a / S;
-  }
-  __syncthreads();
-  for (int j = threadIdx.x; j < p.hidden; j += 256) {
-    float a = p.b1[j];
-    for (int c = 0; c < p.C; ++c) a += p.w1t[(size_t)c * p.hidden + j] * ctx[c];
-    hid[j] = silu_f(a);
-  }
-  __syncthreads();
-  for (int c = threadIdx.x; c < p.C; c += 256) {
-    float a = p.b2[c];
-    for (int j = 0; j < p.hidden; ++j) a += p.w2t[(size_t)j * p.C + c] * hid[j];
-    p.gate[(size_t)b * p.C + c] = sigmoid_f(a);
-  }
+  gca_finalize(p.part + (size_t)b * p.chunks * (p.C + 2), p.chunks, p.C, p.hidden, p.w1t, p.b1, p.w2t, p.b2, p.gate + (size_t)b * p.C, sm);
 }
 
 // ------------------------------------------------------------------------------------------------ embeddings / affine
@@ -549,7 +504,7 @@ int launch_gca_partial(const ImagenGcaPartialParams* p, hipStream_t s) {
 }
 
 int launch_gca_final(const ImagenGcaFinalParams* p, hipStream_t s) {
-  const size_t sm = (size_t)(p->C + p->hidden + p->chunks) * sizeof(float);
+  const size_t sm = (size_t)(p->C + p->hidden + p->chunks + 256) * sizeof(float);
   hipLaunchKernelGGL(gca_final_kernel, dim3(p->B), dim3(256), sm, s, *p);
   return imagen_hip_status("gca_final");
 }

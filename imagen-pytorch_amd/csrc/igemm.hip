@@ -14,6 +14,7 @@
 #include <type_traits>
 #include <utility>
 #include "common.h"
+#include "gca_device.h"
 
 namespace {
 
@@ -33,6 +34,14 @@ constexpr TileCfg kCfgs[] = {
     {1, 2, 2, 2, 1},  // 7:  64 px x 128 co,  8-ch chunks   (channel counts that are only multiples of 8)
     {1, 1, 2, 2, 1},  // 8:  64 px x  64 co,  8-ch chunks
     {1, 1, 4, 1, 1},  // 9: 128 px x  32 co,  8-ch chunks
+    // 1x1 convolutions / linear layers: no halo, so the k-chunk can be 64 or 128 channels deep (G = 8 | 16): 4-8 K=16 steps
+    // per barrier instead of 2, and 2-4x the bytes in flight per staging round trip
+    {2, 1, 1, 4, 16},  // 10:  64 px x 128 co, 128-ch chunks
+    {4, 1, 1, 4, 8},   // 11: 128 px x 128 co,  64-ch chunks
+    {1, 1, 2, 2, 16},  // 12:  64 px x  64 co, 128-ch chunks
+    {1, 1, 4, 1, 8},   // 13: 128 px x  32 co,  64-ch chunks
+    {2, 1, 1, 4, 8},   // 14:  64 px x 128 co,  64-ch chunks
+    {1, 1, 2, 2, 8},   // 15:  64 px x  64 co,  64-ch chunks
 };
 constexpr int kNumCfgs = sizeof(kCfgs) / sizeof(kCfgs[0]);
 
@@ -61,7 +70,7 @@ __global__ __launch_bounds__(256, (MI * NI <= 2 ? 2 : 1)) void igemm_kernel(cons
   constexpr int BN = 32 * NI * WN;
   constexpr int KC = Geo<G>::KC;
   constexpr int PS = Geo<G>::PS;
-  constexpr int LOG2G = (G == 1) ? 0 : (G == 2 ? 1 : 2);
+  constexpr int LOG2G = (G == 1) ? 0 : (G == 2) ? 1 : (G == 4) ? 2 : (G == 8) ? 3 : 4;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -169,7 +178,7 @@ __global__ __launch_bounds__(256, (MI * NI <= 2 ? 2 : 1)) void igemm_kernel(cons
           if (cc < p.C1) src = x1 + (size_t)b * p.bs1 + (size_t)gp * p.ld1 + cc;
           else if (cc - p.C1 < p.C2) src = x2 + (size_t)b * p.bs2 + (size_t)gp * p.ld2 + (cc - p.C1);
           if (src) {
-            raw[it] = *reinterpret_cast<const uint4*>(src);
+            if (!(p.dbg & 16)) raw[it] = *reinterpret_cast<const uint4*>(src);   // dbg 16: ablate the activation loads
             inb_mask |= 1u << it;
             const int sp = b * (p.H * p.W) + gp;
             if (p.rs) st_rs[it] = p.rs[sp];
@@ -369,7 +378,7 @@ __global__ __launch_bounds__(256, (MI * NI <= 2 ? 2 : 1)) void igemm_kernel(cons
           const int yy = 2 * oy + (sub >> 1), xx = 2 * ox + (sub & 1);
           *reinterpret_cast<f16x4*>(y + (size_t)b * p.bsy + ((size_t)yy * (2 * p.OW) + xx) * p.ldy + c) = o;
         } else {
-          *reinterpret_cast<f16x4*>(y + (size_t)b * p.bsy + (size_t)op * p.ldy + co) = o;
+          if (!(p.dbg & 8)) *reinterpret_cast<f16x4*>(y + (size_t)b * p.bsy + (size_t)op * p.ldy + co) = o;   // dbg 8: ablate the stores
         }
       }
     }
@@ -403,6 +412,123 @@ __global__ __launch_bounds__(256, (MI * NI <= 2 ? 2 : 1)) void igemm_kernel(cons
       }
     }
   }
+
+  // ---- optional: fused GlobalContext partials + last-workgroup finalisation (see ImagenIgemmParams.gca_*)
+  if (p.gca_wk) {
+    constexpr int PXW = 32 * MI;
+    float* lds = reinterpret_cast<float*>(smem) + 1024;   // past the ssq scratch; LDS is free after the main loop's last barrier
+    float* red = lds;                                     // [4 waves][PXW]
+    float* s_w = lds + 4 * PXW;                           // [8] per-wave scalars
+    float* chan = s_w + 8;                                // [BN] channel sums
+    int* s_flag = reinterpret_cast<int*>(chan + BN);
+    const int tiles_img = tilesX * tilesY;
+    const int tile_in_img = tile_y * tilesX + tile_x;
+    bool valid[MI];
+    float lg[MI];
+    // 1. logit per pixel: sum over this wave's channels, both lane halves, then all WN waves
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      valid[mi] = opix_y[mi] < p.OH && opix_x[mi] < p.OW;
+      float d = 0.0f;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
+          if (co < p.Cout) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) d += (acc[ni][mi][4 * q + e] + (p.bias ? p.bias[co + e] : 0.0f)) * p.gca_wk[co + e];
+          }
+        }
+      d += __shfl_xor(d, 32);
+      lg[mi] = d;
+    }
+    if (WN > 1) {
+      if (half == 0) {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) red[(wm * WN + wn) * PXW + mi * 32 + l31] = lg[mi];
+      }
+      __syncthreads();
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        float tot = 0.0f;
+#pragma unroll
+        for (int w = 0; w < WN; ++w) tot += red[(wm * WN + w) * PXW + mi * 32 + l31];
+        lg[mi] = tot;
+      }
+    }
+    // 2. tile max
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      lg[mi] += p.gca_bk;
+      if (valid[mi]) mx = fmaxf(mx, lg[mi]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
+    if (lane == 0) s_w[wave] = mx;
+    if (tid < BN) chan[tid] = 0.0f;
+    __syncthreads();
+    const float m_blk = fmaxf(fmaxf(s_w[0], s_w[1]), fmaxf(s_w[2], s_w[3]));
+    // 3. exp weights and their sum (every pixel counted once: wn == 0 waves, lower lane half)
+    float ew[MI];
+    float se = 0.0f;
+#pragma unroll
+    for (int mi = 0; mi < MI; ++mi) {
+      ew[mi] = valid[mi] ? __expf(lg[mi] - m_blk) : 0.0f;
+      se += ew[mi];
+    }
+    if (wn != 0 || half != 0) se = 0.0f;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) se += __shfl_xor(se, off);
+    __syncthreads();   // everyone has read s_w (max) before it is reused for the sums
+    if (lane == 0) s_w[wave] = se;
+    // 4. exp-weighted channel sums: in-lane over MI pixels, across the 32 pixel lanes by shuffles, across WM waves by LDS atomics
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float t = 0.0f;
+          if (co < p.Cout) {
+            const float bb = p.bias ? p.bias[co + e] : 0.0f;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) t += ew[mi] * (acc[ni][mi][4 * q + e] + bb);
+          }
+#pragma unroll
+          for (int off = 16; off > 0; off >>= 1) t += __shfl_xor(t, off);
+          if (l31 == 0 && co < p.Cout) atomicAdd(&chan[co - n0 + e], t);
+        }
+      }
+    __syncthreads();
+    float* part = p.gca_part + ((size_t)b * tiles_img + tile_in_img) * (p.Cout + 2);
+    if (tid < p.Cout) part[2 + tid] = chan[tid];
+    if (tid == 0) {
+      part[0] = m_blk;
+      part[1] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+    }
+    // 5. ticket: the last workgroup of this image merges all tiles (placement-independent release / acquire, agent scope)
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      const int old = __hip_atomic_fetch_add(p.gca_counter + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      const int last = (old == tiles_img - 1) ? 1 : 0;
+      if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+      *s_flag = last;
+    }
+    __syncthreads();
+    const int i_am_last = *s_flag;
+    __syncthreads();   // the finalisation below reuses this LDS region
+    if (i_am_last) {
+      gca_finalize(p.gca_part + (size_t)b * tiles_img * (p.Cout + 2), tiles_img, p.Cout, p.gca_hidden, p.gca_w1t, p.gca_b1, p.gca_w2t,
+                   p.gca_b2, p.gca_gate + (size_t)b * p.Cout, lds);
+      if (tid == 0) __hip_atomic_store(p.gca_counter + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
 }
 
 template <int MI, int NI, int WM, int WN, int G, int KSC>
@@ -418,6 +544,15 @@ int launch_ksc(const ImagenIgemmParams& p, hipStream_t s) {
                "igemm: channel counts / strides must be multiples of 8 (C1=%d C2=%d ld1=%d ld2=%d)", p.C1, p.C2, p.ld1, p.ld2);
   IMAGEN_CHECK(p.out_mode == IMAGEN_OUT_NCHW_F32 || p.Cout % 4 == 0, "igemm: Cout %d must be a multiple of 4", p.Cout);
   IMAGEN_CHECK(p.out_mode != IMAGEN_OUT_PIXEL_SHUFFLE || p.Cout % 16 == 0, "igemm: pixel-shuffle needs Cout %% 16 == 0");
+  if (p.gca_wk) {
+    IMAGEN_CHECK(p.out_mode == IMAGEN_OUT_NHWC && p.Cout <= BN && p.act_out == IMAGEN_ACT_NONE && !p.addend && !p.res,
+                 "igemm: fused GlobalContext needs a plain NHWC conv output and one workgroup covering all %d channels", p.Cout);
+    IMAGEN_CHECK(p.gca_part && p.gca_counter && p.gca_w1t && p.gca_b1 && p.gca_w2t && p.gca_b2 && p.gca_gate && p.gca_hidden > 0,
+                 "igemm: incomplete gca_* parameters");
+    const int tiles_img = ((p.OW + p.TW - 1) / p.TW) * ((p.OH + p.TH - 1) / p.TH);
+    const size_t need = (size_t)(1024 + p.Cout + p.gca_hidden + tiles_img + 256 + 4 * 32 * MI + 8 + BN + 4) * sizeof(float);
+    IMAGEN_CHECK(need <= (size_t)2 * IT * Geo<G>::PS, "igemm: fused GlobalContext scratch (%zu B) exceeds the tile LDS", need);
+  }
   IMAGEN_CHECK(!p.ssq_out || (p.out_mode == IMAGEN_OUT_NHWC && p.Cout <= BN),
                "igemm: ssq_out needs NHWC output and one workgroup covering all %d output channels (tile has %d)", p.Cout, BN);
   const size_t lds = (size_t)2 * IT * Geo<G>::PS;
@@ -443,6 +578,8 @@ int launch_cfg(const ImagenIgemmParams& p, hipStream_t s) {
     if (ks == 2) return launch_ksc<MI, NI, WM, WN, G, (G == 4 ? 2 : 0)>(p, s);
     if (ks == 8) return launch_ksc<MI, NI, WM, WN, G, (G == 4 ? 8 : 0)>(p, s);
   }
+  if (G == 8 && ks == 4) return launch_ksc<MI, NI, WM, WN, G, (G == 8 ? 4 : 0)>(p, s);
+  if (G == 16 && ks == 8) return launch_ksc<MI, NI, WM, WN, G, (G == 16 ? 8 : 0)>(p, s);
   return launch_ksc<MI, NI, WM, WN, G, 0>(p, s);
 }
 
@@ -464,6 +601,12 @@ int launch_igemm(const ImagenIgemmParams* pp, hipStream_t s) {
     case 7: return launch_cfg<1, 2, 2, 2, 1>(p, s);
     case 8: return launch_cfg<1, 1, 2, 2, 1>(p, s);
     case 9: return launch_cfg<1, 1, 4, 1, 1>(p, s);
+    case 10: return launch_cfg<2, 1, 1, 4, 16>(p, s);
+    case 11: return launch_cfg<4, 1, 1, 4, 8>(p, s);
+    case 12: return launch_cfg<1, 1, 2, 2, 16>(p, s);
+    case 13: return launch_cfg<1, 1, 4, 1, 8>(p, s);
+    case 14: return launch_cfg<2, 1, 1, 4, 8>(p, s);
+    case 15: return launch_cfg<1, 1, 2, 2, 8>(p, s);
   }
   return -1;
 }
@@ -483,7 +626,7 @@ static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 constexpr int kTailSteps = 8;  // >= the kernel's weight look-ahead
 
 extern "C" size_t imagen_igemm_packed_elems(int G, int Cin, int Cout_pad, int KH, int KW) {
-  if (G != 1 && G != 2 && G != 4) return 0;
+  if (G != 1 && G != 2 && G != 4 && G != 8 && G != 16) return 0;
   const int KC = 8 * G;
   const int NC = round_up(Cin, KC) / KC;
   const int KGP = ((KH * KW * G + 1) / 2) * 2;
@@ -495,7 +638,7 @@ extern "C" size_t imagen_igemm_packed_elems(int G, int Cin, int Cout_pad, int KH
 // The layout depends only on G (8-channel groups per k-chunk) and Cout_pad, not on the tile configuration.
 extern "C" int imagen_pack_igemm_weights(int G, const float* w_in, const float* in_scale, int Cin, int Cout, int Cout_pad,
                                          int KH, int KW, uint16_t* w_out) {
-  if (G != 1 && G != 2 && G != 4) { imagen_set_error("pack: bad G %d", G); return -1; }
+  if (G != 1 && G != 2 && G != 4 && G != 8 && G != 16) { imagen_set_error("pack: bad G %d", G); return -1; }
   if (Cout_pad < Cout || Cout_pad % 32) { imagen_set_error("pack: bad Cout_pad %d", Cout_pad); return -1; }
   const int KC = 8 * G;
   const int Cin_pad = round_up(Cin, KC);

@@ -50,6 +50,11 @@ def all_gather_images(local: Optional[torch.Tensor], total: int, *, group=None) 
     xGMI); ragged shards are padded to the largest shard first (the payload is ~0.8 MB/image, bandwidth is irrelevant)."""
     rank, world = dist.get_rank(group), dist.get_world_size(group)
     sizes = [shard_bounds(total, r, world)[1] - shard_bounds(total, r, world)[0] for r in range(world)]
+    if local is not None and all(s == sizes[0] for s in sizes):
+        # the common case (B divisible by the world size): exactly one collective, no metadata exchange
+        out = torch.empty((total, *local.shape[1:]), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
     shapes = [None]
     if local is not None:
         shapes = [tuple(local.shape[1:]), str(local.dtype), str(local.device)]

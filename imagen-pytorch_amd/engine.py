@@ -352,19 +352,23 @@ class UnetEngine:
         pa2 = self.pa2[:, off:]
         ps2 = self.ps2[:, off:]
         h2 = self.new(R, H, Wd, Cout)
-        ops.igemm(plan, h1, W.conv(name + ".block2", rb.block2.project), h2, ssq_a=s1, pa=pa2, ps=ps2, pstride=self.total_c,
-                  act_in=ACT_SILU, label=name + ".block2")
-        gate = None
+        gate, gca_args = None, None
         if rb.gca is not None:
             g = rb.gca
+            hidden = g.net[0].weight.shape[0]
+            gate = self.f32buf(R, Cout)
+            gca_args = dict(wk=W.f32(name + ".gca.wk", lambda: g.to_k.weight.reshape(-1)), bk=float(g.to_k.bias.detach().float().item()),
+                            w1t=W.f32(name + ".gca.w1t", lambda: g.net[0].weight.reshape(hidden, Cout).t()),
+                            b1=W.f32(name + ".gca.b1", lambda: g.net[0].bias),
+                            w2t=W.f32(name + ".gca.w2t", lambda: g.net[2].weight.reshape(Cout, hidden).t()),
+                            b2=W.f32(name + ".gca.b2", lambda: g.net[2].bias), gate=gate)
+        op2 = ops.igemm(plan, h1, W.conv(name + ".block2", rb.block2.project), h2, ssq_a=s1, pa=pa2, ps=ps2, pstride=self.total_c,
+                        act_in=ACT_SILU, gca=gca_args, label=name + ".block2")
+        if rb.gca is not None and not op2.gca_fused:   # tile narrower than Cout: stand-alone GlobalContext kernels
             chunks = ops.gca_chunks(H * Wd)
             part = self.f32buf(R, chunks, Cout + 2)
-            gate = self.f32buf(R, Cout)
-            hidden = g.net[0].weight.shape[0]
-            ops.gca(plan, h2, W.f32(name + ".gca.wk", lambda: g.to_k.weight.reshape(-1)), float(g.to_k.bias.detach().float().item()),
-                    W.f32(name + ".gca.w1t", lambda: g.net[0].weight.reshape(hidden, Cout).t()), W.f32(name + ".gca.b1", lambda: g.net[0].bias),
-                    W.f32(name + ".gca.w2t", lambda: g.net[2].weight.reshape(Cout, hidden).t()), W.f32(name + ".gca.b2", lambda: g.net[2].bias),
-                    part, gate, chunks, label=name + ".gca")
+            ops.gca(plan, h2, gca_args["wk"], gca_args["bk"], gca_args["w1t"], gca_args["b1"], gca_args["w2t"], gca_args["b2"], part, gate,
+                    chunks, label=name + ".gca")
         out = self.new(R, H, Wd, Cout)
         out.ssq = self.f32buf(R * H * Wd)
         if rb.res_conv is not None:

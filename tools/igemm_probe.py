@@ -45,7 +45,7 @@ def run(name, B, H, W, C1, C2, Cout, K, variant, cfg=None):
         ps = torch.rand(B, pw.Cin_pad, device=dev)
         kw = dict(rs=rs, pa=pa, ps=ps, pstride=pw.Cin_pad, act_in=ops.ACT_SILU)
     p = ops.igemm(plan, x1, pw, y, x2=x2, cfg=cfg, **kw)
-    p.dbg = {"dbg1": 1, "dbg2": 2, "dbg3": 3}.get(variant, 0)
+    p.dbg = int(variant[3:]) if variant.startswith("dbg") else 0   # bit mask, see ImagenIgemmParams.dbg
     for _ in range(3):
         plan.run()
     torch.cuda.synchronize()
@@ -61,8 +61,15 @@ def run(name, B, H, W, C1, C2, Cout, K, variant, cfg=None):
     return us, fl / us / 1e6, byts / us / 1e3, (p.cfg, p.TH, p.TW)
 
 if __name__ == "__main__":
-    variants = sys.argv[1:] or ["full", "noprologue", "dbg1", "dbg2"]
+    args = sys.argv[1:]
+    only = None
+    if args and args[0].startswith("--only="):
+        only = args[0][7:].split(",")
+        args = args[1:]
+    variants = args or ["full", "noprologue", "dbg1", "dbg2"]
     for shp in SHAPES:
+        if only and not any(o in shp[0] for o in only):
+            continue
         row = []
         for v in variants:
             us, tf, gbs, cfg = run(*shp, v)
