@@ -346,6 +346,26 @@ __global__ __launch_bounds__(256) void gca_partial_online_kernel(const ImagenGca
       out[1] = S;
     }
   }
+  if (p.counter == nullptr) return;
+  // last workgroup of this image finalises (agent-scope release / acquire ticket; placement-independent)
+  __shared__ int s_last;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int old = __hip_atomic_fetch_add(p.counter + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = (old == p.chunks - 1) ? 1 : 0;
+    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    s_last = last;
+  }
+  __syncthreads();
+  if (s_last) {
+    // scratch: the three LDS arrays above are contiguous enough only by luck — use s_acc (2048 floats) explicitly
+    gca_finalize(p.part + (size_t)b * p.chunks * (p.C + 2), p.chunks, p.C, p.hidden, p.w1t, p.b1, p.w2t, p.b2, p.gate + (size_t)b * p.C,
+                 s_acc);
+    if (threadIdx.x == 0) __hip_atomic_store(p.counter + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
 }
 
 // One workgroup per image: merge the chunk partials and run the squeeze MLP (gca_device.h, shared with the fused igemm epilogue).
@@ -494,6 +514,12 @@ int launch_gca_partial(const ImagenGcaPartialParams* p, hipStream_t s) {
   IMAGEN_CHECK(p->C % 8 == 0 && p->C / 8 <= 256, "gca: unsupported C %d", p->C);
   const int chunk_px = (p->HW + p->chunks - 1) / p->chunks;
   const int groups = p->C / 8;
+  if (p->counter) {
+    IMAGEN_CHECK((groups & (groups - 1)) == 0 && groups <= 64, "gca: in-kernel finalisation needs a power-of-two C/8 (C = %d)", p->C);
+    IMAGEN_CHECK(p->w1t && p->b1 && p->w2t && p->b2 && p->gate && p->hidden > 0, "gca: incomplete finalisation parameters");
+    IMAGEN_CHECK(p->C + p->hidden + p->chunks + 256 <= 2048, "gca: finalisation scratch too large (C %d hidden %d chunks %d)", p->C,
+                 p->hidden, p->chunks);
+  }
   if ((groups & (groups - 1)) == 0 && groups <= 64) {
     hipLaunchKernelGGL(gca_partial_online_kernel, dim3(p->chunks, p->B), dim3(256), 0, s, *p, chunk_px);
     return imagen_hip_status("gca_partial");

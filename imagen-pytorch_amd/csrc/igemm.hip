@@ -579,6 +579,7 @@ int launch_cfg(const ImagenIgemmParams& p, hipStream_t s) {
     if (ks == 8) return launch_ksc<MI, NI, WM, WN, G, (G == 4 ? 8 : 0)>(p, s);
   }
   if (G == 8 && ks == 4) return launch_ksc<MI, NI, WM, WN, G, (G == 8 ? 4 : 0)>(p, s);
+  if (G == 8 && ks == 36) return launch_ksc<MI, NI, WM, WN, G, (G == 8 ? 36 : 0)>(p, s);   // 3x3 with 64-channel chunks
   if (G == 16 && ks == 8) return launch_ksc<MI, NI, WM, WN, G, (G == 16 ? 8 : 0)>(p, s);
   return launch_ksc<MI, NI, WM, WN, G, 0>(p, s);
 }

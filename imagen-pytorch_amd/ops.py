@@ -194,6 +194,8 @@ def choose_G(Cin: int, taps: int = 9) -> int:
             return 16
         if Cin % 64 == 0:
             return 8
+    if taps == 9 and DEEP_3X3 and Cin % 64 == 0 and Cin >= 128:
+        return 8    # MFMA-bound 3x3 layers: half as many staging round trips / barriers per tile
     if Cin % 32 == 0:
         return 4
     return 1
@@ -229,7 +231,9 @@ def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], device, in_scale:
 
 import os as _os
 
+DEEP_3X3 = int(_os.environ.get("IMAGEN_DEEP_3X3", "1"))             # A/B switch: 64-channel k-chunks for 3x3 convs with C_in >= 128
 DEEP_CHUNKS = int(_os.environ.get("IMAGEN_DEEP_CHUNKS", "1"))       # A/B switch: 64/128-channel k-chunks for 1x1 convs / linears
+GCA_SINGLE_LAUNCH = int(_os.environ.get("IMAGEN_GCA_SINGLE_LAUNCH", "1"))   # A/B switch: finalise GlobalContext in the partial kernel
 FUSE_GCA_MAX_TILES = int(_os.environ.get("IMAGEN_FUSE_GCA_MAX_TILES", "64"))
 FUSE_GCA = int(_os.environ.get("IMAGEN_FUSE_GCA", "1"))             # A/B switch: GlobalContext partials + finalisation in the conv epilogue
 IGEMM_DBG = int(_os.environ.get("IMAGEN_IGEMM_DBG", "0"))          # kernel A/B switches (see ImagenIgemmParams.dbg); 0 in production
@@ -415,16 +419,28 @@ def qnorm(plan: Plan, q: torch.Tensor, q_scale: torch.Tensor, *, rows, heads, ld
 
 
 def gca(plan: Plan, h: Act, wk, bk: float, w1t, b1, w2t, b2, part: torch.Tensor, gate: torch.Tensor, chunks: int, label: str = ""):
-    """w1t: [C, hidden] (net.0.weight transposed), w2t: [hidden, C] (net.2.weight transposed), fp32 device tensors."""
+    """GlobalContext gate of h.  w1t: [C, hidden] (net.0.weight transposed), w2t: [hidden, C] (net.2.weight transposed), fp32.
+    One launch when the in-kernel finalisation applies (power-of-two C/8, scratch fits), else GCA_PARTIAL + GCA_FINAL."""
     C = h.C
+    hidden = w1t.shape[1]
+    assert tuple(w1t.shape) == (C, w2t.shape[0]) and w2t.shape[1] == C
     p = STRUCTS["ImagenGcaPartialParams"]()
     p.h, p.wk, p.part = h.ptr, wk.data_ptr(), part.data_ptr()
     p.B, p.HW, p.C, p.ld, p.chunks, p.bk = h.B, h.H * h.W, C, h.ld, chunks, bk
-    plan.add(p, (label or "gca") + ".partial", [h.t, wk, part])
+    groups = C // 8
+    single = GCA_SINGLE_LAUNCH and (groups & (groups - 1)) == 0 and groups <= 64 and C + hidden + chunks + 256 <= 2048
+    keep = [h.t, wk, part]
+    if single:
+        counter = torch.zeros(h.B, dtype=torch.int32, device=h.t.device)   # self-resetting ticket
+        p.counter, p.w1t, p.b1, p.w2t, p.b2, p.gate, p.hidden = (counter.data_ptr(), w1t.data_ptr(), b1.data_ptr(), w2t.data_ptr(),
+                                                                 b2.data_ptr(), gate.data_ptr(), hidden)
+        keep += [counter, w1t, b1, w2t, b2, gate]
+    plan.add(p, (label or "gca") + (".fused" if single else ".partial"), keep)
+    if single:
+        return
     f = STRUCTS["ImagenGcaFinalParams"]()
-    assert tuple(w1t.shape) == (C, w2t.shape[0]) and w2t.shape[1] == C
     f.part, f.w1t, f.b1, f.w2t, f.b2, f.gate = part.data_ptr(), w1t.data_ptr(), b1.data_ptr(), w2t.data_ptr(), b2.data_ptr(), gate.data_ptr()
-    f.B, f.C, f.hidden, f.chunks = h.B, C, w1t.shape[1], chunks
+    f.B, f.C, f.hidden, f.chunks = h.B, C, hidden, chunks
     plan.add(f, (label or "gca") + ".final", [part, w1t, b1, w2t, b2, gate])
 
 

@@ -170,7 +170,10 @@ typedef struct ImagenQnormParams {
  *   final: ctx = softmax-pooled mean; gate = sigmoid(W2 silu(W1 ctx + b1) + b2)   -> gate[b][C] */
 typedef struct ImagenGcaPartialParams {
   const void* h; const float* wk; float* part;
-  int32_t B, HW, C, ld, chunks; float bk;
+  /* optional in-kernel finalisation (replaces the GCA_FINAL launch): counter[B] is a zero-initialised, self-resetting ticket;
+   * the last workgroup of an image to finish merges the chunks and writes gate[b][C] (same protocol as the fused IGEMM epilogue) */
+  int32_t* counter; const float* w1t; const float* b1; const float* w2t; const float* b2; float* gate;
+  int32_t B, HW, C, ld, chunks, hidden; float bk;
 } ImagenGcaPartialParams;
 typedef struct ImagenGcaFinalParams {
   const float* part; const float* w1t; const float* b1; const float* w2t; const float* b2; float* gate;
