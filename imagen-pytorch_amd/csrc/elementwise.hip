@@ -309,18 +309,29 @@ __global__ __launch_bounds__(256) void gca_partial_online_kernel(const ImagenGca
   for (int j = 0; j < 8; ++j) wk[j] = p.wk[cg * 8 + j];
   float m = -3.0e38f, se = 0.f;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  for (int px = pl; px < npx; px += npl) {   // uniform trip count within each `groups`-lane team
-    const f16x8 v = *reinterpret_cast<const f16x8*>(h + (size_t)px * p.ld + cg * 8);
-    float d = 0.f;
+  constexpr int U = 4;   // pixels in flight per lane (the loop is a load-latency chain otherwise)
+  for (int px0 = pl; px0 < npx; px0 += npl * U) {   // uniform trip count within each `groups`-lane team
+    f16x8 v[U];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) d += (float)v[j] * wk[j];
-    d = group_sum(d, groups) + p.bk;
-    const float mn = fmaxf(m, d);
-    const float sc = __expf(m - mn), e = __expf(d - mn);
-    m = mn;
-    se = se * sc + e;
+    for (int u = 0; u < U; ++u) {
+      const int px = px0 + u * npl;
+      if (px < npx) v[u] = *reinterpret_cast<const f16x8*>(h + (size_t)px * p.ld + cg * 8);
+    }
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[j] = acc[j] * sc + e * (float)v[j];
+    for (int u = 0; u < U; ++u) {
+      if (px0 + u * npl < npx) {
+        float d = 0.f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) d += (float)v[u][j] * wk[j];
+        d = group_sum(d, groups) + p.bk;
+        const float mn = fmaxf(m, d);
+        const float sc = __expf(m - mn), e = __expf(d - mn);
+        m = mn;
+        se = se * sc + e;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] = acc[j] * sc + e * (float)v[u][j];
+      }
+    }
   }
   s_m[threadIdx.x] = m;
   s_se[threadIdx.x] = se;
@@ -370,7 +381,7 @@ __global__ __launch_bounds__(256) void gca_partial_online_kernel(const ImagenGca
 
 // One workgroup per image: merge the chunk partials and run the squeeze MLP (gca_device.h, shared with the fused igemm epilogue).
 __global__ __launch_bounds__(256) void gca_final_kernel(const ImagenGcaFinalParams p) {
-  extern __shared__ float sm[];  // C + hidden + chunks + 256 floats
+  extern __shared__ float sm[];  // C + hidden + chunks + kGcaScratchFloats floats
   const int b = blockIdx.x;
   gca_finalize(p.part + (size_t)b * p.chunks * (p.C + 2), p.chunks, p.C, p.hidden, p.w1t, p.b1, p.w2t, p.b2, p.gate + (size_t)b * p.C, sm);
 }
@@ -517,7 +528,7 @@ int launch_gca_partial(const ImagenGcaPartialParams* p, hipStream_t s) {
   if (p->counter) {
     IMAGEN_CHECK((groups & (groups - 1)) == 0 && groups <= 64, "gca: in-kernel finalisation needs a power-of-two C/8 (C = %d)", p->C);
     IMAGEN_CHECK(p->w1t && p->b1 && p->w2t && p->b2 && p->gate && p->hidden > 0, "gca: incomplete finalisation parameters");
-    IMAGEN_CHECK(p->C + p->hidden + p->chunks + 256 <= 2048, "gca: finalisation scratch too large (C %d hidden %d chunks %d)", p->C,
+    IMAGEN_CHECK(p->C + p->hidden + p->chunks + kGcaScratchFloats <= 2048, "gca: finalisation scratch too large (C %d hidden %d chunks %d)", p->C,
                  p->hidden, p->chunks);
   }
   if ((groups & (groups - 1)) == 0 && groups <= 64) {
@@ -530,7 +541,7 @@ int launch_gca_partial(const ImagenGcaPartialParams* p, hipStream_t s) {
 }
 
 int launch_gca_final(const ImagenGcaFinalParams* p, hipStream_t s) {
-  const size_t sm = (size_t)(p->C + p->hidden + p->chunks + 256) * sizeof(float);
+  const size_t sm = (size_t)(p->C + p->hidden + p->chunks + kGcaScratchFloats) * sizeof(float);
   hipLaunchKernelGGL(gca_final_kernel, dim3(p->B), dim3(256), sm, s, *p);
   return imagen_hip_status("gca_final");
 }

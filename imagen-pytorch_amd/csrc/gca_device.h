@@ -1,12 +1,74 @@
-// GlobalContext finalisation shared by the stand-alone GCA_FINAL kernel and the fused igemm epilogue
+// GlobalContext finalisation shared by the stand-alone GCA kernels and the fused igemm epilogue
 // (reference: GlobalContext.forward, ip.py:965-970).  Called by ALL 256 threads of one workgroup.
 #pragma once
 #include "common.h"
 
-// part: [chunks][C + 2] = (max logit, sum exp, sum exp * h[c]) per chunk of pixels of ONE image.
+constexpr int kGcaScratchFloats = 1024;   // reduction scratch beyond ctx / hid / wgt (4 floats per thread)
+
+// out[o] = emit(o, sum_i W[i * ldw + o] * in[i]) for o < n_out.  One workgroup; the whole job is a latency chain of
+// n_out * n_in / 256 loads per thread, so a thread owns V consecutive outputs (one vector load) and keeps 8 loads in flight.
+template <int V, class Emit>
+__device__ __forceinline__ void gca_matvec(int n_out, int n_in, const float* wt, int ldw, const float* in, float* s_red, Emit emit) {
+  const int tid = threadIdx.x;
+  const int nv = n_out / V;
+  const int opt = nv < 256 ? nv : 256;   // output vectors per pass
+  const int slices = 256 / opt;          // input slices summed through LDS
+  const int sl = tid / opt, oo = tid - sl * opt;
+  constexpr int U = 8;
+  for (int o0 = 0; o0 < nv; o0 += opt) {
+    float a[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) a[e] = 0.f;
+    if (sl < slices && o0 + oo < nv) {
+      const float* w = wt + (size_t)(o0 + oo) * V;
+      int i = sl;
+      for (; i + (U - 1) * slices < n_in; i += U * slices) {
+        float v[U][V];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const float* q = w + (size_t)(i + u * slices) * ldw;
+          if constexpr (V == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(q);
+            v[u][0] = t.x; v[u][1] = t.y; v[u][2] = t.z; v[u][3] = t.w;
+          } else if constexpr (V == 2) {
+            const float2 t = *reinterpret_cast<const float2*>(q);
+            v[u][0] = t.x; v[u][1] = t.y;
+          } else {
+            v[u][0] = q[0];
+          }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+          const float x = in[i + u * slices];
+#pragma unroll
+          for (int e = 0; e < V; ++e) a[e] += v[u][e] * x;
+        }
+      }
+      for (; i < n_in; i += slices) {
+        const float x = in[i];
+#pragma unroll
+        for (int e = 0; e < V; ++e) a[e] += w[(size_t)i * ldw + e] * x;
+      }
+    }
+#pragma unroll
+    for (int e = 0; e < V; ++e) s_red[e * 256 + tid] = a[e];
+    __syncthreads();
+    if (tid < opt && o0 + tid < nv) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        float t = 0.f;
+        for (int q = 0; q < slices; ++q) t += s_red[e * 256 + q * opt + tid];
+        emit((o0 + tid) * V + e, t);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+// part: [chunks][C + 2] = (max logit, sum exp, sum exp * h[c]) per chunk of pixels of ONE image (8-byte aligned rows).
 //   ctx[c] = sum_i part[i][2+c] * exp(m_i - M) / sum_i s_i * exp(m_i - M)
-//   gate   = sigmoid(W2 silu(W1 ctx + b1) + b2)        (w1t: [C][hidden], w2t: [hidden][C])
-// lds: scratch of at least C + hidden + chunks + 256 floats.
+//   gate   = sigmoid(W2 silu(W1 ctx + b1) + b2)        (w1t: [C][hidden], w2t: [hidden][C], 16-byte aligned, C % 8 == 0)
+// lds: scratch of at least C + hidden + chunks + kGcaScratchFloats floats.
 __device__ __forceinline__ void gca_finalize(const float* part, int chunks, int C, int hidden, const float* w1t, const float* b1,
                                              const float* w2t, const float* b2, float* gate, float* lds) {
   float* ctx = lds;
@@ -37,48 +99,12 @@ __device__ __forceinline__ void gca_finalize(const float* part, int chunks, int 
     if (tid < off) s_red[tid] += s_red[tid + off];
     __syncthreads();
   }
-  const float S = s_red[0];
+  const float inv_S = 1.0f / s_red[0];
   __syncthreads();
-  // ctx: thread = (chunk slice, channel); slices merged through LDS
-  {
-    const int cpt = C < 256 ? C : 256;
-    const int slices = 256 / cpt;
-    const int sl = tid / cpt, cc = tid - sl * cpt;
-    for (int c0 = 0; c0 < C; c0 += cpt) {
-      float a = 0.f;
-      if (sl < slices && c0 + cc < C)
-        for (int i = sl; i < chunks; i += slices) a += part[(size_t)i * stride + 2 + c0 + cc] * wgt[i];
-      s_red[tid] = a;
-      __syncthreads();
-      if (tid < cpt && c0 + tid < C) {
-        float t = 0.f;
-        for (int q = 0; q < slices; ++q) t += s_red[q * cpt + tid];
-        ctx[c0 + tid] = t / S;
-      }
-      __syncthreads();
-    }
-  }
-  // squeeze MLP: out[o] = act(bias[o] + sum_i Wt[i][o] * in[i]); thread = (input slice, output)
-  auto matvec = [&](int n_out, int n_in, const float* wt, const float* bias, const float* in, float* out_lds, float* out_gate)
-                    __attribute__((always_inline)) {
-    const int opt = n_out < 256 ? n_out : 256;
-    const int slices = 256 / opt;
-    const int sl = tid / opt, oo = tid - sl * opt;
-    for (int o0 = 0; o0 < n_out; o0 += opt) {
-      float a = 0.f;
-      if (sl < slices && o0 + oo < n_out)
-        for (int i = sl; i < n_in; i += slices) a += wt[(size_t)i * n_out + o0 + oo] * in[i];
-      s_red[tid] = a;
-      __syncthreads();
-      if (tid < opt && o0 + tid < n_out) {
-        float t = bias[o0 + tid];
-        for (int q = 0; q < slices; ++q) t += s_red[q * opt + tid];
-        if (out_lds) out_lds[o0 + tid] = silu_f(t);
-        else out_gate[o0 + tid] = sigmoid_f(t);
-      }
-      __syncthreads();
-    }
-  };
-  matvec(hidden, C, w1t, b1, ctx, hid, nullptr);
-  matvec(C, hidden, w2t, b2, hid, nullptr, gate);
+  gca_matvec<2>(C, chunks, part + 2, stride, wgt, s_red, [&](int o, float t) __attribute__((always_inline)) { ctx[o] = t * inv_S; });
+  if ((hidden & 3) == 0)
+    gca_matvec<4>(hidden, C, w1t, hidden, ctx, s_red, [&](int o, float t) __attribute__((always_inline)) { hid[o] = silu_f(t + b1[o]); });
+  else
+    gca_matvec<1>(hidden, C, w1t, hidden, ctx, s_red, [&](int o, float t) __attribute__((always_inline)) { hid[o] = silu_f(t + b1[o]); });
+  gca_matvec<4>(C, hidden, w2t, C, hid, s_red, [&](int o, float t) __attribute__((always_inline)) { gate[o] = sigmoid_f(t + b2[o]); });
 }

@@ -550,7 +550,7 @@ int launch_ksc(const ImagenIgemmParams& p, hipStream_t s) {
     IMAGEN_CHECK(p.gca_part && p.gca_counter && p.gca_w1t && p.gca_b1 && p.gca_w2t && p.gca_b2 && p.gca_gate && p.gca_hidden > 0,
                  "igemm: incomplete gca_* parameters");
     const int tiles_img = ((p.OW + p.TW - 1) / p.TW) * ((p.OH + p.TH - 1) / p.TH);
-    const size_t need = (size_t)(1024 + p.Cout + p.gca_hidden + tiles_img + 256 + 4 * 32 * MI + 8 + BN + 4) * sizeof(float);
+    const size_t need = (size_t)(1024 + p.Cout + p.gca_hidden + tiles_img + kGcaScratchFloats + 4 * 32 * MI + 8 + BN + 4) * sizeof(float);
     IMAGEN_CHECK(need <= (size_t)2 * IT * Geo<G>::PS, "igemm: fused GlobalContext scratch (%zu B) exceeds the tile LDS", need);
   }
   IMAGEN_CHECK(!p.ssq_out || (p.out_mode == IMAGEN_OUT_NHWC && p.Cout <= BN),

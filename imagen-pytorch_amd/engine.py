@@ -365,7 +365,7 @@ class UnetEngine:
         op2 = ops.igemm(plan, h1, W.conv(name + ".block2", rb.block2.project), h2, ssq_a=s1, pa=pa2, ps=ps2, pstride=self.total_c,
                         act_in=ACT_SILU, gca=gca_args, label=name + ".block2")
         if rb.gca is not None and not op2.gca_fused:   # tile narrower than Cout: stand-alone GlobalContext kernels
-            chunks = ops.gca_chunks(H * Wd)
+            chunks = ops.gca_chunks(H * Wd, R)
             part = self.f32buf(R, chunks, Cout + 2)
             ops.gca(plan, h2, gca_args["wk"], gca_args["bk"], gca_args["w1t"], gca_args["b1"], gca_args["w2t"], gca_args["b2"], part, gate,
                     chunks, label=name + ".gca")

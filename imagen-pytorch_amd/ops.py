@@ -231,10 +231,10 @@ def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], device, in_scale:
 
 import os as _os
 
-DEEP_3X3 = int(_os.environ.get("IMAGEN_DEEP_3X3", "1"))             # A/B switch: 64-channel k-chunks for 3x3 convs with C_in >= 128
+DEEP_3X3 = int(_os.environ.get("IMAGEN_DEEP_3X3", "0"))             # A/B switch: 64-channel k-chunks for 3x3 convs with C_in >= 128
 DEEP_CHUNKS = int(_os.environ.get("IMAGEN_DEEP_CHUNKS", "1"))       # A/B switch: 64/128-channel k-chunks for 1x1 convs / linears
 GCA_SINGLE_LAUNCH = int(_os.environ.get("IMAGEN_GCA_SINGLE_LAUNCH", "1"))   # A/B switch: finalise GlobalContext in the partial kernel
-FUSE_GCA_MAX_TILES = int(_os.environ.get("IMAGEN_FUSE_GCA_MAX_TILES", "64"))
+FUSE_GCA_MAX_TILES = int(_os.environ.get("IMAGEN_FUSE_GCA_MAX_TILES", "16"))
 FUSE_GCA = int(_os.environ.get("IMAGEN_FUSE_GCA", "1"))             # A/B switch: GlobalContext partials + finalisation in the conv epilogue
 IGEMM_DBG = int(_os.environ.get("IMAGEN_IGEMM_DBG", "0"))          # kernel A/B switches (see ImagenIgemmParams.dbg); 0 in production
 FILL_BLOCKS = int(_os.environ.get("IMAGEN_FILL_BLOCKS", "512"))   # workgroups wanted before growing the tile (2 per CU on 256 CUs)
@@ -348,7 +348,7 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
         ps_ = 16 if g_ == 1 else g_ * 16 + 16
         it_ = ((th - 1) * stride + KH) * ((tw - 1) * stride + KW)
         hidden = gca["w1t"].shape[1]
-        need = (1024 + pw.Cout + hidden + tiles + 256 + 4 * tp_ + 8 + bn_ + 4) * 4
+        need = (1024 + pw.Cout + hidden + tiles + GCA_SCRATCH + 4 * tp_ + 8 + bn_ + 4) * 4
         # measured (MI355X, README cascade): the fused epilogue wins on small maps (fewer launches, u1) and loses on the big
         # ones, where every one of thousands of workgroups pays the extra reductions and one workgroup merges them all
         if need <= 2 * it_ * ps_ and tiles <= FUSE_GCA_MAX_TILES:
@@ -428,7 +428,7 @@ def gca(plan: Plan, h: Act, wk, bk: float, w1t, b1, w2t, b2, part: torch.Tensor,
     p.h, p.wk, p.part = h.ptr, wk.data_ptr(), part.data_ptr()
     p.B, p.HW, p.C, p.ld, p.chunks, p.bk = h.B, h.H * h.W, C, h.ld, chunks, bk
     groups = C // 8
-    single = GCA_SINGLE_LAUNCH and (groups & (groups - 1)) == 0 and groups <= 64 and C + hidden + chunks + 256 <= 2048
+    single = GCA_SINGLE_LAUNCH and (groups & (groups - 1)) == 0 and groups <= 64 and C + hidden + chunks + GCA_SCRATCH <= 2048
     keep = [h.t, wk, part]
     if single:
         counter = torch.zeros(h.B, dtype=torch.int32, device=h.t.device)   # self-resetting ticket
@@ -444,9 +444,15 @@ def gca(plan: Plan, h: Act, wk, bk: float, w1t, b1, w2t, b2, part: torch.Tensor,
     plan.add(f, (label or "gca") + ".final", [part, w1t, b1, w2t, b2, gate])
 
 
-def gca_chunks(HW: int) -> int:
-    c = max(1, math.ceil(HW / 1024))
-    return c
+GCA_SCRATCH = 1024   # csrc/gca_device.h kGcaScratchFloats
+
+
+def gca_chunks(HW: int, B: int = 16) -> int:
+    """Pixel chunks per image for the stand-alone GlobalContext kernel: about 1024 workgroups over the batch (the 256 CUs
+    stay busy even on the 32x32 maps), chunks of at least 64 pixels (the merge cost grows with the chunk count)."""
+    target = max(1, 1024 // max(B, 1))
+    chunk_px = max(64, math.ceil(HW / target))
+    return max(1, math.ceil(HW / chunk_px))
 
 
 def gate_residual(plan: Plan, h: Act, gate: Optional[torch.Tensor], res: Act, out: Act, rs_out: Optional[torch.Tensor] = None,

@@ -60,6 +60,8 @@ CONV_CASES = [
     (2, 8, 8, 256, 128, 256, False),
     (1, 24, 40, 64, 32, 64, True),      # ragged tiles
     (3, 8, 8, 16, 8, 24, True),         # 8-channel-chunk path (G = 1)
+    (2, 16, 24, 96, 32, 128, True),     # 64-channel chunks (G = 8) with the concat boundary inside a chunk
+    (1, 32, 32, 256, 256, 192, True),   # G = 8, Cout not a multiple of the 128 tile
 ]
 
 
