@@ -106,7 +106,7 @@ extern "C" int imagen_graph_end(imagen_stream_t stream, void** graph_exec_out) {
   HIP_TRY(hipStreamEndCapture(reinterpret_cast<hipStream_t>(stream), &graph), "hipStreamEndCapture");
   hipGraphExec_t exec = nullptr;
   hipError_t e = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
-  hipGraphDestroy(graph);
+  (void)hipGraphDestroy(graph);
   if (e != hipSuccess) { imagen_set_error("hipGraphInstantiate: %s", hipGetErrorString(e)); return (int)e; }
   *graph_exec_out = exec;
   return 0;

@@ -11,10 +11,10 @@
 // The k dimension runs over channel chunks of 8*G channels; inside a chunk over (tap, 8-channel group) pairs;
 // two consecutive groups (lane>>5 selects) feed one K=16 MFMA.  Staging of chunk c+1 (global loads issued
 // before, LDS writes after the MFMAs of chunk c) overlaps the matrix work of chunk c.
+#include <algorithm>
 #include <type_traits>
 #include <utility>
 #include "common.h"
-#include "gca_device.h"
 
 namespace {
 
@@ -63,180 +63,269 @@ template <int G> struct Geo {
 // KSC > 0: the number of K=16 steps per channel chunk is a compile-time constant (18 for 3x3 convs with 32-channel
 // chunks, 2 for 1x1 / linear, 8 for the 2x2 stride-2 downsample): the k-loop is fully unrolled so the weight-fragment ring is
 // statically indexed (no register copies of in-flight loads, which would force a vmcnt wait every step).  KSC == 0: generic loop.
-// occupancy target (waves per SIMD): 2 for the 64-pixel-per-wave tilings (<= 256 VGPR+AGPR), 1 for the 128-pixel ones
+//
+// WAVE-SPECIALISED, PERSISTENT workgroups of 8 waves.  vmcnt retires loads in issue order, so a wave that streams weight
+// fragments (L2 latency) and also has activation loads (HBM latency) in flight stalls on the slower stream at every weight
+// wait — staging and matrix work cannot overlap inside one wave.  Hence two roles with independent counters:
+//   waves 4-7 (producers): global loads of phase q+2 in flight, prologue math + LDS writes of phase q+1
+//   waves 0-3 (consumers): weight ring + MFMAs of phase q out of LDS, then the epilogue of a finished tile
+// where a "phase" is (output tile, channel chunk).  One s_barrier per phase hands an LDS buffer over.  The grid is sized to
+// what the chip holds and every workgroup walks a strided list of tiles, so the pipeline also runs ACROSS tiles (layers with
+// one or two chunks per tile — C_in = 32 / 64, most of the 256^2 / 128^2 levels — have no other overlap to offer): the
+// consumers' epilogue stores fly while the producers already stage the next tile, and the weight ring wraps to the next
+// tile's first steps kLookAhead steps before a tile ends.  Workgroup ids are dealt round-robin to the 8 XCDs, so each XCD
+// (own L2) gets a contiguous range of tiles and neighbouring halos meet in the same L2.
+struct TileCoord { int b, oy0, ox0, n0; };
+
+// LDS hand-over between the roles: LDS traffic of this wave retired, then the workgroup barrier.  Deliberately NOT
+// __syncthreads(): global loads stay in flight across it.
+__device__ __forceinline__ void lds_barrier() {
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 template <int MI, int NI, int WM, int WN, int G, int KSC>
-__global__ __launch_bounds__(256, (MI * NI <= 2 ? 2 : 1)) void igemm_kernel(const ImagenIgemmParams p) {
-  static_assert(WM * WN == 4, "4 waves per workgroup");
+__global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(const ImagenIgemmParams p) {
+  static_assert(WM * WN == 4, "4 consumer waves per workgroup");
   constexpr int BN = 32 * NI * WN;
   constexpr int KC = Geo<G>::KC;
   constexpr int PS = Geo<G>::PS;
   constexpr int LOG2G = (G == 1) ? 0 : (G == 2) ? 1 : (G == 4) ? 2 : (G == 8) ? 3 : 4;
+  constexpr int PXW = 32 * MI;  // pixels per consumer wave
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wave = tid >> 6;
-  const int half = lane >> 5, l31 = lane & 31;
-  const int wm = wave / WN, wn = wave % WN;
+  const bool producer = tid >= 256;   // wave-uniform role
+  const int rtid = tid & 255;         // thread index inside the role
 
-  // ---- which output tile
+  // ---- the tile list of this workgroup
   const int tilesX = (p.OW + p.TW - 1) / p.TW;
   const int tilesY = (p.OH + p.TH - 1) / p.TH;
-  int t = blockIdx.x;
-  const int tile_x = t % tilesX;
-  t /= tilesX;
-  const int tile_y = t % tilesY;
-  const int b = t / tilesY;
-  const int oy0 = tile_y * p.TH, ox0 = tile_x * p.TW;
-  const int n0 = blockIdx.y * BN;
+  const int tilesN = (p.Cout + BN - 1) / BN;
+  const int total_tiles = p.B * tilesY * tilesX * tilesN;
+  int t_cursor, t_end, t_step;
+  if ((gridDim.x & 7) == 0 && !(p.dbg & 64)) {
+    const int xcd = blockIdx.x & 7, lw = blockIdx.x >> 3;
+    const int per_xcd = (total_tiles + 7) >> 3;
+    t_cursor = xcd * per_xcd + lw;
+    t_end = min((xcd + 1) * per_xcd, total_tiles);
+    t_step = gridDim.x >> 3;
+  } else {
+    t_cursor = blockIdx.x;
+    t_end = total_tiles;
+    t_step = gridDim.x;
+  }
+  if (t_cursor >= t_end) return;
+  auto decode = [&](int t) __attribute__((always_inline)) -> TileCoord {   // cout tile fastest: the cout tiles of a pixel tile run side by side
+    TileCoord c;
+    const int nt = t % tilesN;
+    t /= tilesN;
+    const int tx = t % tilesX;
+    t /= tilesX;
+    const int ty = t % tilesY;
+    c.b = t / tilesY;
+    c.oy0 = ty * p.TH;
+    c.ox0 = tx * p.TW;
+    c.n0 = nt * BN;
+    return c;
+  };
 
   const int ITW = (p.TW - 1) * p.stride + p.KW;
   const int ITH = (p.TH - 1) * p.stride + p.KH;
   const int IT = ITH * ITW;
-  const int items = IT << LOG2G;
-  const float inv_itw = 1.0f / (float)ITW;
-  const int iy0 = oy0 * p.stride - p.pad, ix0 = ox0 * p.stride - p.pad;
   const int buf_bytes = IT * PS;
-
   const int ntap = p.KH * p.KW;
   const int KG = ntap * G;            // 8-channel groups per chunk
   const int KS = KSC > 0 ? KSC : (KG + 1) >> 1;  // K=16 MFMA steps per chunk (odd KG: last half-step is zero weights)
   const int NC = p.Cin_pad / KC;      // chunks
+  const bool ssq_sync = p.ssq_out != nullptr && WN > 1;   // the epilogue's cross-wave reduction needs one extra workgroup barrier per tile
 
-  // ---- per-lane output pixel coordinates (lane = pixel in the MFMA N dimension)
+  if (producer) {
+    // =========================================================================================== producers (waves 4-7)
+    const int items = IT << LOG2G;
+    const float inv_itw = 1.0f / (float)ITW;
+    const f16* x1 = reinterpret_cast<const f16*>(p.x1);
+    const f16* x2 = reinterpret_cast<const f16*>(p.x2);
+    // per-chunk prologue affine of THIS thread's 8-channel group: every item of a thread has the same group (256 % G == 0) and
+    // the tile lies in one batch row, so the 8 + 8 floats are loaded once per phase, together with the activations
+    const int my_cg = rtid & (G - 1);
+    // tile-independent geometry of this thread's staging items: pixel (iy, ix) inside the halo tile
+    int it_iy[kMaxItems], it_ix[kMaxItems];
+    static_for<kMaxItems>([&](auto ic) __attribute__((always_inline)) {
+      constexpr int it = decltype(ic)::value;
+      const int idx = rtid + it * 256;
+      const int pix = idx >> LOG2G;
+      const int iy = (int)(((float)pix + 0.5f) * inv_itw);
+      it_iy[it] = idx < items ? iy : -(1 << 20);   // slots beyond the tile never pass the bounds test
+      it_ix[it] = pix - iy * ITW;
+    });
+    uint4 raw[kMaxItems];
+    float st_q1[kMaxItems], st_q2[kMaxItems];   // rs | ssq_a | mu (q2: ssq_b | mu) as loaded; the arithmetic happens at write time
+    float4 st_a0, st_a1, st_s0, st_s1;
+    unsigned inb_mask = 0;
+    const float* q1_ptr = p.rs ? p.rs : p.ssq_a;                  // one load site per statistics array (uniform selection, made once)
+    const float* q2_ptr = p.mu ? p.mu : (p.rs ? nullptr : p.ssq_b);
+
+    // ONLY loads (every one unconditional: out-of-range items read a valid dummy address), so that nothing here waits on memory
+    auto stage_load = [&](const TileCoord& tc, int chunk) __attribute__((always_inline)) {
+      inb_mask = 0;
+      const int b = tc.b;
+      const int iy0 = tc.oy0 * p.stride - p.pad, ix0 = tc.ox0 * p.stride - p.pad;
+      const int cc = chunk * KC + my_cg * 8;
+      if (p.pa) {
+        const float4* q = reinterpret_cast<const float4*>(p.pa + (size_t)b * p.pstride + cc);
+        st_a0 = q[0];
+        st_a1 = q[1];
+      }
+      if (p.ps) {
+        const float4* q = reinterpret_cast<const float4*>(p.ps + (size_t)b * p.pstride + cc);
+        st_s0 = q[0];
+        st_s1 = q[1];
+      }
+      const bool from1 = cc < p.C1;
+      const bool chan_ok = from1 || (cc - p.C1 < p.C2);
+      const f16* base = from1 ? x1 + (size_t)b * p.bs1 + cc : x2 + (size_t)b * p.bs2 + (cc - p.C1);
+      const int ld = from1 ? p.ld1 : p.ld2;
+      const int sp0 = b * (p.H * p.W);
+      static_for<kMaxItems>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int it = decltype(ic)::value;
+        const int gy = iy0 + it_iy[it], gx = ix0 + it_ix[it];
+        const bool ok = chan_ok && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        const int gp = ok ? gy * p.W + gx : 0;
+        const f16* src = ok ? base + (size_t)gp * ld : x1;
+        if (!(p.dbg & 16)) raw[it] = *reinterpret_cast<const uint4*>(src);   // dbg 16: ablate the activation loads
+        if (ok) inb_mask |= 1u << it;
+        const int sp = sp0 + gp;
+        if (q1_ptr) st_q1[it] = q1_ptr[sp];
+        if (q2_ptr) st_q2[it] = q2_ptr[sp];
+      });
+    };
+
+    // transform + LDS write of the staged items
+    auto stage_write = [&](char* buf) __attribute__((always_inline)) {
+      float a[8], s[8];
+      if (p.pa) { a[0] = st_a0.x; a[1] = st_a0.y; a[2] = st_a0.z; a[3] = st_a0.w; a[4] = st_a1.x; a[5] = st_a1.y; a[6] = st_a1.z; a[7] = st_a1.w; }
+      else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = 1.0f;
+      }
+      if (p.ps) { s[0] = st_s0.x; s[1] = st_s0.y; s[2] = st_s0.z; s[3] = st_s0.w; s[4] = st_s1.x; s[5] = st_s1.y; s[6] = st_s1.z; s[7] = st_s1.w; }
+      else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) s[j] = 0.0f;
+      }
+      static_for<kMaxItems>([&](auto ic) __attribute__((always_inline)) {
+        constexpr int it = decltype(ic)::value;
+        const int idx = rtid + it * 256;
+        if (idx < items) {
+          const int pix = idx >> LOG2G;
+          f16x8 out;
+          if (inb_mask & (1u << it)) {
+            const f16x8 in = *reinterpret_cast<const f16x8*>(&raw[it]);
+            float rs = 1.0f, mu = 0.0f;
+            if (p.rs) rs = st_q1[it];
+            else if (p.ssq_a) {  // ChanRMSNorm statistics straight from the producers' per-pixel sums of squares
+              float q = st_q1[it];
+              if (p.ssq_b) q += p.ssq_wb * st_q2[it];
+              rs = 1.0f / fmaxf(sqrtf(q), 1e-12f);
+            }
+            if (p.mu) mu = st_q2[it];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+              float v = ((float)in[j] - mu) * rs * a[j] + s[j];
+              if (p.act_in == IMAGEN_ACT_SILU) v = silu_f(v);
+              out[j] = (f16)v;
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) out[j] = (f16)0.0f;
+          }
+          *reinterpret_cast<f16x8*>(buf + pix * PS + my_cg * 16) = out;
+        }
+      });
+    };
+
+    // phase cursor: (t_cursor, chunk) is the phase whose loads are issued next
+    TileCoord tl = decode(t_cursor);
+    int chunk = 0;
+    auto advance = [&]() __attribute__((always_inline)) {
+      if (++chunk == NC) {
+        chunk = 0;
+        t_cursor += t_step;
+        if (t_cursor < t_end) tl = decode(t_cursor);
+      }
+    };
+    // number of phases of this workgroup, and per phase whether it ends a tile: recomputed from counters
+    int tiles_left = (t_end - t_cursor + t_step - 1) / t_step;
+    int phases_left = tiles_left * NC;       // phases whose buffer hand-over barrier is still to come
+    int c_done = 0;                          // chunk index of the phase the consumers are working on
+    stage_load(tl, 0);
+    stage_write(smem);
+    advance();
+    if (t_cursor < t_end && !(p.dbg & 1)) stage_load(tl, chunk);
+    lds_barrier();                           // phase 0 is in buffer 0
+    int cur = 0;
+    while (phases_left > 0) {
+      // consumers: phase q out of buf[cur].  here: phase q+1 into buf[cur^1], loads of phase q+2
+      if (t_cursor < t_end) {
+        if (!(p.dbg & 1)) stage_write(smem + (cur ^ 1) * buf_bytes);
+        advance();
+        if (t_cursor < t_end && !(p.dbg & 1)) stage_load(tl, chunk);
+      }
+      lds_barrier();
+      cur ^= 1;
+      --phases_left;
+      if (++c_done == NC) {
+        c_done = 0;
+        if (ssq_sync) lds_barrier();         // pairs with the consumers' epilogue reduction
+      }
+    }
+    return;
+  }
+
+  // ============================================================================================= consumers (waves 0-3)
+  const int lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wave / WN, wn = wave % WN;
+  float* ep_red = reinterpret_cast<float*>(smem + 2 * buf_bytes);   // [4 waves][PXW] epilogue scratch, disjoint from the staging buffers
+
+  // ---- per-lane output pixel coordinates inside the tile (lane = pixel in the MFMA N dimension)
   int a_base[MI];
-  int opix_y[MI], opix_x[MI];
+  int pix_y[MI], pix_x[MI];
 #pragma unroll
   for (int mi = 0; mi < MI; ++mi) {
     const int tp = (wm * MI + mi) * 32 + l31;
     const int py = tp / p.TW, px = tp - py * p.TW;
-    opix_y[mi] = oy0 + py;
-    opix_x[mi] = ox0 + px;
+    pix_y[mi] = py;
+    pix_x[mi] = px;
     a_base[mi] = ((py * p.stride) * ITW + px * p.stride) * PS;
   }
 
-  // ---- weights: packed [chunk*KGP + kg][Cout_pad] x (8 halves); this lane's rows
-  const int KGP = KS * 2;
-  const f16x8* wbase = reinterpret_cast<const f16x8*>(p.w) + (size_t)half * p.Cout_pad + n0 + wn * (NI * 32) + l31;
-  const size_t wstep = (size_t)2 * p.Cout_pad;  // one K=16 step
-  (void)KGP;
+  // ---- weights: packed [chunk*KGP + kg][Cout_pad] x (8 halves); this lane's rows start at wlane, a tile's at its n0
+  const f16x8* wlane = reinterpret_cast<const f16x8*>(p.w) + (size_t)half * p.Cout_pad + wn * (NI * 32) + l31;
+  const int wstep = 2 * p.Cout_pad;  // one K=16 step
 
   f32x16 acc[NI][MI];
+  auto zero_acc = [&]() __attribute__((always_inline)) {
 #pragma unroll
-  for (int ni = 0; ni < NI; ++ni)
+    for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi)
+      for (int mi = 0; mi < MI; ++mi)
 #pragma unroll
-      for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.0f;
-
-  // ---- staging state
-  uint4 raw[kMaxItems];
-  float st_rs[kMaxItems], st_mu[kMaxItems];
-  unsigned inb_mask = 0;
-
-  const f16* x1 = reinterpret_cast<const f16*>(p.x1);
-  const f16* x2 = reinterpret_cast<const f16*>(p.x2);
-
-  // per-chunk prologue affine of THIS thread's 8-channel group: every item of a thread has the same group (256 % G == 0) and
-  // the tile lies in one batch row, so the 8 + 8 floats are loaded once per chunk, together with the activations
-  float st_a[8], st_s[8];
-  const int my_cg = tid & (G - 1);
-
-  auto stage_load = [&](int chunk) __attribute__((always_inline)) {
-    inb_mask = 0;
-    const int cc = chunk * KC + my_cg * 8;
-    if (p.pa) {
-      const float4* q = reinterpret_cast<const float4*>(p.pa + (size_t)b * p.pstride + cc);
-      const float4 q0 = q[0], q1 = q[1];
-      st_a[0] = q0.x; st_a[1] = q0.y; st_a[2] = q0.z; st_a[3] = q0.w; st_a[4] = q1.x; st_a[5] = q1.y; st_a[6] = q1.z; st_a[7] = q1.w;
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) st_a[j] = 1.0f;
-    }
-    if (p.ps) {
-      const float4* q = reinterpret_cast<const float4*>(p.ps + (size_t)b * p.pstride + cc);
-      const float4 q0 = q[0], q1 = q[1];
-      st_s[0] = q0.x; st_s[1] = q0.y; st_s[2] = q0.z; st_s[3] = q0.w; st_s[4] = q1.x; st_s[5] = q1.y; st_s[6] = q1.z; st_s[7] = q1.w;
-    } else {
-#pragma unroll
-      for (int j = 0; j < 8; ++j) st_s[j] = 0.0f;
-    }
-#pragma unroll
-    for (int it = 0; it < kMaxItems; ++it) {
-      const int idx = tid + it * 256;
-      raw[it] = make_uint4(0, 0, 0, 0);
-      st_rs[it] = 1.0f;
-      st_mu[it] = 0.0f;
-      if (idx < items) {
-        const int pix = idx >> LOG2G;
-        const int iy = (int)(((float)pix + 0.5f) * inv_itw);
-        const int ix = pix - iy * ITW;
-        const int gy = iy0 + iy, gx = ix0 + ix;
-        if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-          const int gp = gy * p.W + gx;
-          const f16* src = nullptr;
-          if (cc < p.C1) src = x1 + (size_t)b * p.bs1 + (size_t)gp * p.ld1 + cc;
-          else if (cc - p.C1 < p.C2) src = x2 + (size_t)b * p.bs2 + (size_t)gp * p.ld2 + (cc - p.C1);
-          if (src) {
-            if (!(p.dbg & 16)) raw[it] = *reinterpret_cast<const uint4*>(src);   // dbg 16: ablate the activation loads
-            inb_mask |= 1u << it;
-            const int sp = b * (p.H * p.W) + gp;
-            if (p.rs) st_rs[it] = p.rs[sp];
-            else if (p.ssq_a) {  // ChanRMSNorm statistics straight from the producers' per-pixel sums of squares
-              float q = p.ssq_a[sp];
-              if (p.ssq_b) q += p.ssq_wb * p.ssq_b[sp];
-              st_rs[it] = 1.0f / fmaxf(sqrtf(q), 1e-12f);
-            }
-            if (p.mu) st_mu[it] = p.mu[sp];
-          }
-        }
-      }
-    }
+        for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.0f;
   };
+  zero_acc();
 
-  // transform + LDS write of ONE staged item (it is a compile-time index at every call site)
-  auto stage_write_item = [&](int it, char* buf) __attribute__((always_inline)) {
-    const int idx = tid + it * 256;
-    if (idx < items) {
-      const int pix = idx >> LOG2G;
-      f16x8 out;
-      if (inb_mask & (1u << it)) {
-        const f16x8 in = *reinterpret_cast<const f16x8*>(&raw[it]);
-        const float rs = st_rs[it], mu = st_mu[it];
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float v = ((float)in[j] - mu) * rs * st_a[j] + st_s[j];
-          if (p.act_in == IMAGEN_ACT_SILU) v = silu_f(v);
-          out[j] = (f16)v;
-        }
-      } else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) out[j] = (f16)0.0f;
-      }
-      *reinterpret_cast<f16x8*>(buf + pix * PS + my_cg * 16) = out;
-    }
-  };
-
-  auto stage_write = [&](char* buf) __attribute__((always_inline)) {
-    static_for<kMaxItems>([&](auto ic) __attribute__((always_inline)) { stage_write_item(decltype(ic)::value, buf); });
-  };
-
-  // ---- weight fragment pipeline (continuous over chunks)
-  // wq[j] holds the fragments of K=16 step (gstep + j); wptr always points at step (gstep + kLookAhead)
+  // ---- weight fragment pipeline, continuous over chunks AND tiles
+  // wq[j] holds the fragments of K=16 step (gstep + j); w_ofs is the offset (in fragments) of step (gstep + kLookAhead)
   constexpr int kLookAhead = KSC == 0 ? 1 : (KSC >= 6 ? 6 : KSC);
-  f16x8 wq[kLookAhead][NI];
-  const f16x8* wptr = wbase;
-#pragma unroll
-  for (int j = 0; j < kLookAhead; ++j) {
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) wq[j][ni] = wptr[ni * 32];
-    wptr += wstep;
-  }
   static_assert(kLookAhead <= 8, "packed weights carry a zero tail of 8 steps");
+  f16x8 wq[kLookAhead][NI];
+  int w_ofs = 0;
 
-  // wbuf != nullptr: the LDS writes of the NEXT chunk's staged items are interleaved with the last kMaxItems MFMA steps, so the
-  // prologue VALU work runs under the matrix pipe instead of serialising behind it (only when the k-loop is unrolled)
-  auto compute = [&](const char* buf, char* wbuf) __attribute__((always_inline)) {
+  // wrap_n0 >= 0: this is the last chunk of the tile — kLookAhead steps before its end the weight prefetch jumps to the first
+  // steps of the next tile (output-channel offset wrap_n0)
+  auto compute = [&](const char* buf, int wrap_n0) __attribute__((always_inline)) {
     // (dy, dx, group) walk of this lane's 8-channel group: kg = 2*ks + half
     int dy = 0, dx = 0, cgp = 0;  // G >= 2: uniform walk, group = 2*cgp + half
     int tap_l = half;             // G == 1: per-lane tap walk (tap = 2*ks + half), kept as (ty_l, tx_l) incrementally
@@ -266,12 +355,12 @@ __global__ __launch_bounds__(256, (MI * NI <= 2 ? 2 : 1)) void igemm_kernel(cons
       for (int mi = 0; mi < MI; ++mi) afrag[mi] = *reinterpret_cast<const f16x8*>(buf + a_base[mi] + a0);
     }
     auto do_step = [&](int ks) __attribute__((always_inline)) {
-      // prefetch the weight fragments kLookAhead steps ahead (L2 latency ~ 2-3 MFMA groups)
-      // (unconditional: the packed buffer carries a zero tail of kTailSteps steps, so reads past the last step stay in bounds)
+      // prefetch the weight fragments kLookAhead steps ahead (L2 latency ~ 2-3 MFMA groups); uniform wrap at the tile end
+      if (ks == KS - kLookAhead && wrap_n0 >= 0) w_ofs = wrap_n0;
       f16x8 wnew[NI];
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) wnew[ni] = wptr[ni * 32];
-      wptr += wstep;
+      for (int ni = 0; ni < NI; ++ni) wnew[ni] = wlane[w_ofs + ni * 32];
+      w_ofs += wstep;
       if (ks + 1 < KS) {
         const int a1 = next_aoff();
 #pragma unroll
@@ -292,243 +381,165 @@ __global__ __launch_bounds__(256, (MI * NI <= 2 ? 2 : 1)) void igemm_kernel(cons
       for (int ni = 0; ni < NI; ++ni) wq[kLookAhead - 1][ni] = wnew[ni];
     };
     if constexpr (KSC > 0) {
-      static_for<KSC>([&](auto ic) __attribute__((always_inline)) {
-        constexpr int ks = decltype(ic)::value;
-        do_step(ks);
-        if constexpr (KSC >= kMaxItems && ks >= KSC - kMaxItems) {
-          if (wbuf != nullptr) stage_write_item(ks - (KSC - kMaxItems), wbuf);
-        }
-      });
+      static_for<KSC>([&](auto ic) __attribute__((always_inline)) { do_step(decltype(ic)::value); });
     } else {
       for (int ks = 0; ks < KS; ++ks) do_step(ks);
     }
   };
 
-  // ---- main loop over channel chunks (double-buffered LDS)
-  stage_load(0);
-  stage_write(smem);
-  __syncthreads();
-  int cur = 0;
-  for (int chunk = 0; chunk < NC; ++chunk) {
-    const bool more = chunk + 1 < NC;
-    const bool restage = more && !(p.dbg & 1);
-    char* nbuf = smem + (cur ^ 1) * buf_bytes;
-    constexpr bool kInterleave = KSC >= kMaxItems;
-    if (restage) stage_load(chunk + 1);
-    if (!(p.dbg & 2)) compute(smem + cur * buf_bytes, (kInterleave && restage) ? nbuf : nullptr);
-    if (restage && (!kInterleave || (p.dbg & 2))) stage_write(nbuf);
-    __syncthreads();
-    cur ^= 1;
-  }
-
-  // ---- epilogue: lane = pixel; register quad q holds couts 8q + 4*half + {0..3} of each 32-cout fragment
+  // ---- epilogue of one finished tile: lane = pixel; register quad q holds couts 8q + 4*half + {0..3} of each 32-cout fragment
   const f16* addend = reinterpret_cast<const f16*>(p.addend);
   const f16* res = reinterpret_cast<const f16*>(p.res);
-  float ssq_px[MI];  // per-pixel sum of squares of this wave's stored channels (for the consumer's ChanRMSNorm)
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    ssq_px[mi] = 0.0f;
-    const int oy = opix_y[mi], ox = opix_x[mi];
-    if (oy >= p.OH || ox >= p.OW) continue;
-    const int op = oy * p.OW + ox;
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
-        if (co >= p.Cout) continue;
-        float v[4];
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float x = acc[ni][mi][4 * q + e];
-          if (p.bias) x += p.bias[co + e];  // bias is padded to Cout_pad by the host
-          if (p.act_out == IMAGEN_ACT_SILU) x = silu_f(x);
-          else if (p.act_out == IMAGEN_ACT_GELU) x = gelu_f(x);
-          v[e] = x;
-        }
-        if (p.out_mode == IMAGEN_OUT_NCHW_F32) {
-          float* y = reinterpret_cast<float*>(p.y);
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (co + e < p.Cout) y[((size_t)b * p.Cout + co + e) * (p.OH * p.OW) + op] = v[e];
-          continue;
-        }
-        if (addend) {
-          const f16x4 ad = *reinterpret_cast<const f16x4*>(addend + (size_t)b * p.bs_add + (size_t)op * p.ld_add + co);
-          const float4 g = *reinterpret_cast<const float4*>(p.gate + (size_t)b * p.gate_stride + co);
-          v[0] += (float)ad[0] * g.x; v[1] += (float)ad[1] * g.y; v[2] += (float)ad[2] * g.z; v[3] += (float)ad[3] * g.w;
-        }
-        if (res) {
-          const f16x4 rr = *reinterpret_cast<const f16x4*>(res + (size_t)b * p.bs_res + (size_t)op * p.ld_res + co);
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
-        }
-        f16x4 o;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          o[e] = (f16)v[e];
-          const float r = (float)o[e];  // statistics of the value the consumer will read back
-          ssq_px[mi] += r * r;
-        }
-        f16* y = reinterpret_cast<f16*>(p.y);
-        if (p.out_mode == IMAGEN_OUT_PIXEL_SHUFFLE) {
-          // output channels are packed (s1, s2, c): cout = (2*s1 + s2) * Cq + c   (PixelShuffle(2), ip.py:616)
-          const int Cq = p.Cout >> 2;
-          const int sub = co / Cq, c = co - sub * Cq;
-          const int yy = 2 * oy + (sub >> 1), xx = 2 * ox + (sub & 1);
-          *reinterpret_cast<f16x4*>(y + (size_t)b * p.bsy + ((size_t)yy * (2 * p.OW) + xx) * p.ldy + c) = o;
-        } else {
-          if (!(p.dbg & 8)) *reinterpret_cast<f16x4*>(y + (size_t)b * p.bsy + (size_t)op * p.ldy + co) = o;   // dbg 8: ablate the stores
-        }
-      }
-    }
-  }
-  // ---- optional: emit the per-pixel sum of squares (launcher guarantees one workgroup covers all Cout: gridDim.y == 1)
-  if (p.ssq_out) {
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) ssq_px[mi] += __shfl_xor(ssq_px[mi], 32);  // both lane halves hold disjoint channel quads
-    if (WN == 1) {
-      if (half == 0) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-          if (opix_y[mi] < p.OH && opix_x[mi] < p.OW) p.ssq_out[(size_t)b * (p.OH * p.OW) + opix_y[mi] * p.OW + opix_x[mi]] = ssq_px[mi];
-      }
-    } else {
-      float* red = reinterpret_cast<float*>(smem);  // [WN][pixels of this wave row]; LDS is free after the main loop's last barrier
-      constexpr int PXW = 32 * MI;                  // pixels per wave
-      if (half == 0) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) red[(wm * WN + wn) * PXW + mi * 32 + l31] = ssq_px[mi];
-      }
-      __syncthreads();
-      if (wn == 0 && half == 0) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          float tot = 0.0f;
-#pragma unroll
-          for (int w = 0; w < WN; ++w) tot += red[(wm * WN + w) * PXW + mi * 32 + l31];
-          if (opix_y[mi] < p.OH && opix_x[mi] < p.OW) p.ssq_out[(size_t)b * (p.OH * p.OW) + opix_y[mi] * p.OW + opix_x[mi]] = tot;
-        }
-      }
-    }
-  }
-
-  // ---- optional: fused GlobalContext partials + last-workgroup finalisation (see ImagenIgemmParams.gca_*)
-  if (p.gca_wk) {
-    constexpr int PXW = 32 * MI;
-    float* lds = reinterpret_cast<float*>(smem) + 1024;   // past the ssq scratch; LDS is free after the main loop's last barrier
-    float* red = lds;                                     // [4 waves][PXW]
-    float* s_w = lds + 4 * PXW;                           // [8] per-wave scalars
-    float* chan = s_w + 8;                                // [BN] channel sums
-    int* s_flag = reinterpret_cast<int*>(chan + BN);
-    const int tiles_img = tilesX * tilesY;
-    const int tile_in_img = tile_y * tilesX + tile_x;
-    bool valid[MI];
-    float lg[MI];
-    // 1. logit per pixel: sum over this wave's channels, both lane halves, then all WN waves
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      valid[mi] = opix_y[mi] < p.OH && opix_x[mi] < p.OW;
-      float d = 0.0f;
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
-          if (co < p.Cout) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) d += (acc[ni][mi][4 * q + e] + (p.bias ? p.bias[co + e] : 0.0f)) * p.gca_wk[co + e];
-          }
-        }
-      d += __shfl_xor(d, 32);
-      lg[mi] = d;
-    }
-    if (WN > 1) {
-      if (half == 0) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) red[(wm * WN + wn) * PXW + mi * 32 + l31] = lg[mi];
-      }
-      __syncthreads();
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        float tot = 0.0f;
-#pragma unroll
-        for (int w = 0; w < WN; ++w) tot += red[(wm * WN + w) * PXW + mi * 32 + l31];
-        lg[mi] = tot;
-      }
-    }
-    // 2. tile max
-    float mx = -3.0e38f;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      lg[mi] += p.gca_bk;
-      if (valid[mi]) mx = fmaxf(mx, lg[mi]);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off));
-    if (lane == 0) s_w[wave] = mx;
-    if (tid < BN) chan[tid] = 0.0f;
-    __syncthreads();
-    const float m_blk = fmaxf(fmaxf(s_w[0], s_w[1]), fmaxf(s_w[2], s_w[3]));
-    // 3. exp weights and their sum (every pixel counted once: wn == 0 waves, lower lane half)
-    float ew[MI];
-    float se = 0.0f;
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      ew[mi] = valid[mi] ? __expf(lg[mi] - m_blk) : 0.0f;
-      se += ew[mi];
-    }
-    if (wn != 0 || half != 0) se = 0.0f;
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) se += __shfl_xor(se, off);
-    __syncthreads();   // everyone has read s_w (max) before it is reused for the sums
-    if (lane == 0) s_w[wave] = se;
-    // 4. exp-weighted channel sums: in-lane over MI pixels, across the 32 pixel lanes by shuffles, across WM waves by LDS atomics
+  auto epilogue = [&](const TileCoord& tc) __attribute__((always_inline)) {
+    const int b = tc.b, n0 = tc.n0;
+    float ssq_px[MI];  // per-pixel sum of squares of this wave's stored channels (for the consumer's ChanRMSNorm)
+    // per-lane channel constants of the tile: bias and gate quads, loaded once (not per pixel) and all at once
+    float4 bq[NI][4], gq[NI][4];
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
+        bq[ni][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        gq[ni][q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) bq[ni][q] = *reinterpret_cast<const float4*>(p.bias + co);   // bias is padded to Cout_pad by the host
+        if (addend && co < p.Cout) gq[ni][q] = *reinterpret_cast<const float4*>(p.gate + (size_t)b * p.gate_stride + co);
+      }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float t = 0.0f;
-          if (co < p.Cout) {
-            const float bb = p.bias ? p.bias[co + e] : 0.0f;
+    for (int mi = 0; mi < MI; ++mi) {
+      ssq_px[mi] = 0.0f;
+      const int oy = tc.oy0 + pix_y[mi], ox = tc.ox0 + pix_x[mi];
+      if (oy >= p.OH || ox >= p.OW) continue;
+      const int op = oy * p.OW + ox;
+      // all addend / residual quads of this pixel in flight before the first one is used
+      f16x4 adq[NI][4], rrq[NI][4];
 #pragma unroll
-            for (int mi = 0; mi < MI; ++mi) t += ew[mi] * (acc[ni][mi][4 * q + e] + bb);
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
+          if (addend && co < p.Cout) adq[ni][q] = *reinterpret_cast<const f16x4*>(addend + (size_t)b * p.bs_add + (size_t)op * p.ld_add + co);
+          if (res && co < p.Cout) rrq[ni][q] = *reinterpret_cast<const f16x4*>(res + (size_t)b * p.bs_res + (size_t)op * p.ld_res + co);
+        }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
+          if (co >= p.Cout) continue;
+          float v[4];
+          const float bb[4] = {bq[ni][q].x, bq[ni][q].y, bq[ni][q].z, bq[ni][q].w};
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float x = acc[ni][mi][4 * q + e] + bb[e];
+            if (p.act_out == IMAGEN_ACT_SILU) x = silu_f(x);
+            else if (p.act_out == IMAGEN_ACT_GELU) x = gelu_f(x);
+            v[e] = x;
           }
+          if (p.out_mode == IMAGEN_OUT_NCHW_F32) {
+            float* y = reinterpret_cast<float*>(p.y);
 #pragma unroll
-          for (int off = 16; off > 0; off >>= 1) t += __shfl_xor(t, off);
-          if (l31 == 0 && co < p.Cout) atomicAdd(&chan[co - n0 + e], t);
+            for (int e = 0; e < 4; ++e)
+              if (co + e < p.Cout) y[((size_t)b * p.Cout + co + e) * (p.OH * p.OW) + op] = v[e];
+            continue;
+          }
+          if (addend) {
+            const f16x4 ad = adq[ni][q];
+            const float4 g = gq[ni][q];
+            v[0] += (float)ad[0] * g.x; v[1] += (float)ad[1] * g.y; v[2] += (float)ad[2] * g.z; v[3] += (float)ad[3] * g.w;
+          }
+          if (res) {
+            const f16x4 rr = rrq[ni][q];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
+          }
+          f16x4 o;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            o[e] = (f16)v[e];
+            const float r = (float)o[e];  // statistics of the value the consumer will read back
+            ssq_px[mi] += r * r;
+          }
+          f16* y = reinterpret_cast<f16*>(p.y);
+          if (p.out_mode == IMAGEN_OUT_PIXEL_SHUFFLE) {
+            // output channels are packed (s1, s2, c): cout = (2*s1 + s2) * Cq + c   (PixelShuffle(2), ip.py:616)
+            const int Cq = p.Cout >> 2;
+            const int sub = co / Cq, c = co - sub * Cq;
+            const int yy = 2 * oy + (sub >> 1), xx = 2 * ox + (sub & 1);
+            *reinterpret_cast<f16x4*>(y + (size_t)b * p.bsy + ((size_t)yy * (2 * p.OW) + xx) * p.ldy + c) = o;
+          } else {
+            if (!(p.dbg & 8)) *reinterpret_cast<f16x4*>(y + (size_t)b * p.bsy + (size_t)op * p.ldy + co) = o;   // dbg 8: ablate the stores
+          }
         }
       }
-    __syncthreads();
-    float* part = p.gca_part + ((size_t)b * tiles_img + tile_in_img) * (p.Cout + 2);
-    if (tid < p.Cout) part[2 + tid] = chan[tid];
-    if (tid == 0) {
-      part[0] = m_blk;
-      part[1] = s_w[0] + s_w[1] + s_w[2] + s_w[3];
     }
-    // 5. ticket: the last workgroup of this image merges all tiles (placement-independent release / acquire, agent scope)
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      const int old = __hip_atomic_fetch_add(p.gca_counter + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = (old == tiles_img - 1) ? 1 : 0;
-      if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      *s_flag = last;
+    // optional: emit the per-pixel sum of squares (launcher guarantees one workgroup covers all Cout: tilesN == 1)
+    if (p.ssq_out) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) ssq_px[mi] += __shfl_xor(ssq_px[mi], 32);  // both lane halves hold disjoint channel quads
+      if (WN == 1) {
+        if (half == 0) {
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            const int oy = tc.oy0 + pix_y[mi], ox = tc.ox0 + pix_x[mi];
+            if (oy < p.OH && ox < p.OW) p.ssq_out[(size_t)b * (p.OH * p.OW) + oy * p.OW + ox] = ssq_px[mi];
+          }
+        }
+      } else {
+        if (half == 0) {
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) ep_red[(wm * WN + wn) * PXW + mi * 32 + l31] = ssq_px[mi];
+        }
+        lds_barrier();   // whole workgroup (the producers execute the matching barrier); ep_red is next written a phase barrier later
+        if (wn == 0 && half == 0) {
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            float tot = 0.0f;
+#pragma unroll
+            for (int w = 0; w < WN; ++w) tot += ep_red[(wm * WN + w) * PXW + mi * 32 + l31];
+            const int oy = tc.oy0 + pix_y[mi], ox = tc.ox0 + pix_x[mi];
+            if (oy < p.OH && ox < p.OW) p.ssq_out[(size_t)b * (p.OH * p.OW) + oy * p.OW + ox] = tot;
+          }
+        }
+      }
     }
-    __syncthreads();
-    const int i_am_last = *s_flag;
-    __syncthreads();   // the finalisation below reuses this LDS region
-    if (i_am_last) {
-      gca_finalize(p.gca_part + (size_t)b * tiles_img * (p.Cout + 2), tiles_img, p.Cout, p.gca_hidden, p.gca_w1t, p.gca_b1, p.gca_w2t,
-                   p.gca_b2, p.gca_gate + (size_t)b * p.Cout, lds);
-      if (tid == 0) __hip_atomic_store(p.gca_counter + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+  };
+
+  // ---- main loop: tiles x chunks, one hand-over barrier per phase
+  TileCoord tc = decode(t_cursor);
+  w_ofs = tc.n0;
+#pragma unroll
+  for (int j = 0; j < kLookAhead; ++j) {
+#pragma unroll
+    for (int ni = 0; ni < NI; ++ni) wq[j][ni] = wlane[w_ofs + ni * 32];
+    w_ofs += wstep;
   }
+  lds_barrier();   // phase 0 staged
+  int cur = 0;
+  while (true) {
+    const int t_next = t_cursor + t_step;
+    const int n0_next = t_next < t_end ? decode(t_next).n0 : tc.n0;
+    for (int chunk = 0; chunk < NC; ++chunk) {
+      if (!(p.dbg & 2)) compute(smem + cur * buf_bytes, chunk == NC - 1 ? n0_next : -1);
+      lds_barrier();   // done with buf[cur]; the producers have filled buf[cur^1]
+      cur ^= 1;
+    }
+    epilogue(tc);
+    if (t_next >= t_end) break;
+    zero_acc();
+    t_cursor = t_next;
+    tc = decode(t_cursor);
+  }
+}
+
+inline int num_cus() {
+  static int n = 0;
+  if (n == 0) {
+    int dev = 0, v = 0;
+    if (hipGetDevice(&dev) == hipSuccess && hipDeviceGetAttribute(&v, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess && v > 0) n = v;
+    else n = 256;
+  }
+  return n;
 }
 
 template <int MI, int NI, int WM, int WN, int G, int KSC>
@@ -544,18 +555,9 @@ int launch_ksc(const ImagenIgemmParams& p, hipStream_t s) {
                "igemm: channel counts / strides must be multiples of 8 (C1=%d C2=%d ld1=%d ld2=%d)", p.C1, p.C2, p.ld1, p.ld2);
   IMAGEN_CHECK(p.out_mode == IMAGEN_OUT_NCHW_F32 || p.Cout % 4 == 0, "igemm: Cout %d must be a multiple of 4", p.Cout);
   IMAGEN_CHECK(p.out_mode != IMAGEN_OUT_PIXEL_SHUFFLE || p.Cout % 16 == 0, "igemm: pixel-shuffle needs Cout %% 16 == 0");
-  if (p.gca_wk) {
-    IMAGEN_CHECK(p.out_mode == IMAGEN_OUT_NHWC && p.Cout <= BN && p.act_out == IMAGEN_ACT_NONE && !p.addend && !p.res,
-                 "igemm: fused GlobalContext needs a plain NHWC conv output and one workgroup covering all %d channels", p.Cout);
-    IMAGEN_CHECK(p.gca_part && p.gca_counter && p.gca_w1t && p.gca_b1 && p.gca_w2t && p.gca_b2 && p.gca_gate && p.gca_hidden > 0,
-                 "igemm: incomplete gca_* parameters");
-    const int tiles_img = ((p.OW + p.TW - 1) / p.TW) * ((p.OH + p.TH - 1) / p.TH);
-    const size_t need = (size_t)(1024 + p.Cout + p.gca_hidden + tiles_img + kGcaScratchFloats + 4 * 32 * MI + 8 + BN + 4) * sizeof(float);
-    IMAGEN_CHECK(need <= (size_t)2 * IT * Geo<G>::PS, "igemm: fused GlobalContext scratch (%zu B) exceeds the tile LDS", need);
-  }
   IMAGEN_CHECK(!p.ssq_out || (p.out_mode == IMAGEN_OUT_NHWC && p.Cout <= BN),
                "igemm: ssq_out needs NHWC output and one workgroup covering all %d output channels (tile has %d)", p.Cout, BN);
-  const size_t lds = (size_t)2 * IT * Geo<G>::PS;
+  const size_t lds = (size_t)2 * IT * Geo<G>::PS + (size_t)4 * 32 * MI * sizeof(float);   // staging double buffer + epilogue scratch
   IMAGEN_CHECK(lds <= 160 * 1024, "igemm: LDS tile %zu bytes too large", lds);
   auto kern = igemm_kernel<MI, NI, WM, WN, G, KSC>;
   static bool attr_done = false;
@@ -564,9 +566,28 @@ int launch_ksc(const ImagenIgemmParams& p, hipStream_t s) {
     if (e != hipSuccess) { imagen_set_error("igemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_done = true;
   }
+  // persistent grid: what the chip holds at once (register- and LDS-limited workgroups per CU), evened out over the rounds
   const int tilesX = (p.OW + p.TW - 1) / p.TW, tilesY = (p.OH + p.TH - 1) / p.TH;
-  dim3 grid(p.B * tilesX * tilesY, (p.Cout + BN - 1) / BN);
-  hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+  const int total = p.B * tilesX * tilesY * ((p.Cout + BN - 1) / BN);
+  static size_t occ_lds = 0;
+  static int occ_blocks = 0;
+  if (occ_blocks == 0 || occ_lds != lds) {   // resident workgroups per CU of THIS instantiation at this LDS size
+    int nb = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&nb, reinterpret_cast<const void*>(kern), 512, lds) != hipSuccess || nb < 1) nb = 1;
+    occ_blocks = nb;
+    occ_lds = lds;
+  }
+  const int per_cu = occ_blocks;
+  const int resident = num_cus() * per_cu;
+  int gx;
+  if ((p.dbg & 32) || total <= resident) {
+    gx = total;                                    // dbg 32: one tile per workgroup (no cross-tile pipelining)
+  } else {
+    const int rounds = (total + resident - 1) / resident;
+    gx = (total + rounds - 1) / rounds;
+    gx = std::min(resident, (gx + 7) / 8 * 8);     // multiple of 8: one contiguous tile range per XCD
+  }
+  hipLaunchKernelGGL(kern, dim3(gx), dim3(512), lds, s, p);
   return imagen_hip_status("igemm launch");
 }
 

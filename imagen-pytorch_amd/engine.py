@@ -363,8 +363,8 @@ class UnetEngine:
                             w2t=W.f32(name + ".gca.w2t", lambda: g.net[2].weight.reshape(Cout, hidden).t()),
                             b2=W.f32(name + ".gca.b2", lambda: g.net[2].bias), gate=gate)
         op2 = ops.igemm(plan, h1, W.conv(name + ".block2", rb.block2.project), h2, ssq_a=s1, pa=pa2, ps=ps2, pstride=self.total_c,
-                        act_in=ACT_SILU, gca=gca_args, label=name + ".block2")
-        if rb.gca is not None and not op2.gca_fused:   # tile narrower than Cout: stand-alone GlobalContext kernels
+                        act_in=ACT_SILU, label=name + ".block2")
+        if rb.gca is not None:   # one launch: chunk partials + last-workgroup finalisation (measured faster than a conv-epilogue fusion)
             chunks = ops.gca_chunks(H * Wd, R)
             part = self.f32buf(R, chunks, Cout + 2)
             ops.gca(plan, h2, gca_args["wk"], gca_args["bk"], gca_args["w1t"], gca_args["b1"], gca_args["w2t"], gca_args["b2"], part, gate,

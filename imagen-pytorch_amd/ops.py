@@ -234,8 +234,6 @@ import os as _os
 DEEP_3X3 = int(_os.environ.get("IMAGEN_DEEP_3X3", "0"))             # A/B switch: 64-channel k-chunks for 3x3 convs with C_in >= 128
 DEEP_CHUNKS = int(_os.environ.get("IMAGEN_DEEP_CHUNKS", "1"))       # A/B switch: 64/128-channel k-chunks for 1x1 convs / linears
 GCA_SINGLE_LAUNCH = int(_os.environ.get("IMAGEN_GCA_SINGLE_LAUNCH", "1"))   # A/B switch: finalise GlobalContext in the partial kernel
-FUSE_GCA_MAX_TILES = int(_os.environ.get("IMAGEN_FUSE_GCA_MAX_TILES", "16"))
-FUSE_GCA = int(_os.environ.get("IMAGEN_FUSE_GCA", "1"))             # A/B switch: GlobalContext partials + finalisation in the conv epilogue
 IGEMM_DBG = int(_os.environ.get("IMAGEN_IGEMM_DBG", "0"))          # kernel A/B switches (see ImagenIgemmParams.dbg); 0 in production
 FILL_BLOCKS = int(_os.environ.get("IMAGEN_FILL_BLOCKS", "512"))   # workgroups wanted before growing the tile (2 per CU on 256 CUs)
 MAX_STAGE_ITEMS = 6 * 256      # kMaxItems * threads in igemm.hip
@@ -278,8 +276,7 @@ def pick_cfg(G: int, Cout: int, OH: int, OW: int, B: int, KH: int = 1, KW: int =
 def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None, mu=None, rs=None, pa=None, ps=None,
           pstride: int = 0, act_in: int = ACT_NONE, act_out: int = ACT_NONE, addend: Optional[Act] = None, gate=None,
           res: Optional[Act] = None, out_mode: int = OUT_NHWC, stride: int = 1, pad: Optional[int] = None,
-          cfg: Optional[tuple] = None, ssq_a=None, ssq_b=None, ssq_wb: float = 1.0, ssq_out=None, gca: Optional[dict] = None,
-          label: str = ""):
+          cfg: Optional[tuple] = None, ssq_a=None, ssq_b=None, ssq_wb: float = 1.0, ssq_out=None, label: str = ""):
     """... ssq_a / ssq_b: producers' per-pixel sums of squares of x1 / x2 (ChanRMSNorm statistics without a separate pass);
     ssq_out: emit the per-pixel sum of squares of the output — honoured only when the chosen tile covers all Cout
     (`p.ssq_emitted` tells the caller, who otherwise falls back to a ROWSTAT op)."""
@@ -340,30 +337,8 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
         p.ssq_out = ssq_out.data_ptr()
         keep.append(ssq_out)
         emitted = True
-    fused = False
-    if gca is not None and FUSE_GCA and out_mode == OUT_NHWC and pw.Cout <= cfg_table()[cid][1] and act_out == ACT_NONE \
-            and addend is None and res is None:
-        tiles = math.ceil(OH / th) * math.ceil(OW / tw)
-        tp_, bn_, g_ = cfg_table()[cid]
-        ps_ = 16 if g_ == 1 else g_ * 16 + 16
-        it_ = ((th - 1) * stride + KH) * ((tw - 1) * stride + KW)
-        hidden = gca["w1t"].shape[1]
-        need = (1024 + pw.Cout + hidden + tiles + GCA_SCRATCH + 4 * tp_ + 8 + bn_ + 4) * 4
-        # measured (MI355X, README cascade): the fused epilogue wins on small maps (fewer launches, u1) and loses on the big
-        # ones, where every one of thousands of workgroups pays the extra reductions and one workgroup merges them all
-        if need <= 2 * it_ * ps_ and tiles <= FUSE_GCA_MAX_TILES:
-            dev = x1.t.device
-            part = torch.empty(x1.B, tiles, pw.Cout + 2, dtype=torch.float32, device=dev)
-            counter = torch.zeros(x1.B, dtype=torch.int32, device=dev)   # self-resetting ticket (the last workgroup stores 0)
-            p.gca_wk, p.gca_part, p.gca_counter = gca["wk"].data_ptr(), part.data_ptr(), counter.data_ptr()
-            p.gca_w1t, p.gca_b1, p.gca_w2t, p.gca_b2 = (gca["w1t"].data_ptr(), gca["b1"].data_ptr(), gca["w2t"].data_ptr(),
-                                                       gca["b2"].data_ptr())
-            p.gca_gate, p.gca_hidden, p.gca_bk = gca["gate"].data_ptr(), hidden, float(gca["bk"])
-            keep += [part, counter, gca["wk"], gca["w1t"], gca["b1"], gca["w2t"], gca["b2"], gca["gate"]]
-            fused = True
     plan.add(p, label or "igemm", keep)
     p.ssq_emitted = emitted
-    p.gca_fused = fused
     return p
 
 

@@ -93,12 +93,6 @@ typedef struct ImagenIgemmParams {
   const float* ssq_a;  /* optional per-input-pixel sum of squares of x1 (emitted by its producer): when set (and rs == NULL) */
   const float* ssq_b;  /*   rs = 1/max(sqrt(ssq_a + ssq_wb*ssq_b), 1e-12) — ChanRMSNorm statistics without a separate pass   */
   float* ssq_out;      /* optional per-output-pixel sum of squares of the stored fp16 output (NHWC mode, Cout <= tile couts) */
-  /* optional fused GlobalContext (ip.py:945-970) of the output h = acc + bias (NHWC mode, Cout <= tile couts): every workgroup
-   * emits its tile's (max logit, sum exp, sum exp*h[c]) into gca_part[b][tile][Cout+2]; the LAST workgroup of an image to finish
-   * (agent-scope release/acquire ticket on gca_counter[b], which it resets to 0) merges the tiles and runs the squeeze MLP
-   * -> gca_gate[b][Cout].  Replaces GCA_PARTIAL + GCA_FINAL and their second pass over h. */
-  const float* gca_wk; float* gca_part; int32_t* gca_counter;
-  const float* gca_w1t; const float* gca_b1; const float* gca_w2t; const float* gca_b2; float* gca_gate;
   int32_t B, H, W;     /* input batch / spatial dims */
   int32_t C1, ld1, bs1; /* channels, pixel stride, batch stride (elements) of x1 */
   int32_t C2, ld2, bs2;
@@ -114,10 +108,9 @@ typedef struct ImagenIgemmParams {
   int32_t out_mode;
   int32_t TH, TW;      /* output tile (TH*TW must equal the tile's pixel count) */
   int32_t cfg;         /* tile configuration id, see imagen_igemm_config_info */
-  int32_t dbg;         /* ablation switches for tools/igemm_probe.py (0 in production): 1 = skip restaging after chunk 0, 2 = skip MFMAs */
-  int32_t gca_hidden;  /* hidden width of the GlobalContext squeeze MLP */
+  int32_t dbg;         /* ablation switches for tools/igemm_probe.py (0 in production): 1 = skip restaging after chunk 0, 2 = skip MFMAs,
+                        * 8 = skip stores, 16 = skip activation loads, 32 = one tile per workgroup (no persistence), 64 = no XCD tile ranges */
   float ssq_wb;        /* weight of ssq_b (skip_connect_scale^2 for the concatenated skip tensor) */
-  float gca_bk;        /* bias of GlobalContext.to_k */
 } ImagenIgemmParams;
 
 /* ROWSTAT — replaces the reductions inside ChanRMSNorm (ip.py:322-329) and LayerNorm (ip.py:331-349,

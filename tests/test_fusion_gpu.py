@@ -93,9 +93,9 @@ def test_tail_kernels_emit_raw_ssq():
 
 
 @pytest.mark.parametrize("B,S,C", [(2, 64, 32), (2, 32, 64), (3, 16, 128), (1, 24, 64)])
-def test_fused_global_context(B, S, C):
-    """GlobalContext (ip.py:945-970) computed in the conv epilogue (tile partials + last-workgroup finalisation) vs fp32 torch;
-    run twice: the ticket counter must reset itself."""
+def test_single_launch_global_context(B, S, C):
+    """GlobalContext (ip.py:945-970) of a conv output in ONE launch (chunk partials + last-workgroup finalisation behind an
+    agent-scope ticket) vs fp32 torch; run twice: the ticket counter must reset itself."""
     from imagen_pytorch_amd import ops
 
     dev = torch.device("cuda:0")
@@ -107,20 +107,22 @@ def test_fused_global_context(B, S, C):
     wk, bk = torch.randn(1, C, 1, 1) / math.sqrt(C), torch.randn(1) * 0.1
     w1, b1 = torch.randn(hidden, C, 1, 1) / math.sqrt(C), torch.randn(hidden) * 0.1
     w2, b2 = torch.randn(C, hidden, 1, 1) / math.sqrt(hidden), torch.randn(C) * 0.1
-    h = F.conv2d(x, w.half().float(), bias, padding=1)
+    h = F.conv2d(x, w.half().float(), bias, padding=1).half().float()   # the gate is computed from the stored fp16 h
     ctx = F.conv2d(h, wk, bk).reshape(B, 1, S * S)
     pooled = torch.einsum("bin,bcn->bci", ctx.softmax(-1), h.reshape(B, C, S * S)).unsqueeze(-1)
     ref = torch.sigmoid(F.conv2d(F.silu(F.conv2d(pooled, w1, b1)), w2, b2)).reshape(B, C)
     gate = torch.zeros(B, C, device=dev)
-    args = dict(wk=wk.reshape(C).to(dev), bk=float(bk), w1t=w1.reshape(hidden, C).t().contiguous().to(dev), b1=b1.to(dev),
-                w2t=w2.reshape(C, hidden).t().contiguous().to(dev), b2=b2.to(dev), gate=gate)
     y = ops.new_act(B, S, S, C, dev)
     plan = ops.Plan()
-    op = ops.igemm(plan, ops.act_from_nchw(x.to(dev)), ops.pack_weight(w, bias, dev), y, gca=args)
-    assert op.gca_fused
+    ops.igemm(plan, ops.act_from_nchw(x.to(dev)), ops.pack_weight(w, bias, dev), y)
+    chunks = ops.gca_chunks(S * S, B)
+    part = torch.empty(B, chunks, C + 2, device=dev)
+    ops.gca(plan, y, wk.reshape(C).to(dev), float(bk), w1.reshape(hidden, C).t().contiguous().to(dev), b1.to(dev),
+            w2.reshape(C, hidden).t().contiguous().to(dev), b2.to(dev), part, gate, chunks)
+    assert len(plan) == 2 or (C // 8) & (C // 8 - 1)   # power-of-two C/8: the single-launch path
     for _ in range(2):
         gate.zero_()
         plan.run()
         torch.cuda.synchronize()
-        assert nerr(gate, ref) < 2e-4, nerr(gate, ref)
+        assert nerr(gate, ref) < 1e-3, nerr(gate, ref)
     assert nerr(ops.act_to_nchw(y), h) < 1e-3

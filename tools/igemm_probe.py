@@ -26,6 +26,9 @@ SHAPES = [  # (name, B, H, W, C1, C2, Cout, K)
     ("u1.L2 128->128 3x3 @16", 16, 16, 16, 128, 0, 128, 3),
     ("u1.L1 64->64 3x3 @32", 16, 32, 32, 64, 0, 64, 3),
     ("lin 256->1024 M=16384", 16, 1, 1024, 256, 0, 1024, 1),
+    ("res 192->128 1x1 @64", 16, 64, 64, 128, 64, 128, 1),
+    ("res 96->64 1x1 @128", 16, 128, 128, 64, 32, 64, 1),
+    ("res 64->32 1x1 @256", 16, 256, 256, 32, 32, 32, 1),
 ]
 
 def run(name, B, H, W, C1, C2, Cout, K, variant, cfg=None):

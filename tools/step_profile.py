@@ -82,7 +82,7 @@ def main():
                 if p.addend:
                     by += 2.0 * p.B * p.OH * p.OW * p.Cout
                 desc = (f"{cin}->{p.Cout} k{p.KH} s{p.stride} @{p.H}x{p.W} B{p.B} cfg{p.cfg}{tab[p.cfg]} t{p.TH}x{p.TW}"
-                        f"{' pro' if (p.pa or p.rs or p.ssq_a) else ''}{' gca' if p.gca_wk else ''}")
+                        f"{' pro' if (p.pa or p.rs or p.ssq_a) else ''}")
                 cls = re.sub(r"\d+", "#", label) + f" [{cin}->{p.Cout} k{p.KH} @{p.H}]"
             else:
                 cls = re.sub(r"\d+", "#", label)
