@@ -19,7 +19,17 @@
 namespace {
 
 struct TileCfg { int MI, NI, WM, WN, G; };
-constexpr int kMaxItems = 6;  // 16B staging items per thread per chunk
+// 16-byte staging items per producer thread and phase, by tile pixels / k-chunk depth / kernel footprint: the producers hold
+// TWO such register sets, so the count is kept as small as the instantiation's use allows (the host asks
+// imagen_igemm_stage_slots() and only picks tile shapes that fit)
+constexpr int stage_slots(int TP, int G, int KSC) {
+  if (KSC == 18 && G == 4) return TP == 64 ? 2 : TP == 128 ? 3 : 6;   // 3x3: 10x10 | 10x18 | 18x18 halo tiles
+  if (KSC == 2 && G == 4) return TP / 64;                             // 1x1
+  if (KSC == 8 && G == 4) return TP == 64 ? 4 : 6;                    // 2x2 stride-2 downsample: 4x the output pixels
+  if (KSC == 4 && G == 8) return TP / 32;                             // 1x1, 64-channel chunks
+  if (KSC == 8 && G == 16) return TP / 16;                            // 1x1, 128-channel chunks
+  return 4;                                                           // generic k-loop (8-channel chunks, 15x15 cross-embed conv, ...)
+}
 
 constexpr TileCfg kCfgs[] = {
     {2, 1, 4, 1, 4},  // 0: 256 px x  32 co, 32-ch chunks   (C_out = 32 layers, 256^2/128^2 levels)
@@ -77,6 +87,9 @@ template <int G> struct Geo {
 // (own L2) gets a contiguous range of tiles and neighbouring halos meet in the same L2.
 struct TileCoord { int b, oy0, ox0, n0; };
 
+__device__ __attribute__((aligned(16))) const float kOnes8[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+__device__ __attribute__((aligned(16))) const float kZeros8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+
 // LDS hand-over between the roles: LDS traffic of this wave retired, then the workgroup barrier.  Deliberately NOT
 // __syncthreads(): global loads stay in flight across it.
 __device__ __forceinline__ void lds_barrier() {
@@ -91,6 +104,7 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
   constexpr int PS = Geo<G>::PS;
   constexpr int LOG2G = (G == 1) ? 0 : (G == 2) ? 1 : (G == 4) ? 2 : (G == 8) ? 3 : 4;
   constexpr int PXW = 32 * MI;  // pixels per consumer wave
+  constexpr int kMaxItems = stage_slots(32 * MI * WM, G, KSC);
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
 
@@ -142,94 +156,117 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
 
   if (producer) {
     // =========================================================================================== producers (waves 4-7)
+    // Two register sets (A, B) alternate between phases, so the global loads of phase q+2 are already in flight while phase
+    // q+1 is transformed and written: the load latency overlaps the prologue math instead of preceding it.  Every load is
+    // unconditional (out-of-range items, absent statistics / affine arrays and phases past the end read a valid dummy
+    // address): the code is straight-line, so the compiler's vmcnt waits are exact — waiting for the older set leaves the
+    // younger set's loads in flight.
     const int items = IT << LOG2G;
     const float inv_itw = 1.0f / (float)ITW;
     const f16* x1 = reinterpret_cast<const f16*>(p.x1);
     const f16* x2 = reinterpret_cast<const f16*>(p.x2);
+    const float* dummy_f = reinterpret_cast<const float*>(p.w);   // >= 32 readable, 16-byte aligned bytes
+    // scalar copies: a per-lane select between two kernel arguments is otherwise compiled into a per-lane LOAD from the argument
+    // segment (select of addresses) with a full vmcnt(0) drain in the middle of the staging code
+    const int ld1_s = __builtin_amdgcn_readfirstlane(p.ld1), ld2_s = __builtin_amdgcn_readfirstlane(p.ld2);
     // per-chunk prologue affine of THIS thread's 8-channel group: every item of a thread has the same group (256 % G == 0) and
-    // the tile lies in one batch row, so the 8 + 8 floats are loaded once per phase, together with the activations
+    // the tile lies in one batch row, so the 8 + 8 floats are loaded once per phase
     const int my_cg = rtid & (G - 1);
     // tile-independent geometry of this thread's staging items: pixel (iy, ix) inside the halo tile
-    int it_iy[kMaxItems], it_ix[kMaxItems];
+    int it_yx[kMaxItems];   // (iy << 16) | ix
     static_for<kMaxItems>([&](auto ic) __attribute__((always_inline)) {
       constexpr int it = decltype(ic)::value;
       const int idx = rtid + it * 256;
       const int pix = idx >> LOG2G;
       const int iy = (int)(((float)pix + 0.5f) * inv_itw);
-      it_iy[it] = idx < items ? iy : -(1 << 20);   // slots beyond the tile never pass the bounds test
-      it_ix[it] = pix - iy * ITW;
+      it_yx[it] = ((idx < items ? iy : 0x4000) << 16) | (pix - iy * ITW);   // slots beyond the tile never pass the bounds test
     });
-    uint4 raw[kMaxItems];
-    float st_q1[kMaxItems], st_q2[kMaxItems];   // rs | ssq_a | mu (q2: ssq_b | mu) as loaded; the arithmetic happens at write time
-    float4 st_a0, st_a1, st_s0, st_s1;
-    unsigned inb_mask = 0;
-    const float* q1_ptr = p.rs ? p.rs : p.ssq_a;                  // one load site per statistics array (uniform selection, made once)
-    const float* q2_ptr = p.mu ? p.mu : (p.rs ? nullptr : p.ssq_b);
+    const float* q1_base = p.rs ? p.rs : (p.ssq_a ? p.ssq_a : dummy_f);            // rs | ssq_a
+    const int q1_on = (p.rs || p.ssq_a) ? 1 : 0;
+    const float* q2_base = p.mu ? p.mu : ((!p.rs && p.ssq_b) ? p.ssq_b : dummy_f);  // mu | ssq_b
+    const int q2_on = (p.mu || (!p.rs && p.ssq_b)) ? 1 : 0;
+    const float* pa_base = p.pa ? p.pa : kOnes8;    // absent affine: neutral constants instead of per-element selects
+    const float* ps_base = p.ps ? p.ps : kZeros8;
+    const int pa_on = p.pa ? 1 : 0, ps_on = p.ps ? 1 : 0;
 
-    // ONLY loads (every one unconditional: out-of-range items read a valid dummy address), so that nothing here waits on memory
-    auto stage_load = [&](const TileCoord& tc, int chunk) __attribute__((always_inline)) {
-      inb_mask = 0;
-      const int b = tc.b;
-      const int iy0 = tc.oy0 * p.stride - p.pad, ix0 = tc.ox0 * p.stride - p.pad;
+    struct StageSet {
+      uint4 raw[kMaxItems];
+      float q1[kMaxItems], q2[kMaxItems];   // statistics as loaded; the arithmetic happens at write time
+      unsigned mask;
+      int b, chunk;                         // phase identity (for the affine load that follows one phase later)
+    };
+    StageSet A, B;
+    float4 st_a0, st_a1, st_s0, st_s1;      // affine of the phase about to be written (shared by both sets)
+
+    // phase cursor: (tl, chunk) is the phase whose loads are issued next; past the end it stays on the last phase (harmless re-loads)
+    TileCoord tl = decode(t_cursor);
+    int chunk = 0;
+    const int tiles_mine = (t_end - t_cursor + t_step - 1) / t_step;
+    const int n_phases = tiles_mine * NC;
+    auto advance = [&]() __attribute__((always_inline)) {
+      if (chunk + 1 < NC) ++chunk;
+      else if (t_cursor + t_step < t_end) {
+        chunk = 0;
+        t_cursor += t_step;
+        tl = decode(t_cursor);
+      }
+    };
+
+    auto load_set = [&](StageSet& S) __attribute__((always_inline)) {
+      S.mask = 0;
+      S.b = tl.b;
+      S.chunk = chunk;
+      const int b = tl.b;
+      const int iy0 = tl.oy0 * p.stride - p.pad, ix0 = tl.ox0 * p.stride - p.pad;
       const int cc = chunk * KC + my_cg * 8;
-      if (p.pa) {
-        const float4* q = reinterpret_cast<const float4*>(p.pa + (size_t)b * p.pstride + cc);
-        st_a0 = q[0];
-        st_a1 = q[1];
-      }
-      if (p.ps) {
-        const float4* q = reinterpret_cast<const float4*>(p.ps + (size_t)b * p.pstride + cc);
-        st_s0 = q[0];
-        st_s1 = q[1];
-      }
       const bool from1 = cc < p.C1;
       const bool chan_ok = from1 || (cc - p.C1 < p.C2);
       const f16* base = from1 ? x1 + (size_t)b * p.bs1 + cc : x2 + (size_t)b * p.bs2 + (cc - p.C1);
-      const int ld = from1 ? p.ld1 : p.ld2;
+      const int ld = from1 ? ld1_s : ld2_s;
       const int sp0 = b * (p.H * p.W);
       static_for<kMaxItems>([&](auto ic) __attribute__((always_inline)) {
         constexpr int it = decltype(ic)::value;
-        const int gy = iy0 + it_iy[it], gx = ix0 + it_ix[it];
+        const int gy = iy0 + (it_yx[it] >> 16), gx = ix0 + (it_yx[it] & 0xffff);
         const bool ok = chan_ok && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
         const int gp = ok ? gy * p.W + gx : 0;
         const f16* src = ok ? base + (size_t)gp * ld : x1;
-        if (!(p.dbg & 16)) raw[it] = *reinterpret_cast<const uint4*>(src);   // dbg 16: ablate the activation loads
-        if (ok) inb_mask |= 1u << it;
+        S.raw[it] = *reinterpret_cast<const uint4*>(src);
+        if (ok) S.mask |= 1u << it;
         const int sp = sp0 + gp;
-        if (q1_ptr) st_q1[it] = q1_ptr[sp];
-        if (q2_ptr) st_q2[it] = q2_ptr[sp];
+        S.q1[it] = q1_base[sp * q1_on];
+        S.q2[it] = q2_base[sp * q2_on];
       });
     };
+    auto load_affine = [&](const StageSet& S) __attribute__((always_inline)) {
+      const int o = S.b * p.pstride + S.chunk * KC + my_cg * 8;
+      const float4* qa = reinterpret_cast<const float4*>(pa_base + o * pa_on);
+      const float4* qs = reinterpret_cast<const float4*>(ps_base + o * ps_on);
+      st_a0 = qa[0];
+      st_a1 = qa[1];
+      st_s0 = qs[0];
+      st_s1 = qs[1];
+    };
 
-    // transform + LDS write of the staged items
-    auto stage_write = [&](char* buf) __attribute__((always_inline)) {
-      float a[8], s[8];
-      if (p.pa) { a[0] = st_a0.x; a[1] = st_a0.y; a[2] = st_a0.z; a[3] = st_a0.w; a[4] = st_a1.x; a[5] = st_a1.y; a[6] = st_a1.z; a[7] = st_a1.w; }
-      else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) a[j] = 1.0f;
-      }
-      if (p.ps) { s[0] = st_s0.x; s[1] = st_s0.y; s[2] = st_s0.z; s[3] = st_s0.w; s[4] = st_s1.x; s[5] = st_s1.y; s[6] = st_s1.z; s[7] = st_s1.w; }
-      else {
-#pragma unroll
-        for (int j = 0; j < 8; ++j) s[j] = 0.0f;
-      }
+    // transform + LDS write of a staged set
+    auto write_set = [&](const StageSet& S, char* buf) __attribute__((always_inline)) {
+      const float a[8] = {st_a0.x, st_a0.y, st_a0.z, st_a0.w, st_a1.x, st_a1.y, st_a1.z, st_a1.w};
+      const float s[8] = {st_s0.x, st_s0.y, st_s0.z, st_s0.w, st_s1.x, st_s1.y, st_s1.z, st_s1.w};
       static_for<kMaxItems>([&](auto ic) __attribute__((always_inline)) {
         constexpr int it = decltype(ic)::value;
         const int idx = rtid + it * 256;
         if (idx < items) {
           const int pix = idx >> LOG2G;
           f16x8 out;
-          if (inb_mask & (1u << it)) {
-            const f16x8 in = *reinterpret_cast<const f16x8*>(&raw[it]);
+          if (S.mask & (1u << it)) {
+            const f16x8 in = *reinterpret_cast<const f16x8*>(&S.raw[it]);
             float rs = 1.0f, mu = 0.0f;
-            if (p.rs) rs = st_q1[it];
+            if (p.rs) rs = S.q1[it];
             else if (p.ssq_a) {  // ChanRMSNorm statistics straight from the producers' per-pixel sums of squares
-              float q = st_q1[it];
-              if (p.ssq_b) q += p.ssq_wb * st_q2[it];
-              rs = 1.0f / fmaxf(sqrtf(q), 1e-12f);
+              float q = S.q1[it];
+              if (p.ssq_b) q += p.ssq_wb * S.q2[it];
+              rs = __builtin_amdgcn_rsqf(fmaxf(q, 1e-24f));   // 1 / max(sqrt(q), 1e-12), F.normalize's clamp (ip.py:328)
             }
-            if (p.mu) mu = st_q2[it];
+            if (p.mu) mu = S.q2[it];
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
               float v = ((float)in[j] - mu) * rs * a[j] + s[j];
@@ -245,40 +282,38 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
       });
     };
 
-    // phase cursor: (t_cursor, chunk) is the phase whose loads are issued next
-    TileCoord tl = decode(t_cursor);
-    int chunk = 0;
-    auto advance = [&]() __attribute__((always_inline)) {
-      if (++chunk == NC) {
-        chunk = 0;
-        t_cursor += t_step;
-        if (t_cursor < t_end) tl = decode(t_cursor);
-      }
-    };
-    // number of phases of this workgroup, and per phase whether it ends a tile: recomputed from counters
-    int tiles_left = (t_end - t_cursor + t_step - 1) / t_step;
-    int phases_left = tiles_left * NC;       // phases whose buffer hand-over barrier is still to come
-    int c_done = 0;                          // chunk index of the phase the consumers are working on
-    stage_load(tl, 0);
-    stage_write(smem);
-    advance();
-    if (t_cursor < t_end && !(p.dbg & 1)) stage_load(tl, chunk);
-    lds_barrier();                           // phase 0 is in buffer 0
-    int cur = 0;
-    while (phases_left > 0) {
-      // consumers: phase q out of buf[cur].  here: phase q+1 into buf[cur^1], loads of phase q+2
-      if (t_cursor < t_end) {
-        if (!(p.dbg & 1)) stage_write(smem + (cur ^ 1) * buf_bytes);
-        advance();
-        if (t_cursor < t_end && !(p.dbg & 1)) stage_load(tl, chunk);
-      }
+    char* buf0 = smem;
+    char* buf1 = smem + buf_bytes;
+    int c_done = 0;   // chunk index of the phase the consumers are working on
+    auto phase_end = [&]() __attribute__((always_inline)) {
       lds_barrier();
-      cur ^= 1;
-      --phases_left;
       if (++c_done == NC) {
         c_done = 0;
-        if (ssq_sync) lds_barrier();         // pairs with the consumers' epilogue reduction
+        if (ssq_sync) lds_barrier();   // pairs with the consumers' epilogue reduction
       }
+    };
+    load_set(A);            // phase 0
+    load_affine(A);
+    advance();
+    load_set(B);            // phase 1
+    advance();
+    write_set(A, buf0);     // waits for A and the affine; B stays in flight
+    load_affine(B);
+    lds_barrier();          // phase 0 is in buffer 0
+    for (int q = 0; q < n_phases; q += 2) {
+      // consumers: phase q out of buf0
+      load_set(A);          // phase q+2
+      advance();
+      write_set(B, buf1);   // phase q+1
+      load_affine(A);
+      phase_end();
+      if (q + 1 >= n_phases) break;
+      // consumers: phase q+1 out of buf1
+      load_set(B);          // phase q+3
+      advance();
+      write_set(A, buf0);   // phase q+2
+      load_affine(B);
+      phase_end();
     }
     return;
   }
@@ -366,11 +401,15 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) anext[mi] = *reinterpret_cast<const f16x8*>(buf + a_base[mi] + a1);
       }
+      // pin the software pipeline: under register pressure the scheduler otherwise sinks the look-ahead loads down to their
+      // first use (load, wait, MFMA — every step then pays a full L2 round trip)
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi)
           acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wq[0][ni], afrag[mi], acc[ni][mi], 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) afrag[mi] = anext[mi];
 #pragma unroll
@@ -393,42 +432,35 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
   auto epilogue = [&](const TileCoord& tc) __attribute__((always_inline)) {
     const int b = tc.b, n0 = tc.n0;
     float ssq_px[MI];  // per-pixel sum of squares of this wave's stored channels (for the consumer's ChanRMSNorm)
-    // per-lane channel constants of the tile: bias and gate quads, loaded once (not per pixel) and all at once
-    float4 bq[NI][4], gq[NI][4];
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
-        bq[ni][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        gq[ni][q] = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias) bq[ni][q] = *reinterpret_cast<const float4*>(p.bias + co);   // bias is padded to Cout_pad by the host
-        if (addend && co < p.Cout) gq[ni][q] = *reinterpret_cast<const float4*>(p.gate + (size_t)b * p.gate_stride + co);
-      }
+    int op[MI];        // output pixel index, -1: outside the image
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       ssq_px[mi] = 0.0f;
       const int oy = tc.oy0 + pix_y[mi], ox = tc.ox0 + pix_x[mi];
-      if (oy >= p.OH || ox >= p.OW) continue;
-      const int op = oy * p.OW + ox;
-      // all addend / residual quads of this pixel in flight before the first one is used
-      f16x4 adq[NI][4], rrq[NI][4];
+      op[mi] = (oy < p.OH && ox < p.OW) ? oy * p.OW + ox : -1;
+    }
+    // one channel quad (4 consecutive couts of this lane) at a time: its bias / gate and the addend / residual quads of all MI
+    // pixels are loaded together, then consumed — a handful of loads in flight per wait instead of one
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
+    for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
-          if (addend && co < p.Cout) adq[ni][q] = *reinterpret_cast<const f16x4*>(addend + (size_t)b * p.bs_add + (size_t)op * p.ld_add + co);
-          if (res && co < p.Cout) rrq[ni][q] = *reinterpret_cast<const f16x4*>(res + (size_t)b * p.bs_res + (size_t)op * p.ld_res + co);
+      for (int q = 0; q < 4; ++q) {
+        const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
+        if (co >= p.Cout) continue;
+        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f), gq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (p.bias) bq = *reinterpret_cast<const float4*>(p.bias + co);   // bias is padded to Cout_pad by the host
+        if (addend) gq = *reinterpret_cast<const float4*>(p.gate + (size_t)b * p.gate_stride + co);
+        f16x4 adq[MI], rrq[MI];
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          if (addend && op[mi] >= 0) adq[mi] = *reinterpret_cast<const f16x4*>(addend + (size_t)b * p.bs_add + (size_t)op[mi] * p.ld_add + co);
+          if (res && op[mi] >= 0) rrq[mi] = *reinterpret_cast<const f16x4*>(res + (size_t)b * p.bs_res + (size_t)op[mi] * p.ld_res + co);
         }
+        const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
-          if (co >= p.Cout) continue;
+        for (int mi = 0; mi < MI; ++mi) {
+          if (op[mi] < 0) continue;
           float v[4];
-          const float bb[4] = {bq[ni][q].x, bq[ni][q].y, bq[ni][q].z, bq[ni][q].w};
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
             float x = acc[ni][mi][4 * q + e] + bb[e];
@@ -440,16 +472,15 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
             float* y = reinterpret_cast<float*>(p.y);
 #pragma unroll
             for (int e = 0; e < 4; ++e)
-              if (co + e < p.Cout) y[((size_t)b * p.Cout + co + e) * (p.OH * p.OW) + op] = v[e];
+              if (co + e < p.Cout) y[((size_t)b * p.Cout + co + e) * (p.OH * p.OW) + op[mi]] = v[e];
             continue;
           }
           if (addend) {
-            const f16x4 ad = adq[ni][q];
-            const float4 g = gq[ni][q];
-            v[0] += (float)ad[0] * g.x; v[1] += (float)ad[1] * g.y; v[2] += (float)ad[2] * g.z; v[3] += (float)ad[3] * g.w;
+            const f16x4 ad = adq[mi];
+            v[0] += (float)ad[0] * gq.x; v[1] += (float)ad[1] * gq.y; v[2] += (float)ad[2] * gq.z; v[3] += (float)ad[3] * gq.w;
           }
           if (res) {
-            const f16x4 rr = rrq[ni][q];
+            const f16x4 rr = rrq[mi];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
           }
@@ -465,10 +496,11 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
             // output channels are packed (s1, s2, c): cout = (2*s1 + s2) * Cq + c   (PixelShuffle(2), ip.py:616)
             const int Cq = p.Cout >> 2;
             const int sub = co / Cq, c = co - sub * Cq;
+            const int oy = tc.oy0 + pix_y[mi], ox = tc.ox0 + pix_x[mi];
             const int yy = 2 * oy + (sub >> 1), xx = 2 * ox + (sub & 1);
             *reinterpret_cast<f16x4*>(y + (size_t)b * p.bsy + ((size_t)yy * (2 * p.OW) + xx) * p.ldy + c) = o;
           } else {
-            if (!(p.dbg & 8)) *reinterpret_cast<f16x4*>(y + (size_t)b * p.bsy + (size_t)op * p.ldy + co) = o;   // dbg 8: ablate the stores
+            if (!(p.dbg & 8)) *reinterpret_cast<f16x4*>(y + (size_t)b * p.bsy + (size_t)op[mi] * p.ldy + co) = o;   // dbg 8: ablate the stores
           }
         }
       }
@@ -548,7 +580,8 @@ int launch_ksc(const ImagenIgemmParams& p, hipStream_t s) {
   const int ITW = (p.TW - 1) * p.stride + p.KW, ITH = (p.TH - 1) * p.stride + p.KH;
   const int IT = ITH * ITW;
   IMAGEN_CHECK(p.TH * p.TW == TP, "igemm: tile %dx%d does not match cfg %d (%d pixels)", p.TH, p.TW, p.cfg, TP);
-  IMAGEN_CHECK(IT * G <= kMaxItems * 256, "igemm: halo tile too large (%d px x %d groups)", IT, G);
+  IMAGEN_CHECK(IT * G <= stage_slots(TP, G, KSC) * 256, "igemm: halo tile too large (%d px x %d groups > %d staging slots)", IT, G,
+               stage_slots(TP, G, KSC));
   IMAGEN_CHECK(p.Cout_pad % BN == 0, "igemm: Cout_pad %d not a multiple of %d", p.Cout_pad, BN);
   IMAGEN_CHECK(p.Cin_pad % (8 * G) == 0, "igemm: Cin_pad %d not a multiple of %d", p.Cin_pad, 8 * G);
   IMAGEN_CHECK(p.C1 % 8 == 0 && p.C2 % 8 == 0 && p.ld1 % 8 == 0 && (p.x2 == nullptr || p.ld2 % 8 == 0),
@@ -600,7 +633,6 @@ int launch_cfg(const ImagenIgemmParams& p, hipStream_t s) {
     if (ks == 8) return launch_ksc<MI, NI, WM, WN, G, (G == 4 ? 8 : 0)>(p, s);
   }
   if (G == 8 && ks == 4) return launch_ksc<MI, NI, WM, WN, G, (G == 8 ? 4 : 0)>(p, s);
-  if (G == 8 && ks == 36) return launch_ksc<MI, NI, WM, WN, G, (G == 8 ? 36 : 0)>(p, s);   // 3x3 with 64-channel chunks
   if (G == 16 && ks == 8) return launch_ksc<MI, NI, WM, WN, G, (G == 16 ? 8 : 0)>(p, s);
   return launch_ksc<MI, NI, WM, WN, G, 0>(p, s);
 }
@@ -642,6 +674,19 @@ extern "C" int imagen_igemm_config_info(int cfg, int* tile_pixels, int* tile_cou
   if (tile_cout) *tile_cout = 32 * c.NI * c.WN;
   if (kgroups) *kgroups = c.G;
   return 0;
+}
+
+static constexpr int ksc_of(int G, int ks) {   // the launch_cfg dispatch, as a function
+  if (G == 4 && (ks == 18 || ks == 2 || ks == 8)) return ks;
+  if (G == 8 && ks == 4) return ks;
+  if (G == 16 && ks == 8) return ks;
+  return 0;
+}
+
+extern "C" int imagen_igemm_stage_slots(int cfg, int KH, int KW) {
+  if (cfg < 0 || cfg >= kNumCfgs || KH < 1 || KW < 1) return -1;
+  const TileCfg& c = kCfgs[cfg];
+  return stage_slots(32 * c.MI * c.WM, c.G, ksc_of(c.G, (KH * KW * c.G + 1) / 2));
 }
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }

@@ -194,8 +194,6 @@ def choose_G(Cin: int, taps: int = 9) -> int:
             return 16
         if Cin % 64 == 0:
             return 8
-    if taps == 9 and DEEP_3X3 and Cin % 64 == 0 and Cin >= 128:
-        return 8    # MFMA-bound 3x3 layers: half as many staging round trips / barriers per tile
     if Cin % 32 == 0:
         return 4
     return 1
@@ -231,12 +229,9 @@ def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], device, in_scale:
 
 import os as _os
 
-DEEP_3X3 = int(_os.environ.get("IMAGEN_DEEP_3X3", "0"))             # A/B switch: 64-channel k-chunks for 3x3 convs with C_in >= 128
 DEEP_CHUNKS = int(_os.environ.get("IMAGEN_DEEP_CHUNKS", "1"))       # A/B switch: 64/128-channel k-chunks for 1x1 convs / linears
 GCA_SINGLE_LAUNCH = int(_os.environ.get("IMAGEN_GCA_SINGLE_LAUNCH", "1"))   # A/B switch: finalise GlobalContext in the partial kernel
 IGEMM_DBG = int(_os.environ.get("IMAGEN_IGEMM_DBG", "0"))          # kernel A/B switches (see ImagenIgemmParams.dbg); 0 in production
-FILL_BLOCKS = int(_os.environ.get("IMAGEN_FILL_BLOCKS", "512"))   # workgroups wanted before growing the tile (2 per CU on 256 CUs)
-MAX_STAGE_ITEMS = 6 * 256      # kMaxItems * threads in igemm.hip
 MAX_LDS_BYTES = 160 * 1024
 
 
@@ -246,31 +241,56 @@ def _tile_shapes(tp: int, OH: int, OW: int):
     return [(tp // tw, tw) for tw in (8, 16, 32, 64) if tp % tw == 0 and tp // tw >= 1]
 
 
-def pick_cfg(G: int, Cout: int, OH: int, OW: int, B: int, KH: int = 1, KW: int = 1, stride: int = 1):
-    """Choose (cfg, TH, TW): output-channel tile closest to Cout, then the largest pixel tile that still fills
-    the 256 CUs (smallest one otherwise), then the tile shape staging the fewest input pixels (halo)."""
+def pick_cfg(G: int, Cout: int, OH: int, OW: int, B: int, KH: int = 1, KW: int = 1, stride: int = 1, full_cout: bool = False):
+    """Choose (cfg, TH, TW) for the wave-specialised persistent kernel.  Measured on MI355X (tools/igemm_probe.py --sweep,
+    gpurun_out/sweep1.txt): the kernel is staging-/latency-bound rather than MFMA-bound, so the 64-pixel-per-wave tilings
+    (MI <= 2) win everywhere, and when a layer has fewer workgroups than the chip has CUs the narrower output-channel tile
+    (twice the workgroups) wins.  Preference order of (tile pixels, tile couts):
+      Cout <= 32 : 256x32 when that still gives >= 1024 workgroups, else 128x32
+      Cout <= 64 : 256x32 (two cout tiles) when >= 2048 workgroups, else 64x64
+      Cout  > 64 : 64x128 when > 256 workgroups, else 64x64
+    full_cout: the caller wants the per-pixel sum of squares from the epilogue, which needs one tile to cover all Cout —
+    tiles narrower than Cout are then only used when nothing wider exists.  Among the tile shapes of the chosen
+    configuration: least padded pixels, then the fewest staged halo pixels."""
     tab = cfg_table()
-    img_px = OH * OW
-    want_bn = 32 if Cout <= 32 else (64 if Cout <= 64 else 128)
     ps = 16 if G == 1 else G * 16 + 16
-    best = None
-    for i, (tp, bn, g) in enumerate(tab):
-        if g != G:
-            continue
+
+    def shapes(tp, max_items):
+        out = []
         for th, tw in _tile_shapes(tp, OH, OW):
             it = ((th - 1) * stride + KH) * ((tw - 1) * stride + KW)
-            if it * G > MAX_STAGE_ITEMS or 2 * it * ps > MAX_LDS_BYTES:
+            if it * G > max_items or 2 * it * ps + 4096 > MAX_LDS_BYTES:
                 continue
             tiles = math.ceil(OH / th) * math.ceil(OW / tw)
-            nb = B * tiles * math.ceil(Cout / bn)
-            waste = tiles * tp / img_px            # padded-pixel overhead (tiles hanging over the image)
-            fill = nb >= FILL_BLOCKS
-            score = (abs(bn - want_bn), waste > 1.5, not fill, -tp if fill else tp, tiles * it)
-            if best is None or score < best[0]:
-                best = (score, i, th, tw)
-    if best is None:
-        raise ValueError(f"no igemm tile configuration for G={G} Cout={Cout} {OH}x{OW} k{KH}x{KW} s{stride}")
-    return best[1], best[2], best[3]
+            out.append((tiles, tiles * it, th, tw))
+        return sorted(out)
+
+    lib = load_library()
+    avail = {}
+    for i, (tp, bn, g) in enumerate(tab):
+        if g == G and (tp, bn) not in avail:
+            sh = shapes(tp, lib.imagen_igemm_stage_slots(i, KH, KW) * 256)
+            if sh:
+                avail[(tp, bn)] = (i, sh[0])
+
+    def wgs(key):
+        return B * avail[key][1][0] * math.ceil(Cout / key[1]) if key in avail else 0
+
+    if Cout <= 32:
+        order = [(256, 32)] if wgs((256, 32)) >= 1024 else []
+        order += [(128, 32), (256, 32), (64, 64), (64, 128)]
+    elif Cout <= 64:
+        order = [(256, 32)] if wgs((256, 32)) >= 2048 and not full_cout else []
+        order += [(64, 64), (64, 128), (128, 32), (256, 32)]
+    else:
+        order = [(64, 128)] if wgs((64, 128)) > 256 or (full_cout and Cout <= 128) else []
+        order += [(64, 64), (64, 128), (128, 32), (256, 32)]
+    order += [(128, 128), (256, 64)]
+    for key in order:
+        if key in avail:
+            i, (_, _, th, tw) = avail[key]
+            return i, th, tw
+    raise ValueError(f"no igemm tile configuration for G={G} Cout={Cout} {OH}x{OW} k{KH}x{KW} s{stride}")
 
 
 def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None, mu=None, rs=None, pa=None, ps=None,
@@ -290,7 +310,7 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
     C2 = x2.C if x2 is not None else 0
     assert x1.C + C2 == pw.Cin, f"{label}: input channels {x1.C}+{C2} != weight Cin {pw.Cin}"
     if cfg is None:
-        cfg = pick_cfg(pw.G, pw.Cout, OH, OW, x1.B, KH, KW, stride)
+        cfg = pick_cfg(pw.G, pw.Cout, OH, OW, x1.B, KH, KW, stride, full_cout=ssq_out is not None and out_mode == OUT_NHWC)
     cid, th, tw = cfg
     p = STRUCTS["ImagenIgemmParams"]()
     p.x1, p.C1, p.ld1, p.bs1 = x1.ptr, x1.C, x1.ld, x1.bs

@@ -290,6 +290,9 @@ int imagen_plan_run(const ImagenOpRef* ops, int n, imagen_stream_t stream);
 /* igemm tile selection + packing.  cfg ids are stable; *_tile_* describe a cfg. */
 int imagen_igemm_num_configs(void);
 int imagen_igemm_config_info(int cfg, int* tile_pixels, int* tile_cout, int* kgroups /* G: 8-channel groups per k-chunk */);
+/* 16-byte staging slots per producer thread the instantiation (cfg, KHxKW kernel) holds: a tile shape is launchable iff
+ * halo_pixels * G <= slots * 256 */
+int imagen_igemm_stage_slots(int cfg, int KH, int KW);
 /* Host-side pack: w_in fp32 [Cout][Cin][KH][KW] (Conv2d / Linear layout, HOST memory) -> packed fp16 (HOST memory)
  * in MFMA fragment order.  G = 8-channel groups per k-chunk (1, 2 or 4; must match the tile cfg used at launch),
  * Cout_pad = multiple of 128 (any tile cfg can then consume it).  in_scale (optional, [Cin]) is folded into W. */

@@ -109,7 +109,7 @@ def test_tile_selection_respects_kernel_limits():
         tp, bn, g = tab[cfg]
         assert g == G and th * tw == tp
         it = ((th - 1) * stride + K) * ((tw - 1) * stride + K)
-        assert it * G <= ops.MAX_STAGE_ITEMS
+        assert it * G <= 256 * ops.load_library().imagen_igemm_stage_slots(cfg, K, K)
         assert 2 * it * (16 if G == 1 else G * 16 + 16) <= ops.MAX_LDS_BYTES
 
 

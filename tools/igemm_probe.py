@@ -31,14 +31,30 @@ SHAPES = [  # (name, B, H, W, C1, C2, Cout, K)
     ("res 64->32 1x1 @256", 16, 256, 256, 32, 32, 32, 1),
 ]
 
-def run(name, B, H, W, C1, C2, Cout, K, variant, cfg=None):
+EXTRA_SHAPES = [  # the small-map layers of unet1 and the token GEMMs (few workgroups: tile choice decides how many CUs work)
+    ("u1.L3 384->256 3x3 @8", 16, 8, 8, 256, 128, 256, 3),
+    ("u1.L3 128->128 3x3 @8", 16, 8, 8, 128, 0, 128, 3),
+    ("u1.L2 192->128 3x3 @16", 16, 16, 16, 128, 64, 128, 3),
+    ("u1.L2 64->64 3x3 @16", 16, 16, 16, 64, 0, 64, 3),
+    ("u1.L0 32->32 3x3 @64", 16, 64, 64, 32, 0, 32, 3),
+    ("u2.L1 64->64 3x3 @128", 16, 128, 128, 64, 0, 64, 3),
+    ("u2.L1 32->32 3x3 @128", 16, 128, 128, 32, 0, 32, 3),
+    ("u2.L2 128->128 3x3 @64", 16, 64, 64, 128, 0, 128, 3),
+    ("qkv 64->640 M=16384", 16, 1, 1024, 64, 0, 640, 1),
+    ("to_q 256->512 M=1024", 16, 1, 64, 256, 0, 512, 1),
+    ("ups 64->128 1x1 @128", 16, 128, 128, 64, 0, 128, 1),
+    ("res 384->256 1x1 @32", 16, 32, 32, 256, 128, 256, 1),
+]
+
+
+def run(name, B, H, W, C1, C2, Cout, K, variant, cfg=None, G=None):
     torch.manual_seed(0)
     x1 = ops.new_act(B, H, W, C1, dev); x1.t.normal_()
     x2 = None
     if C2:
         x2 = ops.new_act(B, H, W, C2, dev); x2.t.normal_()
     C = C1 + C2
-    pw = ops.pack_weight(torch.randn(Cout, C, K, K) / (C * K * K) ** 0.5, torch.zeros(Cout), dev)
+    pw = ops.pack_weight(torch.randn(Cout, C, K, K) / (C * K * K) ** 0.5, torch.zeros(Cout), dev, G=G)
     y = ops.new_act(B, H, W, Cout, dev)
     plan = ops.Plan()
     kw = {}
@@ -63,8 +79,46 @@ def run(name, B, H, W, C1, C2, Cout, K, variant, cfg=None):
     byts = (B * H * W * (C + Cout)) * 2
     return us, fl / us / 1e6, byts / us / 1e3, (p.cfg, p.TH, p.TW)
 
+def sweep(shapes, G_list=None):
+    """Every (cfg, tile shape) the launcher accepts, per shape and k-chunk depth G: the table pick_cfg() should reproduce."""
+    import math
+    tab = ops.cfg_table()
+    for shp in shapes:
+        name, B, H, W, C1, C2, Cout, K = shp
+        C = C1 + C2
+        for G in (G_list or sorted({ops.choose_G(C, K * K), 4})):
+            if C % (8 * G) and G != ops.choose_G(C, K * K):
+                continue
+            res = []
+            for i, (tp, bn, g) in enumerate(tab):
+                if g != G:
+                    continue
+                for th, tw in ops._tile_shapes(tp, H, W):
+                    it = (th - 1 + K) * (tw - 1 + K)
+                    ps = 16 if G == 1 else G * 16 + 16
+                    if it * G > 256 * ops.load_library().imagen_igemm_stage_slots(i, K, K) or 2 * it * ps + 4096 > ops.MAX_LDS_BYTES:
+                        continue
+                    if bn > 32 and bn >= 2 * max(32, Cout):
+                        continue
+                    try:
+                        us, tf, gbs, _ = run(name, B, H, W, C1, C2, Cout, K, "full", cfg=(i, th, tw), G=G)
+                    except Exception as e:  # launcher refused the combination
+                        continue
+                    res.append((us, i, th, tw, tp, bn))
+            res.sort()
+            pk = ops.pick_cfg(G, Cout, H, W, B, K, K, 1)
+            best = " ".join(f"cfg{i}({tp}x{bn}) t{th}x{tw}:{us:.1f}" for us, i, th, tw, tp, bn in res[:5])
+            mine = [r for r in res if (r[1], r[2], r[3]) == tuple(pk)]
+            print(f"{name:26s} G={G:2d} | pick cfg{pk[0]} t{pk[1]}x{pk[2]}: {mine[0][0] if mine else float('nan'):.1f}us | best: {best}", flush=True)
+
+
+
 if __name__ == "__main__":
     args = sys.argv[1:]
+    if args and args[0] == "--sweep":
+        sel = args[1].split(",") if len(args) > 1 else None
+        globals()["sweep"]([s_ for s_ in SHAPES + EXTRA_SHAPES if not sel or any(o in s_[0] for o in sel)])
+        sys.exit(0)
     only = None
     if args and args[0].startswith("--only="):
         only = args[0][7:].split(",")
