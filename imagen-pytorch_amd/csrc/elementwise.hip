@@ -333,22 +333,39 @@ __global__ __launch_bounds__(256) void gca_partial_online_kernel(const ImagenGca
       }
     }
   }
-  s_m[threadIdx.x] = m;
-  s_se[threadIdx.x] = se;
+  // merge the pixel lanes: inside a wave by butterfly shuffles over the lanes that share a channel group (lane distance
+  // groups, 2*groups, ... 32), then the 4 waves through LDS
+  for (int off = groups; off < 64; off <<= 1) {
+    const float m2 = __shfl_xor(m, off), se2 = __shfl_xor(se, off);
+    const float mn = fmaxf(m, m2);
+    const float w1 = __expf(m - mn), w2 = __expf(m2 - mn);   // lanes that saw no pixel carry m = -3e38, se = acc = 0
+    se = se * w1 + se2 * w2;
 #pragma unroll
-  for (int j = 0; j < 8; ++j) s_acc[threadIdx.x * 8 + j] = acc[j];
+    for (int j = 0; j < 8; ++j) acc[j] = acc[j] * w1 + __shfl_xor(acc[j], off) * w2;
+    m = mn;
+  }
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gw = groups < 64 ? groups : 64;   // channel groups per wave
+  if (lane < gw) {
+    const int slot = wave * gw + lane;        // groups == 64: the wave's lanes ARE the groups; else every wave holds all groups
+    s_m[slot] = m;
+    s_se[slot] = se;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) s_acc[slot * 8 + j] = acc[j];
+  }
   __syncthreads();
   float* out = p.part + ((size_t)b * p.chunks + ch) * (p.C + 2);
-  if (threadIdx.x < groups) {  // merge the pixel lanes of channel group threadIdx.x
+  if (threadIdx.x < groups) {  // merge the 4 waves' entries of channel group threadIdx.x
+    const int g = threadIdx.x & (gw - 1);
     float M = -3.0e38f;
-    for (int q = 0; q < npl; ++q) M = fmaxf(M, s_m[q * groups]);
+    for (int q = 0; q < 4; ++q) M = fmaxf(M, s_m[q * gw + g]);
     float tot[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     float S = 0.f;
-    for (int q = 0; q < npl; ++q) {
-      const float w = __expf(s_m[q * groups] - M);   // lanes that saw no pixel carry m = -3e38 -> weight 0
-      S += s_se[q * groups] * w;
+    for (int q = 0; q < 4; ++q) {
+      const float w = __expf(s_m[q * gw + g] - M);
+      S += s_se[q * gw + g] * w;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) tot[j] += s_acc[(q * groups + threadIdx.x) * 8 + j] * w;
+      for (int j = 0; j < 8; ++j) tot[j] += s_acc[(q * gw + g) * 8 + j] * w;
     }
 #pragma unroll
     for (int j = 0; j < 8; ++j) out[2 + threadIdx.x * 8 + j] = tot[j];

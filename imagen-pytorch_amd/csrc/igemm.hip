@@ -353,8 +353,10 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
 
   // ---- weight fragment pipeline, continuous over chunks AND tiles
   // wq[j] holds the fragments of K=16 step (gstep + j); w_ofs is the offset (in fragments) of step (gstep + kLookAhead)
-  constexpr int kLookAhead = KSC == 0 ? 1 : (KSC >= 6 ? 6 : KSC);
-  static_assert(kLookAhead <= 8, "packed weights carry a zero tail of 8 steps");
+  // look-ahead depth of the weight ring: a wave consumes one fragment per MI MFMAs, so the single-MFMA-per-step tilings (small
+  // feature maps: few workgroups, each streaming its whole weight slice) need a deeper ring to cover the L2 round trip
+  constexpr int kWantAhead = (MI * NI == 1) ? 12 : 6;
+  constexpr int kLookAhead = KSC == 0 ? 1 : (KSC >= kWantAhead ? kWantAhead : KSC);
   f16x8 wq[kLookAhead][NI];
   int w_ofs = 0;
 

@@ -230,7 +230,7 @@ def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], device, in_scale:
 import os as _os
 
 DEEP_CHUNKS = int(_os.environ.get("IMAGEN_DEEP_CHUNKS", "1"))       # A/B switch: 64/128-channel k-chunks for 1x1 convs / linears
-GCA_SINGLE_LAUNCH = int(_os.environ.get("IMAGEN_GCA_SINGLE_LAUNCH", "1"))   # A/B switch: finalise GlobalContext in the partial kernel
+GCA_SINGLE_LAUNCH = int(_os.environ.get("IMAGEN_GCA_SINGLE_LAUNCH", "0"))   # A/B switch: finalise GlobalContext in the partial kernel behind an agent-scope ticket (measured slower than a second launch: the release/acquire fences write back and invalidate the XCD L2)
 IGEMM_DBG = int(_os.environ.get("IMAGEN_IGEMM_DBG", "0"))          # kernel A/B switches (see ImagenIgemmParams.dbg); 0 in production
 MAX_LDS_BYTES = 160 * 1024
 
@@ -247,8 +247,8 @@ def pick_cfg(G: int, Cout: int, OH: int, OW: int, B: int, KH: int = 1, KW: int =
     (MI <= 2) win everywhere, and when a layer has fewer workgroups than the chip has CUs the narrower output-channel tile
     (twice the workgroups) wins.  Preference order of (tile pixels, tile couts):
       Cout <= 32 : 256x32 when that still gives >= 1024 workgroups, else 128x32
-      Cout <= 64 : 256x32 (two cout tiles) when >= 2048 workgroups, else 64x64
-      Cout  > 64 : 64x128 when > 256 workgroups, else 64x64
+      Cout <= 64 : 256x32 (two cout tiles) for k > 1 kernels with >= 2048 workgroups, else 64x64
+      Cout  > 64 : 64x128 when >= 192 workgroups, else 64x64
     full_cout: the caller wants the per-pixel sum of squares from the epilogue, which needs one tile to cover all Cout —
     tiles narrower than Cout are then only used when nothing wider exists.  Among the tile shapes of the chosen
     configuration: least padded pixels, then the fewest staged halo pixels."""
@@ -280,10 +280,10 @@ def pick_cfg(G: int, Cout: int, OH: int, OW: int, B: int, KH: int = 1, KW: int =
         order = [(256, 32)] if wgs((256, 32)) >= 1024 else []
         order += [(128, 32), (256, 32), (64, 64), (64, 128)]
     elif Cout <= 64:
-        order = [(256, 32)] if wgs((256, 32)) >= 2048 and not full_cout else []
+        order = [(256, 32)] if wgs((256, 32)) >= 2048 and not full_cout and KH * KW > 1 else []
         order += [(64, 64), (64, 128), (128, 32), (256, 32)]
     else:
-        order = [(64, 128)] if wgs((64, 128)) > 256 or (full_cout and Cout <= 128) else []
+        order = [(64, 128)] if wgs((64, 128)) >= 192 or (full_cout and Cout <= 128) else []
         order += [(64, 64), (64, 128), (128, 32), (256, 32)]
     order += [(128, 128), (256, 64)]
     for key in order:
