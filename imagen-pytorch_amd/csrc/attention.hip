@@ -3,8 +3,8 @@
 // ONE k/v head shared by all 8 query heads), ip.py:812-833 (cross attention, per-head k/v, 39|41 keys) and
 // PerceiverAttention ip.py:424-444.
 //
-// Inputs are prepared by QNORM / KV_PREP: q rows already l2-normalised * q_scale * 8 * log2(e) (so softmax
-// is exp2 of the raw dot product), k rows l2-normalised * k_scale, V stored transposed (V^T[d][key]) and both
+// Inputs are prepared by QNORM (or the fused q_scale path below) / KV_PREP: q rows l2-normalised * q_scale * 8 * log2(e)
+// (so softmax is exp2 of the raw dot product), k rows l2-normalised * k_scale, V stored transposed (V^T[d][key]) and both
 // K / V^T zero-padded to a multiple of 32 keys.  For the shared-k/v self attention the host passes
 // heads = 1 and rows = n*8: the (token, head) pairs are just 8n query rows over one key set.
 //
@@ -36,6 +36,23 @@ __global__ __launch_bounds__(256) void attention_kernel(const ImagenAttentionPar
   f16x8 qf[4];
 #pragma unroll
   for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const f16x8*>(q + 16 * s + 8 * half);
+  if (p.q_scale) {   // fused QNORM (ip.py:559-560): this lane holds 32 of the row's 64 dims, lane ^ 32 the other 32
+    float ssq = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ssq += (float)qf[s][j] * (float)qf[s][j];
+    ssq += __shfl_xor(ssq, 32);
+    const float inv = p.q_mult / fmaxf(sqrtf(ssq), 1e-12f);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float4 g0 = *reinterpret_cast<const float4*>(p.q_scale + 16 * s + 8 * half);
+      const float4 g1 = *reinterpret_cast<const float4*>(p.q_scale + 16 * s + 8 * half + 4);
+      const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[s][j] = (f16)((float)qf[s][j] * inv * g[j]);
+    }
+  }
 
   const f16* kg = reinterpret_cast<const f16*>(p.k) + (size_t)b * p.k_bs + (size_t)hd * p.k_hs;
   const f16* vg = reinterpret_cast<const f16*>(p.vt) + (size_t)b * p.vt_bs + (size_t)hd * p.vt_hs;

@@ -309,7 +309,7 @@ __global__ __launch_bounds__(256) void gca_partial_online_kernel(const ImagenGca
   for (int j = 0; j < 8; ++j) wk[j] = p.wk[cg * 8 + j];
   float m = -3.0e38f, se = 0.f;
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  constexpr int U = 4;   // pixels in flight per lane (the loop is a load-latency chain otherwise)
+  constexpr int U = 8;   // pixels in flight per lane (the loop is a load-latency chain otherwise)
   for (int px0 = pl; px0 < npx; px0 += npl * U) {   // uniform trip count within each `groups`-lane team
     f16x8 v[U];
 #pragma unroll
@@ -374,7 +374,13 @@ __global__ __launch_bounds__(256) void gca_partial_online_kernel(const ImagenGca
       out[1] = S;
     }
   }
-  if (p.counter == nullptr) return;
+  if (p.w1t == nullptr) return;   // partials only: a GCA_FINAL launch follows
+  if (p.chunks == 1) {
+    // the whole image was this workgroup's (small feature maps): finalise straight away, no cross-workgroup protocol
+    __syncthreads();               // workgroup-scope fence + barrier: `out` is visible to all threads of this workgroup
+    gca_finalize(out, 1, p.C, p.hidden, p.w1t, p.b1, p.w2t, p.b2, p.gate + (size_t)b * p.C, s_acc);
+    return;
+  }
   // last workgroup of this image finalises (agent-scope release / acquire ticket; placement-independent)
   __shared__ int s_last;
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -542,9 +548,10 @@ int launch_gca_partial(const ImagenGcaPartialParams* p, hipStream_t s) {
   IMAGEN_CHECK(p->C % 8 == 0 && p->C / 8 <= 256, "gca: unsupported C %d", p->C);
   const int chunk_px = (p->HW + p->chunks - 1) / p->chunks;
   const int groups = p->C / 8;
-  if (p->counter) {
+  if (p->w1t) {
     IMAGEN_CHECK((groups & (groups - 1)) == 0 && groups <= 64, "gca: in-kernel finalisation needs a power-of-two C/8 (C = %d)", p->C);
-    IMAGEN_CHECK(p->w1t && p->b1 && p->w2t && p->b2 && p->gate && p->hidden > 0, "gca: incomplete finalisation parameters");
+    IMAGEN_CHECK(p->b1 && p->w2t && p->b2 && p->gate && p->hidden > 0, "gca: incomplete finalisation parameters");
+    IMAGEN_CHECK(p->chunks == 1 || p->counter, "gca: in-kernel finalisation over %d chunks needs the ticket counter", p->chunks);
     IMAGEN_CHECK(p->C + p->hidden + p->chunks + kGcaScratchFloats <= 2048, "gca: finalisation scratch too large (C %d hidden %d chunks %d)", p->C,
                  p->hidden, p->chunks);
   }

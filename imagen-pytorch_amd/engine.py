@@ -365,7 +365,7 @@ class UnetEngine:
         op2 = ops.igemm(plan, h1, W.conv(name + ".block2", rb.block2.project), h2, ssq_a=s1, pa=pa2, ps=ps2, pstride=self.total_c,
                         act_in=ACT_SILU, label=name + ".block2")
         if rb.gca is not None:   # one launch: chunk partials + last-workgroup finalisation (measured faster than a conv-epilogue fusion)
-            chunks = ops.gca_chunks(H * Wd, R)
+            chunks = ops.gca_chunks(H * Wd, R, Cout)
             part = self.f32buf(R, chunks, Cout + 2)
             ops.gca(plan, h2, gca_args["wk"], gca_args["bk"], gca_args["w1t"], gca_args["b1"], gca_args["w2t"], gca_args["b2"], part, gate,
                     chunks, label=name + ".gca")
@@ -403,8 +403,6 @@ class UnetEngine:
         q = self.new(R, 1, N, inner)
         wq = W.conv(name + ".to_q", ca.to_q)
         ops.igemm(plan, tok, wq, q, mu=mu, rs=rs, pa=W.f32(name + ".norm.g", lambda: _pad_vec(ca.norm.g, wq.Cin_pad)), label=name + ".to_q")
-        ops.qnorm(plan, q.t, W.f32(name + ".q_scale", lambda: ca.q_scale), rows=R * N, heads=heads, ld=inner, mult=SIM_SCALE * LOG2E,
-                  label=name + ".qnorm")
         J = self.NT + 1
         Jp = ops._round_up(J, 32)
         khat = torch.zeros(R, heads, Jp, dh, dtype=torch.float16, device=self.dev)
@@ -414,7 +412,8 @@ class UnetEngine:
         self.attn_sites.append(site)
         o = self.new(R, 1, N, inner)
         ops.attention(plan, q.t, khat, vt, o.t, B=R, heads=heads, rows=N, J=J, q_strides=(N * inner, dh, inner),
-                      k_strides=site["k_strides"], vt_strides=site["vt_strides"], o_strides=(N * inner, dh, inner), label=name + ".attn")
+                      k_strides=site["k_strides"], vt_strides=site["vt_strides"], o_strides=(N * inner, dh, inner),
+                      q_scale=W.f32(name + ".q_scale", lambda: ca.q_scale), q_mult=SIM_SCALE * LOG2E, label=name + ".attn")
         y = self.new(R, 1, N, C)
         ops.igemm(plan, o, W.conv(name + ".to_out", ca.to_out[0]), y, label=name + ".to_out")
         out = self.new(R, h.H, h.W, C)
@@ -441,8 +440,6 @@ class UnetEngine:
             ops.igemm(plan, tok, wqkv, qkv, mu=mu, rs=rs, pa=W.f32(nm + ".norm.g", lambda: _pad_vec(attn.norm.g, wqkv.Cin_pad)),
                       label=nm + ".qkv")
             ld = inner + 2 * dh
-            ops.qnorm(plan, qkv.t, W.f32(nm + ".q_scale", lambda: attn.q_scale), rows=R * N, heads=heads, ld=ld, mult=SIM_SCALE * LOG2E,
-                      label=nm + ".qnorm")
             n_ctx = self.NT if (with_context and attn.to_context is not None) else 0
             J = n_ctx + 1 + N
             Jp = ops._round_up(J, 32)
@@ -456,7 +453,8 @@ class UnetEngine:
                         label=nm + ".kv_self")
             o = self.new(R, 1, N, inner)
             ops.attention(plan, qkv.t, khat, vt, o.t, B=R, heads=heads, rows=N, J=J, q_strides=(N * ld, dh, ld), k_strides=k_strides,
-                          vt_strides=vt_strides, o_strides=(N * inner, dh, inner), label=nm + ".attn")
+                          vt_strides=vt_strides, o_strides=(N * inner, dh, inner), q_scale=W.f32(nm + ".q_scale", lambda: attn.q_scale),
+                          q_mult=SIM_SCALE * LOG2E, label=nm + ".attn")
             y = self.new(R, 1, N, C)
             ops.igemm(plan, o, W.conv(nm + ".to_out", attn.to_out[0]), y, label=nm + ".to_out")
             x1 = self.new(R, 1, N, C)
@@ -708,8 +706,6 @@ class UnetEngine:
                       label=nm_ + ".kv_lat")
             q = self.new(R, 1, NL, inner)
             ops.igemm(plan, lat, W.conv(nm_ + ".to_q", pa.to_q), q, mu=mul, rs=rsl, pa=lnw, ps=lnb, label=nm_ + ".to_q")
-            ops.qnorm(plan, q.t, W.f32(nm_ + ".q_scale", lambda pa=pa: pa.q_scale), rows=R * NL, heads=heads, ld=inner, mult=SIM_SCALE * LOG2E,
-                      label=nm_ + ".qnorm")
             khat = torch.zeros(R, heads, Jp, dh, dtype=torch.float16, device=self.dev)
             vt = torch.zeros(R, heads, dh, Jp, dtype=torch.float16, device=self.dev)
             ks, vs = (heads * Jp * dh, Jp * dh, dh), (heads * dh * Jp, dh * Jp, Jp)
@@ -717,7 +713,8 @@ class UnetEngine:
                         src_strides=(Jk * 2 * inner, 2 * inner, dh), k_strides=ks, vt_strides=vs, k_off=0, v_off=inner, label=nm_ + ".kv_prep")
             o = self.new(R, 1, NL, inner)
             ops.attention(plan, q.t, khat, vt, o.t, B=R, heads=heads, rows=NL, J=Jk, q_strides=(NL * inner, dh, inner), k_strides=ks,
-                          vt_strides=vs, o_strides=(NL * inner, dh, inner), label=nm_ + ".attn")
+                          vt_strides=vs, o_strides=(NL * inner, dh, inner), q_scale=W.f32(nm_ + ".q_scale", lambda pa=pa: pa.q_scale),
+                          q_mult=SIM_SCALE * LOG2E, label=nm_ + ".attn")
             y = self.new(R, 1, NL, cd)
             ops.igemm(plan, o, W.conv(nm_ + ".to_out", pa.to_out[0]), y, label=nm_ + ".to_out")
             lat2 = self.new(R, 1, NL, cd)

@@ -378,15 +378,17 @@ def rowstat(plan: Plan, x1: Act, *, mode: int, rs: torch.Tensor, mu: Optional[to
 
 
 def attention(plan: Plan, q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, o: torch.Tensor, *, B, heads, rows, J,
-              q_strides, k_strides, vt_strides, o_strides, label: str = ""):
+              q_strides, k_strides, vt_strides, o_strides, q_scale: Optional[torch.Tensor] = None, q_mult: float = 0.0, label: str = ""):
+    """q_scale / q_mult: fuse QNORM into the q load (q rows raw); None: q was normalised by a QNORM op."""
     p = STRUCTS["ImagenAttentionParams"]()
     p.q, p.k, p.vt, p.o = q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr()
+    p.q_scale, p.q_mult = ptr(q_scale), q_mult
     p.B, p.heads, p.rows, p.J = B, heads, rows, J
     p.q_bs, p.q_hs, p.q_rs = q_strides
     p.k_bs, p.k_hs, p.k_rs = k_strides
     p.vt_bs, p.vt_hs, p.vt_ds = vt_strides
     p.o_bs, p.o_hs, p.o_rs = o_strides
-    plan.add(p, label or "attention", [q, k, vt, o])
+    plan.add(p, label or "attention", [q, k, vt, o, q_scale])
     return p
 
 
@@ -423,13 +425,16 @@ def gca(plan: Plan, h: Act, wk, bk: float, w1t, b1, w2t, b2, part: torch.Tensor,
     p.h, p.wk, p.part = h.ptr, wk.data_ptr(), part.data_ptr()
     p.B, p.HW, p.C, p.ld, p.chunks, p.bk = h.B, h.H * h.W, C, h.ld, chunks, bk
     groups = C // 8
-    single = GCA_SINGLE_LAUNCH and (groups & (groups - 1)) == 0 and groups <= 64 and C + hidden + chunks + GCA_SCRATCH <= 2048
+    single = ((GCA_SINGLE_LAUNCH or chunks == 1) and (groups & (groups - 1)) == 0 and groups <= 64
+              and C + hidden + chunks + GCA_SCRATCH <= 2048)
     keep = [h.t, wk, part]
     if single:
-        counter = torch.zeros(h.B, dtype=torch.int32, device=h.t.device)   # self-resetting ticket
-        p.counter, p.w1t, p.b1, p.w2t, p.b2, p.gate, p.hidden = (counter.data_ptr(), w1t.data_ptr(), b1.data_ptr(), w2t.data_ptr(),
-                                                                 b2.data_ptr(), gate.data_ptr(), hidden)
-        keep += [counter, w1t, b1, w2t, b2, gate]
+        p.w1t, p.b1, p.w2t, p.b2, p.gate, p.hidden = w1t.data_ptr(), b1.data_ptr(), w2t.data_ptr(), b2.data_ptr(), gate.data_ptr(), hidden
+        keep += [w1t, b1, w2t, b2, gate]
+        if chunks > 1:
+            counter = torch.zeros(h.B, dtype=torch.int32, device=h.t.device)   # self-resetting ticket
+            p.counter = counter.data_ptr()
+            keep.append(counter)
     plan.add(p, (label or "gca") + (".fused" if single else ".partial"), keep)
     if single:
         return
@@ -442,9 +447,13 @@ def gca(plan: Plan, h: Act, wk, bk: float, w1t, b1, w2t, b2, part: torch.Tensor,
 GCA_SCRATCH = 1024   # csrc/gca_device.h kGcaScratchFloats
 
 
-def gca_chunks(HW: int, B: int = 16) -> int:
+def gca_chunks(HW: int, B: int = 16, C: int = 0) -> int:
     """Pixel chunks per image for the stand-alone GlobalContext kernel: about 1024 workgroups over the batch (the 256 CUs
-    stay busy even on the 32x32 maps), chunks of at least 64 pixels (the merge cost grows with the chunk count)."""
+    stay busy even on the 32x32 maps), chunks of at least 64 pixels (the merge cost grows with the chunk count).  Small maps
+    (HW * C <= 128 Ki elements, i.e. <= 256 KiB per image) take ONE chunk: the workgroup then finalises the gate itself and
+    the second launch disappears."""
+    if 0 < HW * C <= 131072:
+        return 1
     target = max(1, 1024 // max(B, 1))
     chunk_px = max(64, math.ceil(HW / target))
     return max(1, math.ceil(HW / chunk_px))

@@ -137,6 +137,8 @@ typedef struct ImagenAttentionParams {
   int32_t k_bs, k_hs, k_rs;
   int32_t vt_bs, vt_hs, vt_ds;
   int32_t o_bs, o_hs, o_rs;
+  /* optional fused QNORM: q rows arrive raw and are l2-normalised * q_scale[64] * q_mult while they are loaded */
+  const float* q_scale; float q_mult;
 } ImagenAttentionParams;
 
 /* KV_PREP — k/v rows -> attention operand buffers (null_kv, context kv, self kv; ip.py:545-561, 805-814).
