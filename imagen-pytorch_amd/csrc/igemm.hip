@@ -87,8 +87,8 @@ template <int G> struct Geo {
 // (own L2) gets a contiguous range of tiles and neighbouring halos meet in the same L2.
 struct TileCoord { int b, oy0, ox0, n0; };
 
-__device__ __attribute__((aligned(16))) const float kOnes8[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
-__device__ __attribute__((aligned(16))) const float kZeros8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+__device__ __attribute__((aligned(16))) float kOnes8[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
+__device__ __attribute__((aligned(16))) float kZeros8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
 // LDS hand-over between the roles: LDS traffic of this wave retired, then the workgroup barrier.  Deliberately NOT
 // __syncthreads(): global loads stay in flight across it.
@@ -152,7 +152,7 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
   const int KG = ntap * G;            // 8-channel groups per chunk
   const int KS = KSC > 0 ? KSC : (KG + 1) >> 1;  // K=16 MFMA steps per chunk (odd KG: last half-step is zero weights)
   const int NC = p.Cin_pad / KC;      // chunks
-  const bool ssq_sync = p.ssq_out != nullptr && WN > 1;   // the epilogue's cross-wave reduction needs one extra workgroup barrier per tile
+  const bool ssq_sync = (p.ssq_out != nullptr || p.post_pa != nullptr) && WN > 1;   // the epilogue's cross-wave reduction needs one extra workgroup barrier per tile
 
   if (producer) {
     // =========================================================================================== producers (waves 4-7)
@@ -172,15 +172,12 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
     // per-chunk prologue affine of THIS thread's 8-channel group: every item of a thread has the same group (256 % G == 0) and
     // the tile lies in one batch row, so the 8 + 8 floats are loaded once per phase
     const int my_cg = rtid & (G - 1);
-    // tile-independent geometry of this thread's staging items: pixel (iy, ix) inside the halo tile
-    int it_yx[kMaxItems];   // (iy << 16) | ix
-    static_for<kMaxItems>([&](auto ic) __attribute__((always_inline)) {
-      constexpr int it = decltype(ic)::value;
-      const int idx = rtid + it * 256;
-      const int pix = idx >> LOG2G;
-      const int iy = (int)(((float)pix + 0.5f) * inv_itw);
-      it_yx[it] = ((idx < items ? iy : 0x4000) << 16) | (pix - iy * ITW);   // slots beyond the tile never pass the bounds test
-    });
+    // tile-independent geometry of this thread's staging items: item `it` is halo pixel pix0 + it * (256 / G); its (iy, ix) is
+    // walked incrementally from item 0's (two registers instead of one per item — the two staging sets need the rest)
+    const int pix0 = rtid >> LOG2G;
+    const int iy_first = (int)(((float)pix0 + 0.5f) * inv_itw);
+    const int ix_first = pix0 - iy_first * ITW;
+    const int step_y = (256 >> LOG2G) / ITW, step_x = (256 >> LOG2G) % ITW;
     const float* q1_base = p.rs ? p.rs : (p.ssq_a ? p.ssq_a : dummy_f);            // rs | ssq_a
     const int q1_on = (p.rs || p.ssq_a) ? 1 : 0;
     const float* q2_base = p.mu ? p.mu : ((!p.rs && p.ssq_b) ? p.ssq_b : dummy_f);  // mu | ssq_b
@@ -188,6 +185,7 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
     const float* pa_base = p.pa ? p.pa : kOnes8;    // absent affine: neutral constants instead of per-element selects
     const float* ps_base = p.ps ? p.ps : kZeros8;
     const int pa_on = p.pa ? 1 : 0, ps_on = p.ps ? 1 : 0;
+    const bool raw_copy = !p.pa && !p.ps && !p.rs && !p.ssq_a && !p.mu && p.act_in == IMAGEN_ACT_NONE;
 
     struct StageSet {
       uint4 raw[kMaxItems];
@@ -224,10 +222,14 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
       const f16* base = from1 ? x1 + (size_t)b * p.bs1 + cc : x2 + (size_t)b * p.bs2 + (cc - p.C1);
       const int ld = from1 ? ld1_s : ld2_s;
       const int sp0 = b * (p.H * p.W);
+      int iy = iy_first, ix = ix_first;
       static_for<kMaxItems>([&](auto ic) __attribute__((always_inline)) {
         constexpr int it = decltype(ic)::value;
-        const int gy = iy0 + (it_yx[it] >> 16), gx = ix0 + (it_yx[it] & 0xffff);
-        const bool ok = chan_ok && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        const int gy = iy0 + iy, gx = ix0 + ix;
+        const bool ok = chan_ok && iy < ITH && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;   // iy >= ITH: slot beyond the tile
+        ix += step_x;
+        iy += step_y;
+        if (ix >= ITW) { ix -= ITW; ++iy; }
         const int gp = ok ? gy * p.W + gx : 0;
         const f16* src = ok ? base + (size_t)gp * ld : x1;
         S.raw[it] = *reinterpret_cast<const uint4*>(src);
@@ -249,6 +251,17 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
 
     // transform + LDS write of a staged set
     auto write_set = [&](const StageSet& S, char* buf) __attribute__((always_inline)) {
+      if (raw_copy) {   // input already activated by its producer (post_pa epilogue) or a plain GEMM operand: zero-fill only
+        static_for<kMaxItems>([&](auto ic) __attribute__((always_inline)) {
+          constexpr int it = decltype(ic)::value;
+          const int idx = rtid + it * 256;
+          if (idx < items) {
+            const uint4 v = (S.mask & (1u << it)) ? S.raw[it] : make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(buf + (idx >> LOG2G) * PS + my_cg * 16) = v;
+          }
+        });
+        return;
+      }
       const float a[8] = {st_a0.x, st_a0.y, st_a0.z, st_a0.w, st_a1.x, st_a1.y, st_a1.z, st_a1.w};
       const float s[8] = {st_s0.x, st_s0.y, st_s0.z, st_s0.w, st_s1.x, st_s1.y, st_s1.z, st_s1.w};
       static_for<kMaxItems>([&](auto ic) __attribute__((always_inline)) {
@@ -292,27 +305,29 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
         if (ssq_sync) lds_barrier();   // pairs with the consumers' epilogue reduction
       }
     };
+    // (the cursor is advanced AFTER the transform: the scalar control flow of advance()/decode() between a set's loads and the
+    // other set's first use makes the compiler's vmcnt bookkeeping fall back to a full drain)
     load_set(A);            // phase 0
     load_affine(A);
     advance();
     load_set(B);            // phase 1
-    advance();
     write_set(A, buf0);     // waits for A and the affine; B stays in flight
     load_affine(B);
+    advance();
     lds_barrier();          // phase 0 is in buffer 0
     for (int q = 0; q < n_phases; q += 2) {
       // consumers: phase q out of buf0
       load_set(A);          // phase q+2
-      advance();
       write_set(B, buf1);   // phase q+1
       load_affine(A);
+      advance();
       phase_end();
       if (q + 1 >= n_phases) break;
       // consumers: phase q+1 out of buf1
       load_set(B);          // phase q+3
-      advance();
       write_set(A, buf0);   // phase q+2
       load_affine(B);
+      advance();
       phase_end();
     }
     return;
@@ -433,6 +448,74 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
   const f16* res = reinterpret_cast<const f16*>(p.res);
   auto epilogue = [&](const TileCoord& tc) __attribute__((always_inline)) {
     const int b = tc.b, n0 = tc.n0;
+    if (p.post_pa) {
+      // ---- output-side Block prologue: two passes over the accumulators (norm over all Cout of the pixel, then activate + store)
+      float tot[MI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) tot[mi] = 0.0f;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
+          if (co >= p.Cout) continue;
+          float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
+          if (p.bias) bq = *reinterpret_cast<const float4*>(p.bias + co);
+          const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const float v = acc[ni][mi][4 * q + e] + bb[e];
+              acc[ni][mi][4 * q + e] = v;   // keep h for the second pass
+              tot[mi] += v * v;
+            }
+        }
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) tot[mi] += __shfl_xor(tot[mi], 32);
+      if (WN > 1) {
+        if (half == 0) {
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) ep_red[(wm * WN + wn) * PXW + mi * 32 + l31] = tot[mi];
+        }
+        lds_barrier();   // whole workgroup (the producers execute the matching barrier)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          float t = 0.0f;
+#pragma unroll
+          for (int w = 0; w < WN; ++w) t += ep_red[(wm * WN + w) * PXW + mi * 32 + l31];
+          tot[mi] = t;
+        }
+      }
+      float rsn[MI];
+      int opx[MI];
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        rsn[mi] = __builtin_amdgcn_rsqf(fmaxf(tot[mi], 1e-24f));
+        const int oy = tc.oy0 + pix_y[mi], ox = tc.ox0 + pix_x[mi];
+        opx[mi] = (oy < p.OH && ox < p.OW) ? oy * p.OW + ox : -1;
+      }
+      f16* y = reinterpret_cast<f16*>(p.y);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
+          if (co >= p.Cout) continue;
+          const float4 pa = *reinterpret_cast<const float4*>(p.post_pa + (size_t)b * p.post_pstride + co);
+          const float4 ps = *reinterpret_cast<const float4*>(p.post_ps + (size_t)b * p.post_pstride + co);
+          const float pav[4] = {pa.x, pa.y, pa.z, pa.w}, psv[4] = {ps.x, ps.y, ps.z, ps.w};
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            if (opx[mi] < 0) continue;
+            f16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o[e] = (f16)silu_f(acc[ni][mi][4 * q + e] * rsn[mi] * pav[e] + psv[e]);
+            if (!(p.dbg & 8)) *reinterpret_cast<f16x4*>(y + (size_t)b * p.bsy + (size_t)opx[mi] * p.ldy + co) = o;
+          }
+        }
+      return;
+    }
     float ssq_px[MI];  // per-pixel sum of squares of this wave's stored channels (for the consumer's ChanRMSNorm)
     int op[MI];        // output pixel index, -1: outside the image
 #pragma unroll
@@ -590,6 +673,9 @@ int launch_ksc(const ImagenIgemmParams& p, hipStream_t s) {
                "igemm: channel counts / strides must be multiples of 8 (C1=%d C2=%d ld1=%d ld2=%d)", p.C1, p.C2, p.ld1, p.ld2);
   IMAGEN_CHECK(p.out_mode == IMAGEN_OUT_NCHW_F32 || p.Cout % 4 == 0, "igemm: Cout %d must be a multiple of 4", p.Cout);
   IMAGEN_CHECK(p.out_mode != IMAGEN_OUT_PIXEL_SHUFFLE || p.Cout % 16 == 0, "igemm: pixel-shuffle needs Cout %% 16 == 0");
+  IMAGEN_CHECK(!p.post_pa || (p.post_ps && p.out_mode == IMAGEN_OUT_NHWC && p.Cout <= BN && !p.addend && !p.res && !p.ssq_out &&
+                              p.act_out == IMAGEN_ACT_NONE && p.Cout % 4 == 0),
+               "igemm: post_pa needs post_ps, a plain NHWC output and one workgroup covering all %d output channels (tile has %d)", p.Cout, BN);
   IMAGEN_CHECK(!p.ssq_out || (p.out_mode == IMAGEN_OUT_NHWC && p.Cout <= BN),
                "igemm: ssq_out needs NHWC output and one workgroup covering all %d output channels (tile has %d)", p.Cout, BN);
   const size_t lds = (size_t)2 * IT * Geo<G>::PS + (size_t)4 * 32 * MI * sizeof(float);   // staging double buffer + epilogue scratch

@@ -19,6 +19,7 @@ without ever launching (host-logic tests).
 from __future__ import annotations
 
 import math
+import os
 from typing import Dict, List, Optional
 
 import torch
@@ -88,6 +89,9 @@ class Weights:
 
 def _fingerprint(unet) -> tuple:
     return tuple(p._version for p in unet.parameters()) + tuple(p.data_ptr() for p in unet.parameters())
+
+
+POST_NORM = int(os.environ.get("IMAGEN_POST_NORM", "1"))   # A/B switch: block2's prologue applied by block1's epilogue
 
 
 class UnetEngine:
@@ -337,20 +341,21 @@ class UnetEngine:
         w1 = W.conv(name + ".block1", rb.block1.project)
         pa1 = W.f32(name + ".block1.pa", lambda: _pad_vec(rb.block1.norm.gamma.detach().float().flatten().cpu() * math.sqrt(Cin)
                                                          * (in_scale if in_scale is not None else 1.0), w1.Cin_pad))
+        off = self._blk_off[self._blk_index[id(rb)]]
+        pa2 = self.pa2[:, off:]
+        ps2 = self.ps2[:, off:]
         h1 = self.new(R, H, Wd, Cout)
         h1.ssq = self.f32buf(R * H * Wd)
+        # without a cross-attention in between, block1's epilogue applies block2's ChanRMSNorm -> (scale+1, shift) -> SiLU itself
+        # (its consumer waves have the slack; block2's producers then stage h1 with no arithmetic at all)
+        post = dict(pa=pa2, ps=ps2, pstride=self.total_c) if (rb.cross_attn is None and POST_NORM) else None
         op = ops.igemm(plan, x, w1, h1, x2=skip, ssq_a=sx, ssq_b=ss, ssq_wb=s * s, pa=pa1, pstride=0, act_in=ACT_SILU, ssq_out=h1.ssq,
-                       label=name + ".block1")
+                       post=post, label=name + ".block1")
         if not op.ssq_emitted:
             h1.ssq = None
         if rb.cross_attn is not None:
             assert with_cond
             h1 = self._cross_attn(plan, h1, rb.cross_attn, name + ".cross_attn")
-        # block2: ChanRMSNorm -> (scale+1, shift) from the time MLP -> SiLU -> conv3x3
-        s1 = self._ssq_of(plan, h1, name + ".block2.stat")
-        off = self._blk_off[self._blk_index[id(rb)]]
-        pa2 = self.pa2[:, off:]
-        ps2 = self.ps2[:, off:]
         h2 = self.new(R, H, Wd, Cout)
         gate, gca_args = None, None
         if rb.gca is not None:
@@ -362,8 +367,12 @@ class UnetEngine:
                             b1=W.f32(name + ".gca.b1", lambda: g.net[0].bias),
                             w2t=W.f32(name + ".gca.w2t", lambda: g.net[2].weight.reshape(Cout, hidden).t()),
                             b2=W.f32(name + ".gca.b2", lambda: g.net[2].bias), gate=gate)
-        op2 = ops.igemm(plan, h1, W.conv(name + ".block2", rb.block2.project), h2, ssq_a=s1, pa=pa2, ps=ps2, pstride=self.total_c,
-                        act_in=ACT_SILU, label=name + ".block2")
+        if op.post_applied:     # h1 already holds silu(norm(h1) * (scale + 1) + shift)
+            ops.igemm(plan, h1, W.conv(name + ".block2", rb.block2.project), h2, label=name + ".block2")
+        else:                   # block2: ChanRMSNorm -> (scale+1, shift) from the time MLP -> SiLU -> conv3x3
+            s1 = self._ssq_of(plan, h1, name + ".block2.stat")
+            ops.igemm(plan, h1, W.conv(name + ".block2", rb.block2.project), h2, ssq_a=s1, pa=pa2, ps=ps2, pstride=self.total_c,
+                      act_in=ACT_SILU, label=name + ".block2")
         if rb.gca is not None:   # one launch: chunk partials + last-workgroup finalisation (measured faster than a conv-epilogue fusion)
             chunks = ops.gca_chunks(H * Wd, R, Cout)
             part = self.f32buf(R, chunks, Cout + 2)

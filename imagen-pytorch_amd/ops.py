@@ -296,7 +296,8 @@ def pick_cfg(G: int, Cout: int, OH: int, OW: int, B: int, KH: int = 1, KW: int =
 def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None, mu=None, rs=None, pa=None, ps=None,
           pstride: int = 0, act_in: int = ACT_NONE, act_out: int = ACT_NONE, addend: Optional[Act] = None, gate=None,
           res: Optional[Act] = None, out_mode: int = OUT_NHWC, stride: int = 1, pad: Optional[int] = None,
-          cfg: Optional[tuple] = None, ssq_a=None, ssq_b=None, ssq_wb: float = 1.0, ssq_out=None, label: str = ""):
+          cfg: Optional[tuple] = None, ssq_a=None, ssq_b=None, ssq_wb: float = 1.0, ssq_out=None, post: Optional[dict] = None,
+          label: str = ""):
     """... ssq_a / ssq_b: producers' per-pixel sums of squares of x1 / x2 (ChanRMSNorm statistics without a separate pass);
     ssq_out: emit the per-pixel sum of squares of the output — honoured only when the chosen tile covers all Cout
     (`p.ssq_emitted` tells the caller, who otherwise falls back to a ROWSTAT op)."""
@@ -310,7 +311,7 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
     C2 = x2.C if x2 is not None else 0
     assert x1.C + C2 == pw.Cin, f"{label}: input channels {x1.C}+{C2} != weight Cin {pw.Cin}"
     if cfg is None:
-        cfg = pick_cfg(pw.G, pw.Cout, OH, OW, x1.B, KH, KW, stride, full_cout=ssq_out is not None and out_mode == OUT_NHWC)
+        cfg = pick_cfg(pw.G, pw.Cout, OH, OW, x1.B, KH, KW, stride, full_cout=(ssq_out is not None or post is not None) and out_mode == OUT_NHWC)
     cid, th, tw = cfg
     p = STRUCTS["ImagenIgemmParams"]()
     p.x1, p.C1, p.ld1, p.bs1 = x1.ptr, x1.C, x1.ld, x1.bs
@@ -352,6 +353,15 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
     if ssq_a is not None:
         p.ssq_a, p.ssq_b, p.ssq_wb = ssq_a.data_ptr(), ptr(ssq_b), ssq_wb
         keep += [ssq_a, ssq_b]
+    # post: dict(pa, ps, pstride) — the NEXT Block's ChanRMSNorm -> scale/shift -> SiLU applied to this conv's output in the epilogue
+    # (`p.post_applied` tells the caller, who otherwise keeps the prologue on the consuming conv); excludes ssq_out
+    posted = False
+    if (post is not None and out_mode == OUT_NHWC and pw.Cout <= cfg_table()[cid][1] and addend is None and res is None
+            and act_out == ACT_NONE and pw.Cout % 4 == 0):
+        p.post_pa, p.post_ps, p.post_pstride = post["pa"].data_ptr(), post["ps"].data_ptr(), post["pstride"]
+        keep += [post["pa"], post["ps"]]
+        posted = True
+        ssq_out = None
     emitted = False
     if ssq_out is not None and out_mode == OUT_NHWC and pw.Cout <= cfg_table()[cid][1]:
         p.ssq_out = ssq_out.data_ptr()
@@ -359,6 +369,7 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
         emitted = True
     plan.add(p, label or "igemm", keep)
     p.ssq_emitted = emitted
+    p.post_applied = posted
     return p
 
 

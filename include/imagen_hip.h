@@ -93,6 +93,11 @@ typedef struct ImagenIgemmParams {
   const float* ssq_a;  /* optional per-input-pixel sum of squares of x1 (emitted by its producer): when set (and rs == NULL) */
   const float* ssq_b;  /*   rs = 1/max(sqrt(ssq_a + ssq_wb*ssq_b), 1e-12) — ChanRMSNorm statistics without a separate pass   */
   float* ssq_out;      /* optional per-output-pixel sum of squares of the stored fp16 output (NHWC mode, Cout <= tile couts) */
+  /* optional output-side Block prologue (NHWC mode, Cout <= tile couts, no addend / residual / act_out): the stored tensor is
+   * silu(h / max(||h||, 1e-12) * post_pa[b, c] + post_ps[b, c]) with h = acc + bias and the norm over all Cout channels of the
+   * pixel (ChanRMSNorm -> scale/shift -> SiLU of the NEXT Block, ip.py:671-691, applied by the producer so that the consuming
+   * conv stages its input with no arithmetic at all) */
+  const float* post_pa; const float* post_ps;
   int32_t B, H, W;     /* input batch / spatial dims */
   int32_t C1, ld1, bs1; /* channels, pixel stride, batch stride (elements) of x1 */
   int32_t C2, ld2, bs2;
@@ -101,6 +106,7 @@ typedef struct ImagenIgemmParams {
   int32_t Cin_pad;     /* C1+C2 rounded up to the k-chunk (8*G) */
   int32_t Cout, Cout_pad; /* Cout_pad = multiple of 32*NI*WN of the chosen tile */
   int32_t pstride;     /* batch stride of pa/ps in floats (0 = shared) */
+  int32_t post_pstride; /* batch stride of post_pa / post_ps in floats */
   int32_t act_in, act_out;
   int32_t ld_add, bs_add, ld_res, bs_res;
   int32_t gate_stride;

@@ -130,3 +130,35 @@ def test_global_context_of_conv_output(B, S, C, single, monkeypatch):
         torch.cuda.synchronize()
         assert nerr(gate, ref) < 1e-3, nerr(gate, ref)
     assert nerr(ops.act_to_nchw(y), h) < 1e-3
+
+
+@pytest.mark.parametrize("B,S,C1,C", [(2, 32, 32, 32), (2, 16, 64, 64), (3, 8, 96, 128), (1, 24, 32, 64)])
+def test_post_norm_epilogue_feeds_plain_conv(B, S, C1, C):
+    """Block chaining (ip.py:671-691): conv1's epilogue applies the NEXT Block's ChanRMSNorm -> (scale+1, shift) -> SiLU to its own
+    output (post_pa / post_ps), conv2 then stages that tensor with no prologue; vs fp32 torch with the norm on conv1's fp32 output."""
+    from imagen_pytorch_amd import ops
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(5)
+    x = torch.randn(B, C1, S, S).half().float()
+    w1 = (torch.randn(C, C1, 3, 3) / math.sqrt(9 * C1)).half().float()
+    b1 = torch.randn(C) * 0.1
+    w2 = (torch.randn(C, C, 3, 3) / math.sqrt(9 * C)).half().float()
+    b2 = torch.randn(C) * 0.1
+    gamma = 1 + 0.1 * torch.randn(C)
+    scale, shift = 0.2 * torch.randn(B, C), 0.2 * torch.randn(B, C)
+    h = F.conv2d(x, w1, b1, padding=1)
+    a = F.silu(F.normalize(h, dim=1) * math.sqrt(C) * gamma.view(1, C, 1, 1) * (scale.view(B, C, 1, 1) + 1) + shift.view(B, C, 1, 1))
+    ref = F.conv2d(a, w2, b2, padding=1)
+    pa = ((gamma * math.sqrt(C)).view(1, C) * (scale + 1)).contiguous().to(dev)
+    ps = shift.contiguous().to(dev)
+    h1 = ops.new_act(B, S, S, C, dev)
+    y = ops.new_act(B, S, S, C, dev)
+    plan = ops.Plan()
+    op = ops.igemm(plan, ops.act_from_nchw(x.to(dev)), ops.pack_weight(w1, b1, dev), h1, post=dict(pa=pa, ps=ps, pstride=C))
+    assert op.post_applied
+    ops.igemm(plan, h1, ops.pack_weight(w2, b2, dev), y)
+    plan.run()
+    torch.cuda.synchronize()
+    assert nerr(ops.act_to_nchw(h1), a) < 1e-3, nerr(ops.act_to_nchw(h1), a)
+    assert nerr(ops.act_to_nchw(y), ref) < 1e-3, nerr(ops.act_to_nchw(y), ref)
