@@ -22,6 +22,8 @@ struct TileCfg { int MI, NI, WM, WN, G; };
 // 16-byte staging items per producer thread and phase, by tile pixels / k-chunk depth / kernel footprint: the producers hold
 // TWO such register sets, so the count is kept as small as the instantiation's use allows (the host asks
 // imagen_igemm_stage_slots() and only picks tile shapes that fit)
+constexpr int kBiasLds = 1024;   // output channels whose bias the consumers keep in LDS (larger layers load it per channel quad)
+
 constexpr int stage_slots(int TP, int G, int KSC) {
   if (KSC == 18 && G == 4) return TP == 64 ? 2 : TP == 128 ? 3 : 6;   // 3x3: 10x10 | 10x18 | 18x18 halo tiles
   if (KSC == 2 && G == 4) return TP / 64;                             // 1x1
@@ -370,14 +372,13 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
   // wq[j] holds the fragments of K=16 step (gstep + j); w_ofs is the offset (in fragments) of step (gstep + kLookAhead)
   // look-ahead depth of the weight ring: a wave consumes one fragment per MI MFMAs, so the single-MFMA-per-step tilings (small
   // feature maps: few workgroups, each streaming its whole weight slice) need a deeper ring to cover the L2 round trip
-  constexpr int kWantAhead = (MI * NI == 1) ? 12 : 6;
+  constexpr int kWantAhead = (MI * NI == 1) ? 12 : (MI * NI == 2 ? 10 : 6);
   constexpr int kLookAhead = KSC == 0 ? 1 : (KSC >= kWantAhead ? kWantAhead : KSC);
   f16x8 wq[kLookAhead][NI];
   int w_ofs = 0;
 
-  // wrap_n0 >= 0: this is the last chunk of the tile — kLookAhead steps before its end the weight prefetch jumps to the first
-  // steps of the next tile (output-channel offset wrap_n0)
-  auto compute = [&](const char* buf, int wrap_n0) __attribute__((always_inline)) {
+  // (the ring runs kLookAhead steps past the tile's last step: the packed buffer carries a zero tail for that)
+  auto compute = [&](const char* buf) __attribute__((always_inline)) {
     // (dy, dx, group) walk of this lane's 8-channel group: kg = 2*ks + half
     int dy = 0, dx = 0, cgp = 0;  // G >= 2: uniform walk, group = 2*cgp + half
     int tap_l = half;             // G == 1: per-lane tap walk (tap = 2*ks + half), kept as (ty_l, tx_l) incrementally
@@ -408,7 +409,6 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
     }
     auto do_step = [&](int ks) __attribute__((always_inline)) {
       // prefetch the weight fragments kLookAhead steps ahead (L2 latency ~ 2-3 MFMA groups); uniform wrap at the tile end
-      if (ks == KS - kLookAhead && wrap_n0 >= 0) w_ofs = wrap_n0;
       f16x8 wnew[NI];
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) wnew[ni] = wlane[w_ofs + ni * 32];
@@ -446,7 +446,26 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
   // ---- epilogue of one finished tile: lane = pixel; register quad q holds couts 8q + 4*half + {0..3} of each 32-cout fragment
   const f16* addend = reinterpret_cast<const f16*>(p.addend);
   const f16* res = reinterpret_cast<const f16*>(p.res);
-  auto epilogue = [&](const TileCoord& tc) __attribute__((always_inline)) {
+  // Under load a dependent global load costs ~2k cycles (measured with s_memtime stamps: the 18-step k-loop of a tile took 5k
+  // cycles, four bias-load -> use -> store rounds of the old epilogue 14k), so the bias is staged in LDS once per workgroup:
+  // the epilogue of a plain conv then contains no global load at all.
+  float* ep_bias = ep_red + 4 * PXW;   // [kBiasLds] floats
+  const bool bias_lds = p.bias != nullptr && p.Cout_pad <= kBiasLds;
+  if (bias_lds)
+    for (int i = rtid; i < p.Cout_pad; i += 256) ep_bias[i] = p.bias[i];   // visible after the phase-0 barrier below
+  // The weight ring is dead during the arithmetic of the epilogue (its registers go to the packed outputs) and is re-primed
+  // with the NEXT tile's first steps right before the stores: those loads are older than the stores, so the next tile's first
+  // weight wait does not cover a store either.
+  auto prime_weights = [&](int n0) __attribute__((always_inline)) {
+    w_ofs = n0;
+#pragma unroll
+    for (int j = 0; j < kLookAhead; ++j) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wq[j][ni] = wlane[w_ofs + ni * 32];
+      w_ofs += wstep;
+    }
+  };
+  auto epilogue = [&](const TileCoord& tc, int n0_next) __attribute__((always_inline)) {
     const int b = tc.b, n0 = tc.n0;
     if (p.post_pa) {
       // ---- output-side Block prologue: two passes over the accumulators (norm over all Cout of the pixel, then activate + store)
@@ -460,7 +479,8 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
           const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
           if (co >= p.Cout) continue;
           float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
-          if (p.bias) bq = *reinterpret_cast<const float4*>(p.bias + co);
+          if (bias_lds) bq = *reinterpret_cast<const float4*>(ep_bias + co);
+          else if (p.bias) bq = *reinterpret_cast<const float4*>(p.bias + co);
           const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
@@ -496,6 +516,7 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
         opx[mi] = (oy < p.OH && ox < p.OW) ? oy * p.OW + ox : -1;
       }
       f16* y = reinterpret_cast<f16*>(p.y);
+      f16x4 pout[NI][4][MI];
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -511,13 +532,26 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
             f16x4 o;
 #pragma unroll
             for (int e = 0; e < 4; ++e) o[e] = (f16)silu_f(acc[ni][mi][4 * q + e] * rsn[mi] * pav[e] + psv[e]);
-            if (!(p.dbg & 8)) *reinterpret_cast<f16x4*>(y + (size_t)b * p.bsy + (size_t)opx[mi] * p.ldy + co) = o;
+            pout[ni][q][mi] = o;
           }
+        }
+      // stores only after the last load (see the note at the store loop of the plain path below)
+      prime_weights(n0_next);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
+          if (co >= p.Cout) continue;
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            if (opx[mi] >= 0 && !(p.dbg & 8)) *reinterpret_cast<f16x4*>(y + (size_t)b * p.bsy + (size_t)opx[mi] * p.ldy + co) = pout[ni][q][mi];
         }
       return;
     }
     float ssq_px[MI];  // per-pixel sum of squares of this wave's stored channels (for the consumer's ChanRMSNorm)
     int op[MI];        // output pixel index, -1: outside the image
+    f16x4 outv[NI][4][MI];   // packed outputs (they take over the accumulators' registers as those die)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       ssq_px[mi] = 0.0f;
@@ -530,10 +564,13 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
     for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
+        __builtin_amdgcn_sched_barrier(0);   // one channel quad at a time: with the stores deferred nothing else stops the scheduler from
+                                             // hoisting every quad's loads to the top (48 more live registers)
         const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
         if (co >= p.Cout) continue;
         float4 bq = make_float4(0.f, 0.f, 0.f, 0.f), gq = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (p.bias) bq = *reinterpret_cast<const float4*>(p.bias + co);   // bias is padded to Cout_pad by the host
+        if (bias_lds) bq = *reinterpret_cast<const float4*>(ep_bias + co);
+          else if (p.bias) bq = *reinterpret_cast<const float4*>(p.bias + co);   // bias is padded to Cout_pad by the host
         if (addend) gq = *reinterpret_cast<const float4*>(p.gate + (size_t)b * p.gate_stride + co);
         f16x4 adq[MI], rrq[MI];
 #pragma unroll
@@ -576,19 +613,37 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
             const float r = (float)o[e];  // statistics of the value the consumer will read back
             ssq_px[mi] += r * r;
           }
-          f16* y = reinterpret_cast<f16*>(p.y);
-          if (p.out_mode == IMAGEN_OUT_PIXEL_SHUFFLE) {
-            // output channels are packed (s1, s2, c): cout = (2*s1 + s2) * Cq + c   (PixelShuffle(2), ip.py:616)
-            const int Cq = p.Cout >> 2;
-            const int sub = co / Cq, c = co - sub * Cq;
-            const int oy = tc.oy0 + pix_y[mi], ox = tc.ox0 + pix_x[mi];
-            const int yy = 2 * oy + (sub >> 1), xx = 2 * ox + (sub & 1);
-            *reinterpret_cast<f16x4*>(y + (size_t)b * p.bsy + ((size_t)yy * (2 * p.OW) + xx) * p.ldy + c) = o;
-          } else {
-            if (!(p.dbg & 8)) *reinterpret_cast<f16x4*>(y + (size_t)b * p.bsy + (size_t)op[mi] * p.ldy + co) = o;   // dbg 8: ablate the stores
-          }
+          outv[ni][q][mi] = o;   // stored below, after the last load of this epilogue
         }
       }
+    }
+    // all stores together: vmcnt retires in issue order and counts stores, so a wait on a load issued AFTER a store also waits
+    // for that store's acknowledgement (~1.5k cycles under load; a load -> use -> store loop per channel quad was measured at
+    // 14k cycles per tile).  With every store behind the last load, no wait in the epilogue covers one.
+    prime_weights(n0_next);
+    if (p.out_mode != IMAGEN_OUT_NCHW_F32) {
+      f16* y = reinterpret_cast<f16*>(p.y);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
+          if (co >= p.Cout) continue;
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            if (op[mi] < 0) continue;
+            if (p.out_mode == IMAGEN_OUT_PIXEL_SHUFFLE) {
+              // output channels are packed (s1, s2, c): cout = (2*s1 + s2) * Cq + c   (PixelShuffle(2), ip.py:616)
+              const int Cq = p.Cout >> 2;
+              const int sub = co / Cq, c = co - sub * Cq;
+              const int oy = tc.oy0 + pix_y[mi], ox = tc.ox0 + pix_x[mi];
+              const int yy = 2 * oy + (sub >> 1), xx = 2 * ox + (sub & 1);
+              *reinterpret_cast<f16x4*>(y + (size_t)b * p.bsy + ((size_t)yy * (2 * p.OW) + xx) * p.ldy + c) = outv[ni][q][mi];
+            } else {
+              if (!(p.dbg & 8)) *reinterpret_cast<f16x4*>(y + (size_t)b * p.bsy + (size_t)op[mi] * p.ldy + co) = outv[ni][q][mi];   // dbg 8: ablate the stores
+            }
+          }
+        }
     }
     // optional: emit the per-pixel sum of squares (launcher guarantees one workgroup covers all Cout: tilesN == 1)
     if (p.ssq_out) {
@@ -624,24 +679,18 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
 
   // ---- main loop: tiles x chunks, one hand-over barrier per phase
   TileCoord tc = decode(t_cursor);
-  w_ofs = tc.n0;
-#pragma unroll
-  for (int j = 0; j < kLookAhead; ++j) {
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni) wq[j][ni] = wlane[w_ofs + ni * 32];
-    w_ofs += wstep;
-  }
+  prime_weights(tc.n0);
   lds_barrier();   // phase 0 staged
   int cur = 0;
   while (true) {
     const int t_next = t_cursor + t_step;
     const int n0_next = t_next < t_end ? decode(t_next).n0 : tc.n0;
     for (int chunk = 0; chunk < NC; ++chunk) {
-      if (!(p.dbg & 2)) compute(smem + cur * buf_bytes, chunk == NC - 1 ? n0_next : -1);
+      if (!(p.dbg & 2)) compute(smem + cur * buf_bytes);
       lds_barrier();   // done with buf[cur]; the producers have filled buf[cur^1]
       cur ^= 1;
     }
-    epilogue(tc);
+    epilogue(tc, n0_next);
     if (t_next >= t_end) break;
     zero_acc();
     t_cursor = t_next;
@@ -678,7 +727,7 @@ int launch_ksc(const ImagenIgemmParams& p, hipStream_t s) {
                "igemm: post_pa needs post_ps, a plain NHWC output and one workgroup covering all %d output channels (tile has %d)", p.Cout, BN);
   IMAGEN_CHECK(!p.ssq_out || (p.out_mode == IMAGEN_OUT_NHWC && p.Cout <= BN),
                "igemm: ssq_out needs NHWC output and one workgroup covering all %d output channels (tile has %d)", p.Cout, BN);
-  const size_t lds = (size_t)2 * IT * Geo<G>::PS + (size_t)4 * 32 * MI * sizeof(float);   // staging double buffer + epilogue scratch
+  const size_t lds = (size_t)2 * IT * Geo<G>::PS + (size_t)(4 * 32 * MI + kBiasLds) * sizeof(float);   // staging double buffer + epilogue scratch + bias
   IMAGEN_CHECK(lds <= 160 * 1024, "igemm: LDS tile %zu bytes too large", lds);
   auto kern = igemm_kernel<MI, NI, WM, WN, G, KSC>;
   static bool attr_done = false;
@@ -778,7 +827,7 @@ extern "C" int imagen_igemm_stage_slots(int cfg, int KH, int KW) {
 }
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
-constexpr int kTailSteps = 8;  // >= the kernel's weight look-ahead
+constexpr int kTailSteps = 16;  // >= the kernel's weight look-ahead (12 for the single-MFMA tilings)
 
 extern "C" size_t imagen_igemm_packed_elems(int G, int Cin, int Cout_pad, int KH, int KW) {
   if (G != 1 && G != 2 && G != 4 && G != 8 && G != 16) return 0;
