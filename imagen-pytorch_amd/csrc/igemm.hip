@@ -12,6 +12,7 @@
 // two consecutive groups (lane>>5 selects) feed one K=16 MFMA.  Staging of chunk c+1 (global loads issued
 // before, LDS writes after the MFMAs of chunk c) overlaps the matrix work of chunk c.
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 #include <utility>
 #include "common.h"
@@ -98,7 +99,26 @@ __device__ __forceinline__ void lds_barrier() {
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
-template <int MI, int NI, int WM, int WN, int G, int KSC>
+// -DIGEMM_TRACE (tools/igemm_probe.py --timeline builds and loads a separate library): with dbg bit 128, lane 0 of the first
+// consumer / producer wave of workgroup 0 stamps s_memtime into the buffer passed in `gate` (unused by the probed launches):
+// trace[role][event], 64 events per role.  Compiled out of the product library (the stamps cost registers in the hot loops).
+#ifdef IGEMM_TRACE
+#define TRACE_STAMP(role, n)                                                                                          \
+  do {                                                                                                                \
+    if ((p.dbg & 128) && blockIdx.x == 0 && (threadIdx.x & 255) == 0 && (n) < 64) {                                   \
+      reinterpret_cast<unsigned long long*>(const_cast<float*>(p.gate))[(role) * 64 + (n)] = __builtin_amdgcn_s_memtime(); \
+      ++(n);                                                                                                          \
+    }                                                                                                                 \
+  } while (0)
+#else
+#define TRACE_STAMP(role, n) do { (void)(n); } while (0)
+#endif
+
+// GEN: the generic epilogue (output activation, gate*addend / residual, pixel-shuffle and fp32-NCHW stores).  The launcher picks the
+// GEN = false instantiation for plain NHWC outputs (optionally with ssq_out or the post_pa output-side prologue): its epilogue is
+// one branch-free block — the generic one tests act_out / out_mode / addend / res per element and quad, ~100 scalar branches
+// per tile that were measured (s_memtime stamps) at 7k of a tile's 13k cycles on the 32-channel 256^2 layers.
+template <int MI, int NI, int WM, int WN, int G, int KSC, bool GEN>
 __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(const ImagenIgemmParams p) {
   static_assert(WM * WN == 4, "4 consumer waves per workgroup");
   constexpr int BN = 32 * NI * WN;
@@ -317,19 +337,28 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
     load_affine(B);
     advance();
     lds_barrier();          // phase 0 is in buffer 0
+    int tn = 0;   // trace events per phase: loop top | loads issued | set written | before the barrier
     for (int q = 0; q < n_phases; q += 2) {
       // consumers: phase q out of buf0
+      TRACE_STAMP(1, tn);
       load_set(A);          // phase q+2
+      TRACE_STAMP(1, tn);
       write_set(B, buf1);   // phase q+1
+      TRACE_STAMP(1, tn);
       load_affine(A);
       advance();
+      TRACE_STAMP(1, tn);
       phase_end();
       if (q + 1 >= n_phases) break;
       // consumers: phase q+1 out of buf1
+      TRACE_STAMP(1, tn);
       load_set(B);          // phase q+3
+      TRACE_STAMP(1, tn);
       write_set(A, buf0);   // phase q+2
+      TRACE_STAMP(1, tn);
       load_affine(B);
       advance();
+      TRACE_STAMP(1, tn);
       phase_end();
     }
     return;
@@ -456,6 +485,7 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
   // The weight ring is dead during the arithmetic of the epilogue (its registers go to the packed outputs) and is re-primed
   // with the NEXT tile's first steps right before the stores: those loads are older than the stores, so the next tile's first
   // weight wait does not cover a store either.
+  int tn = 0;   // trace event counter (IGEMM_TRACE builds only)
   auto prime_weights = [&](int n0) __attribute__((always_inline)) {
     w_ofs = n0;
 #pragma unroll
@@ -551,15 +581,49 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
     }
     float ssq_px[MI];  // per-pixel sum of squares of this wave's stored channels (for the consumer's ChanRMSNorm)
     int op[MI];        // output pixel index, -1: outside the image
-    f16x4 outv[NI][4][MI];   // packed outputs (they take over the accumulators' registers as those die)
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) {
       ssq_px[mi] = 0.0f;
       const int oy = tc.oy0 + pix_y[mi], ox = tc.ox0 + pix_x[mi];
       op[mi] = (oy < p.OH && ox < p.OW) ? oy * p.OW + ox : -1;
     }
-    // one channel quad (4 consecutive couts of this lane) at a time: its bias / gate and the addend / residual quads of all MI
-    // pixels are loaded together, then consumed — a handful of loads in flight per wait instead of one
+    if constexpr (!GEN) {   // plain NHWC output, bias in LDS (launcher-checked): one branch-free block
+      f16x4 pv[NI][4][MI];   // packed outputs (they take over the accumulators' registers as those die)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          __builtin_amdgcn_sched_barrier(0);   // one channel quad at a time (register footprint)
+          const int co = (n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half) & (kBiasLds - 1);   // in range for the LDS read; padded couts are never stored
+          const float4 bq = bias_lds ? *reinterpret_cast<const float4*>(ep_bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            f16x4 o;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              o[e] = (f16)(acc[ni][mi][4 * q + e] + bb[e]);
+              const float r = (float)o[e];
+              ssq_px[mi] += r * r;
+            }
+            pv[ni][q][mi] = o;
+          }
+        }
+      TRACE_STAMP(0, tn);   // (trace: phase 1 of the epilogue done)
+      prime_weights(n0_next);
+      TRACE_STAMP(0, tn);   // (trace: ring re-primed)
+      f16* y = reinterpret_cast<f16*>(p.y) + (size_t)b * p.bsy;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi)
+            if (co < p.Cout && op[mi] >= 0 && !(p.dbg & 8)) *reinterpret_cast<f16x4*>(y + (size_t)op[mi] * p.ldy + co) = pv[ni][q][mi];
+        }
+    } else {
+    f16x4 outv[NI][4][MI];   // packed outputs (they take over the accumulators' registers as those die)
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
@@ -620,7 +684,9 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
     // all stores together: vmcnt retires in issue order and counts stores, so a wait on a load issued AFTER a store also waits
     // for that store's acknowledgement (~1.5k cycles under load; a load -> use -> store loop per channel quad was measured at
     // 14k cycles per tile).  With every store behind the last load, no wait in the epilogue covers one.
+    TRACE_STAMP(0, tn);   // (trace: phase 1 of the epilogue done)
     prime_weights(n0_next);
+    TRACE_STAMP(0, tn);   // (trace: ring re-primed)
     if (p.out_mode != IMAGEN_OUT_NCHW_F32) {
       f16* y = reinterpret_cast<f16*>(p.y);
 #pragma unroll
@@ -645,6 +711,7 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
           }
         }
     }
+    }   // generic path
     // optional: emit the per-pixel sum of squares (launcher guarantees one workgroup covers all Cout: tilesN == 1)
     if (p.ssq_out) {
 #pragma unroll
@@ -686,11 +753,15 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
     const int t_next = t_cursor + t_step;
     const int n0_next = t_next < t_end ? decode(t_next).n0 : tc.n0;
     for (int chunk = 0; chunk < NC; ++chunk) {
+      TRACE_STAMP(0, tn);   // trace events per phase: compute start | compute done | barrier passed (+ per tile: epilogue done)
       if (!(p.dbg & 2)) compute(smem + cur * buf_bytes);
+      TRACE_STAMP(0, tn);
       lds_barrier();   // done with buf[cur]; the producers have filled buf[cur^1]
+      TRACE_STAMP(0, tn);
       cur ^= 1;
     }
     epilogue(tc, n0_next);
+    TRACE_STAMP(0, tn);
     if (t_next >= t_end) break;
     zero_acc();
     t_cursor = t_next;
@@ -708,8 +779,18 @@ inline int num_cus() {
   return n;
 }
 
+template <int MI, int NI, int WM, int WN, int G, int KSC, bool GEN>
+int launch_gen(const ImagenIgemmParams& p, hipStream_t s);
+
 template <int MI, int NI, int WM, int WN, int G, int KSC>
 int launch_ksc(const ImagenIgemmParams& p, hipStream_t s) {
+  const bool plain = p.act_out == IMAGEN_ACT_NONE && p.out_mode == IMAGEN_OUT_NHWC && !p.addend && !p.res &&
+                     (p.bias == nullptr || p.Cout_pad <= kBiasLds);
+  return plain ? launch_gen<MI, NI, WM, WN, G, KSC, false>(p, s) : launch_gen<MI, NI, WM, WN, G, KSC, true>(p, s);
+}
+
+template <int MI, int NI, int WM, int WN, int G, int KSC, bool GEN>
+int launch_gen(const ImagenIgemmParams& p, hipStream_t s) {
   constexpr int TP = 32 * MI * WM, BN = 32 * NI * WN;
   const int ITW = (p.TW - 1) * p.stride + p.KW, ITH = (p.TH - 1) * p.stride + p.KH;
   const int IT = ITH * ITW;
@@ -729,7 +810,7 @@ int launch_ksc(const ImagenIgemmParams& p, hipStream_t s) {
                "igemm: ssq_out needs NHWC output and one workgroup covering all %d output channels (tile has %d)", p.Cout, BN);
   const size_t lds = (size_t)2 * IT * Geo<G>::PS + (size_t)(4 * 32 * MI + kBiasLds) * sizeof(float);   // staging double buffer + epilogue scratch + bias
   IMAGEN_CHECK(lds <= 160 * 1024, "igemm: LDS tile %zu bytes too large", lds);
-  auto kern = igemm_kernel<MI, NI, WM, WN, G, KSC>;
+  auto kern = igemm_kernel<MI, NI, WM, WN, G, KSC, GEN>;
   static bool attr_done = false;
   if (!attr_done) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -747,7 +828,8 @@ int launch_ksc(const ImagenIgemmParams& p, hipStream_t s) {
     occ_blocks = nb;
     occ_lds = lds;
   }
-  const int per_cu = occ_blocks;
+  static const int forced_per_cu = [] { const char* e = getenv("IMAGEN_IGEMM_WG_PER_CU"); return e ? atoi(e) : 0; }();   // probe knob
+  const int per_cu = forced_per_cu > 0 ? forced_per_cu : occ_blocks;
   const int resident = num_cus() * per_cu;
   int gx;
   if ((p.dbg & 32) || total <= resident) {

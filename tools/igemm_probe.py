@@ -113,8 +113,50 @@ def sweep(shapes, G_list=None):
 
 
 
+def timeline(shapes):
+    """s_memtime stamps of workgroup 0's first consumer / producer wave (cycles relative to the first stamp).  Needs the trace
+    build: `bash tools/build_trace_lib.sh; IMAGEN_LIB_PATH=imagen-pytorch_amd/libimagen_hip_trace.so python tools/igemm_probe.py --timeline`"""
+    for shp in shapes:
+        name, B, H, W, C1, C2, Cout, K = shp
+        for variant in ("full", "noprologue"):
+            torch.manual_seed(0)
+            x1 = ops.new_act(B, H, W, C1, dev); x1.t.normal_()
+            x2 = None
+            if C2:
+                x2 = ops.new_act(B, H, W, C2, dev); x2.t.normal_()
+            C = C1 + C2
+            pw = ops.pack_weight(torch.randn(Cout, C, K, K) / (C * K * K) ** 0.5, torch.zeros(Cout), dev)
+            y = ops.new_act(B, H, W, Cout, dev)
+            plan = ops.Plan()
+            kw = {}
+            if variant == "full":
+                kw = dict(rs=torch.rand(B * H * W, device=dev) + 0.5, pa=torch.rand(B, pw.Cin_pad, device=dev) + 0.5,
+                          ps=torch.rand(B, pw.Cin_pad, device=dev), pstride=pw.Cin_pad, act_in=ops.ACT_SILU)
+            p = ops.igemm(plan, x1, pw, y, x2=x2, **kw)
+            trace = torch.zeros(128, dtype=torch.int64, device=dev)
+            p.gate = trace.data_ptr()
+            for _ in range(3):
+                plan.run()
+            torch.cuda.synchronize()
+            p.dbg = 128
+            trace.zero_()
+            plan.run()
+            torch.cuda.synchronize()
+            t = trace.cpu().tolist()
+            t0 = min(v for v in t if v)
+            cons = [v - t0 for v in t[:64] if v]
+            prod = [v - t0 for v in t[64:] if v]
+            print(f"{name} [{variant}] cfg{(p.cfg, p.TH, p.TW)}")
+            print("  consumer (per phase: start, compute done, barrier passed; per tile: + epilogue done):", cons[:44])
+            print("  producer (per phase: top, loads issued, set written, before barrier):", prod[:44], flush=True)
+
+
 if __name__ == "__main__":
     args = sys.argv[1:]
+    if args and args[0] == "--timeline":
+        sel = args[1].split(",") if len(args) > 1 else None
+        timeline([s_ for s_ in SHAPES + EXTRA_SHAPES if not sel or any(o in s_[0] for o in sel)])
+        sys.exit(0)
     if args and args[0] == "--sweep":
         sel = args[1].split(",") if len(args) > 1 else None
         globals()["sweep"]([s_ for s_ in SHAPES + EXTRA_SHAPES if not sel or any(o in s_[0] for o in sel)])
