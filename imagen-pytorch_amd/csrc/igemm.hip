@@ -648,11 +648,13 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
           if (op[mi] < 0) continue;
           float v[4];
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            float x = acc[ni][mi][4 * q + e] + bb[e];
-            if (p.act_out == IMAGEN_ACT_SILU) x = silu_f(x);
-            else if (p.act_out == IMAGEN_ACT_GELU) x = gelu_f(x);
-            v[e] = x;
+          for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][4 * q + e] + bb[e];
+          if (p.act_out == IMAGEN_ACT_SILU) {        // one scalar branch per quad, not per element
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
+          } else if (p.act_out == IMAGEN_ACT_GELU) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
           }
           if (p.out_mode == IMAGEN_OUT_NCHW_F32) {
             float* y = reinterpret_cast<float*>(p.y);

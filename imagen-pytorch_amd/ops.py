@@ -247,7 +247,7 @@ def pick_cfg(G: int, Cout: int, OH: int, OW: int, B: int, KH: int = 1, KW: int =
     (MI <= 2) win everywhere, and when a layer has fewer workgroups than the chip has CUs the narrower output-channel tile
     (twice the workgroups) wins.  Preference order of (tile pixels, tile couts):
       Cout <= 32 : 256x32 when that still gives >= 1024 workgroups, else 128x32
-      Cout <= 64 : 256x32 (two cout tiles) for k > 1 kernels with >= 2048 workgroups, else 64x64
+      Cout <= 64 : 256x64 for k > 1 kernels with >= 1024 workgroups (profiles/r01_igemm_tile_sweep.txt), else 64x64
       Cout  > 64 : 64x128 when >= 192 workgroups, else 64x64
     full_cout: the caller wants the per-pixel sum of squares from the epilogue, which needs one tile to cover all Cout —
     tiles narrower than Cout are then only used when nothing wider exists.  Among the tile shapes of the chosen
@@ -280,7 +280,7 @@ def pick_cfg(G: int, Cout: int, OH: int, OW: int, B: int, KH: int = 1, KW: int =
         order = [(256, 32)] if wgs((256, 32)) >= 1024 else []
         order += [(128, 32), (256, 32), (64, 64), (64, 128)]
     elif Cout <= 64:
-        order = [(256, 32)] if wgs((256, 32)) >= 2048 and not full_cout and KH * KW > 1 else []
+        order = [(256, 64)] if wgs((256, 64)) >= 1024 and KH * KW > 1 else []
         order += [(64, 64), (64, 128), (128, 32), (256, 32)]
     else:
         order = [(64, 128)] if wgs((64, 128)) >= 192 or (full_cout and Cout <= 128) else []
