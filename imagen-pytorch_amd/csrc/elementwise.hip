@@ -225,6 +225,7 @@ __global__ __launch_bounds__(256) void gca_partial_kernel(const ImagenGcaPartial
   __shared__ float s_logit[kGcaMaxChunk];
   __shared__ float s_red[256];
   __shared__ float s_acc[256 * 8];
+  __shared__ float s_fin[2048];   // chunks == 1: ctx [C] | hid [hidden] | kGcaScratchFloats (C + hidden <= 1024 checked by the launcher)
   const int b = blockIdx.y, ch = blockIdx.x;
   const int p0 = ch * chunk_px;
   const int npx = min(chunk_px, p.HW - p0);
@@ -297,6 +298,7 @@ __global__ __launch_bounds__(256) void gca_partial_online_kernel(const ImagenGca
   __shared__ float s_m[256];
   __shared__ float s_se[256];
   __shared__ float s_acc[256 * 8];
+  __shared__ float s_fin[2048];   // chunks == 1: ctx [C] | hid [hidden] | kGcaScratchFloats (C + hidden <= 1024 checked by the launcher)
   const int b = blockIdx.y, ch = blockIdx.x;
   const int p0 = ch * chunk_px;
   const int npx = min(chunk_px, p.HW - p0);
@@ -367,18 +369,25 @@ __global__ __launch_bounds__(256) void gca_partial_online_kernel(const ImagenGca
 #pragma unroll
       for (int j = 0; j < 8; ++j) tot[j] += s_acc[(q * gw + g) * 8 + j] * w;
     }
+    if (p.chunks == 1 && p.w1t != nullptr) {
+      // the whole image was this workgroup's (small feature maps): the pooled context goes straight to LDS (no partials in
+      // global memory, no merge over chunks) and the squeeze MLP runs here
+      const float inv = 1.0f / S;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) out[2 + threadIdx.x * 8 + j] = tot[j];
-    if (threadIdx.x == 0) {
-      out[0] = M;
-      out[1] = S;
+      for (int j = 0; j < 8; ++j) s_fin[threadIdx.x * 8 + j] = tot[j] * inv;
+    } else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) out[2 + threadIdx.x * 8 + j] = tot[j];
+      if (threadIdx.x == 0) {
+        out[0] = M;
+        out[1] = S;
+      }
     }
   }
   if (p.w1t == nullptr) return;   // partials only: a GCA_FINAL launch follows
   if (p.chunks == 1) {
-    // the whole image was this workgroup's (small feature maps): finalise straight away, no cross-workgroup protocol
-    __syncthreads();               // workgroup-scope fence + barrier: `out` is visible to all threads of this workgroup
-    gca_finalize(out, 1, p.C, p.hidden, p.w1t, p.b1, p.w2t, p.b2, p.gate + (size_t)b * p.C, s_acc);
+    __syncthreads();
+    gca_mlp(s_fin, s_fin + p.C, s_fin + p.C + p.hidden, p.C, p.hidden, p.w1t, p.b1, p.w2t, p.b2, p.gate + (size_t)b * p.C);
     return;
   }
   // last workgroup of this image finalises (agent-scope release / acquire ticket; placement-independent)

@@ -65,6 +65,17 @@ __device__ __forceinline__ void gca_matvec(int n_out, int n_in, const float* wt,
   }
 }
 
+// squeeze MLP on a context vector already in LDS: gate = sigmoid(W2 silu(W1 ctx + b1) + b2).  ctx: [C], hid: [hidden] scratch,
+// s_red: kGcaScratchFloats scratch (all LDS).  Called by all 256 threads; ctx must be visible (barrier before the call).
+__device__ __forceinline__ void gca_mlp(const float* ctx, float* hid, float* s_red, int C, int hidden, const float* w1t, const float* b1,
+                                        const float* w2t, const float* b2, float* gate) {
+  if ((hidden & 3) == 0)
+    gca_matvec<4>(hidden, C, w1t, hidden, ctx, s_red, [&](int o, float t) __attribute__((always_inline)) { hid[o] = silu_f(t + b1[o]); });
+  else
+    gca_matvec<1>(hidden, C, w1t, hidden, ctx, s_red, [&](int o, float t) __attribute__((always_inline)) { hid[o] = silu_f(t + b1[o]); });
+  gca_matvec<4>(C, hidden, w2t, C, hid, s_red, [&](int o, float t) __attribute__((always_inline)) { gate[o] = sigmoid_f(t + b2[o]); });
+}
+
 // part: [chunks][C + 2] = (max logit, sum exp, sum exp * h[c]) per chunk of pixels of ONE image (8-byte aligned rows).
 //   ctx[c] = sum_i part[i][2+c] * exp(m_i - M) / sum_i s_i * exp(m_i - M)
 //   gate   = sigmoid(W2 silu(W1 ctx + b1) + b2)        (w1t: [C][hidden], w2t: [hidden][C], 16-byte aligned, C % 8 == 0)
@@ -102,9 +113,6 @@ __device__ __forceinline__ void gca_finalize(const float* part, int chunks, int 
   const float inv_S = 1.0f / s_red[0];
   __syncthreads();
   gca_matvec<2>(C, chunks, part + 2, stride, wgt, s_red, [&](int o, float t) __attribute__((always_inline)) { ctx[o] = t * inv_S; });
-  if ((hidden & 3) == 0)
-    gca_matvec<4>(hidden, C, w1t, hidden, ctx, s_red, [&](int o, float t) __attribute__((always_inline)) { hid[o] = silu_f(t + b1[o]); });
-  else
-    gca_matvec<1>(hidden, C, w1t, hidden, ctx, s_red, [&](int o, float t) __attribute__((always_inline)) { hid[o] = silu_f(t + b1[o]); });
-  gca_matvec<4>(C, hidden, w2t, C, hid, s_red, [&](int o, float t) __attribute__((always_inline)) { gate[o] = sigmoid_f(t + b2[o]); });
+  gca_mlp(ctx, hid, s_red, C, hidden, w1t, b1, w2t, b2, gate);
 }
+

@@ -461,9 +461,9 @@ GCA_SCRATCH = 1024   # csrc/gca_device.h kGcaScratchFloats
 def gca_chunks(HW: int, B: int = 16, C: int = 0) -> int:
     """Pixel chunks per image for the stand-alone GlobalContext kernel: about 1024 workgroups over the batch (the 256 CUs
     stay busy even on the 32x32 maps), chunks of at least 64 pixels (the merge cost grows with the chunk count).  Small maps
-    (HW * C <= 128 Ki elements, i.e. <= 256 KiB per image) take ONE chunk: the workgroup then finalises the gate itself and
+    (HW * C <= 64 Ki elements, i.e. <= 128 KiB per image; measured: beyond that one workgroup per image streams too slowly) take ONE chunk: the workgroup then finalises the gate itself and
     the second launch disappears."""
-    if 0 < HW * C <= 131072:
+    if 0 < HW * C <= 65536:
         return 1
     target = max(1, 1024 // max(B, 1))
     chunk_px = max(64, math.ceil(HW / target))
