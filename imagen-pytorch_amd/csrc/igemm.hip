@@ -624,24 +624,37 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
         }
     } else {
     f16x4 outv[NI][4][MI];   // packed outputs (they take over the accumulators' registers as those die)
+    // gate + (addend | residual) quads of one channel-quad group, loaded ONE group ahead of their use: the epilogue of a
+    // res_conv / residual GEMM is otherwise four dependent global round trips (~2k cycles each under load) per tile
+    struct EpiOps { float4 g; f16x4 ar[MI]; };
+    auto load_group = [&](int g, EpiOps& o) __attribute__((always_inline)) {
+      const int co = n0 + (wn * NI + (g >> 2)) * 32 + 8 * (g & 3) + 4 * half;
+      if (co >= p.Cout) return;
+      if (addend) {
+        o.g = *reinterpret_cast<const float4*>(p.gate + (size_t)b * p.gate_stride + co);
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) {
+        for (int mi = 0; mi < MI; ++mi)
+          o.ar[mi] = *reinterpret_cast<const f16x4*>(addend + (size_t)b * p.bs_add + (size_t)max(op[mi], 0) * p.ld_add + co);
+      } else if (res) {
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        __builtin_amdgcn_sched_barrier(0);   // one channel quad at a time: with the stores deferred nothing else stops the scheduler from
-                                             // hoisting every quad's loads to the top (48 more live registers)
-        const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
-        if (co >= p.Cout) continue;
-        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f), gq = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int mi = 0; mi < MI; ++mi)
+          o.ar[mi] = *reinterpret_cast<const f16x4*>(res + (size_t)b * p.bs_res + (size_t)max(op[mi], 0) * p.ld_res + co);
+      }
+    };
+    EpiOps X, Y;
+    load_group(0, X);
+    static_for<4 * NI>([&](auto gc) __attribute__((always_inline)) {
+      constexpr int g = decltype(gc)::value;
+      constexpr int ni = g >> 2, q = g & 3;
+      EpiOps& cur = (g & 1) ? Y : X;
+      EpiOps& nxt = (g & 1) ? X : Y;
+      __builtin_amdgcn_sched_barrier(0);   // one group (plus the next one's loads) at a time: bounds the register footprint
+      if constexpr (g + 1 < 4 * NI) load_group(g + 1, nxt);
+      const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
+      if (co < p.Cout) {
+        float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);
         if (bias_lds) bq = *reinterpret_cast<const float4*>(ep_bias + co);
-          else if (p.bias) bq = *reinterpret_cast<const float4*>(p.bias + co);   // bias is padded to Cout_pad by the host
-        if (addend) gq = *reinterpret_cast<const float4*>(p.gate + (size_t)b * p.gate_stride + co);
-        f16x4 adq[MI], rrq[MI];
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          if (addend && op[mi] >= 0) adq[mi] = *reinterpret_cast<const f16x4*>(addend + (size_t)b * p.bs_add + (size_t)op[mi] * p.ld_add + co);
-          if (res && op[mi] >= 0) rrq[mi] = *reinterpret_cast<const f16x4*>(res + (size_t)b * p.bs_res + (size_t)op[mi] * p.ld_res + co);
-        }
+        else if (p.bias) bq = *reinterpret_cast<const float4*>(p.bias + co);   // > kBiasLds couts: padded to Cout_pad by the host
         const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
@@ -664,11 +677,10 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
             continue;
           }
           if (addend) {
-            const f16x4 ad = adq[mi];
-            v[0] += (float)ad[0] * gq.x; v[1] += (float)ad[1] * gq.y; v[2] += (float)ad[2] * gq.z; v[3] += (float)ad[3] * gq.w;
-          }
-          if (res) {
-            const f16x4 rr = rrq[mi];
+            const f16x4 ad = cur.ar[mi];
+            v[0] += (float)ad[0] * cur.g.x; v[1] += (float)ad[1] * cur.g.y; v[2] += (float)ad[2] * cur.g.z; v[3] += (float)ad[3] * cur.g.w;
+          } else if (res) {
+            const f16x4 rr = cur.ar[mi];
 #pragma unroll
             for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
           }
@@ -682,7 +694,7 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
           outv[ni][q][mi] = o;   // stored below, after the last load of this epilogue
         }
       }
-    }
+    });
     // all stores together: vmcnt retires in issue order and counts stores, so a wait on a load issued AFTER a store also waits
     // for that store's acknowledgement (~1.5k cycles under load; a load -> use -> store loop per channel quad was measured at
     // 14k cycles per tile).  With every store behind the last load, no wait in the epilogue covers one.
@@ -808,6 +820,7 @@ int launch_gen(const ImagenIgemmParams& p, hipStream_t s) {
   IMAGEN_CHECK(!p.post_pa || (p.post_ps && p.out_mode == IMAGEN_OUT_NHWC && p.Cout <= BN && !p.addend && !p.res && !p.ssq_out &&
                               p.act_out == IMAGEN_ACT_NONE && p.Cout % 4 == 0),
                "igemm: post_pa needs post_ps, a plain NHWC output and one workgroup covering all %d output channels (tile has %d)", p.Cout, BN);
+  IMAGEN_CHECK(!(p.addend && p.res), "igemm: addend and residual are mutually exclusive");
   IMAGEN_CHECK(!p.ssq_out || (p.out_mode == IMAGEN_OUT_NHWC && p.Cout <= BN),
                "igemm: ssq_out needs NHWC output and one workgroup covering all %d output channels (tile has %d)", p.Cout, BN);
   const size_t lds = (size_t)2 * IT * Geo<G>::PS + (size_t)(4 * 32 * MI + kBiasLds) * sizeof(float);   // staging double buffer + epilogue scratch + bias
