@@ -88,30 +88,26 @@ __device__ __forceinline__ void gca_finalize(const float* part, int chunks, int 
   float* s_red = wgt + chunks;
   const int tid = threadIdx.x;
   const int stride = C + 2;
+  // (max, sum-exp) of the chunks: ONE round trip (both values of a chunk sit in the same cache line), block reductions by
+  // wave shuffles + one LDS hop each — the 256-thread trees this replaces cost 16 barriers and a second round trip
+  const int lane = tid & 63, wave = tid >> 6;
   float lm = -3.0e38f;
   for (int i = tid; i < chunks; i += 256) lm = fmaxf(lm, part[(size_t)i * stride]);
-  s_red[tid] = lm;
+  for (int off = 32; off > 0; off >>= 1) lm = fmaxf(lm, __shfl_xor(lm, off));
+  if (lane == 0) s_red[wave] = lm;
   __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (tid < off) s_red[tid] = fmaxf(s_red[tid], s_red[tid + off]);
-    __syncthreads();
-  }
-  const float M = s_red[0];
-  __syncthreads();
+  const float M = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
   float ls = 0.f;
   for (int i = tid; i < chunks; i += 256) {
     const float w = __expf(part[(size_t)i * stride] - M);
     wgt[i] = w;
     ls += part[(size_t)i * stride + 1] * w;
   }
-  s_red[tid] = ls;
-  __syncthreads();
-  for (int off = 128; off > 0; off >>= 1) {
-    if (tid < off) s_red[tid] += s_red[tid + off];
-    __syncthreads();
-  }
-  const float inv_S = 1.0f / s_red[0];
-  __syncthreads();
+  for (int off = 32; off > 0; off >>= 1) ls += __shfl_xor(ls, off);
+  if (lane == 0) s_red[4 + wave] = ls;
+  __syncthreads();   // also publishes wgt[]
+  const float inv_S = 1.0f / (s_red[4] + s_red[5] + s_red[6] + s_red[7]);
+  __syncthreads();   // s_red is reused by the matvecs
   gca_matvec<2>(C, chunks, part + 2, stride, wgt, s_red, [&](int o, float t) __attribute__((always_inline)) { ctx[o] = t * inv_S; });
   gca_mlp(ctx, hid, s_red, C, hidden, w1t, b1, w2t, b2, gate);
 }
