@@ -272,15 +272,21 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
     };
 
     // transform + LDS write of a staged set
+    // transform + LDS write of a staged set — WITHOUT control flow: one producer wave is a chain of dependent VALU ops (measured
+    // ~10 cycles per instruction), so the items of a set must be interleaved by the scheduler, which stops at every branch.
+    // Mode choices (rs | ssq | none, mu, activation) are uniform selects; out-of-image items are zeroed by a select; slots beyond
+    // the tile write to a 16-byte dummy behind the epilogue scratch.
+    char* lds_dummy = smem + 2 * buf_bytes + (4 * PXW + kBiasLds) * (int)sizeof(float);
+    const bool use_rs = p.rs != nullptr, use_ssq = !use_rs && p.ssq_a != nullptr, use_ssqb = use_ssq && p.ssq_b != nullptr;
+    const bool use_mu = p.mu != nullptr, use_silu = p.act_in == IMAGEN_ACT_SILU;
     auto write_set = [&](const StageSet& S, char* buf) __attribute__((always_inline)) {
       if (raw_copy) {   // input already activated by its producer (post_pa epilogue) or a plain GEMM operand: zero-fill only
         static_for<kMaxItems>([&](auto ic) __attribute__((always_inline)) {
           constexpr int it = decltype(ic)::value;
           const int idx = rtid + it * 256;
-          if (idx < items) {
-            const uint4 v = (S.mask & (1u << it)) ? S.raw[it] : make_uint4(0, 0, 0, 0);
-            *reinterpret_cast<uint4*>(buf + (idx >> LOG2G) * PS + my_cg * 16) = v;
-          }
+          const uint4 v = (S.mask & (1u << it)) ? S.raw[it] : make_uint4(0, 0, 0, 0);
+          char* dst = idx < items ? buf + (idx >> LOG2G) * PS + my_cg * 16 : lds_dummy;
+          *reinterpret_cast<uint4*>(dst) = v;
         });
         return;
       }
@@ -289,31 +295,23 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
       static_for<kMaxItems>([&](auto ic) __attribute__((always_inline)) {
         constexpr int it = decltype(ic)::value;
         const int idx = rtid + it * 256;
-        if (idx < items) {
-          const int pix = idx >> LOG2G;
-          f16x8 out;
-          if (S.mask & (1u << it)) {
-            const f16x8 in = *reinterpret_cast<const f16x8*>(&S.raw[it]);
-            float rs = 1.0f, mu = 0.0f;
-            if (p.rs) rs = S.q1[it];
-            else if (p.ssq_a) {  // ChanRMSNorm statistics straight from the producers' per-pixel sums of squares
-              float q = S.q1[it];
-              if (p.ssq_b) q += p.ssq_wb * S.q2[it];
-              rs = __builtin_amdgcn_rsqf(fmaxf(q, 1e-24f));   // 1 / max(sqrt(q), 1e-12), F.normalize's clamp (ip.py:328)
-            }
-            if (p.mu) mu = S.q2[it];
+        const f16x8 in = *reinterpret_cast<const f16x8*>(&S.raw[it]);
+        // ChanRMSNorm statistics straight from the producers' per-pixel sums of squares: 1 / max(sqrt(q), 1e-12) (ip.py:328)
+        const float q = S.q1[it] + (use_ssqb ? p.ssq_wb * S.q2[it] : 0.0f);
+        const float rq = __builtin_amdgcn_rsqf(fmaxf(q, 1e-24f));
+        const float rs = use_rs ? S.q1[it] : (use_ssq ? rq : 1.0f);
+        const float mu = use_mu ? S.q2[it] : 0.0f;
+        const bool ok = (S.mask & (1u << it)) != 0;
+        f16x8 out;
 #pragma unroll
-            for (int j = 0; j < 8; ++j) {
-              float v = ((float)in[j] - mu) * rs * a[j] + s[j];
-              if (p.act_in == IMAGEN_ACT_SILU) v = silu_f(v);
-              out[j] = (f16)v;
-            }
-          } else {
-#pragma unroll
-            for (int j = 0; j < 8; ++j) out[j] = (f16)0.0f;
-          }
-          *reinterpret_cast<f16x8*>(buf + pix * PS + my_cg * 16) = out;
+        for (int j = 0; j < 8; ++j) {
+          float v = ((float)in[j] - mu) * rs * a[j] + s[j];
+          const float vs = silu_f(v);
+          v = use_silu ? vs : v;
+          out[j] = (f16)(ok ? v : 0.0f);
         }
+        char* dst = idx < items ? buf + (idx >> LOG2G) * PS + my_cg * 16 : lds_dummy;
+        *reinterpret_cast<f16x8*>(dst) = out;
       });
     };
 
@@ -823,7 +821,7 @@ int launch_gen(const ImagenIgemmParams& p, hipStream_t s) {
   IMAGEN_CHECK(!(p.addend && p.res), "igemm: addend and residual are mutually exclusive");
   IMAGEN_CHECK(!p.ssq_out || (p.out_mode == IMAGEN_OUT_NHWC && p.Cout <= BN),
                "igemm: ssq_out needs NHWC output and one workgroup covering all %d output channels (tile has %d)", p.Cout, BN);
-  const size_t lds = (size_t)2 * IT * Geo<G>::PS + (size_t)(4 * 32 * MI + kBiasLds) * sizeof(float);   // staging double buffer + epilogue scratch + bias
+  const size_t lds = (size_t)2 * IT * Geo<G>::PS + (size_t)(4 * 32 * MI + kBiasLds) * sizeof(float) + 16;   // staging double buffer + epilogue scratch + bias + dummy
   IMAGEN_CHECK(lds <= 160 * 1024, "igemm: LDS tile %zu bytes too large", lds);
   auto kern = igemm_kernel<MI, NI, WM, WN, G, KSC, GEN>;
   static bool attr_done = false;
