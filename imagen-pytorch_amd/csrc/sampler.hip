@@ -37,20 +37,33 @@ constexpr int kScratch = IMAGEN_QUANTILE_SCRATCH_WORDS;
 
 struct Narrow { uint32_t prefix; uint32_t k; };
 
-// Re-derive (prefix, remaining rank) from the histograms of the passes already done.
-__device__ Narrow narrow_from_hist(const uint32_t* hist, int passes_done, uint32_t k) {
+// Re-derive (prefix, remaining rank) from the histograms of the passes already done — by the whole 256-thread workgroup:
+// thread t owns bin t, a block-wide exclusive scan finds the bin that holds rank k (a single thread walking 4 x 256 counters
+// in global memory was most of the old quantile's 150 us).  s_scan: 8 words of LDS.  All threads get the result.
+__device__ Narrow narrow_block(const uint32_t* hist, int passes_done, uint32_t k, uint32_t* s_scan) {
   Narrow nr{0u, k};
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   for (int ps = 0; ps < passes_done; ++ps) {
-    const uint32_t* h = hist + ps * 256;
-    uint32_t cum = 0;
-    int bin = 0;
-    for (; bin < 256; ++bin) {
-      const uint32_t c = h[bin];
-      if (cum + c > nr.k) break;
-      cum += c;
+    const uint32_t c = hist[ps * 256 + tid];
+    uint32_t v = c;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const uint32_t t = __shfl_up(v, off);
+      if (lane >= off) v += t;
     }
-    if (bin > 255) bin = 255;
-    nr.prefix |= (uint32_t)bin << (24 - 8 * ps);
+    if (lane == 63) s_scan[wave] = v;
+    if (tid == 0) { s_scan[4] = 255u; s_scan[5] = 0xFFFFFFFFu; }   // fallback: last bin (rank beyond the counted keys: cannot happen)
+    __syncthreads();
+    uint32_t base = 0;
+    for (int w = 0; w < wave; ++w) base += s_scan[w];
+    const uint32_t incl = v + base, excl = incl - c;
+    if (excl <= nr.k && nr.k < incl) { s_scan[4] = (uint32_t)tid; s_scan[5] = excl; }
+    __syncthreads();
+    const uint32_t bin = s_scan[4];
+    uint32_t cum = s_scan[5];
+    if (cum == 0xFFFFFFFFu) cum = s_scan[0] + s_scan[1] + s_scan[2] + s_scan[3] - hist[ps * 256 + 255];
+    __syncthreads();   // s_scan is rewritten by the next pass
+    nr.prefix |= bin << (24 - 8 * ps);
     nr.k -= cum;
   }
   return nr;
@@ -63,13 +76,13 @@ __device__ __forceinline__ uint32_t rank_below(int n, float q) {
 
 __global__ __launch_bounds__(256) void quantile_hist_kernel(const ImagenQuantileParams p, int pass, int blocks_per_sample) {
   __shared__ uint32_t s_hist[256];
-  __shared__ Narrow s_nr;
+  __shared__ uint32_t s_scan[8];
   const int b = blockIdx.x / blocks_per_sample, blk = blockIdx.x % blocks_per_sample;
   uint32_t* scratch = p.scratch + (size_t)b * kScratch;
   s_hist[threadIdx.x] = 0;
-  if (threadIdx.x == 0) s_nr = narrow_from_hist(scratch, pass, rank_below(p.n, p.q));
+  const Narrow nr = narrow_block(scratch, pass, rank_below(p.n, p.q), s_scan);
   __syncthreads();
-  const uint32_t prefix = s_nr.prefix;
+  const uint32_t prefix = nr.prefix;
   const uint32_t himask = pass == 0 ? 0u : (0xFFFFFFFFu << (32 - 8 * pass));
   const int shift = 24 - 8 * pass;
   const uint32_t* keys = reinterpret_cast<const uint32_t*>(p.absx0) + (size_t)b * p.n;
@@ -84,17 +97,17 @@ __global__ __launch_bounds__(256) void quantile_hist_kernel(const ImagenQuantile
 
 // After 4 passes the rank-k key is fully known; count keys <= it and find the smallest key above it.
 __global__ __launch_bounds__(256) void quantile_tail_kernel(const ImagenQuantileParams p, int blocks_per_sample) {
-  __shared__ Narrow s_nr;
+  __shared__ uint32_t s_scan[8];
   __shared__ uint32_t s_cnt, s_min;
   const int b = blockIdx.x / blocks_per_sample, blk = blockIdx.x % blocks_per_sample;
   uint32_t* scratch = p.scratch + (size_t)b * kScratch;
   if (threadIdx.x == 0) {
-    s_nr = narrow_from_hist(scratch, 4, rank_below(p.n, p.q));
     s_cnt = 0;
     s_min = 0xFFFFFFFFu;
   }
+  const Narrow nr = narrow_block(scratch, 4, rank_below(p.n, p.q), s_scan);
   __syncthreads();
-  const uint32_t vlo = s_nr.prefix;
+  const uint32_t vlo = nr.prefix;
   const uint32_t* keys = reinterpret_cast<const uint32_t*>(p.absx0) + (size_t)b * p.n;
   uint32_t cnt = 0, mn = 0xFFFFFFFFu;
   for (int i = blk * 256 + threadIdx.x; i < p.n; i += blocks_per_sample * 256) {
@@ -111,27 +124,26 @@ __global__ __launch_bounds__(256) void quantile_tail_kernel(const ImagenQuantile
   }
 }
 
-__global__ void quantile_final_kernel(const ImagenQuantileParams p) {
-  const int b = blockIdx.x * blockDim.x + threadIdx.x;
-  if (b >= p.B) return;
-  const uint32_t* scratch = p.scratch + (size_t)b * kScratch;
+// One workgroup per sample.  Leaves the sample's scratch zeroed (min slot = ~0) for the next call, so a replayed plan needs
+// no separate clearing launch; the host initialises it once when the op is built (ops.quantile).
+__global__ __launch_bounds__(256) void quantile_final_kernel(const ImagenQuantileParams p) {
+  __shared__ uint32_t s_scan[8];
+  const int b = blockIdx.x;
+  uint32_t* scratch = p.scratch + (size_t)b * kScratch;
   const float rank = p.q * (float)(p.n - 1);
   const uint32_t k = (uint32_t)floorf(rank);
   const float w = rank - floorf(rank);
-  const Narrow nr = narrow_from_hist(scratch, 4, k);
-  const uint32_t cnt_le = scratch[1024];
-  const uint32_t hi_key = (cnt_le >= k + 2u || scratch[1025] == 0xFFFFFFFFu) ? nr.prefix : scratch[1025];
-  const float lo = __uint_as_float(nr.prefix), hi = __uint_as_float(hi_key);
-  // torch lerp: w < 0.5 ? a + w*(b-a) : b - (b-a)*(1-w)
-  const float d = hi - lo;
-  p.out[b] = (w < 0.5f) ? (lo + w * d) : (hi - d * (1.0f - w));
-}
-
-__global__ __launch_bounds__(256) void memset_u32_kernel(uint32_t* dst, int count, int stride_words, int min_slot) {
-  // zero the histograms and counters; the "min" slot starts at 0xFFFFFFFF
-  const int i = blockIdx.x * 256 + threadIdx.x;
-  if (i >= count) return;
-  dst[i] = ((i % stride_words) == min_slot) ? 0xFFFFFFFFu : 0u;
+  const Narrow nr = narrow_block(scratch, 4, k, s_scan);
+  const uint32_t cnt_le = scratch[1024], min_gt = scratch[1025];
+  __syncthreads();   // everyone has read the scratch
+  for (int i = threadIdx.x; i < 1026; i += 256) scratch[i] = (i == 1025) ? 0xFFFFFFFFu : 0u;
+  if (threadIdx.x == 0) {
+    const uint32_t hi_key = (cnt_le >= k + 2u || min_gt == 0xFFFFFFFFu) ? nr.prefix : min_gt;
+    const float lo = __uint_as_float(nr.prefix), hi = __uint_as_float(hi_key);
+    // torch lerp: w < 0.5 ? a + w*(b-a) : b - (b-a)*(1-w)
+    const float d = hi - lo;
+    p.out[b] = (w < 0.5f) ? (lo + w * d) : (hi - d * (1.0f - w));
+  }
 }
 
 // ---- Philox4x32-10 + Box-Muller ------------------------------------------------------------------------
@@ -245,12 +257,11 @@ int launch_quantile(const ImagenQuantileParams* p, hipStream_t s) {
   int bps = (p->n + 8191) / 8192;  // blocks per sample: ~8k keys each
   if (bps < 1) bps = 1;
   if (bps > 64) bps = 64;
-  const int words = p->B * kScratch;
-  hipLaunchKernelGGL(memset_u32_kernel, dim3((words + 255) / 256), dim3(256), 0, s, p->scratch, words, kScratch, 1025);
+  // the scratch arrives clean: initialised by the host when the op is built, re-cleaned by quantile_final_kernel after each use
   for (int pass = 0; pass < 4; ++pass)
     hipLaunchKernelGGL(quantile_hist_kernel, dim3(p->B * bps), dim3(256), 0, s, *p, pass, bps);
   hipLaunchKernelGGL(quantile_tail_kernel, dim3(p->B * bps), dim3(256), 0, s, *p, bps);
-  hipLaunchKernelGGL(quantile_final_kernel, dim3((p->B + 63) / 64), dim3(64), 0, s, *p);
+  hipLaunchKernelGGL(quantile_final_kernel, dim3(p->B), dim3(256), 0, s, *p);
   return imagen_hip_status("quantile");
 }
 

@@ -573,7 +573,11 @@ def cfg_x0(plan: Plan, x, pred, coef, step_ptr, x0, absx0, *, B, n_per_sample, c
 def quantile(plan: Plan, absx0, out, scratch, *, B, n, q: float, label: str = ""):
     p = STRUCTS["ImagenQuantileParams"]()
     p.absx0, p.out, p.scratch, p.B, p.n, p.q = absx0.data_ptr(), out.data_ptr(), scratch.data_ptr(), B, n, q
-    assert scratch.numel() >= B * ENUMS["IMAGEN_QUANTILE_SCRATCH_WORDS"]
+    W = ENUMS["IMAGEN_QUANTILE_SCRATCH_WORDS"]
+    assert scratch.numel() >= B * W and scratch.dtype == torch.int32
+    sv = scratch.view(-1)[: B * W].view(B, W)   # cleared once here; the op's last kernel re-clears it after every use
+    sv.zero_()
+    sv[:, 1025] = -1
     plan.add(p, label or "quantile", [absx0, out, scratch])
     return p
 

@@ -234,7 +234,8 @@ typedef struct ImagenCfgX0Params {
 
 /* QUANTILE — torch.quantile(|x0| per sample, q) ip.py:2097-2101 (linear interpolation), exact. */
 typedef struct ImagenQuantileParams {
-  const float* absx0; float* out; uint32_t* scratch; /* scratch: B * IMAGEN_QUANTILE_SCRATCH_WORDS uint32, zeroed by the op */
+  const float* absx0; float* out; uint32_t* scratch; /* scratch: B * IMAGEN_QUANTILE_SCRATCH_WORDS uint32; must arrive
+                                                      * cleared (all 0, word 1025 of each sample = 0xFFFFFFFF); the op leaves it cleared again */
   int32_t B, n; float q;
 } ImagenQuantileParams;
 #define IMAGEN_QUANTILE_SCRATCH_WORDS (4 * 256 + 8)
