@@ -302,16 +302,22 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
         const float rs = use_rs ? S.q1[it] : (use_ssq ? rq : 1.0f);
         const float mu = use_mu ? S.q2[it] : 0.0f;
         const bool ok = (S.mask & (1u << it)) != 0;
+        // stage-wise over the 8 channels (all affines, then all exp2, then all rcp ...): a source order in which neighbouring
+        // instructions are independent — the quarter-rate exp / rcp of one element otherwise sit back to back behind s_nops
+        float v[8], e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = ((float)in[j] - mu) * rs * a[j] + s[j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = __builtin_amdgcn_exp2f(-1.4426950408889634f * v[j]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = __builtin_amdgcn_rcpf(1.0f + e[j]);
         f16x8 out;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          float v = ((float)in[j] - mu) * rs * a[j] + s[j];
-          const float vs = silu_f(v);
-          v = use_silu ? vs : v;
-          out[j] = (f16)(ok ? v : 0.0f);
-        }
+        for (int j = 0; j < 8; ++j) out[j] = (f16)(use_silu ? v[j] * e[j] : v[j]);
+        uint4 ow = *reinterpret_cast<const uint4*>(&out);
+        ow = ok ? ow : make_uint4(0, 0, 0, 0);   // out-of-image pixels / channels: zero padding (on the packed words)
         char* dst = idx < items ? buf + (idx >> LOG2G) * PS + my_cg * 16 : lds_dummy;
-        *reinterpret_cast<f16x8*>(dst) = out;
+        *reinterpret_cast<uint4*>(dst) = ow;
       });
     };
 
