@@ -74,7 +74,11 @@ MEMEFF = dict(dim=32, cond_dim=64, dim_mults=(1, 2, 4), num_resnet_blocks=(1, 2,
               layer_cross_attns=(False, True, True), memory_efficient=True, lowres_cond=True, attn_heads=4)
 
 
-@pytest.mark.parametrize("kw,S", [(README_U1, 64), (README_U2, 64), (MEMEFF, 32)], ids=["readme-unet1@64", "readme-unet2@64", "memory-efficient@32"])
+C2_BASE = dict(README_U1, dim=128)   # BASELINE config C2: the base unet at dim 128 (channels 128..1024, 128-channel k-chunks, several cout tiles)
+
+
+@pytest.mark.parametrize("kw,S", [(README_U1, 64), (README_U2, 64), (MEMEFF, 32), (C2_BASE, 32)],
+                         ids=["readme-unet1@64", "readme-unet2@64", "memory-efficient@32", "c2-dim128@32"])
 def test_unet_forward_vs_oracle(kw, S):
     """README-sized unets (32-channel-chunk MFMA paths, 1024-token attention) vs the fp32 CPU oracle, stage by stage."""
     from imagen_pytorch_amd import Unet
