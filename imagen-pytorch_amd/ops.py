@@ -229,6 +229,7 @@ def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], device, in_scale:
 
 import os as _os
 
+PICK_128 = int(_os.environ.get("IMAGEN_PICK_128", "0"))              # A/B switch: 128x128 tiles for the big C_out >= 128 layers (3-9 % faster in the isolated probe, 3 % slower in the model: off)
 DEEP_CHUNKS = int(_os.environ.get("IMAGEN_DEEP_CHUNKS", "1"))       # A/B switch: 64/128-channel k-chunks for 1x1 convs / linears
 GCA_SINGLE_LAUNCH = int(_os.environ.get("IMAGEN_GCA_SINGLE_LAUNCH", "0"))   # A/B switch: finalise GlobalContext in the partial kernel behind an agent-scope ticket (measured slower than a second launch: the release/acquire fences write back and invalidate the XCD L2)
 IGEMM_DBG = int(_os.environ.get("IMAGEN_IGEMM_DBG", "0"))          # kernel A/B switches (see ImagenIgemmParams.dbg); 0 in production
@@ -248,7 +249,7 @@ def pick_cfg(G: int, Cout: int, OH: int, OW: int, B: int, KH: int = 1, KW: int =
     (twice the workgroups) wins.  Preference order of (tile pixels, tile couts):
       Cout <= 32 : 256x32 when that still gives >= 1024 workgroups, else 128x32
       Cout <= 64 : 256x64 for k > 1 kernels with >= 1024 workgroups (profiles/r01_igemm_tile_sweep.txt), else 64x64
-      Cout  > 64 : 64x128 when >= 192 workgroups, else 64x64
+      Cout  > 64 : 128x128 when that gives >= 256 workgroups, 64x128 when >= 192, else 64x64
     full_cout: the caller wants the per-pixel sum of squares from the epilogue, which needs one tile to cover all Cout —
     tiles narrower than Cout are then only used when nothing wider exists.  Among the tile shapes of the chosen
     configuration: least padded pixels, then the fewest staged halo pixels."""
@@ -283,7 +284,8 @@ def pick_cfg(G: int, Cout: int, OH: int, OW: int, B: int, KH: int = 1, KW: int =
         order = [(256, 64)] if wgs((256, 64)) >= 1024 and KH * KW > 1 else []
         order += [(64, 64), (64, 128), (128, 32), (256, 32)]
     else:
-        order = [(64, 128)] if wgs((64, 128)) >= 192 or (full_cout and Cout <= 128) else []
+        order = [(128, 128)] if wgs((128, 128)) >= 256 and PICK_128 else []          # big layers: 3-9 % over 64x128 (MI = 4: half the weight traffic)
+        order += [(64, 128)] if wgs((64, 128)) >= 192 or (full_cout and Cout <= 128) else []
         order += [(64, 64), (64, 128), (128, 32), (256, 32)]
     order += [(128, 128), (256, 64)]
     for key in order:

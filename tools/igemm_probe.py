@@ -44,6 +44,13 @@ EXTRA_SHAPES = [  # the small-map layers of unet1 and the token GEMMs (few workg
     ("to_q 256->512 M=1024", 16, 1, 64, 256, 0, 512, 1),
     ("ups 64->128 1x1 @128", 16, 128, 128, 64, 0, 128, 1),
     ("res 384->256 1x1 @32", 16, 32, 32, 256, 128, 256, 1),
+    # BASELINE config C2 (base unet at dim 128, 64^2, rows 16)
+    ("c2.L3 1024->1024 3x3 @8", 16, 8, 8, 1024, 0, 1024, 3),
+    ("c2.L3 1536->1024 3x3 @8", 16, 8, 8, 1024, 512, 1024, 3),
+    ("c2.L2 512->512 3x3 @16", 16, 16, 16, 512, 0, 512, 3),
+    ("c2.L1 256->256 3x3 @32", 16, 32, 32, 256, 0, 256, 3),
+    ("c2.L0 128->128 3x3 @64", 16, 64, 64, 128, 0, 128, 3),
+    ("c2.L0 256->128 3x3 @64", 16, 64, 64, 128, 128, 128, 3),
 ]
 
 
