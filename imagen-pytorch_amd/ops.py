@@ -229,6 +229,8 @@ def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], device, in_scale:
 
 import os as _os
 
+PICK_256x64 = int(_os.environ.get("IMAGEN_PICK_256x64", "1"))
+PICK_256x32 = int(_os.environ.get("IMAGEN_PICK_256x32", "1"))
 PICK_128 = int(_os.environ.get("IMAGEN_PICK_128", "0"))              # A/B switch: 128x128 tiles for the big C_out >= 128 layers (3-9 % faster in the isolated probe, 3 % slower in the model: off)
 DEEP_CHUNKS = int(_os.environ.get("IMAGEN_DEEP_CHUNKS", "1"))       # A/B switch: 64/128-channel k-chunks for 1x1 convs / linears
 GCA_SINGLE_LAUNCH = int(_os.environ.get("IMAGEN_GCA_SINGLE_LAUNCH", "0"))   # A/B switch: finalise GlobalContext in the partial kernel behind an agent-scope ticket (measured slower than a second launch: the release/acquire fences write back and invalidate the XCD L2)
@@ -278,10 +280,10 @@ def pick_cfg(G: int, Cout: int, OH: int, OW: int, B: int, KH: int = 1, KW: int =
         return B * avail[key][1][0] * math.ceil(Cout / key[1]) if key in avail else 0
 
     if Cout <= 32:
-        order = [(256, 32)] if wgs((256, 32)) >= 1024 else []
+        order = [(256, 32)] if wgs((256, 32)) >= 1024 and PICK_256x32 else []
         order += [(128, 32), (256, 32), (64, 64), (64, 128)]
     elif Cout <= 64:
-        order = [(256, 64)] if wgs((256, 64)) >= 1024 and KH * KW > 1 else []
+        order = [(256, 64)] if wgs((256, 64)) >= 1024 and KH * KW > 1 and PICK_256x64 else []
         order += [(64, 64), (64, 128), (128, 32), (256, 32)]
     else:
         order = [(128, 128)] if wgs((128, 128)) >= 256 and PICK_128 else []          # big layers: 3-9 % over 64x128 (MI = 4: half the weight traffic)
@@ -458,6 +460,8 @@ def gca(plan: Plan, h: Act, wk, bk: float, w1t, b1, w2t, b2, part: torch.Tensor,
 
 
 GCA_SCRATCH = 1024   # csrc/gca_device.h kGcaScratchFloats
+GCA_ONE_WG_ELEMS = int(_os.environ.get("IMAGEN_GCA_ONE_WG_ELEMS", "65536"))   # A/B knobs of gca_chunks()
+GCA_TARGET_WGS = int(_os.environ.get("IMAGEN_GCA_TARGET_WGS", "1024"))
 
 
 def gca_chunks(HW: int, B: int = 16, C: int = 0) -> int:
@@ -465,9 +469,9 @@ def gca_chunks(HW: int, B: int = 16, C: int = 0) -> int:
     stay busy even on the 32x32 maps), chunks of at least 64 pixels (the merge cost grows with the chunk count).  Small maps
     (HW * C <= 64 Ki elements, i.e. <= 128 KiB per image; measured: beyond that one workgroup per image streams too slowly) take ONE chunk: the workgroup then finalises the gate itself and
     the second launch disappears."""
-    if 0 < HW * C <= 65536:
+    if 0 < HW * C <= GCA_ONE_WG_ELEMS:
         return 1
-    target = max(1, 1024 // max(B, 1))
+    target = max(1, GCA_TARGET_WGS // max(B, 1))
     chunk_px = max(64, math.ceil(HW / target))
     return max(1, math.ceil(HW / chunk_px))
 
