@@ -101,6 +101,7 @@ OP_STRUCT = {
     ENUMS["IMAGEN_OP_MEAN_ROWS"]: STRUCTS["ImagenMeanRowsParams"],
     ENUMS["IMAGEN_OP_RANDN"]: STRUCTS["ImagenRandnParams"],
     ENUMS["IMAGEN_OP_LOWRES_PREP"]: STRUCTS["ImagenLowresPrepParams"],
+    ENUMS["IMAGEN_OP_LINCOMB"]: STRUCTS["ImagenLincombParams"],
 }
 STRUCT_KIND = {v: k for k, v in OP_STRUCT.items()}
 

@@ -41,6 +41,7 @@ extern "C" size_t imagen_sizeof(int kind) {
     case IMAGEN_OP_MEAN_ROWS: return sizeof(ImagenMeanRowsParams);
     case IMAGEN_OP_RANDN: return sizeof(ImagenRandnParams);
     case IMAGEN_OP_LOWRES_PREP: return sizeof(ImagenLowresPrepParams);
+    case IMAGEN_OP_LINCOMB: return sizeof(ImagenLincombParams);
     default: return 0;
   }
 }
@@ -70,6 +71,7 @@ extern "C" int imagen_launch(int kind, const void* params, imagen_stream_t strea
     case IMAGEN_OP_MEAN_ROWS: return launch_mean_rows(static_cast<const ImagenMeanRowsParams*>(params), s);
     case IMAGEN_OP_RANDN: return launch_randn(static_cast<const ImagenRandnParams*>(params), s);
     case IMAGEN_OP_LOWRES_PREP: return launch_lowres_prep(static_cast<const ImagenLowresPrepParams*>(params), s);
+    case IMAGEN_OP_LINCOMB: return launch_lincomb(static_cast<const ImagenLincombParams*>(params), s);
     default: imagen_set_error("imagen_launch: unknown op kind %d", kind); return -1;
   }
 }

@@ -60,3 +60,4 @@ int launch_select_rows(const ImagenSelectRowsParams* p, hipStream_t s);
 int launch_mean_rows(const ImagenMeanRowsParams* p, hipStream_t s);
 int launch_randn(const ImagenRandnParams* p, hipStream_t s);
 int launch_lowres_prep(const ImagenLowresPrepParams* p, hipStream_t s);
+int launch_lincomb(const ImagenLincombParams* p, hipStream_t s);

@@ -243,7 +243,54 @@ __global__ __launch_bounds__(256) void lowres_prep_kernel(const ImagenLowresPrep
   p.out[i] = p.alpha * v + p.sigma * p.noise[i];
 }
 
+// ElucidatedImagen state updates (see ImagenLincombParams).  n_per_sample % 4 == 0: a 4-element group stays inside one sample.
+__global__ __launch_bounds__(256) void lincomb_kernel(const ImagenLincombParams p) {
+  const size_t n = (size_t)p.B * p.n_per_sample;
+  const size_t i4 = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i4 >= n) return;
+  const int step = *p.step_ptr;
+  const float* w = p.coef + (size_t)step * 8;
+  const float w0 = w[0], w1 = w[1], w2 = w[2], w3 = w[3], w4 = w[4], w5 = w[5];
+  const int b = (int)(i4 / p.n_per_sample);
+  float z[4] = {0.f, 0.f, 0.f, 0.f};
+  if (w4 != 0.0f) {
+    const uint32_t within = (uint32_t)((i4 - (size_t)b * p.n_per_sample) >> 2);
+    const uint32_t k0 = p.seed_ptr ? p.seed_ptr[0] : p.seed_lo, k1 = p.seed_ptr ? p.seed_ptr[1] : p.seed_hi;
+    philox_normal4(within, (uint32_t)step, p.stream_id, (uint32_t)(p.sample_offset + b), k0, k1, z);
+  }
+  const float s1 = (p.thr_mode == 1 && p.q1) ? fmaxf(p.q1[b], 1.0f) : 1.0f;
+  const float s3 = (p.thr_mode == 1 && p.q3) ? fmaxf(p.q3[b], 1.0f) : 1.0f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const size_t i = i4 + e;
+    float v = w0 * p.t0[i] + w4 * z[e];
+    if (p.t1) {
+      float t = p.t1[i];
+      if (p.thr_mode) t = fminf(fmaxf(t, -s1), s1) / s1;
+      v += w1 * t;
+    }
+    if (p.t2) v += w2 * p.t2[i];
+    if (p.t3) {
+      float t = p.t3[i];
+      if (p.thr_mode) t = fminf(fmaxf(t, -s3), s3) / s3;
+      v += w3 * t;
+    }
+    p.out[i] = v;
+    if (p.out2) p.out2[i] = w5 * v;
+    if (p.final && p.final_out) p.final_out[i] = (fminf(fmaxf(v, -1.0f), 1.0f) + 1.0f) * 0.5f;
+  }
+}
+
 }  // namespace
+
+int launch_lincomb(const ImagenLincombParams* p, hipStream_t s) {
+  IMAGEN_CHECK(p->t0 && p->out && p->coef && p->step_ptr, "lincomb: t0 / out / coef / step_ptr required");
+  IMAGEN_CHECK(p->n_per_sample % 4 == 0 && p->B > 0, "lincomb: n_per_sample %% 4");
+  const size_t n = (size_t)p->B * p->n_per_sample;
+  hipLaunchKernelGGL(lincomb_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, *p);
+  if (p->advance) hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, p->step_ptr);
+  return imagen_hip_status("lincomb");
+}
 
 int launch_cfg_x0(const ImagenCfgX0Params* p, hipStream_t s) {
   IMAGEN_CHECK(p->step_ptr && p->coef, "cfg_x0: coef table / step counter required");

@@ -57,7 +57,8 @@ enum ImagenOpKind {
   IMAGEN_OP_MEAN_ROWS = 19,    /* mean over the token axis                                             */
   IMAGEN_OP_RANDN = 20,        /* counter-based (Philox4x32-10) standard normal fill, keyed by global sample index */
   IMAGEN_OP_LOWRES_PREP = 21,  /* nearest resize + normalise + noise-augment the previous stage's image  */
-  IMAGEN_OP_KIND_COUNT = 22
+  IMAGEN_OP_LINCOMB = 22,      /* per-step weighted sum of up to 4 fp32 images (+ Philox noise): the EDM sampler's state updates */
+  IMAGEN_OP_KIND_COUNT = 23
 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -265,6 +266,24 @@ typedef struct ImagenLowresPrepParams {
   const float* img; const float* noise; float* out;
   int32_t B, C, Hin, Win, Hout, Wout; float alpha, sigma;
 } ImagenLowresPrepParams;
+
+/* LINCOMB — the elementwise state updates of the ElucidatedImagen sampler (elucidated_imagen.py:481-540), one launch each:
+ *   out = w0*t0 + w1*thr(t1, q1) + w2*t2 + w3*thr(t3, q3) + w4*z,   out2 = w5*out,   z ~ N(0,1) (Philox, keyed by the step)
+ * with the six weights read from row *step_ptr of a device table coef[rows][8] (so one captured graph serves every step):
+ *   x_hat = x + sqrt(sigma_hat^2 - sigma^2)*S_noise*z, c_in*x_hat         (:489-494, :360)
+ *   Euler:  x_next = x_hat + (sigma_next - sigma_hat) * (x_hat - x0)/sigma_hat                      (:509-511)
+ *   Heun :  x = x_hat + 0.5*(sigma_next - sigma_hat)*((x_hat - x0)/sigma_hat + (x_next - x0')/sigma_next)   (:528-529)
+ * thr(t, q) = threshold_x_start (:309-321): thr_mode 1: clamp(t, -s, s)/s with s = max(q[b], 1); 2: clamp(t, -1, 1); 0: t.
+ * final != 0: final_out = (clamp(out, -1, 1) + 1)/2 (:540, unnormalize_img).  advance != 0: *step_ptr += 1 afterwards. */
+typedef struct ImagenLincombParams {
+  const float* t0; const float* t1; const float* t2; const float* t3;  /* fp32 [B, n_per_sample]; t1..t3 may be NULL */
+  const float* q1; const float* q3;   /* [B] quantiles for thr_mode 1 */
+  float* out; float* out2; float* final_out;  /* out2 / final_out may be NULL */
+  const float* coef; int32_t* step_ptr;
+  const uint32_t* seed_ptr;  /* optional device [2] Philox key (overrides seed_lo/hi) */
+  int32_t B, n_per_sample, thr_mode, final, advance, sample_offset;
+  uint32_t seed_lo, seed_hi, stream_id;
+} ImagenLincombParams;
 
 /* ROWS_COPY — dst[b, r0 + r, :C] = src[b (or 0), r, :C]  (fp16). */
 typedef struct ImagenRowsCopyParams {

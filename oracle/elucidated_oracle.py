@@ -1,0 +1,128 @@
+"""CPU oracle for the ElucidatedImagen sampler (TEST INFRASTRUCTURE — see oracle/unet_oracle.py header).
+
+Restates, in fp32 torch on CPU, `ElucidatedImagen.sample / one_unet_sample / preconditioned_network_forward /
+threshold_x_start / sample_schedule` (el.py = imagen_pytorch/elucidated_imagen.py :309-392, :393-545, :547-745) for
+text_embeds-conditioned image sampling: Karras sigma schedule, stochastic churn, preconditioned denoiser
+(c_in / c_noise / c_skip / c_out, Table 1 of Karras et al.), dynamic thresholding, second-order (Heun) correction,
+low-res noise-conditioning augmentation.  Inpainting / init_images / skip_steps / self-conditioning / video are out of scope.
+
+Gaussian noise is drawn through an injectable `noise_fn(tag, shape)` in the reference's call order per stage:
+("lowres", stage) [el.py:705], ("init", stage) [el.py:442], ("step", stage, i) [el.py:489].
+
+Parity status: pinned against the live reference in tests/test_oracle_vs_reference.py (container only) and
+tests/golden/sample_tiny_elucidated.pt (travels).
+"""
+from __future__ import annotations
+
+import math
+from typing import Callable, Optional, Sequence
+
+import torch
+import torch.nn.functional as F
+
+from .sampler_oracle import SCHEDULES, alpha_sigma
+from .unet_oracle import unet_forward_with_cond_scale
+
+Tensor = torch.Tensor
+
+DEFAULT_HPARAMS = dict(num_sample_steps=32, sigma_min=0.002, sigma_max=80.0, sigma_data=0.5, rho=7.0, S_churn=80.0, S_tmin=0.05,
+                       S_tmax=50.0, S_noise=1.003)   # el.py:100-110
+
+
+def sample_schedule(num_sample_steps: int, rho: float, sigma_min: float, sigma_max: float) -> Tensor:
+    """el.py:373-391 — Karras eq. (5) in fp32, with a trailing sigma = 0."""
+    N = num_sample_steps
+    inv_rho = 1 / rho
+    steps = torch.arange(N, dtype=torch.float32)
+    sigmas = (sigma_max ** inv_rho + steps / (N - 1) * (sigma_min ** inv_rho - sigma_max ** inv_rho)) ** rho
+    return F.pad(sigmas, (0, 1), value=0.0)
+
+
+def step_table(hp: dict):
+    """el.py:428-436, 484: the per-step python floats (sigma, sigma_next, gamma)."""
+    sigmas = sample_schedule(hp["num_sample_steps"], hp["rho"], hp["sigma_min"], hp["sigma_max"])
+    gammas = torch.where((sigmas >= hp["S_tmin"]) & (sigmas <= hp["S_tmax"]),
+                         min(hp["S_churn"] / hp["num_sample_steps"], math.sqrt(2) - 1), 0.0)
+    return [(s.item(), sn.item(), g.item()) for s, sn, g in zip(sigmas[:-1], sigmas[1:], gammas[:-1])], sigmas[0].item()
+
+
+def threshold_x_start(x_start: Tensor, dynamic_threshold: bool = True, percentile: float = 0.95) -> Tensor:
+    """el.py:309-321."""
+    if not dynamic_threshold:
+        return x_start.clamp(-1.0, 1.0)
+    s = torch.quantile(x_start.flatten(1).abs(), percentile, dim=-1)
+    s.clamp_(min=1.0)
+    s = s.view(-1, *([1] * (x_start.ndim - 1)))
+    return x_start.clamp(-s, s) / s
+
+
+def preconditioned_forward(net: Callable[[Tensor, Tensor], Tensor], noised: Tensor, sigma: float, sigma_data: float, *, clamp: bool,
+                           dynamic_threshold: bool, percentile: float) -> Tensor:
+    """el.py:340-369 — sigma is a python float broadcast to the batch (fp32)."""
+    b = noised.shape[0]
+    sig = torch.full((b,), sigma, dtype=torch.float32)
+    ps = sig.view(-1, 1, 1, 1)
+    c_in = 1 * (ps ** 2 + sigma_data ** 2) ** -0.5
+    c_noise = torch.log(sig.clamp(min=1e-20)) * 0.25
+    c_skip = (sigma_data ** 2) / (ps ** 2 + sigma_data ** 2)
+    c_out = ps * sigma_data * (sigma_data ** 2 + ps ** 2) ** -0.5
+    out = c_skip * noised + c_out * net(c_in * noised, c_noise)
+    return threshold_x_start(out, dynamic_threshold, percentile) if clamp else out
+
+
+def one_unet_sample(net: Callable[[Tensor, Tensor], Tensor], shape, hp: dict, *, noise_fn: Callable, stage: int, clamp: bool = True,
+                    dynamic_threshold: bool = True, percentile: float = 0.95, max_steps: Optional[int] = None) -> Tensor:
+    """el.py:393-545 without inpainting / init images / self-conditioning.  Returns the UNNORMALISED [0, 1] image."""
+    table, init_sigma = step_table(hp)
+    images = init_sigma * noise_fn(("init", stage), shape)
+    total = len(table)
+    for ind, (sigma, sigma_next, gamma) in enumerate(table):
+        if max_steps is not None and ind >= max_steps:
+            break
+        eps = hp["S_noise"] * noise_fn(("step", stage, ind), shape)
+        sigma_hat = sigma + gamma * sigma
+        images_hat = images + math.sqrt(sigma_hat ** 2 - sigma ** 2) * eps
+        kw = dict(clamp=clamp, dynamic_threshold=dynamic_threshold, percentile=percentile)
+        model_output = preconditioned_forward(net, images_hat, sigma_hat, hp["sigma_data"], **kw)
+        denoised_over_sigma = (images_hat - model_output) / sigma_hat
+        images_next = images_hat + (sigma_next - sigma_hat) * denoised_over_sigma
+        if sigma_next != 0:   # second-order correction
+            model_output_next = preconditioned_forward(net, images_next, sigma_next, hp["sigma_data"], **kw)
+            denoised_prime_over_sigma = (images_next - model_output_next) / sigma_next
+            images_next = images_hat + 0.5 * (sigma_next - sigma_hat) * (denoised_over_sigma + denoised_prime_over_sigma)
+        images = images_next
+    images = images.clamp(-1.0, 1.0)
+    return (images + 1) * 0.5
+
+
+def elucidated_sample(unets: Sequence[tuple], image_sizes: Sequence[int], text_embeds: Tensor, *, hparams: Optional[dict] = None,
+                      cond_scale=1.0, lowres_noise_schedule: str = "linear", lowres_sample_noise_level: float = 0.2,
+                      dynamic_thresholding: bool = True, percentile: float = 0.95, channels: int = 3, text_masks: Optional[Tensor] = None,
+                      noise_fn: Optional[Callable] = None, max_steps: Optional[int] = None, return_all: bool = False):
+    """el.py:547-745.  `unets`: [(state_dict, ctor_kwargs), ...]; `hparams`: overrides of DEFAULT_HPARAMS (same for every stage)."""
+    n = len(unets)
+    hp = dict(DEFAULT_HPARAMS, **(hparams or {}))
+    cond_scale = cond_scale if isinstance(cond_scale, (list, tuple)) else (cond_scale,) * n
+    if noise_fn is None:
+        noise_fn = lambda tag, shape: torch.randn(shape)
+    if text_masks is None:
+        text_masks = torch.any(text_embeds != 0.0, dim=-1)   # el.py:591
+    b = text_embeds.shape[0]
+    outputs, img = [], None
+    for stage, ((sd, kw), size, cs) in enumerate(zip(unets, image_sizes, cond_scale)):
+        lowres_img = lowres_times = None
+        if kw.get("lowres_cond", False):
+            lowres_times = torch.full((b,), lowres_sample_noise_level, dtype=torch.float32)   # el.py:700 — passed on RAW (:728)
+            up = img if img.shape[-1] == size else F.interpolate(img, size, mode="nearest")
+            up = up * 2 - 1
+            a, s = alpha_sigma(SCHEDULES[lowres_noise_schedule](lowres_times).reshape(-1, 1, 1, 1))
+            lowres_img = a * up + s * noise_fn(("lowres", stage), up.shape)                  # el.py:705
+
+        def net(x, c_noise, _sd=sd, _kw=kw, _cs=cs, _li=lowres_img, _lt=lowres_times):
+            return unet_forward_with_cond_scale(_sd, _kw, x, c_noise, cond_scale=_cs, text_embeds=text_embeds, text_mask=text_masks,
+                                                lowres_cond_img=_li, lowres_noise_times=_lt)
+
+        img = one_unet_sample(net, (b, channels, size, size), hp, noise_fn=noise_fn, stage=stage, dynamic_threshold=dynamic_thresholding,
+                              percentile=percentile, max_steps=max_steps)
+        outputs.append(img)
+    return outputs if return_all else outputs[-1]

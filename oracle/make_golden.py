@@ -105,8 +105,63 @@ def make_sample_fixture(ip, path, seed=7, T=3):
     print(f"wrote {path}: out std {outs[-1].std():.4f}")
 
 
+ELUCIDATED_HP = dict(num_sample_steps=5, sigma_min=0.002, sigma_max=80, sigma_data=0.5, rho=7, S_churn=80, S_tmin=0.05, S_tmax=50,
+                     S_noise=1.003)
+
+
+def make_elucidated_fixture(ip, el, path, seed=9):
+    """ElucidatedImagen.sample (el.py:547-745) on the tiny 2-stage cascade, 5 Karras steps (4 of them with the Heun correction),
+    every Gaussian draw recorded."""
+    torch.manual_seed(seed)
+    u1, u2 = ip.Unet(**TINY_BASE), ip.Unet(**{k: v for k, v in TINY_SR.items() if k != "lowres_cond"})
+    model = el.ElucidatedImagen((u1, u2), image_sizes=(16, 32), text_embed_dim=32, cond_drop_prob=0.1, **ELUCIDATED_HP).eval()
+    for u in model.unets:
+        _derandomise(u)
+    text_embeds = torch.randn(2, 9, 32)
+    draws = []
+    real_randn, real_randn_like = torch.randn, torch.randn_like
+
+    def rec_randn(*a, **k):
+        t = real_randn(*a, **k)
+        draws.append(t.clone())
+        return t
+
+    def rec_randn_like(x, **k):
+        t = real_randn_like(x, **k)
+        draws.append(t.clone())
+        return t
+
+    torch.randn, torch.randn_like = rec_randn, rec_randn_like
+    try:
+        outs = model.sample(text_embeds=text_embeds, cond_scale=3., use_tqdm=False, return_all_unet_outputs=True)
+    finally:
+        torch.randn, torch.randn_like = real_randn, real_randn_like
+    # order of draws (el.py:705, 442, 489): per stage: [lowres aug], init, one per step
+    T = ELUCIDATED_HP["num_sample_steps"]
+    noise = {}
+    it = iter(draws)
+    for stage in range(2):
+        if stage > 0:
+            noise[("lowres", stage)] = next(it)
+        noise[("init", stage)] = next(it)
+        for i in range(T):
+            noise[("step", stage, i)] = next(it)
+    assert next(it, None) is None
+    unets = []
+    for i, (u, kw) in enumerate(zip(model.unets, (TINY_BASE, TINY_SR))):
+        unets.append(dict(kwargs={**{k: v for k, v in kw.items() if k != "lowres_cond"}, "lowres_cond": i > 0},
+                          state_dict={k: v.clone() for k, v in u.state_dict().items()}))
+    torch.save(dict(unets=unets, image_sizes=(16, 32), hparams=dict(ELUCIDATED_HP), cond_scale=3., text_embeds=text_embeds, noise=noise,
+                    outputs=[o.clone() for o in outs], generator="oracle/make_golden.py",
+                    reference="lucidrains/imagen-pytorch v2.0.0 ElucidatedImagen.sample (elucidated_imagen.py:547-745)"), path)
+    print(f"wrote {path}: out std {outs[-1].std():.4f}")
+
+
 def main():
     ip = load_reference()
+    if "--elucidated" in sys.argv:   # only the NEXT-1 fixture (the others are committed and stay byte-identical)
+        make_elucidated_fixture(ip, load_reference("elucidated_imagen"), os.path.join(GOLDEN, "sample_tiny_elucidated.pt"))
+        return
     os.makedirs(GOLDEN, exist_ok=True)
     make_unet_fixture(ip, TINY_BASE, 16, 11, os.path.join(GOLDEN, "unet_tiny_base.pt"))
     make_unet_fixture(ip, TINY_SR, 32, 12, os.path.join(GOLDEN, "unet_tiny_sr.pt"))

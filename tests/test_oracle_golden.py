@@ -54,3 +54,37 @@ def test_schedule_tables_match_oracle():
             an, sn = so.alpha_sigma(ln)
             ref = torch.stack([a, s, an, sn, -torch.special.expm1(l - ln), torch.tensor(0.0 if tn == 0 else 1.0), l])
             assert torch.equal(tab[i, :7], ref)
+
+
+def test_elucidated_oracle_matches_reference_fixture():
+    """oracle/elucidated_oracle.py vs the recorded ElucidatedImagen.sample run of the live reference (5 Karras steps, Heun
+    correction, dynamic thresholding, CFG 3, 2-stage cascade with low-res augmentation), identical Gaussian draws.
+    Stage 1 in isolation to 2e-4; stage 2 in isolation (started from the reference's own stage-1 image) to 2e-4; the chained
+    cascade to 2e-3 (the 5-step sampler from sigma = 80 amplifies stage 1's 4e-5 by ~20x)."""
+    import torch.nn.functional as F
+
+    from oracle import elucidated_oracle as eo
+    from oracle.unet_oracle import unet_forward_with_cond_scale
+
+    g = _load("sample_tiny_elucidated.pt")
+    unets = [(u["state_dict"], u["kwargs"]) for u in g["unets"]]
+    noise_fn = lambda tag, shape: g["noise"][tag]
+    with torch.no_grad():
+        outs = eo.elucidated_sample(unets, g["image_sizes"], g["text_embeds"], hparams=g["hparams"], cond_scale=g["cond_scale"],
+                                    noise_fn=noise_fn, return_all=True)
+    assert torch.allclose(outs[0], g["outputs"][0], atol=2e-4), (outs[0] - g["outputs"][0]).abs().max()
+    assert torch.allclose(outs[1], g["outputs"][1], atol=2e-3), (outs[1] - g["outputs"][1]).abs().max()
+    # stage 2 alone
+    hp = dict(eo.DEFAULT_HPARAMS, **g["hparams"])
+    sd, kw = unets[1]
+    te = g["text_embeds"]
+    tm = torch.any(te != 0.0, dim=-1)
+    lt = torch.full((te.shape[0],), 0.2)
+    up = F.interpolate(g["outputs"][0], g["image_sizes"][1], mode="nearest") * 2 - 1
+    a, sg = so.alpha_sigma(so.SCHEDULES["linear"](lt).reshape(-1, 1, 1, 1))
+    li = a * up + sg * g["noise"][("lowres", 1)]
+    net = lambda x, c: unet_forward_with_cond_scale(sd, kw, x, c, cond_scale=g["cond_scale"], text_embeds=te, text_mask=tm,
+                                                    lowres_cond_img=li, lowres_noise_times=lt)
+    with torch.no_grad():
+        out = eo.one_unet_sample(net, tuple(g["outputs"][1].shape), hp, noise_fn=noise_fn, stage=1)
+    assert torch.allclose(out, g["outputs"][1], atol=2e-4), (out - g["outputs"][1]).abs().max()
