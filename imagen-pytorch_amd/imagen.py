@@ -379,7 +379,9 @@ class Imagen(nn.Module):
                 if unet.lowres_cond:
                     assert img is not None
                     a, s, lsnr = self.lowres_noise_schedule.q_sample_coefficients(level)
-                    lowres_logsnr = torch.full((batch_size,), lsnr, dtype=torch.float32)
+                    # Imagen conditions on the log-SNR of the augmentation level (ip.py:2081); ElucidatedImagen.sample passes the
+                    # raw level (elucidated_imagen.py:700, 728) — `_lowres_time_raw` is set by that subclass
+                    lowres_logsnr = torch.full((batch_size,), level if getattr(self, "_lowres_time_raw", False) else lsnr, dtype=torch.float32)
                     aug = torch.empty(batch_size, self.channels, S, S, device=device)
                     if noise_fn is not None:
                         aug.copy_(noise_fn(("lowres", idx), tuple(aug.shape)))

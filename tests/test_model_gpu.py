@@ -164,3 +164,42 @@ def test_sample_philox_determinism_and_sharding():
     assert a.shape == (4, 3, 32, 32) and a.min() >= 0 and a.max() <= 1 and torch.isfinite(a).all()
     hi = imagen.sample(text_embeds=te[2:], cond_scale=3.0, use_tqdm=False, seed=99, sample_offset=2)
     assert nerr(hi, a[2:]) < 1e-5
+
+
+def test_elucidated_sample_vs_reference_fixture():
+    """SURVEY §8(f) NEXT-1 / BASELINE config C4: ElucidatedImagen.sample (Karras schedule, churn, preconditioning, dynamic
+    threshold, Heun correction, 2-stage cascade) vs the recorded run of the live reference with identical Gaussian draws;
+    hipGraph replay == eager.  Tolerances as for the DDPM cascade (stage 1 alone; the chained second stage amplifies)."""
+    from imagen_pytorch_amd import ElucidatedImagen, Unet
+
+    dev = torch.device("cuda:0")
+    g = _load("sample_tiny_elucidated.pt")
+    unets = []
+    for u in g["unets"]:
+        kw = {k: v for k, v in u["kwargs"].items() if k != "lowres_cond"}
+        m = Unet(**kw, lowres_cond=u["kwargs"]["lowres_cond"]).eval()
+        m.load_state_dict(u["state_dict"])
+        unets.append(m)
+    model = ElucidatedImagen(tuple(unets), image_sizes=g["image_sizes"], text_embed_dim=32, cond_drop_prob=0.1, **g["hparams"]).to(dev).eval()
+    for m, u in zip(model.unets, g["unets"]):
+        m.load_state_dict(u["state_dict"])       # cast_model_parameters may have re-instantiated a unet
+    noise_fn = lambda tag, shape: g["noise"][tag].to(dev)
+    te = g["text_embeds"].to(dev)
+    outs = model.sample(text_embeds=te, cond_scale=g["cond_scale"], use_tqdm=False, return_all_unet_outputs=True, noise_fn=noise_fn)
+    e0, e1 = nerr(outs[0], g["outputs"][0]), nerr(outs[1], g["outputs"][1])
+    print(f"elucidated cascade vs reference: stage1 {e0:.2e} stage2 {e1:.2e}")
+    assert e0 < 1e-2 and e1 < 3e-2, (e0, e1)
+    eager = model.sample(text_embeds=te, cond_scale=g["cond_scale"], use_tqdm=False, return_all_unet_outputs=True, noise_fn=noise_fn,
+                         use_graph=False)
+    assert torch.equal(eager[0], outs[0]) and torch.equal(eager[1], outs[1])
+    # stage 2 alone from the reference's stage-1 image: no amplified stage-1 error
+    alone = model.sample(text_embeds=te, cond_scale=g["cond_scale"], use_tqdm=False, noise_fn=noise_fn, start_at_unet_number=2,
+                         start_image_or_video=g["outputs"][0].to(dev))
+    e2 = nerr(alone, g["outputs"][1])
+    print(f"elucidated stage 2 alone: {e2:.2e}")
+    assert e2 < 1e-2, e2
+    # Philox path: deterministic per seed, different across seeds
+    a = model.sample(text_embeds=te, cond_scale=3., use_tqdm=False, seed=5)
+    b = model.sample(text_embeds=te, cond_scale=3., use_tqdm=False, seed=5)
+    c = model.sample(text_embeds=te, cond_scale=3., use_tqdm=False, seed=6)
+    assert torch.equal(a, b) and not torch.equal(a, c) and torch.isfinite(a).all()
