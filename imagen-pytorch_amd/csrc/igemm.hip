@@ -3,14 +3,15 @@
 // the activation staging and bias / activation / gate*addend / residual / pixel-shuffle fused into the
 // epilogue.  Replaces the ATen sequences cited at ImagenIgemmParams in include/imagen_hip.h.
 //
-// Data flow per workgroup (256 threads = 4 wave64, one output tile of TP pixels x BN output channels):
-//   HBM (NHWC fp16) --16B/lane loads--> VGPR --prologue in fp32--> LDS halo tile [pixels][8*G ch], padded rows
-//   LDS --ds_read_b128 per (tap, 8-channel group)--> MFMA B operand (pixels are the N/lane dimension)
-//   packed weights (L2-resident, fragment order) --16B/lane loads--> MFMA A operand (output channels = rows)
-//   accumulators D[cout][pixel]: lane = pixel, 4 consecutive couts per register quad -> 8B NHWC stores.
-// The k dimension runs over channel chunks of 8*G channels; inside a chunk over (tap, 8-channel group) pairs;
-// two consecutive groups (lane>>5 selects) feed one K=16 MFMA.  Staging of chunk c+1 (global loads issued
-// before, LDS writes after the MFMAs of chunk c) overlaps the matrix work of chunk c.
+// Data flow per workgroup (512 threads = 8 wave64: 4 producer + 4 consumer waves, a persistent walk over output tiles of TP pixels
+// x BN output channels — see the comment above igemm_kernel):
+//   HBM (NHWC fp16) --16B/lane loads, two phases ahead--> producer VGPRs --prologue in fp32--> LDS halo tile [pixels][8*G ch]
+//   LDS --ds_read_b128 per (tap, 8-channel group)--> consumer MFMA B operand (pixels are the N/lane dimension)
+//   packed weights (L2-resident, fragment order) --16B/lane loads, 6-12 steps ahead--> MFMA A operand (output channels = rows)
+//   accumulators D[cout][pixel]: lane = pixel, 4 consecutive couts per register quad -> 8B NHWC stores, all after the last load.
+// The k dimension runs over channel chunks of 8*G channels; inside a chunk over (tap, 8-channel group) pairs; two consecutive
+// groups (lane>>5 selects) feed one K=16 MFMA.  A "phase" = (tile, chunk); one s_barrier per phase hands an LDS buffer from the
+// producers to the consumers.
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>

@@ -70,8 +70,9 @@ enum ImagenOpKind {
  *   in(p, c)  = concat(x1[.., :C1], x2[.., :C2])                       (x2 optional)
  *   a(p, c)   = act_in( (in - mu[p]) * rs[p] * pa[b, c] + ps[b, c] )   (each factor optional), 0 outside the image
  *   acc(q, o) = sum_{ky,kx,c} a(q*stride - pad + (ky,kx), c) * W[o][ky][kx][c]
- *   v         = act_out(acc + bias[o]);  v += addend(q,o) * gate[b,o];  v += res(q,o)
- *   y         = v   (NHWC fp16 | pixel-shuffle NHWC fp16 | NCHW fp32)
+ *   v         = act_out(acc + bias[o]);  v += addend(q,o) * gate[b,o]  |  v += res(q,o)      (addend and res exclude each other)
+ *   y         = v   (NHWC fp16 | pixel-shuffle NHWC fp16 | NCHW fp32);   ssq_out[q] = sum_o fp16(v)^2   (optional)
+ *   or, with post_pa:  y = silu(v / max(||v||_2 over o, 1e-12) * post_pa[b,o] + post_ps[b,o])        (the next Block's prologue)
  *
  * Weights are pre-packed by imagen_pack_igemm_weights() into MFMA-fragment order.
  */
