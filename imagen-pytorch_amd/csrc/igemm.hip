@@ -406,7 +406,13 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
   // wq[j] holds the fragments of K=16 step (gstep + j); w_ofs is the offset (in fragments) of step (gstep + kLookAhead)
   // look-ahead depth of the weight ring: a wave consumes one fragment per MI MFMAs, so the single-MFMA-per-step tilings (small
   // feature maps: few workgroups, each streaming its whole weight slice) need a deeper ring to cover the L2 round trip
-  constexpr int kWantAhead = (MI * NI == 1) ? 12 : (MI * NI == 2 ? 10 : 6);
+#ifndef IGEMM_LA1
+#define IGEMM_LA1 8    // ring depth of the 1- and 2-MFMA-per-step tilings (A/B builds in the model: 8/6 beat 12/10 and 16/12 by 1-2 %)
+#endif
+#ifndef IGEMM_LA2
+#define IGEMM_LA2 6
+#endif
+  constexpr int kWantAhead = (MI * NI == 1) ? IGEMM_LA1 : (MI * NI == 2 ? IGEMM_LA2 : 6);
   constexpr int kLookAhead = KSC == 0 ? 1 : (KSC >= kWantAhead ? kWantAhead : KSC);
   f16x8 wq[kLookAhead][NI];
   int w_ofs = 0;
