@@ -102,6 +102,7 @@ OP_STRUCT = {
     ENUMS["IMAGEN_OP_RANDN"]: STRUCTS["ImagenRandnParams"],
     ENUMS["IMAGEN_OP_LOWRES_PREP"]: STRUCTS["ImagenLowresPrepParams"],
     ENUMS["IMAGEN_OP_LINCOMB"]: STRUCTS["ImagenLincombParams"],
+    ENUMS["IMAGEN_OP_KV_PREP_MULTI"]: STRUCTS["ImagenKvPrepMultiParams"],
 }
 STRUCT_KIND = {v: k for k, v in OP_STRUCT.items()}
 

@@ -42,6 +42,7 @@ extern "C" size_t imagen_sizeof(int kind) {
     case IMAGEN_OP_RANDN: return sizeof(ImagenRandnParams);
     case IMAGEN_OP_LOWRES_PREP: return sizeof(ImagenLowresPrepParams);
     case IMAGEN_OP_LINCOMB: return sizeof(ImagenLincombParams);
+    case IMAGEN_OP_KV_PREP_MULTI: return sizeof(ImagenKvPrepMultiParams);
     default: return 0;
   }
 }
@@ -72,6 +73,7 @@ extern "C" int imagen_launch(int kind, const void* params, imagen_stream_t strea
     case IMAGEN_OP_RANDN: return launch_randn(static_cast<const ImagenRandnParams*>(params), s);
     case IMAGEN_OP_LOWRES_PREP: return launch_lowres_prep(static_cast<const ImagenLowresPrepParams*>(params), s);
     case IMAGEN_OP_LINCOMB: return launch_lincomb(static_cast<const ImagenLincombParams*>(params), s);
+    case IMAGEN_OP_KV_PREP_MULTI: return launch_kv_prep_multi(static_cast<const ImagenKvPrepMultiParams*>(params), s);
     default: imagen_set_error("imagen_launch: unknown op kind %d", kind); return -1;
   }
 }

@@ -61,3 +61,4 @@ int launch_mean_rows(const ImagenMeanRowsParams* p, hipStream_t s);
 int launch_randn(const ImagenRandnParams* p, hipStream_t s);
 int launch_lowres_prep(const ImagenLowresPrepParams* p, hipStream_t s);
 int launch_lincomb(const ImagenLincombParams* p, hipStream_t s);
+int launch_kv_prep_multi(const ImagenKvPrepMultiParams* p, hipStream_t s);

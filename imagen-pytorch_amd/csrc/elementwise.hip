@@ -182,10 +182,10 @@ __global__ __launch_bounds__(256) void qnorm_kernel(const ImagenQnormParams p) {
   *reinterpret_cast<f16x8*>(q) = o;
 }
 
-__global__ __launch_bounds__(256) void kv_prep_kernel(const ImagenKvPrepParams p) {
-  const int bh = blockIdx.y;
+__device__ __forceinline__ void kv_prep_body(const ImagenKvPrepParams& p, int bx, int bh) {
+  if (bh >= p.B * p.heads) return;
   const int b = bh / p.heads, hd = bh - b * p.heads;
-  const int row = blockIdx.x * 32 + (threadIdx.x >> 3);
+  const int row = bx * 32 + (threadIdx.x >> 3);
   const int dg = threadIdx.x & 7;
   if (row >= p.rows) return;
   const size_t soff = (size_t)b * p.src_bs + (size_t)row * p.src_rs + (size_t)hd * p.src_hs + dg * 8;
@@ -214,6 +214,14 @@ __global__ __launch_bounds__(256) void kv_prep_kernel(const ImagenKvPrepParams p
   f16* vt = reinterpret_cast<f16*>(p.vt) + (size_t)b * p.vt_bs + (size_t)hd * p.vt_hs + (p.r0 + row);
 #pragma unroll
   for (int j = 0; j < 8; ++j) vt[(size_t)(dg * 8 + j) * p.vt_ds] = (f16)vv[j];
+}
+
+__global__ __launch_bounds__(256) void kv_prep_kernel(const ImagenKvPrepParams p) { kv_prep_body(p, blockIdx.x, blockIdx.y); }
+
+// grid.z = job: the params of the job are read from device memory (uniform address: scalar loads)
+__global__ __launch_bounds__(256) void kv_prep_multi_kernel(const ImagenKvPrepMultiParams m) {
+  const ImagenKvPrepParams p = m.jobs[blockIdx.z];
+  kv_prep_body(p, blockIdx.x, blockIdx.y);
 }
 
 // ------------------------------------------------------------------------------------------------ global context
@@ -551,6 +559,12 @@ int launch_kv_prep(const ImagenKvPrepParams* p, hipStream_t s) {
   IMAGEN_CHECK(p->rows > 0, "kv_prep: empty");
   hipLaunchKernelGGL(kv_prep_kernel, dim3((p->rows + 31) / 32, p->B * p->heads), dim3(256), 0, s, *p);
   return imagen_hip_status("kv_prep");
+}
+
+int launch_kv_prep_multi(const ImagenKvPrepMultiParams* p, hipStream_t s) {
+  IMAGEN_CHECK(p->jobs && p->n > 0 && p->max_rows > 0 && p->max_bh > 0, "kv_prep_multi: empty");
+  hipLaunchKernelGGL(kv_prep_multi_kernel, dim3((p->max_rows + 31) / 32, p->max_bh, p->n), dim3(256), 0, s, *p);
+  return imagen_hip_status("kv_prep_multi");
 }
 
 int launch_gca_partial(const ImagenGcaPartialParams* p, hipStream_t s) {

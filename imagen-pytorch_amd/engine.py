@@ -92,6 +92,7 @@ def _fingerprint(unet) -> tuple:
 
 
 POST_NORM = int(os.environ.get("IMAGEN_POST_NORM", "1"))   # A/B switch: block2's prologue applied by block1's epilogue
+KV_BATCH = int(os.environ.get("IMAGEN_KV_BATCH", "1"))     # A/B switch: one launch for the context K/V rows of all attention sites
 
 
 class UnetEngine:
@@ -558,6 +559,7 @@ class UnetEngine:
         R, W = self.R, self.W
         selfs, crosses, ws, wc = self._ctx_weights()
         n = rows_per_batch
+        jobs = [] if KV_BATCH else None   # one K^/V^T job per site, all run by a single launch after the two projections
         if selfs:
             mu, rs = self.f32buf(R * n), self.f32buf(R * n)
             ops.rowstat(plan, c_rows, mode=1, rs=rs, mu=mu, eps=1e-5, label=f"ctx.{tag}.ln")
@@ -566,7 +568,7 @@ class UnetEngine:
             for i, s in enumerate(selfs):
                 ops.kv_prep(plan, st.t, st.t, W.f32(s["name"] + ".k_scale", lambda s=s: s["mod"].k_scale), s["khat"], s["vt"], B=R, heads=1,
                             rows=n, r0=k_row0_self, src_strides=(n * ws.Cout, ws.Cout, 0), k_strides=s["k_strides"], vt_strides=s["vt_strides"],
-                            k_off=i * 128, v_off=i * 128 + 64, label=f"{s['name']}.kv_ctx.{tag}")
+                            k_off=i * 128, v_off=i * 128 + 64, batch=jobs)
         if crosses:
             st = self.new(1, 1, R * n, wc.Cout)
             ops.igemm(plan, c_rows, wc, st, label=f"ctx.{tag}.cross")
@@ -575,9 +577,11 @@ class UnetEngine:
                 inner = s["heads"] * 64
                 ops.kv_prep(plan, st.t, st.t, W.f32(s["name"] + ".k_scale", lambda s=s: s["mod"].k_scale), s["khat"], s["vt"], B=R,
                             heads=s["heads"], rows=n, r0=k_row0_cross, src_strides=(n * wc.Cout, wc.Cout, 64), k_strides=s["k_strides"],
-                            vt_strides=s["vt_strides"], k_off=col, v_off=col + inner, label=f"{s['name']}.kv_ctx.{tag}")
+                            vt_strides=s["vt_strides"], k_off=col, v_off=col + inner, batch=jobs)
                 col += 2 * inner
             assert col == wc.Cout
+        if jobs:
+            ops.kv_prep_multi(plan, jobs, self.dev, label=f"kv_ctx.{tag}")
 
     def _emit_null_kv(self, plan):
         """learned null key/value (ip.py:545-547 self: after the context; ip.py:805-808 cross: first)."""

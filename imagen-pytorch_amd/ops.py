@@ -408,8 +408,10 @@ def attention(plan: Plan, q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, o:
 
 
 def kv_prep(plan: Plan, k_src: torch.Tensor, v_src: torch.Tensor, k_scale: torch.Tensor, khat: torch.Tensor, vt: torch.Tensor, *,
-            B, heads, rows, r0, src_strides, k_strides, vt_strides, k_off: int = 0, v_off: int = 0, label: str = ""):
-    """k_off / v_off: element offsets of the k and v columns inside the source rows."""
+            B, heads, rows, r0, src_strides, k_strides, vt_strides, k_off: int = 0, v_off: int = 0, label: str = "",
+            batch: Optional[list] = None):
+    """k_off / v_off: element offsets of the k and v columns inside the source rows.  With `batch` the job is appended to that
+    list instead of the plan; kv_prep_multi(plan, batch) then runs all of them in one launch."""
     p = STRUCTS["ImagenKvPrepParams"]()
     es = k_src.element_size()
     p.k_src, p.v_src = k_src.data_ptr() + k_off * es, v_src.data_ptr() + v_off * es
@@ -419,7 +421,27 @@ def kv_prep(plan: Plan, k_src: torch.Tensor, v_src: torch.Tensor, k_scale: torch
     p.k_bs, p.k_hs, p.k_rs = k_strides
     p.vt_bs, p.vt_hs, p.vt_ds = vt_strides
     p.src_is_f32 = 1 if k_src.dtype == torch.float32 else 0
-    plan.add(p, label or "kv_prep", [k_src, v_src, k_scale, khat, vt])
+    if batch is not None:
+        batch.append((p, [k_src, v_src, k_scale, khat, vt]))
+    else:
+        plan.add(p, label or "kv_prep", [k_src, v_src, k_scale, khat, vt])
+    return p
+
+
+def kv_prep_multi(plan: Plan, batch: list, device, label: str = ""):
+    """One launch for the jobs collected with kv_prep(batch=...): their parameter blocks are uploaded once, at plan build."""
+    if not batch:
+        return None
+    if len(batch) == 1:
+        plan.add(batch[0][0], label or "kv_prep", batch[0][1])
+        return batch[0][0]
+    blob = b"".join(bytes(j) for j, _ in batch)
+    jobs = torch.frombuffer(bytearray(blob), dtype=torch.uint8).to(device)
+    p = STRUCTS["ImagenKvPrepMultiParams"]()
+    p.jobs, p.n = jobs.data_ptr(), len(batch)
+    p.max_rows = max(j.rows for j, _ in batch)
+    p.max_bh = max(j.B * j.heads for j, _ in batch)
+    plan.add(p, label or "kv_prep_multi", [jobs] + [t for _, keep in batch for t in keep])
     return p
 
 

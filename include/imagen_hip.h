@@ -58,7 +58,8 @@ enum ImagenOpKind {
   IMAGEN_OP_RANDN = 20,        /* counter-based (Philox4x32-10) standard normal fill, keyed by global sample index */
   IMAGEN_OP_LOWRES_PREP = 21,  /* nearest resize + normalise + noise-augment the previous stage's image  */
   IMAGEN_OP_LINCOMB = 22,      /* per-step weighted sum of up to 4 fp32 images (+ Philox noise): the EDM sampler's state updates */
-  IMAGEN_OP_KIND_COUNT = 23
+  IMAGEN_OP_KV_PREP_MULTI = 23, /* several KV_PREP jobs (one per attention site) in ONE launch                         */
+  IMAGEN_OP_KIND_COUNT = 24
 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -160,6 +161,12 @@ typedef struct ImagenKvPrepParams {
   int32_t vt_bs, vt_hs, vt_ds;
   int32_t src_is_f32; /* null_kv parameters are fp32 */
 } ImagenKvPrepParams;
+
+/* KV_PREP_MULTI — the per-step context K/V rows of ALL attention sites (2 time tokens each) in one launch instead of one
+ * tiny launch per site: `jobs` is a DEVICE array of n ImagenKvPrepParams, grid.z = job. */
+typedef struct ImagenKvPrepMultiParams {
+  const ImagenKvPrepParams* jobs; int32_t n, max_rows, max_bh; /* max over the jobs of rows and B*heads (grid extents) */
+} ImagenKvPrepMultiParams;
 
 /* QNORM — q[r, h, :] = l2norm(q[r, h, :]) * q_scale * mult   in place (ip.py:559-560, 812-813). */
 typedef struct ImagenQnormParams {

@@ -277,6 +277,34 @@ def test_attention(ops, dev, B, heads, rows, J, shared, fused_qnorm):
     assert e < 2e-3, f"attention normwise error {e:.2e}"
 
 
+def test_kv_prep_multi_matches_individual_launches(ops, dev):
+    """Jobs with different head counts / row counts / source dtypes in one launch: bit-identical to one launch per job."""
+    torch.manual_seed(11)
+    D, B = 64, 3
+    specs = [(1, 2, torch.float16), (8, 2, torch.float16), (4, 5, torch.float16), (2, 1, torch.float32)]   # (heads, rows, dtype)
+    outs = []
+    for batched in (False, True):
+        plan, jobs, res = ops.Plan(), [], []
+        torch.manual_seed(12)
+        for heads, J, dt in specs:
+            Jp = 16
+            src = torch.randn(B, J, 2 * heads * D).to(dt).to(dev)
+            ks = (torch.rand(D) + 0.5).to(dev)
+            khat = torch.zeros(B, heads, Jp, D, dtype=torch.float16, device=dev)
+            vt = torch.zeros(B, heads, D, Jp, dtype=torch.float16, device=dev)
+            ops.kv_prep(plan, src, src, ks, khat, vt, B=B, heads=heads, rows=J, r0=3, src_strides=(J * 2 * heads * D, 2 * heads * D, D),
+                        k_strides=(heads * Jp * D, Jp * D, D), vt_strides=(heads * D * Jp, D * Jp, Jp), k_off=0, v_off=heads * D,
+                        batch=jobs if batched else None)
+            res += [khat, vt]
+        if batched:
+            ops.kv_prep_multi(plan, jobs, dev)
+            assert len(plan) == 1
+        _run(plan)
+        outs.append([r.cpu() for r in res])
+    for a, b in zip(*outs):
+        assert a.abs().sum() > 0 and torch.equal(a, b)
+
+
 # ------------------------------------------------------------------------------------------------ glue kernels
 
 def test_rowstat_gate_ln(ops, dev):
