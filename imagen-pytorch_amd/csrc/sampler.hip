@@ -275,6 +275,7 @@ __global__ __launch_bounds__(256) void lincomb_kernel(const ImagenLincombParams 
       if (p.thr_mode) t = fminf(fmaxf(t, -s3), s3) / s3;
       v += w3 * t;
     }
+    if (p.mask && p.mask[i] == 0.0f) v = p.mask_else[i];
     p.out[i] = v;
     if (p.out2) p.out2[i] = w5 * v;
     if (p.final && p.final_out) p.final_out[i] = (fminf(fmaxf(v, -1.0f), 1.0f) + 1.0f) * 0.5f;
@@ -286,6 +287,7 @@ __global__ __launch_bounds__(256) void lincomb_kernel(const ImagenLincombParams 
 int launch_lincomb(const ImagenLincombParams* p, hipStream_t s) {
   IMAGEN_CHECK(p->t0 && p->out && p->coef && p->step_ptr, "lincomb: t0 / out / coef / step_ptr required");
   IMAGEN_CHECK(p->n_per_sample % 4 == 0 && p->B > 0, "lincomb: n_per_sample %% 4");
+  IMAGEN_CHECK(!p->mask || p->mask_else, "lincomb: mask needs mask_else");
   const size_t n = (size_t)p->B * p->n_per_sample;
   hipLaunchKernelGGL(lincomb_kernel, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, s, *p);
   if (p->advance) hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, p->step_ptr);
@@ -331,6 +333,6 @@ int launch_ddpm_update(const ImagenDdpmUpdateParams* p, hipStream_t s) {
   IMAGEN_CHECK(!p->dynamic_threshold || p->quant, "ddpm_update: dynamic thresholding needs the quantile");
   const size_t n4 = ((size_t)p->B * p->n_per_sample + 3) / 4;
   hipLaunchKernelGGL(ddpm_update_kernel, dim3((unsigned)((n4 + 255) / 256)), dim3(256), 0, s, *p);
-  hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, p->step_ptr);
+  if (!p->no_advance) hipLaunchKernelGGL(step_advance_kernel, dim3(1), dim3(1), 0, s, p->step_ptr);
   return imagen_hip_status("ddpm_update");
 }

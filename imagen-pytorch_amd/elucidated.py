@@ -120,7 +120,8 @@ class ElucidatedImagen(Imagen):
         return sigmas[0].item(), [t.float().contiguous() for t in (coef, w_hat, w_euler, w_heun)]
 
     # ---- per-stage plans --------------------------------------------------------------------------------------------------
-    def _stage(self, idx: int, B: int, device, *, cond_scale: float, with_text: bool, inject_noise: bool, sample_offset: int):
+    def _stage(self, idx: int, B: int, device, *, cond_scale: float, with_text: bool, inject_noise: bool, sample_offset: int,
+               resample_times: int = 0):
         unet = self.unets[idx]
         S = self.image_sizes[idx]
         hp = self.hparams[idx]
@@ -190,8 +191,9 @@ class ElucidatedImagen(Imagen):
 
     @torch.no_grad()
     def p_sample_loop(self, st, *, noise_fn: Optional[Callable], stage: int, seed: int, use_graph: bool = True, use_tqdm: bool = False,
-                      max_steps: Optional[int] = None, trace: Optional[list] = None):
-        """el.py:393-545 for one stage."""
+                      max_steps: Optional[int] = None, trace: Optional[list] = None, init_images=None, skip_steps=None):
+        """el.py:393-545 for one stage (init_images / skip_steps are rejected by sample())."""
+        assert init_images is None and not skip_steps
         eng, T, x = st['eng'], st['T'], st['x']
         stream = torch.cuda.current_stream()
         B = eng.src_batch
@@ -274,12 +276,15 @@ class ElucidatedImagen(Imagen):
     ):
         if sigma_min is not None or sigma_max is not None:
             _out_of_scope("sample(sigma_min=/sigma_max=) per-call overrides (set them on the constructor)")
+        if inpaint_images is not None or inpaint_masks is not None or skip_steps is not None or any(
+                i is not None for i in _cast_tuple(init_images)):
+            _out_of_scope("ElucidatedImagen.sample(inpaint_images= / init_images= / skip_steps=) (el.py:446-452, 497-533)")
         was_training = self.training
         self.eval()
         try:
             return self._sample(texts, text_masks, text_embeds, video_frames, cond_images, cond_video_frames, post_cond_video_frames,
-                                inpaint_videos, inpaint_images, inpaint_masks, init_images, skip_steps, batch_size, cond_scale,
-                                lowres_sample_noise_level, start_at_unet_number, start_image_or_video, stop_at_unet_number,
+                                inpaint_videos, inpaint_images, inpaint_masks, inpaint_resample_times, init_images, skip_steps, batch_size,
+                                cond_scale, lowres_sample_noise_level, start_at_unet_number, start_image_or_video, stop_at_unet_number,
                                 return_all_unet_outputs, return_pil_images, device, use_tqdm, noise_fn, seed, sample_offset, use_graph,
                                 max_steps)
         finally:

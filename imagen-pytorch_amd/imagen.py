@@ -15,6 +15,7 @@ import os
 from typing import Callable, List, Optional
 
 import torch
+import torch.nn.functional as F
 from torch import nn
 
 from . import ops
@@ -178,15 +179,21 @@ class Imagen(nn.Module):
         _out_of_scope("Imagen.forward (training loss, ip.py:2500-2734)")
 
     # ---- one cascade stage -------------------------------------------------------------------------------------
-    def _stage(self, idx: int, B: int, device, *, cond_scale: float, with_text: bool, inject_noise: bool, sample_offset: int):
-        """Build (or fetch) the per-timestep plan + graph of stage `idx` for batch B."""
+    def _stage(self, idx: int, B: int, device, *, cond_scale: float, with_text: bool, inject_noise: bool, sample_offset: int,
+               resample_times: int = 0):
+        """Build (or fetch) the per-timestep plan + graph of stage `idx` for batch B.
+
+        resample_times = R > 0 selects the inpainting plan (ip.py:2237-2275): the device counter then counts INNER iterations
+        (timestep i, resample r = R-1..0), every coefficient table has one row per inner iteration, and one launch sequence
+        [blend known pixels at level t -> denoiser -> posterior step -> re-noise t_next -> t] serves all of them: the re-noising
+        weights are the identity on the rows where the reference skips it, so a single captured graph covers the whole loop."""
         unet = self.unets[idx]
         S = self.image_sizes[idx]
         sched = self.noise_schedulers[idx]
         T = sched.num_timesteps
         cfg = cond_scale != 1.
         key = (idx, B, S, str(device), float(cond_scale), with_text, inject_noise, sample_offset, self.dynamic_thresholding[idx],
-               self.pred_objectives[idx], self.dynamic_thresholding_percentile)
+               self.pred_objectives[idx], self.dynamic_thresholding_percentile, resample_times)
         st = self._stages.get(key)
         if st is not None and not st['eng'].stale():
             return st
@@ -195,7 +202,11 @@ class Imagen(nn.Module):
         eng = UnetEngine(unet, rows, B, S, device, with_text=with_text)
         n = self.channels * S * S
         dev = device
-        coef = sched.step_coefficients().to(dev)
+        R = resample_times
+        if R:
+            coef, blend_coef, renoise_coef = (t.to(dev) for t in sched.inpaint_coefficients(R, philox=not inject_noise))
+        else:
+            coef = sched.step_coefficients().to(dev)
         step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
         seed_dev = torch.zeros(2, dtype=torch.int32, device=dev)
         eng.bind_step_counter(coef, step_ptr)
@@ -206,6 +217,15 @@ class Imagen(nn.Module):
         noise = torch.empty(B, self.channels, S, S, device=dev) if inject_noise else None
         final = torch.empty(B, self.channels, S, S, device=dev)
         plan = Plan(f"stage{idx}-step")
+        extra = {}
+        if R:
+            known = torch.zeros(B, self.channels, S, S, device=dev)      # the known image, normalised, at this stage's size
+            mask = torch.zeros(B, self.channels, S, S, device=dev)       # 1.0 where the known pixel is kept
+            noise_blend = torch.zeros_like(known) if inject_noise else None
+            noise_renoise = torch.zeros_like(known) if inject_noise else None
+            ops.lincomb(plan, known, eng.x_in, blend_coef, step_ptr, B=B, n_per_sample=n, t1=noise_blend, mask=mask, mask_else=eng.x_in,
+                        stream_id=idx | 0x100, sample_offset=sample_offset, seed_ptr=seed_dev, label="inpaint.blend")
+            extra = dict(known=known, mask=mask, noise_blend=noise_blend, noise_renoise=noise_renoise)
         plan.extend(eng.step_plan)
         ops.cfg_x0(plan, eng.x_in, eng.out, coef, step_ptr, x0, absx0, B=B, n_per_sample=n, cfg=cfg, cond_scale=float(cond_scale),
                    objective=self.pred_objectives[idx])
@@ -213,38 +233,52 @@ class Imagen(nn.Module):
         if dyn:
             ops.quantile(plan, absx0, quant, scratch, B=B, n=n, q=float(self.dynamic_thresholding_percentile))
         ops.ddpm_update(plan, eng.x_in, x0, quant if dyn else None, coef, noise, final, step_ptr, B=B, n_per_sample=n,
-                        dynamic_threshold=dyn, total_steps=T, seed=0, stream_id=idx, sample_offset=sample_offset, seed_ptr=seed_dev)
+                        dynamic_threshold=dyn, total_steps=T * max(R, 1), seed=0, stream_id=idx, sample_offset=sample_offset,
+                        seed_ptr=seed_dev, advance=not R)
+        if R:
+            ops.lincomb(plan, eng.x_in, eng.x_in, renoise_coef, step_ptr, B=B, n_per_sample=n, t1=extra['noise_renoise'], advance=True,
+                        stream_id=idx | 0x200, sample_offset=sample_offset, seed_ptr=seed_dev, label="inpaint.renoise")
         st = dict(eng=eng, plan=plan, graph=None, coef=coef, step_ptr=step_ptr, seed_dev=seed_dev, noise=noise, final=final, T=T, S=S,
-                  quant=quant, x0=x0)
+                  quant=quant, x0=x0, R=R, **extra)
         self._stages[key] = st
         return st
 
     @torch.no_grad()
     def p_sample_loop(self, st, *, noise_fn: Optional[Callable], stage: int, seed: int, use_graph: bool = True, use_tqdm: bool = False,
-                      max_steps: Optional[int] = None, trace: Optional[list] = None):
-        """ip.py:2167-2289 for one stage: x_T ~ N(0, I), T ancestral steps, clamp + unnormalise (done by the last step's kernel)."""
-        eng, plan, T = st['eng'], st['plan'], st['T']
+                      max_steps: Optional[int] = None, trace: Optional[list] = None, init_images: Optional[torch.Tensor] = None,
+                      skip_steps: Optional[int] = None):
+        """ip.py:2167-2289 for one stage: x_T ~ N(0, I) (+ init_images), the ancestral steps from `skip_steps` on (each run
+        `inpaint_resample_times` times when st is an inpainting plan), clamp + unnormalise (done by the last step's kernel) and
+        the final paste of the known pixels."""
+        eng, plan, T, R = st['eng'], st['plan'], st['T'], st['R']
         B, S = eng.src_batch, st['S']
         stream = torch.cuda.current_stream()
-        if noise_fn is not None:
-            eng.x_in.copy_(noise_fn(("init", stage), tuple(eng.x_in.shape)))
-        else:
+        skip = skip_steps or 0
+        assert 0 <= skip < T, 'skip_steps must leave at least one timestep'
+        inner = max(R, 1)
+        init = None
+        if noise_fn is None:
             init = Plan("init-noise")
             ops.randn(init, eng.x_in, seed=seed, stream_id=stage, tag=TAG_INIT, sample_offset=st.get('sample_offset', 0))
-            init.run()
-        st['step_ptr'].zero_()
-        st['seed_dev'].copy_(torch.tensor([seed & 0x7FFFFFFF, (seed >> 31) & 0x7FFFFFFF], dtype=torch.int32))
-        steps = T if max_steps is None else min(T, max_steps)
-        if use_graph and st['graph'] is None:
-            plan.run()                                   # warm-up outside capture (sets kernel attributes), then rewind
-            st['step_ptr'].zero_()
+
+        def reset_state():
             if noise_fn is not None:
                 eng.x_in.copy_(noise_fn(("init", stage), tuple(eng.x_in.shape)))
             else:
                 init.run()
+            if init_images is not None:
+                eng.x_in.add_(init_images)              # ip.py:2205-2206
+            st['step_ptr'].fill_(skip * inner)           # ip.py:2228-2229: the skipped timesteps are simply never run
+
+        reset_state()
+        st['seed_dev'].copy_(torch.tensor([seed & 0x7FFFFFFF, (seed >> 31) & 0x7FFFFFFF], dtype=torch.int32))
+        steps = T - skip if max_steps is None else min(T - skip, max_steps)
+        if use_graph and st['graph'] is None:
+            plan.run()                                   # warm-up outside capture (sets kernel attributes), then rewind
+            reset_state()
             torch.cuda.synchronize()
             st['graph'] = ops.Graph(plan, stream)
-        it = range(steps)
+        it = range(skip, skip + steps)
         if use_tqdm:
             try:
                 from tqdm.auto import tqdm
@@ -252,17 +286,29 @@ class Imagen(nn.Module):
             except ImportError:
                 pass
         for i in it:
-            if noise_fn is not None:
-                st['noise'].copy_(noise_fn(("step", stage, i), tuple(st['noise'].shape)))
-            if use_graph:
-                st['graph'].launch()
-            else:
-                plan.run()
-            if trace is not None:
-                trace.append(eng.x_in.clone())
-        if steps == T:
-            return st['final']
-        return (eng.x_in.clamp(-1., 1.) + 1) * 0.5  # truncated loop (tests): same epilogue as ip.py:2281-2288
+            for r in reversed(range(inner)):
+                if noise_fn is not None:
+                    shape = tuple(st['noise'].shape)
+                    if R:
+                        st['noise_blend'].copy_(noise_fn(("inpaint", stage, i, r), shape))
+                        st['noise'].copy_(noise_fn(("step", stage, i, r), shape))
+                        if r > 0 and i < T - 1:          # the reference draws no re-noising sample otherwise (ip.py:2268)
+                            st['noise_renoise'].copy_(noise_fn(("renoise", stage, i, r), shape))
+                    else:
+                        st['noise'].copy_(noise_fn(("step", stage, i), shape))
+                if use_graph:
+                    st['graph'].launch()
+                else:
+                    plan.run()
+                if trace is not None:
+                    trace.append(eng.x_in.clone())
+        if skip + steps == T:
+            out = st['final']
+        else:
+            out = (eng.x_in.clamp(-1., 1.) + 1) * 0.5    # truncated loop (tests): same epilogue as ip.py:2281-2288
+        if R:
+            out = torch.where(st['mask'] != 0, (st['known'] + 1) * 0.5, out)   # ip.py:2283-2288
+        return out
 
     # ---- public sampling API (ip.py:2291-2498) ------------------------------------------------------------------
     @torch.no_grad()
@@ -303,15 +349,15 @@ class Imagen(nn.Module):
         self.eval()
         try:
             return self._sample(texts, text_masks, text_embeds, video_frames, cond_images, cond_video_frames, post_cond_video_frames,
-                                inpaint_videos, inpaint_images, inpaint_masks, init_images, skip_steps, batch_size, cond_scale,
-                                lowres_sample_noise_level, start_at_unet_number, start_image_or_video, stop_at_unet_number,
+                                inpaint_videos, inpaint_images, inpaint_masks, inpaint_resample_times, init_images, skip_steps, batch_size,
+                                cond_scale, lowres_sample_noise_level, start_at_unet_number, start_image_or_video, stop_at_unet_number,
                                 return_all_unet_outputs, return_pil_images, device, use_tqdm, noise_fn, seed, sample_offset, use_graph,
                                 max_steps)
         finally:
             self.train(was_training)
 
     def _sample(self, texts, text_masks, text_embeds, video_frames, cond_images, cond_video_frames, post_cond_video_frames,
-                inpaint_videos, inpaint_images, inpaint_masks, init_images, skip_steps, batch_size, cond_scale,
+                inpaint_videos, inpaint_images, inpaint_masks, inpaint_resample_times, init_images, skip_steps, batch_size, cond_scale,
                 lowres_sample_noise_level, start_at_unet_number, start_image_or_video, stop_at_unet_number, return_all_unet_outputs,
                 return_pil_images, device, use_tqdm, noise_fn, seed, sample_offset, use_graph, max_steps):
         device = torch.device(device) if device is not None else self.device
@@ -321,12 +367,9 @@ class Imagen(nn.Module):
         if texts is not None and text_embeds is None and not self.unconditional:
             _out_of_scope("T5 text encoding (`texts=`): pass precomputed `text_embeds=`")
         for name, val in (('video_frames', video_frames), ('cond_images', cond_images), ('cond_video_frames', cond_video_frames),
-                          ('post_cond_video_frames', post_cond_video_frames), ('inpaint_videos', inpaint_videos),
-                          ('inpaint_images', inpaint_images), ('inpaint_masks', inpaint_masks), ('skip_steps', skip_steps)):
+                          ('post_cond_video_frames', post_cond_video_frames), ('inpaint_videos', inpaint_videos)):
             if val is not None:
                 _out_of_scope(f"sample({name}=...)")
-        if init_images is not None and any(i is not None for i in _cast_tuple(init_images)):
-            _out_of_scope("sample(init_images=...)")
         if return_pil_images:
             _out_of_scope("return_pil_images (torchvision is not part of this stack)")
 
@@ -336,12 +379,29 @@ class Imagen(nn.Module):
             if text_masks is None:
                 text_masks = torch.any(text_embeds != 0., dim=-1)    # ip.py:2337
             batch_size = text_embeds.shape[0]
+        if inpaint_images is not None:                   # ip.py:2344-2351
+            if self.unconditional and batch_size == 1:
+                batch_size = inpaint_images.shape[0]
+            assert inpaint_images.shape[0] == batch_size, \
+                'number of inpainting images must be equal to the specified batch size on sample `sample(batch_size=<int>)``'
+            assert not (self.condition_on_text and inpaint_images.shape[0] != text_embeds.shape[0]), \
+                'number of inpainting images must be equal to the number of text to be conditioned on'
         assert not (self.condition_on_text and text_embeds is None), 'text or text encodings must be passed into imagen if specified'
         assert not (not self.condition_on_text and text_embeds is not None), 'imagen specified not to be conditioned on text, yet it is presented'
         assert not (text_embeds is not None and text_embeds.shape[-1] != self.text_embed_dim), \
             f'invalid text embedding dimension being passed in (should be {self.text_embed_dim})'
 
+        assert not ((inpaint_images is not None) ^ (inpaint_masks is not None)), \
+            'inpaint images and masks must be both passed in to do inpainting'
         num_unets = len(self.unets)
+        normalize = (lambda im: im * 2 - 1) if self.auto_normalize_img else (lambda im: im)             # ip.py:1885-1888
+        resize = lambda im, size: im if im.shape[-1] == size else F.interpolate(im, size, mode='nearest')   # ip.py:152-168
+        known = known_mask = None
+        if inpaint_images is not None:                   # ip.py:2217-2220
+            known = normalize(inpaint_images.to(device).float())
+            known_mask = inpaint_masks.to(device)[:, None].float()
+        init_images = [None if im is None else normalize(im.to(device).float()) for im in _cast_tuple(init_images, num_unets)]  # ip.py:2390-2391
+        skip_steps = _cast_tuple(skip_steps, num_unets)
         level = lowres_sample_noise_level if lowres_sample_noise_level is not None else self.lowres_sample_noise_level
         cond_scale = _cast_tuple(cond_scale, num_unets)
         if seed is None:
@@ -371,10 +431,13 @@ class Imagen(nn.Module):
                     'imagen was not trained with conditional dropout, and thus one cannot use classifier free guidance (cond_scale anything other than 1)'
                 with_text = text_embeds is not None and unet.cond_on_text
                 st = self._stage(idx, batch_size, device, cond_scale=cs, with_text=with_text, inject_noise=noise_fn is not None,
-                                 sample_offset=sample_offset)
+                                 sample_offset=sample_offset, resample_times=inpaint_resample_times if known is not None else 0)
                 st['sample_offset'] = sample_offset
                 eng = st['eng']
                 S = self.image_sizes[idx]
+                if known is not None:
+                    st['known'].copy_(resize(known, S))
+                    st['mask'].copy_(resize(known_mask, S).bool().expand(-1, self.channels, -1, -1))
                 lowres_logsnr = None
                 if unet.lowres_cond:
                     assert img is not None
@@ -403,7 +466,8 @@ class Imagen(nn.Module):
                     import time as _time
                     t_stage = _time.perf_counter()
                 out = self.p_sample_loop(st, noise_fn=noise_fn, stage=idx, seed=seed, use_graph=use_graph, use_tqdm=use_tqdm,
-                                         max_steps=max_steps)
+                                         max_steps=max_steps, skip_steps=skip_steps[idx],
+                                         init_images=None if init_images[idx] is None else resize(init_images[idx], S))
                 if timing:
                     self._stream.synchronize()
                     dt = _time.perf_counter() - t_stage

@@ -612,12 +612,13 @@ def quantile(plan: Plan, absx0, out, scratch, *, B, n, q: float, label: str = ""
 
 def ddpm_update(plan: Plan, x, x0, quant, coef, noise, final_out, step_ptr, *, B, n_per_sample, dynamic_threshold: bool,
                 total_steps: int, seed: int, stream_id: int, sample_offset: int = 0, seed_ptr: Optional[torch.Tensor] = None,
-                label: str = ""):
+                advance: bool = True, label: str = ""):
     p = STRUCTS["ImagenDdpmUpdateParams"]()
     p.x, p.x0, p.quant, p.coef, p.noise, p.final_out, p.step_ptr = (x.data_ptr(), x0.data_ptr(), ptr(quant), coef.data_ptr(), ptr(noise),
                                                                    ptr(final_out), step_ptr.data_ptr())
     p.B, p.n_per_sample, p.dynamic_threshold, p.total_steps = B, n_per_sample, int(dynamic_threshold), total_steps
     p.sample_offset = sample_offset
+    p.no_advance = 0 if advance else 1
     p.seed_ptr = ptr(seed_ptr)
     if seed_ptr is not None:
         plan.keep.append(seed_ptr)
@@ -646,15 +647,17 @@ def lowres_prep(plan: Plan, img: torch.Tensor, noise: torch.Tensor, out: torch.T
 
 def lincomb(plan: Plan, t0, out, coef, step_ptr, *, B, n_per_sample, t1=None, t2=None, t3=None, q1=None, q3=None, out2=None,
             final_out=None, thr_mode: int = 0, final: bool = False, advance: bool = False, seed: int = 0, stream_id: int = 0,
-            sample_offset: int = 0, seed_ptr: Optional[torch.Tensor] = None, label: str = ""):
-    """ElucidatedImagen state update (ImagenLincombParams): out = w0*t0 + w1*thr(t1) + w2*t2 + w3*thr(t3) + w4*z, out2 = w5*out,
-    weights = coef[*step_ptr, 0:6]."""
+            sample_offset: int = 0, seed_ptr: Optional[torch.Tensor] = None, mask=None, mask_else=None, label: str = ""):
+    """Per-step state update (ImagenLincombParams): out = w0*t0 + w1*thr(t1) + w2*t2 + w3*thr(t3) + w4*z, out2 = w5*out,
+    weights = coef[*step_ptr, 0:6]; with `mask` (fp32 0/1, same shape) out keeps `mask_else` where the mask is 0."""
     p = STRUCTS["ImagenLincombParams"]()
     p.t0, p.t1, p.t2, p.t3 = t0.data_ptr(), ptr(t1), ptr(t2), ptr(t3)
     p.q1, p.q3, p.out, p.out2, p.final_out = ptr(q1), ptr(q3), out.data_ptr(), ptr(out2), ptr(final_out)
     p.coef, p.step_ptr, p.seed_ptr = coef.data_ptr(), step_ptr.data_ptr(), ptr(seed_ptr)
     p.B, p.n_per_sample, p.thr_mode, p.final, p.advance, p.sample_offset = B, n_per_sample, thr_mode, int(final), int(advance), sample_offset
     p.seed_lo, p.seed_hi, p.stream_id = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, stream_id
+    p.mask, p.mask_else = ptr(mask), ptr(mask_else)
     assert coef.dtype == torch.float32 and coef.shape[-1] == 8
-    plan.add(p, label or "lincomb", [t0, t1, t2, t3, q1, q3, out, out2, final_out, coef, step_ptr, seed_ptr])
+    assert mask is None or (mask.dtype == torch.float32 and mask_else is not None and mask.numel() == B * n_per_sample)
+    plan.add(p, label or "lincomb", [t0, t1, t2, t3, q1, q3, out, out2, final_out, coef, step_ptr, seed_ptr, mask, mask_else])
     return p

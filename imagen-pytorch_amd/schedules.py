@@ -67,6 +67,34 @@ class GaussianDiffusionContinuousTimes(nn.Module):
             rows.append(torch.stack([alpha, sigma, alpha_n, sigma_n, c, torch.tensor(nonzero), l, torch.tensor(0.0)]))
         return torch.stack(rows).float().contiguous()
 
+    def inpaint_coefficients(self, resample_times: int, philox: bool):
+        """Tables for the inpainting resample loop (ip.py:2237-2275), one row per INNER iteration (timestep i, resample r = R-1..0):
+        the step table with every row repeated R times, the blend weights of `img*~m + q_sample(known, t)*m` (w0 = alpha_t on the
+        known image, sigma_t on the noise) and the re-noising weights of q_sample_from_to(x, t_next -> t) (ip.py:286-307), which are
+        the identity on the last resample of a timestep and on the whole last timestep.  The noise weight sits in column 4 (the
+        kernel's own Philox draw) when `philox`, else in column 1 (an injected noise image passed as t1)."""
+        R = resample_times
+        pairs = self.get_sampling_timesteps()
+        blend, renoise = [], []
+        nz = 4 if philox else 1
+        for t, t_next in pairs:
+            l, ln = self.log_snr(t), self.log_snr(t_next)
+            alpha_t, sigma_t = log_snr_to_alpha_sigma(l)
+            alpha_n, sigma_n = log_snr_to_alpha_sigma(ln)
+            last_t = float(t_next) == 0.0
+            for r in reversed(range(R)):
+                b = torch.zeros(8)
+                b[0], b[nz] = alpha_t, sigma_t
+                blend.append(b)
+                q = torch.zeros(8)
+                if r == 0 or last_t:
+                    q[0] = 1.0
+                else:
+                    q[0], q[nz] = alpha_t / alpha_n, (sigma_t * alpha_n - sigma_n * alpha_t) / alpha_n
+                renoise.append(q)
+        step = self.step_coefficients().repeat_interleave(R, dim=0).contiguous()
+        return step, torch.stack(blend).float().contiguous(), torch.stack(renoise).float().contiguous()
+
     def q_sample_coefficients(self, t: float):
         """alpha, sigma of q(x_t | x_0) at noise level t (ip.py:272-284) as python floats (fp32-rounded)."""
         l = self.log_snr(torch.tensor(t, dtype=torch.float32))

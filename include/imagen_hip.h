@@ -258,6 +258,7 @@ typedef struct ImagenDdpmUpdateParams {
   int32_t B, n_per_sample, dynamic_threshold, total_steps;
   int32_t sample_offset; /* global index of local sample 0 (batch sharding: noise is keyed by the global sample index) */
   uint32_t seed_lo, seed_hi, stream_id;
+  int32_t no_advance; /* != 0: leave *step_ptr alone (inpainting: a LINCOMB re-noising step of the same table row follows, ip.py:2268-2275) */
 } ImagenDdpmUpdateParams;
 
 /* RANDN — out[b, i] ~ N(0,1), Philox4x32-10 counter (i/4, tag, stream_id, sample_offset + b), key = seed.
@@ -282,7 +283,10 @@ typedef struct ImagenLowresPrepParams {
  *   Euler:  x_next = x_hat + (sigma_next - sigma_hat) * (x_hat - x0)/sigma_hat                      (:509-511)
  *   Heun :  x = x_hat + 0.5*(sigma_next - sigma_hat)*((x_hat - x0)/sigma_hat + (x_next - x0')/sigma_next)   (:528-529)
  * thr(t, q) = threshold_x_start (:309-321): thr_mode 1: clamp(t, -s, s)/s with s = max(q[b], 1); 2: clamp(t, -1, 1); 0: t.
- * final != 0: final_out = (clamp(out, -1, 1) + 1)/2 (:540, unnormalize_img).  advance != 0: *step_ptr += 1 afterwards. */
+ * final != 0: final_out = (clamp(out, -1, 1) + 1)/2 (:540, unnormalize_img).  advance != 0: *step_ptr += 1 afterwards.
+ * mask != NULL: out = mask[i] != 0 ? (the sum above) : mask_else[i] — the inpainting blend `img * ~mask + q_sample(inpaint) * mask`
+ * (ip.py:2244-2246) with t0 = the known image, w0 = alpha_t, w4 = sigma_t; the same op with t0 = x re-noises x_{t_next} -> x_t
+ * (q_sample_from_to, ip.py:286-307).  In-place use (out == mask_else or out == t0) is allowed. */
 typedef struct ImagenLincombParams {
   const float* t0; const float* t1; const float* t2; const float* t3;  /* fp32 [B, n_per_sample]; t1..t3 may be NULL */
   const float* q1; const float* q3;   /* [B] quantiles for thr_mode 1 */
@@ -291,6 +295,7 @@ typedef struct ImagenLincombParams {
   const uint32_t* seed_ptr;  /* optional device [2] Philox key (overrides seed_lo/hi) */
   int32_t B, n_per_sample, thr_mode, final, advance, sample_offset;
   uint32_t seed_lo, seed_hi, stream_id;
+  const float* mask; const float* mask_else;  /* optional fp32 [B, n_per_sample] 0/1 mask and the image kept where it is 0 */
 } ImagenLincombParams;
 
 /* ROWS_COPY — dst[b, r0 + r, :C] = src[b (or 0), r, :C]  (fp16). */

@@ -157,8 +157,89 @@ def make_elucidated_fixture(ip, el, path, seed=9):
     print(f"wrote {path}: out std {outs[-1].std():.4f}")
 
 
+def _record_draws(fn):
+    """Run fn() with torch.randn / randn_like recording every Gaussian draw, in call order."""
+    draws = []
+    real_randn, real_randn_like = torch.randn, torch.randn_like
+
+    def rec_randn(*a, **k):
+        t = real_randn(*a, **k)
+        draws.append(t.clone())
+        return t
+
+    def rec_randn_like(x, **k):
+        t = real_randn_like(x, **k)
+        draws.append(t.clone())
+        return t
+
+    torch.randn, torch.randn_like = rec_randn, rec_randn_like
+    try:
+        out = fn()
+    finally:
+        torch.randn, torch.randn_like = real_randn, real_randn_like
+    return out, draws
+
+
+def make_sample_options_fixture(ip, path, seed=13, T=3, R=2, skip=1):
+    """The p_sample_loop options outside the BASELINE configs (ip.py:2167-2289): (A) init_images + skip_steps, (B) inpainting
+    with `inpaint_resample_times = R`, on the same tiny cascade."""
+    torch.manual_seed(seed)
+    u1, u2 = ip.Unet(**TINY_BASE), ip.Unet(**{k: v for k, v in TINY_SR.items() if k != "lowres_cond"})
+    imagen = ip.Imagen((u1, u2), image_sizes=(16, 32), timesteps=T, text_embed_dim=32, cond_drop_prob=0.1).eval()
+    for u in imagen.unets:
+        _derandomise(u)
+    text_embeds = torch.randn(2, 9, 32)
+    init_images = torch.rand(2, 3, 16, 16)
+    inpaint_images = torch.rand(2, 3, 32, 32)
+    inpaint_masks = torch.rand(2, 32, 32) > 0.5
+    inpaint_masks[:, 8:20, 4:24] = True
+    runs = {}
+    # (A) draws per stage (ip.py:2449, 2195, 2160): [lowres], init, one per remaining timestep
+    outs, draws = _record_draws(lambda: imagen.sample(text_embeds=text_embeds, cond_scale=3., use_tqdm=False, return_all_unet_outputs=True,
+                                                      init_images=init_images, skip_steps=skip))
+    noise, it = {}, iter(draws)
+    for stage in range(2):
+        if stage > 0:
+            noise[("lowres", stage)] = next(it)
+        noise[("init", stage)] = next(it)
+        for i in range(skip, T):
+            noise[("step", stage, i)] = next(it)
+    assert next(it, None) is None
+    runs["init_skip"] = dict(noise=noise, outputs=[o.clone() for o in outs], init_images=init_images, skip_steps=skip)
+    # (B) draws per inner iteration (ip.py:2244, 2160, 2269): known-image noise, step noise, re-noise unless r == 0 / last timestep
+    outs, draws = _record_draws(lambda: imagen.sample(text_embeds=text_embeds, cond_scale=3., use_tqdm=False, return_all_unet_outputs=True,
+                                                      inpaint_images=inpaint_images, inpaint_masks=inpaint_masks,
+                                                      inpaint_resample_times=R))
+    noise, it = {}, iter(draws)
+    for stage in range(2):
+        if stage > 0:
+            noise[("lowres", stage)] = next(it)
+        noise[("init", stage)] = next(it)
+        for i in range(T):
+            for r in reversed(range(R)):
+                noise[("inpaint", stage, i, r)] = next(it)
+                noise[("step", stage, i, r)] = next(it)
+                if r > 0 and i < T - 1:
+                    noise[("renoise", stage, i, r)] = next(it)
+    assert next(it, None) is None
+    runs["inpaint"] = dict(noise=noise, outputs=[o.clone() for o in outs], inpaint_images=inpaint_images, inpaint_masks=inpaint_masks,
+                           inpaint_resample_times=R)
+    unets = []
+    for i, (u, kw) in enumerate(zip(imagen.unets, (TINY_BASE, TINY_SR))):
+        unets.append(dict(kwargs={**{k: v for k, v in kw.items() if k != "lowres_cond"}, "lowres_cond": i > 0},
+                          state_dict={k: v.clone() for k, v in u.state_dict().items()}))
+    torch.save(dict(unets=unets, image_sizes=(16, 32), timesteps=T, cond_scale=3., text_embeds=text_embeds, runs=runs,
+                    generator="oracle/make_golden.py --options",
+                    reference="lucidrains/imagen-pytorch v2.0.0 Imagen.sample (ip.py:2291-2498) with init_images/skip_steps/inpainting"), path)
+    for k, r in runs.items():
+        print(f"wrote {path} [{k}]: out std {r['outputs'][-1].std():.4f}, {len(r['noise'])} draws")
+
+
 def main():
     ip = load_reference()
+    if "--options" in sys.argv:      # only the p_sample_loop-options fixture
+        make_sample_options_fixture(ip, os.path.join(GOLDEN, "sample_tiny_options.pt"))
+        return
     if "--elucidated" in sys.argv:   # only the NEXT-1 fixture (the others are committed and stay byte-identical)
         make_elucidated_fixture(ip, load_reference("elucidated_imagen"), os.path.join(GOLDEN, "sample_tiny_elucidated.pt"))
         return

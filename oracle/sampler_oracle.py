@@ -4,15 +4,18 @@ Restates, in fp32 torch on CPU, the continuous-time Gaussian diffusion helpers
 (ip.py:212-318) and the ancestral sampler `Imagen.p_mean_variance / p_sample /
 p_sample_loop / sample` (ip.py:2042-2498) for the options the BASELINE configs use:
 noise-prediction objective, dynamic thresholding, classifier-free guidance, low-res
-noise-conditioning augmentation.  Inpainting / init_images / skip_steps / video are
-out of scope.
+noise-conditioning augmentation, plus the p_sample_loop options init_images, skip_steps
+and inpainting with resampling (ip.py:2205-2206, 2228-2229, 2237-2286).  Video,
+cond_images and self-conditioning are out of scope.
 
 All Gaussian noise is drawn through an injectable `noise_fn(tag, shape)` so the HIP
 path and the reference can be fed identical tensors (CPU and GPU RNG streams differ,
-SURVEY §7.3-8).  Tags: ("init", stage), ("lowres", stage), ("step", stage, step_index).
+SURVEY §7.3-8).  Tags: ("init", stage), ("lowres", stage), ("step", stage, step_index);
+with inpainting ("inpaint" | "step" | "renoise", stage, step_index, resample_index).
 
 Parity status: pinned against the live reference in tests/test_oracle_vs_reference.py
-(container only) and tests/golden/sample_*.pt (travels).
+(container only) and tests/golden/sample_*.pt (travels; sample_tiny_options.pt holds the
+init_images/skip_steps and inpainting runs).
 """
 from __future__ import annotations
 
@@ -92,25 +95,61 @@ def ddpm_step(x: Tensor, pred_noise: Tensor, t: Tensor, t_next: Tensor, noise: T
 
 # ---------------------------------------------------------------- loops (ip.py:2167-2289, 2291-2498)
 
+def q_sample_from_to(x: Tensor, t_from: Tensor, t_to: Tensor, noise: Tensor, schedule: str) -> Tensor:
+    """ip.py:286-307."""
+    fn = SCHEDULES[schedule]
+    pad = lambda v: v.reshape(-1, *([1] * (x.ndim - 1)))
+    alpha, sigma = alpha_sigma(pad(fn(t_from)))
+    alpha_to, sigma_to = alpha_sigma(pad(fn(t_to)))
+    return x * (alpha_to / alpha) + noise * (sigma_to * alpha - sigma * alpha_to) / alpha
+
+
 def p_sample_loop(denoise: Callable[[Tensor, Tensor], Tensor], shape, *, schedule: str, num_timesteps: int,
                   noise_fn: Callable, stage: int, dynamic_thresholding: bool = True, percentile: float = 0.95,
-                  max_steps: Optional[int] = None, trace: Optional[list] = None) -> Tensor:
-    """denoise(x_t, log_snr(t)) -> guided eps_hat.  Returns the un-normalised image in [0, 1] (ip.py:2281-2289)."""
-    b = shape[0]
+                  max_steps: Optional[int] = None, trace: Optional[list] = None, init_images: Optional[Tensor] = None,
+                  skip_steps: Optional[int] = None, inpaint_images: Optional[Tensor] = None, inpaint_masks: Optional[Tensor] = None,
+                  inpaint_resample_times: int = 5) -> Tensor:
+    """denoise(x_t, log_snr(t)) -> guided eps_hat.  Returns the un-normalised image in [0, 1] (ip.py:2167-2289).
+
+    init_images / inpaint_images arrive NORMALISED to [-1, 1] and at any resolution (resized here, ip.py:2219-2220, 2457);
+    inpaint_masks: (B, H, W) bool, True = keep the known pixel.  With inpainting every timestep is run `inpaint_resample_times`
+    times (RePaint); the draws are tagged ("inpaint", stage, i, r), ("step", stage, i, r), ("renoise", stage, i, r) in the
+    reference's call order; without it the step draw keeps its 3-tuple tag ("step", stage, i)."""
+    b, size = shape[0], shape[-1]
+    resize = lambda im: im if im.shape[-1] == size else F.interpolate(im, size, mode="nearest")   # ip.py:152-168
     img = noise_fn(("init", stage), shape)
+    if init_images is not None:
+        img = img + resize(init_images)                                     # ip.py:2205-2206 (+ the resize of :2457)
+    inpainting = inpaint_images is not None and inpaint_masks is not None
+    R = inpaint_resample_times if inpainting else 1
+    if inpainting:
+        known = resize(inpaint_images)
+        mask = resize(inpaint_masks[:, None].float()).bool()               # ip.py:2220
     fn = SCHEDULES[schedule]
     pairs = sampling_time_pairs(num_timesteps)
+    first = skip_steps or 0                                                 # ip.py:2228-2229
     if max_steps is not None:
-        pairs = pairs[:max_steps]
-    for i, (tt, tn) in enumerate(pairs):
+        pairs = pairs[:first + max_steps]
+    for i, (tt, tn) in list(enumerate(pairs))[first:]:
         t = tt.expand(b).clone()
         t_next = tn.expand(b).clone()
-        pred = denoise(img, fn(t))
-        img, _ = ddpm_step(img, pred, t, t_next, noise_fn(("step", stage, i), shape), schedule,
-                           dynamic_thresholding, percentile)
-        if trace is not None:
-            trace.append(img.clone())
-    return (img.clamp(-1.0, 1.0) + 1) * 0.5
+        last_t = bool((t_next == 0).all())
+        for r in reversed(range(R)):
+            if inpainting:
+                a, s_ = alpha_sigma(fn(t).reshape(-1, 1, 1, 1))
+                noised = a * known + s_ * noise_fn(("inpaint", stage, i, r), shape)       # ip.py:2244-2246
+                img = img * ~mask + noised * mask
+            pred = denoise(img, fn(t))
+            tag = ("step", stage, i, r) if inpainting else ("step", stage, i)
+            img, _ = ddpm_step(img, pred, t, t_next, noise_fn(tag, shape), schedule, dynamic_thresholding, percentile)
+            if inpainting and not (r == 0 or last_t):
+                img = q_sample_from_to(img, t_next, t, noise_fn(("renoise", stage, i, r), shape), schedule)   # ip.py:2268-2275
+            if trace is not None:
+                trace.append(img.clone())
+    img = img.clamp(-1.0, 1.0)
+    if inpainting:
+        img = img * ~mask + known * mask                                    # ip.py:2283-2286
+    return (img + 1) * 0.5
 
 
 def imagen_sample(
@@ -130,8 +169,13 @@ def imagen_sample(
     noise_fn: Optional[Callable] = None,
     max_steps: Optional[int] = None,
     return_all: bool = False,
+    init_images=None,                 # one [0, 1] image batch (or None) per unet, or a single batch for all   (ip.py:2390-2393)
+    skip_steps=None,                  # int (or None) per unet
+    inpaint_images: Optional[Tensor] = None,   # [0, 1] images, same for every stage
+    inpaint_masks: Optional[Tensor] = None,    # (B, H, W) bool
+    inpaint_resample_times: int = 5,
 ):
-    """ip.py:2291-2498 for text_embeds-conditioned image sampling (no inpainting/init images/video)."""
+    """ip.py:2291-2498 for text_embeds-conditioned image sampling (no video, no cond_images, no self-conditioning)."""
     n = len(unets)
     timesteps = timesteps if isinstance(timesteps, (list, tuple)) else (timesteps,) * n
     cond_scale = cond_scale if isinstance(cond_scale, (list, tuple)) else (cond_scale,) * n
@@ -141,6 +185,10 @@ def imagen_sample(
     if text_masks is None:
         text_masks = torch.any(text_embeds != 0.0, dim=-1)  # ip.py:2337
     b = text_embeds.shape[0]
+    as_tuple = lambda v: tuple(v) if isinstance(v, (list, tuple)) else (v,) * n
+    init_images = [None if im is None else im * 2 - 1 for im in as_tuple(init_images)]   # normalize_img, ip.py:2391
+    skip_steps = as_tuple(skip_steps)
+    known = None if inpaint_images is None else inpaint_images * 2 - 1                   # ip.py:2218
     outputs, img = [], None
     for stage, ((sd, kw), size, T, cs, sched) in enumerate(zip(unets, image_sizes, timesteps, cond_scale, schedules)):
         lowres_img = lowres_times = None
@@ -158,6 +206,7 @@ def imagen_sample(
 
         img = p_sample_loop(denoise, (b, channels, size, size), schedule=sched, num_timesteps=T, noise_fn=noise_fn,
                             stage=stage, dynamic_thresholding=dynamic_thresholding, percentile=percentile,
-                            max_steps=max_steps)
+                            max_steps=max_steps, init_images=init_images[stage], skip_steps=skip_steps[stage], inpaint_images=known,
+                            inpaint_masks=inpaint_masks, inpaint_resample_times=inpaint_resample_times)
         outputs.append(img)
     return outputs if return_all else outputs[-1]

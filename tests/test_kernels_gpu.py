@@ -490,6 +490,44 @@ def test_ddpm_step_vs_formula(ops, dev):
             assert nerr(final, (ref.clamp(-1, 1) + 1) * 0.5) < 1e-5
 
 
+def test_lincomb_masked_blend_and_counter(ops, dev):
+    """LINCOMB: out = mask ? w0*t0 + w1*t1 + w4*z : mask_else, in place, row picked by the device counter; `advance` bumps it,
+    a DDPM_UPDATE with advance=False leaves it alone (the inpainting step sequence of Imagen._stage)."""
+    torch.manual_seed(21)
+    B, n = 2, 3 * 16 * 16
+    known, noise, x = torch.randn(B, n), torch.randn(B, n), torch.randn(B, n)
+    mask = (torch.rand(B, n) > 0.4).float()
+    coef = torch.zeros(3, 8)
+    coef[:, 0] = torch.tensor([0.3, 0.6, 0.9])
+    coef[:, 1] = torch.tensor([0.8, 0.5, 0.2])
+    step = torch.tensor([1], dtype=torch.int32, device=dev)
+    xd = x.to(dev)
+    plan = ops.Plan()
+    ops.lincomb(plan, known.to(dev), xd, coef.to(dev), step, B=B, n_per_sample=n, t1=noise.to(dev), mask=mask.to(dev), mask_else=xd)
+    _run(plan)
+    ref = torch.where(mask != 0, 0.6 * known + 0.5 * noise, x)
+    assert torch.allclose(xd.cpu(), ref, atol=1e-6) and int(step.item()) == 1
+    # Philox column: masked-out elements untouched, the others get fresh unit-variance noise on top of w0*t0
+    coef2 = torch.zeros(3, 8)
+    coef2[:, 0], coef2[:, 4] = 1.0, 2.0
+    big = torch.zeros(1, 1 << 18, device=dev)
+    m2 = (torch.rand(1, 1 << 18) > 0.5).float().to(dev)
+    plan = ops.Plan()
+    ops.lincomb(plan, big, big, coef2.to(dev), step, B=1, n_per_sample=1 << 18, mask=m2, mask_else=big, advance=True, seed=3, stream_id=0x100)
+    _run(plan)
+    assert int(step.item()) == 2
+    z = big[m2 != 0]
+    assert (big[m2 == 0] == 0).all() and abs(z.std().item() - 2.0) < 0.02 and abs(z.mean().item()) < 0.02
+    # posterior step that keeps the counter
+    x0 = torch.zeros(B, n, device=dev)
+    c3 = torch.tensor([[1.0, 0.0, 1.0, 1.0, 1.0, 1.0, 0.0, 0.0]] * 3, device=dev)
+    plan = ops.Plan()
+    ops.ddpm_update(plan, xd, x0, None, c3, None, None, step, B=B, n_per_sample=n, dynamic_threshold=False, total_steps=3, seed=1,
+                    stream_id=0, advance=False)
+    _run(plan)
+    assert int(step.item()) == 2
+
+
 def test_philox_normal_statistics(ops, dev):
     B, n = 1, 1 << 20
     x = torch.zeros(B, n, device=dev)

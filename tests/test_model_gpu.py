@@ -145,6 +145,51 @@ def test_sample_vs_reference_fixture():
         assert torch.equal(a, b), "hipGraph replay must be bit-identical to eager launches"
 
 
+def _tiny_cascade(g, dev, timesteps):
+    from imagen_pytorch_amd import Imagen, Unet
+
+    unets = [Unet(**spec["kwargs"]).eval() for spec in g["unets"]]
+    imagen = Imagen(unets, image_sizes=g["image_sizes"], timesteps=timesteps, text_embed_dim=32, cond_drop_prob=0.1).to(dev)
+    for u, spec in zip(imagen.unets, g["unets"]):   # cast_model_parameters may have re-instantiated: (re)load
+        u.load_state_dict(spec["state_dict"])
+    return imagen
+
+
+@pytest.mark.parametrize("run", ["init_skip", "inpaint"])
+def test_sample_options_vs_reference_fixture(run):
+    """The p_sample_loop options outside the BASELINE configs (ip.py:2167-2289): init_images + skip_steps, and
+    RePaint-style inpainting with resampling, vs recorded runs of the live reference fed the same Gaussian draws."""
+    dev = torch.device("cuda:0")
+    g = _load("sample_tiny_options.pt")
+    r = g["runs"][run]
+    imagen = _tiny_cascade(g, dev, g["timesteps"])
+    kw = {k: (r[k].to(dev) if torch.is_tensor(r[k]) else r[k])
+          for k in ("init_images", "skip_steps", "inpaint_images", "inpaint_masks", "inpaint_resample_times") if k in r}
+    noise_fn = lambda tag, shape: r["noise"][tag].to(dev)
+    results = {}
+    for use_graph in (False, True):
+        outs = imagen.sample(text_embeds=g["text_embeds"].to(dev), cond_scale=g["cond_scale"], use_tqdm=False, return_all_unet_outputs=True,
+                             noise_fn=noise_fn, use_graph=use_graph, **kw)
+        errs = [nerr(o, ref) for o, ref in zip(outs, r["outputs"])]
+        print(run, "graph" if use_graph else "eager", errs)
+        assert max(errs) < 2e-2, errs     # same bar as test_sample_vs_reference_fixture
+        results[use_graph] = outs
+    for a, b in zip(results[False], results[True]):
+        assert torch.equal(a, b), "hipGraph replay must be bit-identical to eager launches"
+    if run == "inpaint":
+        # known pixels are pasted back exactly (ip.py:2283-2286); Philox path: deterministic per seed, pastes too
+        m = r["inpaint_masks"][:, None].expand(-1, 3, -1, -1)
+        assert torch.allclose(results[True][-1].cpu()[m], r["inpaint_images"][m], atol=1e-6)
+        a = imagen.sample(text_embeds=g["text_embeds"].to(dev), cond_scale=3.0, use_tqdm=False, seed=4, **kw)
+        b = imagen.sample(text_embeds=g["text_embeds"].to(dev), cond_scale=3.0, use_tqdm=False, seed=4, **kw)
+        c = imagen.sample(text_embeds=g["text_embeds"].to(dev), cond_scale=3.0, use_tqdm=False, seed=5, **kw)
+        assert torch.equal(a, b) and not torch.equal(a, c) and torch.isfinite(a).all()
+        assert torch.allclose(a.cpu()[m], r["inpaint_images"][m], atol=1e-6)
+        # ... and the unmasked sampler is untouched by the inpainting plans cached on the same module
+        plain = imagen.sample(text_embeds=g["text_embeds"].to(dev), cond_scale=3.0, use_tqdm=False, seed=4)
+        assert not torch.equal(plain, a) and torch.isfinite(plain).all()
+
+
 def test_sample_philox_determinism_and_sharding():
     """In-kernel Philox noise: same seed -> identical images; noise is keyed by the GLOBAL sample index, so a batch
     shard (sample_offset) reproduces the corresponding rows of the unsharded run (SURVEY.md §8e parity test)."""

@@ -40,6 +40,46 @@ def test_sampler_oracle_matches_reference_fixture():
         assert torch.allclose(got, ref, atol=2e-4), (got - ref).abs().max()
 
 
+@pytest.mark.parametrize("run", ["init_skip", "inpaint"])
+def test_sampler_oracle_options_match_reference_fixture(run):
+    """init_images + skip_steps, and the inpainting resample loop (ip.py:2167-2289), vs recorded runs of the live reference."""
+    g = _load("sample_tiny_options.pt")
+    r = g["runs"][run]
+    unets = [(u["state_dict"], u["kwargs"]) for u in g["unets"]]
+    kw = {k: r[k] for k in ("init_images", "skip_steps", "inpaint_images", "inpaint_masks", "inpaint_resample_times") if k in r}
+    with torch.no_grad():
+        outs = so.imagen_sample(unets, g["image_sizes"], g["text_embeds"], timesteps=g["timesteps"], cond_scale=g["cond_scale"],
+                                noise_fn=lambda tag, shape: r["noise"][tag], return_all=True, **kw)
+    for got, ref in zip(outs, r["outputs"]):
+        assert got.shape == ref.shape
+        assert torch.allclose(got, ref, atol=2e-4), (got - ref).abs().max()
+
+
+def test_inpaint_tables_match_oracle():
+    """schedules.inpaint_coefficients vs the oracle's q_sample / q_sample_from_to on a probe image."""
+    from imagen_pytorch_amd.schedules import GaussianDiffusionContinuousTimes
+
+    T, R = 5, 3
+    sch = GaussianDiffusionContinuousTimes(noise_schedule="cosine", timesteps=T)
+    step, blend, renoise = sch.inpaint_coefficients(R, philox=True)
+    assert step.shape == blend.shape == renoise.shape == (T * R, 8)
+    assert torch.equal(step, sch.step_coefficients().repeat_interleave(R, dim=0))
+    x, z = torch.randn(1, 3, 4, 4), torch.randn(1, 3, 4, 4)
+    row = 0
+    for i, (t, tn) in enumerate(so.sampling_time_pairs(T)):
+        for r in reversed(range(R)):
+            a, s = so.alpha_sigma(so.SCHEDULES["cosine"](t))
+            assert torch.allclose(blend[row, 0] * x + blend[row, 4] * z, a * x + s * z, atol=1e-6)
+            if r == 0 or i == T - 1:
+                assert renoise[row].tolist() == [1.0, 0, 0, 0, 0, 0, 0, 0]
+            else:
+                ref = so.q_sample_from_to(x, tn.reshape(1), t.reshape(1), z, "cosine")
+                assert torch.allclose(renoise[row, 0] * x + renoise[row, 4] * z, ref, atol=1e-6)
+            row += 1
+    _, b1, q1 = sch.inpaint_coefficients(R, philox=False)     # injected noise: the weight moves to column 1
+    assert torch.equal(b1[:, 1], blend[:, 4]) and torch.equal(q1[:, 1], renoise[:, 4]) and not b1[:, 4].any() and not q1[:, 4].any()
+
+
 def test_schedule_tables_match_oracle():
     """Host coefficient table (imagen-pytorch_amd/schedules.py) vs the oracle's per-step formulas."""
     from imagen_pytorch_amd.schedules import GaussianDiffusionContinuousTimes
