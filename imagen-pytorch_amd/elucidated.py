@@ -273,6 +273,7 @@ class ElucidatedImagen(Imagen):
         sample_offset: int = 0,
         use_graph: bool = True,
         max_steps: Optional[int] = None,
+        conditioning=None,
     ):
         if sigma_min is not None or sigma_max is not None:
             _out_of_scope("sample(sigma_min=/sigma_max=) per-call overrides (set them on the constructor)")
@@ -282,10 +283,17 @@ class ElucidatedImagen(Imagen):
         was_training = self.training
         self.eval()
         try:
+            self._conditioning = conditioning
+            if conditioning is not None:
+                assert texts is None and text_embeds is None and text_masks is None, 'pass either `conditioning` or texts / text_embeds'
+                text_embeds, text_masks = conditioning.text_embeds, conditioning.text_masks
+                if text_embeds is None:
+                    batch_size = conditioning.batch_size
             return self._sample(texts, text_masks, text_embeds, video_frames, cond_images, cond_video_frames, post_cond_video_frames,
                                 inpaint_videos, inpaint_images, inpaint_masks, inpaint_resample_times, init_images, skip_steps, batch_size,
                                 cond_scale, lowres_sample_noise_level, start_at_unet_number, start_image_or_video, stop_at_unet_number,
                                 return_all_unet_outputs, return_pil_images, device, use_tqdm, noise_fn, seed, sample_offset, use_graph,
                                 max_steps)
         finally:
+            self._conditioning = None
             self.train(was_training)

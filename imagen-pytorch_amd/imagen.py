@@ -11,6 +11,7 @@ outside the hot-path scope and raise.
 """
 from __future__ import annotations
 
+import functools
 import os
 from typing import Callable, List, Optional
 
@@ -21,6 +22,7 @@ from torch import nn
 from . import ops
 from .ops import Plan
 from .schedules import GaussianDiffusionContinuousTimes
+from .t5 import t5_encode_text
 from .unet import NullUnet, Unet
 
 T5_DIMS = {  # d_model of the encoders the reference accepts by name (t5.py:47-58 reads it from the HF config)
@@ -48,6 +50,20 @@ def _pad_tuple(t, length, fill):
 
 def _out_of_scope(what):
     raise NotImplementedError(f"{what} is outside the MI355X sampling hot path of this build (SURVEY.md §2 / §8)")
+
+
+class Conditioning:
+    """Handle on the timestep-invariant conditioning of a batch of prompts (SURVEY.md §8(f) NEXT-3).
+
+    Everything the denoiser derives from the text alone — projected tokens, Perceiver-pooled latents, the non-attention text
+    hidden, and the cross-attention K/V of every site (ip.py:1595-1660, 793-808) — is computed by the engines' static plan,
+    once per `sample()` call.  Passing the SAME handle to several `sample(conditioning=...)` calls (more seeds for the same
+    prompts, `start_at_unet_number` re-runs, ...) lets each stage keep what its static plan wrote the first time: the engine
+    buffers are stamped with the handle's token and the static plan is skipped while the stamp matches."""
+
+    def __init__(self, text_embeds: Optional[torch.Tensor], text_masks: Optional[torch.Tensor], batch_size: int):
+        self.text_embeds, self.text_masks, self.batch_size = text_embeds, text_masks, batch_size
+        self.token = object()
 
 
 class Imagen(nn.Module):
@@ -100,6 +116,8 @@ class Imagen(nn.Module):
         self.pred_objectives = _cast_tuple(pred_objectives, num_unets)
 
         self.text_encoder_name = text_encoder_name
+        # hook of sample(texts=...), ip.py:1832 / 2326-2332; replace it to plug in another encoder
+        self.encode_text = functools.partial(t5_encode_text, name=text_encoder_name)
         if text_embed_dim is None:
             if text_encoder_name not in T5_DIMS:
                 raise ValueError(f"unknown text encoder '{text_encoder_name}': pass text_embed_dim explicitly")
@@ -344,17 +362,48 @@ class Imagen(nn.Module):
         sample_offset: int = 0,                # extension: global index of sample 0 (batch sharding)
         use_graph: bool = True,
         max_steps: Optional[int] = None,
+        conditioning: Optional[Conditioning] = None,   # extension: handle from prepare_conditioning() instead of texts / text_embeds
     ):
         was_training = self.training
         self.eval()
         try:
+            self._conditioning = conditioning
+            if conditioning is not None:
+                assert texts is None and text_embeds is None and text_masks is None, 'pass either `conditioning` or texts / text_embeds'
+                text_embeds, text_masks = conditioning.text_embeds, conditioning.text_masks
+                if text_embeds is None:
+                    batch_size = conditioning.batch_size
             return self._sample(texts, text_masks, text_embeds, video_frames, cond_images, cond_video_frames, post_cond_video_frames,
                                 inpaint_videos, inpaint_images, inpaint_masks, inpaint_resample_times, init_images, skip_steps, batch_size,
                                 cond_scale, lowres_sample_noise_level, start_at_unet_number, start_image_or_video, stop_at_unet_number,
                                 return_all_unet_outputs, return_pil_images, device, use_tqdm, noise_fn, seed, sample_offset, use_graph,
                                 max_steps)
         finally:
+            self._conditioning = None
             self.train(was_training)
+
+    def _resolve_text(self, texts, text_embeds, text_masks, device):
+        """ip.py:2326-2337: texts -> encoder hook; default mask = any non-zero feature."""
+        if texts is not None and text_embeds is None and not self.unconditional:
+            assert all([*map(len, texts)]), 'text cannot be empty'
+            text_embeds, text_masks = self.encode_text(texts, return_attn_mask=True)
+        if not self.unconditional:
+            assert text_embeds is not None, 'text must be passed in if the network was not trained without text `condition_on_text` must be set to `False` when training'
+            text_embeds = text_embeds.to(device)
+            text_masks = text_masks.to(device) if text_masks is not None else torch.any(text_embeds != 0., dim=-1)
+        return text_embeds, text_masks
+
+    @torch.no_grad()
+    def prepare_conditioning(self, texts: Optional[List[str]] = None, *, text_embeds=None, text_masks=None, batch_size: int = 1,
+                             device=None) -> Conditioning:
+        """Encode / stage the prompts once; reuse the returned handle with `sample(conditioning=handle, ...)`."""
+        device = torch.device(device) if device is not None else self.device
+        text_embeds, text_masks = self._resolve_text(texts, text_embeds, text_masks, device)
+        assert not (self.condition_on_text and text_embeds is None), 'text or text encodings must be passed into imagen if specified'
+        assert not (not self.condition_on_text and text_embeds is not None), 'imagen specified not to be conditioned on text, yet it is presented'
+        assert not (text_embeds is not None and text_embeds.shape[-1] != self.text_embed_dim), \
+            f'invalid text embedding dimension being passed in (should be {self.text_embed_dim})'
+        return Conditioning(text_embeds, text_masks, text_embeds.shape[0] if text_embeds is not None else batch_size)
 
     def _sample(self, texts, text_masks, text_embeds, video_frames, cond_images, cond_video_frames, post_cond_video_frames,
                 inpaint_videos, inpaint_images, inpaint_masks, inpaint_resample_times, init_images, skip_steps, batch_size, cond_scale,
@@ -364,8 +413,6 @@ class Imagen(nn.Module):
         if device.type != 'cuda':
             raise RuntimeError("imagen_pytorch_amd.Imagen.sample runs on MI355X only (move the module to 'cuda'); there is no CPU path")
         self.reset_unets_all_one_device(device)
-        if texts is not None and text_embeds is None and not self.unconditional:
-            _out_of_scope("T5 text encoding (`texts=`): pass precomputed `text_embeds=`")
         for name, val in (('video_frames', video_frames), ('cond_images', cond_images), ('cond_video_frames', cond_video_frames),
                           ('post_cond_video_frames', post_cond_video_frames), ('inpaint_videos', inpaint_videos)):
             if val is not None:
@@ -373,11 +420,8 @@ class Imagen(nn.Module):
         if return_pil_images:
             _out_of_scope("return_pil_images (torchvision is not part of this stack)")
 
+        text_embeds, text_masks = self._resolve_text(texts, text_embeds, text_masks, device)
         if not self.unconditional:
-            assert text_embeds is not None, 'text must be passed in if the network was not trained without text `condition_on_text` must be set to `False` when training'
-            text_embeds = text_embeds.to(device)
-            if text_masks is None:
-                text_masks = torch.any(text_embeds != 0., dim=-1)    # ip.py:2337
             batch_size = text_embeds.shape[0]
         if inpaint_images is not None:                   # ip.py:2344-2351
             if self.unconditional and batch_size == 1:
@@ -458,8 +502,13 @@ class Imagen(nn.Module):
                 keep = torch.ones(rows, dtype=torch.bool)
                 if rows == 2 * batch_size:
                     keep[batch_size:] = False            # second half = null-conditioned CFG branch (cond_drop_prob = 1, ip.py:1521)
-                eng.set_conditioning(text_embeds=text_embeds if with_text else None, text_mask=text_masks if with_text else None,
-                                     keep=keep, lowres_noise_times=lowres_logsnr)
+                cond = getattr(self, '_conditioning', None)
+                stamp = None if cond is None else (cond.token, None if lowres_logsnr is None else float(lowres_logsnr[0]))
+                if stamp is None or getattr(eng, '_cond_stamp', None) != stamp:
+                    eng.set_conditioning(text_embeds=text_embeds if with_text else None, text_mask=text_masks if with_text else None,
+                                         keep=keep, lowres_noise_times=lowres_logsnr)
+                    eng.static_runs = getattr(eng, 'static_runs', 0) + 1
+                eng._cond_stamp = stamp
                 timing = os.environ.get("IMAGEN_TIMING")
                 if timing:
                     self._stream.synchronize()

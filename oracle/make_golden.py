@@ -235,8 +235,46 @@ def make_sample_options_fixture(ip, path, seed=13, T=3, R=2, skip=1):
         print(f"wrote {path} [{k}]: out std {r['outputs'][-1].std():.4f}, {len(r['noise'])} draws")
 
 
+def make_checkpoint_fixture(ip, path, seed=17, T=2):
+    """A trainer-format checkpoint (tr.py:696-741) of a one-unet Imagen built by the reference's own `ImagenConfig(...).create()`,
+    plus what the reference samples from its plain and from its EMA weights.  ema_pytorch is not installed, so the `ema` entry is
+    laid out by hand as `nn.ModuleList([EMA(unet)]).state_dict()` would be ({i}.online_model.*, {i}.ema_model.*, {i}.initted,
+    {i}.step); the EMA weights are a perturbed copy so that loading the wrong set is visible."""
+    cfg = load_reference("configs")
+    torch.manual_seed(seed)
+    unet_kw = {k: (list(v) if k == "dim_mults" else v) for k, v in TINY_BASE.items()}
+    params = dict(unets=[unet_kw], image_sizes=[16], timesteps=T, text_embed_dim=32, cond_drop_prob=0.1)
+    imagen = cfg.ImagenConfig(**params).create().eval()
+    _derandomise(imagen.unets[0])
+    model_sd = {k: v.clone() for k, v in imagen.state_dict().items()}
+    unet_sd = {k: v.clone() for k, v in imagen.unets[0].state_dict().items()}
+    ema_sd = {k: (v * 0.9 + 0.02 * torch.randn_like(v) if v.is_floating_point() else v.clone()) for k, v in unet_sd.items()}
+    ema = {f"0.online_model.{k}": v for k, v in unet_sd.items()}
+    ema.update({f"0.ema_model.{k}": v for k, v in ema_sd.items()})
+    ema["0.initted"], ema["0.step"] = torch.tensor([True]), torch.tensor([12])
+    version = load_reference("version").__version__
+    ckpt = dict(model=model_sd, version=version, steps=torch.tensor([12.]), ema=ema, imagen_type="original", imagen_params=imagen._config)
+    text_embeds = torch.randn(2, 9, 32)
+    expected = {}
+    for which, sd in (("model", unet_sd), ("ema", ema_sd)):
+        imagen.unets[0].load_state_dict(sd)
+        out, draws = _record_draws(lambda: imagen.sample(text_embeds=text_embeds, cond_scale=3., use_tqdm=False))
+        noise = {("init", 0): draws[0], **{("step", 0, i): d for i, d in enumerate(draws[1:])}}
+        assert len(draws) == T + 1
+        expected[which] = dict(output=out.clone(), noise=noise)
+    el = cfg.ElucidatedImagenConfig(unets=[unet_kw], image_sizes=[16], text_embed_dim=32).create()
+    torch.save(dict(checkpoint=ckpt, text_embeds=text_embeds, expected=expected, cond_scale=3., elucidated_config=el._config,
+                    unet_config_defaults=cfg.UnetConfig(dim=8, dim_mults=[1, 2]).dict(),
+                    generator="oracle/make_golden.py --checkpoint",
+                    reference=f"lucidrains/imagen-pytorch v{version}: configs.ImagenConfig.create + ImagenTrainer.save layout (tr.py:696-741)"), path)
+    print(f"wrote {path}: {len(model_sd)} model tensors, {len(ema)} ema entries, out std {expected['ema']['output'].std():.4f}")
+
+
 def main():
     ip = load_reference()
+    if "--checkpoint" in sys.argv:   # only the checkpoint-interchange fixture (SURVEY §8(f) NEXT-4)
+        make_checkpoint_fixture(ip, os.path.join(GOLDEN, "checkpoint_tiny.pt"))
+        return
     if "--options" in sys.argv:      # only the p_sample_loop-options fixture
         make_sample_options_fixture(ip, os.path.join(GOLDEN, "sample_tiny_options.pt"))
         return

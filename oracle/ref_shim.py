@@ -27,7 +27,7 @@ _cached = {}
 
 
 def load_reference(module: str = "imagen_pytorch"):
-    """Return the reference module `imagen_pytorch.<module>` (imagen_pytorch | elucidated_imagen | imagen_video)."""
+    """Return the reference module `imagen_pytorch.<module>` (imagen_pytorch | elucidated_imagen | imagen_video | configs)."""
     if module in _cached:
         return _cached[module]
     if not reference_available():
@@ -58,6 +58,19 @@ def load_reference(module: str = "imagen_pytorch"):
     ko = _stub("kornia")
     ka = _stub("kornia.augmentation", RandomCrop=None)
     ko.augmentation = ka
+
+    if module in ("configs", "trainer", "utils"):
+        # checkpoint-format fixtures only (oracle/make_golden.py --checkpoint): the trainer module's absent dependencies are
+        # stubbed so `configs.ImagenConfig(...).create()` runs; no trainer / EMA object is ever constructed through these stubs
+        import torch.nn as _nn
+
+        class _AbsentEMA(_nn.Module):
+            def __init__(self, *a, **k):
+                raise RuntimeError("ema_pytorch is not installed in this image (stub)")
+
+        _stub("ema_pytorch", EMA=_AbsentEMA)
+        _stub("pytorch_warmup")
+        _stub("imagen_pytorch.data", cycle=None)   # the data loaders pull in `datasets`, which rejects the torchvision stub
 
     if "imagen_pytorch" not in sys.modules or not hasattr(sys.modules["imagen_pytorch"], "__path__"):
         pkg = types.ModuleType("imagen_pytorch")

@@ -261,3 +261,40 @@ def test_elucidated_step_tables_match_oracle():
             assert math.isclose(got, ref_x, rel_tol=1e-4, abs_tol=1e-4)
         else:
             assert i == len(table) - 1 and w_euler[2 * i, 0].item() == 0.0 and w_euler[2 * i, 1].item() == 1.0
+
+
+def test_text_encoder_hook_and_conditioning_handle():
+    """sample(texts=...) goes through the `encode_text` hook (ip.py:2326-2332); prepare_conditioning() stages prompts once.
+    Host logic only: no kernel runs here."""
+    from imagen_pytorch_amd import Conditioning, Imagen, Unet
+
+    kw = dict(dim=8, cond_dim=32, text_embed_dim=32, dim_mults=(1, 2), num_resnet_blocks=1, layer_attns=(False, True),
+              layer_cross_attns=(False, True), attn_heads=2, max_text_len=16, attn_pool_num_latents=8)
+    imagen = Imagen([Unet(**kw)], image_sizes=(16,), timesteps=2, text_embed_dim=32)
+    calls = []
+
+    def fake_encoder(texts, return_attn_mask=False):
+        calls.append(list(texts))
+        emb = torch.zeros(len(texts), 5, 32)
+        for i, t in enumerate(texts):
+            emb[i, : len(t.split())] = 1.0 + i
+        mask = emb.abs().sum(-1) > 0
+        return (emb, mask) if return_attn_mask else emb
+
+    imagen.encode_text = fake_encoder
+    emb, mask = imagen._resolve_text(["a b c", "d"], None, None, torch.device("cpu"))
+    assert calls == [["a b c", "d"]] and emb.shape == (2, 5, 32) and mask.tolist() == [[True] * 3 + [False] * 2, [True] + [False] * 4]
+    with pytest.raises(AssertionError, match="text cannot be empty"):
+        imagen._resolve_text(["ok", ""], None, None, torch.device("cpu"))
+    # precomputed embeddings bypass the hook; the default mask is "any non-zero feature" (ip.py:2337)
+    emb2, mask2 = imagen._resolve_text(None, emb, None, torch.device("cpu"))
+    assert len(calls) == 1 and torch.equal(mask2, mask)
+    c = imagen.prepare_conditioning(["x y", "z"], device="cpu")
+    assert isinstance(c, Conditioning) and c.batch_size == 2 and c.text_embeds.shape == (2, 5, 32) and len(calls) == 2
+    assert imagen.prepare_conditioning(text_embeds=emb, device="cpu").token is not c.token
+    with pytest.raises(AssertionError, match="invalid text embedding dimension"):
+        imagen.prepare_conditioning(text_embeds=torch.zeros(1, 3, 7), device="cpu")
+    # the default hook needs T5 weights on local disk: absent here -> a loud, actionable error (never the network)
+    fresh = Imagen([Unet(**kw)], image_sizes=(16,), timesteps=2, text_embed_dim=32, text_encoder_name="google/t5-v1_1-small")
+    with pytest.raises(RuntimeError, match="not available from local files"):
+        fresh.encode_text(["hello"], return_attn_mask=True)

@@ -190,6 +190,55 @@ def test_sample_options_vs_reference_fixture(run):
         assert not torch.equal(plain, a) and torch.isfinite(plain).all()
 
 
+@pytest.mark.parametrize("which", ["model", "ema"])
+def test_sample_from_reference_trainer_checkpoint(which, tmp_path):
+    """SURVEY §8(f) NEXT-4: a trainer-format checkpoint written for the reference (config + plain + EMA weights) is loaded by
+    load_imagen_from_checkpoint and sampled on the HIP path; the image matches what the reference sampled from the same weights."""
+    from imagen_pytorch_amd import load_imagen_from_checkpoint
+
+    dev = torch.device("cuda:0")
+    g = _load("checkpoint_tiny.pt")
+    path = tmp_path / "ckpt.pt"
+    torch.save(g["checkpoint"], str(path))
+    imagen = load_imagen_from_checkpoint(path, load_ema_if_available=which == "ema").to(dev)
+    exp = g["expected"][which]
+    out = imagen.sample(text_embeds=g["text_embeds"].to(dev), cond_scale=g["cond_scale"], use_tqdm=False,
+                        noise_fn=lambda tag, shape: exp["noise"][tag].to(dev))
+    e = nerr(out, exp["output"])
+    cross = nerr(out, g["expected"]["ema" if which == "model" else "model"]["output"])
+    print(f"checkpoint[{which}] sample vs reference: {e:.2e} (vs the other weight set: {cross:.2e})")
+    assert e < 2e-2 and cross > 5 * e
+
+
+def test_conditioning_handle_skips_static_plan():
+    """SURVEY §8(f) NEXT-3: the same Conditioning handle over several sample() calls runs each stage's timestep-invariant plan
+    once; images are bit-identical to passing text_embeds every time.  texts= goes through the encode_text hook."""
+    dev = torch.device("cuda:0")
+    g = _load("sample_tiny_cascade.pt")
+    imagen = _tiny_cascade(g, dev, 3)
+    te = g["text_embeds"].to(dev)
+    ref1 = imagen.sample(text_embeds=te, cond_scale=3.0, use_tqdm=False, seed=1)
+    ref2 = imagen.sample(text_embeds=te, cond_scale=3.0, use_tqdm=False, seed=2)
+    engines = [st["eng"] for st in imagen._stages.values()]
+    base = [e.static_runs for e in engines]
+    assert base == [2, 2]
+    cond = imagen.prepare_conditioning(text_embeds=te)
+    a1 = imagen.sample(conditioning=cond, cond_scale=3.0, use_tqdm=False, seed=1)
+    a2 = imagen.sample(conditioning=cond, cond_scale=3.0, use_tqdm=False, seed=2)
+    assert torch.equal(a1, ref1) and torch.equal(a2, ref2)
+    assert [e.static_runs for e in engines] == [b + 1 for b in base], "second call with the same handle must reuse the staged conditioning"
+    # a different handle (other prompts) re-stages; so does a plain text_embeds call in between
+    other = imagen.prepare_conditioning(text_embeds=te.flip(0))
+    b1 = imagen.sample(conditioning=other, cond_scale=3.0, use_tqdm=False, seed=1)
+    assert not torch.equal(b1, ref1) and torch.isfinite(b1).all()
+    a3 = imagen.sample(conditioning=cond, cond_scale=3.0, use_tqdm=False, seed=1)
+    assert torch.equal(a3, ref1)
+    # texts= through the hook
+    imagen.encode_text = lambda texts, return_attn_mask=False: (te, torch.ones(te.shape[:2], dtype=torch.bool, device=dev))
+    t1 = imagen.sample(texts=["first prompt", "second prompt"], cond_scale=3.0, use_tqdm=False, seed=1)
+    assert torch.equal(t1, ref1)
+
+
 def test_sample_philox_determinism_and_sharding():
     """In-kernel Philox noise: same seed -> identical images; noise is keyed by the GLOBAL sample index, so a batch
     shard (sample_offset) reproduces the corresponding rows of the unsharded run (SURVEY.md §8e parity test)."""
