@@ -157,6 +157,50 @@ def make_elucidated_fixture(ip, el, path, seed=9):
     print(f"wrote {path}: out std {outs[-1].std():.4f}")
 
 
+TINY_3D = dict(dim=8, cond_dim=32, text_embed_dim=32, dim_mults=(1, 2), num_resnet_blocks=1, layer_attns=(False, True),
+               layer_cross_attns=(False, True), attn_heads=2, attn_dim_head=64, max_text_len=16, attn_pool_num_latents=8,
+               temporal_strides=(1, 2))
+
+
+def derandomise_unet3d(unet):
+    """Unet3D starts as an image Unet applied per frame: zero final_conv (iv.py:1578), dirac temporal convs (iv.py:415-417),
+    zero out-norm gain of every temporal attention (`init_zero`, iv.py:496-497).  Randomise all three so the temporal paths count."""
+    g = torch.Generator().manual_seed(1234)
+    for name, prm in unet.named_parameters():
+        if name.startswith("final_conv.") or ".temporal_conv." in name:
+            prm.data.copy_(torch.randn(prm.shape, generator=g) * 0.3)
+        elif name.endswith("fn.fn.to_out.1.g"):
+            prm.data.copy_(1.0 + 0.2 * torch.randn(prm.shape, generator=g))
+
+
+def make_unet3d_fixture(iv, path, seed=21):
+    """Unet3D.forward of the live reference on a tiny clip (2 x 3 x 4 frames x 16 x 16), base and low-res-conditioned variants,
+    plus `ignore_time` (the per-frame image path, iv.py:1736-1738)."""
+    runs = {}
+    for tag, kw in (("base", TINY_3D), ("sr", {**TINY_3D, "lowres_cond": True, "num_resnet_blocks": (1, 2)})):
+        torch.manual_seed(seed)
+        unet = iv.Unet3D(**kw).eval()
+        derandomise_unet3d(unet)
+        B, Fr, S = 2, 4, 16
+        x = torch.randn(B, 3, Fr, S, S)
+        time = torch.tensor([0.7, -2.3])
+        text_embeds = torch.randn(B, 11, 32)
+        text_mask = torch.ones(B, 11, dtype=torch.bool)
+        text_mask[1, 7:] = False
+        extra = dict(lowres_cond_img=torch.randn(B, 3, Fr, S, S), lowres_noise_times=torch.tensor([1.1, 1.1])) if kw.get("lowres_cond") else {}
+        with torch.no_grad():
+            out_cond = unet(x, time, text_embeds=text_embeds, text_mask=text_mask, **extra)
+            out_null = unet(x, time, text_embeds=text_embeds, text_mask=text_mask, cond_drop_prob=1., **extra)
+            out_cfg = unet.forward_with_cond_scale(x, time, text_embeds=text_embeds, text_mask=text_mask, cond_scale=3., **extra)
+            out_notime = unet(x, time, text_embeds=text_embeds, text_mask=text_mask, ignore_time=True, **extra)
+        runs[tag] = dict(kwargs=kw, state_dict={k: v.clone() for k, v in unet.state_dict().items()}, x=x, time=time, text_embeds=text_embeds,
+                         text_mask=text_mask, extra=extra, out_cond=out_cond, out_null=out_null, out_cfg=out_cfg, out_notime=out_notime)
+        print(f"unet3d[{tag}]: |out_cond| = {out_cond.abs().mean():.4f}, |cond - ignore_time| = {(out_cond - out_notime).abs().mean():.4f}")
+    torch.save(dict(runs=runs, generator="oracle/make_golden.py --unet3d",
+                    reference="lucidrains/imagen-pytorch v2.0.0 Unet3D.forward (imagen_video.py:1650-1941)"), path)
+    print(f"wrote {path}")
+
+
 def _record_draws(fn):
     """Run fn() with torch.randn / randn_like recording every Gaussian draw, in call order."""
     draws = []
@@ -272,6 +316,9 @@ def make_checkpoint_fixture(ip, path, seed=17, T=2):
 
 def main():
     ip = load_reference()
+    if "--unet3d" in sys.argv:       # only the Imagen-Video denoiser fixture (SURVEY §8(f) NEXT-2 groundwork)
+        make_unet3d_fixture(load_reference("imagen_video"), os.path.join(GOLDEN, "unet3d_tiny.pt"))
+        return
     if "--checkpoint" in sys.argv:   # only the checkpoint-interchange fixture (SURVEY §8(f) NEXT-4)
         make_checkpoint_fixture(ip, os.path.join(GOLDEN, "checkpoint_tiny.pt"))
         return

@@ -6,6 +6,7 @@ import pytest
 import torch
 
 from oracle import sampler_oracle as so
+from oracle import unet3d_oracle as u3
 from oracle import unet_oracle as uo
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
@@ -128,3 +129,20 @@ def test_elucidated_oracle_matches_reference_fixture():
     with torch.no_grad():
         out = eo.one_unet_sample(net, tuple(g["outputs"][1].shape), hp, noise_fn=noise_fn, stage=1)
     assert torch.allclose(out, g["outputs"][1], atol=2e-4), (out - g["outputs"][1]).abs().max()
+
+
+@pytest.mark.parametrize("tag", ["base", "sr"])
+def test_unet3d_oracle_matches_reference_fixture(tag):
+    """SURVEY §8(f) NEXT-2 groundwork: oracle/unet3d_oracle.py vs Unet3D.forward of the live reference (tiny clip, temporal convs /
+    temporal attention / time token shift / temporal down+up-sampling de-initialised so they all contribute)."""
+    g = _load("unet3d_tiny.pt")["runs"][tag]
+    kw = dict(text_embeds=g["text_embeds"], text_mask=g["text_mask"], **g["extra"])
+    with torch.no_grad():
+        cond = u3.unet3d_forward(g["state_dict"], g["kwargs"], g["x"], g["time"], **kw)
+        null = u3.unet3d_forward(g["state_dict"], g["kwargs"], g["x"], g["time"], cond_drop_prob=1.0, **kw)
+        cfg = u3.unet3d_forward_with_cond_scale(g["state_dict"], g["kwargs"], g["x"], g["time"], cond_scale=3.0, **kw)
+        notime = u3.unet3d_forward(g["state_dict"], g["kwargs"], g["x"], g["time"], ignore_time=True, **kw)
+    assert (g["out_cond"] - g["out_notime"]).abs().mean() > 0.5, "vacuous fixture: the temporal layers are still at their identity init"
+    for got, ref in ((cond, g["out_cond"]), (null, g["out_null"]), (cfg, g["out_cfg"]), (notime, g["out_notime"])):
+        assert got.shape == ref.shape and ref.abs().mean() > 0.05
+        assert torch.allclose(got, ref, atol=5e-5, rtol=1e-5), (got - ref).abs().max()

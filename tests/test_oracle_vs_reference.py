@@ -66,3 +66,25 @@ def test_sampler_small_cascade():
     got = so.imagen_sample(unets, (16, 32), te, timesteps=4, cond_scale=3., return_all=True)
     for a, b in zip(ref, got):
         assert torch.allclose(a, b, atol=5e-4), (a - b).abs().max()
+
+
+def test_unet3d_forward_readme_config():
+    """SURVEY §8(f) NEXT-2 groundwork: oracle/unet3d_oracle.py vs the live `Unet3D` at the README video config's structure
+    (`Unet3D(dim = 64, dim_mults = (1, 2, 4, 8))`, README.md:587; here dim 32 and an 8-frame 16x16 clip to keep the CPU test
+    short), with temporal strides and the identity-initialised temporal layers randomised."""
+    from oracle import unet3d_oracle as u3
+    from oracle.make_golden import derandomise_unet3d
+
+    iv = ref_shim.load_reference("imagen_video")
+    kw = dict(dim=32, dim_mults=(1, 2, 4, 8), temporal_strides=(1, 1, 2, 2), layer_attns=(False, False, False, True))
+    torch.manual_seed(0)
+    u = iv.Unet3D(**kw).eval()
+    derandomise_unet3d(u)
+    x, t = torch.randn(1, 3, 8, 16, 16), torch.tensor([0.3])
+    te = torch.randn(1, 20, 768)
+    with torch.no_grad():
+        for cdp in (0.0, 1.0):
+            r = u(x, t, text_embeds=te, cond_drop_prob=cdp)
+            o = u3.unet3d_forward(u.state_dict(), kw, x, t, text_embeds=te, cond_drop_prob=cdp)
+            assert r.abs().mean() > 0.05
+            assert torch.allclose(r, o, atol=1e-4, rtol=1e-4), (r - o).abs().max()
