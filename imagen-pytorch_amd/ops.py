@@ -187,6 +187,12 @@ class PackedWeight:
     Cout_pad: int
 
 
+# Host-logic tests (tests/plan_interp.py) execute plans on the CPU from the documented op contracts; the packed MFMA-fragment
+# order is kernel-private, so with this switch on pack_weight() also remembers the plain (fp16-rounded) weight of every packed buffer.
+KEEP_REFERENCE_WEIGHTS = False
+REFERENCE_WEIGHTS: dict = {}   # packed.data_ptr() -> (w [Cout, Cin, KH, KW] fp32 holding fp16-rounded values, bias or None)
+
+
 def choose_G(Cin: int, taps: int = 9) -> int:
     """8-channel groups per k-chunk.  1x1 convs / linears have no halo, so their chunks go 64-128 channels deep."""
     if taps == 1 and DEEP_CHUNKS:
@@ -222,7 +228,10 @@ def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], device, in_scale:
         b = torch.zeros(Cout_pad, dtype=torch.float32)
         b[:Cout] = bias.detach().float().cpu()
         b = b.to(device)
-    return PackedWeight(out.to(device), b, Cin, Cout, KH, KW, G, Cin_pad, Cout_pad)
+    packed = out.to(device)
+    if KEEP_REFERENCE_WEIGHTS:
+        REFERENCE_WEIGHTS[packed.data_ptr()] = ((w if sc is None else w * sc[None, :, None, None]).half().float(), bias)
+    return PackedWeight(packed, b, Cin, Cout, KH, KW, G, Cin_pad, Cout_pad)
 
 
 # ------------------------------------------------------------------------------------------------ igemm

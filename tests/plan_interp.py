@@ -1,0 +1,311 @@
+"""CPU interpreter of kernel plans (TEST INFRASTRUCTURE — never imported by the product).
+
+The planners (`imagen_pytorch_amd/engine.py`, ...) only emit `Imagen*Params` structs: raw pointers, strides, op order.  With
+`dry=True` they do so over CPU memory.  This module executes such a plan on the CPU by implementing, in plain torch, the
+CONTRACT of every op kind exactly as include/imagen_hip.h documents it (fp16 storage, fp32 arithmetic) and reading / writing the
+same buffers through their raw addresses.  It lets the host logic — which buffer feeds which op, strides, offsets, folded
+weights, the order of launches — be checked against the oracle without a GPU.  It says nothing about the HIP kernels themselves:
+those are checked against fp32 torch and the oracle by the `-m gpu` tests.
+
+Weights: `ops.KEEP_REFERENCE_WEIGHTS = True` makes `ops.pack_weight` remember the unpacked (fp16-rounded) weight behind every
+packed buffer, because the packed MFMA-fragment order is a kernel-private detail.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict
+
+import torch
+import torch.nn.functional as F
+
+from imagen_pytorch_amd import _abi, ops
+
+K = _abi.ENUMS
+f16, f32, i32, u8 = torch.float16, torch.float32, torch.int32, torch.uint8
+
+
+class Mem:
+    """Raw address -> flat typed view of the torch storage that contains it."""
+
+    def __init__(self):
+        self.storages: Dict[int, torch.UntypedStorage] = {}
+
+    def register(self, t):
+        if isinstance(t, torch.Tensor) and t.numel() > 0:
+            st = t.untyped_storage()
+            self.storages[st.data_ptr()] = st
+
+    def register_plan(self, plan):
+        for t in plan.keep:
+            self.register(t)
+
+    def view(self, addr, dtype) -> torch.Tensor:
+        assert addr, "null pointer dereferenced by the interpreter"
+        for base, st in self.storages.items():
+            if base <= addr < base + st.nbytes():
+                isz = torch.empty(0, dtype=dtype).element_size()
+                assert (addr - base) % isz == 0
+                n = (st.nbytes() - (addr - base)) // isz
+                return torch.empty(0, dtype=dtype).set_(st, (addr - base) // isz, (n,), (1,))
+        raise KeyError(f"address {addr:#x} is not inside any registered buffer")
+
+    def strided(self, addr, dtype, size, stride) -> torch.Tensor:
+        return self.view(addr, dtype).as_strided(size, stride)
+
+
+def _act(x, kind):
+    if kind == ops.ACT_SILU:
+        return F.silu(x)
+    if kind == ops.ACT_GELU:
+        return F.gelu(x)
+    return x
+
+
+class Interpreter:
+    def __init__(self):
+        self.mem = Mem()
+        self.gca_ctx = {}       # part pointer -> pooled context (GCA_PARTIAL -> GCA_FINAL hand-over)
+        self.trace = []
+
+    # ------------------------------------------------------------------------------------------------ driver
+    def run(self, plan):
+        self.mem.register_plan(plan)
+        for kind, p, label in plan.ops:
+            fn = self.DISPATCH.get(kind)
+            if fn is None:
+                raise NotImplementedError(f"plan interpreter: op kind {kind} ({label})")
+            fn(self, p)
+            self.trace.append(label)
+
+    # ------------------------------------------------------------------------------------------------ IGEMM
+    def igemm(self, p):
+        m = self.mem
+        B, H, W, C1, C2 = p.B, p.H, p.W, p.C1, p.C2
+        x = m.strided(p.x1, f16, (B, H, W, C1), (p.bs1, W * p.ld1, p.ld1, 1)).float()
+        if p.x2:
+            x = torch.cat((x, m.strided(p.x2, f16, (B, H, W, C2), (p.bs2, W * p.ld2, p.ld2, 1)).float()), dim=-1)
+        C = C1 + C2
+        npx = B * H * W
+        a = x
+        if p.mu:
+            a = a - m.view(p.mu, f32)[:npx].reshape(B, H, W, 1)
+        rs = None
+        if p.rs:
+            rs = m.view(p.rs, f32)[:npx]
+        elif p.ssq_a:
+            ssq = m.view(p.ssq_a, f32)[:npx].clone()
+            if p.ssq_b:
+                ssq = ssq + p.ssq_wb * m.view(p.ssq_b, f32)[:npx]
+            rs = 1.0 / ssq.sqrt().clamp(min=1e-12)
+        if rs is not None:
+            a = a * rs.reshape(B, H, W, 1)
+        if p.pa:
+            a = a * m.strided(p.pa, f32, (B, C), (p.pstride, 1)).reshape(B, 1, 1, C)
+        if p.ps:
+            a = a + m.strided(p.ps, f32, (B, C), (p.pstride, 1)).reshape(B, 1, 1, C)
+        a = _act(a, p.act_in).half().float()
+        wref, bias = ops.REFERENCE_WEIGHTS[p.w]
+        assert wref.shape[1] >= C and wref.shape[2:] == (p.KH, p.KW) and wref.shape[0] == p.Cout
+        acc = F.conv2d(a.permute(0, 3, 1, 2), wref[:, :C], None, stride=p.stride, padding=p.pad)[:, :, :p.OH, :p.OW]
+        assert acc.shape[2:] == (p.OH, p.OW), (acc.shape, p.OH, p.OW)
+        v = acc.permute(0, 2, 3, 1)                                   # (B, OH, OW, Cout)
+        if p.bias:
+            v = v + m.view(p.bias, f32)[:p.Cout]
+        OH, OW, Co = p.OH, p.OW, p.Cout
+        if p.post_pa:
+            nrm = v.norm(dim=-1, keepdim=True).clamp(min=1e-12)
+            pa = m.strided(p.post_pa, f32, (B, Co), (p.post_pstride, 1)).reshape(B, 1, 1, Co)
+            ps = m.strided(p.post_ps, f32, (B, Co), (p.post_pstride, 1)).reshape(B, 1, 1, Co)
+            v = F.silu(v / nrm * pa + ps)
+        v = _act(v, p.act_out)
+        if p.addend:
+            add = m.strided(p.addend, f16, (B, OH, OW, Co), (p.bs_add, OW * p.ld_add, p.ld_add, 1)).float()
+            v = v + add * m.strided(p.gate, f32, (B, Co), (p.gate_stride, 1)).reshape(B, 1, 1, Co)
+        if p.res:
+            v = v + m.strided(p.res, f16, (B, OH, OW, Co), (p.bs_res, OW * p.ld_res, p.ld_res, 1)).float()
+        if p.out_mode == ops.OUT_NCHW_F32:
+            m.strided(p.y, f32, (B, Co, OH, OW), (Co * OH * OW, OH * OW, OW, 1)).copy_(v.permute(0, 3, 1, 2))
+        elif p.out_mode == ops.OUT_PIXEL_SHUFFLE:
+            # packed output channel o = s * (Co/4) + c with s = dy*2 + dx (the engine permutes the conv's output channels)
+            cq = Co // 4
+            y = m.strided(p.y, f16, (B, 2 * OH, 2 * OW, cq), (p.bsy, 2 * OW * p.ldy, p.ldy, 1))
+            vv = v.reshape(B, OH, OW, 2, 2, cq)
+            for dy in range(2):
+                for dx in range(2):
+                    y[:, dy::2, dx::2, :] = vv[:, :, :, dy, dx, :].half()
+        else:
+            y = m.strided(p.y, f16, (B, OH, OW, Co), (p.bsy, OW * p.ldy, p.ldy, 1))
+            y.copy_(v.half())
+            if p.ssq_out:
+                m.view(p.ssq_out, f32)[:B * OH * OW].copy_((v.half().float() ** 2).sum(-1).reshape(-1))
+
+    # ------------------------------------------------------------------------------------------------ statistics / glue
+    def _rows(self, addr, rows, rpb, C, ld, bs):
+        nb = rows // rpb
+        return self.mem.strided(addr, f16, (nb, rpb, C), (bs, ld, 1))
+
+    def rowstat(self, p):
+        m = self.mem
+        x = self._rows(p.x1, p.rows, p.rows_per_batch, p.C1, p.ld1, p.bs1).float().reshape(p.rows, p.C1)
+        x2 = self._rows(p.x2, p.rows, p.rows_per_batch, p.C2, p.ld2, p.bs2).float().reshape(p.rows, p.C2) if p.x2 else None
+        if p.mode in (0, 2):
+            tot = (x ** 2).sum(-1) + (p.w2 * (x2 ** 2).sum(-1) if x2 is not None else 0.0)
+            m.view(p.rs, f32)[:p.rows].copy_(tot if p.mode == 2 else 1.0 / tot.sqrt().clamp(min=1e-12))
+        else:
+            full = x if x2 is None else torch.cat((x, x2), dim=-1)
+            m.view(p.mu, f32)[:p.rows].copy_(full.mean(-1))
+            m.view(p.rs, f32)[:p.rows].copy_(torch.rsqrt(full.var(-1, unbiased=False) + p.eps))
+
+    def gate_residual(self, p):
+        m = self.mem
+        h = m.strided(p.h, f16, (p.rows, p.C), (p.ld_h, 1)).float()
+        res = m.strided(p.res, f16, (p.rows, p.C), (p.ld_res, 1)).float()
+        if p.gate:
+            nb = p.rows // p.rows_per_batch
+            g = m.strided(p.gate, f32, (nb, p.C), (p.C, 1)).repeat_interleave(p.rows_per_batch, dim=0)
+            h = h * g
+        out = (h + res).half()
+        m.strided(p.out, f16, (p.rows, p.C), (p.ld_out, 1)).copy_(out)
+        if p.rs_out:
+            ssq = (out.float() ** 2).sum(-1)
+            m.view(p.rs_out, f32)[:p.rows].copy_(ssq if p.raw_ssq else 1.0 / ssq.sqrt().clamp(min=1e-12))
+
+    def ln_residual(self, p):
+        m = self.mem
+        y = self._rows(p.y, p.rows, p.rows_per_batch, p.C, p.ld_y, p.bs_y).float()
+        out = (y - y.mean(-1, keepdim=True)) * torch.rsqrt(y.var(-1, unbiased=False, keepdim=True) + p.eps) * m.view(p.g, f32)[:p.C]
+        if p.beta:
+            out = out + m.view(p.beta, f32)[:p.C]
+        if p.res:
+            out = out + self._rows(p.res, p.rows, p.rows_per_batch, p.C, p.ld_res, p.bs_res).float()
+        out = out.half()
+        self._rows(p.out, p.rows, p.rows_per_batch, p.C, p.ld_out, p.bs_out).copy_(out)
+        if p.ssq_out:
+            m.view(p.ssq_out, f32)[:p.rows].copy_((out.float() ** 2).sum(-1).reshape(-1))
+
+    def time_embed(self, p):
+        m = self.mem
+        nf = 2 * p.half_dim + 1
+        if p.step_ptr:
+            step = int(m.view(p.step_ptr, i32)[0])
+            x = m.view(p.coef, f32)[step * 8 + 6].expand(p.B)
+        else:
+            x = m.view(p.times, f32)[:p.B]
+        fr = x[:, None] * m.view(p.freqs, f32)[:p.half_dim][None, :] * (2 * math.pi)
+        feats = torch.cat((x[:, None], fr.sin(), fr.cos()), dim=-1)
+        w = m.view(p.w, f32)[:p.out_dim * nf].reshape(p.out_dim, nf)
+        hid = F.silu(feats @ w.t() + m.view(p.bias, f32)[:p.out_dim])
+        m.strided(p.hid, f16, (p.B, p.out_dim), (p.ld_hid, 1)).copy_(hid.half())
+
+    def scale_shift(self, p):
+        m = self.mem
+        ss = m.strided(p.ss, f16, (p.B, p.ld_ss), (p.ld_ss, 1)).float()
+        isc = m.view(p.idx_scale, i32)[:p.total_c].long()
+        ish = m.view(p.idx_shift, i32)[:p.total_c].long()
+        m.view(p.pa, f32)[:p.B * p.total_c].copy_((m.view(p.gamma_s, f32)[:p.total_c] * (ss[:, isc] + 1.0)).reshape(-1))
+        m.view(p.ps, f32)[:p.B * p.total_c].copy_(ss[:, ish].reshape(-1))
+
+    def pack_image(self, p):
+        m = self.mem
+        HW = p.H * p.W
+        a = m.view(p.a, f32)[:p.B * p.Ca * HW].reshape(p.B, p.Ca, p.H, p.W)
+        out = torch.zeros(p.B, p.H, p.W, p.Cpad)
+        out[..., :p.Ca] = a.permute(0, 2, 3, 1)
+        if p.b:
+            out[..., p.Ca:p.Ca + p.Cb] = m.view(p.b, f32)[:p.B * p.Cb * HW].reshape(p.B, p.Cb, p.H, p.W).permute(0, 2, 3, 1)
+        m.view(p.out, f16)[:p.B * p.Brep * HW * p.Cpad].copy_(out.repeat(p.Brep, 1, 1, 1).half().reshape(-1))
+
+    def rows_copy(self, p):
+        m = self.mem
+        src = m.strided(p.src, f16, (p.B, p.rows, p.C), (p.src_bs, p.src_rs, 1))
+        m.strided(p.dst, f16, (p.B, p.rows, p.C), (p.dst_bs, p.dst_rs, 1)).copy_(src.clone())
+
+    def memset32(self, p):
+        self.mem.view(p.dst, i32)[:p.count].fill_(p.value if p.value < 2 ** 31 else p.value - 2 ** 32)
+
+    def select_rows(self, p):
+        m = self.mem
+        src = m.view(p.src, i32)[:p.R].long()
+        keep = m.view(p.keep, u8)[:p.R].bool()
+        nsrc = int(src.max()) + 1
+        a = m.view(p.a, f16)[:nsrc * p.L * p.C].reshape(nsrc, p.L, p.C)
+        nul = m.view(p.nul, f16)[:p.L * p.C].reshape(1, p.L, p.C)
+        sel = keep[:, None].expand(p.R, p.L)
+        if p.mask:
+            sel = sel & m.view(p.mask, u8)[:nsrc * p.L].reshape(nsrc, p.L).bool()[src]
+        m.view(p.dst, f16)[:p.R * p.L * p.C].copy_(torch.where(sel[..., None], a[src], nul.expand(p.R, -1, -1)).reshape(-1))
+
+    def mean_rows(self, p):
+        m = self.mem
+        x = m.strided(p.x, f16, (p.B, p.rows, p.C), (p.bs_x, p.ld_x, 1)).float()
+        m.strided(p.out, f16, (p.B, p.C), (p.ld_out, 1)).copy_(x.mean(1).half())
+
+    # ------------------------------------------------------------------------------------------------ attention
+    def kv_prep(self, p):
+        m = self.mem
+        dt = f32 if p.src_is_f32 else f16
+        sz = (p.B, p.heads, p.rows, 64)
+        st = (p.src_bs, p.src_hs, p.src_rs, 1)
+        k = m.strided(p.k_src, dt, sz, st).float()
+        v = m.strided(p.v_src, dt, sz, st).float()
+        khat = F.normalize(k, dim=-1, eps=1e-12) * m.view(p.k_scale, f32)[:64]
+        m.strided(p.khat + 2 * p.r0 * p.k_rs, f16, sz, (p.k_bs, p.k_hs, p.k_rs, 1)).copy_(khat.half())
+        m.strided(p.vt + 2 * p.r0, f16, sz, (p.vt_bs, p.vt_hs, 1, p.vt_ds)).copy_(v.half())
+
+    def kv_prep_multi(self, p):
+        st = _abi.STRUCTS["ImagenKvPrepParams"]
+        import ctypes
+        for i in range(p.n):
+            job = st.from_address(p.jobs + i * ctypes.sizeof(st))
+            self.kv_prep(job)
+
+    def qnorm(self, p):
+        m = self.mem
+        q = m.strided(p.q, f16, (p.rows, p.heads, 64), (p.ld, 64, 1))
+        q.copy_((F.normalize(q.float(), dim=-1, eps=1e-12) * m.view(p.q_scale, f32)[:64] * p.mult).half())
+
+    def attention(self, p):
+        m = self.mem
+        q = m.strided(p.q, f16, (p.B, p.heads, p.rows, 64), (p.q_bs, p.q_hs, p.q_rs, 1)).float()
+        if p.q_scale:
+            q = (F.normalize(q, dim=-1, eps=1e-12) * m.view(p.q_scale, f32)[:64] * p.q_mult).half().float()
+        k = m.strided(p.k, f16, (p.B, p.heads, p.J, 64), (p.k_bs, p.k_hs, p.k_rs, 1)).float()
+        v = m.strided(p.vt, f16, (p.B, p.heads, p.J, 64), (p.vt_bs, p.vt_hs, 1, p.vt_ds)).float()
+        sim = torch.einsum("bhid,bhjd->bhij", q, k) * math.log(2.0)       # the kernel's exponent base is 2
+        o = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), v)
+        m.strided(p.o, f16, (p.B, p.heads, p.rows, 64), (p.o_bs, p.o_hs, p.o_rs, 1)).copy_(o.half())
+
+    # ------------------------------------------------------------------------------------------------ GlobalContext
+    def _gca_gate(self, ctx, w1t, b1, w2t, b2, C, hidden):
+        m = self.mem
+        W1 = m.view(w1t, f32)[:C * hidden].reshape(C, hidden)
+        W2 = m.view(w2t, f32)[:hidden * C].reshape(hidden, C)
+        hid = F.silu(ctx @ W1 + m.view(b1, f32)[:hidden])
+        return torch.sigmoid(hid @ W2 + m.view(b2, f32)[:C])
+
+    def gca_partial(self, p):
+        m = self.mem
+        h = m.strided(p.h, f16, (p.B, p.HW, p.C), (p.HW * p.ld, p.ld, 1)).float()
+        logits = h @ m.view(p.wk, f32)[:p.C] + p.bk
+        ctx = torch.einsum("bn,bnc->bc", logits.softmax(-1), h)
+        if p.gate:
+            m.view(p.gate, f32)[:p.B * p.C].copy_(self._gca_gate(ctx, p.w1t, p.b1, p.w2t, p.b2, p.C, p.hidden).reshape(-1))
+        else:
+            self.gca_ctx[p.part] = ctx
+
+    def gca_final(self, p):
+        ctx = self.gca_ctx.pop(p.part)
+        self.mem.view(p.gate, f32)[:p.B * p.C].copy_(self._gca_gate(ctx, p.w1t, p.b1, p.w2t, p.b2, p.C, p.hidden).reshape(-1))
+
+    DISPATCH = {}
+
+
+Interpreter.DISPATCH = {
+    K["IMAGEN_OP_IGEMM"]: Interpreter.igemm, K["IMAGEN_OP_ROWSTAT"]: Interpreter.rowstat, K["IMAGEN_OP_ATTENTION"]: Interpreter.attention,
+    K["IMAGEN_OP_KV_PREP"]: Interpreter.kv_prep, K["IMAGEN_OP_KV_PREP_MULTI"]: Interpreter.kv_prep_multi, K["IMAGEN_OP_QNORM"]: Interpreter.qnorm,
+    K["IMAGEN_OP_GCA_PARTIAL"]: Interpreter.gca_partial, K["IMAGEN_OP_GCA_FINAL"]: Interpreter.gca_final,
+    K["IMAGEN_OP_GATE_RESIDUAL"]: Interpreter.gate_residual, K["IMAGEN_OP_LN_RESIDUAL"]: Interpreter.ln_residual,
+    K["IMAGEN_OP_TIME_EMBED"]: Interpreter.time_embed, K["IMAGEN_OP_SCALE_SHIFT"]: Interpreter.scale_shift,
+    K["IMAGEN_OP_PACK_IMAGE"]: Interpreter.pack_image, K["IMAGEN_OP_ROWS_COPY"]: Interpreter.rows_copy, K["IMAGEN_OP_MEMSET32"]: Interpreter.memset32,
+    K["IMAGEN_OP_SELECT_ROWS"]: Interpreter.select_rows, K["IMAGEN_OP_MEAN_ROWS"]: Interpreter.mean_rows,
+}
