@@ -12,11 +12,12 @@ __all__ = ["ImagenHipError", "load_library"]
 
 try:  # the model classes need the ops layer; keep the ABI importable on its own for the symbol tests
     from .unet import Unet, NullUnet, BaseUnet64, SRUnet256, SRUnet1024  # noqa: F401
+    from .unet3d import Unet3D  # noqa: F401
     from .imagen import Conditioning, Imagen  # noqa: F401
     from .elucidated import ElucidatedImagen  # noqa: F401
     from .schedules import GaussianDiffusionContinuousTimes  # noqa: F401
     from .checkpoint import load_imagen_from_checkpoint, load_trainer_checkpoint, save_checkpoint  # noqa: F401
-    __all__ += ["Unet", "NullUnet", "BaseUnet64", "SRUnet256", "SRUnet1024", "Imagen", "Conditioning", "ElucidatedImagen", "GaussianDiffusionContinuousTimes",
+    __all__ += ["Unet", "Unet3D", "NullUnet", "BaseUnet64", "SRUnet256", "SRUnet1024", "Imagen", "Conditioning", "ElucidatedImagen", "GaussianDiffusionContinuousTimes",
                 "load_imagen_from_checkpoint", "load_trainer_checkpoint", "save_checkpoint"]
 except ModuleNotFoundError as _e:  # pragma: no cover - only while the package is being bootstrapped
     if _e.name not in ("imagen_pytorch_amd.unet", "imagen_pytorch_amd.imagen", "imagen_pytorch_amd.schedules"):

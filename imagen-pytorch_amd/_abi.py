@@ -103,6 +103,8 @@ OP_STRUCT = {
     ENUMS["IMAGEN_OP_LOWRES_PREP"]: STRUCTS["ImagenLowresPrepParams"],
     ENUMS["IMAGEN_OP_LINCOMB"]: STRUCTS["ImagenLincombParams"],
     ENUMS["IMAGEN_OP_KV_PREP_MULTI"]: STRUCTS["ImagenKvPrepMultiParams"],
+    ENUMS["IMAGEN_OP_TEMPORAL_PEG"]: STRUCTS["ImagenTemporalPegParams"],
+    ENUMS["IMAGEN_OP_TEMPORAL_ATTENTION"]: STRUCTS["ImagenTemporalAttentionParams"],
 }
 STRUCT_KIND = {v: k for k, v in OP_STRUCT.items()}
 

@@ -43,6 +43,8 @@ extern "C" size_t imagen_sizeof(int kind) {
     case IMAGEN_OP_LOWRES_PREP: return sizeof(ImagenLowresPrepParams);
     case IMAGEN_OP_LINCOMB: return sizeof(ImagenLincombParams);
     case IMAGEN_OP_KV_PREP_MULTI: return sizeof(ImagenKvPrepMultiParams);
+    case IMAGEN_OP_TEMPORAL_PEG: return sizeof(ImagenTemporalPegParams);
+    case IMAGEN_OP_TEMPORAL_ATTENTION: return sizeof(ImagenTemporalAttentionParams);
     default: return 0;
   }
 }
@@ -74,6 +76,8 @@ extern "C" int imagen_launch(int kind, const void* params, imagen_stream_t strea
     case IMAGEN_OP_LOWRES_PREP: return launch_lowres_prep(static_cast<const ImagenLowresPrepParams*>(params), s);
     case IMAGEN_OP_LINCOMB: return launch_lincomb(static_cast<const ImagenLincombParams*>(params), s);
     case IMAGEN_OP_KV_PREP_MULTI: return launch_kv_prep_multi(static_cast<const ImagenKvPrepMultiParams*>(params), s);
+    case IMAGEN_OP_TEMPORAL_PEG: return launch_temporal_peg(static_cast<const ImagenTemporalPegParams*>(params), s);
+    case IMAGEN_OP_TEMPORAL_ATTENTION: return launch_temporal_attention(static_cast<const ImagenTemporalAttentionParams*>(params), s);
     default: imagen_set_error("imagen_launch: unknown op kind %d", kind); return -1;
   }
 }

@@ -62,3 +62,5 @@ int launch_randn(const ImagenRandnParams* p, hipStream_t s);
 int launch_lowres_prep(const ImagenLowresPrepParams* p, hipStream_t s);
 int launch_lincomb(const ImagenLincombParams* p, hipStream_t s);
 int launch_kv_prep_multi(const ImagenKvPrepMultiParams* p, hipStream_t s);
+int launch_temporal_peg(const ImagenTemporalPegParams* p, hipStream_t s);
+int launch_temporal_attention(const ImagenTemporalAttentionParams* p, hipStream_t s);

@@ -434,44 +434,51 @@ class UnetEngine:
 
     # ---- TransformerBlock (ip.py:992-1022): depth x [multi-query self attention + FeedForward]
     def _transformer(self, plan, x: Act, tb: TransformerBlockP, name: str, with_context: bool) -> Act:
-        W, R = self.W, self.R
+        R = self.R
         N, C = x.H * x.W, x.C
         cur = x
         for d, (attn, ff) in enumerate(tb.layers):
             nm = f"{name}.layers.{d}"
-            heads, dh = attn.heads, attn.dim_head
-            inner = heads * dh
-            tok = cur.tokens()
-            mu, rs = self.f32buf(R * N), self.f32buf(R * N)
-            ops.rowstat(plan, tok, mode=1, rs=rs, mu=mu, eps=1e-5, label=nm + ".norm")
-            # q | k | v from ONE GEMM (to_q and to_kv are both bias-free on the same normalised input, ip.py:539)
-            wqkv = W.raw(nm + ".qkv", torch.cat((attn.to_q.weight.detach().float(), attn.to_kv.weight.detach().float())), None)
-            qkv = self.new(R, 1, N, inner + 2 * dh)
-            ops.igemm(plan, tok, wqkv, qkv, mu=mu, rs=rs, pa=W.f32(nm + ".norm.g", lambda: _pad_vec(attn.norm.g, wqkv.Cin_pad)),
-                      label=nm + ".qkv")
-            ld = inner + 2 * dh
-            n_ctx = self.NT if (with_context and attn.to_context is not None) else 0
-            J = n_ctx + 1 + N
-            Jp = ops._round_up(J, 32)
-            khat = torch.zeros(R, Jp, dh, dtype=torch.float16, device=self.dev)
-            vt = torch.zeros(R, dh, Jp, dtype=torch.float16, device=self.dev)
-            k_strides, vt_strides = (Jp * dh, 0, dh), (dh * Jp, 0, Jp)
-            site = dict(kind="self", name=nm, mod=attn, khat=khat, vt=vt, heads=1, Jp=Jp, n_ctx=n_ctx, k_strides=k_strides, vt_strides=vt_strides)
-            self.attn_sites.append(site)
-            ops.kv_prep(plan, qkv.t, qkv.t, W.f32(nm + ".k_scale", lambda: attn.k_scale), khat, vt, B=R, heads=1, rows=N, r0=n_ctx + 1,
-                        src_strides=(N * ld, ld, 0), k_strides=k_strides, vt_strides=vt_strides, k_off=inner, v_off=inner + dh,
-                        label=nm + ".kv_self")
-            o = self.new(R, 1, N, inner)
-            ops.attention(plan, qkv.t, khat, vt, o.t, B=R, heads=heads, rows=N, J=J, q_strides=(N * ld, dh, ld), k_strides=k_strides,
-                          vt_strides=vt_strides, o_strides=(N * inner, dh, inner), q_scale=W.f32(nm + ".q_scale", lambda: attn.q_scale),
-                          q_mult=SIM_SCALE * LOG2E, label=nm + ".attn")
-            y = self.new(R, 1, N, C)
-            ops.igemm(plan, o, W.conv(nm + ".to_out", attn.to_out[0]), y, label=nm + ".to_out")
-            x1 = self.new(R, 1, N, C)
-            ops.ln_residual(plan, y, W.f32(nm + ".out_g", lambda: attn.to_out[1].g), x1, res=tok, eps=1e-5, label=nm + ".out_norm")
+            x1 = self._self_attn(plan, cur.tokens(), attn, nm, with_context)
             ffo = self._feed_forward(plan, x1, ff, nm + ".ff")
             cur = Act(ffo.t, R, x.H, x.W, C, C, N * C, ssq=ffo.ssq)
         return cur
+
+    def _self_attn(self, plan, tok: Act, attn, nm: str, with_context: bool) -> Act:
+        """attn(tok) + tok for the (R, 1, N, C) token view `tok` (ip.py:502-591, 1017): LayerNorm -> q | k | v in one GEMM ->
+        K^/V^T rows behind the conditioning and null rows -> flash attention -> to_out -> LayerNorm + residual."""
+        W, R = self.W, self.R
+        N, C = tok.H * tok.W, tok.C
+        heads, dh = attn.heads, attn.dim_head
+        inner = heads * dh
+        mu, rs = self.f32buf(R * N), self.f32buf(R * N)
+        ops.rowstat(plan, tok, mode=1, rs=rs, mu=mu, eps=1e-5, label=nm + ".norm")
+        # q | k | v from ONE GEMM (to_q and to_kv are both bias-free on the same normalised input, ip.py:539)
+        wqkv = W.raw(nm + ".qkv", torch.cat((attn.to_q.weight.detach().float(), attn.to_kv.weight.detach().float())), None)
+        qkv = self.new(R, 1, N, inner + 2 * dh)
+        ops.igemm(plan, tok, wqkv, qkv, mu=mu, rs=rs, pa=W.f32(nm + ".norm.g", lambda: _pad_vec(attn.norm.g, wqkv.Cin_pad)),
+                  label=nm + ".qkv")
+        ld = inner + 2 * dh
+        n_ctx = self.NT if (with_context and attn.to_context is not None) else 0
+        J = n_ctx + 1 + N
+        Jp = ops._round_up(J, 32)
+        khat = torch.zeros(R, Jp, dh, dtype=torch.float16, device=self.dev)
+        vt = torch.zeros(R, dh, Jp, dtype=torch.float16, device=self.dev)
+        k_strides, vt_strides = (Jp * dh, 0, dh), (dh * Jp, 0, Jp)
+        site = dict(kind="self", name=nm, mod=attn, khat=khat, vt=vt, heads=1, Jp=Jp, n_ctx=n_ctx, k_strides=k_strides, vt_strides=vt_strides)
+        self.attn_sites.append(site)
+        ops.kv_prep(plan, qkv.t, qkv.t, W.f32(nm + ".k_scale", lambda: attn.k_scale), khat, vt, B=R, heads=1, rows=N, r0=n_ctx + 1,
+                    src_strides=(N * ld, ld, 0), k_strides=k_strides, vt_strides=vt_strides, k_off=inner, v_off=inner + dh,
+                    label=nm + ".kv_self")
+        o = self.new(R, 1, N, inner)
+        ops.attention(plan, qkv.t, khat, vt, o.t, B=R, heads=heads, rows=N, J=J, q_strides=(N * ld, dh, ld), k_strides=k_strides,
+                      vt_strides=vt_strides, o_strides=(N * inner, dh, inner), q_scale=W.f32(nm + ".q_scale", lambda: attn.q_scale),
+                      q_mult=SIM_SCALE * LOG2E, label=nm + ".attn")
+        y = self.new(R, 1, N, C)
+        ops.igemm(plan, o, W.conv(nm + ".to_out", attn.to_out[0]), y, label=nm + ".to_out")
+        x1 = self.new(R, 1, N, C)
+        ops.ln_residual(plan, y, W.f32(nm + ".out_g", lambda: attn.to_out[1].g), x1, res=tok, eps=1e-5, label=nm + ".out_norm")
+        return x1
 
     def _feed_forward(self, plan, x: Act, ff: nn.Sequential, name: str) -> Act:
         """ip.py:972-980 + residual (ip.py:1018): LN -> Linear -> GELU -> LN -> Linear, + x."""
@@ -763,7 +770,7 @@ class UnetEngine:
                 tm = text_mask[:, :L].to(torch.uint8).cpu()
                 m[:, : tm.shape[1]] = tm
             else:
-                m[:, :n_tok] = 1
+                m[:, :] = 1      # no mask: the zero-padded positions stay zero tokens, they are NOT replaced by null_text_embed (ip.py:1619-1632)
             mask_u8.copy_(m)
         if not self.dry:
             plan.run()

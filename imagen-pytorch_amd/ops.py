@@ -670,3 +670,28 @@ def lincomb(plan: Plan, t0, out, coef, step_ptr, *, B, n_per_sample, t1=None, t2
     assert mask is None or (mask.dtype == torch.float32 and mask_else is not None and mask.numel() == B * n_per_sample)
     plan.add(p, label or "lincomb", [t0, t1, t2, t3, q1, q3, out, out2, final_out, coef, step_ptr, seed_ptr, mask, mask_else])
     return p
+
+
+# ------------------------------------------------------------------------------------------------ Imagen-Video ops
+
+def temporal_peg(plan: Plan, x: Act, w: torch.Tensor, bias: torch.Tensor, out: Act, *, B: int, F: int, causal: bool, label: str = ""):
+    """x / out: the clip as B*F consecutive NHWC frames (Act.B == B*F, dense); w: fp32 [C, 3] depthwise taps; bias: fp32 [C]."""
+    assert x.B == B * F and out.B == B * F and x.ld == x.C == out.ld == out.C and x.bs == x.H * x.W * x.C == out.bs
+    assert tuple(w.shape) == (x.C, 3) and w.dtype == torch.float32 and bias.numel() == x.C
+    p = STRUCTS["ImagenTemporalPegParams"]()
+    p.x, p.w, p.bias, p.out = x.ptr, w.data_ptr(), bias.data_ptr(), out.ptr
+    p.B, p.F, p.P, p.C, p.causal = B, F, x.H * x.W, x.C, int(causal)
+    plan.add(p, label or "temporal_peg", [x.t, w, bias, out.t])
+    return p
+
+
+def temporal_attention(plan: Plan, qkv: Act, null_kv: torch.Tensor, q_scale: torch.Tensor, k_scale: torch.Tensor, bias: torch.Tensor,
+                       o: Act, *, B: int, F: int, P: int, heads: int, causal: bool, scale: float, label: str = ""):
+    """qkv: rows (b, f, p) of q (heads*64) | k (64) | v (64); bias: fp32 [heads, F, F+1] (column 0 = null key); o: rows of heads*64."""
+    assert qkv.rows == B * F * P == o.rows and qkv.C == heads * 64 + 128 and o.C == heads * 64
+    assert tuple(bias.shape) == (heads, F, F + 1) and bias.dtype == torch.float32 and F <= 32
+    p = STRUCTS["ImagenTemporalAttentionParams"]()
+    p.qkv, p.null_kv, p.q_scale, p.k_scale, p.bias, p.o = qkv.ptr, null_kv.data_ptr(), q_scale.data_ptr(), k_scale.data_ptr(), bias.data_ptr(), o.ptr
+    p.B, p.F, p.P, p.heads, p.ld, p.ld_o, p.causal, p.scale = B, F, P, heads, qkv.ld, o.ld, int(causal), scale
+    plan.add(p, label or "temporal_attention", [qkv.t, null_kv, q_scale, k_scale, bias, o.t])
+    return p

@@ -59,7 +59,9 @@ enum ImagenOpKind {
   IMAGEN_OP_LOWRES_PREP = 21,  /* nearest resize + normalise + noise-augment the previous stage's image  */
   IMAGEN_OP_LINCOMB = 22,      /* per-step weighted sum of up to 4 fp32 images (+ Philox noise): the EDM sampler's state updates */
   IMAGEN_OP_KV_PREP_MULTI = 23, /* several KV_PREP jobs (one per attention site) in ONE launch                         */
-  IMAGEN_OP_KIND_COUNT = 24
+  IMAGEN_OP_TEMPORAL_PEG = 24,  /* Imagen-Video: depthwise causal conv over 3 frames + residual                        */
+  IMAGEN_OP_TEMPORAL_ATTENTION = 25, /* Imagen-Video: per-pixel causal attention over the frames, with a bias table    */
+  IMAGEN_OP_KIND_COUNT = 26
 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -167,6 +169,27 @@ typedef struct ImagenKvPrepParams {
 typedef struct ImagenKvPrepMultiParams {
   const ImagenKvPrepParams* jobs; int32_t n, max_rows, max_bh; /* max over the jobs of rows and B*heads (grid extents) */
 } ImagenKvPrepMultiParams;
+
+/* ---- Imagen-Video (imagen_pytorch/imagen_video.py = "iv.py") ----------------------------------------------------------------
+ * Video activations are fp16 [B, F, P, C]: the F frames of a clip are consecutive NHWC images of P = H*W pixels, so every per-frame
+ * op of the image path applies unchanged with batch B*F, and every per-clip op (GlobalContext, space-time attention) with H*W := F*P.
+ *
+ * TEMPORAL_PEG — iv.py:1413-1414, Residual(Pad + depthwise Conv3d (3,1,1)):
+ *   out[b,f,p,c] = x[b,f,p,c] + bias[c] + sum_{k<3} w[c][k] * x[b, f + k - (causal ? 2 : 1), p, c]     (zero outside [0, F))
+ * TEMPORAL_ATTENTION — iv.py:499-570 applied along the frame axis (RearrangeTimeCentric, iv.py:257-270): for every clip b, pixel p
+ * and head h the F frames of that pixel attend to each other (one shared key/value head) and to the learned null key:
+ *   qh = l2norm(q[b,i,p,h,:]) * q_scale * scale ;  kh[0] = l2norm(null_k) * k_scale, kh[1+j] = l2norm(k[b,j,p,:]) * k_scale
+ *   sim[i][j'] = qh . kh[j'] + bias[h][i][j']   (bias: [heads][F][F+1] fp32, column 0 = null-key bias, the rest = the generated
+ *   relative position bias);  causal: keys with frame index > i are masked;  o[b,i,p,h,:] = softmax_j'(sim) @ [null_v, v[b,:,p,:]]
+ * qkv rows (b, f, p) hold q (heads*64) | k (64) | v (64) at row stride ld (fp16); o rows have stride ld_o.  F <= 32. */
+typedef struct ImagenTemporalPegParams {
+  const void* x; const float* w; const float* bias; void* out;
+  int32_t B, F, P, C, causal;
+} ImagenTemporalPegParams;
+typedef struct ImagenTemporalAttentionParams {
+  const void* qkv; const float* null_kv; const float* q_scale; const float* k_scale; const float* bias; void* o;
+  int32_t B, F, P, heads, ld, ld_o, causal; float scale;
+} ImagenTemporalAttentionParams;
 
 /* QNORM — q[r, h, :] = l2norm(q[r, h, :]) * q_scale * mult   in place (ip.py:559-560, 812-813). */
 typedef struct ImagenQnormParams {

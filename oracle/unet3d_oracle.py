@@ -367,14 +367,19 @@ def unet3d_forward(sd: Dict[str, Tensor], kwargs: dict, x: Tensor, time: Tensor,
                 x = (conv_frames(x, lp("7.fns.0.weight"), lp("7.fns.0.bias"), padding=1)
                      + conv_frames(x, lp("7.fns.1.weight"), lp("7.fns.1.bias")))
 
+    tap("mid_in", x)
     x = resnet_block3d(p.sub("mid_block1"), x, t, c, ignore_time)             # iv.py:1885-1901
+    tap("mid_block1", x)
     if cfg["attend_at_middle"]:
         tok = to_tokens(x)
         tok = attention3d(p.sub("mid_attn.fn"), tok) + tok
         x = from_tokens(tok, x)
+    tap("mid_attn", x)
     if not ignore_time:
         x = temporal_peg(p.sub("mid_temporal_peg"), x, causal)
+        tap("mid_peg", x)
         x = temporal_attention(p.sub("mid_temporal_attn"), x, causal)
+        tap("mid_tattn", x)
     x = resnet_block3d(p.sub("mid_block2"), x, t, c, ignore_time)
     tap("mid", x)
 

@@ -297,6 +297,36 @@ class Interpreter:
         ctx = self.gca_ctx.pop(p.part)
         self.mem.view(p.gate, f32)[:p.B * p.C].copy_(self._gca_gate(ctx, p.w1t, p.b1, p.w2t, p.b2, p.C, p.hidden).reshape(-1))
 
+    # ------------------------------------------------------------------------------------------------ Imagen-Video ops
+    def temporal_peg(self, p):
+        m = self.mem
+        x = m.strided(p.x, f16, (p.B, p.F, p.P, p.C), (p.F * p.P * p.C, p.P * p.C, p.C, 1)).float()
+        w = m.view(p.w, f32)[:p.C * 3].reshape(p.C, 3)
+        pad = (2, 0) if p.causal else (1, 1)
+        xp = F.pad(x, (0, 0, 0, 0, pad[0], pad[1]))
+        out = x + m.view(p.bias, f32)[:p.C]
+        for k in range(3):
+            out = out + w[:, k] * xp[:, k:k + p.F]
+        m.strided(p.out, f16, (p.B, p.F, p.P, p.C), (p.F * p.P * p.C, p.P * p.C, p.C, 1)).copy_(out.half())
+
+    def temporal_attention(self, p):
+        m = self.mem
+        Fr, P, H = p.F, p.P, p.heads
+        rows = m.strided(p.qkv, f16, (p.B, Fr, P, H * 64 + 128), (Fr * P * p.ld, P * p.ld, p.ld, 1)).float()
+        q = rows[..., :H * 64].reshape(p.B, Fr, P, H, 64).permute(0, 2, 3, 1, 4)          # b p h i d
+        k, v = rows[..., H * 64:H * 64 + 64].permute(0, 2, 1, 3), rows[..., H * 64 + 64:].permute(0, 2, 1, 3)   # b p j d
+        nkv = m.view(p.null_kv, f32)[:128].reshape(2, 64)
+        k = torch.cat((nkv[0].expand(p.B, P, 1, 64), k), dim=2)
+        v = torch.cat((nkv[1].expand(p.B, P, 1, 64), v), dim=2)
+        qh = F.normalize(q, dim=-1, eps=1e-12) * m.view(p.q_scale, f32)[:64] * p.scale
+        kh = F.normalize(k, dim=-1, eps=1e-12) * m.view(p.k_scale, f32)[:64]
+        sim = torch.einsum("bphid,bpjd->bphij", qh, kh) + m.view(p.bias, f32)[:H * Fr * (Fr + 1)].reshape(H, Fr, Fr + 1)
+        if p.causal:
+            sim = sim.masked_fill(torch.ones(Fr, Fr + 1, dtype=torch.bool).triu(2), -torch.finfo(sim.dtype).max)
+        o = torch.einsum("bphij,bpjd->bphid", sim.softmax(-1), v)                       # b p h i d
+        o = o.permute(0, 3, 1, 2, 4).reshape(p.B, Fr, P, H * 64)
+        m.strided(p.o, f16, (p.B, Fr, P, H * 64), (Fr * P * p.ld_o, P * p.ld_o, p.ld_o, 1)).copy_(o.half())
+
     DISPATCH = {}
 
 
@@ -308,4 +338,5 @@ Interpreter.DISPATCH = {
     K["IMAGEN_OP_TIME_EMBED"]: Interpreter.time_embed, K["IMAGEN_OP_SCALE_SHIFT"]: Interpreter.scale_shift,
     K["IMAGEN_OP_PACK_IMAGE"]: Interpreter.pack_image, K["IMAGEN_OP_ROWS_COPY"]: Interpreter.rows_copy, K["IMAGEN_OP_MEMSET32"]: Interpreter.memset32,
     K["IMAGEN_OP_SELECT_ROWS"]: Interpreter.select_rows, K["IMAGEN_OP_MEAN_ROWS"]: Interpreter.mean_rows,
+    K["IMAGEN_OP_TEMPORAL_PEG"]: Interpreter.temporal_peg, K["IMAGEN_OP_TEMPORAL_ATTENTION"]: Interpreter.temporal_attention,
 }
