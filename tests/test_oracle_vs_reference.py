@@ -88,3 +88,32 @@ def test_unet3d_forward_readme_config():
             o = u3.unet3d_forward(u.state_dict(), kw, x, t, text_embeds=te, cond_drop_prob=cdp)
             assert r.abs().mean() > 0.05
             assert torch.allclose(r, o, atol=1e-4, rtol=1e-4), (r - o).abs().max()
+
+
+def _sweep_inputs(kw, seed=5):
+    torch.manual_seed(seed)
+    B, S = 2, 16
+    x, t = torch.randn(B, kw.get("channels", 3), S, S), torch.tensor([0.4, -1.7])
+    te = torch.randn(B, 7, kw["text_embed_dim"]) if kw.get("cond_on_text", True) else None
+    extra = dict(lowres_cond_img=torch.randn(B, 3, S, S), lowres_noise_times=torch.tensor([0.9, 0.9])) if kw.get("lowres_cond") else {}
+    return x, t, te, extra
+
+
+@pytest.mark.parametrize("name", list(__import__("unet_config_sweep").SWEEP))
+def test_unet_oracle_config_sweep(name):
+    """The oracle against the live reference over constructor-flag combinations beyond the README unets (the planner is then checked
+    against the oracle for the same configurations in tests/test_plan_interp.py)."""
+    from unet_config_sweep import SWEEP
+
+    kw = SWEEP[name]
+    ip = ref_shim.load_reference()
+    torch.manual_seed(1)
+    u = ip.Unet(**kw).eval()
+    _dezero(u)
+    x, t, te, extra = _sweep_inputs(kw)
+    with torch.no_grad():
+        for cdp in (0.0, 1.0):
+            r = u(x, t, text_embeds=te, cond_drop_prob=cdp, **extra)
+            o = uo.unet_forward(u.state_dict(), kw, x, t, text_embeds=te, cond_drop_prob=cdp, **extra)
+            assert r.abs().mean() > 1e-3
+            assert torch.allclose(r, o, atol=2e-5, rtol=1e-4), (name, cdp, (r - o).abs().max())

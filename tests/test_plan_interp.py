@@ -162,3 +162,45 @@ def test_unet_plan_without_text_mask(reference_weights):
         ref = uo.unet_forward(g["state_dict"], g["kwargs"], g["x"], g["time"], text_embeds=g["text_embeds"], text_mask=None)
     assert nerr(eng.out, ref) < 5e-3
     assert nerr(eng.out, g["out_cond"]) > 2e-2     # the masked run of the fixture is a different function
+
+
+@pytest.mark.parametrize("name", list(__import__("unet_config_sweep").SWEEP))
+def test_unet_plan_config_sweep(name, reference_weights):
+    """Planner + interpreter vs the oracle over constructor-flag combinations the GPU fixtures do not cover (memory-efficient layout,
+    no attention pooling, unconditional, deeper transformer blocks, no final resnet block, plain init conv, three levels, ...)."""
+    from imagen_pytorch_amd import Unet
+    from imagen_pytorch_amd.engine import UnetEngine
+    from oracle import unet_oracle as uo
+    from plan_interp import Interpreter
+    from unet_config_sweep import SWEEP
+
+    kw = SWEEP[name]
+    torch.manual_seed(1)
+    u = Unet(**kw).eval()
+    torch.nn.init.normal_(u.final_conv.weight, std=0.05)
+    torch.nn.init.normal_(u.final_conv.bias, std=0.05)
+    B, S = 2, 16
+    torch.manual_seed(5)
+    x, t = torch.randn(B, 3, S, S), torch.tensor([0.4, -1.7])
+    with_text = kw.get("cond_on_text", True)
+    te = torch.randn(B, 7, kw["text_embed_dim"]) if with_text else None
+    extra = dict(lowres_cond_img=torch.randn(B, 3, S, S), lowres_noise_times=torch.tensor([0.9, 0.9])) if kw.get("lowres_cond") else {}
+    eng = UnetEngine(u, 2 * B, B, S, "cpu", with_text=with_text, dry=True)
+    keep = torch.ones(2 * B, dtype=torch.bool)
+    keep[B:] = False
+    eng.set_conditioning(text_embeds=te, text_mask=None, keep=keep, lowres_noise_times=extra.get("lowres_noise_times"))
+    it = Interpreter()
+    for buf in (eng.x_in, eng.lowres_in, eng.times, eng.lowres_times, eng.out, eng.keep_u8, eng.src_idx, eng.arange_idx, eng.t_const.t):
+        it.mem.register(buf)
+    it.run(eng._static_plans[te.shape[1] if with_text else 0][0])
+    eng.x_in.copy_(x)
+    if eng.lowres:
+        eng.lowres_in.copy_(extra["lowres_cond_img"])
+    eng.times.copy_(t.repeat(2))
+    it.run(eng.step_plan)
+    sd = u.state_dict()
+    with torch.no_grad():
+        ref_c = uo.unet_forward(sd, kw, x, t, text_embeds=te, **extra)
+        ref_n = uo.unet_forward(sd, kw, x, t, text_embeds=te, cond_drop_prob=1.0, **extra)
+    e_c, e_n = nerr(eng.out[:B], ref_c), nerr(eng.out[B:], ref_n)
+    assert e_c < 1e-2 and e_n < 1e-2, (name, e_c, e_n)

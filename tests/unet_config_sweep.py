@@ -1,0 +1,22 @@
+"""Constructor-flag combinations of the image `Unet` outside the two README unets: shared by the oracle-vs-live-reference sweep
+(tests/test_oracle_vs_reference.py) and the planner-vs-oracle sweep (tests/test_plan_interp.py)."""
+
+_T = dict(dim=8, cond_dim=32, text_embed_dim=32, dim_mults=(1, 2), attn_heads=2, max_text_len=16, attn_pool_num_latents=8)
+
+SWEEP = {
+    "memory_efficient": dict(_T, num_resnet_blocks=(1, 2), layer_attns=(False, True), layer_cross_attns=(False, True), memory_efficient=True),
+    "memory_efficient_lowres": dict(_T, num_resnet_blocks=2, layer_attns=(False, True), layer_cross_attns=(False, True), memory_efficient=True,
+                                    lowres_cond=True),
+    "no_attn_pool": dict(_T, num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(True, True), attn_pool_text=False),
+    "unconditional": dict(_T, num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=False, cond_on_text=False),
+    "depth2_attn_everywhere": dict(_T, num_resnet_blocks=1, layer_attns=True, layer_attns_depth=2, layer_mid_attns_depth=2, layer_cross_attns=True),
+    "no_final_resnet_no_skip_scale": dict(_T, num_resnet_blocks=2, layer_attns=(False, True), layer_cross_attns=(False, True),
+                                          final_resnet_block=False, scale_skip_connection=False),
+    "plain_init_conv_no_mid_attn": dict(_T, num_resnet_blocks=1, layer_attns=False, layer_cross_attns=(False, True), init_cross_embed=False,
+                                        attend_at_middle=False, init_conv_kernel_size=7),
+    "three_levels_no_gca": dict(_T, dim_mults=(1, 2, 4), num_resnet_blocks=(1, 1, 2), layer_attns=(False, False, True),
+                                layer_cross_attns=(False, True, True), use_global_context_attn=False),
+    "four_time_tokens_init_dim": dict(_T, num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True), num_time_tokens=4,
+                                      init_dim=16, ff_mult=4.),
+    "channels_out_6": dict(_T, num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True), channels_out=6),
+}
