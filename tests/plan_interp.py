@@ -327,6 +327,83 @@ class Interpreter:
         o = o.permute(0, 3, 1, 2, 4).reshape(p.B, Fr, P, H * 64)
         m.strided(p.o, f16, (p.B, Fr, P, H * 64), (Fr * P * p.ld_o, P * p.ld_o, p.ld_o, 1)).copy_(o.half())
 
+    # ------------------------------------------------------------------------------------------------ sampler ops (injected noise only)
+    def _coef_row(self, coef, step_ptr):
+        step = int(self.mem.view(step_ptr, i32)[0])
+        return step, self.mem.view(coef, f32)[step * 8: step * 8 + 8]
+
+    def cfg_x0(self, p):
+        m = self.mem
+        n = p.B * p.n_per_sample
+        _, cf = self._coef_row(p.coef, p.step_ptr)
+        alpha, sigma = cf[0], cf[1]
+        x = m.view(p.x, f32)[:n]
+        pred = m.view(p.pred, f32)[: (2 * n if p.cfg else n)]
+        out = pred[n:] + (pred[:n] - pred[n:]) * p.cond_scale if p.cfg else pred
+        if p.objective == 0:
+            x0 = (x - sigma * out) / alpha.clamp(min=1e-8)
+        elif p.objective == 1:
+            x0 = out
+        else:
+            x0 = alpha * x - sigma * out
+        m.view(p.x0, f32)[:n].copy_(x0)
+        m.view(p.absx0, f32)[:n].copy_(x0.abs())
+
+    def quantile(self, p):
+        a = self.mem.view(p.absx0, f32)[: p.B * p.n].reshape(p.B, p.n)
+        self.mem.view(p.out, f32)[: p.B].copy_(torch.quantile(a, p.q, dim=-1))
+
+    def ddpm_update(self, p):
+        m = self.mem
+        assert p.noise, "the interpreter only supports injected noise (the Philox stream is a kernel detail)"
+        n = p.B * p.n_per_sample
+        step, cf = self._coef_row(p.coef, p.step_ptr)
+        alpha, alpha_next, sigma_next, c, nonzero = cf[0], cf[2], cf[3], cf[4], cf[5]
+        x0 = m.view(p.x0, f32)[:n].reshape(p.B, -1)
+        if p.dynamic_threshold:
+            s = m.view(p.quant, f32)[: p.B].clamp(min=1.0).reshape(p.B, 1)
+            x0 = x0.clamp(-s, s) / s
+        else:
+            x0 = x0.clamp(-1.0, 1.0)
+        x = m.view(p.x, f32)[:n].reshape(p.B, -1)
+        mean = alpha_next * (x * (1.0 - c) / alpha + c * x0)
+        xn = mean + nonzero * (sigma_next * sigma_next * c).clamp(min=1e-20).sqrt() * m.view(p.noise, f32)[:n].reshape(p.B, -1)
+        x.copy_(xn)
+        if step + 1 >= p.total_steps and p.final_out:
+            m.view(p.final_out, f32)[:n].copy_(((xn.clamp(-1.0, 1.0) + 1.0) * 0.5).reshape(-1))
+        if not p.no_advance:
+            m.view(p.step_ptr, i32)[0] += 1
+
+    def lincomb(self, p):
+        m = self.mem
+        n = p.B * p.n_per_sample
+        _, w = self._coef_row(p.coef, p.step_ptr)
+        assert float(w[4]) == 0.0, "the interpreter only supports injected noise (pass it as t1)"
+        thr = lambda t, q: t
+        if p.thr_mode == 1:
+            def thr(t, q):
+                s = m.view(q, f32)[: p.B].clamp(min=1.0).reshape(p.B, 1)
+                return (t.reshape(p.B, -1).clamp(-s, s) / s).reshape(-1)
+        elif p.thr_mode == 2:
+            thr = lambda t, q: t.clamp(-1.0, 1.0)
+        v = w[0] * m.view(p.t0, f32)[:n]
+        if p.t1:
+            v = v + w[1] * thr(m.view(p.t1, f32)[:n], p.q1)
+        if p.t2:
+            v = v + w[2] * m.view(p.t2, f32)[:n]
+        if p.t3:
+            v = v + w[3] * thr(m.view(p.t3, f32)[:n], p.q3)
+        if p.mask:
+            v = torch.where(m.view(p.mask, f32)[:n] != 0, v, m.view(p.mask_else, f32)[:n])
+        v = v.clone()
+        m.view(p.out, f32)[:n].copy_(v)
+        if p.out2:
+            m.view(p.out2, f32)[:n].copy_(w[5] * v)
+        if p.final and p.final_out:
+            m.view(p.final_out, f32)[:n].copy_((v.clamp(-1.0, 1.0) + 1.0) * 0.5)
+        if p.advance:
+            m.view(p.step_ptr, i32)[0] += 1
+
     DISPATCH = {}
 
 
@@ -338,5 +415,7 @@ Interpreter.DISPATCH = {
     K["IMAGEN_OP_TIME_EMBED"]: Interpreter.time_embed, K["IMAGEN_OP_SCALE_SHIFT"]: Interpreter.scale_shift,
     K["IMAGEN_OP_PACK_IMAGE"]: Interpreter.pack_image, K["IMAGEN_OP_ROWS_COPY"]: Interpreter.rows_copy, K["IMAGEN_OP_MEMSET32"]: Interpreter.memset32,
     K["IMAGEN_OP_SELECT_ROWS"]: Interpreter.select_rows, K["IMAGEN_OP_MEAN_ROWS"]: Interpreter.mean_rows,
+    K["IMAGEN_OP_CFG_X0"]: Interpreter.cfg_x0, K["IMAGEN_OP_QUANTILE"]: Interpreter.quantile, K["IMAGEN_OP_DDPM_UPDATE"]: Interpreter.ddpm_update,
+    K["IMAGEN_OP_LINCOMB"]: Interpreter.lincomb,
     K["IMAGEN_OP_TEMPORAL_PEG"]: Interpreter.temporal_peg, K["IMAGEN_OP_TEMPORAL_ATTENTION"]: Interpreter.temporal_attention,
 }

@@ -204,3 +204,83 @@ def test_unet_plan_config_sweep(name, reference_weights):
         ref_n = uo.unet_forward(sd, kw, x, t, text_embeds=te, cond_drop_prob=1.0, **extra)
     e_c, e_n = nerr(eng.out[:B], ref_c), nerr(eng.out[B:], ref_n)
     assert e_c < 1e-2 and e_n < 1e-2, (name, e_c, e_n)
+
+
+def _dry_engines(monkeypatch):
+    """Make Imagen._stage build its engines on CPU memory without launching (test-side patch; the product has no such switch)."""
+    import functools
+
+    from imagen_pytorch_amd import engine
+
+    monkeypatch.setattr(engine, "UnetEngine", functools.partial(engine.UnetEngine, dry=True))
+
+
+def _stage0_loop(imagen, st, it, g, noise, *, resample_times=0, known=None, mask=None, init=None, skip=0):
+    """The driver loop of Imagen.p_sample_loop for one stage (ip.py:2167-2289), with the per-step plan run by the interpreter."""
+    eng, T = st['eng'], st['T']
+    R = max(resample_times, 1)
+    eng.x_in.copy_(noise[("init", 0)])
+    if init is not None:
+        eng.x_in.add_(init)
+    if resample_times:
+        st['known'].copy_(known)
+        st['mask'].copy_(mask)
+    st['step_ptr'].fill_(skip * R)
+    for i in range(skip, T):
+        for r in reversed(range(R)):
+            if resample_times:
+                st['noise_blend'].copy_(noise[("inpaint", 0, i, r)])
+                st['noise'].copy_(noise[("step", 0, i, r)])
+                if r > 0 and i < T - 1:
+                    st['noise_renoise'].copy_(noise[("renoise", 0, i, r)])
+            else:
+                st['noise'].copy_(noise[("step", 0, i)])
+            it.run(st['plan'])
+    out = st['final']
+    if resample_times:
+        out = torch.where(st['mask'] != 0, (st['known'] + 1) * 0.5, out)
+    return out
+
+
+@pytest.mark.parametrize("run", ["plain", "init_skip", "inpaint"])
+def test_sampler_stage_plan_on_cpu(run, reference_weights, monkeypatch):
+    """Stage 1 of the tiny cascade: denoiser plan + CFG / x0 / exact quantile / posterior step (+ the inpainting blend and re-noising
+    ops) wired by Imagen._stage, replayed on the CPU with the reference's recorded Gaussian draws, vs the reference's stage-1 image."""
+    import torch.nn.functional as F
+
+    from imagen_pytorch_amd import Imagen, Unet
+    from plan_interp import Interpreter
+
+    _dry_engines(monkeypatch)
+    if run == "plain":
+        g = torch.load(os.path.join(GOLDEN, "sample_tiny_cascade.pt"), weights_only=False)
+        r = dict(noise=g["noise"], outputs=g["outputs"])
+    else:
+        g = torch.load(os.path.join(GOLDEN, "sample_tiny_options.pt"), weights_only=False)
+        r = g["runs"][run]
+    unets = [Unet(**spec["kwargs"]).eval() for spec in g["unets"]]
+    imagen = Imagen(unets, image_sizes=g["image_sizes"], timesteps=g["timesteps"], text_embed_dim=32, cond_drop_prob=0.1)
+    for u, spec in zip(imagen.unets, g["unets"]):
+        u.load_state_dict(spec["state_dict"])
+    B, S = g["text_embeds"].shape[0], g["image_sizes"][0]
+    R = r.get("inpaint_resample_times", 0) if run == "inpaint" else 0
+    st = imagen._stage(0, B, torch.device("cpu"), cond_scale=g["cond_scale"], with_text=True, inject_noise=True, sample_offset=0, resample_times=R)
+    eng = st['eng']
+    keep = torch.ones(2 * B, dtype=torch.bool)
+    keep[B:] = False
+    te = g["text_embeds"]
+    eng.set_conditioning(text_embeds=te, text_mask=torch.any(te != 0., dim=-1), keep=keep, lowres_noise_times=None)
+    it = Interpreter()
+    for buf in (eng.x_in, eng.times, eng.lowres_times, eng.out, eng.keep_u8, eng.src_idx, eng.arange_idx, eng.t_const.t):
+        it.mem.register(buf)
+    it.run(eng._static_plans[te.shape[1]][0])
+    kw = {}
+    if run == "init_skip":
+        kw = dict(init=r["init_images"] * 2 - 1, skip=r["skip_steps"])
+    if run == "inpaint":
+        known = F.interpolate(r["inpaint_images"] * 2 - 1, S, mode="nearest")
+        mask = F.interpolate(r["inpaint_masks"][:, None].float(), S, mode="nearest").bool().expand(-1, 3, -1, -1).float()
+        kw = dict(resample_times=R, known=known, mask=mask)
+    out = _stage0_loop(imagen, st, it, g, r["noise"], **kw)
+    e = nerr(out, r["outputs"][0])
+    assert e < 2e-2, e                      # the bar of tests/test_model_gpu.py::test_sample_vs_reference_fixture
