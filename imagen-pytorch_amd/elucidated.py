@@ -121,7 +121,9 @@ class ElucidatedImagen(Imagen):
 
     # ---- per-stage plans --------------------------------------------------------------------------------------------------
     def _stage(self, idx: int, B: int, device, *, cond_scale: float, with_text: bool, inject_noise: bool, sample_offset: int,
-               resample_times: int = 0):
+               resample_times: int = 0, frames: int = 0):
+        if frames:
+            _out_of_scope("ElucidatedImagen with Unet3D (video)")
         unet = self.unets[idx]
         S = self.image_sizes[idx]
         hp = self.hparams[idx]

@@ -24,6 +24,7 @@ from .ops import Plan
 from .schedules import GaussianDiffusionContinuousTimes
 from .t5 import t5_encode_text
 from .unet import NullUnet, Unet
+from .unet3d import Unet3D
 
 T5_DIMS = {  # d_model of the encoders the reference accepts by name (t5.py:47-58 reads it from the HF config)
     't5-small': 512, 't5-base': 768, 't5-large': 1024, 't5-3b': 1024, 't5-11b': 1024,
@@ -128,7 +129,7 @@ class Imagen(nn.Module):
         self.unet_being_trained_index = -1
         self.only_train_unet_number = only_train_unet_number
         for ind, one_unet in enumerate(unets):
-            assert isinstance(one_unet, (Unet, NullUnet))
+            assert isinstance(one_unet, (Unet, Unet3D, NullUnet))
             one_unet = one_unet.cast_model_parameters(
                 lowres_cond=ind > 0, cond_on_text=self.condition_on_text,
                 text_embed_dim=self.text_embed_dim if self.condition_on_text else None,
@@ -139,7 +140,7 @@ class Imagen(nn.Module):
         self.image_sizes = image_sizes
         assert num_unets == len(image_sizes), f'you did not supply the correct number of u-nets ({len(unets)}) for resolutions {image_sizes}'
         self.sample_channels = _cast_tuple(self.channels, num_unets)
-        self.is_video = False
+        self.is_video = any(isinstance(u, Unet3D) for u in self.unets)     # ip.py:1918-1919
         self.resize_mode = resize_mode
         if resize_mode != 'nearest':
             _out_of_scope(f"resize_mode='{resize_mode}'")
@@ -198,7 +199,7 @@ class Imagen(nn.Module):
 
     # ---- one cascade stage -------------------------------------------------------------------------------------
     def _stage(self, idx: int, B: int, device, *, cond_scale: float, with_text: bool, inject_noise: bool, sample_offset: int,
-               resample_times: int = 0):
+               resample_times: int = 0, frames: int = 0):
         """Build (or fetch) the per-timestep plan + graph of stage `idx` for batch B.
 
         resample_times = R > 0 selects the inpainting plan (ip.py:2237-2275): the device counter then counts INNER iterations
@@ -211,14 +212,24 @@ class Imagen(nn.Module):
         T = sched.num_timesteps
         cfg = cond_scale != 1.
         key = (idx, B, S, str(device), float(cond_scale), with_text, inject_noise, sample_offset, self.dynamic_thresholding[idx],
-               self.pred_objectives[idx], self.dynamic_thresholding_percentile, resample_times)
+               self.pred_objectives[idx], self.dynamic_thresholding_percentile, resample_times, frames)
         st = self._stages.get(key)
         if st is not None and not st['eng'].stale():
             return st
         rows = 2 * B if cfg else B
-        from .engine import UnetEngine
-        eng = UnetEngine(unet, rows, B, S, device, with_text=with_text)
-        n = self.channels * S * S
+        video = isinstance(unet, Unet3D)
+        if video:
+            # Imagen-Video stage: the sampler state is the engine's frame-major clip (b, f, c, h, w); every sampler kernel is
+            # elementwise per sample (the dynamic threshold is one quantile over the whole clip, ip.py:1921, 2097-2101), so only
+            # the sample size changes.  sample() converts from / to the reference's (b, c, f, h, w) at the API boundary.
+            assert frames > 0, 'video_frames must be passed in on sample time if training on video'
+            assert not resample_times, 'inpainting of videos is outside this build'
+            from . import engine3d
+            eng = engine3d.UnetEngine3D(unet, rows, B, frames, S, device, with_text=with_text)
+        else:
+            from . import engine
+            eng = engine.UnetEngine(unet, rows, B, S, device, with_text=with_text)
+        n = eng.x_in[0].numel()
         dev = device
         R = resample_times
         if R:
@@ -232,8 +243,8 @@ class Imagen(nn.Module):
         absx0 = torch.empty(B, n, device=dev)
         quant = torch.empty(B, device=dev)
         scratch = torch.empty(B * ops.ENUMS["IMAGEN_QUANTILE_SCRATCH_WORDS"], dtype=torch.int32, device=dev)
-        noise = torch.empty(B, self.channels, S, S, device=dev) if inject_noise else None
-        final = torch.empty(B, self.channels, S, S, device=dev)
+        noise = torch.empty_like(eng.x_in) if inject_noise else None
+        final = torch.empty_like(eng.x_in)
         plan = Plan(f"stage{idx}-step")
         extra = {}
         if R:
@@ -257,7 +268,7 @@ class Imagen(nn.Module):
             ops.lincomb(plan, eng.x_in, eng.x_in, renoise_coef, step_ptr, B=B, n_per_sample=n, t1=extra['noise_renoise'], advance=True,
                         stream_id=idx | 0x200, sample_offset=sample_offset, seed_ptr=seed_dev, label="inpaint.renoise")
         st = dict(eng=eng, plan=plan, graph=None, coef=coef, step_ptr=step_ptr, seed_dev=seed_dev, noise=noise, final=final, T=T, S=S,
-                  quant=quant, x0=x0, R=R, **extra)
+                  quant=quant, x0=x0, R=R, video=video, frames=frames, **extra)
         self._stages[key] = st
         return st
 
@@ -279,9 +290,18 @@ class Imagen(nn.Module):
             init = Plan("init-noise")
             ops.randn(init, eng.x_in, seed=seed, stream_id=stage, tag=TAG_INIT, sample_offset=st.get('sample_offset', 0))
 
+        video = st.get('video', False)
+
+        def draw(tag, like):
+            """Injected Gaussian draw for the internal buffer `like`; videos are drawn in the reference's (b, c, f, h, w) layout."""
+            if not video:
+                return noise_fn(tag, tuple(like.shape))
+            b, f, c, h, w = like.shape
+            return noise_fn(tag, (b, c, f, h, w)).permute(0, 2, 1, 3, 4)
+
         def reset_state():
             if noise_fn is not None:
-                eng.x_in.copy_(noise_fn(("init", stage), tuple(eng.x_in.shape)))
+                eng.x_in.copy_(draw(("init", stage), eng.x_in))
             else:
                 init.run()
             if init_images is not None:
@@ -306,14 +326,13 @@ class Imagen(nn.Module):
         for i in it:
             for r in reversed(range(inner)):
                 if noise_fn is not None:
-                    shape = tuple(st['noise'].shape)
                     if R:
-                        st['noise_blend'].copy_(noise_fn(("inpaint", stage, i, r), shape))
-                        st['noise'].copy_(noise_fn(("step", stage, i, r), shape))
+                        st['noise_blend'].copy_(draw(("inpaint", stage, i, r), st['noise']))
+                        st['noise'].copy_(draw(("step", stage, i, r), st['noise']))
                         if r > 0 and i < T - 1:          # the reference draws no re-noising sample otherwise (ip.py:2268)
-                            st['noise_renoise'].copy_(noise_fn(("renoise", stage, i, r), shape))
+                            st['noise_renoise'].copy_(draw(("renoise", stage, i, r), st['noise']))
                     else:
-                        st['noise'].copy_(noise_fn(("step", stage, i), shape))
+                        st['noise'].copy_(draw(("step", stage, i), st['noise']))
                 if use_graph:
                     st['graph'].launch()
                 else:
@@ -413,10 +432,18 @@ class Imagen(nn.Module):
         if device.type != 'cuda':
             raise RuntimeError("imagen_pytorch_amd.Imagen.sample runs on MI355X only (move the module to 'cuda'); there is no CPU path")
         self.reset_unets_all_one_device(device)
-        for name, val in (('video_frames', video_frames), ('cond_images', cond_images), ('cond_video_frames', cond_video_frames),
+        for name, val in (('cond_images', cond_images), ('cond_video_frames', cond_video_frames),
                           ('post_cond_video_frames', post_cond_video_frames), ('inpaint_videos', inpaint_videos)):
             if val is not None:
                 _out_of_scope(f"sample({name}=...)")
+        assert not (self.is_video and video_frames is None), 'video_frames must be passed in on sample time if training on video'   # ip.py:2381
+        if self.is_video:
+            if inpaint_images is not None or skip_steps is not None or any(i is not None for i in _cast_tuple(init_images)):
+                _out_of_scope("inpainting / init_images / skip_steps for video")
+            if any(f != 1 for f in self.temporal_downsample_factor):
+                _out_of_scope("temporal_downsample_factor != 1 (every stage samples all video_frames)")
+        frames = int(video_frames) if self.is_video else 0
+        to_internal = (lambda t: t.permute(0, 2, 1, 3, 4).contiguous()) if self.is_video else (lambda t: t)   # (b,c,f,h,w) <-> (b,f,c,h,w)
         if return_pil_images:
             _out_of_scope("return_pil_images (torchvision is not part of this stack)")
 
@@ -457,7 +484,7 @@ class Imagen(nn.Module):
             assert start_at_unet_number <= num_unets, 'must start a unet that is less than the total number of unets'
             assert stop_at_unet_number is None or start_at_unet_number <= stop_at_unet_number
             assert start_image_or_video is not None, 'starting image or video must be supplied if only doing upscaling'
-            img = start_image_or_video.to(device).float().contiguous()
+            img = to_internal(start_image_or_video.to(device).float()).contiguous()
 
         if self._stream is None or self._stream.device != device:
             self._stream = torch.cuda.Stream(device=device)
@@ -475,7 +502,8 @@ class Imagen(nn.Module):
                     'imagen was not trained with conditional dropout, and thus one cannot use classifier free guidance (cond_scale anything other than 1)'
                 with_text = text_embeds is not None and unet.cond_on_text
                 st = self._stage(idx, batch_size, device, cond_scale=cs, with_text=with_text, inject_noise=noise_fn is not None,
-                                 sample_offset=sample_offset, resample_times=inpaint_resample_times if known is not None else 0)
+                                 sample_offset=sample_offset, resample_times=inpaint_resample_times if known is not None else 0,
+                                 frames=frames if isinstance(unet, Unet3D) else 0)
                 st['sample_offset'] = sample_offset
                 eng = st['eng']
                 S = self.image_sizes[idx]
@@ -489,14 +517,21 @@ class Imagen(nn.Module):
                     # Imagen conditions on the log-SNR of the augmentation level (ip.py:2081); ElucidatedImagen.sample passes the
                     # raw level (elucidated_imagen.py:700, 728) — `_lowres_time_raw` is set by that subclass
                     lowres_logsnr = torch.full((batch_size,), level if getattr(self, "_lowres_time_raw", False) else lsnr, dtype=torch.float32)
-                    aug = torch.empty(batch_size, self.channels, S, S, device=device)
+                    aug = torch.empty_like(eng.lowres_in)
                     if noise_fn is not None:
-                        aug.copy_(noise_fn(("lowres", idx), tuple(aug.shape)))
+                        if st.get('video', False):
+                            b_, f_, c_, h_, w_ = aug.shape
+                            aug.copy_(noise_fn(("lowres", idx), (b_, c_, f_, h_, w_)).permute(0, 2, 1, 3, 4))
+                        else:
+                            aug.copy_(noise_fn(("lowres", idx), tuple(aug.shape)))
                     prep = Plan("lowres-prep")
                     if noise_fn is None:
                         ops.randn(prep, aug, seed=seed, stream_id=idx, tag=TAG_LOWRES, sample_offset=sample_offset)
-                    src = img if self.auto_normalize_img else (img + 1) * 0.5   # kernel normalises [0,1] -> [-1,1]
-                    ops.lowres_prep(prep, src.contiguous(), aug, eng.lowres_in, alpha=a, sigma=s)
+                    src = (img if self.auto_normalize_img else (img + 1) * 0.5).contiguous()   # kernel normalises [0,1] -> [-1,1]
+                    # frames are independent images for the nearest resize (resize_video_to with unchanged frame count, iv.py:134-156)
+                    as_images = lambda t: t.reshape(-1, *t.shape[-3:])
+                    ops.lowres_prep(prep, as_images(src), as_images(aug), as_images(eng.lowres_in), alpha=a, sigma=s)
+                    prep.keep += [src, aug, eng.lowres_in]
                     prep.run()
                 rows = eng.R
                 keep = torch.ones(rows, dtype=torch.bool)
@@ -524,10 +559,10 @@ class Imagen(nn.Module):
                     self.last_stage_seconds[idx] = dt
                     print(f"[imagen] stage {idx} ({S}x{S}, rows {eng.R}): {dt * 1e3:.1f} ms for {st['T'] if max_steps is None else min(st['T'], max_steps)} steps "
                           f"({len(st['plan'])} launches/step)", flush=True, file=__import__('sys').stderr)
-                img = out.clone()
+                img = out.clone()                    # internal layout (videos: frame-major), feeds the next stage's low-res conditioning
                 if not self.auto_normalize_img:
                     img = img * 2 - 1
-                outputs.append(img)
+                outputs.append(to_internal(img) if st.get('video', False) else img)   # the permutation is its own inverse
                 if stop_at_unet_number is not None and stop_at_unet_number == unet_number:
                     break
         self._stream.synchronize()

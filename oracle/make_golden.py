@@ -201,6 +201,35 @@ def make_unet3d_fixture(iv, path, seed=21):
     print(f"wrote {path}")
 
 
+def make_video_sample_fixture(ip, iv, path, seed=23, T=2, frames=4):
+    """Imagen.sample of the live reference over two Unet3D stages (8 -> 16 pixels, `video_frames` = 4, CFG 3), every Gaussian draw
+    recorded.  Draws per stage (ip.py:2449, 2195, 2160): [lowres augmentation], init, T steps — all of shape (b, c, f, h, w)."""
+    torch.manual_seed(seed)
+    kw1 = {**TINY_3D, "temporal_strides": (1, 2)}
+    kw2 = {**TINY_3D, "temporal_strides": (2, 1), "num_resnet_blocks": (1, 2)}
+    u1, u2 = iv.Unet3D(**kw1), iv.Unet3D(**kw2)
+    imagen = ip.Imagen((u1, u2), image_sizes=(8, 16), timesteps=T, text_embed_dim=32, cond_drop_prob=0.1).eval()
+    for u in imagen.unets:
+        derandomise_unet3d(u)
+    text_embeds = torch.randn(2, 9, 32)
+    outs, draws = _record_draws(lambda: imagen.sample(text_embeds=text_embeds, video_frames=frames, cond_scale=3., use_tqdm=False,
+                                                      return_all_unet_outputs=True))
+    noise, it = {}, iter(draws)
+    for stage in range(2):
+        if stage > 0:
+            noise[("lowres", stage)] = next(it)
+        noise[("init", stage)] = next(it)
+        for i in range(T):
+            noise[("step", stage, i)] = next(it)
+    assert next(it, None) is None
+    unets = [dict(kwargs={**kw, "lowres_cond": i > 0}, state_dict={k: v.clone() for k, v in u.state_dict().items()})
+             for i, (u, kw) in enumerate(zip(imagen.unets, (kw1, kw2)))]
+    torch.save(dict(unets=unets, image_sizes=(8, 16), timesteps=T, frames=frames, cond_scale=3., text_embeds=text_embeds, noise=noise,
+                    outputs=[o.clone() for o in outs], generator="oracle/make_golden.py --video",
+                    reference="lucidrains/imagen-pytorch v2.0.0 Imagen.sample over Unet3D stages (ip.py:2291-2498, imagen_video.py)"), path)
+    print(f"wrote {path}: outputs {[tuple(o.shape) for o in outs]}, std {outs[-1].std():.4f}, {len(draws)} draws")
+
+
 def _record_draws(fn):
     """Run fn() with torch.randn / randn_like recording every Gaussian draw, in call order."""
     draws = []
@@ -316,6 +345,9 @@ def make_checkpoint_fixture(ip, path, seed=17, T=2):
 
 def main():
     ip = load_reference()
+    if "--video" in sys.argv:        # only the video sampling fixture
+        make_video_sample_fixture(ip, load_reference("imagen_video"), os.path.join(GOLDEN, "sample_tiny_video.pt"))
+        return
     if "--unet3d" in sys.argv:       # only the Imagen-Video denoiser fixture (SURVEY §8(f) NEXT-2 groundwork)
         make_unet3d_fixture(load_reference("imagen_video"), os.path.join(GOLDEN, "unet3d_tiny.pt"))
         return

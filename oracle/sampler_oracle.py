@@ -25,6 +25,7 @@ from typing import Callable, Dict, List, Optional, Sequence
 import torch
 import torch.nn.functional as F
 
+from .unet3d_oracle import unet3d_forward_with_cond_scale
 from .unet_oracle import unet_forward_with_cond_scale
 
 Tensor = torch.Tensor
@@ -174,6 +175,7 @@ def imagen_sample(
     inpaint_images: Optional[Tensor] = None,   # [0, 1] images, same for every stage
     inpaint_masks: Optional[Tensor] = None,    # (B, H, W) bool
     inpaint_resample_times: int = 5,
+    video_frames: Optional[int] = None,        # Imagen-Video: the unets are Unet3D state_dicts, every stage samples this many frames
 ):
     """ip.py:2291-2498 for text_embeds-conditioned image sampling (no video, no cond_images, no self-conditioning)."""
     n = len(unets)
@@ -185,6 +187,7 @@ def imagen_sample(
     if text_masks is None:
         text_masks = torch.any(text_embeds != 0.0, dim=-1)  # ip.py:2337
     b = text_embeds.shape[0]
+    video = video_frames is not None          # Imagen-Video: every unet is a Unet3D, samples are (b, c, f, h, w)  (ip.py:1918, 2381-2383)
     as_tuple = lambda v: tuple(v) if isinstance(v, (list, tuple)) else (v,) * n
     init_images = [None if im is None else im * 2 - 1 for im in as_tuple(init_images)]   # normalize_img, ip.py:2391
     skip_steps = as_tuple(skip_steps)
@@ -194,17 +197,23 @@ def imagen_sample(
         lowres_img = lowres_times = None
         if kw.get("lowres_cond", False):
             lowres_times = torch.full((b,), lowres_sample_noise_level, dtype=torch.float32)
-            up = img if img.shape[-1] == size else F.interpolate(img, size, mode="nearest")  # ip.py:152-168
+            if video:   # resize_video_to with an unchanged frame count (iv.py:134-156): nearest over (f, h, w)
+                up = img if img.shape[-1] == size else F.interpolate(img, (img.shape[2], size, size), mode="nearest")
+            else:
+                up = img if img.shape[-1] == size else F.interpolate(img, size, mode="nearest")  # ip.py:152-168
             up = up * 2 - 1
-            a, s = alpha_sigma(SCHEDULES[lowres_noise_schedule](lowres_times).reshape(-1, 1, 1, 1))
+            a, s = alpha_sigma(SCHEDULES[lowres_noise_schedule](lowres_times).reshape(-1, *([1] * (up.ndim - 1))))
             lowres_img = a * up + s * noise_fn(("lowres", stage), up.shape)       # ip.py:272-284, 2449
             lowres_logsnr = SCHEDULES[lowres_noise_schedule](lowres_times)       # ip.py:2081
 
-        def denoise(x, log_snr, _sd=sd, _kw=kw, _cs=cs, _li=lowres_img, _lt=(lowres_logsnr if lowres_img is not None else None)):
-            return unet_forward_with_cond_scale(_sd, _kw, x, log_snr, cond_scale=_cs, text_embeds=text_embeds,
-                                                text_mask=text_masks, lowres_cond_img=_li, lowres_noise_times=_lt)
+        fwd = unet3d_forward_with_cond_scale if video else unet_forward_with_cond_scale
 
-        img = p_sample_loop(denoise, (b, channels, size, size), schedule=sched, num_timesteps=T, noise_fn=noise_fn,
+        def denoise(x, log_snr, _sd=sd, _kw=kw, _cs=cs, _li=lowres_img, _lt=(lowres_logsnr if lowres_img is not None else None)):
+            return fwd(_sd, _kw, x, log_snr, cond_scale=_cs, text_embeds=text_embeds, text_mask=text_masks, lowres_cond_img=_li,
+                       lowres_noise_times=_lt)
+
+        shape = (b, channels, video_frames, size, size) if video else (b, channels, size, size)
+        img = p_sample_loop(denoise, shape, schedule=sched, num_timesteps=T, noise_fn=noise_fn,
                             stage=stage, dynamic_thresholding=dynamic_thresholding, percentile=percentile,
                             max_steps=max_steps, init_images=init_images[stage], skip_steps=skip_steps[stage], inpaint_images=known,
                             inpaint_masks=inpaint_masks, inpaint_resample_times=inpaint_resample_times)

@@ -146,3 +146,15 @@ def test_unet3d_oracle_matches_reference_fixture(tag):
     for got, ref in ((cond, g["out_cond"]), (null, g["out_null"]), (cfg, g["out_cfg"]), (notime, g["out_notime"])):
         assert got.shape == ref.shape and ref.abs().mean() > 0.05
         assert torch.allclose(got, ref, atol=5e-5, rtol=1e-5), (got - ref).abs().max()
+
+
+def test_video_sampler_oracle_matches_reference_fixture():
+    """Imagen.sample over two Unet3D stages (`video_frames` = 4): sampler oracle + Unet3D oracle vs the recorded reference run."""
+    g = _load("sample_tiny_video.pt")
+    unets = [(u["state_dict"], u["kwargs"]) for u in g["unets"]]
+    with torch.no_grad():
+        outs = so.imagen_sample(unets, g["image_sizes"], g["text_embeds"], timesteps=g["timesteps"], cond_scale=g["cond_scale"],
+                                noise_fn=lambda tag, shape: g["noise"][tag], return_all=True, video_frames=g["frames"])
+    for got, ref in zip(outs, g["outputs"]):
+        assert got.shape == ref.shape and got.ndim == 5
+        assert torch.allclose(got, ref, atol=2e-4), (got - ref).abs().max()

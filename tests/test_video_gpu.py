@@ -99,3 +99,25 @@ def test_unet3d_forward_vs_reference_fixture(tag):
     e_g = nerr(cfg, g["out_cfg"])
     print(f"unet3d[{tag}] vs reference: cond {e_c:.2e} null {e_n:.2e} ignore_time {e_i:.2e} cfg {e_g:.2e}")
     assert max(e_c, e_n, e_i) < 1e-2 and e_g < 2e-2
+
+
+def test_video_cascade_sample_vs_reference_fixture():
+    """Imagen.sample(video_frames=4) over two Unet3D stages vs the recorded reference run (same draws); graph == eager."""
+    from imagen_pytorch_amd import Imagen, Unet3D
+
+    dev = torch.device("cuda:0")
+    g = torch.load(os.path.join(GOLDEN, "sample_tiny_video.pt"), weights_only=False)
+    unets = [Unet3D(**spec["kwargs"]).eval() for spec in g["unets"]]
+    imagen = Imagen(unets, image_sizes=g["image_sizes"], timesteps=g["timesteps"], text_embed_dim=32, cond_drop_prob=0.1).to(dev)
+    for u, spec in zip(imagen.unets, g["unets"]):
+        u.load_state_dict(spec["state_dict"])
+    noise_fn = lambda tag, shape: g["noise"][tag].to(dev)
+    res = {}
+    for use_graph in (False, True):
+        outs = imagen.sample(text_embeds=g["text_embeds"].to(dev), video_frames=g["frames"], cond_scale=g["cond_scale"], use_tqdm=False,
+                             return_all_unet_outputs=True, noise_fn=noise_fn, use_graph=use_graph)
+        errs = [nerr(o, r) for o, r in zip(outs, g["outputs"])]
+        print("video cascade", "graph" if use_graph else "eager", errs)
+        assert all(o.shape == r.shape for o, r in zip(outs, g["outputs"])) and max(errs) < 2e-2
+        res[use_graph] = outs
+    assert all(torch.equal(a, b) for a, b in zip(res[False], res[True]))
