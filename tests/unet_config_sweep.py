@@ -18,5 +18,9 @@ SWEEP = {
                                 layer_cross_attns=(False, True, True), use_global_context_attn=False),
     "four_time_tokens_init_dim": dict(_T, num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True), num_time_tokens=4,
                                       init_dim=16, ff_mult=4.),
+    "dim32_three_levels": dict(dim=32, cond_dim=64, text_embed_dim=32, dim_mults=(1, 2, 4), attn_heads=4, max_text_len=16, attn_pool_num_latents=8,
+                               num_resnet_blocks=(1, 2, 2), layer_attns=(False, True, True), layer_cross_attns=(False, True, True)),
+    "dim24_lowres": dict(dim=24, cond_dim=40, text_embed_dim=32, dim_mults=(1, 2), attn_heads=2, max_text_len=16, attn_pool_num_latents=8,
+                         num_resnet_blocks=2, layer_attns=(False, True), layer_cross_attns=(True, True), lowres_cond=True),
     "channels_out_6": dict(_T, num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True), channels_out=6),
 }
