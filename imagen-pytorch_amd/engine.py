@@ -230,6 +230,7 @@ class UnetEngine:
         x = self.new(R, S, S, self.lc["init_dim"])
         self._init_conv(plan, x)
         self.taps['init_conv'] = x
+        init_res = x if u.init_conv_to_final_conv_residual else None      # ip.py:1568-1569 (buffers are never overwritten: no clone)
         if u.init_resnet_block is not None:
             x = self._resnet(plan, x, None, u.init_resnet_block, "init_resnet", with_cond=False)
         hiddens: List[Act] = []
@@ -263,10 +264,12 @@ class UnetEngine:
                 x = self._transformer(plan, x, attn_block, f"ups.{i}.2", with_context=True)
             if isinstance(upsample, PixelShuffleUpsampleP):
                 x = self._upsample(plan, x, upsample, f"ups.{i}.3")
+            elif isinstance(upsample, nn.Sequential):
+                x = self._upsample_nearest_conv(plan, x, upsample, f"ups.{i}.3")
             self.taps[f'up{i}'] = x
         assert not hiddens
-        if u.final_res_block is not None:
-            x = self._resnet(plan, x, None, u.final_res_block, "final_res_block", with_cond=False)
+        if u.final_res_block is not None:   # with init_conv_to_final_conv_residual its input is cat(x, init conv output), unscaled (ip.py:1716-1720)
+            x = self._resnet(plan, x, init_res, u.final_res_block, "final_res_block", with_cond=False, skip_scale=1.0)
         self.taps['final_res'] = x
         self._final_conv(plan, x)
 
@@ -324,12 +327,12 @@ class UnetEngine:
         ops.igemm(plan, x, self.W.get("final_conv", make), self.out, x2=extra, out_mode=OUT_NCHW_F32, label="final_conv")
 
     # ---- ResnetBlock (ip.py:693-757)
-    def _resnet(self, plan, x: Act, skip: Optional[Act], rb: ResnetBlockP, name: str, with_cond: bool) -> Act:
+    def _resnet(self, plan, x: Act, skip: Optional[Act], rb: ResnetBlockP, name: str, with_cond: bool, skip_scale: Optional[float] = None) -> Act:
         W, R = self.W, self.R
         C1, C2 = x.C, (skip.C if skip is not None else 0)
         Cin, Cout = C1 + C2, rb.dim_out
         assert Cin == rb.dim, f"{name}: {Cin} input channels, block expects {rb.dim}"
-        s = self.unet.skip_connect_scale
+        s = self.unet.skip_connect_scale if skip_scale is None else skip_scale
         H, Wd = x.H, x.W
         in_scale = None
         if skip is not None:
@@ -535,6 +538,23 @@ class UnetEngine:
         w = self.W.conv(name, conv, out_perm=perm)
         out = self.new(self.R, 2 * x.H, 2 * x.W, cq)
         ops.igemm(plan, x, w, out, act_out=ACT_SILU, out_mode=OUT_PIXEL_SHUFFLE, label=name)
+        return out
+
+    def _upsample_nearest_conv(self, plan, x: Act, mod: nn.Sequential, name: str) -> Act:
+        """`Upsample` (ip.py:595-601, pixel_shuffle_upsample=False): nearest x2 as four strided row copies (one per output parity; a
+        "batch" of the copy is one input row), then the 3x3 conv."""
+        R, H, Wd, C = self.R, x.H, x.W, x.C
+        assert x.ld == C and x.bs == H * Wd * C
+        up = self.new(R, 2 * H, 2 * Wd, C)
+        for dy in range(2):
+            for dx in range(2):
+                ops.rows_copy(plan, x.t, up.t, B=R * H, rows=Wd, C=C, src_bs=Wd * C, src_rs=C, dst_bs=4 * Wd * C, dst_rs=2 * C,
+                              src_off=x.off, dst_off=(dy * 2 * Wd + dx) * C, label=f"{name}.nearest{dy}{dx}")
+        w = self.W.conv(name + ".conv", mod[1])
+        out = self.new(R, 2 * H, 2 * Wd, w.Cout)
+        out.ssq = self.f32buf(out.rows)
+        if not ops.igemm(plan, up, w, out, ssq_out=out.ssq, label=name + ".conv").ssq_emitted:
+            out.ssq = None
         return out
 
     # ------------------------------------------------------------------------------------------ conditioning K/V

@@ -208,3 +208,8 @@ class PixelShuffleUpsampleP(Holder):
         with torch.no_grad():
             conv.weight.copy_(base.repeat_interleave(4, dim=0))
             conv.bias.zero_()
+
+
+def upsample_conv_p(dim, dim_out=None):
+    """ip.py:595-601 `Upsample`: Sequential(nn.Upsample(x2, nearest), Conv2d(dim, dim_out, 3, padding = 1)); the conv sits at index 1."""
+    return nn.Sequential(nn.Upsample(scale_factor=2, mode='nearest'), nn.Conv2d(dim, dim_out or dim, 3, padding=1))

@@ -13,7 +13,7 @@ import torch
 from torch import nn
 
 from .modules import (AttentionP, CrossEmbedP, GainNorm, Holder, ParallelP, PerceiverResamplerP, PixelShuffleUpsampleP,
-                      ResnetBlockP, SinuPosEmbP, TransformerBlockP, downsample_p)
+                      ResnetBlockP, SinuPosEmbP, TransformerBlockP, downsample_p, upsample_conv_p)
 
 DEFAULT_TEXT_EMBED_DIM = 768  # d_model of the reference's default T5 ('google/t5-v1_1-base', t5.py:47-58, ip.py:1117)
 
@@ -106,13 +106,13 @@ class Unet(nn.Module):
             v = self._locals[name]
             if any(_cast_tuple(v)):
                 _unsupported(name)
-        for name in ('cross_embed_downsample', 'self_cond', 'combine_upsample_fmaps', 'init_conv_to_final_conv_residual'):
+        for name in ('cross_embed_downsample', 'self_cond', 'combine_upsample_fmaps'):
             if self._locals[name]:
                 _unsupported(name)
         if cond_images_channels > 0:
             _unsupported('cond_images_channels')
-        if not pixel_shuffle_upsample:
-            _unsupported('pixel_shuffle_upsample=False')
+        if init_conv_to_final_conv_residual and not final_resnet_block:
+            _unsupported('init_conv_to_final_conv_residual without final_resnet_block')   # final_conv would need three inputs
         if attn_dim_head != 64:
             raise NotImplementedError("the attention kernel is specialised for dim_head = 64 (every reference preset / README config)")
 
@@ -229,12 +229,15 @@ class Unet(nn.Module):
                                for _ in range(n_blocks)]),
                 (TransformerBlockP(dim=dim_out, depth=l_depth, ff_mult=ff_mult, context_dim=cond_dim, **attn_kwargs)
                  if l_attn else nn.Identity()),
-                PixelShuffleUpsampleP(dim_out, dim_in) if (not is_last or memory_efficient) else nn.Identity(),
+                ((PixelShuffleUpsampleP if pixel_shuffle_upsample else upsample_conv_p)(dim_out, dim_in)
+                 if (not is_last or memory_efficient) else nn.Identity()),
             ]))
 
         self.upsample_combiner = Holder()  # disabled combiner has no parameters (ip.py:1093-1095)
-        self.init_conv_to_final_conv_residual = False
-        final_conv_dim = dim
+        self.init_conv_to_final_conv_residual = init_conv_to_final_conv_residual          # ip.py:1426-1427
+        if init_conv_to_final_conv_residual:
+            assert init_dim == dim, 'init_conv_to_final_conv_residual needs init_dim == dim (the reference concatenates `dim` channels)'
+        final_conv_dim = dim + (dim if init_conv_to_final_conv_residual else 0)
 
         self.final_res_block = ResnetBlockP(final_conv_dim, dim, time_cond_dim=time_cond_dim, use_gca=True) if final_resnet_block else None
         final_conv_dim_in = dim if final_resnet_block else final_conv_dim

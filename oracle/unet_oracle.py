@@ -17,7 +17,7 @@ against fixtures generated from the reference by oracle/make_golden.py
 
 Scope: every constructor flag used by the BASELINE.json configs.  Flags outside that
 scope (linear attention, cross-embed downsample, self-conditioning, conditioning
-images, upsample combiner, init->final residual, non-pixel-shuffle upsample) raise.
+images, upsample combiner) raise.
 """
 from __future__ import annotations
 
@@ -59,13 +59,11 @@ def resolve_config(kwargs: dict) -> dict:
         v = cfg[flag]
         if any(v) if isinstance(v, (list, tuple)) else v:
             raise NotImplementedError(f"oracle: {flag} is outside the hot-path scope")
-    for flag in ("cross_embed_downsample", "self_cond", "combine_upsample_fmaps", "init_conv_to_final_conv_residual"):
+    for flag in ("cross_embed_downsample", "self_cond", "combine_upsample_fmaps"):
         if cfg[flag]:
             raise NotImplementedError(f"oracle: {flag} is outside the hot-path scope")
     if cfg["cond_images_channels"]:
         raise NotImplementedError("oracle: cond_images_channels is outside the hot-path scope")
-    if not cfg["pixel_shuffle_upsample"]:
-        raise NotImplementedError("oracle: nearest+conv upsample is outside the hot-path scope")
     dim = cfg["dim"]
     n = len(cfg["dim_mults"])
     cfg["init_dim"] = cfg["init_dim"] or dim
@@ -341,6 +339,7 @@ def unet_forward(
     else:
         x = F.conv2d(x, p("init_conv.weight"), p("init_conv.bias"), padding=cfg["init_conv_kernel_size"] // 2)
     tap("init_conv", x)
+    init_conv_residual = x.clone() if cfg["init_conv_to_final_conv_residual"] else None   # ip.py:1568-1569
 
     # time conditioning (ip.py:1573-1589)
     t, time_tokens = time_conditioning(p, "", time, cfg["cond_dim"])
@@ -426,9 +425,14 @@ def unet_forward(
         if cfg["layer_attns_t"][lvl]:
             x = transformer_block(lp.sub("2"), x, c, heads, cfg["layer_attns_depth_t"][lvl])
         if i < n_levels - 1 or cfg["memory_efficient"]:
-            x = pixel_shuffle_up(lp.sub("3"), x)
+            if cfg["pixel_shuffle_upsample"]:
+                x = pixel_shuffle_up(lp.sub("3"), x)
+            else:   # ip.py:595-601 — nearest x2, then a 3x3 conv
+                x = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), lp("3.1.weight"), lp("3.1.bias"), padding=1)
         tap(f"up{i}", x)
 
+    if init_conv_residual is not None:                                                    # ip.py:1716-1717
+        x = torch.cat((x, init_conv_residual), dim=1)
     if cfg["final_resnet_block"]:
         x = resnet_block(p.sub("final_res_block"), x, t, None, heads)
     tap("final_res", x)

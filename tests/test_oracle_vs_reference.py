@@ -110,6 +110,10 @@ def test_unet_oracle_config_sweep(name):
     torch.manual_seed(1)
     u = ip.Unet(**kw).eval()
     _dezero(u)
+    from imagen_pytorch_amd import Unet
+    ours = Unet(**kw).state_dict()
+    ref_sd = u.state_dict()
+    assert list(ours.keys()) == list(ref_sd.keys()) and all(ours[k].shape == ref_sd[k].shape for k in ref_sd), "state_dict layout"
     x, t, te, extra = _sweep_inputs(kw)
     with torch.no_grad():
         for cdp in (0.0, 1.0):

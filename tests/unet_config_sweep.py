@@ -22,5 +22,9 @@ SWEEP = {
                                num_resnet_blocks=(1, 2, 2), layer_attns=(False, True, True), layer_cross_attns=(False, True, True)),
     "dim24_lowres": dict(dim=24, cond_dim=40, text_embed_dim=32, dim_mults=(1, 2), attn_heads=2, max_text_len=16, attn_pool_num_latents=8,
                          num_resnet_blocks=2, layer_attns=(False, True), layer_cross_attns=(True, True), lowres_cond=True),
+    "nearest_upsample_init_residual": dict(_T, dim_mults=(1, 2, 4), num_resnet_blocks=1, layer_attns=(False, False, True),
+                                           layer_cross_attns=(False, True, True), pixel_shuffle_upsample=False, init_conv_to_final_conv_residual=True),
+    "init_residual_memory_efficient": dict(_T, num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True), memory_efficient=True,
+                                           init_conv_to_final_conv_residual=True),
     "channels_out_6": dict(_T, num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True), channels_out=6),
 }
