@@ -145,6 +145,9 @@ class Imagen(nn.Module):
         if resize_mode != 'nearest':
             _out_of_scope(f"resize_mode='{resize_mode}'")
         self.temporal_downsample_factor = _cast_tuple(temporal_downsample_factor, num_unets)
+        assert self.temporal_downsample_factor[-1] == 1, 'downsample factor of last stage must be 1'                       # ip.py:1934
+        assert tuple(sorted(self.temporal_downsample_factor, reverse=True)) == self.temporal_downsample_factor, \
+            'temporal downsample factor must be in order of descending'                                                   # ip.py:1935
 
         lowres_conditions = tuple(u.lowres_cond for u in self.unets)
         assert lowres_conditions == (False, *((True,) * (num_unets - 1))), \
@@ -440,8 +443,8 @@ class Imagen(nn.Module):
         if self.is_video:
             if inpaint_images is not None or skip_steps is not None or any(i is not None for i in _cast_tuple(init_images)):
                 _out_of_scope("inpainting / init_images / skip_steps for video")
-            if any(f != 1 for f in self.temporal_downsample_factor):
-                _out_of_scope("temporal_downsample_factor != 1 (every stage samples all video_frames)")
+            for f in self.temporal_downsample_factor:                       # calc_all_frame_dims, ip.py:170-183
+                assert int(video_frames) % f == 0, f'video_frames {video_frames} must be divisible by the temporal downsample factor {f}'
         frames = int(video_frames) if self.is_video else 0
         to_internal = (lambda t: t.permute(0, 2, 1, 3, 4).contiguous()) if self.is_video else (lambda t: t)   # (b,c,f,h,w) <-> (b,f,c,h,w)
         if return_pil_images:
@@ -503,7 +506,7 @@ class Imagen(nn.Module):
                 with_text = text_embeds is not None and unet.cond_on_text
                 st = self._stage(idx, batch_size, device, cond_scale=cs, with_text=with_text, inject_noise=noise_fn is not None,
                                  sample_offset=sample_offset, resample_times=inpaint_resample_times if known is not None else 0,
-                                 frames=frames if isinstance(unet, Unet3D) else 0)
+                                 frames=frames // self.temporal_downsample_factor[idx] if isinstance(unet, Unet3D) else 0)
                 st['sample_offset'] = sample_offset
                 eng = st['eng']
                 S = self.image_sizes[idx]
@@ -527,7 +530,13 @@ class Imagen(nn.Module):
                     prep = Plan("lowres-prep")
                     if noise_fn is None:
                         ops.randn(prep, aug, seed=seed, stream_id=idx, tag=TAG_LOWRES, sample_offset=sample_offset)
-                    src = (img if self.auto_normalize_img else (img + 1) * 0.5).contiguous()   # kernel normalises [0,1] -> [-1,1]
+                    src = img if self.auto_normalize_img else (img + 1) * 0.5                  # kernel normalises [0,1] -> [-1,1]
+                    if st.get('video', False) and src.shape[1] != aug.shape[1]:
+                        # a stage sampled at a lower frame rate feeds this one: nearest over the frame axis (resize_video_to,
+                        # iv.py:134-156; F.interpolate 'nearest' takes source index floor(dst * F_in / F_out)); once per stage
+                        f_in, f_out = src.shape[1], aug.shape[1]
+                        src = src[:, (torch.arange(f_out, device=src.device) * f_in) // f_out]
+                    src = src.contiguous()
                     # frames are independent images for the nearest resize (resize_video_to with unchanged frame count, iv.py:134-156)
                     as_images = lambda t: t.reshape(-1, *t.shape[-3:])
                     ops.lowres_prep(prep, as_images(src), as_images(aug), as_images(eng.lowres_in), alpha=a, sigma=s)

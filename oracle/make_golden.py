@@ -224,8 +224,22 @@ def make_video_sample_fixture(ip, iv, path, seed=23, T=2, frames=4):
     assert next(it, None) is None
     unets = [dict(kwargs={**kw, "lowres_cond": i > 0}, state_dict={k: v.clone() for k, v in u.state_dict().items()})
              for i, (u, kw) in enumerate(zip(imagen.unets, (kw1, kw2)))]
+    # same weights, first stage sampled at half the frame rate (temporal_downsample_factor = (2, 1), ip.py:1928-1935, 2383, 2441-2447)
+    imagen2 = ip.Imagen(tuple(imagen.unets), image_sizes=(8, 16), timesteps=T, text_embed_dim=32, cond_drop_prob=0.1,
+                        temporal_downsample_factor=(2, 1)).eval()
+    outs2, draws2 = _record_draws(lambda: imagen2.sample(text_embeds=text_embeds, video_frames=frames, cond_scale=3., use_tqdm=False,
+                                                        return_all_unet_outputs=True))
+    noise2, it2 = {}, iter(draws2)
+    for stage in range(2):
+        if stage > 0:
+            noise2[("lowres", stage)] = next(it2)
+        noise2[("init", stage)] = next(it2)
+        for i in range(T):
+            noise2[("step", stage, i)] = next(it2)
+    assert next(it2, None) is None and outs2[0].shape[2] == frames // 2
+    tds = dict(temporal_downsample_factor=(2, 1), noise=noise2, outputs=[o.clone() for o in outs2])
     torch.save(dict(unets=unets, image_sizes=(8, 16), timesteps=T, frames=frames, cond_scale=3., text_embeds=text_embeds, noise=noise,
-                    outputs=[o.clone() for o in outs], generator="oracle/make_golden.py --video",
+                    outputs=[o.clone() for o in outs], tds=tds, generator="oracle/make_golden.py --video",
                     reference="lucidrains/imagen-pytorch v2.0.0 Imagen.sample over Unet3D stages (ip.py:2291-2498, imagen_video.py)"), path)
     print(f"wrote {path}: outputs {[tuple(o.shape) for o in outs]}, std {outs[-1].std():.4f}, {len(draws)} draws")
 

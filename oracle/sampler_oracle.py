@@ -175,7 +175,8 @@ def imagen_sample(
     inpaint_images: Optional[Tensor] = None,   # [0, 1] images, same for every stage
     inpaint_masks: Optional[Tensor] = None,    # (B, H, W) bool
     inpaint_resample_times: int = 5,
-    video_frames: Optional[int] = None,        # Imagen-Video: the unets are Unet3D state_dicts, every stage samples this many frames
+    video_frames: Optional[int] = None,        # Imagen-Video: the unets are Unet3D state_dicts, samples are (b, c, f, h, w)
+    temporal_downsample_factor=1,              # per stage: stage i samples video_frames // factor[i] frames (ip.py:170-183, 1928-1935)
 ):
     """ip.py:2291-2498 for text_embeds-conditioned image sampling (no video, no cond_images, no self-conditioning)."""
     n = len(unets)
@@ -188,6 +189,7 @@ def imagen_sample(
         text_masks = torch.any(text_embeds != 0.0, dim=-1)  # ip.py:2337
     b = text_embeds.shape[0]
     video = video_frames is not None          # Imagen-Video: every unet is a Unet3D, samples are (b, c, f, h, w)  (ip.py:1918, 2381-2383)
+    tds = temporal_downsample_factor if isinstance(temporal_downsample_factor, (list, tuple)) else (temporal_downsample_factor,) * n
     as_tuple = lambda v: tuple(v) if isinstance(v, (list, tuple)) else (v,) * n
     init_images = [None if im is None else im * 2 - 1 for im in as_tuple(init_images)]   # normalize_img, ip.py:2391
     skip_steps = as_tuple(skip_steps)
@@ -197,8 +199,9 @@ def imagen_sample(
         lowres_img = lowres_times = None
         if kw.get("lowres_cond", False):
             lowres_times = torch.full((b,), lowres_sample_noise_level, dtype=torch.float32)
-            if video:   # resize_video_to with an unchanged frame count (iv.py:134-156): nearest over (f, h, w)
-                up = img if img.shape[-1] == size else F.interpolate(img, (img.shape[2], size, size), mode="nearest")
+            if video:   # resize_video_to (iv.py:134-156): nearest over (f, h, w) to this stage's frame count and size
+                target = (video_frames // tds[stage], size, size)
+                up = img if tuple(img.shape[-3:]) == target else F.interpolate(img, target, mode="nearest")
             else:
                 up = img if img.shape[-1] == size else F.interpolate(img, size, mode="nearest")  # ip.py:152-168
             up = up * 2 - 1
@@ -212,7 +215,7 @@ def imagen_sample(
             return fwd(_sd, _kw, x, log_snr, cond_scale=_cs, text_embeds=text_embeds, text_mask=text_masks, lowres_cond_img=_li,
                        lowres_noise_times=_lt)
 
-        shape = (b, channels, video_frames, size, size) if video else (b, channels, size, size)
+        shape = (b, channels, video_frames // tds[stage], size, size) if video else (b, channels, size, size)
         img = p_sample_loop(denoise, shape, schedule=sched, num_timesteps=T, noise_fn=noise_fn,
                             stage=stage, dynamic_thresholding=dynamic_thresholding, percentile=percentile,
                             max_steps=max_steps, init_images=init_images[stage], skip_steps=skip_steps[stage], inpaint_images=known,

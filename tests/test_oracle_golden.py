@@ -158,3 +158,12 @@ def test_video_sampler_oracle_matches_reference_fixture():
     for got, ref in zip(outs, g["outputs"]):
         assert got.shape == ref.shape and got.ndim == 5
         assert torch.allclose(got, ref, atol=2e-4), (got - ref).abs().max()
+    # first stage at half the frame rate (temporal_downsample_factor = (2, 1)): nearest resize over the frame axis in between
+    t = g["tds"]
+    with torch.no_grad():
+        outs = so.imagen_sample(unets, g["image_sizes"], g["text_embeds"], timesteps=g["timesteps"], cond_scale=g["cond_scale"],
+                                noise_fn=lambda tag, shape: t["noise"][tag], return_all=True, video_frames=g["frames"],
+                                temporal_downsample_factor=t["temporal_downsample_factor"])
+    assert outs[0].shape[2] == g["frames"] // 2 and outs[1].shape[2] == g["frames"]
+    for got, ref in zip(outs, t["outputs"]):
+        assert torch.allclose(got, ref, atol=2e-4), (got - ref).abs().max()

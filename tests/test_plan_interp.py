@@ -286,7 +286,8 @@ def test_sampler_stage_plan_on_cpu(run, reference_weights, monkeypatch):
     assert e < 2e-2, e                      # the bar of tests/test_model_gpu.py::test_sample_vs_reference_fixture
 
 
-def test_video_sampler_stage_plans_on_cpu(reference_weights, monkeypatch):
+@pytest.mark.parametrize("tds", [(1, 1), (2, 1)])
+def test_video_sampler_stage_plans_on_cpu(tds, reference_weights, monkeypatch):
     """Imagen-Video sampling, host logic: both Unet3D stages of the tiny video cascade (frame-major sampler state, per-clip dynamic
     threshold, low-res clip conditioning) wired by Imagen._stage and replayed on the CPU with the reference's recorded draws."""
     import functools
@@ -300,15 +301,18 @@ def test_video_sampler_stage_plans_on_cpu(reference_weights, monkeypatch):
     monkeypatch.setattr(engine3d, "UnetEngine3D", functools.partial(engine3d.UnetEngine3D, dry=True))
     g = torch.load(os.path.join(GOLDEN, "sample_tiny_video.pt"), weights_only=False)
     unets = [Unet3D(**spec["kwargs"]).eval() for spec in g["unets"]]
-    imagen = Imagen(unets, image_sizes=g["image_sizes"], timesteps=g["timesteps"], text_embed_dim=32, cond_drop_prob=0.1)
+    imagen = Imagen(unets, image_sizes=g["image_sizes"], timesteps=g["timesteps"], text_embed_dim=32, cond_drop_prob=0.1,
+                    temporal_downsample_factor=tds)
     assert imagen.is_video
+    run = g if tds == (1, 1) else g["tds"]
     for u, spec in zip(imagen.unets, g["unets"]):
         u.load_state_dict(spec["state_dict"])
     te = g["text_embeds"]
-    B, Fr, T = te.shape[0], g["frames"], g["timesteps"]
+    B, T = te.shape[0], g["timesteps"]
     fm = lambda t: t.permute(0, 2, 1, 3, 4).contiguous()      # (b, c, f, h, w) <-> (b, f, c, h, w)
     prev = None
     for idx in range(2):
+        Fr = g["frames"] // tds[idx]
         st = imagen._stage(idx, B, torch.device("cpu"), cond_scale=g["cond_scale"], with_text=True, inject_noise=True, sample_offset=0, frames=Fr)
         eng, S = st['eng'], g["image_sizes"][idx]
         assert st['video'] and tuple(eng.x_in.shape) == (B, Fr, 3, S, S)
@@ -318,20 +322,22 @@ def test_video_sampler_stage_plans_on_cpu(reference_weights, monkeypatch):
             it.mem.register(buf)
         if idx > 0:   # what Imagen._sample does with LOWRES_PREP (ip.py:2443-2449): nearest resize per frame, normalise, augment at level 0.2
             a, s, lsnr = imagen.lowres_noise_schedule.q_sample_coefficients(imagen.lowres_sample_noise_level)
+            if prev.shape[1] != Fr:                         # the frame-axis part of resize_video_to, as Imagen._sample does it
+                prev = prev[:, (torch.arange(Fr) * prev.shape[1]) // Fr]
             up = F.interpolate(prev.reshape(-1, *prev.shape[-3:]), S, mode="nearest").reshape(B, Fr, 3, S, S)
-            eng.lowres_in.copy_(a * (up * 2 - 1) + s * fm(g["noise"][("lowres", idx)]))
+            eng.lowres_in.copy_(a * (up * 2 - 1) + s * fm(run["noise"][("lowres", idx)]))
             lowres_logsnr = torch.full((B,), lsnr)
         keep = torch.ones(2 * B, dtype=torch.bool)
         keep[B:] = False
         eng.set_conditioning(text_embeds=te, text_mask=torch.any(te != 0., dim=-1), keep=keep, lowres_noise_times=lowres_logsnr)
         it.run(eng._static_plans[te.shape[1]][0])
-        eng.x_in.copy_(fm(g["noise"][("init", idx)]))
+        eng.x_in.copy_(fm(run["noise"][("init", idx)]))
         st['step_ptr'].zero_()
         for i in range(T):
-            st['noise'].copy_(fm(g["noise"][("step", idx, i)]))
+            st['noise'].copy_(fm(run["noise"][("step", idx, i)]))
             it.run(st['plan'])
         prev = st['final'].clone()
-        e = nerr(fm(prev), g["outputs"][idx])
+        e = nerr(fm(prev), run["outputs"][idx])
         assert e < 2e-2, (idx, e)
 
 
