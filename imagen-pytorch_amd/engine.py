@@ -26,8 +26,8 @@ import torch
 from torch import nn
 
 from . import ops
-from .modules import AttentionP, CrossAttentionP, CrossEmbedP, ParallelP, PixelShuffleUpsampleP, ResnetBlockP, TransformerBlockP
-from .ops import ACT_GELU, ACT_NONE, ACT_SILU, LOG2E, OUT_NCHW_F32, OUT_PIXEL_SHUFFLE, Act, Plan
+from .modules import CrossAttentionP, CrossEmbedP, ParallelP, PixelShuffleUpsampleP, ResnetBlockP, TransformerBlockP
+from .ops import ACT_GELU, ACT_SILU, LOG2E, OUT_NCHW_F32, OUT_PIXEL_SHUFFLE, Act, Plan
 
 SIM_SCALE = 8.0  # cosine-sim attention scale (ip.py:510, 768, 386)
 

@@ -8,8 +8,6 @@ container so the key layout can be checked against the source.
 """
 from __future__ import annotations
 
-import math
-
 import torch
 from torch import nn
 

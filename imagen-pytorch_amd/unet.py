@@ -7,12 +7,10 @@ from __future__ import annotations
 
 from functools import partial
 from pathlib import Path
-from typing import Optional
-
 import torch
 from torch import nn
 
-from .modules import (AttentionP, CrossEmbedP, GainNorm, Holder, ParallelP, PerceiverResamplerP, PixelShuffleUpsampleP,
+from .modules import (CrossEmbedP, Holder, ParallelP, PerceiverResamplerP, PixelShuffleUpsampleP,
                       ResnetBlockP, SinuPosEmbP, TransformerBlockP, downsample_p, upsample_conv_p)
 
 DEFAULT_TEXT_EMBED_DIM = 768  # d_model of the reference's default T5 ('google/t5-v1_1-base', t5.py:47-58, ip.py:1117)

@@ -22,7 +22,7 @@ images, upsample combiner) raise.
 from __future__ import annotations
 
 import math
-from typing import Dict, Optional, Sequence
+from typing import Dict, Optional
 
 import torch
 import torch.nn.functional as F

@@ -295,7 +295,6 @@ def test_video_sampler_stage_plans_on_cpu(tds, reference_weights, monkeypatch):
     import torch.nn.functional as F
 
     from imagen_pytorch_amd import Imagen, Unet3D, engine3d
-    from imagen_pytorch_amd.schedules import GaussianDiffusionContinuousTimes
     from plan_interp import Interpreter
 
     monkeypatch.setattr(engine3d, "UnetEngine3D", functools.partial(engine3d.UnetEngine3D, dry=True))
