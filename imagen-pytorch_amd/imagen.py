@@ -33,6 +33,7 @@ T5_DIMS = {  # d_model of the encoders the reference accepts by name (t5.py:47-5
 }
 DEFAULT_T5_NAME = 'google/t5-v1_1-base'
 
+_SAMPLING_DEVICE_TYPES = ('cuda',)   # where plans can be launched; tests/test_sample_cpu_replay.py widens it after replacing the launcher
 TAG_INIT, TAG_LOWRES = 0x7FFF0001, 0x7FFF0002  # RANDN counter tags (step noise uses the step index)
 
 
@@ -432,7 +433,7 @@ class Imagen(nn.Module):
                 lowres_sample_noise_level, start_at_unet_number, start_image_or_video, stop_at_unet_number, return_all_unet_outputs,
                 return_pil_images, device, use_tqdm, noise_fn, seed, sample_offset, use_graph, max_steps):
         device = torch.device(device) if device is not None else self.device
-        if device.type != 'cuda':
+        if device.type not in _SAMPLING_DEVICE_TYPES:
             raise RuntimeError("imagen_pytorch_amd.Imagen.sample runs on MI355X only (move the module to 'cuda'); there is no CPU path")
         self.reset_unets_all_one_device(device)
         for name, val in (('cond_images', cond_images), ('cond_video_frames', cond_video_frames),

@@ -404,6 +404,13 @@ class Interpreter:
         if p.advance:
             m.view(p.step_ptr, i32)[0] += 1
 
+    def lowres_prep(self, p):
+        m = self.mem
+        img = m.view(p.img, f32)[: p.B * p.C * p.Hin * p.Win].reshape(p.B, p.C, p.Hin, p.Win)
+        up = img if (p.Hin, p.Win) == (p.Hout, p.Wout) else F.interpolate(img, (p.Hout, p.Wout), mode="nearest")
+        n = p.B * p.C * p.Hout * p.Wout
+        m.view(p.out, f32)[:n].copy_((p.alpha * (up * 2.0 - 1.0) + p.sigma * m.view(p.noise, f32)[:n].reshape(up.shape)).reshape(-1))
+
     DISPATCH = {}
 
 
@@ -416,6 +423,6 @@ Interpreter.DISPATCH = {
     K["IMAGEN_OP_PACK_IMAGE"]: Interpreter.pack_image, K["IMAGEN_OP_ROWS_COPY"]: Interpreter.rows_copy, K["IMAGEN_OP_MEMSET32"]: Interpreter.memset32,
     K["IMAGEN_OP_SELECT_ROWS"]: Interpreter.select_rows, K["IMAGEN_OP_MEAN_ROWS"]: Interpreter.mean_rows,
     K["IMAGEN_OP_CFG_X0"]: Interpreter.cfg_x0, K["IMAGEN_OP_QUANTILE"]: Interpreter.quantile, K["IMAGEN_OP_DDPM_UPDATE"]: Interpreter.ddpm_update,
-    K["IMAGEN_OP_LINCOMB"]: Interpreter.lincomb,
+    K["IMAGEN_OP_LINCOMB"]: Interpreter.lincomb, K["IMAGEN_OP_LOWRES_PREP"]: Interpreter.lowres_prep,
     K["IMAGEN_OP_TEMPORAL_PEG"]: Interpreter.temporal_peg, K["IMAGEN_OP_TEMPORAL_ATTENTION"]: Interpreter.temporal_attention,
 }

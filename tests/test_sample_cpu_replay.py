@@ -1,0 +1,160 @@
+"""CPU: the REAL sampling driver — Imagen.sample / ElucidatedImagen.sample, p_sample_loop, stage caching, graph objects, low-res
+conditioning, layout conversion — executed end to end with the kernel launcher replaced by the plan interpreter
+(tests/plan_interp.py), against the recorded runs of the live reference.
+
+Only test-side patches: `ops.Plan.run` and `ops.Graph` go to the interpreter, the few `torch.cuda` calls of the driver become
+no-ops, and imagen._SAMPLING_DEVICE_TYPES admits 'cpu'.  Nothing of this exists in the product, which has no CPU path; what it buys
+is that every line of the host-side sampling code is exercised without a GPU (the HIP kernels are covered by the -m gpu tests)."""
+import contextlib
+import os
+
+import pytest
+import torch
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
+
+
+def nerr(a, b):
+    return float((a.float() - b.float()).norm() / b.float().norm())
+
+
+class _Stream:
+    device = torch.device("cpu")
+    cuda_stream = 0
+
+    def __init__(self, *a, **k):
+        pass
+
+    def synchronize(self):
+        pass
+
+
+@pytest.fixture()
+def cpu_backend(monkeypatch):
+    from imagen_pytorch_amd import imagen as imagen_mod
+    from imagen_pytorch_amd import ops
+    from plan_interp import Interpreter
+
+    it = Interpreter()
+    ops.KEEP_REFERENCE_WEIGHTS = True
+    monkeypatch.setattr(ops.Plan, "run", lambda self, stream=None: it.run(self))
+
+    class Graph:
+        def __init__(self, plan, stream):
+            self.plan = plan
+
+        def launch(self):
+            self.plan.run()
+
+    monkeypatch.setattr(ops, "Graph", Graph)
+    monkeypatch.setattr(imagen_mod, "_SAMPLING_DEVICE_TYPES", ("cuda", "cpu"))
+    monkeypatch.setattr(torch.cuda, "Stream", _Stream)
+    monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: _Stream())
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
+    monkeypatch.setattr(torch.cuda, "device", lambda *a, **k: contextlib.nullcontext())
+    monkeypatch.setattr(torch.cuda, "stream", lambda *a, **k: contextlib.nullcontext())
+    try:
+        yield it
+    finally:
+        ops.KEEP_REFERENCE_WEIGHTS = False
+        ops.REFERENCE_WEIGHTS.clear()
+
+
+def _cascade(g, klass=None, **kw):
+    from imagen_pytorch_amd import Imagen, Unet, Unet3D
+
+    video = "frames" in g
+    make = Unet3D if video else Unet
+    unets = [make(**spec["kwargs"]).eval() for spec in g["unets"]]
+    imagen = (klass or Imagen)(unets, image_sizes=g["image_sizes"], text_embed_dim=32, cond_drop_prob=0.1, **kw)
+    for u, spec in zip(imagen.unets, g["unets"]):
+        u.load_state_dict(spec["state_dict"])
+    return imagen.eval()
+
+
+@pytest.mark.parametrize("use_graph", [True, False])
+def test_cascade_sample_driver(cpu_backend, use_graph):
+    g = torch.load(os.path.join(GOLDEN, "sample_tiny_cascade.pt"), weights_only=False)
+    imagen = _cascade(g, timesteps=g["timesteps"])
+    outs = imagen.sample(text_embeds=g["text_embeds"], cond_scale=g["cond_scale"], use_tqdm=False, return_all_unet_outputs=True,
+                         noise_fn=lambda tag, shape: g["noise"][tag], use_graph=use_graph, device="cpu")
+    errs = [nerr(o, r) for o, r in zip(outs, g["outputs"])]
+    assert max(errs) < 2e-2, errs
+    # a second call reuses the cached stages / graphs and gives the same images
+    again = imagen.sample(text_embeds=g["text_embeds"], cond_scale=g["cond_scale"], use_tqdm=False, noise_fn=lambda tag, shape: g["noise"][tag],
+                          use_graph=use_graph, device="cpu")
+    assert torch.equal(again, outs[-1])
+    # stage 2 alone from the reference's stage-1 image
+    alone = imagen.sample(text_embeds=g["text_embeds"], cond_scale=g["cond_scale"], use_tqdm=False, noise_fn=lambda tag, shape: g["noise"][tag],
+                          start_at_unet_number=2, start_image_or_video=g["outputs"][0], device="cpu")
+    assert nerr(alone, g["outputs"][1]) < 2e-2
+
+
+@pytest.mark.parametrize("run", ["init_skip", "inpaint"])
+def test_sample_options_driver(cpu_backend, run):
+    g = torch.load(os.path.join(GOLDEN, "sample_tiny_options.pt"), weights_only=False)
+    r = g["runs"][run]
+    imagen = _cascade(g, timesteps=g["timesteps"])
+    kw = {k: r[k] for k in ("init_images", "skip_steps", "inpaint_images", "inpaint_masks", "inpaint_resample_times") if k in r}
+    outs = imagen.sample(text_embeds=g["text_embeds"], cond_scale=g["cond_scale"], use_tqdm=False, return_all_unet_outputs=True,
+                         noise_fn=lambda tag, shape: r["noise"][tag], device="cpu", **kw)
+    errs = [nerr(o, ref) for o, ref in zip(outs, r["outputs"])]
+    assert max(errs) < 2e-2, errs
+    if run == "inpaint":
+        m = r["inpaint_masks"][:, None].expand(-1, 3, -1, -1)
+        assert torch.allclose(outs[-1][m], r["inpaint_images"][m], atol=1e-6)
+
+
+@pytest.mark.parametrize("tds", [(1, 1), (2, 1)])
+def test_video_sample_driver(cpu_backend, tds):
+    g = torch.load(os.path.join(GOLDEN, "sample_tiny_video.pt"), weights_only=False)
+    run = g if tds == (1, 1) else g["tds"]
+    imagen = _cascade(g, timesteps=g["timesteps"], temporal_downsample_factor=tds)
+    outs = imagen.sample(text_embeds=g["text_embeds"], video_frames=g["frames"], cond_scale=g["cond_scale"], use_tqdm=False,
+                         return_all_unet_outputs=True, noise_fn=lambda tag, shape: run["noise"][tag], device="cpu")
+    assert [tuple(o.shape) for o in outs] == [tuple(o.shape) for o in run["outputs"]]
+    errs = [nerr(o, ref) for o, ref in zip(outs, run["outputs"])]
+    assert max(errs) < 2e-2, errs
+
+
+def test_elucidated_sample_driver(cpu_backend):
+    from imagen_pytorch_amd import ElucidatedImagen
+
+    g = torch.load(os.path.join(GOLDEN, "sample_tiny_elucidated.pt"), weights_only=False)
+    model = _cascade(g, klass=ElucidatedImagen, **g["hparams"])
+    nf = lambda tag, shape: g["noise"][tag]
+    outs = model.sample(text_embeds=g["text_embeds"], cond_scale=g["cond_scale"], use_tqdm=False, return_all_unet_outputs=True, noise_fn=nf,
+                        device="cpu")
+    e0 = nerr(outs[0], g["outputs"][0])
+    alone = model.sample(text_embeds=g["text_embeds"], cond_scale=g["cond_scale"], use_tqdm=False, noise_fn=nf, start_at_unet_number=2,
+                         start_image_or_video=g["outputs"][0], device="cpu")
+    e1 = nerr(alone, g["outputs"][1])
+    assert e0 < 3e-2 and e1 < 3e-2, (e0, e1)    # cf. tests/test_plan_interp.py::test_elucidated_stage_plan_on_cpu
+
+
+@pytest.mark.parametrize("which", ["model", "ema"])
+def test_checkpoint_sample_driver(cpu_backend, which, tmp_path):
+    from imagen_pytorch_amd import load_imagen_from_checkpoint
+
+    g = torch.load(os.path.join(GOLDEN, "checkpoint_tiny.pt"), weights_only=False)
+    path = tmp_path / "ckpt.pt"
+    torch.save(g["checkpoint"], str(path))
+    imagen = load_imagen_from_checkpoint(path, load_ema_if_available=which == "ema").eval()
+    exp = g["expected"][which]
+    out = imagen.sample(text_embeds=g["text_embeds"], cond_scale=g["cond_scale"], use_tqdm=False, noise_fn=lambda tag, shape: exp["noise"][tag],
+                        device="cpu")
+    assert nerr(out, exp["output"]) < 2e-2
+
+
+def test_conditioning_handle_driver(cpu_backend):
+    g = torch.load(os.path.join(GOLDEN, "sample_tiny_cascade.pt"), weights_only=False)
+    imagen = _cascade(g, timesteps=g["timesteps"])
+    nf = lambda tag, shape: g["noise"][tag]
+    ref = imagen.sample(text_embeds=g["text_embeds"], cond_scale=3.0, use_tqdm=False, noise_fn=nf, device="cpu")
+    cond = imagen.prepare_conditioning(text_embeds=g["text_embeds"], device="cpu")
+    a = imagen.sample(conditioning=cond, cond_scale=3.0, use_tqdm=False, noise_fn=nf, device="cpu")
+    engines = [st["eng"] for st in imagen._stages.values()]
+    runs = [e.static_runs for e in engines]
+    b = imagen.sample(conditioning=cond, cond_scale=3.0, use_tqdm=False, noise_fn=nf, device="cpu")
+    assert torch.equal(a, ref) and torch.equal(b, ref)
+    assert [e.static_runs for e in engines] == runs, "the second call with the same handle must not re-run the static plans"
