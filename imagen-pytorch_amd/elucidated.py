@@ -21,6 +21,7 @@ from typing import Callable, List, Optional
 import torch
 
 from . import ops
+from .unet3d import Unet3D
 from .imagen import DEFAULT_T5_NAME, TAG_INIT, Imagen, _cast_tuple, _out_of_scope
 from .ops import Plan
 
@@ -122,21 +123,25 @@ class ElucidatedImagen(Imagen):
     # ---- per-stage plans --------------------------------------------------------------------------------------------------
     def _stage(self, idx: int, B: int, device, *, cond_scale: float, with_text: bool, inject_noise: bool, sample_offset: int,
                resample_times: int = 0, frames: int = 0):
-        if frames:
-            _out_of_scope("ElucidatedImagen with Unet3D (video)")
         unet = self.unets[idx]
         S = self.image_sizes[idx]
         hp = self.hparams[idx]
         cfg = cond_scale != 1.
         key = ("edm", idx, B, S, str(device), float(cond_scale), with_text, inject_noise, sample_offset, self.dynamic_thresholding[idx],
-               self.dynamic_thresholding_percentile, tuple(hp))
+               self.dynamic_thresholding_percentile, tuple(hp), frames)
         st = self._stages.get(key)
         if st is not None and not st['eng'].stale():
             return st
         rows = 2 * B if cfg else B
-        from .engine import UnetEngine
-        eng = UnetEngine(unet, rows, B, S, device, with_text=with_text)
-        n = self.channels * S * S
+        video = isinstance(unet, Unet3D)
+        if video:      # as in Imagen._stage: the state is the engine's frame-major clip, every update below is elementwise per sample
+            assert frames > 0, 'video_frames must be passed in on sample time if training on video'
+            from . import engine3d
+            eng = engine3d.UnetEngine3D(unet, rows, B, frames, S, device, with_text=with_text)
+        else:
+            from . import engine
+            eng = engine.UnetEngine(unet, rows, B, S, device, with_text=with_text)
+        n = eng.x_in[0].numel()
         dev = device
         init_sigma, (coef, w_hat, w_euler, w_heun) = self._tables(hp)
         coef, w_hat, w_euler, w_heun = (t.to(dev) for t in (coef, w_hat, w_euler, w_heun))
@@ -146,7 +151,7 @@ class ElucidatedImagen(Imagen):
         step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
         seed_dev = torch.zeros(2, dtype=torch.int32, device=dev)
         eng.bind_step_counter(coef, step_ptr)
-        mk = lambda: torch.empty(B, self.channels, S, S, device=dev)
+        mk = lambda: torch.empty_like(eng.x_in)
         x, xhat, xnext, x0a, x0b, absx0, final = mk(), mk(), mk(), mk(), mk(), mk(), mk()
         qa, qb = torch.empty(B, device=dev), torch.empty(B, device=dev)
         W = ops.ENUMS["IMAGEN_QUANTILE_SCRATCH_WORDS"]
@@ -187,6 +192,7 @@ class ElucidatedImagen(Imagen):
         zero_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
         st = dict(eng=eng, plan=full, last=last, graph=None, graph_last=None, coef=coef, step_ptr=step_ptr, seed_dev=seed_dev, noise=noise,
                   final=final, T=hp.num_sample_steps, S=S, x=x, w_init=w_init, zero_ptr=zero_ptr, tables=(w_hat, w_euler, w_heun),
+                  video=video, frames=frames,
                   bufs=(xhat, xnext, x0a, x0b, absx0, qa, qb, scr_a, scr_b))
         self._stages[key] = st
         return st
@@ -201,9 +207,15 @@ class ElucidatedImagen(Imagen):
         B = eng.src_batch
         n = x[0].numel()
 
+        def draw(tag, like):   # videos are drawn in the reference's (b, c, f, h, w) layout, the state is frame-major
+            if not st.get('video', False):
+                return noise_fn(tag, tuple(like.shape))
+            b, f, c, h, w = like.shape
+            return noise_fn(tag, (b, c, f, h, w)).permute(0, 2, 1, 3, 4)
+
         def init_state():
             if noise_fn is not None:
-                x.copy_(noise_fn(("init", stage), tuple(x.shape)))
+                x.copy_(draw(("init", stage), x))
             else:
                 pl = Plan("edm-init-noise")
                 ops.randn(pl, x, seed=seed, stream_id=stage, tag=TAG_INIT, sample_offset=st.get('sample_offset', 0))
@@ -227,7 +239,7 @@ class ElucidatedImagen(Imagen):
         init_state()
         for i in range(steps):
             if noise_fn is not None:
-                st['noise'].copy_(noise_fn(("step", stage, i), tuple(st['noise'].shape)))
+                st['noise'].copy_(draw(("step", stage, i), st['noise']))
             is_last = i == T - 1
             if use_graph:
                 (st['graph_last'] if is_last else st['graph']).launch()

@@ -21,6 +21,7 @@ import torch
 import torch.nn.functional as F
 
 from .sampler_oracle import SCHEDULES, alpha_sigma
+from .unet3d_oracle import unet3d_forward_with_cond_scale
 from .unet_oracle import unet_forward_with_cond_scale
 
 Tensor = torch.Tensor
@@ -61,7 +62,7 @@ def preconditioned_forward(net: Callable[[Tensor, Tensor], Tensor], noised: Tens
     """el.py:340-369 — sigma is a python float broadcast to the batch (fp32)."""
     b = noised.shape[0]
     sig = torch.full((b,), sigma, dtype=torch.float32)
-    ps = sig.view(-1, 1, 1, 1)
+    ps = sig.view(-1, *([1] * (noised.ndim - 1)))
     c_in = 1 * (ps ** 2 + sigma_data ** 2) ** -0.5
     c_noise = torch.log(sig.clamp(min=1e-20)) * 0.25
     c_skip = (sigma_data ** 2) / (ps ** 2 + sigma_data ** 2)
@@ -98,8 +99,10 @@ def one_unet_sample(net: Callable[[Tensor, Tensor], Tensor], shape, hp: dict, *,
 def elucidated_sample(unets: Sequence[tuple], image_sizes: Sequence[int], text_embeds: Tensor, *, hparams: Optional[dict] = None,
                       cond_scale=1.0, lowres_noise_schedule: str = "linear", lowres_sample_noise_level: float = 0.2,
                       dynamic_thresholding: bool = True, percentile: float = 0.95, channels: int = 3, text_masks: Optional[Tensor] = None,
-                      noise_fn: Optional[Callable] = None, max_steps: Optional[int] = None, return_all: bool = False):
-    """el.py:547-745.  `unets`: [(state_dict, ctor_kwargs), ...]; `hparams`: overrides of DEFAULT_HPARAMS (same for every stage)."""
+                      noise_fn: Optional[Callable] = None, max_steps: Optional[int] = None, return_all: bool = False,
+                      video_frames: Optional[int] = None):
+    """el.py:547-745.  `unets`: [(state_dict, ctor_kwargs), ...]; `hparams`: overrides of DEFAULT_HPARAMS (same for every stage).
+    video_frames: the unets are Unet3D state_dicts and every stage samples (b, c, video_frames, h, w) clips."""
     n = len(unets)
     hp = dict(DEFAULT_HPARAMS, **(hparams or {}))
     cond_scale = cond_scale if isinstance(cond_scale, (list, tuple)) else (cond_scale,) * n
@@ -113,16 +116,22 @@ def elucidated_sample(unets: Sequence[tuple], image_sizes: Sequence[int], text_e
         lowres_img = lowres_times = None
         if kw.get("lowres_cond", False):
             lowres_times = torch.full((b,), lowres_sample_noise_level, dtype=torch.float32)   # el.py:700 — passed on RAW (:728)
-            up = img if img.shape[-1] == size else F.interpolate(img, size, mode="nearest")
+            if video_frames is not None:
+                up = img if img.shape[-1] == size else F.interpolate(img, (img.shape[2], size, size), mode="nearest")
+            else:
+                up = img if img.shape[-1] == size else F.interpolate(img, size, mode="nearest")
             up = up * 2 - 1
-            a, s = alpha_sigma(SCHEDULES[lowres_noise_schedule](lowres_times).reshape(-1, 1, 1, 1))
+            a, s = alpha_sigma(SCHEDULES[lowres_noise_schedule](lowres_times).reshape(-1, *([1] * (up.ndim - 1))))
             lowres_img = a * up + s * noise_fn(("lowres", stage), up.shape)                  # el.py:705
 
-        def net(x, c_noise, _sd=sd, _kw=kw, _cs=cs, _li=lowres_img, _lt=lowres_times):
-            return unet_forward_with_cond_scale(_sd, _kw, x, c_noise, cond_scale=_cs, text_embeds=text_embeds, text_mask=text_masks,
-                                                lowres_cond_img=_li, lowres_noise_times=_lt)
+        fwd = unet3d_forward_with_cond_scale if video_frames is not None else unet_forward_with_cond_scale
 
-        img = one_unet_sample(net, (b, channels, size, size), hp, noise_fn=noise_fn, stage=stage, dynamic_threshold=dynamic_thresholding,
+        def net(x, c_noise, _sd=sd, _kw=kw, _cs=cs, _li=lowres_img, _lt=lowres_times):
+            return fwd(_sd, _kw, x, c_noise, cond_scale=_cs, text_embeds=text_embeds, text_mask=text_masks, lowres_cond_img=_li,
+                       lowres_noise_times=_lt)
+
+        shape = (b, channels, video_frames, size, size) if video_frames is not None else (b, channels, size, size)
+        img = one_unet_sample(net, shape, hp, noise_fn=noise_fn, stage=stage, dynamic_threshold=dynamic_thresholding,
                               percentile=percentile, max_steps=max_steps)
         outputs.append(img)
     return outputs if return_all else outputs[-1]

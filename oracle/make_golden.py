@@ -238,8 +238,23 @@ def make_video_sample_fixture(ip, iv, path, seed=23, T=2, frames=4):
             noise2[("step", stage, i)] = next(it2)
     assert next(it2, None) is None and outs2[0].shape[2] == frames // 2
     tds = dict(temporal_downsample_factor=(2, 1), noise=noise2, outputs=[o.clone() for o in outs2])
+    # same weights under the Karras et al. sampler (ElucidatedImagen over Unet3D stages, 3 steps)
+    el = load_reference("elucidated_imagen")
+    hp = dict(ELUCIDATED_HP, num_sample_steps=3)
+    edm_model = el.ElucidatedImagen(tuple(imagen.unets), image_sizes=(8, 16), text_embed_dim=32, cond_drop_prob=0.1, **hp).eval()
+    outs3, draws3 = _record_draws(lambda: edm_model.sample(text_embeds=text_embeds, video_frames=frames, cond_scale=3., use_tqdm=False,
+                                                          return_all_unet_outputs=True))
+    noise3, it3 = {}, iter(draws3)
+    for stage in range(2):
+        if stage > 0:
+            noise3[("lowres", stage)] = next(it3)
+        noise3[("init", stage)] = next(it3)
+        for i in range(hp["num_sample_steps"]):
+            noise3[("step", stage, i)] = next(it3)
+    assert next(it3, None) is None
+    edm = dict(hparams=hp, noise=noise3, outputs=[o.clone() for o in outs3])
     torch.save(dict(unets=unets, image_sizes=(8, 16), timesteps=T, frames=frames, cond_scale=3., text_embeds=text_embeds, noise=noise,
-                    outputs=[o.clone() for o in outs], tds=tds, generator="oracle/make_golden.py --video",
+                    outputs=[o.clone() for o in outs], tds=tds, edm=edm, generator="oracle/make_golden.py --video",
                     reference="lucidrains/imagen-pytorch v2.0.0 Imagen.sample over Unet3D stages (ip.py:2291-2498, imagen_video.py)"), path)
     print(f"wrote {path}: outputs {[tuple(o.shape) for o in outs]}, std {outs[-1].std():.4f}, {len(draws)} draws")
 

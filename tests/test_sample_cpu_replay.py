@@ -158,3 +158,20 @@ def test_conditioning_handle_driver(cpu_backend):
     b = imagen.sample(conditioning=cond, cond_scale=3.0, use_tqdm=False, noise_fn=nf, device="cpu")
     assert torch.equal(a, ref) and torch.equal(b, ref)
     assert [e.static_runs for e in engines] == runs, "the second call with the same handle must not re-run the static plans"
+
+
+def test_video_elucidated_sample_driver(cpu_backend):
+    from imagen_pytorch_amd import ElucidatedImagen
+
+    g = torch.load(os.path.join(GOLDEN, "sample_tiny_video.pt"), weights_only=False)
+    e = g["edm"]
+    model = _cascade(g, klass=ElucidatedImagen, **e["hparams"])
+    nf = lambda tag, shape: e["noise"][tag]
+    outs = model.sample(text_embeds=g["text_embeds"], video_frames=g["frames"], cond_scale=g["cond_scale"], use_tqdm=False,
+                        return_all_unet_outputs=True, noise_fn=nf, device="cpu")
+    assert tuple(outs[0].shape) == tuple(e["outputs"][0].shape)
+    e0 = nerr(outs[0], e["outputs"][0])
+    alone = model.sample(text_embeds=g["text_embeds"], video_frames=g["frames"], cond_scale=g["cond_scale"], use_tqdm=False, noise_fn=nf,
+                         start_at_unet_number=2, start_image_or_video=e["outputs"][0], device="cpu")
+    e1 = nerr(alone, e["outputs"][1])
+    assert e0 < 3e-2 and e1 < 3e-2, (e0, e1)
