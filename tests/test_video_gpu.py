@@ -121,3 +121,24 @@ def test_video_cascade_sample_vs_reference_fixture():
         assert all(o.shape == r.shape for o, r in zip(outs, g["outputs"])) and max(errs) < 2e-2
         res[use_graph] = outs
     assert all(torch.equal(a, b) for a, b in zip(res[False], res[True]))
+
+
+def test_video_elucidated_sample_vs_reference_fixture():
+    from imagen_pytorch_amd import ElucidatedImagen, Unet3D
+
+    dev = torch.device("cuda:0")
+    g = torch.load(os.path.join(GOLDEN, "sample_tiny_video.pt"), weights_only=False)
+    e = g["edm"]
+    unets = [Unet3D(**spec["kwargs"]).eval() for spec in g["unets"]]
+    model = ElucidatedImagen(unets, image_sizes=g["image_sizes"], text_embed_dim=32, cond_drop_prob=0.1, **e["hparams"]).to(dev).eval()
+    for u, spec in zip(model.unets, g["unets"]):
+        u.load_state_dict(spec["state_dict"])
+    nf = lambda tag, shape: e["noise"][tag].to(dev)
+    outs = model.sample(text_embeds=g["text_embeds"].to(dev), video_frames=g["frames"], cond_scale=g["cond_scale"], use_tqdm=False,
+                        return_all_unet_outputs=True, noise_fn=nf)
+    e0 = nerr(outs[0], e["outputs"][0])
+    alone = model.sample(text_embeds=g["text_embeds"].to(dev), video_frames=g["frames"], cond_scale=g["cond_scale"], use_tqdm=False, noise_fn=nf,
+                         start_at_unet_number=2, start_image_or_video=e["outputs"][0].to(dev))
+    e1 = nerr(alone, e["outputs"][1])
+    print(f"video EDM vs reference: stage1 {e0:.2e}, stage 2 alone {e1:.2e}")
+    assert e0 < 3e-2 and e1 < 3e-2
