@@ -47,6 +47,48 @@ def _both(build):
     return outs
 
 
+def test_igemm_view_patterns_of_the_video_planner():
+    """The IGEMM argument patterns only the video planner uses: frame-shifted 1x1 GEMMs accumulating in place through `res == y`
+    (temporal conv), a two-input GEMM over even / odd frames with batch stride 2 frames (temporal down-sampling), and one GEMM per phase
+    writing every r-th frame (temporal pixel-shuffle)."""
+    from imagen_pytorch_amd import ops
+    from imagen_pytorch_amd.ops import Act
+
+    def build(plan, dev):
+        ops.KEEP_REFERENCE_WEIGHTS = dev.type == "cpu"
+        try:
+            R, f, P, C, Co = 2, 6, 64, 32, 32
+            x = ops.new_act(R * f, 8, 8, C, dev)
+            x.t.copy_(torch.randn(x.t.shape).half())
+            w = torch.randn(Co, C, 3) / (3 * C) ** 0.5
+            bias = torch.randn(Co)
+            y = ops.new_act(R * f, 8, 8, Co, dev, zero=True)
+            for shift in range(3):                                  # engine3d._temporal_conv
+                pw = ops.pack_weight(w[:, :, 2 - shift], bias if shift == 0 else None, dev)
+                n = f - shift
+                xin = Act(x.t, R, n, P, C, C, f * P * C, 0)
+                yout = Act(y.t, R, n, P, Co, Co, f * P * Co, shift * P * Co)
+                ops.igemm(plan, xin, pw, yout, res=yout if shift else None)
+            fr = P * Co                                              # engine3d._temporal_down
+            wd = torch.randn(16, 2 * Co) / (2 * Co) ** 0.5
+            pwd = ops.pack_weight(torch.cat((wd[:, 0::2], wd[:, 1::2]), dim=1), torch.randn(16), dev)
+            even = Act(y.t, R * f // 2, 8, 8, Co, Co, 2 * fr, 0)
+            odd = Act(y.t, R * f // 2, 8, 8, Co, Co, 2 * fr, fr)
+            d = ops.new_act(R * f // 2, 8, 8, 16, dev)
+            ops.igemm(plan, even, pwd, d, x2=odd)
+            wu, bu = torch.randn(2 * 24, 16) / 4.0, torch.randn(2 * 24)   # engine3d._temporal_up
+            up = ops.new_act(R * f, 8, 8, 24, dev, zero=True)
+            for j in range(2):
+                pwu = ops.pack_weight(wu[j::2], bu[j::2], dev)
+                ops.igemm(plan, d, pwu, Act(up.t, R * f // 2, 8, 8, 24, 24, 2 * P * 24, j * P * 24), act_out=ops.ACT_SILU)
+            return torch.cat((y.t.flatten(), d.t.flatten(), up.t.flatten()))
+        finally:
+            ops.KEEP_REFERENCE_WEIGHTS = False
+
+    hip, ref = _both(build)
+    assert nerr(hip, ref) < 2e-3
+
+
 @pytest.mark.parametrize("causal", [True, False])
 def test_temporal_peg_kernel(causal):
     from imagen_pytorch_amd import ops
