@@ -29,6 +29,7 @@ import torch
 from .elucidated import ElucidatedImagen
 from .imagen import DEFAULT_T5_NAME, T5_DIMS, Imagen
 from .unet import NullUnet, Unet
+from .unet3d import Unet3D
 
 # configs.py:42-49 — what a `UnetConfig` fills in when the key is missing.  NOTE attn_dim_head / attn_heads: the config
 # defaults (32 / 16) differ from the Unet constructor's (64 / 8, ip.py:1127-1128).
@@ -45,7 +46,7 @@ def _default_text_embed_dim() -> int:
     return T5_DIMS[DEFAULT_T5_NAME]   # configs.py:44 (`get_encoded_dim(DEFAULT_T5_NAME)`)
 
 
-def _make_unet(params: dict):
+def _make_unet(params: dict, video: bool = False):
     if 'is_null' in params:                                   # NullUnetConfig, configs.py:36-40
         return NullUnet()
     for required in ('dim', 'dim_mults'):
@@ -53,7 +54,7 @@ def _make_unet(params: dict):
             raise ValueError(f'unet config needs `{required}` (configs.py:42-44)')
     kw = {'text_embed_dim': _default_text_embed_dim(), **_UNET_DEFAULTS, **params}
     kw['dim_mults'] = tuple(kw['dim_mults'])
-    return Unet(**kw)
+    return (Unet3D if video else Unet)(**kw)                   # configs.py:87-93: `video` selects Unet3D for every non-null unet
 
 
 def imagen_from_config(imagen_type: str, imagen_params: dict):
@@ -71,14 +72,57 @@ def imagen_from_config(imagen_type: str, imagen_params: dict):
             raise ValueError(f'imagen config needs `{required}`')
     params = {**defaults, **imagen_params}
     unet_params = list(params.pop('unets'))
-    if params.pop('video', False):
-        raise NotImplementedError('video checkpoints (Unet3D) are outside this build (SURVEY.md §8(f) NEXT-2)')
+    video = bool(params.pop('video', False))
     if len(params['image_sizes']) != len(unet_params):         # configs.py:77-81
         raise ValueError(f"image sizes length {len(params['image_sizes'])} must be equivalent to the number of unets {len(unet_params)}")
     params['image_sizes'] = tuple(params['image_sizes'])
-    model = klass([_make_unet(dict(u)) for u in unet_params], **params)
-    model._config = {**params, 'unets': [dict(u) for u in unet_params], 'video': False}
+    model = klass([_make_unet(dict(u), video) for u in unet_params], **params)
+    model._config = {**params, 'unets': [dict(u) for u in unet_params], 'video': video}
     return model
+
+
+class _Config:
+    """Thin stand-ins for the reference's pydantic config classes (configs.py): `Config(**kwargs).create()`."""
+    imagen_type = 'original'
+
+    def __init__(self, **kwargs):
+        self.kwargs = kwargs
+
+    def dict(self):
+        return dict(self.kwargs)
+
+    def create(self):
+        return imagen_from_config(self.imagen_type, self.kwargs)
+
+
+class ImagenConfig(_Config):
+    """configs.py:65-107."""
+
+
+class ElucidatedImagenConfig(_Config):
+    """configs.py:109-160."""
+    imagen_type = 'elucidated'
+
+
+class UnetConfig(_Config):
+    """configs.py:42-52."""
+
+    def create(self):
+        return _make_unet(dict(self.kwargs))
+
+
+class Unet3DConfig(_Config):
+    """configs.py:54-63."""
+
+    def create(self):
+        return _make_unet(dict(self.kwargs), video=True)
+
+
+class NullUnetConfig(_Config):
+    """configs.py:36-40."""
+
+    def create(self):
+        return NullUnet()
 
 
 def restore_parts(state_dict_target: Dict[str, torch.Tensor], state_dict_from: Dict[str, torch.Tensor]):

@@ -86,8 +86,8 @@ def test_imagen_from_config_validation(fixture):
     params = fixture["checkpoint"]["imagen_params"]
     with pytest.raises(ValueError, match="image sizes length"):                    # configs.py:77-81
         imagen_from_config("original", {**params, "image_sizes": [16, 32]})
-    with pytest.raises(NotImplementedError, match="video"):
-        imagen_from_config("original", {**params, "video": True})
+    vid = imagen_from_config("original", {**params, "video": True})               # configs.py:87-93: every unet becomes a Unet3D
+    assert vid.is_video and type(vid.unets[0]).__name__ == "Unet3D" and vid._config["video"] is True
     with pytest.raises(NotImplementedError, match="dim_head"):                     # config default attn_dim_head = 32
         imagen_from_config("original", {**params, "unets": [{k: v for k, v in params["unets"][0].items() if k != "attn_dim_head"}]})
     el = imagen_from_config("elucidated", {k: v for k, v in fixture["elucidated_config"].items()
@@ -127,3 +127,17 @@ def test_trainer_checkpoint_roundtrip_and_partial_load(fixture, ckpt_path, tmp_p
     assert list(re["model"].keys()) == list(fixture["checkpoint"]["model"].keys())
     assert set(re["ema"].keys()) == set(fixture["checkpoint"]["ema"].keys())
     assert all(torch.equal(v, want[k]) for k, v in ema_unet_state_dicts(re["ema"], 1)[0].items())
+
+
+def test_config_classes(fixture):
+    """ImagenConfig / ElucidatedImagenConfig / UnetConfig / Unet3DConfig / NullUnetConfig(...).create() (configs.py:36-160)."""
+    from imagen_pytorch_amd import (ElucidatedImagen, ElucidatedImagenConfig, Imagen, ImagenConfig, NullUnet, NullUnetConfig, Unet, Unet3D,
+                                    Unet3DConfig, UnetConfig)
+
+    params = fixture["checkpoint"]["imagen_params"]
+    im = ImagenConfig(**params).create()
+    assert type(im) is Imagen and im._config["timesteps"] == params["timesteps"]
+    el = ElucidatedImagenConfig(**{k: v for k, v in params.items() if k not in ("timesteps", "noise_schedules", "loss_type")}, num_sample_steps=3).create()
+    assert type(el) is ElucidatedImagen and el.hparams[0].num_sample_steps == 3
+    uk = dict(params["unets"][0])
+    assert type(UnetConfig(**uk).create()) is Unet and type(Unet3DConfig(**uk).create()) is Unet3D and type(NullUnetConfig(is_null=True).create()) is NullUnet
