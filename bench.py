@@ -123,7 +123,7 @@ def roofline_leg(imagen, batch: int, device):
     return {
         "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
         "traffic": traffic,
-        "kernel": f"igemm_kernel cfg {cfg} ({tab[cfg][0]} px x {tab[cfg][1]} cout tile, G={tab[cfg][2]})",
+        "kernel": f"{'conv_lds_kernel' if tab[cfg][3] else 'igemm_kernel'} cfg {cfg} ({tab[cfg][0]} px x {tab[cfg][1]} cout tile, G={tab[cfg][2]})",
         "launches_per_denoiser_step_pair": n, "avg_launch_us": round(sec / n * 1e6, 2), "avg_launch_gflop": round(fl / n / 1e9, 3),
         "per_cfg": summary,
     }

@@ -884,11 +884,19 @@ int launch_cfg(const ImagenIgemmParams& p, hipStream_t s) {
 
 }  // namespace
 
+// second kernel family (conv_lds.hip): tile cfg ids kNumCfgs .. kNumCfgs + imagen_conv_lds_num_configs() - 1
+int imagen_conv_lds_num_configs();
+int imagen_conv_lds_config_info(int idx, int* tile_pixels, int* tile_cout, int* kgroups);
+int imagen_conv_lds_stage_slots(int idx, int KH, int KW);
+long imagen_conv_lds_lds_bytes(int idx, int KH, int KW, int TH, int TW);
+int launch_conv_lds(const ImagenIgemmParams* p, int idx, hipStream_t s);
+
 int launch_igemm(const ImagenIgemmParams* pp, hipStream_t s) {
   const ImagenIgemmParams& p = *pp;
-  IMAGEN_CHECK(p.cfg >= 0 && p.cfg < kNumCfgs, "igemm: bad cfg %d", p.cfg);
+  IMAGEN_CHECK(p.cfg >= 0 && p.cfg < kNumCfgs + imagen_conv_lds_num_configs(), "igemm: bad cfg %d", p.cfg);
   IMAGEN_CHECK(p.x1 && p.w && p.y, "igemm: null x1/w/y");
   IMAGEN_CHECK(!p.addend || p.gate, "igemm: addend requires gate");
+  if (p.cfg >= kNumCfgs) return launch_conv_lds(pp, p.cfg - kNumCfgs, s);
   switch (p.cfg) {
     case 0: return launch_cfg<2, 1, 4, 1, 4>(p, s);
     case 1: return launch_cfg<4, 1, 1, 4, 4>(p, s);
@@ -910,9 +918,15 @@ int launch_igemm(const ImagenIgemmParams* pp, hipStream_t s) {
   return -1;
 }
 
-extern "C" int imagen_igemm_num_configs(void) { return kNumCfgs; }
+extern "C" int imagen_igemm_num_configs(void) { return kNumCfgs + imagen_conv_lds_num_configs(); }
+
+extern "C" int imagen_igemm_config_family(int cfg) {   // 0: wave-specialised persistent kernel (this file), 1: LDS-staged kernel (conv_lds.hip)
+  if (cfg < 0 || cfg >= imagen_igemm_num_configs()) return -1;
+  return cfg >= kNumCfgs ? 1 : 0;
+}
 
 extern "C" int imagen_igemm_config_info(int cfg, int* tile_pixels, int* tile_cout, int* kgroups) {
+  if (cfg >= kNumCfgs) return imagen_conv_lds_config_info(cfg - kNumCfgs, tile_pixels, tile_cout, kgroups);
   if (cfg < 0 || cfg >= kNumCfgs) return -1;
   const TileCfg& c = kCfgs[cfg];
   if (tile_pixels) *tile_pixels = 32 * c.MI * c.WM;
@@ -929,9 +943,23 @@ static constexpr int ksc_of(int G, int ks) {   // the launch_cfg dispatch, as a 
 }
 
 extern "C" int imagen_igemm_stage_slots(int cfg, int KH, int KW) {
+  if (cfg >= kNumCfgs) return imagen_conv_lds_stage_slots(cfg - kNumCfgs, KH, KW);
   if (cfg < 0 || cfg >= kNumCfgs || KH < 1 || KW < 1) return -1;
   const TileCfg& c = kCfgs[cfg];
   return stage_slots(32 * c.MI * c.WM, c.G, ksc_of(c.G, (KH * KW * c.G + 1) / 2));
+}
+
+// dynamic LDS bytes of a launch of `cfg` with a KH x KW kernel (at `stride`) and a TH x TW output tile; -1: the combination is not launchable
+extern "C" long imagen_igemm_lds_bytes(int cfg, int KH, int KW, int stride, int TH, int TW) {
+  if (cfg >= kNumCfgs) return stride == 1 ? imagen_conv_lds_lds_bytes(cfg - kNumCfgs, KH, KW, TH, TW) : -1;
+  if (cfg < 0 || KH < 1 || KW < 1 || TH < 1 || TW < 1) return -1;
+  const TileCfg& c = kCfgs[cfg];
+  if (TH * TW != 32 * c.MI * c.WM) return -1;
+  const int IT = ((TH - 1) * stride + KH) * ((TW - 1) * stride + KW);
+  if (IT * c.G > imagen_igemm_stage_slots(cfg, KH, KW) * 256) return -1;
+  const long PS = c.G == 1 ? 16 : c.G * 16 + 16;
+  const long lds = 2 * IT * PS + (long)(4 * 32 * c.MI + kBiasLds) * (long)sizeof(float) + 16;
+  return lds <= 160 * 1024 ? lds : -1;
 }
 
 static inline int round_up(int v, int m) { return (v + m - 1) / m * m; }

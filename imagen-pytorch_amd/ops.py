@@ -25,6 +25,8 @@ _CFG_TABLE = None
 
 
 def cfg_table():
+    """[(tile pixels, tile couts, G, family)] per tile cfg id; family 0 = wave-specialised persistent kernel (csrc/igemm.hip),
+    1 = LDS-staged kernel (csrc/conv_lds.hip: 1x1 / 3x3, stride 1)."""
     global _CFG_TABLE
     if _CFG_TABLE is None:
         lib = load_library()
@@ -32,7 +34,7 @@ def cfg_table():
         for i in range(lib.imagen_igemm_num_configs()):
             tp, bn, g = ctypes.c_int(), ctypes.c_int(), ctypes.c_int()
             lib.imagen_igemm_config_info(i, ctypes.byref(tp), ctypes.byref(bn), ctypes.byref(g))
-            tab.append((tp.value, bn.value, g.value))
+            tab.append((tp.value, bn.value, g.value, lib.imagen_igemm_config_family(i)))
         _CFG_TABLE = tab
     return _CFG_TABLE
 
@@ -217,7 +219,7 @@ def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], device, in_scale:
     G = G or choose_G(Cin, KH * KW)
     KC = 8 * G
     Cin_pad = _round_up(Cin, KC)
-    Cout_pad = _round_up(Cout, 128)
+    Cout_pad = _round_up(Cout, 128 if Cout <= 128 else 256)   # every tile width (32 .. 256 couts) divides it
     n = lib.imagen_igemm_packed_elems(G, Cin, Cout_pad, KH, KW)
     out = torch.empty(n, dtype=torch.float16)
     sc = None if in_scale is None else in_scale.detach().float().cpu().contiguous()
@@ -253,11 +255,36 @@ def _tile_shapes(tp: int, OH: int, OW: int):
     return [(tp // tw, tw) for tw in (8, 16, 32, 64) if tp % tw == 0 and tp // tw >= 1]
 
 
-def pick_cfg(G: int, Cout: int, OH: int, OW: int, B: int, KH: int = 1, KW: int = 1, stride: int = 1, full_cout: bool = False):
-    """Choose (cfg, TH, TW) for the wave-specialised persistent kernel.  Measured on MI355X (tools/igemm_probe.py --sweep,
-    gpurun_out/sweep1.txt): the kernel is staging-/latency-bound rather than MFMA-bound, so the 64-pixel-per-wave tilings
-    (MI <= 2) win everywhere, and when a layer has fewer workgroups than the chip has CUs the narrower output-channel tile
-    (twice the workgroups) wins.  Preference order of (tile pixels, tile couts):
+def launchable_shapes(cfg: int, OH: int, OW: int, KH: int, KW: int, stride: int):
+    """Tile shapes (tiles, staged halo pixels, th, tw) of `cfg` the launcher accepts for this layer, best first: least padded pixels,
+    then the fewest staged halo pixels."""
+    lib = load_library()
+    tp = cfg_table()[cfg][0]
+    out = []
+    for th, tw in _tile_shapes(tp, OH, OW):
+        if lib.imagen_igemm_lds_bytes(cfg, KH, KW, stride, th, tw) <= 0:
+            continue
+        it = ((th - 1) * stride + KH) * ((tw - 1) * stride + KW)
+        tiles = math.ceil(OH / th) * math.ceil(OW / tw)
+        out.append((tiles, tiles * it, th, tw))
+    return sorted(out)
+
+
+CONV_LDS = int(_os.environ.get("IMAGEN_CONV_LDS", "1"))             # A/B switch: the LDS-staged kernel family for 3x3 convs
+CONV_LDS_1X1 = int(_os.environ.get("IMAGEN_CONV_LDS_1X1", "0"))     # ... and for 1x1 convs / linears
+
+
+def pick_cfg(G: int, Cout: int, OH: int, OW: int, B: int, KH: int = 1, KW: int = 1, stride: int = 1, full_cout: bool = False,
+             family: Optional[int] = None):
+    """Choose (cfg, TH, TW).
+
+    Family 1 (LDS-staged kernel, conv_lds.hip) takes the stride-1 3x3 convs with 32-channel chunks (and, behind a switch, 1x1):
+      Cout % 128 == 0 : 128 px x 128 co when that gives >= 256 workgroups, else 64 px x 128 co
+      Cout == 64      : 256 px x 64 co with >= 1024 workgroups, 128 x 64 with >= 512, else 64 x 64
+      Cout == 32      : 256 px x 32 co with >= 1024 workgroups, else 128 x 32
+    Family 0 (wave-specialised persistent kernel, igemm.hip) takes everything else, measured on MI355X (tools/igemm_probe.py
+    --sweep): the 64-pixel-per-wave tilings (MI <= 2) win everywhere, and when a layer has fewer workgroups than the chip has CUs
+    the narrower output-channel tile (twice the workgroups) wins.  Preference order of (tile pixels, tile couts):
       Cout <= 32 : 256x32 when that still gives >= 1024 workgroups, else 128x32
       Cout <= 64 : 256x64 for k > 1 kernels with >= 1024 workgroups (profiles/r01_igemm_tile_sweep.txt), else 64x64
       Cout  > 64 : 128x128 when that gives >= 256 workgroups, 64x128 when >= 192, else 64x64
@@ -265,44 +292,46 @@ def pick_cfg(G: int, Cout: int, OH: int, OW: int, B: int, KH: int = 1, KW: int =
     tiles narrower than Cout are then only used when nothing wider exists.  Among the tile shapes of the chosen
     configuration: least padded pixels, then the fewest staged halo pixels."""
     tab = cfg_table()
-    ps = 16 if G == 1 else G * 16 + 16
+    want1 = stride == 1 and G in (4, 8) and ((KH == 3 and KW == 3 and G == 4 and CONV_LDS) or (KH == 1 and KW == 1 and CONV_LDS_1X1))
+    fams = [family] if family is not None else ([1, 0] if want1 else [0])
+    for fam in fams:
+        avail = {}
+        for i, (tp, bn, g, f) in enumerate(tab):
+            if g == G and f == fam and (tp, bn) not in avail:
+                sh = launchable_shapes(i, OH, OW, KH, KW, stride)
+                if sh:
+                    avail[(tp, bn)] = (i, sh[0])
 
-    def shapes(tp, max_items):
-        out = []
-        for th, tw in _tile_shapes(tp, OH, OW):
-            it = ((th - 1) * stride + KH) * ((tw - 1) * stride + KW)
-            if it * G > max_items or 2 * it * ps + 4096 > MAX_LDS_BYTES:
-                continue
-            tiles = math.ceil(OH / th) * math.ceil(OW / tw)
-            out.append((tiles, tiles * it, th, tw))
-        return sorted(out)
+        def wgs(key):
+            return B * avail[key][1][0] * math.ceil(Cout / key[1]) if key in avail else 0
 
-    lib = load_library()
-    avail = {}
-    for i, (tp, bn, g) in enumerate(tab):
-        if g == G and (tp, bn) not in avail:
-            sh = shapes(tp, lib.imagen_igemm_stage_slots(i, KH, KW) * 256)
-            if sh:
-                avail[(tp, bn)] = (i, sh[0])
-
-    def wgs(key):
-        return B * avail[key][1][0] * math.ceil(Cout / key[1]) if key in avail else 0
-
-    if Cout <= 32:
-        order = [(256, 32)] if wgs((256, 32)) >= 1024 and PICK_256x32 else []
-        order += [(128, 32), (256, 32), (64, 64), (64, 128)]
-    elif Cout <= 64:
-        order = [(256, 64)] if wgs((256, 64)) >= 1024 and KH * KW > 1 and PICK_256x64 else []
-        order += [(64, 64), (64, 128), (128, 32), (256, 32)]
-    else:
-        order = [(128, 128)] if wgs((128, 128)) >= 256 and PICK_128 else []          # big layers: 3-9 % over 64x128 (MI = 4: half the weight traffic)
-        order += [(64, 128)] if wgs((64, 128)) >= 192 or (full_cout and Cout <= 128) else []
-        order += [(64, 64), (64, 128), (128, 32), (256, 32)]
-    order += [(128, 128), (256, 64)]
-    for key in order:
-        if key in avail:
-            i, (_, _, th, tw) = avail[key]
-            return i, th, tw
+        if fam == 1:
+            if Cout <= 32:
+                order = [(256, 32)] if wgs((256, 32)) >= 1024 else []
+                order += [(128, 32), (256, 32), (64, 64), (128, 64)]
+            elif Cout <= 64:
+                order = [(256, 64)] if wgs((256, 64)) >= 1024 else []
+                order += [(128, 64)] if wgs((128, 64)) >= 512 else []
+                order += [(64, 64), (128, 64), (256, 64)]
+            else:
+                order = [(128, 128)] if wgs((128, 128)) >= 256 else []
+                order += [(64, 128), (128, 128), (64, 64)]
+        elif Cout <= 32:
+            order = [(256, 32)] if wgs((256, 32)) >= 1024 and PICK_256x32 else []
+            order += [(128, 32), (256, 32), (64, 64), (64, 128)]
+        elif Cout <= 64:
+            order = [(256, 64)] if wgs((256, 64)) >= 1024 and KH * KW > 1 and PICK_256x64 else []
+            order += [(64, 64), (64, 128), (128, 32), (256, 32)]
+        else:
+            order = [(128, 128)] if wgs((128, 128)) >= 256 and PICK_128 else []          # big layers: 3-9 % over 64x128 (MI = 4: half the weight traffic)
+            order += [(64, 128)] if wgs((64, 128)) >= 192 or (full_cout and Cout <= 128) else []
+            order += [(64, 64), (64, 128), (128, 32), (256, 32)]
+        if fam == 0:
+            order += [(128, 128), (256, 64)]
+        for key in order:
+            if key in avail:
+                i, (_, _, th, tw) = avail[key]
+                return i, th, tw
     raise ValueError(f"no igemm tile configuration for G={G} Cout={Cout} {OH}x{OW} k{KH}x{KW} s{stride}")
 
 

@@ -357,6 +357,11 @@ int imagen_igemm_config_info(int cfg, int* tile_pixels, int* tile_cout, int* kgr
 /* 16-byte staging slots per producer thread the instantiation (cfg, KHxKW kernel) holds: a tile shape is launchable iff
  * halo_pixels * G <= slots * 256 */
 int imagen_igemm_stage_slots(int cfg, int KH, int KW);
+/* kernel family of a tile cfg: 0 = wave-specialised persistent kernel (weights streamed from L2 per wave; every kernel size and
+ * stride), 1 = LDS-staged kernel (both MFMA operands through LDS, weights by direct-to-LDS loads; 1x1 and 3x3, stride 1). */
+int imagen_igemm_config_family(int cfg);
+/* dynamic LDS bytes of a launch of `cfg` with a KHxKW kernel at `stride` and a THxTW output tile; -1 = not launchable */
+long imagen_igemm_lds_bytes(int cfg, int KH, int KW, int stride, int TH, int TW);
 /* Host-side pack: w_in fp32 [Cout][Cin][KH][KW] (Conv2d / Linear layout, HOST memory) -> packed fp16 (HOST memory)
  * in MFMA fragment order.  G = 8-channel groups per k-chunk (1, 2 or 4; must match the tile cfg used at launch),
  * Cout_pad = multiple of 128 (any tile cfg can then consume it).  in_scale (optional, [Cin]) is folded into W. */

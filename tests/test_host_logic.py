@@ -105,12 +105,16 @@ def test_tile_selection_respects_kernel_limits():
     for G, Cout, OH, OW, B, K, stride in [(4, 32, 256, 256, 16, 3, 1), (4, 256, 32, 32, 16, 3, 1), (4, 256, 8, 8, 16, 3, 1),
                                           (1, 32, 256, 256, 16, 15, 1), (4, 64, 128, 128, 16, 2, 2), (4, 512, 1, 1024, 16, 1, 1),
                                           (4, 13000, 1, 16, 1, 1, 1), (1, 16, 24, 40, 1, 3, 1), (4, 3, 64, 64, 2, 3, 1)]:
-        cfg, th, tw = ops.pick_cfg(G, Cout, OH, OW, B, K, K, stride)
-        tp, bn, g = tab[cfg]
-        assert g == G and th * tw == tp
-        it = ((th - 1) * stride + K) * ((tw - 1) * stride + K)
-        assert it * G <= 256 * ops.load_library().imagen_igemm_stage_slots(cfg, K, K)
-        assert 2 * it * (16 if G == 1 else G * 16 + 16) <= ops.MAX_LDS_BYTES
+        for fam in (None, 0):
+            cfg, th, tw = ops.pick_cfg(G, Cout, OH, OW, B, K, K, stride, family=fam)
+            tp, bn, g, family = tab[cfg]
+            assert g == G and th * tw == tp and (fam is None or family == fam)
+            it = ((th - 1) * stride + K) * ((tw - 1) * stride + K)
+            assert it * G <= 256 * ops.load_library().imagen_igemm_stage_slots(cfg, K, K)
+            lds = ops.load_library().imagen_igemm_lds_bytes(cfg, K, K, stride, th, tw)
+            assert 0 < lds <= ops.MAX_LDS_BYTES
+            if family == 1:   # LDS-staged family: stride 1, 1x1 / 3x3 only, tile widths with conflict-free row pitches
+                assert stride == 1 and K in (1, 3) and (tw in (8, 16) or tw % 32 == 0)
 
 
 @pytest.mark.parametrize("name", ["unet_tiny_base.pt", "unet_tiny_sr.pt"])

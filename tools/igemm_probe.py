@@ -99,13 +99,11 @@ def sweep(shapes, G_list=None):
             if C % (8 * G) and G != ops.choose_G(C, K * K):
                 continue
             res = []
-            for i, (tp, bn, g) in enumerate(tab):
+            for i, (tp, bn, g, fam) in enumerate(tab):
                 if g != G:
                     continue
                 for th, tw in ops._tile_shapes(tp, H, W):
-                    it = (th - 1 + K) * (tw - 1 + K)
-                    ps = 16 if G == 1 else G * 16 + 16
-                    if it * G > 256 * ops.load_library().imagen_igemm_stage_slots(i, K, K) or 2 * it * ps + 4096 > ops.MAX_LDS_BYTES:
+                    if ops.load_library().imagen_igemm_lds_bytes(i, K, K, 1, th, tw) <= 0:
                         continue
                     if bn > 32 and bn >= 2 * max(32, Cout):
                         continue
@@ -116,7 +114,9 @@ def sweep(shapes, G_list=None):
                     res.append((us, i, th, tw, tp, bn))
             res.sort()
             pk = ops.pick_cfg(G, Cout, H, W, B, K, K, 1)
-            best = " ".join(f"cfg{i}({tp}x{bn}) t{th}x{tw}:{us:.1f}" for us, i, th, tw, tp, bn in res[:5])
+            best = " ".join(f"cfg{i}({tp}x{bn}) t{th}x{tw}:{us:.1f}" for us, i, th, tw, tp, bn in res[:6])
+            best0 = [r for r in res if tab[r[1]][3] == 0][:1]
+            best += "".join(f" | best family-0 cfg{i}({tp}x{bn}) t{th}x{tw}:{us:.1f}" for us, i, th, tw, tp, bn in best0)
             mine = [r for r in res if (r[1], r[2], r[3]) == tuple(pk)]
             print(f"{name:26s} G={G:2d} | pick cfg{pk[0]} t{pk[1]}x{pk[2]}: {mine[0][0] if mine else float('nan'):.1f}us | best: {best}", flush=True)
 
