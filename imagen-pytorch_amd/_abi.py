@@ -105,12 +105,13 @@ OP_STRUCT = {
     ENUMS["IMAGEN_OP_KV_PREP_MULTI"]: STRUCTS["ImagenKvPrepMultiParams"],
     ENUMS["IMAGEN_OP_TEMPORAL_PEG"]: STRUCTS["ImagenTemporalPegParams"],
     ENUMS["IMAGEN_OP_TEMPORAL_ATTENTION"]: STRUCTS["ImagenTemporalAttentionParams"],
+    ENUMS["IMAGEN_OP_ACT_PREP"]: STRUCTS["ImagenActPrepParams"],
 }
 STRUCT_KIND = {v: k for k, v in OP_STRUCT.items()}
 
 EXPORTED_SYMBOLS = [
     "imagen_abi_version", "imagen_last_error", "imagen_sizeof", "imagen_launch", "imagen_plan_run",
-    "imagen_igemm_num_configs", "imagen_igemm_config_info", "imagen_igemm_stage_slots", "imagen_igemm_config_family", "imagen_igemm_lds_bytes", "imagen_igemm_packed_elems", "imagen_pack_igemm_weights",
+    "imagen_igemm_num_configs", "imagen_igemm_config_info", "imagen_igemm_stage_slots", "imagen_igemm_config_family", "imagen_igemm_config_ring", "imagen_igemm_lds_bytes", "imagen_igemm_packed_elems", "imagen_pack_igemm_weights",
     "imagen_graph_begin", "imagen_graph_end", "imagen_graph_launch", "imagen_graph_destroy",
     "imagen_event_create", "imagen_event_record", "imagen_event_elapsed_ms", "imagen_event_destroy",
 ]
@@ -147,6 +148,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.imagen_igemm_config_info.argtypes = [ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 3
     lib.imagen_igemm_stage_slots.argtypes = [ctypes.c_int] * 3
     lib.imagen_igemm_config_family.argtypes = [ctypes.c_int]
+    lib.imagen_igemm_config_ring.argtypes = [ctypes.c_int]
     lib.imagen_igemm_lds_bytes.restype = ctypes.c_long
     lib.imagen_igemm_lds_bytes.argtypes = [ctypes.c_int] * 6
     lib.imagen_igemm_packed_elems.restype = ctypes.c_size_t

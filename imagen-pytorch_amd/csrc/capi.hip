@@ -45,6 +45,7 @@ extern "C" size_t imagen_sizeof(int kind) {
     case IMAGEN_OP_KV_PREP_MULTI: return sizeof(ImagenKvPrepMultiParams);
     case IMAGEN_OP_TEMPORAL_PEG: return sizeof(ImagenTemporalPegParams);
     case IMAGEN_OP_TEMPORAL_ATTENTION: return sizeof(ImagenTemporalAttentionParams);
+    case IMAGEN_OP_ACT_PREP: return sizeof(ImagenActPrepParams);
     default: return 0;
   }
 }
@@ -78,6 +79,7 @@ extern "C" int imagen_launch(int kind, const void* params, imagen_stream_t strea
     case IMAGEN_OP_KV_PREP_MULTI: return launch_kv_prep_multi(static_cast<const ImagenKvPrepMultiParams*>(params), s);
     case IMAGEN_OP_TEMPORAL_PEG: return launch_temporal_peg(static_cast<const ImagenTemporalPegParams*>(params), s);
     case IMAGEN_OP_TEMPORAL_ATTENTION: return launch_temporal_attention(static_cast<const ImagenTemporalAttentionParams*>(params), s);
+    case IMAGEN_OP_ACT_PREP: return launch_act_prep(static_cast<const ImagenActPrepParams*>(params), s);
     default: imagen_set_error("imagen_launch: unknown op kind %d", kind); return -1;
   }
 }

@@ -25,6 +25,7 @@
 #include <type_traits>
 #include <utility>
 #include "common.h"
+#include "conv_epilogue.h"
 
 namespace {
 
@@ -37,8 +38,6 @@ __device__ __forceinline__ void cl_static_for(F&& f) {
   cl_static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 
-struct ClTile { int b, oy0, ox0, n0; };
-
 __device__ __attribute__((aligned(16))) float clOnes8[8] = {1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f, 1.f};
 __device__ __attribute__((aligned(16))) float clZeros8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
 
@@ -47,7 +46,6 @@ constexpr int cl_stage_slots(int TP, int G, int TAPS) {
   if (TAPS == 9) return TP == 64 ? 2 : TP == 128 ? 3 : 6;   // 10x10 | 10x18 | 18x18 (10x34) halo tiles of 32-channel chunks
   return TP * G / 256;                                       // 1x1: no halo
 }
-constexpr int cl_ring(int TAPS) { return TAPS == 9 ? 4 : 3; }
 
 // s_waitcnt vmcnt(n) only (expcnt / lgkmcnt fields at their maximum = no wait); gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14].
 // The builtin (not inline asm: the waitcnt pass forgets its scoreboard behind an asm statement and drains lgkmcnt(0) at the next LDS
@@ -58,7 +56,11 @@ constexpr int cl_ring(int TAPS) { return TAPS == 9 ? 4 : 3; }
     asm volatile("" ::: "memory");                                                                \
   } while (0)
 
-template <int MI, int NI, int WM, int WN, int G, int TAPS, bool GEN>
+// -DCL_PROBE (tools/build_probe_lib.sh builds a separate library; tools/conv_probe.py drives it): ImagenIgemmParams.dbg bits ablate
+// parts of the kernel to attribute time — 1: no waits for the weight DMA, 2: no MFMAs, 4: no activation staging inside the loop, 8: no
+// stores, 16: no weight DMA inside the loop, 32: no chunk barrier, 64: no B-fragment reads, 128: no A-fragment reads, 256: no chunk
+// rotation.  Results of ablated runs are numerically meaningless; the product library compiles all of it out.
+template <int MI, int NI, int WM, int WN, int G, int TAPS, int RW, bool GEN>
 __global__ __launch_bounds__(256, (MI * NI <= 2 ? 3 : 2)) void conv_lds_kernel(const ImagenIgemmParams p, const int RP) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(TAPS == 1 || TAPS == 9, "1x1 or 3x3");
@@ -69,7 +71,6 @@ __global__ __launch_bounds__(256, (MI * NI <= 2 ? 3 : 2)) void conv_lds_kernel(c
   constexpr int LOG2G = (G == 4) ? 2 : (G == 8) ? 3 : 4;
   constexpr int KW = TAPS == 9 ? 3 : 1;
   constexpr int KSTEPS = G / 2;            // K=16 MFMA steps per stage
-  constexpr int RW = cl_ring(TAPS);
   constexpr int SLOTW = NI * G * 512;      // bytes of one wave-private weight stage slot: [NI][G groups][32 couts][8 halves]
   constexpr int kItems = cl_stage_slots(TP, G, TAPS);
   constexpr int PXW = 32 * MI;
@@ -253,10 +254,14 @@ __global__ __launch_bounds__(256, (MI * NI <= 2 ? 3 : 2)) void conv_lds_kernel(c
   struct Frags { f16x8 a[NI], b[MI]; };
   Frags F0, F1;
   auto read_frags = [&](Frags& F, const char* abuf, int tap_off, const char* wslot, int ks) __attribute__((always_inline)) {
+    if (!CL_DBG(128)) {
 #pragma unroll
-    for (int ni = 0; ni < NI; ++ni) F.a[ni] = *reinterpret_cast<const f16x8*>(wslot + ni * (G * 512) + ks * 1024 + lane * 16);
+      for (int ni = 0; ni < NI; ++ni) F.a[ni] = *reinterpret_cast<const f16x8*>(wslot + ni * (G * 512) + ks * 1024 + lane * 16);
+    }
+    if (!CL_DBG(64)) {
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) F.b[mi] = *reinterpret_cast<const f16x8*>(abuf + a_base[mi] + tap_off + ks * 32);
+      for (int mi = 0; mi < MI; ++mi) F.b[mi] = *reinterpret_cast<const f16x8*>(abuf + a_base[mi] + tap_off + ks * 32);
+    }
   };
   auto mfma_step = [&](const Frags& F) __attribute__((always_inline)) {
 #pragma unroll
@@ -267,10 +272,16 @@ __global__ __launch_bounds__(256, (MI * NI <= 2 ? 3 : 2)) void conv_lds_kernel(c
   };
 
   // ================================================================================================ pipeline
+  // (Starting every tile at its own chunk, so that the CUs of an XCD do not pull the same weights through the same L2 channels
+  // at the same time, was measured and changes nothing: tools/conv_probe.py, profiles/r02_conv_probe_b.txt.)
+  auto rot = [&](int c) __attribute__((always_inline)) -> int { return c; };
   // prologue: this wave's weight stages 0..RW-2 in flight, chunk 0 staged, fragments of the first K step read
 #pragma unroll
-  for (int j = 0; j < RW - 1; ++j) dma_stage(j / TAPS, j % TAPS, j);
-  load_set(0);
+  for (int j = 0; j < RW - 1; ++j) {
+    const int cj = j / TAPS;
+    dma_stage(cj < NC ? rot(cj) : NC + (cj - NC), j % TAPS, j);   // (past the end: the zero tail behind the last chunk)
+  }
+  load_set(rot(0));
   write_set(abuf0);
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
   read_frags(F0, abuf0, 0, ring, 0);
@@ -278,11 +289,12 @@ __global__ __launch_bounds__(256, (MI * NI <= 2 ? 3 : 2)) void conv_lds_kernel(c
   constexpr int L = kItems * 3 + 4;   // ordinary loads of one load_set (activations, two statistics, affine)
   constexpr int WRITE_TAP = TAPS == 9 ? 5 : 0;
   static_assert((TAPS * KSTEPS) % 2 == 0, "fragment set parity must repeat per chunk");
+  static_assert(TAPS == 1 || RW - 1 <= TAPS, "the weight look-ahead may cross one chunk boundary only");
   int s = 0;   // global stage index of tap 0 of the current chunk
   for (int c = 0; c < NC; ++c, s += TAPS) {
     const char* abuf = abuf0 + (c & 1) * abuf_bytes;
     char* abuf_next = abuf0 + ((c + 1) & 1) * abuf_bytes;
-    const int c_next = c + 1 < NC ? c + 1 : c;
+    const int c_next = c + 1 < NC ? rot(c + 1) : rot(c);
     cl_static_for<TAPS * KSTEPS>([&](auto kc) __attribute__((always_inline)) {
       constexpr int k = decltype(kc)::value;
       constexpr int t = k / KSTEPS, ks = k % KSTEPS;
@@ -291,229 +303,50 @@ __global__ __launch_bounds__(256, (MI * NI <= 2 ? 3 : 2)) void conv_lds_kernel(c
       if constexpr (ks == 0) {
         // 3x3: transform + write the next chunk's halo tile BEFORE this stage's DMA is issued — the compiler's wait for the
         // activation loads is a full vmcnt(0) (it cannot see the asm DMAs), and the youngest DMA is then a whole stage old
-        if constexpr (TAPS == 9 && t == WRITE_TAP) write_set(abuf_next);
+        if constexpr (TAPS == 9 && t == WRITE_TAP) {
+          if (!CL_DBG(4)) write_set(abuf_next);
+        }
         // refill the slot of the stage that just finished with stage s + t + RW - 1 (past the end: the packed buffer's zero
         // tail, into a slot this wave never reads again)
         int cn = c, tn = t + RW - 1;
         if (TAPS == 1) { cn = c + RW - 1; tn = 0; }
         else if (tn >= TAPS) { tn -= TAPS; ++cn; }
-        dma_stage(cn, tn, (s + t + RW - 1) % RW);
-        if constexpr (t == 0) load_set(c_next);
+        if (!CL_DBG(16)) dma_stage(cn < NC ? rot(cn) : NC + (cn - NC), tn, (s + t + RW - 1) % RW);
+        if constexpr (t == 0) {
+          if (!CL_DBG(4)) load_set(c_next);
+        }
       }
-      if constexpr (TAPS == 1 && ks == KSTEPS - 1) write_set(abuf_next);
+      if constexpr (TAPS == 1 && ks == KSTEPS - 1) {
+        if (!CL_DBG(4)) write_set(abuf_next);
+      }
       // ---- fragments of the next K step
       if constexpr (ks + 1 < KSTEPS) {
         read_frags(nxt, abuf, (t / KW) * RP + (t % KW) * PS, ring + ((s + t) % RW) * SLOTW, ks + 1);
       } else {
         // first step of the next stage: its weight slot must have landed (this wave's own DMA: no barrier); everything issued
         // after that DMA may stay in flight
-        if (TAPS == 1) CL_WAIT_VM(KD);                                              // (load_set's loads were consumed by write_set above)
-        else if (t + 1 >= 1 && t + 1 <= 3 && t + 1 < WRITE_TAP) CL_WAIT_VM((RW - 2) * KD + L);   // load_set's loads were issued after that DMA
-        else CL_WAIT_VM((RW - 2) * KD);
+        if (!CL_DBG(1 | 16)) {
+          if (TAPS == 1) CL_WAIT_VM(KD);                                    // (load_set's loads were consumed by write_set above)
+          else if (t <= RW - 2 && t < WRITE_TAP && !CL_DBG(4)) CL_WAIT_VM((RW - 2) * KD + L);   // load_set's loads were issued after that DMA
+          else CL_WAIT_VM((RW - 2) * KD);
+        }
         if constexpr (t + 1 < TAPS) {
           read_frags(nxt, abuf, ((t + 1) / KW) * RP + ((t + 1) % KW) * PS, ring + ((s + t + 1) % RW) * SLOTW, 0);
         } else {
           // chunk boundary: every wave has written its part of the next activation buffer and finished reading this one
-          asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          if (!CL_DBG(32)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
           read_frags(nxt, abuf_next, 0, ring + ((s + TAPS) % RW) * SLOTW, 0);
         }
       }
       __builtin_amdgcn_sched_barrier(0);
-      mfma_step(cur);
+      if (!CL_DBG(2)) mfma_step(cur);
       __builtin_amdgcn_sched_barrier(0);
     });
   }
   CL_WAIT_VM(0);   // stray look-ahead DMAs must not outlive the workgroup's LDS allocation
   __syncthreads(); // (ep_red below is disjoint from the rings, but the allocation is released when the LAST wave ends)
 
-  // ================================================================================================ epilogue
-  // lane = pixel; register quad q holds couts 8q + 4*half + {0..3} of each 32-cout fragment
-  const int b = tc.b, n0 = tc.n0;
-  const f16* addend = reinterpret_cast<const f16*>(p.addend);
-  const f16* res = reinterpret_cast<const f16*>(p.res);
-  int op[MI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    const int oy = tc.oy0 + pix_y[mi], ox = tc.ox0 + pix_x[mi];
-    op[mi] = (oy < p.OH && ox < p.OW) ? oy * p.OW + ox : -1;
-  }
-  auto load_bias = [&](int co) __attribute__((always_inline)) -> float4 {
-    return p.bias ? *reinterpret_cast<const float4*>(p.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);   // padded to Cout_pad by the host
-  };
-
-  if (p.post_pa) {
-    // ---- output-side Block prologue: norm over all Cout of the pixel, then activate + store
-    float tot[MI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) tot[mi] = 0.0f;
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
-        if (co >= p.Cout) continue;
-        const float4 bq = load_bias(co);
-        const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            const float v = acc[ni][mi][4 * q + e] + bb[e];
-            acc[ni][mi][4 * q + e] = v;
-            tot[mi] += v * v;
-          }
-      }
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) tot[mi] += __shfl_xor(tot[mi], 32);
-    if (WN > 1) {
-      if (half == 0) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) ep_red[(wm * WN + wn) * PXW + mi * 32 + l31] = tot[mi];
-      }
-      __syncthreads();
-#pragma unroll
-      for (int mi = 0; mi < MI; ++mi) {
-        float t = 0.0f;
-#pragma unroll
-        for (int w = 0; w < WN; ++w) t += ep_red[(wm * WN + w) * PXW + mi * 32 + l31];
-        tot[mi] = t;
-      }
-    }
-    float rsn[MI];
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) rsn[mi] = __builtin_amdgcn_rsqf(fmaxf(tot[mi], 1e-24f));
-    f16* y = reinterpret_cast<f16*>(p.y) + (size_t)b * p.bsy;
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
-        if (co >= p.Cout) continue;
-        const float4 pa = *reinterpret_cast<const float4*>(p.post_pa + (size_t)b * p.post_pstride + co);
-        const float4 ps = *reinterpret_cast<const float4*>(p.post_ps + (size_t)b * p.post_pstride + co);
-        const float pav[4] = {pa.x, pa.y, pa.z, pa.w}, psv[4] = {ps.x, ps.y, ps.z, ps.w};
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          if (op[mi] < 0) continue;
-          f16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (f16)silu_f(acc[ni][mi][4 * q + e] * rsn[mi] * pav[e] + psv[e]);
-          if (!(p.dbg & 8)) *reinterpret_cast<f16x4*>(y + (size_t)op[mi] * p.ldy + co) = o;
-        }
-      }
-    return;
-  }
-
-  float ssq_px[MI];
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) ssq_px[mi] = 0.0f;
-
-  if constexpr (!GEN) {   // plain NHWC output (optionally + ssq_out): branch-free
-    f16* y = reinterpret_cast<f16*>(p.y) + (size_t)b * p.bsy;
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
-        const float4 bq = load_bias(co);   // co < Cout_pad always
-        const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          f16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            o[e] = (f16)(acc[ni][mi][4 * q + e] + bb[e]);
-            const float r = (float)o[e];
-            ssq_px[mi] += r * r;
-          }
-          if (co < p.Cout && op[mi] >= 0 && !(p.dbg & 8)) *reinterpret_cast<f16x4*>(y + (size_t)op[mi] * p.ldy + co) = o;
-        }
-      }
-  } else {
-#pragma unroll
-    for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
-        if (co >= p.Cout) continue;
-        const float4 bq = load_bias(co);
-        const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
-        float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (addend) g = *reinterpret_cast<const float4*>(p.gate + (size_t)b * p.gate_stride + co);
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          if (op[mi] < 0) continue;
-          float v[4];
-#pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = acc[ni][mi][4 * q + e] + bb[e];
-          if (p.act_out == IMAGEN_ACT_SILU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = silu_f(v[e]);
-          } else if (p.act_out == IMAGEN_ACT_GELU) {
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] = gelu_f(v[e]);
-          }
-          if (p.out_mode == IMAGEN_OUT_NCHW_F32) {
-            float* y = reinterpret_cast<float*>(p.y);
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-              if (co + e < p.Cout) y[((size_t)b * p.Cout + co + e) * (p.OH * p.OW) + op[mi]] = v[e];
-            continue;
-          }
-          if (addend) {
-            const f16x4 ad = *reinterpret_cast<const f16x4*>(addend + (size_t)b * p.bs_add + (size_t)op[mi] * p.ld_add + co);
-            v[0] += (float)ad[0] * g.x; v[1] += (float)ad[1] * g.y; v[2] += (float)ad[2] * g.z; v[3] += (float)ad[3] * g.w;
-          } else if (res) {
-            const f16x4 rr = *reinterpret_cast<const f16x4*>(res + (size_t)b * p.bs_res + (size_t)op[mi] * p.ld_res + co);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) v[e] += (float)rr[e];
-          }
-          f16x4 o;
-#pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            o[e] = (f16)v[e];
-            const float r = (float)o[e];
-            ssq_px[mi] += r * r;
-          }
-          f16* y = reinterpret_cast<f16*>(p.y);
-          if (p.out_mode == IMAGEN_OUT_PIXEL_SHUFFLE) {
-            const int Cq = p.Cout >> 2;
-            const int sub = co / Cq, cc = co - sub * Cq;
-            const int oy = tc.oy0 + pix_y[mi], ox = tc.ox0 + pix_x[mi];
-            const int yy = 2 * oy + (sub >> 1), xx = 2 * ox + (sub & 1);
-            *reinterpret_cast<f16x4*>(y + (size_t)b * p.bsy + ((size_t)yy * (2 * p.OW) + xx) * p.ldy + cc) = o;
-          } else if (!(p.dbg & 8)) {
-            *reinterpret_cast<f16x4*>(y + (size_t)b * p.bsy + (size_t)op[mi] * p.ldy + co) = o;
-          }
-        }
-      }
-  }
-  if (p.ssq_out) {   // launcher guarantees tilesN == 1
-#pragma unroll
-    for (int mi = 0; mi < MI; ++mi) ssq_px[mi] += __shfl_xor(ssq_px[mi], 32);
-    if (WN == 1) {
-      if (half == 0) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi)
-          if (op[mi] >= 0) p.ssq_out[(size_t)b * (p.OH * p.OW) + op[mi]] = ssq_px[mi];
-      }
-    } else {
-      if (half == 0) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) ep_red[(wm * WN + wn) * PXW + mi * 32 + l31] = ssq_px[mi];
-      }
-      __syncthreads();
-      if (wn == 0 && half == 0) {
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          float tot = 0.0f;
-#pragma unroll
-          for (int w = 0; w < WN; ++w) tot += ep_red[(wm * WN + w) * PXW + mi * 32 + l31];
-          if (op[mi] >= 0) p.ssq_out[(size_t)b * (p.OH * p.OW) + op[mi]] = tot;
-        }
-      }
-    }
-  }
+  cl_epilogue<MI, NI, WM, WN, GEN>(p, tc, acc, pix_y, pix_x, ep_red, reinterpret_cast<float*>(smem), wm, wn, half, l31);
 }
 
 // row pitch of the staged halo tile (bytes): conflict-free B-fragment reads (see the file header)
@@ -526,7 +359,7 @@ inline int cl_row_pitch(int TW, int ITW, int PS) {
   return rp;
 }
 
-template <int MI, int NI, int WM, int WN, int G, int TAPS, bool GEN>
+template <int MI, int NI, int WM, int WN, int G, int TAPS, int RW, bool GEN>
 int cl_launch_gen(const ImagenIgemmParams& p, hipStream_t s) {
   constexpr int TP = 32 * MI * WM, BN = 32 * NI * WN;
   constexpr int PS = G * 16 + 16;
@@ -549,12 +382,13 @@ int cl_launch_gen(const ImagenIgemmParams& p, hipStream_t s) {
                               p.act_out == IMAGEN_ACT_NONE && p.Cout % 4 == 0),
                "conv_lds: post_pa needs post_ps, a plain NHWC output and one workgroup covering all %d output channels (tile has %d)", p.Cout, BN);
   IMAGEN_CHECK(!(p.addend && p.res), "conv_lds: addend and residual are mutually exclusive");
+  IMAGEN_CHECK(!p.gca_part || (p.gca_wk && !GEN && !p.post_pa && p.Cout <= BN), "conv_lds: gca_part needs gca_wk, a plain NHWC output and one tile covering all %d couts", p.Cout);
   IMAGEN_CHECK(!p.ssq_out || (p.out_mode == IMAGEN_OUT_NHWC && p.Cout <= BN),
                "conv_lds: ssq_out needs NHWC output and one workgroup covering all %d output channels (tile has %d)", p.Cout, BN);
   const int RP = cl_row_pitch(p.TW, ITW, PS);
-  const size_t lds = (size_t)2 * ITH * RP + (size_t)4 * cl_ring(TAPS) * (NI * G * 512) + (size_t)(4 * 32 * MI) * sizeof(float) + 16;
+  const size_t lds = (size_t)2 * ITH * RP + (size_t)4 * RW * (NI * G * 512) + (size_t)(4 * 32 * MI) * sizeof(float) + 16;
   IMAGEN_CHECK(lds <= 160 * 1024, "conv_lds: LDS tile %zu bytes too large", lds);
-  auto kern = conv_lds_kernel<MI, NI, WM, WN, G, TAPS, GEN>;
+  auto kern = conv_lds_kernel<MI, NI, WM, WN, G, TAPS, RW, GEN>;
   static bool attr_done[16] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -569,34 +403,36 @@ int cl_launch_gen(const ImagenIgemmParams& p, hipStream_t s) {
   return imagen_hip_status("conv_lds launch");
 }
 
-template <int MI, int NI, int WM, int WN, int G, int TAPS>
+template <int MI, int NI, int WM, int WN, int G, int TAPS, int RW>
 int cl_launch(const ImagenIgemmParams& p, hipStream_t s) {
   const bool plain = p.act_out == IMAGEN_ACT_NONE && p.out_mode == IMAGEN_OUT_NHWC && !p.addend && !p.res;
-  return plain ? cl_launch_gen<MI, NI, WM, WN, G, TAPS, false>(p, s) : cl_launch_gen<MI, NI, WM, WN, G, TAPS, true>(p, s);
+  return plain ? cl_launch_gen<MI, NI, WM, WN, G, TAPS, RW, false>(p, s) : cl_launch_gen<MI, NI, WM, WN, G, TAPS, RW, true>(p, s);
 }
 
-struct ClCfg { int MI, NI, WM, WN, G; };
+struct ClCfg { int MI, NI, WM, WN, G, RW3; };   // RW3: weight ring depth (stages) of the 3x3 instantiation; 1x1: 3
 constexpr ClCfg kClCfgs[] = {
-    {4, 1, 1, 4, 4},   // 16: 128 px x 128 co   (C_out >= 128)
-    {2, 1, 1, 4, 4},   // 17:  64 px x 128 co   (small maps)
-    {2, 2, 1, 4, 4},   // 18:  64 px x 256 co   (C_out = 256 on 32^2 maps: the activation tile is staged once for all couts)
-    {4, 1, 2, 2, 4},   // 19: 256 px x  64 co   (C_out = 64, big maps)
-    {2, 1, 2, 2, 4},   // 20: 128 px x  64 co
-    {1, 1, 2, 2, 4},   // 21:  64 px x  64 co
-    {2, 1, 4, 1, 4},   // 22: 256 px x  32 co   (C_out = 32)
-    {1, 1, 4, 1, 4},   // 23: 128 px x  32 co
-    {4, 1, 1, 4, 8},   // 24: 128 px x 128 co, 64-channel chunks (1x1 only)
-    {2, 1, 1, 4, 8},   // 25:  64 px x 128 co, 64-channel chunks (1x1 only)
-    {4, 1, 2, 2, 8},   // 26: 256 px x  64 co, 64-channel chunks (1x1 only)
-    {2, 1, 4, 1, 8},   // 27: 256 px x  32 co, 64-channel chunks (1x1 only)
+    {4, 1, 1, 4, 4, 4},   // 16: 128 px x 128 co   (C_out >= 128)
+    {2, 1, 1, 4, 4, 4},   // 17:  64 px x 128 co   (small maps)
+    {2, 2, 1, 4, 4, 4},   // 18:  64 px x 256 co   (C_out = 256 on 32^2 maps: the activation tile is staged once for all couts)
+    {4, 1, 2, 2, 4, 4},   // 19: 256 px x  64 co   (C_out = 64, big maps)
+    {2, 1, 2, 2, 4, 4},   // 20: 128 px x  64 co
+    {1, 1, 2, 2, 4, 4},   // 21:  64 px x  64 co
+    {2, 1, 4, 1, 4, 4},   // 22: 256 px x  32 co   (C_out = 32)
+    {1, 1, 4, 1, 4, 4},   // 23: 128 px x  32 co
+    {4, 1, 1, 4, 8, 0},   // 24: 128 px x 128 co, 64-channel chunks (1x1 only)
+    {2, 1, 1, 4, 8, 0},   // 25:  64 px x 128 co, 64-channel chunks (1x1 only)
+    {4, 1, 2, 2, 8, 0},   // 26: 256 px x  64 co, 64-channel chunks (1x1 only)
+    {2, 1, 4, 1, 8, 0},   // 27: 256 px x  32 co, 64-channel chunks (1x1 only)
+    {4, 1, 1, 4, 4, 8},   // 28: 128 px x 128 co, weight ring 8 stages deep (one workgroup per CU: the 32^2 maps have no more anyway)
+    {2, 1, 1, 4, 4, 8},   // 29:  64 px x 128 co, weight ring 8 stages deep
 };
 constexpr int kNumClCfgs = sizeof(kClCfgs) / sizeof(kClCfgs[0]);
 
-template <int MI, int NI, int WM, int WN, int G>
+template <int MI, int NI, int WM, int WN, int G, int RW3 = 4>
 int cl_launch_taps(const ImagenIgemmParams& p, hipStream_t s) {
-  if (p.KH == 1 && p.KW == 1) return cl_launch<MI, NI, WM, WN, G, 1>(p, s);
+  if (p.KH == 1 && p.KW == 1) return cl_launch<MI, NI, WM, WN, G, 1, 3>(p, s);
   if constexpr (G == 4) {
-    if (p.KH == 3 && p.KW == 3) return cl_launch<MI, NI, WM, WN, G, 9>(p, s);
+    if (p.KH == 3 && p.KW == 3) return cl_launch<MI, NI, WM, WN, G, 9, RW3>(p, s);
   }
   imagen_set_error("conv_lds: cfg %d supports 1x1%s kernels only (got %dx%d)", p.cfg, G == 4 ? " / 3x3" : "", p.KH, p.KW);
   return -1;
@@ -632,7 +468,7 @@ long imagen_conv_lds_lds_bytes(int idx, int KH, int KW, int TH, int TW) {
   const int ITW = TW - 1 + KW, ITH = TH - 1 + KH;
   if (ITW * ITH * c.G > slots * 256) return -1;
   const int PS = c.G * 16 + 16;
-  const long lds = 2L * ITH * cl_row_pitch(TW, ITW, PS) + 4L * cl_ring(KH * KW) * (c.NI * c.G * 512) + 4L * 32 * c.MI * 4 + 16;
+  const long lds = 2L * ITH * cl_row_pitch(TW, ITW, PS) + 4L * (KH * KW == 9 ? c.RW3 : 3) * (c.NI * c.G * 512) + 4L * 32 * c.MI * 4 + 16;
   return lds <= 160 * 1024 ? lds : -1;
 }
 
@@ -651,6 +487,8 @@ int launch_conv_lds(const ImagenIgemmParams* pp, int idx, hipStream_t s) {
     case 9: return cl_launch_taps<2, 1, 1, 4, 8>(p, s);
     case 10: return cl_launch_taps<4, 1, 2, 2, 8>(p, s);
     case 11: return cl_launch_taps<2, 1, 4, 1, 8>(p, s);
+    case 12: return cl_launch_taps<4, 1, 1, 4, 4, 8>(p, s);
+    case 13: return cl_launch_taps<2, 1, 1, 4, 4, 8>(p, s);
   }
   imagen_set_error("conv_lds: bad cfg index %d", idx);
   return -1;

@@ -1,6 +1,7 @@
 // elementwise.hip — the HBM-bound glue of the Imagen denoiser (statistics, gates, residuals, token
 // assembly, embeddings).  All kernels move 16 B per lane (8 fp16) with consecutive lanes on consecutive
 // addresses; reductions over a row use a power-of-two sub-group of the wave64 and __shfl_xor.
+#include <algorithm>
 #include "common.h"
 #include "gca_device.h"
 
@@ -522,6 +523,63 @@ int host_lpr(int groups) {
   return l;
 }
 
+// ------------------------------------------------------------------------------------------------ act_prep
+// one lane = 8 channels (16 B) of one pixel, U items per thread in flight (the pass is a pure latency chain otherwise); the per-pixel
+// statistics and the per-(batch, channel) affine are L2-resident
+__global__ __launch_bounds__(256) void act_prep_kernel(const ImagenActPrepParams p) {
+  constexpr int U = 4;
+  const int gpp = (p.C1 + p.C2) >> 3;                    // 8-channel groups per pixel
+  const long total = (long)p.rows * gpp;
+  const f16* x1 = reinterpret_cast<const f16*>(p.x1);
+  const f16* x2 = reinterpret_cast<const f16*>(p.x2);
+  f16* y = reinterpret_cast<f16*>(p.y);
+  const long stride = (long)gridDim.x * 256;
+  for (long i0 = (long)blockIdx.x * 256 + threadIdx.x; i0 < total; i0 += stride * U) {
+    f16x8 in[U];
+    float rs[U], mu[U], qb[U];
+    float4 a0[U], a1[U], s0[U], s1[U];
+    f16* dst[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const long i = i0 + u * stride;
+      const bool ok = i < total;
+      const long ii = ok ? i : 0;
+      const int r = (int)(ii / gpp), g = (int)(ii - (long)r * gpp);
+      const int b = r / p.rows_per_batch, rr = r - b * p.rows_per_batch;
+      const int c0 = g * 8;
+      const f16* src = c0 < p.C1 ? x1 + (size_t)b * p.bs1 + (size_t)rr * p.ld1 + c0 : x2 + (size_t)b * p.bs2 + (size_t)rr * p.ld2 + (c0 - p.C1);
+      in[u] = *reinterpret_cast<const f16x8*>(src);
+      rs[u] = p.rs ? p.rs[r] : (p.ssq_a ? p.ssq_a[r] : 1.0f);
+      qb[u] = (!p.rs && p.ssq_b) ? p.ssq_b[r] : 0.0f;
+      mu[u] = p.mu ? p.mu[r] : 0.0f;
+      const float* pa = p.pa ? p.pa + (size_t)b * p.pstride + c0 : nullptr;
+      const float* ps = p.ps ? p.ps + (size_t)b * p.pstride + c0 : nullptr;
+      a0[u] = pa ? *reinterpret_cast<const float4*>(pa) : make_float4(1.f, 1.f, 1.f, 1.f);
+      a1[u] = pa ? *reinterpret_cast<const float4*>(pa + 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+      s0[u] = ps ? *reinterpret_cast<const float4*>(ps) : make_float4(0.f, 0.f, 0.f, 0.f);
+      s1[u] = ps ? *reinterpret_cast<const float4*>(ps + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+      dst[u] = ok ? y + (size_t)b * p.bsy + (size_t)rr * p.ldy + c0 : nullptr;
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      if (!dst[u]) continue;
+      float sc = rs[u];
+      if (!p.rs && p.ssq_a) sc = __builtin_amdgcn_rsqf(fmaxf(rs[u] + p.ssq_wb * qb[u], 1e-24f));
+      const float a[8] = {a0[u].x, a0[u].y, a0[u].z, a0[u].w, a1[u].x, a1[u].y, a1[u].z, a1[u].w};
+      const float sh[8] = {s0[u].x, s0[u].y, s0[u].z, s0[u].w, s1[u].x, s1[u].y, s1[u].z, s1[u].w};
+      f16x8 out;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float v = ((float)in[u][j] - mu[u]) * sc * a[j] + sh[j];
+        if (p.act_in == IMAGEN_ACT_SILU) v = silu_f(v);
+        else if (p.act_in == IMAGEN_ACT_GELU) v = gelu_f(v);
+        out[j] = (f16)v;
+      }
+      *reinterpret_cast<f16x8*>(dst[u]) = out;
+    }
+  }
+}
+
 }  // namespace
 
 int launch_rowstat(const ImagenRowstatParams* p, hipStream_t s) {
@@ -636,4 +694,14 @@ int launch_memset32(const ImagenMemset32Params* p, hipStream_t s) {
   hipLaunchKernelGGL(memset32_kernel, dim3((p->count + 255) / 256), dim3(256), 0, s, reinterpret_cast<uint32_t*>(p->dst), p->value,
                      p->count);
   return imagen_hip_status("memset32");
+}
+
+int launch_act_prep(const ImagenActPrepParams* p, hipStream_t s) {
+  IMAGEN_CHECK(p->x1 && p->y && p->rows > 0 && p->rows_per_batch > 0, "act_prep: null x1/y or empty problem");
+  IMAGEN_CHECK(p->C1 % 8 == 0 && p->C2 % 8 == 0 && p->ld1 % 8 == 0 && p->ldy % 8 == 0 && (!p->x2 || p->ld2 % 8 == 0) && (p->x2 || p->C2 == 0),
+               "act_prep: channel counts / strides must be multiples of 8 (C1=%d C2=%d ld1=%d ld2=%d ldy=%d)", p->C1, p->C2, p->ld1, p->ld2, p->ldy);
+  const long total = (long)p->rows * ((p->C1 + p->C2) >> 3);
+  const int blocks = (int)std::min<long>((total + 1023) / 1024, 256L * 8);   // 4 items per thread and pass
+  hipLaunchKernelGGL(act_prep_kernel, dim3(blocks), dim3(256), 0, s, *p);
+  return imagen_hip_status("act_prep");
 }

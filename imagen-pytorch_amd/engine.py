@@ -92,6 +92,9 @@ def _fingerprint(unet) -> tuple:
 
 
 POST_NORM = int(os.environ.get("IMAGEN_POST_NORM", "1"))   # A/B switch: block2's prologue applied by block1's epilogue
+# ACT_PREP + all-DMA conv for the Blocks with at least this many output channels (the MFMA-bound layers: the prologue pass costs one
+# read + one write of the input, the conv kernel drops its staging instruction stream); 0 = never
+ACT_PREP_MIN_COUT = int(os.environ.get("IMAGEN_ACT_PREP_MIN_COUT", "128"))
 KV_BATCH = int(os.environ.get("IMAGEN_KV_BATCH", "1"))     # A/B switch: one launch for the context K/V rows of all attention sites
 
 
@@ -353,8 +356,14 @@ class UnetEngine:
         # without a cross-attention in between, block1's epilogue applies block2's ChanRMSNorm -> (scale+1, shift) -> SiLU itself
         # (its consumer waves have the slack; block2's producers then stage h1 with no arithmetic at all)
         post = dict(pa=pa2, ps=ps2, pstride=self.total_c) if (rb.cross_attn is None and POST_NORM) else None
-        op = ops.igemm(plan, x, w1, h1, x2=skip, ssq_a=sx, ssq_b=ss, ssq_wb=s * s, pa=pa1, pstride=0, act_in=ACT_SILU, ssq_out=h1.ssq,
-                       post=post, label=name + ".block1")
+        prep = ops.CONV_DMA and ACT_PREP_MIN_COUT > 0 and Cout >= ACT_PREP_MIN_COUT and Cin % 32 == 0 and Cout % 32 == 0
+        if prep:   # MFMA-bound layer: the prologue as its own pass, then the all-DMA conv on the activated concat
+            xa = self.new(R, H, Wd, Cin)
+            ops.act_prep(plan, x, xa, x2=skip, ssq_a=sx, ssq_b=ss, ssq_wb=s * s, pa=pa1, pstride=0, act_in=ACT_SILU, label=name + ".block1.prep")
+            op = ops.igemm(plan, xa, w1, h1, ssq_out=h1.ssq, post=post, label=name + ".block1")
+        else:
+            op = ops.igemm(plan, x, w1, h1, x2=skip, ssq_a=sx, ssq_b=ss, ssq_wb=s * s, pa=pa1, pstride=0, act_in=ACT_SILU, ssq_out=h1.ssq,
+                           post=post, label=name + ".block1")
         if not op.ssq_emitted:
             h1.ssq = None
         if rb.cross_attn is not None:
@@ -371,17 +380,27 @@ class UnetEngine:
                             b1=W.f32(name + ".gca.b1", lambda: g.net[0].bias),
                             w2t=W.f32(name + ".gca.w2t", lambda: g.net[2].weight.reshape(Cout, hidden).t()),
                             b2=W.f32(name + ".gca.b2", lambda: g.net[2].bias), gate=gate)
+        gca_ep = dict(wk=gca_args["wk"], bk=gca_args["bk"]) if rb.gca is not None else None   # GlobalContext partials from block2's epilogue
         if op.post_applied:     # h1 already holds silu(norm(h1) * (scale + 1) + shift)
-            ops.igemm(plan, h1, W.conv(name + ".block2", rb.block2.project), h2, label=name + ".block2")
+            op2 = ops.igemm(plan, h1, W.conv(name + ".block2", rb.block2.project), h2, gca=gca_ep, label=name + ".block2")
         else:                   # block2: ChanRMSNorm -> (scale+1, shift) from the time MLP -> SiLU -> conv3x3
             s1 = self._ssq_of(plan, h1, name + ".block2.stat")
-            ops.igemm(plan, h1, W.conv(name + ".block2", rb.block2.project), h2, ssq_a=s1, pa=pa2, ps=ps2, pstride=self.total_c,
-                      act_in=ACT_SILU, label=name + ".block2")
-        if rb.gca is not None:   # one launch: chunk partials + last-workgroup finalisation (measured faster than a conv-epilogue fusion)
-            chunks = ops.gca_chunks(H * Wd, R, Cout)
-            part = self.f32buf(R, chunks, Cout + 2)
-            ops.gca(plan, h2, gca_args["wk"], gca_args["bk"], gca_args["w1t"], gca_args["b1"], gca_args["w2t"], gca_args["b2"], part, gate,
-                    chunks, label=name + ".gca")
+            if prep:
+                ha = self.new(R, H, Wd, Cout)
+                ops.act_prep(plan, h1, ha, ssq_a=s1, pa=pa2, ps=ps2, pstride=self.total_c, act_in=ACT_SILU, label=name + ".block2.prep")
+                op2 = ops.igemm(plan, ha, W.conv(name + ".block2", rb.block2.project), h2, gca=gca_ep, label=name + ".block2")
+            else:
+                op2 = ops.igemm(plan, h1, W.conv(name + ".block2", rb.block2.project), h2, ssq_a=s1, pa=pa2, ps=ps2, pstride=self.total_c,
+                                act_in=ACT_SILU, gca=gca_ep, label=name + ".block2")
+        if rb.gca is not None:
+            if op2.gca_part_t is not None:   # the partials came out of block2's epilogue: only the merge + squeeze MLP is left
+                ops.gca_final(plan, op2.gca_part_t, gca_args["w1t"], gca_args["b1"], gca_args["w2t"], gca_args["b2"], gate, B=R, C=Cout,
+                              chunks=op2.gca_chunks, label=name + ".gca")
+            else:                            # stand-alone pass over h2 (+ in-kernel finalisation where one workgroup covers the image)
+                chunks = ops.gca_chunks(H * Wd, R, Cout)
+                part = self.f32buf(R, chunks, Cout + 2)
+                ops.gca(plan, h2, gca_args["wk"], gca_args["bk"], gca_args["w1t"], gca_args["b1"], gca_args["w2t"], gca_args["b2"], part, gate,
+                        chunks, label=name + ".gca")
         out = self.new(R, H, Wd, Cout)
         out.ssq = self.f32buf(R * H * Wd)
         if rb.res_conv is not None:

@@ -48,6 +48,25 @@ def current_stream_handle() -> int:
 
 
 # ------------------------------------------------------------------------------------------------ plan
+import os as _os0
+import re as _re0
+
+# IMAGEN_SKIP=<regex over "kind:label">: ops whose description matches are left out of every plan (IMAGEN_SKIP_NOOP=1: replaced by a
+# one-word fill, so the launch stays).  ONLY for tools/ablate_step.py: the wall-clock difference is the true in-graph cost of an op
+# class; results are garbage.  Unset in production.
+_SKIP_RE = _re0.compile(_os0.environ["IMAGEN_SKIP"]) if _os0.environ.get("IMAGEN_SKIP") else None
+_SKIP_NOOP = _os0.environ.get("IMAGEN_SKIP_NOOP") == "1"
+_KIND_NAME = {v: k.replace("IMAGEN_OP_", "").lower() for k, v in ENUMS.items() if k.startswith("IMAGEN_OP_") and k != "IMAGEN_OP_KIND_COUNT"}
+_SKIP_SCRATCH = {}
+
+
+def _skip_scratch(keep):
+    dev = next((k.device for k in keep if isinstance(k, torch.Tensor)), torch.device("cpu"))
+    if dev not in _SKIP_SCRATCH:
+        _SKIP_SCRATCH[dev] = torch.zeros(4, dtype=torch.int32, device=dev)
+    return _SKIP_SCRATCH[dev]
+
+
 
 class Plan:
     """Ordered list of kernel launches with their params structs (kept alive here)."""
@@ -60,6 +79,15 @@ class Plan:
 
     def add(self, struct, label: str = "", keep: Sequence = ()):
         kind = _abi.STRUCT_KIND[type(struct)]
+        if _SKIP_RE is not None and _SKIP_RE.search(f"{_KIND_NAME.get(kind, kind)}:{label}"):
+            # timing ablation (tools/ablate_step.py): the op is dropped, or replaced by a one-word fill so that the launch itself stays
+            self.keep.extend(k for k in keep if k is not None)
+            if _SKIP_NOOP:
+                m = STRUCTS["ImagenMemset32Params"]()
+                m.dst, m.value, m.count = _skip_scratch(keep).data_ptr(), 0, 1
+                self.ops.append((_abi.STRUCT_KIND[type(m)], m, "noop:" + label))
+                self._arr = None
+            return struct
         self.ops.append((kind, struct, label))
         self.keep.extend(k for k in keep if k is not None)
         self._arr = None
@@ -270,12 +298,60 @@ def launchable_shapes(cfg: int, OH: int, OW: int, KH: int, KW: int, stride: int)
     return sorted(out)
 
 
-CONV_LDS = int(_os.environ.get("IMAGEN_CONV_LDS", "1"))             # A/B switch: the LDS-staged kernel family for 3x3 convs
+CONV_LDS = int(_os.environ.get("IMAGEN_CONV_LDS", "0"))             # A/B switch: the LDS-staged kernel family (in-kernel prologue) for 3x3 convs
+GCA_IN_EPILOGUE = int(_os.environ.get("IMAGEN_GCA_IN_EPILOGUE", "1"))   # A/B switch: GlobalContext partials from the producing conv's epilogue
+CONV_DMA = int(_os.environ.get("IMAGEN_CONV_DMA", "1"))             # A/B switch: the all-DMA kernel family for prologue-free single-input 3x3 convs
 CONV_LDS_1X1 = int(_os.environ.get("IMAGEN_CONV_LDS_1X1", "0"))     # ... and for 1x1 convs / linears
 
 
+def _pick_dma(Cout: int, OH: int, OW: int, B: int, full_cout: bool):
+    """All-DMA family (conv_dma.hip): fixed tile shape per cfg.  Preference by (tile pixels, tile couts, ring depth), first launchable
+    entry wins; the deep rings go to the layers with at most ~2 workgroups per CU (nothing else hides the weight latency there)."""
+    tab = cfg_table()
+    lib = load_library()
+    cand = {}
+    for i, (tp, bn, g, fam) in enumerate(tab):
+        if fam != 2:
+            continue
+        sh = launchable_shapes(i, OH, OW, 3, 3, 1)
+        if sh:
+            cand[(tp, bn, lib.imagen_igemm_config_ring(i))] = (i, sh[0])
+
+    def wgs(tp, bn):
+        k = next((k for k in cand if k[0] == tp and k[1] == bn), None)
+        return B * cand[k][1][0] * math.ceil(Cout / bn) if k else 0
+
+    if Cout > 128:   # (one tile over all 256 couts only where the epilogue needs them: post_pa / ssq_out — and the map is large enough)
+        order = [(64, 256, 3), (64, 256, 6)] if full_cout and wgs(64, 256) >= 128 else []
+        order += [(128, 128, 3), (128, 128, 6)] if wgs(128, 128) >= 256 else []
+        order += [(64, 128, 6), (64, 128, 3)] if wgs(64, 128) >= 128 else []
+        order += [(64, 64, 6), (64, 128, 6), (64, 256, 3)]
+    elif Cout > 64:
+        if wgs(128, 128) >= 512:
+            order = [(128, 128, 3), (128, 128, 6)]
+        elif wgs(128, 128) >= 256:
+            order = [(128, 128, 6), (128, 128, 3)]
+        else:
+            order = []
+        order += [(64, 128, 6), (64, 128, 3)] if wgs(64, 128) >= 128 or full_cout else []
+        order += [(64, 64, 6), (64, 128, 6)]
+    elif Cout > 32:
+        order = [(256, 64, 3)] if wgs(256, 64) >= 1024 else []
+        order += [(128, 64, 3 if wgs(128, 64) >= 1024 else 6)] if wgs(128, 64) >= 256 else []
+        order += [(64, 64, 6), (128, 64, 6), (128, 64, 3)]
+    else:
+        order = [(256, 32, 3)] if wgs(256, 32) >= 1024 else []
+        order += [(128, 32, 3), (256, 32, 3)]
+    small = full_cout and all(key[1] < Cout for key in order[:1])   # the wide tile was skipped on a small map: the caller falls back
+    for key in order:
+        if key in cand and (not full_cout or small or key[1] >= Cout):
+            i, (_, _, th, tw) = cand[key]
+            return i, th, tw
+    return None
+
+
 def pick_cfg(G: int, Cout: int, OH: int, OW: int, B: int, KH: int = 1, KW: int = 1, stride: int = 1, full_cout: bool = False,
-             family: Optional[int] = None):
+             family: Optional[int] = None, raw: bool = False):
     """Choose (cfg, TH, TW).
 
     Family 1 (LDS-staged kernel, conv_lds.hip) takes the stride-1 3x3 convs with 32-channel chunks (and, behind a switch, 1x1):
@@ -292,6 +368,11 @@ def pick_cfg(G: int, Cout: int, OH: int, OW: int, B: int, KH: int = 1, KW: int =
     tiles narrower than Cout are then only used when nothing wider exists.  Among the tile shapes of the chosen
     configuration: least padded pixels, then the fewest staged halo pixels."""
     tab = cfg_table()
+    if raw and CONV_DMA and stride == 1 and KH == 3 and KW == 3 and G == 4 and family in (None, 2):
+        got = _pick_dma(Cout, OH, OW, B, full_cout)
+        if got is not None:
+            return got
+    assert family != 2, "no all-DMA tile configuration for this layer"
     want1 = stride == 1 and G in (4, 8) and ((KH == 3 and KW == 3 and G == 4 and CONV_LDS) or (KH == 1 and KW == 1 and CONV_LDS_1X1))
     fams = [family] if family is not None else ([1, 0] if want1 else [0])
     for fam in fams:
@@ -339,7 +420,7 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
           pstride: int = 0, act_in: int = ACT_NONE, act_out: int = ACT_NONE, addend: Optional[Act] = None, gate=None,
           res: Optional[Act] = None, out_mode: int = OUT_NHWC, stride: int = 1, pad: Optional[int] = None,
           cfg: Optional[tuple] = None, ssq_a=None, ssq_b=None, ssq_wb: float = 1.0, ssq_out=None, post: Optional[dict] = None,
-          label: str = ""):
+          gca: Optional[dict] = None, label: str = ""):
     """... ssq_a / ssq_b: producers' per-pixel sums of squares of x1 / x2 (ChanRMSNorm statistics without a separate pass);
     ssq_out: emit the per-pixel sum of squares of the output — honoured only when the chosen tile covers all Cout
     (`p.ssq_emitted` tells the caller, who otherwise falls back to a ROWSTAT op)."""
@@ -352,8 +433,12 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
     OW = (W + 2 * pad - KW) // stride + 1
     C2 = x2.C if x2 is not None else 0
     assert x1.C + C2 == pw.Cin, f"{label}: input channels {x1.C}+{C2} != weight Cin {pw.Cin}"
+    want_gca = gca is not None and GCA_IN_EPILOGUE and out_mode == OUT_NHWC and act_out == ACT_NONE and addend is None and res is None and post is None
     if cfg is None:
-        cfg = pick_cfg(pw.G, pw.Cout, OH, OW, x1.B, KH, KW, stride, full_cout=(ssq_out is not None or post is not None) and out_mode == OUT_NHWC)
+        raw = (x2 is None and mu is None and rs is None and pa is None and ps is None and ssq_a is None and act_in == ACT_NONE
+               and x1.C % 32 == 0 and pw.Cin_pad == x1.C and x1.ld % 8 == 0)
+        cfg = pick_cfg(pw.G, pw.Cout, OH, OW, x1.B, KH, KW, stride,
+                       full_cout=(ssq_out is not None or post is not None or want_gca) and out_mode == OUT_NHWC, raw=raw)
     cid, th, tw = cfg
     p = STRUCTS["ImagenIgemmParams"]()
     p.x1, p.C1, p.ld1, p.bs1 = x1.ptr, x1.C, x1.ld, x1.bs
@@ -409,6 +494,15 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
         p.ssq_out = ssq_out.data_ptr()
         keep.append(ssq_out)
         emitted = True
+    # gca: dict(wk=fp32 [Cout], bk=float): GlobalContext partials of the output from the epilogue (kernel families 1 / 2, one tile over
+    # all Cout); `p.gca_part_t` ([B, chunks, Cout + 2], chunks = tiles per image = `p.gca_chunks`) then feeds GCA_FINAL directly
+    p.gca_part_t, p.gca_chunks = None, 0
+    if want_gca and cfg_table()[cid][3] in (1, 2) and pw.Cout <= cfg_table()[cid][1]:
+        chunks = math.ceil(OH / th) * math.ceil(OW / tw)
+        part = torch.empty(x1.B, chunks, pw.Cout + 2, dtype=torch.float32, device=x1.t.device)
+        p.gca_wk, p.gca_part, p.gca_bk = gca["wk"].data_ptr(), part.data_ptr(), gca["bk"]
+        keep += [gca["wk"], part]
+        p.gca_part_t, p.gca_chunks = part, chunks
     plan.add(p, label or "igemm", keep)
     p.ssq_emitted = emitted
     p.post_applied = posted
@@ -416,6 +510,25 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
 
 
 # ------------------------------------------------------------------------------------------------ small ops
+
+def act_prep(plan: Plan, x1: Act, y: Act, *, x2: Optional[Act] = None, mu=None, rs=None, pa=None, ps=None, pstride: int = 0,
+             act_in: int = ACT_NONE, ssq_a=None, ssq_b=None, ssq_wb: float = 1.0, label: str = ""):
+    """The IGEMM prologue as its own pass: y = fp16(act_in((concat(x1, x2) - mu) * rs * pa + ps)) (ImagenActPrepParams)."""
+    p = STRUCTS["ImagenActPrepParams"]()
+    C2 = x2.C if x2 is not None else 0
+    assert y.C == x1.C + C2 and (y.B, y.H * y.W) == (x1.B, x1.H * x1.W)
+    p.x1, p.C1, p.ld1, p.bs1 = x1.ptr, x1.C, x1.ld, x1.bs
+    if x2 is not None:
+        assert (x2.B, x2.H, x2.W) == (x1.B, x1.H, x1.W)
+        p.x2, p.C2, p.ld2, p.bs2 = x2.ptr, x2.C, x2.ld, x2.bs
+    p.mu, p.rs, p.pa, p.ps = ptr(mu), ptr(rs), ptr(pa), ptr(ps)
+    p.ssq_a, p.ssq_b, p.ssq_wb = ptr(ssq_a), ptr(ssq_b), ssq_wb
+    p.y, p.ldy, p.bsy = y.ptr, y.ld, y.bs
+    p.rows, p.rows_per_batch = x1.rows, x1.H * x1.W
+    p.pstride, p.act_in = pstride, act_in
+    plan.add(p, label or "act_prep", [x1.t, x2.t if x2 is not None else None, mu, rs, pa, ps, ssq_a, ssq_b, y.t])
+    return p
+
 
 def rowstat(plan: Plan, x1: Act, *, mode: int, rs: torch.Tensor, mu: Optional[torch.Tensor] = None, x2: Optional[Act] = None,
             w2: float = 1.0, eps: float = 1e-5, label: str = ""):
@@ -488,6 +601,15 @@ def qnorm(plan: Plan, q: torch.Tensor, q_scale: torch.Tensor, *, rows, heads, ld
     p.q, p.q_scale, p.rows, p.heads, p.ld, p.mult = q.data_ptr(), q_scale.data_ptr(), rows, heads, ld, mult
     plan.add(p, label or "qnorm", [q, q_scale])
     return p
+
+
+def gca_final(plan: Plan, part: torch.Tensor, w1t, b1, w2t, b2, gate: torch.Tensor, *, B: int, C: int, chunks: int, label: str = ""):
+    """GCA_FINAL alone: merge `chunks` partial rows per image (from GCA_PARTIAL or from a conv epilogue) and run the squeeze MLP."""
+    f = STRUCTS["ImagenGcaFinalParams"]()
+    f.part, f.w1t, f.b1, f.w2t, f.b2, f.gate = part.data_ptr(), w1t.data_ptr(), b1.data_ptr(), w2t.data_ptr(), b2.data_ptr(), gate.data_ptr()
+    f.B, f.C, f.hidden, f.chunks = B, C, w1t.shape[1], chunks
+    plan.add(f, (label or "gca") + ".final", [part, w1t, b1, w2t, b2, gate])
+    return f
 
 
 def gca(plan: Plan, h: Act, wk, bk: float, w1t, b1, w2t, b2, part: torch.Tensor, gate: torch.Tensor, chunks: int, label: str = ""):

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define IMAGEN_ABI_VERSION 1
+#define IMAGEN_ABI_VERSION 2
 
 typedef void* imagen_stream_t; /* hipStream_t */
 
@@ -61,7 +61,8 @@ enum ImagenOpKind {
   IMAGEN_OP_KV_PREP_MULTI = 23, /* several KV_PREP jobs (one per attention site) in ONE launch                         */
   IMAGEN_OP_TEMPORAL_PEG = 24,  /* Imagen-Video: depthwise causal conv over 3 frames + residual                        */
   IMAGEN_OP_TEMPORAL_ATTENTION = 25, /* Imagen-Video: per-pixel causal attention over the frames, with a bias table    */
-  IMAGEN_OP_KIND_COUNT = 26
+  IMAGEN_OP_ACT_PREP = 26,     /* the IGEMM prologue as its own pass: norm -> affine -> SiLU of a (two-tensor) input, written as fp16 */
+  IMAGEN_OP_KIND_COUNT = 27
 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -103,6 +104,11 @@ typedef struct ImagenIgemmParams {
    * pixel (ChanRMSNorm -> scale/shift -> SiLU of the NEXT Block, ip.py:671-691, applied by the producer so that the consuming
    * conv stages its input with no arithmetic at all) */
   const float* post_pa; const float* post_ps;
+  /* optional GlobalContext partials of the OUTPUT (plain NHWC mode, Cout <= tile couts, kernel families 1 and 2): with
+   * logit[q] = y[q, :] . gca_wk + gca_bk (ip.py:965-966), every output tile writes (max logit, sum exp, sum exp * y[q, c]) over its
+   * pixels to gca_part[b][tile][Cout + 2] (tile = ty * tilesX + tx): exactly the rows GCA_PARTIAL produces with chunks = tiles per
+   * image, ready for GCA_FINAL — the separate pass over the tensor disappears. */
+  const float* gca_wk; float* gca_part;
   int32_t B, H, W;     /* input batch / spatial dims */
   int32_t C1, ld1, bs1; /* channels, pixel stride, batch stride (elements) of x1 */
   int32_t C2, ld2, bs2;
@@ -122,7 +128,22 @@ typedef struct ImagenIgemmParams {
   int32_t dbg;         /* ablation switches for tools/igemm_probe.py (0 in production): 1 = skip restaging after chunk 0, 2 = skip MFMAs,
                         * 8 = skip stores, 16 = skip activation loads, 32 = one tile per workgroup (no persistence), 64 = no XCD tile ranges */
   float ssq_wb;        /* weight of ssq_b (skip_connect_scale^2 for the concatenated skip tensor) */
+  float gca_bk;        /* bias of the GlobalContext logit (to_k.bias) */
 } ImagenIgemmParams;
+
+/* ACT_PREP — the IGEMM prologue (Block: ChanRMSNorm -> scale/shift -> SiLU, ip.py:683-690) materialised once:
+ *   y[p, c] = fp16( act_in( (concat(x1, x2)[p, c] - mu[p]) * rs[p] * pa[b, c] + ps[b, c] ) )      rs from ssq_a (+ ssq_wb * ssq_b) when rs == NULL
+ * Used in front of the all-DMA conv kernel family (csrc/conv_dma.hip), which copies its input global -> LDS without touching it, for
+ * the MFMA-bound layers (C >= 128): the activation is then computed once per element instead of once per staging workgroup
+ * (halo overlap x output-channel tiles = 2.8x on the 384 -> 256 convs) and leaves the conv's instruction stream. */
+typedef struct ImagenActPrepParams {
+  const void* x1; const void* x2; const float* mu; const float* rs; const float* pa; const float* ps;
+  const float* ssq_a; const float* ssq_b; void* y;
+  int32_t rows, rows_per_batch;   /* pixels in total / per batch element */
+  int32_t C1, ld1, bs1, C2, ld2, bs2;
+  int32_t ldy, bsy, pstride, act_in;
+  float ssq_wb;
+} ImagenActPrepParams;
 
 /* ROWSTAT — replaces the reductions inside ChanRMSNorm (ip.py:322-329) and LayerNorm (ip.py:331-349,
  * nn.LayerNorm).  mode 0: rs = 1/max(sqrt(ssq1 + w2*ssq2), 1e-12), mu untouched.
@@ -358,8 +379,10 @@ int imagen_igemm_config_info(int cfg, int* tile_pixels, int* tile_cout, int* kgr
  * halo_pixels * G <= slots * 256 */
 int imagen_igemm_stage_slots(int cfg, int KH, int KW);
 /* kernel family of a tile cfg: 0 = wave-specialised persistent kernel (weights streamed from L2 per wave; every kernel size and
- * stride), 1 = LDS-staged kernel (both MFMA operands through LDS, weights by direct-to-LDS loads; 1x1 and 3x3, stride 1). */
+ * stride), 1 = LDS-staged kernel (both MFMA operands through LDS, weights by direct-to-LDS loads; 1x1 and 3x3, stride 1),
+ * 2 = all-DMA kernel (3x3 stride 1, one input tensor, NO prologue: both operands by direct-to-LDS loads; fixed tile shape per cfg). */
 int imagen_igemm_config_family(int cfg);
+int imagen_igemm_config_ring(int cfg);   /* weight look-ahead ring depth in stages (family 2; 0 for the others) */
 /* dynamic LDS bytes of a launch of `cfg` with a KHxKW kernel at `stride` and a THxTW output tile; -1 = not launchable */
 long imagen_igemm_lds_bytes(int cfg, int KH, int KW, int stride, int TH, int TW);
 /* Host-side pack: w_in fp32 [Cout][Cin][KH][KW] (Conv2d / Linear layout, HOST memory) -> packed fp16 (HOST memory)

@@ -31,7 +31,8 @@ DEFAULTS = dict(B=2, H=16, W=16, C1=32, C2=0, Cout=32, K=3, stride=1, pad=None, 
                 prologue="rs",      # none | rs | ssq | ln  (ln = mu + rs, LayerNorm statistics)
                 affine=True,        # per-(batch, channel) pa / ps
                 act_in="silu", act_out="none", epilogue="plain",   # plain | post | addend | res | shuffle | nchw
-                ssq_out=False, bias=True, seed=0)
+                ssq_out=False, bias=True, seed=0,
+                gca=False)          # GlobalContext partials of the output from the epilogue (families 1 / 2, plain output, one cout tile)
 
 
 def run_case(ops, dev, **kw):
@@ -135,6 +136,9 @@ def run_case(ops, dev, **kw):
         y = ops.new_act(B, OH, OW, Cout, dev)
     if ep != "nchw":
         y.t.fill_(float("nan"))
+    if c["gca"]:
+        wk_ref, bk_ref = rn(Cout) * 0.3, 0.1
+        kwargs["gca"] = dict(wk=wk_ref.to(dev), bk=bk_ref)
     plan = ops.Plan("case")
     p = ops.igemm(plan, a1, pw, y, x2=a2, stride=stride, pad=pad, cfg=c["cfg"], **kwargs)
     if ep == "post":
@@ -147,4 +151,12 @@ def run_case(ops, dev, **kw):
     out = dict(err=nerr(got, ref), cfg=(p.cfg, p.TH, p.TW))
     if c["ssq_out"]:
         out["err_ssq"] = nerr(ssq_t, ref_ssq)
+    if c["gca"]:
+        assert p.gca_part_t is not None, "GlobalContext partials were not emitted (family 0 cfg or tile narrower than Cout?)"
+        hq = h16(v).permute(0, 2, 3, 1).reshape(B, OH * OW, Cout)
+        ctx_ref = torch.einsum("bn,bnc->bc", (hq @ wk_ref + bk_ref).softmax(-1), hq)
+        rows = p.gca_part_t.cpu()
+        w = torch.exp(rows[:, :, 0] - rows[:, :, 0].max(dim=1, keepdim=True).values)
+        ctx = torch.einsum("bk,bkc->bc", w, rows[:, :, 2:]) / (w * rows[:, :, 1]).sum(1, keepdim=True)
+        out["err_gca"] = nerr(ctx, ctx_ref)
     return out

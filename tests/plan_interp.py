@@ -77,6 +77,30 @@ class Interpreter:
             fn(self, p)
             self.trace.append(label)
 
+    # ------------------------------------------------------------------------------------------------ ACT_PREP
+    def act_prep(self, p):
+        m = self.mem
+        B, n = p.rows // p.rows_per_batch, p.rows_per_batch
+        x = m.strided(p.x1, f16, (B, n, p.C1), (p.bs1, p.ld1, 1)).float()
+        if p.x2:
+            x = torch.cat((x, m.strided(p.x2, f16, (B, n, p.C2), (p.bs2, p.ld2, 1)).float()), dim=-1)
+        C = x.shape[-1]
+        a = x
+        if p.mu:
+            a = a - m.view(p.mu, f32)[:p.rows].reshape(B, n, 1)
+        if p.rs:
+            a = a * m.view(p.rs, f32)[:p.rows].reshape(B, n, 1)
+        elif p.ssq_a:
+            ssq = m.view(p.ssq_a, f32)[:p.rows].clone()
+            if p.ssq_b:
+                ssq = ssq + p.ssq_wb * m.view(p.ssq_b, f32)[:p.rows]
+            a = a * (1.0 / ssq.sqrt().clamp(min=1e-12)).reshape(B, n, 1)
+        if p.pa:
+            a = a * m.strided(p.pa, f32, (B, C), (p.pstride, 1)).reshape(B, 1, C)
+        if p.ps:
+            a = a + m.strided(p.ps, f32, (B, C), (p.pstride, 1)).reshape(B, 1, C)
+        m.strided(p.y, f16, (B, n, C), (p.bsy, p.ldy, 1)).copy_(_act(a, p.act_in).half())
+
     # ------------------------------------------------------------------------------------------------ IGEMM
     def igemm(self, p):
         m = self.mem
@@ -138,6 +162,20 @@ class Interpreter:
             y.copy_(v.half())
             if p.ssq_out:
                 m.view(p.ssq_out, f32)[:B * OH * OW].copy_((v.half().float() ** 2).sum(-1).reshape(-1))
+            if p.gca_part:   # per output tile: (max logit, sum exp, sum exp * y) -> part[b][tile][Cout + 2]
+                hq = v.half().float()
+                wk = m.view(p.gca_wk, f32)[:Co]
+                ty, tx = -(-OH // p.TH), -(-OW // p.TW)
+                part = m.view(p.gca_part, f32)[:B * ty * tx * (Co + 2)].reshape(B, ty * tx, Co + 2)
+                for iy in range(ty):
+                    for ix in range(tx):
+                        t = hq[:, iy * p.TH:(iy + 1) * p.TH, ix * p.TW:(ix + 1) * p.TW, :].reshape(B, -1, Co)
+                        k = t @ wk + p.gca_bk
+                        mx = k.max(dim=1).values
+                        e = torch.exp(k - mx[:, None])
+                        part[:, iy * tx + ix, 0] = mx
+                        part[:, iy * tx + ix, 1] = e.sum(1)
+                        part[:, iy * tx + ix, 2:] = torch.einsum("bp,bpc->bc", e, t)
 
     # ------------------------------------------------------------------------------------------------ statistics / glue
     def _rows(self, addr, rows, rpb, C, ld, bs):
@@ -294,7 +332,12 @@ class Interpreter:
             self.gca_ctx[p.part] = ctx
 
     def gca_final(self, p):
-        ctx = self.gca_ctx.pop(p.part)
+        if p.part in self.gca_ctx:
+            ctx = self.gca_ctx.pop(p.part)
+        else:   # partial rows in memory (written by a conv epilogue): merge (max, sum exp, sum exp * h) over the chunks
+            rows = self.mem.view(p.part, f32)[:p.B * p.chunks * (p.C + 2)].reshape(p.B, p.chunks, p.C + 2)
+            w = torch.exp(rows[:, :, 0] - rows[:, :, 0].max(dim=1, keepdim=True).values)
+            ctx = torch.einsum("bk,bkc->bc", w, rows[:, :, 2:]) / (w * rows[:, :, 1]).sum(1, keepdim=True)
         self.mem.view(p.gate, f32)[:p.B * p.C].copy_(self._gca_gate(ctx, p.w1t, p.b1, p.w2t, p.b2, p.C, p.hidden).reshape(-1))
 
     # ------------------------------------------------------------------------------------------------ Imagen-Video ops
@@ -425,4 +468,5 @@ Interpreter.DISPATCH = {
     K["IMAGEN_OP_CFG_X0"]: Interpreter.cfg_x0, K["IMAGEN_OP_QUANTILE"]: Interpreter.quantile, K["IMAGEN_OP_DDPM_UPDATE"]: Interpreter.ddpm_update,
     K["IMAGEN_OP_LINCOMB"]: Interpreter.lincomb, K["IMAGEN_OP_LOWRES_PREP"]: Interpreter.lowres_prep,
     K["IMAGEN_OP_TEMPORAL_PEG"]: Interpreter.temporal_peg, K["IMAGEN_OP_TEMPORAL_ATTENTION"]: Interpreter.temporal_attention,
+    K["IMAGEN_OP_ACT_PREP"]: Interpreter.act_prep,
 }

@@ -63,7 +63,7 @@ def test_bench_descriptors_are_enumerable():
     descs = bench_descriptors()
     tab = ops.cfg_table()
     fams = {tab[d["cfg"][0]][3] for d, _, _ in descs}
-    assert len(descs) > 30 and fams == {0, 1}, (len(descs), fams)
+    assert len(descs) > 30 and 0 in fams and fams & {1, 2}, (len(descs), fams)
 
 
 @pytest.mark.gpu

@@ -33,7 +33,7 @@ def _num_cfgs():
 
         return len(o.cfg_table())
     except Exception:   # library not built yet: collection must still work
-        return 28
+        return 44
 
 
 NUM_CFGS = _num_cfgs()
@@ -48,8 +48,8 @@ def _shapes(ops, cfg, K, stride, H, W):
 def test_conv3x3_block_every_cfg_and_tile_shape(ops, dev, cfg):
     """Block conv (prologue rs * pa + ps -> SiLU, concat input, bias), plain NHWC output with ssq_out where one tile covers Cout."""
     tp, bn, G, fam = ops.cfg_table()[cfg]
-    if G not in (1, 4):
-        pytest.skip("3x3 convs use 8- or 32-channel chunks")
+    if G not in (1, 4) or fam == 2:
+        pytest.skip("3x3 convs with a prologue use 8- or 32-channel chunks of families 0 / 1")
     C1, C2 = (64, 32) if G == 4 else (16, 8)
     H, W = (40, 36) if tp >= 128 else (20, 24)
     shapes = _shapes(ops, cfg, 3, 1, H, W)
@@ -69,8 +69,8 @@ def test_conv3x3_raw_post_and_ssq_prologue_every_cfg(ops, dev, cfg):
     """The two fused forms of a ResnetBlock: conv1 with ssq statistics (ssq_a + wb * ssq_b over the concat) and the output-side
     Block prologue (post_pa); conv2 staging an already activated input with no arithmetic (prologue none)."""
     tp, bn, G, fam = ops.cfg_table()[cfg]
-    if G != 4:
-        pytest.skip("32-channel chunks only")
+    if G != 4 or fam == 2:
+        pytest.skip("32-channel chunks of families 0 / 1 only")
     H, W = (32, 48) if tp >= 128 else (16, 24)
     shapes = _shapes(ops, cfg, 3, 1, H, W)
     if not shapes:
@@ -79,8 +79,70 @@ def test_conv3x3_raw_post_and_ssq_prologue_every_cfg(ops, dev, cfg):
     Cout = bn
     r = run_case(ops, dev, B=2, H=H, W=W, C1=32, C2=32, Cout=Cout, K=3, G=G, cfg=(cfg, th, tw), prologue="ssq", affine=False, epilogue="post")
     assert r["err"] < TOL, ("ssq+post", cfg, r)
-    r = run_case(ops, dev, B=2, H=H, W=W, C1=64, C2=0, Cout=Cout, K=3, G=G, cfg=(cfg, th, tw), prologue="none", act_in="none")
-    assert r["err"] < TOL, ("raw", cfg, r)
+    r = run_case(ops, dev, B=2, H=H, W=W, C1=64, C2=0, Cout=Cout, K=3, G=G, cfg=(cfg, th, tw), prologue="none", act_in="none", gca=(fam == 1))
+    assert r["err"] < TOL and r.get("err_gca", 0.0) < 2e-3, ("raw", cfg, r)
+
+
+@pytest.mark.parametrize("cfg", range(NUM_CFGS))
+def test_conv_dma_every_cfg(ops, dev, cfg):
+    """The all-DMA family (csrc/conv_dma.hip): prologue-free single-input 3x3 convs; ragged image sizes (partial tiles, zero padding
+    from the zero page), 1-3 channel chunks (both chunk parities and the ring wrap), several output-channel tiles, every epilogue."""
+    tp, bn, G, fam = ops.cfg_table()[cfg]
+    if fam != 2:
+        pytest.skip("family 2 only")
+    H, W = (40, 36) if tp >= 128 else (20, 24)
+    (th, tw), = _shapes(ops, cfg, 3, 1, H, W)
+    raw = dict(prologue="none", act_in="none", K=3, G=4, cfg=(cfg, th, tw))
+    for Cin in (32, 64, 96):
+        r = run_case(ops, dev, B=2, H=H, W=W, C1=Cin, Cout=bn, ssq_out=True, gca=True, **raw)
+        assert r["err"] < TOL and r["err_ssq"] < 2e-3 and r["err_gca"] < 2e-3, (cfg, Cin, r)
+    r = run_case(ops, dev, B=2, H=H - 5, W=W - 3, C1=64, Cout=bn - 8, gca=True, **raw)   # ragged tiles, couts that do not fill the tile
+    assert r["err"] < TOL and r["err_gca"] < 2e-3, (cfg, "gca ragged", r)
+    r = run_case(ops, dev, B=3, H=H - 3, W=W + 5, C1=128, Cout=bn + 64 if bn >= 128 else 2 * bn + 32, **raw)
+    assert r["err"] < TOL, (cfg, "cout tiles", r)
+    for ep in ("post", "addend", "res"):
+        r = run_case(ops, dev, B=2, H=H, W=W, C1=64, Cout=bn, epilogue=ep, **raw)
+        assert r["err"] < TOL, (cfg, ep, r)
+    if bn <= 128:
+        r = run_case(ops, dev, B=2, H=H, W=W, C1=32, Cout=3, epilogue="nchw", **raw)
+        assert r["err"] < TOL, (cfg, "nchw", r)
+
+
+def test_act_prep(ops, dev):
+    """ACT_PREP: the Block prologue as its own pass (ssq statistics over a two-tensor concat, per-channel gain, SiLU; and the
+    LayerNorm form with a per-(batch, channel) affine) vs fp32 torch."""
+    import torch.nn.functional as F
+
+    torch.manual_seed(0)
+    B, H, W, C1, C2 = 2, 12, 20, 64, 32
+    x1, x2 = torch.randn(B, C1, H, W).half().float(), (torch.randn(B, C2, H, W) * 0.7).half().float()
+    wb = 0.5
+    g = 1 + 0.2 * torch.randn(C1 + C2)
+    q = (x1 * x1).sum(1, keepdim=True) + wb * (x2 * x2).sum(1, keepdim=True)
+    ref = F.silu(torch.cat((x1, x2), 1) / q.sqrt() * g.view(1, -1, 1, 1))
+    a1, a2 = ops.act_from_nchw(x1.to(dev)), ops.act_from_nchw(x2.to(dev))
+    y = ops.new_act(B, H, W, C1 + C2, dev)
+    plan = ops.Plan()
+    ops.act_prep(plan, a1, y, x2=a2, ssq_a=(x1 * x1).sum(1).reshape(-1).to(dev), ssq_b=(x2 * x2).sum(1).reshape(-1).to(dev), ssq_wb=wb,
+                 pa=g.to(dev), pstride=0, act_in=ops.ACT_SILU)
+    plan.run()
+    torch.cuda.synchronize()
+    assert nerr_(ops.act_to_nchw(y), ref) < 5e-4
+    xin = x1
+    mu, rs = xin.mean(1, keepdim=True), torch.rsqrt(xin.var(1, unbiased=False, keepdim=True) + 1e-5)
+    pa, ps = 1 + 0.2 * torch.randn(B, C1), 0.2 * torch.randn(B, C1)
+    ref = (xin - mu) * rs * pa.view(B, C1, 1, 1) + ps.view(B, C1, 1, 1)
+    y = ops.new_act(B, H, W, C1, dev)
+    plan = ops.Plan()
+    ops.act_prep(plan, a1, y, mu=mu.reshape(-1).contiguous().to(dev), rs=rs.reshape(-1).contiguous().to(dev), pa=pa.to(dev), ps=ps.to(dev), pstride=C1)
+    plan.run()
+    torch.cuda.synchronize()
+    assert nerr_(ops.act_to_nchw(y), ref) < 5e-4
+
+
+def nerr_(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return ((a - b).norm() / b.norm().clamp(min=1e-12)).item()
 
 
 @pytest.mark.parametrize("cfg", range(NUM_CFGS))

@@ -88,7 +88,7 @@ def run(name, B, H, W, C1, C2, Cout, K, variant, cfg=None, G=None):
     byts = (B * H * W * (C + Cout)) * 2
     return us, fl / us / 1e6, byts / us / 1e3, (p.cfg, p.TH, p.TW)
 
-def sweep(shapes, G_list=None):
+def sweep(shapes, G_list=None, variant="full"):
     """Every (cfg, tile shape) the launcher accepts, per shape and k-chunk depth G: the table pick_cfg() should reproduce."""
     import math
     tab = ops.cfg_table()
@@ -108,12 +108,12 @@ def sweep(shapes, G_list=None):
                     if bn > 32 and bn >= 2 * max(32, Cout):
                         continue
                     try:
-                        us, tf, gbs, _ = run(name, B, H, W, C1, C2, Cout, K, "full", cfg=(i, th, tw), G=G)
+                        us, tf, gbs, _ = run(name, B, H, W, C1, C2, Cout, K, variant, cfg=(i, th, tw), G=G)
                     except Exception as e:  # launcher refused the combination
                         continue
                     res.append((us, i, th, tw, tp, bn))
             res.sort()
-            pk = ops.pick_cfg(G, Cout, H, W, B, K, K, 1)
+            pk = ops.pick_cfg(G, Cout, H, W, B, K, K, 1, raw=(variant == "noprologue" and C2 == 0 and C % 32 == 0))
             best = " ".join(f"cfg{i}({tp}x{bn}) t{th}x{tw}:{us:.1f}" for us, i, th, tw, tp, bn in res[:6])
             best0 = [r for r in res if tab[r[1]][3] == 0][:1]
             best += "".join(f" | best family-0 cfg{i}({tp}x{bn}) t{th}x{tw}:{us:.1f}" for us, i, th, tw, tp, bn in best0)
@@ -166,9 +166,13 @@ if __name__ == "__main__":
         sel = args[1].split(",") if len(args) > 1 else None
         timeline([s_ for s_ in SHAPES + EXTRA_SHAPES if not sel or any(o in s_[0] for o in sel)])
         sys.exit(0)
-    if args and args[0] == "--sweep":
+    if args and args[0] in ("--sweep", "--sweep-raw"):
         sel = args[1].split(",") if len(args) > 1 else None
-        globals()["sweep"]([s_ for s_ in SHAPES + EXTRA_SHAPES if not sel or any(o in s_[0] for o in sel)])
+        raw = args[0] == "--sweep-raw"   # prologue-free single-input variant of every shape (the concat becomes one tensor): all three families
+        shp = [s_ for s_ in SHAPES + EXTRA_SHAPES if not sel or any(o in s_[0] for o in sel)]
+        if raw:
+            shp = [(n, B, H, W, C1 + C2, 0, Co, K) for n, B, H, W, C1, C2, Co, K in shp if K == 3]
+        globals()["sweep"](shp, variant="noprologue" if raw else "full")
         sys.exit(0)
     only = None
     if args and args[0].startswith("--only="):
