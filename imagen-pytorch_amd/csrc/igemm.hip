@@ -635,8 +635,7 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
         }
     } else {
     f16x4 outv[NI][4][MI];   // packed outputs (they take over the accumulators' registers as those die)
-    // gate + (addend | residual) quads of one channel-quad group, loaded ONE group ahead of their use: the epilogue of a
-    // res_conv / residual GEMM is otherwise four dependent global round trips (~2k cycles each under load) per tile
+    // gate + (addend | residual) quads of the channel-quad groups
     struct EpiOps { float4 g; f16x4 ar[MI]; };
     auto load_group = [&](int g, EpiOps& o) __attribute__((always_inline)) {
       const int co = n0 + (wn * NI + (g >> 2)) * 32 + 8 * (g & 3) + 4 * half;
@@ -652,15 +651,16 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
           o.ar[mi] = *reinterpret_cast<const f16x4*>(res + (size_t)b * p.bs_res + (size_t)max(op[mi], 0) * p.ld_res + co);
       }
     };
-    EpiOps X, Y;
-    load_group(0, X);
+    // ALL groups' operands are requested before the first one is used (4 + 2 MI registers per group): one memory round trip per
+    // tile instead of one per channel quad — in the graph the res_conv launches (a 1x1 GEMM of 1-3 k-chunks behind this epilogue)
+    // cost 1.18 ms of a 10.5 ms step pair with the one-group-ahead form (tools/ablate_step.sh)
+    EpiOps E[4 * NI];
+    static_for<4 * NI>([&](auto gc) __attribute__((always_inline)) { load_group(decltype(gc)::value, E[decltype(gc)::value]); });
     static_for<4 * NI>([&](auto gc) __attribute__((always_inline)) {
       constexpr int g = decltype(gc)::value;
       constexpr int ni = g >> 2, q = g & 3;
-      EpiOps& cur = (g & 1) ? Y : X;
-      EpiOps& nxt = (g & 1) ? X : Y;
-      __builtin_amdgcn_sched_barrier(0);   // one group (plus the next one's loads) at a time: bounds the register footprint
-      if constexpr (g + 1 < 4 * NI) load_group(g + 1, nxt);
+      EpiOps& cur = E[g];
+      __builtin_amdgcn_sched_barrier(0);   // one group at a time: bounds the register footprint of the arithmetic
       const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
       if (co < p.Cout) {
         float4 bq = make_float4(0.f, 0.f, 0.f, 0.f);

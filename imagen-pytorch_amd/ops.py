@@ -299,6 +299,9 @@ def launchable_shapes(cfg: int, OH: int, OW: int, KH: int, KW: int, stride: int)
 
 
 CONV_LDS = int(_os.environ.get("IMAGEN_CONV_LDS", "0"))             # A/B switch: the LDS-staged kernel family (in-kernel prologue) for 3x3 convs
+# ... only for launches of at most this many tiles: the partials cost every TILE a fixed ~2 us of reductions and barriers, a stand-alone
+# pass over the tensor costs ~9 us per LAUNCH + its read (measured in the model: a loss on the 4096-tile 256^2 layers, a gain below)
+GCA_EPILOGUE_MAX_TILES = int(_os.environ.get("IMAGEN_GCA_EPILOGUE_MAX_TILES", "1024"))
 GCA_IN_EPILOGUE = int(_os.environ.get("IMAGEN_GCA_IN_EPILOGUE", "1"))   # A/B switch: GlobalContext partials from the producing conv's epilogue
 CONV_DMA = int(_os.environ.get("IMAGEN_CONV_DMA", "1"))             # A/B switch: the all-DMA kernel family for prologue-free single-input 3x3 convs
 CONV_LDS_1X1 = int(_os.environ.get("IMAGEN_CONV_LDS_1X1", "0"))     # ... and for 1x1 convs / linears
@@ -497,8 +500,8 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
     # gca: dict(wk=fp32 [Cout], bk=float): GlobalContext partials of the output from the epilogue (kernel families 1 / 2, one tile over
     # all Cout); `p.gca_part_t` ([B, chunks, Cout + 2], chunks = tiles per image = `p.gca_chunks`) then feeds GCA_FINAL directly
     p.gca_part_t, p.gca_chunks = None, 0
-    if want_gca and cfg_table()[cid][3] in (1, 2) and pw.Cout <= cfg_table()[cid][1]:
-        chunks = math.ceil(OH / th) * math.ceil(OW / tw)
+    chunks = math.ceil(OH / th) * math.ceil(OW / tw)
+    if want_gca and cfg_table()[cid][3] in (1, 2) and pw.Cout <= cfg_table()[cid][1] and x1.B * chunks <= GCA_EPILOGUE_MAX_TILES:
         part = torch.empty(x1.B, chunks, pw.Cout + 2, dtype=torch.float32, device=x1.t.device)
         p.gca_wk, p.gca_part, p.gca_bk = gca["wk"].data_ptr(), part.data_ptr(), gca["bk"]
         keep += [gca["wk"], part]
