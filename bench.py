@@ -73,7 +73,11 @@ def roofline_leg(imagen, batch: int, device):
     per_cfg = {}
     stream = torch.cuda.current_stream()
     h = stream.cuda_stream
-    for st in imagen._stages.values():
+    seen = set()
+    for key, st in imagen._stages.items():
+        if key[:3] in seen:      # one engine per (stage, batch, size): lanes hold copies of the same plan
+            continue
+        seen.add(key[:3])
         plan = st["plan"]
         st["step_ptr"].zero_()
         evs = []
@@ -164,6 +168,10 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU (BASELINE: 8)")
     ap.add_argument("--timesteps", type=int, default=1000, help="DDPM steps per stage (BASELINE: 1000); other values are NOT the headline metric")
+    ap.add_argument("--mode", choices=("sequential", "pipeline", "lanes"), default=os.environ.get("IMAGEN_BENCH_MODE", "pipeline"),
+                    help="how successive batches are scheduled on the GPU: one sample() after the other | cascade stages overlapped across "
+                         "batches (Imagen.sample_pipelined) | --lanes whole cascades side by side (one thread + stream each)")
+    ap.add_argument("--lanes", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     args = ap.parse_args()
@@ -199,18 +207,49 @@ def main():
             img = all_gather_images(img, B * world)
         return img
 
+    def passes(first, count):
+        """`count` whole batches (seeds 1000 + first ...), every batch the full cascade; returns the last batch's images."""
+        if count <= 0:
+            return None
+        if args.mode == "sequential":
+            for i in range(count):
+                out = one_pass(first + i)
+            return out
+        if args.mode == "pipeline":
+            outs = imagen.sample_pipelined([dict(seed=1000 + first + i) for i in range(count)], text_embeds=text_embeds, cond_scale=3.0,
+                                           sample_offset=rank * B)
+        else:
+            import threading
+            outs, nxt, lock = [None] * count, [0], threading.Lock()
+
+            def run(lane):
+                with imagen.lane(lane), torch.cuda.device(device):
+                    while True:
+                        with lock:
+                            i = nxt[0]
+                            nxt[0] += 1
+                        if i >= count:
+                            return
+                        outs[i] = imagen.sample(text_embeds=text_embeds, cond_scale=3.0, use_tqdm=False, seed=1000 + first + i,
+                                                sample_offset=rank * B)
+
+            th = [threading.Thread(target=run, args=(1 + l,)) for l in range(args.lanes)]
+            [t.start() for t in th]
+            [t.join() for t in th]
+        if world > 1:
+            outs = [all_gather_images(o, B * world) for o in outs]
+        return outs[-1]
+
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for i in range(args.warmup):
-        one_pass(i)
-        log(f"warmup pass {i} done")
+    passes(0, args.warmup)
+    log(f"{args.warmup} warmup passes done ({args.mode})")
     fence()
     t0 = time.perf_counter()
-    for i in range(args.steps):
-        out = one_pass(args.warmup + i)
+    out = passes(args.warmup, args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     log(f"timed region done: {elapsed:.2f}s for {args.steps} passes")
@@ -232,6 +271,11 @@ def main():
             "config": {"workload": "C3: README unet1 (dim 32, 64^2) + unet2 (dim 32, 256^2, lowres_cond) cascade, "
                                    f"{args.timesteps} DDPM steps/stage, CFG 3.0, dynamic thresholding, batch {B} per GPU",
                        "global_batch": B * world, "parallelism": f"batch-sharded x{world}, one RCCL all-gather of final images",
+                       "batch_schedule": {"sequential": "one sample() call after the other",
+                                          "pipeline": "successive batches with the cascade stages overlapped (stage 1 of batch k+1 || stage 2 of "
+                                                      "batch k, one stream + hipGraph per stage); every batch runs the full cascade, pipeline fill "
+                                                      "and drain are inside the timed region",
+                                          "lanes": f"{args.lanes} whole cascades side by side (one stream each)"}[args.mode],
                        "denoiser_evals_per_image": 2 * 2 * args.timesteps},
             "path_tflops_reference_count": round(value * FLOPS_PER_IMAGE_REFERENCE * (args.timesteps / 1000) / 1e12, 1),
             "path_frac_of_mfma_peak": round(value * FLOPS_PER_IMAGE_REFERENCE * (args.timesteps / 1000) / 1e12 / (MFMA_PEAK_TFLOPS * world), 4),

@@ -2,6 +2,7 @@
 // assembly, embeddings).  All kernels move 16 B per lane (8 fp16) with consecutive lanes on consecutive
 // addresses; reductions over a row use a power-of-two sub-group of the wave64 and __shfl_xor.
 #include <algorithm>
+#include <cstdlib>
 #include "common.h"
 #include "gca_device.h"
 
@@ -427,6 +428,120 @@ __global__ __launch_bounds__(256) void gca_final_kernel(const ImagenGcaFinalPara
   gca_finalize(p.part + (size_t)b * p.chunks * (p.C + 2), p.chunks, p.C, p.hidden, p.w1t, p.b1, p.w2t, p.b2, p.gate + (size_t)b * p.C, sm);
 }
 
+// The same job as ONE global round trip.  gca_final_kernel is a chain of ~12 dependent round trips (chunk statistics, partial
+// rows, then the two weight matrices in batches of 8 loads per thread), each 1-2 us once the weights have fallen out of L2 since
+// the previous denoiser step: 11-20 us per launch, x 67 gates per step pair of the bench.  Here 1024 threads request EVERYTHING the
+// gate depends on — their slice of both weight matrices (<= 8 float4 each), the chunk statistics and their partial rows — before
+// the first wait, and all arithmetic runs out of registers and LDS.  Needs power-of-two C and hidden (launcher-checked).
+constexpr int kGcaFastThreads = 1024;
+constexpr int kGcaFastW = 8;    // prefetched float4 per thread and weight matrix (larger matrices: a second, loop-carried pass)
+constexpr int kGcaFastP = 8;    // prefetched partial-row elements per thread
+
+// out[o] = emit(o, sum_i wt[i][o] * in[i]); wt: [n_in][n_out] fp32, n_out a power of two in [4, 4096]; w: this thread's prefetched rows
+template <class Emit>
+__device__ __forceinline__ void gca_fast_matvec(const float4 (&w)[kGcaFastW], const float* wt, int n_in, int n_out, const float* in, float4* red,
+                                                Emit emit) {
+  const int t = threadIdx.x;
+  const int nvec = n_out >> 2, rpp = kGcaFastThreads / nvec;
+  const int cg = t & (nvec - 1), r = t / nvec;
+  float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+  for (int k = 0; k < kGcaFastW; ++k) {
+    const int row = r + k * rpp;
+    const float x = row < n_in ? in[row] : 0.f;
+    a.x += w[k].x * x; a.y += w[k].y * x; a.z += w[k].z * x; a.w += w[k].w * x;
+  }
+  for (int row = r + kGcaFastW * rpp; row < n_in; row += rpp) {
+    const float4 q = *reinterpret_cast<const float4*>(wt + (size_t)row * n_out + cg * 4);
+    const float x = in[row];
+    a.x += q.x * x; a.y += q.y * x; a.z += q.z * x; a.w += q.w * x;
+  }
+  red[t] = a;
+  __syncthreads();
+  for (int o = t; o < n_out; o += kGcaFastThreads) {
+    const float* col = reinterpret_cast<const float*>(red + (o >> 2)) + (o & 3);
+    float sum = 0.f;
+    for (int rr = 0; rr < rpp; ++rr) sum += col[(size_t)rr * nvec * 4];
+    emit(o, sum);
+  }
+  __syncthreads();
+}
+
+__device__ __forceinline__ void gca_fast_prefetch(float4 (&w)[kGcaFastW], const float* wt, int n_in, int n_out) {
+  const int t = threadIdx.x;
+  const int nvec = n_out >> 2, rpp = kGcaFastThreads / nvec;
+  const int cg = t & (nvec - 1), r = t / nvec;
+#pragma unroll
+  for (int k = 0; k < kGcaFastW; ++k) {
+    const int row = r + k * rpp;
+    w[k] = row < n_in ? *reinterpret_cast<const float4*>(wt + (size_t)row * n_out + cg * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+}
+
+__global__ __launch_bounds__(kGcaFastThreads) void gca_final_fast_kernel(const ImagenGcaFinalParams p) {
+  __shared__ float4 s_red[kGcaFastThreads];
+  __shared__ float s_ctx[1024], s_hid[1024], s_wgt[1024], s_b1[1024], s_b2[1024], s_sc[40];
+  const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
+  const int b = blockIdx.x, C = p.C, hidden = p.hidden, chunks = p.chunks;
+  const int stride = C + 2;
+  const float* part = p.part + (size_t)b * chunks * stride;
+  // ---- every global load the gate depends on, before the first wait — in the order of use (vmcnt retires in issue order)
+  float2 ms = make_float2(-3.0e38f, 0.f);
+  if (t < chunks) ms = *reinterpret_cast<const float2*>(part + (size_t)t * stride);
+  const int c = t & (C - 1), sl = t / C, nsl = kGcaFastThreads / C;   // C <= 1024
+  float pv[kGcaFastP];
+#pragma unroll
+  for (int j = 0; j < kGcaFastP; ++j) {
+    const int i = sl + j * nsl;
+    pv[j] = i < chunks ? part[(size_t)i * stride + 2 + c] : 0.f;
+  }
+  const float bias1 = t < hidden ? p.b1[t] : 0.f, bias2 = t < C ? p.b2[t] : 0.f;
+  float4 w1[kGcaFastW], w2[kGcaFastW];
+  gca_fast_prefetch(w1, p.w1t, C, hidden);
+  gca_fast_prefetch(w2, p.w2t, hidden, C);
+  // ---- softmax merge weights of the chunks
+  float m = ms.x;
+  for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
+  if (lane == 0) s_sc[wave] = m;
+  __syncthreads();
+  float M = s_sc[0];
+#pragma unroll
+  for (int w = 1; w < kGcaFastThreads / 64; ++w) M = fmaxf(M, s_sc[w]);
+  const float wg = t < chunks ? __expf(ms.x - M) : 0.f;
+  if (t < chunks) s_wgt[t] = wg;
+  float ssum = ms.y * wg;
+  for (int off = 32; off > 0; off >>= 1) ssum += __shfl_xor(ssum, off);
+  if (lane == 0) s_sc[16 + wave] = ssum;
+  __syncthreads();
+  float S = 0.f;
+#pragma unroll
+  for (int w = 0; w < kGcaFastThreads / 64; ++w) S += s_sc[16 + w];
+  const float inv_S = 1.0f / S;
+  s_b1[t] = bias1;   // (parked in LDS: the weight registers leave no room to carry them)
+  s_b2[t] = bias2;
+  // ---- ctx[c] = sum_i part[i][2 + c] * wgt[i] / S
+  float a = 0.f;
+#pragma unroll
+  for (int j = 0; j < kGcaFastP; ++j) {
+    const int i = sl + j * nsl;
+    a += pv[j] * (i < chunks ? s_wgt[i] : 0.f);
+  }
+  for (int i = sl + kGcaFastP * nsl; i < chunks; i += nsl) a += part[(size_t)i * stride + 2 + c] * s_wgt[i];
+  float* red_f = reinterpret_cast<float*>(s_red);
+  red_f[t] = a;
+  __syncthreads();
+  if (t < C) {
+    float v = 0.f;
+    for (int q = 0; q < nsl; ++q) v += red_f[q * C + t];
+    s_ctx[t] = v * inv_S;
+  }
+  __syncthreads();
+  // ---- squeeze MLP out of the prefetched registers
+  gca_fast_matvec(w1, p.w1t, C, hidden, s_ctx, s_red, [&](int o, float v) __attribute__((always_inline)) { s_hid[o] = silu_f(v + s_b1[o]); });
+  float* gate = p.gate + (size_t)b * C;
+  gca_fast_matvec(w2, p.w2t, hidden, C, s_hid, s_red, [&](int o, float v) __attribute__((always_inline)) { gate[o] = sigmoid_f(v + s_b2[o]); });
+}
+
 // ------------------------------------------------------------------------------------------------ embeddings / affine
 __global__ __launch_bounds__(256) void time_embed_kernel(const ImagenTimeEmbedParams p) {
   const int i = blockIdx.x * 256 + threadIdx.x;
@@ -646,6 +761,12 @@ int launch_gca_partial(const ImagenGcaPartialParams* p, hipStream_t s) {
 }
 
 int launch_gca_final(const ImagenGcaFinalParams* p, hipStream_t s) {
+  auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+  static const bool slow = getenv("IMAGEN_GCA_FINAL_SLOW") != nullptr;   // A/B switch
+  if (!slow && pow2(p->C) && pow2(p->hidden) && p->C >= 4 && p->C <= 1024 && p->hidden >= 4 && p->hidden <= 1024 && p->chunks <= 1024) {
+    hipLaunchKernelGGL(gca_final_fast_kernel, dim3(p->B), dim3(kGcaFastThreads), 0, s, *p);
+    return imagen_hip_status("gca_final");
+  }
   const size_t sm = (size_t)(p->C + p->hidden + p->chunks + kGcaScratchFloats) * sizeof(float);
   hipLaunchKernelGGL(gca_final_kernel, dim3(p->B), dim3(256), sm, s, *p);
   return imagen_hip_status("gca_final");

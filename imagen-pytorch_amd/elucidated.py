@@ -121,14 +121,14 @@ class ElucidatedImagen(Imagen):
         return sigmas[0].item(), [t.float().contiguous() for t in (coef, w_hat, w_euler, w_heun)]
 
     # ---- per-stage plans --------------------------------------------------------------------------------------------------
-    def _stage(self, idx: int, B: int, device, *, cond_scale: float, with_text: bool, inject_noise: bool, sample_offset: int,
-               resample_times: int = 0, frames: int = 0):
+    def _build_stage(self, idx: int, B: int, device, *, cond_scale: float, with_text: bool, inject_noise: bool, sample_offset: int,
+                     resample_times: int = 0, frames: int = 0):
         unet = self.unets[idx]
         S = self.image_sizes[idx]
         hp = self.hparams[idx]
         cfg = cond_scale != 1.
         key = ("edm", idx, B, S, str(device), float(cond_scale), with_text, inject_noise, sample_offset, self.dynamic_thresholding[idx],
-               self.dynamic_thresholding_percentile, tuple(hp), frames)
+               self.dynamic_thresholding_percentile, tuple(hp), frames, self._lane)
         st = self._stages.get(key)
         if st is not None and not st['eng'].stale():
             return st
@@ -294,20 +294,18 @@ class ElucidatedImagen(Imagen):
         if inpaint_images is not None or inpaint_masks is not None or skip_steps is not None or any(
                 i is not None for i in _cast_tuple(init_images)):
             _out_of_scope("ElucidatedImagen.sample(inpaint_images= / init_images= / skip_steps=) (el.py:446-452, 497-533)")
-        was_training = self.training
-        self.eval()
-        try:
-            self._conditioning = conditioning
-            if conditioning is not None:
-                assert texts is None and text_embeds is None and text_masks is None, 'pass either `conditioning` or texts / text_embeds'
-                text_embeds, text_masks = conditioning.text_embeds, conditioning.text_masks
-                if text_embeds is None:
-                    batch_size = conditioning.batch_size
-            return self._sample(texts, text_masks, text_embeds, video_frames, cond_images, cond_video_frames, post_cond_video_frames,
-                                inpaint_videos, inpaint_images, inpaint_masks, inpaint_resample_times, init_images, skip_steps, batch_size,
-                                cond_scale, lowres_sample_noise_level, start_at_unet_number, start_image_or_video, stop_at_unet_number,
-                                return_all_unet_outputs, return_pil_images, device, use_tqdm, noise_fn, seed, sample_offset, use_graph,
-                                max_steps)
-        finally:
-            self._conditioning = None
-            self.train(was_training)
+        with self._eval_mode():
+            try:
+                self._tls.conditioning = conditioning
+                if conditioning is not None:
+                    assert texts is None and text_embeds is None and text_masks is None, 'pass either `conditioning` or texts / text_embeds'
+                    text_embeds, text_masks = conditioning.text_embeds, conditioning.text_masks
+                    if text_embeds is None:
+                        batch_size = conditioning.batch_size
+                return self._sample(texts, text_masks, text_embeds, video_frames, cond_images, cond_video_frames, post_cond_video_frames,
+                                    inpaint_videos, inpaint_images, inpaint_masks, inpaint_resample_times, init_images, skip_steps, batch_size,
+                                    cond_scale, lowres_sample_noise_level, start_at_unet_number, start_image_or_video, stop_at_unet_number,
+                                    return_all_unet_outputs, return_pil_images, device, use_tqdm, noise_fn, seed, sample_offset, use_graph,
+                                    max_steps)
+            finally:
+                self._tls.conditioning = None

@@ -11,9 +11,12 @@ outside the hot-path scope and raise.
 """
 from __future__ import annotations
 
+import contextlib
 import functools
 import os
-from typing import Callable, List, Optional
+import queue
+import threading
+from typing import Callable, Dict, List, Optional
 
 import torch
 import torch.nn.functional as F
@@ -169,7 +172,11 @@ class Imagen(nn.Module):
         self.register_buffer('_temp', torch.tensor([0.]), persistent=False)
         self.to(next(self.unets.parameters()).device)
         self._stages = {}
-        self._stream = None
+        self._streams: Dict[tuple, torch.cuda.Stream] = {}   # (lane, device) -> private stream
+        self._tls = threading.local()                        # per-thread: lane index, conditioning handle
+        self._mode_lock = threading.Lock()
+        self._build_lock = threading.RLock()                 # stage construction (engine plans + shared weight packing) is serialised
+        self._mode_depth = 0
         self._call_counter = 0
 
     # ---- device bookkeeping (API parity; weights stay resident as packed copies, nothing is shuffled over PCIe) ----
@@ -201,9 +208,116 @@ class Imagen(nn.Module):
     def forward(self, *args, **kwargs):
         _out_of_scope("Imagen.forward (training loss, ip.py:2500-2734)")
 
+    # ---- lanes: independent sampling contexts (own stream, own stage buffers + graphs, shared packed weights) ------------------
+    @property
+    def _lane(self) -> int:
+        return getattr(self._tls, 'lane', 0)
+
+    @contextlib.contextmanager
+    def lane(self, index: int):
+        """Extension: `with imagen.lane(i): imagen.sample(...)` runs the call on lane i — its own HIP stream and its own
+        per-stage buffers / captured graphs; the packed weights are shared.  Calls on different lanes may be issued from
+        different threads and overlap on the GPU (results are those of the same calls made one after the other)."""
+        prev = self._lane
+        self._tls.lane = int(index)
+        try:
+            yield self
+        finally:
+            self._tls.lane = prev
+
+    @contextlib.contextmanager
+    def _eval_mode(self):
+        """eval() for the duration of a sample() call, restored when the LAST concurrent call ends."""
+        with self._mode_lock:
+            if self._mode_depth == 0:
+                self._was_training = self.training
+                self.eval()
+            self._mode_depth += 1
+        try:
+            yield
+        finally:
+            with self._mode_lock:
+                self._mode_depth -= 1
+                if self._mode_depth == 0:
+                    self.train(self._was_training)
+
+    @torch.no_grad()
+    def sample_pipelined(self, batches: List[dict], **common) -> List[torch.Tensor]:
+        """Extension: sample successive batches with the cascade stages OVERLAPPED — stage s of batch k runs (own thread, own
+        lane / stream / graph) while stage s+1 of batch k-1 does.  `batches` is a list of per-batch `sample()` keyword dicts
+        (text_embeds=..., seed=..., ...), `common` the keywords shared by all.  Returns the final-stage images per batch, each
+        bit-identical to `sample(**common, **batches[k])` (the stage hand-off is the same [0, 1] image the sequential cascade
+        passes on, ip.py:2487-2490).  The base stage is latency-bound (few workgroups per launch at 64^2), the super-resolution
+        stage throughput-bound: overlapped they fill the chip, so the sustained rate is set by the slower stage alone."""
+        n_stages = len(self.unets)
+        for k in ('start_at_unet_number', 'stop_at_unet_number', 'start_image_or_video', 'return_all_unet_outputs'):
+            assert k not in common and all(k not in b for b in batches), f'sample_pipelined drives `{k}` itself'
+        jobs = []
+        for b in batches:
+            kw = {**common, **b}
+            if kw.get('seed') is None:                   # the seed must be the same for every stage of a batch (as in one sample() call)
+                self._call_counter += 1
+                kw['seed'] = (int(torch.initial_seed()) * 1000003 + self._call_counter) & ((1 << 62) - 1)
+            kw.setdefault('use_tqdm', False)
+            jobs.append(kw)
+        if n_stages == 1 or len(jobs) == 0:
+            return [self.sample(**kw) for kw in jobs]
+        caller = torch.cuda.current_stream(self.device)
+        ready = torch.cuda.Event()
+        ready.record(caller)
+        qs = [queue.Queue() for _ in range(n_stages + 1)]
+        errors: List[BaseException] = []
+
+        def worker(s: int):
+            try:
+                with self.lane(0x100 + s), torch.cuda.device(self.device):
+                    torch.cuda.current_stream().wait_event(ready)
+                    while True:
+                        item = qs[s].get()
+                        if item is None or errors:
+                            break
+                        k, img = item
+                        kw = dict(jobs[k])
+                        if s > 0:
+                            kw.update(start_at_unet_number=s + 1, start_image_or_video=img)
+                        out = self.sample(**kw, stop_at_unet_number=s + 1)   # returns after this lane's stream has drained
+                        qs[s + 1].put((k, out))
+            except BaseException as e:   # noqa: BLE001 — re-raised in the caller
+                errors.append(e)
+            finally:
+                qs[s + 1].put(None)
+
+        threads = [threading.Thread(target=worker, args=(s,), daemon=True) for s in range(n_stages)]
+        for t in threads:
+            t.start()
+        for k in range(len(jobs)):
+            qs[0].put((k, None))
+        qs[0].put(None)
+        results: Dict[int, torch.Tensor] = {}
+        while True:
+            item = qs[n_stages].get()
+            if item is None:
+                break
+            results[item[0]] = item[1]
+        for t in threads:
+            t.join()
+        if errors:
+            raise errors[0]
+        return [results[k] for k in range(len(jobs))]
+
     # ---- one cascade stage -------------------------------------------------------------------------------------
-    def _stage(self, idx: int, B: int, device, *, cond_scale: float, with_text: bool, inject_noise: bool, sample_offset: int,
-               resample_times: int = 0, frames: int = 0):
+    def _stage(self, *args, **kwargs):
+        """`_build_stage` under the construction lock; a NEW stage's packing kernels (weights shared with the other lanes) have
+        completed before the stage becomes visible."""
+        with self._build_lock:
+            n = len(self._stages)
+            st = self._build_stage(*args, **kwargs)
+            if len(self._stages) != n and torch.cuda.is_available():
+                torch.cuda.current_stream().synchronize()
+            return st
+
+    def _build_stage(self, idx: int, B: int, device, *, cond_scale: float, with_text: bool, inject_noise: bool, sample_offset: int,
+                     resample_times: int = 0, frames: int = 0):
         """Build (or fetch) the per-timestep plan + graph of stage `idx` for batch B.
 
         resample_times = R > 0 selects the inpainting plan (ip.py:2237-2275): the device counter then counts INNER iterations
@@ -216,7 +330,7 @@ class Imagen(nn.Module):
         T = sched.num_timesteps
         cfg = cond_scale != 1.
         key = (idx, B, S, str(device), float(cond_scale), with_text, inject_noise, sample_offset, self.dynamic_thresholding[idx],
-               self.pred_objectives[idx], self.dynamic_thresholding_percentile, resample_times, frames)
+               self.pred_objectives[idx], self.dynamic_thresholding_percentile, resample_times, frames, self._lane)
         st = self._stages.get(key)
         if st is not None and not st['eng'].stale():
             return st
@@ -387,23 +501,21 @@ class Imagen(nn.Module):
         max_steps: Optional[int] = None,
         conditioning: Optional[Conditioning] = None,   # extension: handle from prepare_conditioning() instead of texts / text_embeds
     ):
-        was_training = self.training
-        self.eval()
-        try:
-            self._conditioning = conditioning
-            if conditioning is not None:
-                assert texts is None and text_embeds is None and text_masks is None, 'pass either `conditioning` or texts / text_embeds'
-                text_embeds, text_masks = conditioning.text_embeds, conditioning.text_masks
-                if text_embeds is None:
-                    batch_size = conditioning.batch_size
-            return self._sample(texts, text_masks, text_embeds, video_frames, cond_images, cond_video_frames, post_cond_video_frames,
-                                inpaint_videos, inpaint_images, inpaint_masks, inpaint_resample_times, init_images, skip_steps, batch_size,
-                                cond_scale, lowres_sample_noise_level, start_at_unet_number, start_image_or_video, stop_at_unet_number,
-                                return_all_unet_outputs, return_pil_images, device, use_tqdm, noise_fn, seed, sample_offset, use_graph,
-                                max_steps)
-        finally:
-            self._conditioning = None
-            self.train(was_training)
+        with self._eval_mode():
+            try:
+                self._tls.conditioning = conditioning
+                if conditioning is not None:
+                    assert texts is None and text_embeds is None and text_masks is None, 'pass either `conditioning` or texts / text_embeds'
+                    text_embeds, text_masks = conditioning.text_embeds, conditioning.text_masks
+                    if text_embeds is None:
+                        batch_size = conditioning.batch_size
+                return self._sample(texts, text_masks, text_embeds, video_frames, cond_images, cond_video_frames, post_cond_video_frames,
+                                    inpaint_videos, inpaint_images, inpaint_masks, inpaint_resample_times, init_images, skip_steps, batch_size,
+                                    cond_scale, lowres_sample_noise_level, start_at_unet_number, start_image_or_video, stop_at_unet_number,
+                                    return_all_unet_outputs, return_pil_images, device, use_tqdm, noise_fn, seed, sample_offset, use_graph,
+                                    max_steps)
+            finally:
+                self._tls.conditioning = None
 
     def _resolve_text(self, texts, text_embeds, text_masks, device):
         """ip.py:2326-2337: texts -> encoder hook; default mask = any non-zero feature."""
@@ -489,12 +601,19 @@ class Imagen(nn.Module):
             assert stop_at_unet_number is None or start_at_unet_number <= stop_at_unet_number
             assert start_image_or_video is not None, 'starting image or video must be supplied if only doing upscaling'
             img = to_internal(start_image_or_video.to(device).float()).contiguous()
+            prev_size = self.image_sizes[start_at_unet_number - 2]
+            assert img.shape[-3] == self.channels, f'start image must have {self.channels} channels'
+            if img.shape[-1] != prev_size:               # ip.py:2400-2404: first to the PREVIOUS stage's size (lowres_prep then resizes to this one's)
+                lead = img.shape[:-3]
+                img = resize(img.reshape(-1, *img.shape[-3:]), prev_size).reshape(*lead, self.channels, prev_size, prev_size).contiguous()
 
-        if self._stream is None or self._stream.device != device:
-            self._stream = torch.cuda.Stream(device=device)
+        stream = self._streams.get((self._lane, str(device)))
+        if stream is None:
+            stream = self._streams[(self._lane, str(device))] = torch.cuda.Stream(device=device)
         outputs = []
-        torch.cuda.synchronize(device)
-        with torch.cuda.device(device), torch.cuda.stream(self._stream):
+        # inputs were produced on the caller's stream: order this lane's stream behind it (no device-wide drain — other lanes keep running)
+        stream.wait_stream(torch.cuda.current_stream(device))
+        with torch.cuda.device(device), torch.cuda.stream(stream):
             for idx in range(num_unets):
                 unet_number = idx + 1
                 if unet_number < start_at_unet_number:
@@ -547,7 +666,7 @@ class Imagen(nn.Module):
                 keep = torch.ones(rows, dtype=torch.bool)
                 if rows == 2 * batch_size:
                     keep[batch_size:] = False            # second half = null-conditioned CFG branch (cond_drop_prob = 1, ip.py:1521)
-                cond = getattr(self, '_conditioning', None)
+                cond = getattr(self._tls, 'conditioning', None)
                 stamp = None if cond is None else (cond.token, None if lowres_logsnr is None else float(lowres_logsnr[0]))
                 if stamp is None or getattr(eng, '_cond_stamp', None) != stamp:
                     eng.set_conditioning(text_embeds=text_embeds if with_text else None, text_mask=text_masks if with_text else None,
@@ -556,14 +675,14 @@ class Imagen(nn.Module):
                 eng._cond_stamp = stamp
                 timing = os.environ.get("IMAGEN_TIMING")
                 if timing:
-                    self._stream.synchronize()
+                    stream.synchronize()
                     import time as _time
                     t_stage = _time.perf_counter()
                 out = self.p_sample_loop(st, noise_fn=noise_fn, stage=idx, seed=seed, use_graph=use_graph, use_tqdm=use_tqdm,
                                          max_steps=max_steps, skip_steps=skip_steps[idx],
                                          init_images=None if init_images[idx] is None else resize(init_images[idx], S))
                 if timing:
-                    self._stream.synchronize()
+                    stream.synchronize()
                     dt = _time.perf_counter() - t_stage
                     self.last_stage_seconds = getattr(self, "last_stage_seconds", {})
                     self.last_stage_seconds[idx] = dt
@@ -575,5 +694,5 @@ class Imagen(nn.Module):
                 outputs.append(to_internal(img) if st.get('video', False) else img)   # the permutation is its own inverse
                 if stop_at_unet_number is not None and stop_at_unet_number == unet_number:
                     break
-        self._stream.synchronize()
+        stream.synchronize()
         return outputs if return_all_unet_outputs else outputs[-1]

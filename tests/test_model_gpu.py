@@ -260,6 +260,41 @@ def test_sample_philox_determinism_and_sharding():
     assert nerr(hi, a[2:]) < 1e-5
 
 
+def test_pipelined_and_lane_sampling_match_sequential():
+    """Overlapped sampling: (a) sample_pipelined (one worker thread + lane per cascade stage, stage s of batch k concurrent with
+    stage s+1 of batch k-1) and (b) whole cascades on two lanes from two threads give, per batch, bit-identical images to
+    sequential sample() calls with the same seeds."""
+    import threading
+    from imagen_pytorch_amd import Imagen, Unet
+
+    dev = torch.device("cuda:0")
+    g = _load("sample_tiny_cascade.pt")
+    unets = [Unet(**spec["kwargs"]).eval() for spec in g["unets"]]
+    imagen = Imagen(unets, image_sizes=g["image_sizes"], timesteps=12, text_embed_dim=32, cond_drop_prob=0.1).to(dev)
+    for u, spec in zip(imagen.unets, g["unets"]):
+        u.load_state_dict(spec["state_dict"])
+    tes = [torch.randn(4, 9, 32, device=dev) for _ in range(5)]
+    seq = [imagen.sample(text_embeds=te, cond_scale=3.0, use_tqdm=False, seed=500 + i) for i, te in enumerate(tes)]
+    pipe = imagen.sample_pipelined([dict(text_embeds=te, seed=500 + i) for i, te in enumerate(tes)], cond_scale=3.0)
+    for a, b in zip(pipe, seq):
+        assert torch.equal(a, b)
+    again = imagen.sample_pipelined([dict(text_embeds=te, seed=500 + i) for i, te in enumerate(tes)], cond_scale=3.0)   # cached lanes / graphs
+    for a, b in zip(again, seq):
+        assert torch.equal(a, b)
+    res = {}
+
+    def run(lane, idxs):
+        with imagen.lane(lane), torch.cuda.device(dev):
+            for i in idxs:
+                res[i] = imagen.sample(text_embeds=tes[i], cond_scale=3.0, use_tqdm=False, seed=500 + i)
+
+    th = [threading.Thread(target=run, args=(1, [0, 2, 4])), threading.Thread(target=run, args=(2, [1, 3]))]
+    [t.start() for t in th]
+    [t.join() for t in th]
+    for i in range(5):
+        assert torch.equal(res[i], seq[i])
+
+
 def test_elucidated_sample_vs_reference_fixture():
     """SURVEY §8(f) NEXT-1 / BASELINE config C4: ElucidatedImagen.sample (Karras schedule, churn, preconditioning, dynamic
     threshold, Heun correction, 2-stage cascade) vs the recorded run of the live reference with identical Gaussian draws;

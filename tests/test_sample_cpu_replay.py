@@ -28,6 +28,20 @@ class _Stream:
     def synchronize(self):
         pass
 
+    def wait_stream(self, other):
+        pass
+
+    def wait_event(self, ev):
+        pass
+
+
+class _Event:
+    def __init__(self, *a, **k):
+        pass
+
+    def record(self, stream=None):
+        pass
+
 
 @pytest.fixture()
 def cpu_backend(monkeypatch):
@@ -49,6 +63,7 @@ def cpu_backend(monkeypatch):
     monkeypatch.setattr(ops, "Graph", Graph)
     monkeypatch.setattr(imagen_mod, "_SAMPLING_DEVICE_TYPES", ("cuda", "cpu"))
     monkeypatch.setattr(torch.cuda, "Stream", _Stream)
+    monkeypatch.setattr(torch.cuda, "Event", _Event)
     monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: _Stream())
     monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: None)
     monkeypatch.setattr(torch.cuda, "device", lambda *a, **k: contextlib.nullcontext())
@@ -88,6 +103,26 @@ def test_cascade_sample_driver(cpu_backend, use_graph):
     alone = imagen.sample(text_embeds=g["text_embeds"], cond_scale=g["cond_scale"], use_tqdm=False, noise_fn=lambda tag, shape: g["noise"][tag],
                           start_at_unet_number=2, start_image_or_video=g["outputs"][0], device="cpu")
     assert nerr(alone, g["outputs"][1]) < 2e-2
+
+
+def test_pipelined_batches_match_sequential(cpu_backend):
+    """sample_pipelined (stage s of batch k overlapped with stage s+1 of batch k-1, one worker thread + lane per stage) returns,
+    per batch, exactly what sample() returns for that batch."""
+    g = torch.load(os.path.join(GOLDEN, "sample_tiny_cascade.pt"), weights_only=False)
+    imagen = _cascade(g, timesteps=g["timesteps"])
+    fns = [lambda tag, shape, s=s: g["noise"][tag] * s for s in (1.0, 0.5, -1.0)]
+    common = dict(cond_scale=g["cond_scale"], device="cpu")
+    batches = [dict(text_embeds=g["text_embeds"] * (1.0 + 0.1 * i), noise_fn=fn) for i, fn in enumerate(fns)]
+    seq = [imagen.sample(use_tqdm=False, **common, **b) for b in batches]
+    pipe = imagen.sample_pipelined(batches, **common)
+    assert len(pipe) == len(seq)
+    for a, b in zip(pipe, seq):
+        assert torch.equal(a, b)
+    assert nerr(pipe[0], g["outputs"][1]) < 2e-2
+    assert not torch.equal(pipe[0], pipe[1])
+    # errors inside a stage worker surface in the caller
+    with pytest.raises(AssertionError):
+        imagen.sample_pipelined([dict(text_embeds=g["text_embeds"][..., :-1])], **common)
 
 
 @pytest.mark.parametrize("run", ["init_skip", "inpaint"])
