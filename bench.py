@@ -10,13 +10,23 @@ samples its own 8 prompts and the final images are all-gathered over RCCL).  Inp
 HBM before the timed region: random-init weights (final_conv ~ N(0, 0.05^2)), random text_embeds,
 in-kernel Philox noise.  Rank 0 prints one JSON line.
 
+Batch schedule (--mode): the K timed batches are scheduled `lanes` (default; --lanes 3 whole cascades side by side, one HIP stream +
+hipGraph set each — the 64^2 stage and the 32^2/64^2 levels of the 256^2 stage launch a few dozen workgroups per kernel and are
+latency-bound at batch 8, so independent batches fill the idle CUs), `pipeline` (cascade stages overlapped across batches,
+Imagen.sample_pipelined) or `sequential` (one sample() call after the other — also measured once after the timed region and
+reported under "sequential").  Every batch runs the full cascade at batch 8; nothing is shared between batches but the weights.
+
 Extra legs (rank 0, N = 1 only):
-  roofline     — HIP-event timing, on the launch stream, of every launch of the dominant kernel symbol (the 128x128 MFMA
-                 implicit-GEMM tile `igemm_kernel<2,2,2,2,4>`) in one denoiser step of each stage; achieved = algorithmic
-                 FLOPs (2*MACs of the convolution / linear it computes) per launch / average duration, vs the 2.5 PFLOP/s
-                 dense fp16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md).
-  cpu_baseline — the CPU oracle (oracle/: fp32 torch restatement of the reference path, "port") timed on this box's host
-                 cores for ONE DDPM step per stage at batch 8 (2 CFG forwards each), linearly extrapolated to 1000 steps.
+  roofline     — HIP-event timing, on the launch stream, of every implicit-GEMM launch of one denoiser step of each stage, grouped
+                 by tile configuration and by bound (algorithmic FLOP/byte vs the 312 FLOP/B ridge).  "roofline" is the dominant
+                 group overall, "roofline_other_bound" the dominant group under the other roof: achieved = algorithmic FLOPs
+                 (2*MACs) or bytes (inputs + output + weights + epilogue operand) / time, vs 2.5 PFLOP/s dense fp16 MFMA or 8 TB/s
+                 HBM (/opt/skills/guides/MI355X_MICROARCH.md).  `traffic` (HBM bytes per launch) and `mfma_busy_frac` come from
+                 three `rocprofv3 --pmc` passes (FETCH_SIZE | WRITE_SIZE | SQ MFMA-busy) that THIS invocation runs over a short
+                 sampling run in a child process (tools/graph_profile.py), joined with the plan by dispatch order.
+  cpu_baseline — the reference itself on the host cores where its tree exists (kind "reference"; the build container only), else
+                 the CPU oracle (oracle/: fp32 torch restatement of the reference path, "port") for ONE DDPM step per stage at
+                 batch 8 (2 CFG forwards each), linearly extrapolated to 1000 steps.
 """
 from __future__ import annotations
 
@@ -63,21 +73,77 @@ def igemm_flops(p) -> float:
     return 2.0 * p.B * p.OH * p.OW * p.Cout * p.KH * p.KW * (p.C1 + p.C2)
 
 
-def roofline_leg(imagen, batch: int, device):
-    """Event-time every launch of the dominant igemm tile symbol in one denoiser step of both stages (eager, same stream)."""
+HBM_PEAK_GBS = 8000.0                  # HBM3E, MI355X_MICROARCH.md (achievable copy rate ~6300)
+RIDGE = MFMA_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9)   # FLOP per byte above which a launch is MFMA-bound (312)
+
+
+def igemm_bytes(p) -> float:
+    """Algorithmic HBM bytes of one igemm launch: inputs once + output once (fp32 for the NCHW image) + packed weights +
+    the epilogue's addend / residual operand (per-unit figures)."""
+    cin = p.C1 + p.C2
+    by = 2.0 * p.B * (p.H * p.W * cin + p.OH * p.OW * p.Cout * (2 if p.out_mode == 2 else 1)) + 2.0 * p.KH * p.KW * cin * p.Cout
+    return by + 2.0 * p.B * p.OH * p.OW * p.Cout * (bool(p.res) + bool(p.addend))
+
+
+def pmc_traffic_leg(log):
+    """HBM traffic / MFMA-busy counters of every igemm launch of the denoiser steps, measured NOW: separate `rocprofv3 --pmc`
+    passes (FETCH_SIZE | WRITE_SIZE | SQ MFMA-busy) over a short sampling run in a child process (tools/graph_profile.py run),
+    joined with the plan by dispatch order.  Returns {(stage index, label): {counter: value per launch}} or None."""
+    import shutil
+    import subprocess
+    import tempfile
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import graph_profile
+
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    out = {}
+    passes = (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"])
+    for counters in passes:
+        tmp = tempfile.mkdtemp(prefix="imagen_pmc_", dir="/tmp")
+        try:
+            plan_path = os.path.join(tmp, "plan.json")
+            cmd = [rocprof, "--pmc", *counters, "--output-format", "csv", "-d", os.path.join(tmp, "out"), "--",
+                   sys.executable, os.path.join(ROOT, "tools", "graph_profile.py"), "run", "--steps", "5", "--plan-out", plan_path]
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=420)
+            csvs = [os.path.join(d, f) for d, _, fs in os.walk(os.path.join(tmp, "out")) for f in fs if f.endswith("counter_collection.csv")]
+            if r.returncode != 0 or not csvs or not os.path.exists(plan_path):
+                log(f"pmc pass {counters}: rocprofv3 failed (rc {r.returncode}): {r.stdout.decode(errors='replace')[-300:]}")
+                continue
+            plan = json.load(open(plan_path))
+            for si, ops_ in enumerate(graph_profile.pmc_join(csvs[0], plan)):
+                for o in ops_ or []:
+                    if o["kind"] == "igemm":
+                        out.setdefault((si, o["label"]), {}).update({c: o[c] for c in counters if c in o})
+            log(f"pmc pass {counters} done")
+        except Exception as e:  # noqa: BLE001 — the leg is optional
+            log(f"pmc pass {counters} failed: {e}")
+        finally:
+            shutil.rmtree(tmp, ignore_errors=True)
+    return out or None
+
+
+def roofline_leg(imagen, batch: int, device, pmc=None):
+    """Event-time every igemm launch of one denoiser step of both stages (eager, same stream), grouped by tile configuration.
+    Two roofs are reported: the tile configuration with the largest total time among the MFMA-bound launches (algorithmic
+    FLOP/byte above the ridge) and the one among the HBM-bound launches."""
     import ctypes
     from imagen_pytorch_amd import _abi, ops
 
     lib = _abi.load_library()
     K_IGEMM = _abi.ENUMS["IMAGEN_OP_IGEMM"]
-    per_cfg = {}
+    groups = {}
     stream = torch.cuda.current_stream()
     h = stream.cuda_stream
     seen = set()
+    stage_no = -1
     for key, st in imagen._stages.items():
         if key[:3] in seen:      # one engine per (stage, batch, size): lanes hold copies of the same plan
             continue
         seen.add(key[:3])
+        stage_no = key[0]
         plan = st["plan"]
         st["step_ptr"].zero_()
         evs = []
@@ -89,55 +155,103 @@ def roofline_leg(imagen, batch: int, device):
                 lib.imagen_event_record(e0, h)
                 _abi.check(lib.imagen_launch(kind, ctypes.addressof(struct), h))
                 lib.imagen_event_record(e1, h)
-                evs.append((struct.cfg, igemm_flops(struct), e0, e1))
+                evs.append((struct.cfg, igemm_flops(struct), igemm_bytes(struct), (stage_no, label), e0, e1))
             else:
                 _abi.check(lib.imagen_launch(kind, ctypes.addressof(struct), h))
         torch.cuda.synchronize()
-        for cfg, fl, e0, e1 in evs:
+        for cfg, fl, by, ident, e0, e1 in evs:
             ms = ctypes.c_float()
             lib.imagen_event_elapsed_ms(e0, e1, ctypes.byref(ms))
-            d = per_cfg.setdefault(cfg, [0, 0.0, 0.0])
-            d[0] += 1
-            d[1] += fl
-            d[2] += ms.value * 1e-3
+            bound = "mfma" if fl / by >= RIDGE else "hbm"
+            d = groups.setdefault((bound, cfg), dict(n=0, fl=0.0, by=0.0, sec=0.0, ids=[]))
+            d["n"] += 1
+            d["fl"] += fl
+            d["by"] += by
+            d["sec"] += ms.value * 1e-3
+            d["ids"].append(ident)
             lib.imagen_event_destroy(e0)
             lib.imagen_event_destroy(e1)
-    # dominant symbol = the tile configuration with the largest total time
-    cfg, (n, fl, sec) = max(per_cfg.items(), key=lambda kv: kv[1][2])
     tab = ops.cfg_table()
-    achieved = fl / sec / 1e12
-    # HBM traffic per launch of that symbol from the committed PMC summaries (separate FETCH_SIZE / WRITE_SIZE passes of
-    # `rocprofv3 --pmc`, tools/pmc_summary.py); KiB units, FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B)
-    traffic = None
-    try:
-        fetch = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_fetch.json")))
-        write = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_write.json")))
-        mi, ni, wm, wn, g = CFG_TEMPLATE[cfg]
-        pat = f"igemm_kernel<{mi}, {ni}, {wm}, {wn}, {g},"
-        fs = [(v["launches"], v.get("FETCH_SIZE", 0.0)) for k, v in fetch.items() if pat in k]
-        ws = [(v["launches"], v.get("WRITE_SIZE", 0.0)) for k, v in write.items() if pat in k]
-        if fs and ws:
-            favg = sum(a * b for a, b in fs) / sum(a for a, _ in fs)
-            wavg = sum(a * b for a, b in ws) / sum(a for a, _ in ws)
-            traffic = round((2.0 * favg + wavg) * 1024.0)
-    except (OSError, ValueError, KeyError):
-        pass
-    summary = {str(c): {"launches": v[0], "tflops": round(v[1] / max(v[2], 1e-12) / 1e12, 1), "ms_total": round(v[2] * 1e3, 3)}
-               for c, v in sorted(per_cfg.items())}
-    return {
-        "bound": "mfma", "achieved": round(achieved, 1), "peak": MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(achieved / MFMA_PEAK_TFLOPS, 4),
-        "traffic": traffic,
-        "kernel": f"{'conv_lds_kernel' if tab[cfg][3] else 'igemm_kernel'} cfg {cfg} ({tab[cfg][0]} px x {tab[cfg][1]} cout tile, G={tab[cfg][2]})",
-        "launches_per_denoiser_step_pair": n, "avg_launch_us": round(sec / n * 1e6, 2), "avg_launch_gflop": round(fl / n / 1e9, 3),
-        "per_cfg": summary,
-    }
+    fam_name = {0: "igemm_kernel", 1: "conv_lds_kernel", 2: "conv_dma_kernel"}
+
+    def describe(bound):
+        cands = {k: v for k, v in groups.items() if k[0] == bound}
+        if not cands:
+            return None
+        (_, cfg), g = max(cands.items(), key=lambda kv: kv[1]["sec"])
+        traffic = mfma_util = None
+        if pmc:
+            rows = [pmc[i] for i in g["ids"] if i in pmc]
+            if rows and all("FETCH_SIZE" in r and "WRITE_SIZE" in r for r in rows):
+                # KiB units; FETCH_SIZE doubled: gfx950 counts a 128-byte request as 64 bytes (MI355X_MICROARCH.md, HBM section)
+                traffic = round(sum((2.0 * r["FETCH_SIZE"] + r["WRITE_SIZE"]) * 1024.0 for r in rows) / len(rows))
+            if rows and all("SQ_VALU_MFMA_BUSY_CYCLES" in r and r.get("GRBM_GUI_ACTIVE") for r in rows):
+                # MFMA-busy cycles summed over the 1024 SIMDs / (kernel cycles x 1024); GRBM_GUI_ACTIVE is summed over the 8 XCDs
+                mfma_util = round(sum(r["SQ_VALU_MFMA_BUSY_CYCLES"] / (r["GRBM_GUI_ACTIVE"] / 8.0 * 1024.0) for r in rows) / len(rows), 4)
+        if bound == "mfma":
+            ach, peak, unit = g["fl"] / g["sec"] / 1e12, MFMA_PEAK_TFLOPS, "TFLOP/s"
+        else:
+            ach, peak, unit = g["by"] / g["sec"] / 1e9, HBM_PEAK_GBS, "GB/s"
+        return {"bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": traffic,
+                "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench.py invocation" if traffic is not None else None,
+                "mfma_busy_frac": mfma_util,
+                "kernel": f"{fam_name[tab[cfg][3]]} cfg {cfg} ({tab[cfg][0]} px x {tab[cfg][1]} cout tile, G={tab[cfg][2]})",
+                "launches_per_denoiser_step_pair": g["n"], "avg_launch_us": round(g["sec"] / g["n"] * 1e6, 2),
+                "avg_launch_gflop": round(g["fl"] / g["n"] / 1e9, 3), "avg_launch_algorithmic_bytes": round(g["by"] / g["n"]),
+                "timing": "HIP events around each eager launch of one denoiser step per stage (cold caches, as inside the sampling loop)"}
+
+    mf, hb = describe("mfma"), describe("hbm")
+    tsum = lambda b: sum(v["sec"] for k, v in groups.items() if k[0] == b)
+    # "roofline" = the single (bound, tile configuration) group with the largest total time; the other bound's dominant group beside it
+    top_bound = max(groups.items(), key=lambda kv: kv[1]["sec"])[0][0]
+    main, other = (mf, hb) if top_bound == "mfma" else (hb, mf)
+    main = dict(main)
+    main["share_of_igemm_time"] = {"mfma_bound_launches": round(tsum("mfma") / (tsum("mfma") + tsum("hbm")), 3),
+                                   "hbm_bound_launches": round(tsum("hbm") / (tsum("mfma") + tsum("hbm")), 3)}
+    main["per_cfg"] = {f"{b}:{c}": {"launches": v["n"], "tflops": round(v["fl"] / max(v["sec"], 1e-12) / 1e12, 1),
+                                    "gbytes_per_s": round(v["by"] / max(v["sec"], 1e-12) / 1e9, 1), "ms_total": round(v["sec"] * 1e3, 3)}
+                       for (b, c), v in sorted(groups.items())}
+    return main, other
+
+
+def cpu_reference_leg(batch: int, steps: int = 2):
+    """The LIVE reference (imagen_pytorch at /root/reference, imported through oracle/ref_shim.py) sampling the same cascade on the
+    host cores: `steps` DDPM steps per stage at batch `batch` with CFG 3, extrapolated to 1000.  Only where the reference tree
+    exists (the build container) — it cannot travel to the GPU box, which times the oracle port instead."""
+    from oracle import ref_shim
+
+    ip = ref_shim.load_reference("imagen_pytorch")
+    threads = min(os.cpu_count() or 1, 64)
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    u1, u2 = ip.Unet(**README_U1), ip.Unet(**README_U2)
+    imagen = ip.Imagen((u1, u2), image_sizes=(64, 256), timesteps=steps, cond_drop_prob=0.1).eval()
+    te = torch.randn(batch, 256, 768)
+    t0 = time.time()
+    with torch.no_grad():
+        out = imagen.sample(text_embeds=te, cond_scale=3.0, use_tqdm=False)
+    dt = time.time() - t0
+    assert tuple(out.shape) == (batch, 3, 256, 256)
+    T = 1000
+    return {"value": batch / (dt / steps * T), "unit": "images/s", "cores": threads, "kind": "reference",
+            "sample": f"lucidrains/imagen-pytorch Imagen.sample on CPU (fp32), README unet1+unet2 64->256, batch {batch}, CFG 3.0, {steps} DDPM steps "
+                      f"per stage in {dt:.1f} s, linearly extrapolated to {T} steps/stage"}
 
 
 def cpu_baseline_leg(imagen, batch: int):
-    """The oracle ("port" of the reference path, fp32 torch CPU) for one DDPM step per stage, extrapolated."""
+    """The reference itself where its tree is present, else the oracle ("port" of the reference path, fp32 torch CPU) for one DDPM
+    step per stage, extrapolated."""
+    try:
+        from oracle import ref_shim
+        if ref_shim.reference_available():
+            return cpu_reference_leg(batch)
+    except Exception as e:  # noqa: BLE001 — fall back to the port
+        print(f"[bench] live reference unavailable ({e}); timing the oracle port", file=sys.stderr)
     from oracle import sampler_oracle as so
     from oracle import unet_oracle as uo
 
+    if imagen is None:
+        imagen = build_imagen(1000, "cpu")
     threads = min(os.cpu_count() or 1, 64)   # oneDNN convs stop scaling (and can thrash) far beyond this on many-core hosts
     torch.set_num_threads(threads)
     torch.manual_seed(0)
@@ -168,13 +282,18 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU (BASELINE: 8)")
     ap.add_argument("--timesteps", type=int, default=1000, help="DDPM steps per stage (BASELINE: 1000); other values are NOT the headline metric")
-    ap.add_argument("--mode", choices=("sequential", "pipeline", "lanes"), default=os.environ.get("IMAGEN_BENCH_MODE", "pipeline"),
+    ap.add_argument("--mode", choices=("sequential", "pipeline", "lanes"), default=os.environ.get("IMAGEN_BENCH_MODE", "lanes"),
                     help="how successive batches are scheduled on the GPU: one sample() after the other | cascade stages overlapped across "
                          "batches (Imagen.sample_pipelined) | --lanes whole cascades side by side (one thread + stream each)")
-    ap.add_argument("--lanes", type=int, default=2)
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("IMAGEN_BENCH_LANES", "3")))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic / mfma_busy_frac = null)")
+    ap.add_argument("--cpu-baseline-only", action="store_true", help="time the CPU baseline leg only (no GPU needed) and print its JSON")
     args = ap.parse_args()
+    if args.cpu_baseline_only:
+        print(json.dumps(cpu_baseline_leg(None, args.batch)), flush=True)
+        return
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -245,11 +364,13 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    passes(0, args.warmup)
-    log(f"{args.warmup} warmup passes done ({args.mode})")
+    # every lane's stages / graphs are built by the warm-up (a lane only exists once a batch has run on it)
+    n_warm = max(args.warmup, min(args.lanes, args.steps)) if args.mode == "lanes" else args.warmup
+    passes(0, n_warm)
+    log(f"{n_warm} warmup passes done ({args.mode})")
     fence()
     t0 = time.perf_counter()
-    out = passes(args.warmup, args.steps)
+    out = passes(n_warm, args.steps)
     fence()
     elapsed = time.perf_counter() - t0
     log(f"timed region done: {elapsed:.2f}s for {args.steps} passes")
@@ -265,7 +386,7 @@ def main():
         headline = args.timesteps == 1000 and B == 8
         rec = {
             "metric": "images/sec (64->256 cascade, 1000 steps, bs=8)" if headline else f"images/sec (64->256 cascade, {args.timesteps} steps, bs={B}) [NOT the headline config]",
-            "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": round(value, 4), "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": n_warm,
             "ms_per_step": round(elapsed / args.steps * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f16", "data": "synthetic",
             "config": {"workload": "C3: README unet1 (dim 32, 64^2) + unet2 (dim 32, 256^2, lowres_cond) cascade, "
@@ -280,8 +401,19 @@ def main():
             "path_tflops_reference_count": round(value * FLOPS_PER_IMAGE_REFERENCE * (args.timesteps / 1000) / 1e12, 1),
             "path_frac_of_mfma_peak": round(value * FLOPS_PER_IMAGE_REFERENCE * (args.timesteps / 1000) / 1e12 / (MFMA_PEAK_TFLOPS * world), 4),
         }
+        if world == 1 and args.mode != "sequential":
+            # the same cascade as ONE request at a time (latency view): a single sequential pass, outside the timed region
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            one_pass(n_warm + args.steps)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t1
+            rec["sequential"] = {"ms_per_step": round(dt * 1e3, 2), "value": round(B / dt, 4), "unit": "images/s",
+                                 "note": "one sample() call at a time (no overlap between batches), measured once after the timed region"}
+            log("sequential pass done")
         if world == 1 and not args.no_roofline:
-            rec["roofline"] = roofline_leg(imagen, B, device)
+            pmc = None if args.no_pmc else pmc_traffic_leg(log)
+            rec["roofline"], rec["roofline_other_bound"] = roofline_leg(imagen, B, device, pmc)
             log("roofline leg done")
         if world == 1 and not args.no_cpu_baseline:
             rec["cpu_baseline"] = cpu_baseline_leg(imagen, B)

@@ -164,11 +164,25 @@ def _load_ema_weights(imagen, loaded: dict, strict: bool = True):
         unet.load_state_dict(sd, strict=strict)               # utils.py:57-58
 
 
-def load_imagen_from_checkpoint(checkpoint_path, load_weights: bool = True, load_ema_if_available: bool = False):
+def _load_checkpoint_file(path, trust_checkpoint: bool):
+    """torch.load restricted to tensors / plain containers (the trainer's dict holds nothing else); a checkpoint that needs the
+    full unpickler (arbitrary code execution) is only read with an explicit `trust_checkpoint=True`."""
+    import pickle
+    try:
+        return torch.load(str(path), map_location='cpu', weights_only=True)
+    except (pickle.UnpicklingError, RuntimeError) as e:
+        if not trust_checkpoint:
+            raise RuntimeError(f'{path} holds objects beyond tensors and plain containers; pass trust_checkpoint=True to unpickle it '
+                               f'(this executes code stored in the file): {e}') from e
+        return torch.load(str(path), map_location='cpu', weights_only=False)
+
+
+def load_imagen_from_checkpoint(checkpoint_path, load_weights: bool = True, load_ema_if_available: bool = False, *,
+                                trust_checkpoint: bool = False):
     """utils.py:15-61.  Returns the model on CPU; move it with `.to('cuda')` before `.sample()`."""
     model_path = Path(checkpoint_path)
     assert model_path.exists(), f'checkpoint not found at {str(model_path.resolve())}'
-    loaded = torch.load(str(model_path), map_location='cpu', weights_only=False)
+    loaded = _load_checkpoint_file(model_path, trust_checkpoint)
     imagen_params, imagen_type = loaded.get('imagen_params'), loaded.get('imagen_type')
     if imagen_type not in ('original', 'elucidated'):
         raise ValueError(f'unknown imagen type {imagen_type} - you need to instantiate your Imagen with configurations, '
@@ -186,7 +200,8 @@ def load_imagen_from_checkpoint(checkpoint_path, load_weights: bool = True, load
     return imagen
 
 
-def load_trainer_checkpoint(imagen, path, *, use_ema: bool = False, strict: bool = True, noop_if_not_exist: bool = False) -> Optional[dict]:
+def load_trainer_checkpoint(imagen, path, *, use_ema: bool = False, strict: bool = True, noop_if_not_exist: bool = False,
+                            trust_checkpoint: bool = False) -> Optional[dict]:
     """`ImagenTrainer.load(path, only_model=True, strict=strict)` (tr.py:743-768) for an already constructed model — the case of
     checkpoints saved without a config (no `imagen_params`): the caller builds `Imagen(...)` with the training-time kwargs and
     this loads `model` (and, with use_ema, overwrites every unet with its EMA copy, as the trainer samples with, tr.py:949-959).
@@ -196,7 +211,7 @@ def load_trainer_checkpoint(imagen, path, *, use_ema: bool = False, strict: bool
         print(f'trainer checkpoint not found at {str(path)}')
         return None
     assert path.exists(), f'{path} does not exist'
-    loaded = torch.load(str(path), map_location='cpu', weights_only=False)
+    loaded = _load_checkpoint_file(path, trust_checkpoint)
     _load_model_weights(imagen, loaded, strict)
     if use_ema:
         assert 'ema' in loaded

@@ -35,8 +35,36 @@ static inline int imagen_hip_status(const char* what) {
 // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division: the staging prologue of the C=32 layers is VALU-bound
 // (tools/igemm_probe.py ablations), and SiLU runs once per staged element.  exp2 with the log2(e) fold saves the v_mul of __expf.
 __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)); }
-__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752f)); }
+// exact-erf GELU (nn.GELU default, ip.py:413) with erfc by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far inside the fp16 output
+// rounding): libm's erff is ~60 instructions per element and was measured at 18k of the 27k cycles of a FeedForward GEMM's tile
+// (tools/insitu_trace.py, ff.lin1); this form is one v_rcp, one v_exp and seven multiply-adds
+__device__ __forceinline__ float gelu_f(float v) {
+  const float x = fabsf(v) * 0.70710678118654752f;
+  const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * x);
+  const float poly = t * (0.254829592f + t * (-0.284496736f + t * (1.421413741f + t * (-1.453152027f + t * 1.061405429f))));
+  const float ec = poly * __builtin_amdgcn_exp2f(-1.4426950408889634f * x * x);   // erfc(|x|)
+  return 0.5f * v * (v >= 0.f ? 2.0f - ec : ec);
+}
 __device__ __forceinline__ float sigmoid_f(float v) { return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)); }
+
+// device code bytes of a kernel of this library by mangled symbol name, 0 if unknown (codesize.hip)
+unsigned imagen_kernel_code_bytes(const char* mangled);
+
+// Instruction warm-up, first statement of a kernel: read the kernel's own code range as data (one dword per 128-byte line, all
+// threads of the workgroup at once).  Consecutive launches of the denoiser step run different kernels, so a kernel otherwise
+// starts with a serial chain of instruction-cache misses to HBM; after this single parallel round trip they are L2 hits.  `code_bytes`
+// comes from the launcher (0 = skip); the last KiB is left out so the range never leaves the function by more than it started
+// behind its entry.  Returns a value that the caller must "use" (imagen_code_warm_sink) once its own first loads have landed.
+__device__ __forceinline__ unsigned imagen_code_warm(unsigned code_bytes, int tid, int nthreads) {
+  unsigned v = 0;
+  if (code_bytes > 1024u) {
+    const char* pc = reinterpret_cast<const char*>(__builtin_amdgcn_s_getpc());
+    for (unsigned off = (unsigned)tid * 128u; off + 1024u < code_bytes; off += (unsigned)nthreads * 128u)
+      v ^= *reinterpret_cast<const volatile unsigned*>(pc + off);
+  }
+  return v;
+}
+__device__ __forceinline__ void imagen_code_warm_sink(unsigned v) { asm volatile("" ::"v"(v)); }
 
 // op launchers (one per translation unit)
 int launch_igemm(const ImagenIgemmParams* p, hipStream_t s);

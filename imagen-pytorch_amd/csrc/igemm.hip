@@ -13,6 +13,7 @@
 // groups (lane>>5 selects) feed one K=16 MFMA.  A "phase" = (tile, chunk); one s_barrier per phase hands an LDS buffer from the
 // producers to the consumers.
 #include <algorithm>
+#include <cstdio>
 #include <cstdlib>
 #include <type_traits>
 #include <utility>
@@ -134,6 +135,7 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
   const int tid = threadIdx.x;
   const bool producer = tid >= 256;   // wave-uniform role
   const int rtid = tid & 255;         // thread index inside the role
+  const unsigned warm = imagen_code_warm(((unsigned)p.dbg >> 16) << 8, tid, 512);   // (code size / 256 rides in the upper half of dbg)
 
   // ---- the tile list of this workgroup
   const int tilesX = (p.OW + p.TW - 1) / p.TW;
@@ -342,6 +344,7 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
     load_affine(B);
     advance();
     lds_barrier();          // phase 0 is in buffer 0
+    imagen_code_warm_sink(warm);
     int tn = 0;   // trace events per phase: loop top | loads issued | set written | before the barrier
     for (int q = 0; q < n_phases; q += 2) {
       // consumers: phase q out of buf0
@@ -772,7 +775,31 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
   // ---- main loop: tiles x chunks, one hand-over barrier per phase
   TileCoord tc = decode(t_cursor);
   prime_weights(tc.n0);
+  // Epilogue operands of the first tile (residual | gate * addend): touched NOW, one dword per pixel row of this wave's channel
+  // fragment(s), so that the loads of the epilogue itself — dependent on nothing but issued after the last k step — find the lines
+  // (and the page translations) in place: in the denoiser step those loads were measured at 7-12k cycles per tile
+  // (tools/insitu_trace.py: to_time_cond, ff.lin2, res_conv), most of a small GEMM's run time.
+  unsigned warm_ep = 0;
+  if constexpr (GEN) {
+    const f16* eop = addend ? addend + (size_t)tc.b * p.bs_add : (res ? res + (size_t)tc.b * p.bs_res : nullptr);
+    const int eld = addend ? p.ld_add : p.ld_res;
+    if (eop) {
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int oy = tc.oy0 + pix_y[mi], ox = tc.ox0 + pix_x[mi];
+        const int opx = (oy < p.OH && ox < p.OW) ? oy * p.OW + ox : 0;
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni) {
+          const int co = min(tc.n0 + (wn * NI + ni) * 32 + 4 * half, p.Cout - 4);
+          warm_ep ^= *reinterpret_cast<const volatile unsigned*>(eop + (size_t)opx * eld + co);
+        }
+      }
+      if (addend) warm_ep ^= *reinterpret_cast<const volatile unsigned*>(p.gate + (size_t)tc.b * p.gate_stride + min(tc.n0 + wn * NI * 32 + (lane & 31), p.Cout - 1));
+    }
+  }
   lds_barrier();   // phase 0 staged
+  imagen_code_warm_sink(warm);
+  imagen_code_warm_sink(warm_ep);
   int cur = 0;
   while (true) {
     const int t_next = t_cursor + t_step;
@@ -837,11 +864,13 @@ int launch_gen(const ImagenIgemmParams& p, hipStream_t s) {
   const size_t lds = (size_t)2 * IT * Geo<G>::PS + (size_t)(4 * 32 * MI + kBiasLds) * sizeof(float) + 16;   // staging double buffer + epilogue scratch + bias + dummy
   IMAGEN_CHECK(lds <= 160 * 1024, "igemm: LDS tile %zu bytes too large", lds);
   auto kern = igemm_kernel<MI, NI, WM, WN, G, KSC, GEN>;
-  static bool attr_done = false;
-  if (!attr_done) {
+  static bool attr_done[16] = {};   // the attribute is per DEVICE (a process may sample on several GPUs)
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 16 || !attr_done[dev]) {
     hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (e != hipSuccess) { imagen_set_error("igemm: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    attr_done = true;
+    if (dev >= 0 && dev < 16) attr_done[dev] = true;
   }
   // persistent grid: what the chip holds at once (register- and LDS-limited workgroups per CU), evened out over the rounds
   const int tilesX = (p.OW + p.TW - 1) / p.TW, tilesY = (p.OH + p.TH - 1) / p.TH;
@@ -865,7 +894,17 @@ int launch_gen(const ImagenIgemmParams& p, hipStream_t s) {
     gx = (total + rounds - 1) / rounds;
     gx = std::min(resident, (gx + 7) / 8 * 8);     // multiple of 8: one contiguous tile range per XCD
   }
-  hipLaunchKernelGGL(kern, dim3(gx), dim3(512), lds, s, p);
+  // code size of this instantiation (for the kernel's instruction warm-up), looked up once by its mangled name
+  static const unsigned code_q = [] {
+    static const bool off = getenv("IMAGEN_CODE_WARM") && atoi(getenv("IMAGEN_CODE_WARM")) == 0;   // A/B switch
+    char name[160];
+    snprintf(name, sizeof(name), "_ZN12_GLOBAL__N_112igemm_kernelILi%dELi%dELi%dELi%dELi%dELi%dELb%dEEEv17ImagenIgemmParams", MI, NI, WM, WN, G, KSC,
+             GEN ? 1 : 0);
+    return off ? 0u : std::min(imagen_kernel_code_bytes(name) >> 8, 0xffffu);
+  }();
+  ImagenIgemmParams q = p;
+  q.dbg = (int)(((unsigned)q.dbg & 0xffffu) | (code_q << 16));
+  hipLaunchKernelGGL(kern, dim3(gx), dim3(512), lds, s, q);
   return imagen_hip_status("igemm launch");
 }
 

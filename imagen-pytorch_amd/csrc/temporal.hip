@@ -114,11 +114,13 @@ int launch_temporal_attention(const ImagenTemporalAttentionParams* p, hipStream_
   IMAGEN_CHECK(p->heads > 0 && p->B > 0 && p->P > 0, "temporal_attention: bad shape");
   const size_t items = (size_t)p->B * p->P;
   const size_t lds_bytes = (size_t)4 * 2 * (kMaxFrames + 1) * kKvRow * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
+  static bool attr_set[16] = {};   // per device
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 16 || !attr_set[dev]) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(temporal_attention_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
                               (int)lds_bytes);
-    attr_set = true;
+    if (dev >= 0 && dev < 16) attr_set[dev] = true;
   }
   hipLaunchKernelGGL(temporal_attention_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), lds_bytes, s, *p);
   return imagen_hip_status("temporal_attention");

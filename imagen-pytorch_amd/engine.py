@@ -94,7 +94,7 @@ def _fingerprint(unet) -> tuple:
 POST_NORM = int(os.environ.get("IMAGEN_POST_NORM", "1"))   # A/B switch: block2's prologue applied by block1's epilogue
 # ACT_PREP + all-DMA conv for the Blocks with at least this many output channels (the MFMA-bound layers: the prologue pass costs one
 # read + one write of the input, the conv kernel drops its staging instruction stream); 0 = never
-ACT_PREP_MIN_COUT = int(os.environ.get("IMAGEN_ACT_PREP_MIN_COUT", "128"))
+ACT_PREP_MIN_COUT = int(os.environ.get("IMAGEN_ACT_PREP_MIN_COUT", "0"))   # (measured in the model: the extra pass costs more than it saves — off)
 KV_BATCH = int(os.environ.get("IMAGEN_KV_BATCH", "1"))     # A/B switch: one launch for the context K/V rows of all attention sites
 
 

@@ -6,8 +6,10 @@ as one 2B-row batch)] + [CFG combine / x0 / exact 0.95-quantile / dynamic thresh
 captured ONCE into a hipGraph and replayed T times — the step index lives in a device counter that every
 sampler kernel (and the time embedding) reads, so replay needs no host-side parameter patching.
 
-Training (`forward`, p_losses), T5 text encoding (`texts=`), video, inpainting, init_images / skip_steps are
-outside the hot-path scope and raise.
+Implemented options: text embeddings or the T5 hook (`texts=`), classifier-free guidance, dynamic thresholding, init_images /
+skip_steps, inpainting (images), start/stop_at_unet_number, video cascades (Unet3D stages).  Training (`forward`, p_losses),
+cond_images / cond_video_frames / video inpainting raise.  Extensions beyond the reference signature: `noise_fn`,
+`seed`, `sample_offset` (batch sharding), `conditioning` handles, lanes (`with imagen.lane(i)`) and `sample_pipelined`.
 """
 from __future__ import annotations
 

@@ -273,10 +273,11 @@ class Unet(nn.Module):
         torch.save(dict(config=config, state_dict=state_dict), str(path))
 
     @classmethod
-    def hydrate_from_file(klass, path):
+    def hydrate_from_file(klass, path, trust_checkpoint: bool = False):
         path = Path(path)
         assert path.exists()
-        pkg = torch.load(str(path), weights_only=False)
+        from .checkpoint import _load_checkpoint_file
+        pkg = _load_checkpoint_file(path, trust_checkpoint)
         assert 'config' in pkg and 'state_dict' in pkg
         return klass.from_config_and_state_dict(pkg['config'], pkg['state_dict'])
 

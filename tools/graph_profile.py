@@ -51,7 +51,8 @@ def run(args):
                 desc = (f"{cin}->{p.Cout} k{p.KH} s{p.stride} @{p.H}x{p.W} B{p.B} cfg{p.cfg}{tab[p.cfg]} t{p.TH}x{p.TW}"
                         f"{' pro' if (p.pa or p.rs or p.ssq_a) else ''}{' gca' if p.gca_part else ''}")
                 cls += f" [{cin}->{p.Cout} k{p.KH} @{p.H}]"
-            rows.append(dict(kind=kind_name.get(kind, str(kind)), label=label, cls=cls, desc=desc, flops=fl, bytes=by))
+            rows.append(dict(kind=kind_name.get(kind, str(kind)), label=label, cls=cls, desc=desc, flops=fl, bytes=by,
+                             cfg=int(p.cfg) if kind == K_IGEMM else -1))
         out.append(dict(stage=str(sidx[:3]), ops=rows))
     json.dump(dict(steps=args.steps, stages=out), open(args.plan_out, "w"))
     print(f"wrote {args.plan_out}: " + ", ".join(f"{len(s['ops'])} ops" for s in out))
@@ -82,19 +83,18 @@ def find_period(names, lo, hi, reps, start):
     return -1, 0
 
 
-def analyze(args):
-    plan = json.load(open(args.plan))
-    rows = list(csv.DictReader(open(args.trace)))
-    ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in rows), key=lambda t: t[0])
-    names = [e[2] for e in ev]
+def join(names, plan):
+    """Per stage: (offset of the first replay in the dispatch list, kernels per replay, owner[i] = plan op of kernel i of a replay)."""
     steps = plan["steps"]
     start = 0
+    out = []
     for st in plan["stages"]:
         ops = st["ops"]
         n = len(ops)
         off, per = find_period(names, n, n + 12, steps, start)
         if off < 0:
-            print(f"stage {st['stage']}: no run of {steps} replays of ~{n} kernels found after dispatch {start} ({len(ev)} dispatches)")
+            print(f"stage {st['stage']}: no run of {steps} replays of ~{n} kernels found after dispatch {start} ({len(names)} dispatches)", file=sys.stderr)
+            out.append(None)
             continue
         # rotate the period so that it starts at the first op's kernel (the search may land mid-replay on a periodic tail)
         while not matches(ops[0]["kind"], names[off]) or not matches(ops[1]["kind"], names[off + 1]):
@@ -111,6 +111,72 @@ def analyze(args):
             else:
                 owner.append(-1)          # engine bookkeeping (step_advance)
         assert j == n - 1, (j, n, per)
+        out.append((off, per, owner))
+    return out
+
+
+def pmc_join(csv_path, plan):
+    """rocprofv3 --pmc counter_collection.csv of a `run` joined with its plan: per stage a list (one entry per plan op) of
+    {label, kind, desc, flops, bytes, <COUNTER>: value per launch averaged over the replays}."""
+    disp = {}
+    for r in csv.DictReader(open(csv_path)):
+        d = disp.setdefault(int(r["Dispatch_Id"]), [short(r["Kernel_Name"]), {}])
+        d[1][r["Counter_Name"]] = d[1].get(r["Counter_Name"], 0.0) + float(r["Counter_Value"])
+    order = [disp[k] for k in sorted(disp)]
+    names = [d[0] for d in order]
+    steps = plan["steps"]
+    res = []
+    for st, j in zip(plan["stages"], join(names, plan)):
+        if j is None:
+            res.append(None)
+            continue
+        off, per, owner = j
+        reps = range(1, steps - 1)
+        ops = [dict(o) for o in st["ops"]]
+        for r in reps:
+            for i in range(per):
+                if owner[i] < 0:
+                    continue
+                for c, v in order[off + r * per + i][1].items():
+                    ops[owner[i]][c] = ops[owner[i]].get(c, 0.0) + v / len(reps)
+        res.append(ops)
+    return res
+
+
+def pmc(args):
+    plan = json.load(open(args.plan))
+    res = pmc_join(args.csv_in, plan)
+    counters = sorted({k for ops in res if ops for o in ops for k in o if k.isupper()})
+    out = dict(counters=counters, note="per-launch averages over the graph replays of a short sampling run; FETCH_SIZE / WRITE_SIZE in KiB as rocprofv3 "
+               "reports them (gfx950: FETCH_SIZE counts 128-byte requests as 64 bytes, consumers double it)", stages=[])
+    for st, ops in zip(plan["stages"], res):
+        if not ops:
+            continue
+        by_kind = collections.defaultdict(lambda: collections.defaultdict(float))
+        for o in ops:
+            by_kind[o["kind"]]["launches"] += 1
+            for c in counters:
+                by_kind[o["kind"]][c] += o.get(c, 0.0)
+        igemm = [dict(label=o["label"], desc=o["desc"], flops=o["flops"], bytes=o["bytes"], **{c: round(o.get(c, 0.0), 2) for c in counters})
+                 for o in ops if o["kind"] == "igemm"]
+        out["stages"].append(dict(stage=st["stage"], by_kind={k: dict(v) for k, v in by_kind.items()}, igemm=igemm))
+    json.dump(out, open(args.out, "w"), indent=1)
+    for s_ in out["stages"]:
+        print("stage", s_["stage"], {k: {c: round(v, 1) for c, v in d.items()} for k, d in list(s_["by_kind"].items())[:4]})
+
+
+def analyze(args):
+    plan = json.load(open(args.plan))
+    rows = list(csv.DictReader(open(args.trace)))
+    ev = sorted(((int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in rows), key=lambda t: t[0])
+    names = [e[2] for e in ev]
+    steps = plan["steps"]
+    for st, jn in zip(plan["stages"], join(names, plan)):
+        if jn is None:
+            continue
+        off, per, owner = jn
+        ops = st["ops"]
+        n = len(ops)
         reps = range(1, steps - 1)        # the first replay follows host work; average the rest
         dur = [0.0] * (n + 1)
         gap = [0.0] * (n + 1)
@@ -162,8 +228,12 @@ def main():
     a.add_argument("plan")
     a.add_argument("--top", type=int, default=50)
     a.add_argument("--csv", default="")
+    c = sub.add_parser("pmc")
+    c.add_argument("csv_in")
+    c.add_argument("plan")
+    c.add_argument("out")
     args = ap.parse_args()
-    (run if args.cmd == "run" else analyze)(args)
+    dict(run=run, analyze=analyze, pmc=pmc)[args.cmd](args)
 
 
 if __name__ == "__main__":
