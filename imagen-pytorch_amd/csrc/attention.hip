@@ -14,17 +14,23 @@
 //   O^T[d][q]   += mfma_32x32x16(A = V^T rows (LDS, 2x ds_read_b64), B = P (registers, fp16))  4 MFMA
 // The key order of the PV contraction is chosen to match the S^T accumulator layout, so P never moves
 // between lanes.  K / V^T tiles are register-prefetched one tile ahead and double-buffered in LDS.
+#include <cstdlib>
 #include "common.h"
 
 namespace {
 
 constexpr int KT = 32;        // keys per tile
-constexpr int KSTR = 144;     // LDS bytes per K row   (128 + 16: conflict-free ds_read_b128)
+constexpr int KSTR = 144;     // LDS bytes per K row at head dim 64 (128 + 16: conflict-free ds_read_b128)
 constexpr int VSTR = 72;      // LDS bytes per V^T row (64 + 8: conflict-free ds_read_b64)
-constexpr int KBYTES = KT * KSTR;
-constexpr int VBYTES = 64 * VSTR;
 
+// D = head dim: 64 (every README config) or 32 (the reference's UnetConfig default, configs.py:48-49)
+template <int D>
 __global__ __launch_bounds__(256) void attention_kernel(const ImagenAttentionParams p) {
+  constexpr int KS = D / 16;            // K=16 steps of the S^T contraction
+  constexpr int DB = D / 32;            // 32-dim blocks of O^T
+  constexpr int KSTRD = 2 * D + 16;     // LDS bytes per K row
+  constexpr int KBYTES = KT * KSTRD;
+  constexpr int VBYTES = D * VSTR;
   __shared__ __attribute__((aligned(16))) char smem[2 * (KBYTES + VBYTES)];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
@@ -33,19 +39,19 @@ __global__ __launch_bounds__(256) void attention_kernel(const ImagenAttentionPar
   const int row_c = row < p.rows ? row : p.rows - 1;
 
   const f16* q = reinterpret_cast<const f16*>(p.q) + (size_t)b * p.q_bs + (size_t)hd * p.q_hs + (size_t)row_c * p.q_rs;
-  f16x8 qf[4];
+  f16x8 qf[KS];
 #pragma unroll
-  for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const f16x8*>(q + 16 * s + 8 * half);
-  if (p.q_scale) {   // fused QNORM (ip.py:559-560): this lane holds 32 of the row's 64 dims, lane ^ 32 the other 32
+  for (int s = 0; s < KS; ++s) qf[s] = *reinterpret_cast<const f16x8*>(q + 16 * s + 8 * half);
+  if (p.q_scale) {   // fused QNORM (ip.py:559-560): this lane holds half of the row's dims, lane ^ 32 the other half
     float ssq = 0.f;
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int s = 0; s < KS; ++s)
 #pragma unroll
       for (int j = 0; j < 8; ++j) ssq += (float)qf[s][j] * (float)qf[s][j];
     ssq += __shfl_xor(ssq, 32);
     const float inv = p.q_mult / fmaxf(sqrtf(ssq), 1e-12f);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
+    for (int s = 0; s < KS; ++s) {
       const float4 g0 = *reinterpret_cast<const float4*>(p.q_scale + 16 * s + 8 * half);
       const float4 g1 = *reinterpret_cast<const float4*>(p.q_scale + 16 * s + 8 * half + 4);
       const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
@@ -56,25 +62,30 @@ __global__ __launch_bounds__(256) void attention_kernel(const ImagenAttentionPar
 
   const f16* kg = reinterpret_cast<const f16*>(p.k) + (size_t)b * p.k_bs + (size_t)hd * p.k_hs;
   const f16* vg = reinterpret_cast<const f16*>(p.vt) + (size_t)b * p.vt_bs + (size_t)hd * p.vt_hs;
-  // staging roles: K tile 32 keys x 8 groups of 8 dims; V^T tile 64 dims x 4 groups of 8 keys
-  const int sk_key = tid >> 3, sk_dg = tid & 7;
-  const int sv_d = tid >> 2, sv_kg = tid & 3;
+  // staging roles: K tile 32 keys x D/8 groups of 8 dims; V^T tile D dims x 4 groups of 8 keys (D = 32: threads 0-127 only)
+  const bool stager = tid < 4 * D;
+  const int sk_key = tid / (D / 8), sk_dg = tid % (D / 8);
+  const int sv_d = (tid >> 2) & (D - 1), sv_kg = tid & 3;
 
-  uint4 k_stage, v_stage;
+  uint4 k_stage = make_uint4(0, 0, 0, 0), v_stage = make_uint4(0, 0, 0, 0);
   auto tile_load = [&](int kt0) {
-    k_stage = *reinterpret_cast<const uint4*>(kg + (size_t)(kt0 + sk_key) * p.k_rs + sk_dg * 8);
-    v_stage = *reinterpret_cast<const uint4*>(vg + (size_t)sv_d * p.vt_ds + kt0 + sv_kg * 8);
+    if (stager) {
+      k_stage = *reinterpret_cast<const uint4*>(kg + (size_t)(kt0 + sk_key) * p.k_rs + sk_dg * 8);
+      v_stage = *reinterpret_cast<const uint4*>(vg + (size_t)sv_d * p.vt_ds + kt0 + sv_kg * 8);
+    }
   };
   auto tile_store = [&](char* buf) {
-    *reinterpret_cast<uint4*>(buf + sk_key * KSTR + sk_dg * 16) = k_stage;
-    uint2* vd = reinterpret_cast<uint2*>(buf + KBYTES + sv_d * VSTR + sv_kg * 16);
-    vd[0] = make_uint2(v_stage.x, v_stage.y);
-    vd[1] = make_uint2(v_stage.z, v_stage.w);
+    if (stager) {
+      *reinterpret_cast<uint4*>(buf + sk_key * KSTRD + sk_dg * 16) = k_stage;
+      uint2* vd = reinterpret_cast<uint2*>(buf + KBYTES + sv_d * VSTR + sv_kg * 16);
+      vd[0] = make_uint2(v_stage.x, v_stage.y);
+      vd[1] = make_uint2(v_stage.z, v_stage.w);
+    }
   };
 
-  f32x16 oacc[2];
+  f32x16 oacc[DB];
 #pragma unroll
-  for (int db = 0; db < 2; ++db)
+  for (int db = 0; db < DB; ++db)
 #pragma unroll
     for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
   float m_run = -1.0e30f, l_run = 0.f;
@@ -95,8 +106,8 @@ __global__ __launch_bounds__(256) void attention_kernel(const ImagenAttentionPar
 #pragma unroll
     for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const f16x8 kf = *reinterpret_cast<const f16x8*>(kb + l31 * KSTR + (16 * s + 8 * half) * 2);
+    for (int s = 0; s < KS; ++s) {
+      const f16x8 kf = *reinterpret_cast<const f16x8*>(kb + l31 * KSTRD + (16 * s + 8 * half) * 2);
       sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc, 0, 0, 0);
     }
     // ---- mask the ragged last tile, online softmax (lane = query; this lane holds 16 of the tile's 32 keys)
@@ -122,7 +133,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const ImagenAttentionPar
     }
     l_run = l_run * alpha + psum;
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
+    for (int db = 0; db < DB; ++db)
 #pragma unroll
       for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
 
@@ -130,7 +141,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const ImagenAttentionPar
 #pragma unroll
     for (int s = 0; s < 2; ++s) {
 #pragma unroll
-      for (int db = 0; db < 2; ++db) {
+      for (int db = 0; db < DB; ++db) {
         const char* vrow = vb + (32 * db + l31) * VSTR + (16 * s + 4 * half) * 2;
         const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
         const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16);
@@ -143,6 +154,377 @@ __global__ __launch_bounds__(256) void attention_kernel(const ImagenAttentionPar
     if (more) tile_store(smem + (cur ^ 1) * (KBYTES + VBYTES));
     __syncthreads();
     cur ^= 1;
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  if (row < p.rows) {
+    f16* o = reinterpret_cast<f16*>(p.o) + (size_t)b * p.o_bs + (size_t)hd * p.o_hs + (size_t)row * p.o_rs;
+#pragma unroll
+    for (int db = 0; db < DB; ++db)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        f16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (f16)(oacc[db][4 * qd + e] * inv);
+        *reinterpret_cast<f16x4*>(o + 32 * db + 8 * qd + 4 * half) = v;
+      }
+  }
+}
+
+// ---- second tiling: 8 waves (256 query rows) per workgroup, 64-key tiles.
+// Per tile and wave 8 + 8 MFMAs behind ONE workgroup barrier (the 4-wave / 32-key kernel above: 4 + 4), the K / V^T tile is staged
+// once for twice the queries, the ragged-tile mask is applied to the last tile only, exponentials are raw v_exp_f32, and the
+// accumulator rescale (32 multiplies per lane) is skipped while no lane of the wave has seen a new maximum — after the first few tiles
+// of a row that is almost always.  Used when a (batch, head) has at least 256 query rows.
+constexpr int KT2 = 64;
+constexpr int VSTR2 = 144;                 // LDS bytes per V^T row (128 + 16: conflict-free ds_read_b128)
+constexpr int KBYTES2 = KT2 * KSTR;
+constexpr int VBYTES2 = 64 * VSTR2;
+
+// MINW: waves per SIMD the register budget is capped for (4: two workgroups per CU; 2: one, no spills).  SUB: 64-key tiles per
+// workgroup barrier — a staging buffer holds SUB tiles, so with SUB = 2 the 8 waves meet half as often (counters of SUB = 1 on the
+// 1024-token site: 37 % of the wave cycles parked at s_waitcnt / s_barrier, tools/gpu_r2_y.sh).
+template <int MINW, int SUB>
+__global__ __launch_bounds__(512, MINW) void attention_kernel_w8(const ImagenAttentionParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 buffers x SUB tiles x (KBYTES2 + VBYTES2)
+  constexpr int SLOT = KBYTES2 + VBYTES2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int row = blockIdx.x * 256 + wave * 32 + l31;
+  const int row_c = row < p.rows ? row : p.rows - 1;
+
+  const f16* q = reinterpret_cast<const f16*>(p.q) + (size_t)b * p.q_bs + (size_t)hd * p.q_hs + (size_t)row_c * p.q_rs;
+  f16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const f16x8*>(q + 16 * s + 8 * half);
+  if (p.q_scale) {   // fused QNORM (ip.py:559-560)
+    float ssq = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ssq += (float)qf[s][j] * (float)qf[s][j];
+    ssq += __shfl_xor(ssq, 32);
+    const float inv = p.q_mult / fmaxf(sqrtf(ssq), 1e-12f);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float4 g0 = *reinterpret_cast<const float4*>(p.q_scale + 16 * s + 8 * half);
+      const float4 g1 = *reinterpret_cast<const float4*>(p.q_scale + 16 * s + 8 * half + 4);
+      const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[s][j] = (f16)((float)qf[s][j] * inv * g[j]);
+    }
+  }
+
+  const f16* kg = reinterpret_cast<const f16*>(p.k) + (size_t)b * p.k_bs + (size_t)hd * p.k_hs;
+  const f16* vg = reinterpret_cast<const f16*>(p.vt) + (size_t)b * p.vt_bs + (size_t)hd * p.vt_hs;
+  // staging roles (512 threads, one 16-byte item each per tile): K tile 64 keys x 8 groups of 8 dims; V^T tile 64 dims x 8 groups of 8
+  // keys.  K / V^T are zero-padded to a multiple of 32 keys by KV_PREP: the second half of the last 64-key tile may lie beyond the
+  // padding, its loads are redirected to the tile's first half (masked below, never used); tiles past the end re-read tile 0
+  const int sk_key = tid >> 3, sk_dg = tid & 7;
+  const int sv_d = tid >> 3, sv_kg = tid & 7;
+  const int Jpad = (p.J + 31) & ~31;
+  const int ntiles = (p.J + KT2 - 1) / KT2;
+
+  uint4 ks0, vs0, ks1, vs1;   // staged tile(s) (scalars, not arrays: the lambdas below would otherwise pin them in scratch)
+  auto one_load = [&](int t, uint4& ks, uint4& vs) __attribute__((always_inline)) {
+    const int kt0 = t < ntiles ? t * KT2 : 0;
+    const int kk = kt0 + sk_key < Jpad ? kt0 + sk_key : kt0;
+    const int kv = kt0 + sv_kg * 8 < Jpad ? kt0 + sv_kg * 8 : kt0;
+    ks = *reinterpret_cast<const uint4*>(kg + (size_t)kk * p.k_rs + sk_dg * 8);
+    vs = *reinterpret_cast<const uint4*>(vg + (size_t)sv_d * p.vt_ds + kv);
+  };
+  auto one_store = [&](char* buf, const uint4& ks, const uint4& vs) __attribute__((always_inline)) {
+    *reinterpret_cast<uint4*>(buf + sk_key * KSTR + sk_dg * 16) = ks;
+    // keys of a 16-key group are stored in the order [0-3, 8-11, 4-7, 12-15]: the 8 keys a lane contracts in one PV step (the keys
+    // of 8 consecutive S^T accumulator registers: 4h + {0-3, 8-11}) are then contiguous — one ds_read_b128 instead of two b64
+    char* vrow = buf + KBYTES2 + sv_d * VSTR2 + (sv_kg >> 1) * 32 + (sv_kg & 1) * 8;
+    *reinterpret_cast<uint2*>(vrow) = make_uint2(vs.x, vs.y);
+    *reinterpret_cast<uint2*>(vrow + 16) = make_uint2(vs.z, vs.w);
+  };
+  auto group_load = [&](int t0) __attribute__((always_inline)) {
+    one_load(t0, ks0, vs0);
+    if constexpr (SUB > 1) one_load(t0 + 1, ks1, vs1);
+  };
+  auto group_store = [&](char* buf) __attribute__((always_inline)) {
+    one_store(buf, ks0, vs0);
+    if constexpr (SUB > 1) one_store(buf + SLOT, ks1, vs1);
+  };
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
+  float m_run = -1.0e30f, l_run = 0.f;
+
+  group_load(0);
+  group_store(smem);
+  __syncthreads();
+  int cur = 0;
+  for (int t0 = 0; t0 < ntiles; t0 += SUB) {
+    const bool more = t0 + SUB < ntiles;
+    if (more) group_load(t0 + SUB);
+#pragma unroll
+    for (int u = 0; u < SUB; ++u) {
+      const int t = t0 + u;
+      if (u > 0 && t >= ntiles) continue;   // (wave-uniform)
+      const char* kb = smem + (cur * SUB + u) * SLOT;
+      const char* vb = kb + KBYTES2;
+
+      // ---- S^T = K . Q^T for the two 32-key halves of the tile
+      f32x16 sacc[2];
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sacc[h2][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 4; ++s) {
+          const f16x8 kf = *reinterpret_cast<const f16x8*>(kb + (32 * h2 + l31) * KSTR + (16 * s + 8 * half) * 2);
+          sacc[h2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[s], sacc[h2], 0, 0, 0);
+        }
+      }
+      if (t == ntiles - 1) {   // ragged last tile: keys >= J contribute nothing
+#pragma unroll
+        for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = t * KT2 + 32 * h2 + 4 * half + (r & 3) + 8 * (r >> 2);
+            if (key >= p.J) sacc[h2][r] = -1.0e30f;
+          }
+      }
+      // ---- online softmax (lane = query; this lane holds 32 of the tile's 64 keys, lane ^ 32 the others)
+      float mx = sacc[0][0];
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sacc[h2][r]);
+      mx = fmaxf(mx, __shfl_xor(mx, 32));
+      const float m_new = fmaxf(m_run, mx);
+      if (__any(m_new > m_run)) {   // wave-uniform: rescale only when some row of the wave has a new maximum
+        const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+        l_run *= alpha;
+#pragma unroll
+        for (int db = 0; db < 2; ++db)
+#pragma unroll
+          for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+        m_run = m_new;
+      }
+      float psum = 0.f;
+      f16x8 pf[4];
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const float e = __builtin_amdgcn_exp2f(sacc[h2][r] - m_run);
+          psum += e;
+          pf[2 * h2 + (r >> 3)][r & 7] = (f16)e;
+        }
+      l_run += psum;
+
+      // ---- O^T += V^T . P^T   (k-step s of key half h2 covers the keys of accumulator registers 8s..8s+7 of sacc[h2])
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+#pragma unroll
+          for (int db = 0; db < 2; ++db) {
+            const f16x8 vf = *reinterpret_cast<const f16x8*>(vb + (32 * db + l31) * VSTR2 + (32 * h2 + 16 * s + 8 * half) * 2);
+            oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[2 * h2 + s], oacc[db], 0, 0, 0);
+          }
+        }
+    }
+    if (more) group_store(smem + (cur ^ 1) * SUB * SLOT);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  if (row < p.rows) {
+    f16* o = reinterpret_cast<f16*>(p.o) + (size_t)b * p.o_bs + (size_t)hd * p.o_hs + (size_t)row * p.o_rs;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        f16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (f16)(oacc[db][4 * qd + e] * inv);
+        *reinterpret_cast<f16x4*>(o + 32 * db + 8 * qd + 4 * half) = v;
+      }
+  }
+}
+
+// ---- third tiling: the 8-wave / 64-key kernel software-pipelined INSIDE each wave.
+// The softmax of a tile is ~0.9k VALU cycles per wave (32 quarter-rate v_exp_f32 + adds + converts), its 16 MFMAs 0.5k matrix-pipe
+// cycles; issued one after the other (kernel above) the two pipes take turns.  Here the 8 S^T MFMAs of tile t+1 are issued between
+// the exponentials of tile t, and the running-max bookkeeping of tile t+1 between the 8 PV MFMAs of tile t: an in-order wave keeps
+// issuing VALU while its MFMA executes, so both pipes work at once.  Further:
+//   * the S^T accumulators start at -m_run (the C operand of the first MFMA), so exp2 takes them as they come — the subtraction of
+//     the running maximum costs nothing unless a row sees a NEW maximum in this tile (wave-uniform check, rare after the first tiles);
+//   * K / V^T tiles sit in a ring of three LDS slots (tile t+1 must be resident while tile t is being consumed), global loads run
+//     two tiles ahead in registers.
+// One workgroup per CU (the two S^T accumulator sets + O^T need ~160 registers).
+__global__ __launch_bounds__(512, 2) void attention_kernel_w8p(const ImagenAttentionParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
+  constexpr int SLOT = KBYTES2 + VBYTES2;
+  char* smem = smem_dyn;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int row = blockIdx.x * 256 + wave * 32 + l31;
+  const int row_c = row < p.rows ? row : p.rows - 1;
+
+  const f16* q = reinterpret_cast<const f16*>(p.q) + (size_t)b * p.q_bs + (size_t)hd * p.q_hs + (size_t)row_c * p.q_rs;
+  f16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const f16x8*>(q + 16 * s + 8 * half);
+  if (p.q_scale) {   // fused QNORM (ip.py:559-560)
+    float ssq = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ssq += (float)qf[s][j] * (float)qf[s][j];
+    ssq += __shfl_xor(ssq, 32);
+    const float inv = p.q_mult / fmaxf(sqrtf(ssq), 1e-12f);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float4 g0 = *reinterpret_cast<const float4*>(p.q_scale + 16 * s + 8 * half);
+      const float4 g1 = *reinterpret_cast<const float4*>(p.q_scale + 16 * s + 8 * half + 4);
+      const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[s][j] = (f16)((float)qf[s][j] * inv * g[j]);
+    }
+  }
+
+  const f16* kg = reinterpret_cast<const f16*>(p.k) + (size_t)b * p.k_bs + (size_t)hd * p.k_hs;
+  const f16* vg = reinterpret_cast<const f16*>(p.vt) + (size_t)b * p.vt_bs + (size_t)hd * p.vt_hs;
+  const int sk_key = tid >> 3, sk_dg = tid & 7;
+  const int sv_d = tid >> 3, sv_kg = tid & 7;
+  const int Jpad = (p.J + 31) & ~31;
+  const int ntiles = (p.J + KT2 - 1) / KT2;
+
+  uint4 k_stage, v_stage;
+  auto tile_load = [&](int t) {   // tiles past the end re-read tile 0 (never consumed)
+    const int kt0 = t < ntiles ? t * KT2 : 0;
+    const int kk = kt0 + sk_key < Jpad ? kt0 + sk_key : kt0;
+    const int kv = kt0 + sv_kg * 8 < Jpad ? kt0 + sv_kg * 8 : kt0;
+    k_stage = *reinterpret_cast<const uint4*>(kg + (size_t)kk * p.k_rs + sk_dg * 8);
+    v_stage = *reinterpret_cast<const uint4*>(vg + (size_t)sv_d * p.vt_ds + kv);
+  };
+  auto tile_store = [&](char* buf) {
+    *reinterpret_cast<uint4*>(buf + sk_key * KSTR + sk_dg * 16) = k_stage;
+    char* vrow = buf + KBYTES2 + sv_d * VSTR2 + (sv_kg >> 1) * 32 + (sv_kg & 1) * 8;   // key order [0-3, 8-11, 4-7, 12-15] per 16 keys
+    *reinterpret_cast<uint2*>(vrow) = make_uint2(v_stage.x, v_stage.y);
+    *reinterpret_cast<uint2*>(vrow + 16) = make_uint2(v_stage.z, v_stage.w);
+  };
+  auto k_frag = [&](const char* kb, int h2, int s) __attribute__((always_inline)) -> f16x8 {
+    return *reinterpret_cast<const f16x8*>(kb + (32 * h2 + l31) * KSTR + (16 * s + 8 * half) * 2);
+  };
+
+  f32x16 oacc[2];
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
+  float m_run = 0.f, l_run = 0.f;   // (the first tile sets m_run to its row maximum, whatever its sign)
+
+  // S'(t) = S(t) - m_run in sc; masked for the ragged last tile; then the running maximum is raised if a row exceeds it
+  f32x16 sc[2], sn[2];
+  auto finish_scores = [&](f32x16 (&sx)[2], int t) __attribute__((always_inline)) {
+    if (t == ntiles - 1) {
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = t * KT2 + 32 * h2 + 4 * half + (r & 3) + 8 * (r >> 2);
+          if (key >= p.J) sx[h2][r] = -1.0e30f;
+        }
+    }
+    float mx = sx[0][0];
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sx[h2][r]);
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    if (t == 0 || __any(mx > 0.f)) {   // some row of the wave has a new maximum: shift its scores, rescale what it has accumulated
+      const float d = t == 0 ? mx : fmaxf(mx, 0.f);
+      const float alpha = __builtin_amdgcn_exp2f(-d);
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) sx[h2][r] -= d;
+      l_run *= alpha;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
+      m_run += d;
+    }
+  };
+
+  // ---- prologue: tiles 0 and 1 into the ring, S'(0)
+  tile_load(0);
+  tile_store(smem);
+  tile_load(1);
+  tile_store(smem + SLOT);
+  tile_load(2);
+  __syncthreads();
+#pragma unroll
+  for (int h2 = 0; h2 < 2; ++h2) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) sc[h2][r] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) sc[h2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k_frag(smem, h2, s), qf[s], sc[h2], 0, 0, 0);
+  }
+  finish_scores(sc, 0);
+
+  int slot = 0;   // ring slot of tile t
+  for (int t = 0; t < ntiles; ++t) {
+    const char* kb_n = smem + (slot == 2 ? 0 : slot + 1) * SLOT;        // tile t+1 (resident since the previous barrier)
+    const char* vb = smem + slot * SLOT + KBYTES2;                      // V^T of tile t
+    // ---- part A: exponentials of tile t (VALU) with the S^T MFMAs of tile t+1 between them
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) sn[h2][r] = -m_run;
+    float psum = 0.f;
+    f16x8 pf[4];
+#pragma unroll
+    for (int g = 0; g < 8; ++g) {   // 8 groups: one MFMA + 4 exponentials each
+      const int h2m = g >> 2, sm = g & 3;
+      sn[h2m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k_frag(kb_n, h2m, sm), qf[sm], sn[h2m], 0, 0, 0);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int e = 4 * g + j, h2 = e >> 4, r = e & 15;
+        const float ex = __builtin_amdgcn_exp2f(sc[h2][r]);
+        psum += ex;
+        pf[2 * h2 + (r >> 3)][r & 7] = (f16)ex;
+      }
+    }
+    l_run += psum;
+    // ---- part B: PV MFMAs of tile t (matrix pipe) with the maximum bookkeeping of tile t+1 (VALU) behind them
+#pragma unroll
+    for (int h2 = 0; h2 < 2; ++h2)
+#pragma unroll
+      for (int s = 0; s < 2; ++s)
+#pragma unroll
+        for (int db = 0; db < 2; ++db) {
+          const f16x8 vf = *reinterpret_cast<const f16x8*>(vb + (32 * db + l31) * VSTR2 + (32 * h2 + 16 * s + 8 * half) * 2);
+          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[2 * h2 + s], oacc[db], 0, 0, 0);
+        }
+    if (t + 1 < ntiles) {
+      finish_scores(sn, t + 1);
+#pragma unroll
+      for (int h2 = 0; h2 < 2; ++h2) sc[h2] = sn[h2];
+    }
+    // ---- ring: tile t+2 (in registers since the previous iteration) into the slot tile t-1 occupied; loads of tile t+3
+    const int slot_w = slot == 0 ? 2 : slot - 1;
+    tile_store(smem + slot_w * SLOT);
+    tile_load(t + 3);
+    __syncthreads();
+    slot = slot == 2 ? 0 : slot + 1;
   }
 
   const float l_tot = l_run + __shfl_xor(l_run, 32);
@@ -167,7 +549,30 @@ int launch_attention(const ImagenAttentionParams* p, hipStream_t s) {
   IMAGEN_CHECK(p->rows > 0 && p->J > 0 && p->B > 0 && p->heads > 0, "attention: empty problem");
   IMAGEN_CHECK(p->q_rs % 8 == 0 && p->k_rs % 8 == 0 && p->vt_ds % 8 == 0 && p->o_rs % 4 == 0,
                "attention: strides must keep 16B alignment");
+  static const int force = [] { const char* e = getenv("IMAGEN_ATTN_KERNEL"); return e ? atoi(e) : 0; }();   // A/B: 1 = 4-wave, 2.. = 8-wave variants
+  IMAGEN_CHECK(p->head_dim == 0 || p->head_dim == 64 || p->head_dim == 32, "attention: head_dim %d (64 or 32)", p->head_dim);
+  if (p->head_dim != 32 && ((p->rows >= 256 && force != 1) || force >= 2)) {
+    dim3 grid((p->rows + 255) / 256, p->heads, p->B);
+    auto launch = [&](auto kern, int lds) {
+      static bool attr_done[16] = {};   // (per kernel instantiation: one lambda instantiation per `kern` type; per device)
+      int dev = 0;
+      (void)hipGetDevice(&dev);
+      if (dev < 0 || dev >= 16 || !attr_done[dev]) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+        if (dev >= 0 && dev < 16) attr_done[dev] = true;
+      }
+      hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, *p);
+    };
+    constexpr int slot = KBYTES2 + VBYTES2;
+    if (force == 4) launch(attention_kernel_w8p, 3 * slot);
+    else if (force == 3) launch(attention_kernel_w8<2, 1>, 2 * slot);
+    else if (force == 2) launch(attention_kernel_w8<4, 1>, 2 * slot);
+    else if (p->J <= 2 * KT2) launch(attention_kernel_w8<4, 1>, 2 * slot);   // one or two tiles: nothing to gain from staging two at a time
+    else launch(attention_kernel_w8<4, 2>, 4 * slot);
+    return imagen_hip_status("attention");
+  }
   dim3 grid((p->rows + 127) / 128, p->heads, p->B);
-  hipLaunchKernelGGL(attention_kernel, grid, dim3(256), 0, s, *p);
+  if (p->head_dim == 32) hipLaunchKernelGGL(attention_kernel<32>, grid, dim3(256), 0, s, *p);
+  else hipLaunchKernelGGL(attention_kernel<64>, grid, dim3(256), 0, s, *p);
   return imagen_hip_status("attention");
 }

@@ -165,18 +165,21 @@ __global__ __launch_bounds__(256) void ln_residual_kernel(const ImagenLnResidual
 }
 
 // ------------------------------------------------------------------------------------------------ q / kv preparation
-// 8 lanes per 64-wide head row; each lane owns 8 consecutive dims.
+// head_dim / 8 lanes (8 | 4) per head row; each lane owns 8 consecutive dims.
+__device__ __forceinline__ int head_dim_of(int v) { return v == 32 ? 32 : 64; }
+
 __global__ __launch_bounds__(256) void qnorm_kernel(const ImagenQnormParams p) {
-  const int item = blockIdx.x * 32 + (threadIdx.x >> 3);  // (row, head)
-  const int dg = threadIdx.x & 7;
+  const int D = head_dim_of(p.head_dim), lpr = D >> 3, sh = D == 64 ? 3 : 2;
+  const int item = blockIdx.x * (256 >> sh) + (threadIdx.x >> sh);  // (row, head)
+  const int dg = threadIdx.x & (lpr - 1);
   if (item >= p.rows * p.heads) return;
   const int row = item / p.heads, hd = item - row * p.heads;
-  f16* q = reinterpret_cast<f16*>(p.q) + (size_t)row * p.ld + hd * 64 + dg * 8;
+  f16* q = reinterpret_cast<f16*>(p.q) + (size_t)row * p.ld + hd * D + dg * 8;
   const f16x8 v = *reinterpret_cast<const f16x8*>(q);
   float ssq = 0.f;
 #pragma unroll
   for (int j = 0; j < 8; ++j) ssq += (float)v[j] * (float)v[j];
-  ssq = group_sum(ssq, 8);
+  ssq = group_sum(ssq, lpr);
   const float inv = p.mult / fmaxf(sqrtf(ssq), 1e-12f);
   f16x8 o;
 #pragma unroll
@@ -187,8 +190,9 @@ __global__ __launch_bounds__(256) void qnorm_kernel(const ImagenQnormParams p) {
 __device__ __forceinline__ void kv_prep_body(const ImagenKvPrepParams& p, int bx, int bh) {
   if (bh >= p.B * p.heads) return;
   const int b = bh / p.heads, hd = bh - b * p.heads;
-  const int row = bx * 32 + (threadIdx.x >> 3);
-  const int dg = threadIdx.x & 7;
+  const int D = head_dim_of(p.head_dim), lpr = D >> 3, sh = D == 64 ? 3 : 2;
+  const int row = bx * (256 >> sh) + (threadIdx.x >> sh);
+  const int dg = threadIdx.x & (lpr - 1);
   if (row >= p.rows) return;
   const size_t soff = (size_t)b * p.src_bs + (size_t)row * p.src_rs + (size_t)hd * p.src_hs + dg * 8;
   float kv[8], vv[8];
@@ -206,7 +210,7 @@ __device__ __forceinline__ void kv_prep_body(const ImagenKvPrepParams& p, int bx
   float ssq = 0.f;
 #pragma unroll
   for (int j = 0; j < 8; ++j) ssq += kv[j] * kv[j];
-  ssq = group_sum(ssq, 8);
+  ssq = group_sum(ssq, lpr);
   const float inv = 1.0f / fmaxf(sqrtf(ssq), 1e-12f);
   f16x8 ko;
 #pragma unroll

@@ -439,13 +439,13 @@ class UnetEngine:
         Jp = ops._round_up(J, 32)
         khat = torch.zeros(R, heads, Jp, dh, dtype=torch.float16, device=self.dev)
         vt = torch.zeros(R, heads, dh, Jp, dtype=torch.float16, device=self.dev)
-        site = dict(kind="cross", name=name, mod=ca, khat=khat, vt=vt, heads=heads, Jp=Jp,
+        site = dict(kind="cross", name=name, mod=ca, khat=khat, vt=vt, heads=heads, Jp=Jp, dh=dh,
                     k_strides=(heads * Jp * dh, Jp * dh, dh), vt_strides=(heads * dh * Jp, dh * Jp, Jp))
         self.attn_sites.append(site)
         o = self.new(R, 1, N, inner)
         ops.attention(plan, q.t, khat, vt, o.t, B=R, heads=heads, rows=N, J=J, q_strides=(N * inner, dh, inner),
                       k_strides=site["k_strides"], vt_strides=site["vt_strides"], o_strides=(N * inner, dh, inner),
-                      q_scale=W.f32(name + ".q_scale", lambda: ca.q_scale), q_mult=SIM_SCALE * LOG2E, label=name + ".attn")
+                      q_scale=W.f32(name + ".q_scale", lambda: ca.q_scale), q_mult=SIM_SCALE * LOG2E, label=name + ".attn", head_dim=dh)
         y = self.new(R, 1, N, C)
         ops.igemm(plan, o, W.conv(name + ".to_out", ca.to_out[0]), y, label=name + ".to_out")
         out = self.new(R, h.H, h.W, C)
@@ -487,15 +487,15 @@ class UnetEngine:
         khat = torch.zeros(R, Jp, dh, dtype=torch.float16, device=self.dev)
         vt = torch.zeros(R, dh, Jp, dtype=torch.float16, device=self.dev)
         k_strides, vt_strides = (Jp * dh, 0, dh), (dh * Jp, 0, Jp)
-        site = dict(kind="self", name=nm, mod=attn, khat=khat, vt=vt, heads=1, Jp=Jp, n_ctx=n_ctx, k_strides=k_strides, vt_strides=vt_strides)
+        site = dict(kind="self", name=nm, mod=attn, khat=khat, vt=vt, heads=1, Jp=Jp, n_ctx=n_ctx, dh=dh, k_strides=k_strides, vt_strides=vt_strides)
         self.attn_sites.append(site)
         ops.kv_prep(plan, qkv.t, qkv.t, W.f32(nm + ".k_scale", lambda: attn.k_scale), khat, vt, B=R, heads=1, rows=N, r0=n_ctx + 1,
                     src_strides=(N * ld, ld, 0), k_strides=k_strides, vt_strides=vt_strides, k_off=inner, v_off=inner + dh,
-                    label=nm + ".kv_self")
+                    label=nm + ".kv_self", head_dim=dh)
         o = self.new(R, 1, N, inner)
         ops.attention(plan, qkv.t, khat, vt, o.t, B=R, heads=heads, rows=N, J=J, q_strides=(N * ld, dh, ld), k_strides=k_strides,
                       vt_strides=vt_strides, o_strides=(N * inner, dh, inner), q_scale=W.f32(nm + ".q_scale", lambda: attn.q_scale),
-                      q_mult=SIM_SCALE * LOG2E, label=nm + ".attn")
+                      q_mult=SIM_SCALE * LOG2E, label=nm + ".attn", head_dim=dh)
         y = self.new(R, 1, N, C)
         ops.igemm(plan, o, W.conv(nm + ".to_out", attn.to_out[0]), y, label=nm + ".to_out")
         x1 = self.new(R, 1, N, C)
@@ -611,19 +611,24 @@ class UnetEngine:
             ops.rowstat(plan, c_rows, mode=1, rs=rs, mu=mu, eps=1e-5, label=f"ctx.{tag}.ln")
             st = self.new(1, 1, R * n, ws.Cout)
             ops.igemm(plan, c_rows, ws, st, mu=mu, rs=rs, label=f"ctx.{tag}.self")
-            for i, s in enumerate(selfs):
+            col = 0   # to_context of site i yields (k | v) = 2 * dim_head columns
+            for s in selfs:
+                d_ = s["dh"]
                 ops.kv_prep(plan, st.t, st.t, W.f32(s["name"] + ".k_scale", lambda s=s: s["mod"].k_scale), s["khat"], s["vt"], B=R, heads=1,
                             rows=n, r0=k_row0_self, src_strides=(n * ws.Cout, ws.Cout, 0), k_strides=s["k_strides"], vt_strides=s["vt_strides"],
-                            k_off=i * 128, v_off=i * 128 + 64, batch=jobs)
+                            k_off=col, v_off=col + d_, batch=jobs, head_dim=d_)
+                col += 2 * d_
+            assert col == ws.Cout
         if crosses:
             st = self.new(1, 1, R * n, wc.Cout)
             ops.igemm(plan, c_rows, wc, st, label=f"ctx.{tag}.cross")
-            col = 0  # sites differ in head count (the mid blocks are always 8 x 64, ip.py:1380-1382): cumulative column offsets
+            col = 0  # sites differ in head count / head dim (the mid blocks are always 8 x 64, ip.py:1380-1382): cumulative column offsets
             for s in crosses:
-                inner = s["heads"] * 64
+                d_ = s["dh"]
+                inner = s["heads"] * d_
                 ops.kv_prep(plan, st.t, st.t, W.f32(s["name"] + ".k_scale", lambda s=s: s["mod"].k_scale), s["khat"], s["vt"], B=R,
-                            heads=s["heads"], rows=n, r0=k_row0_cross, src_strides=(n * wc.Cout, wc.Cout, 64), k_strides=s["k_strides"],
-                            vt_strides=s["vt_strides"], k_off=col, v_off=col + inner, batch=jobs)
+                            heads=s["heads"], rows=n, r0=k_row0_cross, src_strides=(n * wc.Cout, wc.Cout, d_), k_strides=s["k_strides"],
+                            vt_strides=s["vt_strides"], k_off=col, v_off=col + inner, batch=jobs, head_dim=d_)
                 col += 2 * inner
             assert col == wc.Cout
         if jobs:
@@ -636,8 +641,8 @@ class UnetEngine:
             nk = W.f32(s["name"] + ".null_kv", lambda s=s: s["mod"].null_kv)
             r0 = s["n_ctx"] if s["kind"] == "self" else 0
             ops.kv_prep(plan, nk, nk, W.f32(s["name"] + ".k_scale", lambda s=s: s["mod"].k_scale), s["khat"], s["vt"], B=R, heads=s["heads"],
-                        rows=1, r0=r0, src_strides=(0, 0, 0), k_strides=s["k_strides"], vt_strides=s["vt_strides"], k_off=0, v_off=64,
-                        label=s["name"] + ".kv_null")
+                        rows=1, r0=r0, src_strides=(0, 0, 0), k_strides=s["k_strides"], vt_strides=s["vt_strides"], k_off=0, v_off=s["dh"],
+                        label=s["name"] + ".kv_null", head_dim=s["dh"])
 
     # ------------------------------------------------------------------------------------------ static plan
     def _build_static_plan(self, n_tok: int):
@@ -769,11 +774,12 @@ class UnetEngine:
             vt = torch.zeros(R, heads, dh, Jp, dtype=torch.float16, device=self.dev)
             ks, vs = (heads * Jp * dh, Jp * dh, dh), (heads * dh * Jp, dh * Jp, Jp)
             ops.kv_prep(plan, kv.t, kv.t, W.f32(nm_ + ".k_scale", lambda pa=pa: pa.k_scale), khat, vt, B=R, heads=heads, rows=Jk, r0=0,
-                        src_strides=(Jk * 2 * inner, 2 * inner, dh), k_strides=ks, vt_strides=vs, k_off=0, v_off=inner, label=nm_ + ".kv_prep")
+                        src_strides=(Jk * 2 * inner, 2 * inner, dh), k_strides=ks, vt_strides=vs, k_off=0, v_off=inner, label=nm_ + ".kv_prep",
+                        head_dim=dh)
             o = self.new(R, 1, NL, inner)
             ops.attention(plan, q.t, khat, vt, o.t, B=R, heads=heads, rows=NL, J=Jk, q_strides=(NL * inner, dh, inner), k_strides=ks,
                           vt_strides=vs, o_strides=(NL * inner, dh, inner), q_scale=W.f32(nm_ + ".q_scale", lambda pa=pa: pa.q_scale),
-                          q_mult=SIM_SCALE * LOG2E, label=nm_ + ".attn")
+                          q_mult=SIM_SCALE * LOG2E, label=nm_ + ".attn", head_dim=dh)
             y = self.new(R, 1, NL, cd)
             ops.igemm(plan, o, W.conv(nm_ + ".to_out", pa.to_out[0]), y, label=nm_ + ".to_out")
             lat2 = self.new(R, 1, NL, cd)

@@ -547,9 +547,12 @@ def rowstat(plan: Plan, x1: Act, *, mode: int, rs: torch.Tensor, mu: Optional[to
 
 
 def attention(plan: Plan, q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, o: torch.Tensor, *, B, heads, rows, J,
-              q_strides, k_strides, vt_strides, o_strides, q_scale: Optional[torch.Tensor] = None, q_mult: float = 0.0, label: str = ""):
-    """q_scale / q_mult: fuse QNORM into the q load (q rows raw); None: q was normalised by a QNORM op."""
+              q_strides, k_strides, vt_strides, o_strides, q_scale: Optional[torch.Tensor] = None, q_mult: float = 0.0, label: str = "",
+              head_dim: int = 64):
+    """q_scale / q_mult: fuse QNORM into the q load (q rows raw); None: q was normalised by a QNORM op.  head_dim: 64 or 32."""
+    assert head_dim in (32, 64), f"attention head dim {head_dim}: the kernels are built for 64 and 32"
     p = STRUCTS["ImagenAttentionParams"]()
+    p.head_dim = head_dim
     p.q, p.k, p.vt, p.o = q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr()
     p.q_scale, p.q_mult = ptr(q_scale), q_mult
     p.B, p.heads, p.rows, p.J = B, heads, rows, J
@@ -563,10 +566,12 @@ def attention(plan: Plan, q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, o:
 
 def kv_prep(plan: Plan, k_src: torch.Tensor, v_src: torch.Tensor, k_scale: torch.Tensor, khat: torch.Tensor, vt: torch.Tensor, *,
             B, heads, rows, r0, src_strides, k_strides, vt_strides, k_off: int = 0, v_off: int = 0, label: str = "",
-            batch: Optional[list] = None):
+            batch: Optional[list] = None, head_dim: int = 64):
     """k_off / v_off: element offsets of the k and v columns inside the source rows.  With `batch` the job is appended to that
     list instead of the plan; kv_prep_multi(plan, batch) then runs all of them in one launch."""
+    assert head_dim in (32, 64)
     p = STRUCTS["ImagenKvPrepParams"]()
+    p.head_dim = head_dim
     es = k_src.element_size()
     p.k_src, p.v_src = k_src.data_ptr() + k_off * es, v_src.data_ptr() + v_off * es
     p.k_scale, p.khat, p.vt = k_scale.data_ptr(), khat.data_ptr(), vt.data_ptr()
@@ -599,8 +604,10 @@ def kv_prep_multi(plan: Plan, batch: list, device, label: str = ""):
     return p
 
 
-def qnorm(plan: Plan, q: torch.Tensor, q_scale: torch.Tensor, *, rows, heads, ld, mult, label: str = ""):
+def qnorm(plan: Plan, q: torch.Tensor, q_scale: torch.Tensor, *, rows, heads, ld, mult, label: str = "", head_dim: int = 64):
+    assert head_dim in (32, 64)
     p = STRUCTS["ImagenQnormParams"]()
+    p.head_dim = head_dim
     p.q, p.q_scale, p.rows, p.heads, p.ld, p.mult = q.data_ptr(), q_scale.data_ptr(), rows, heads, ld, mult
     plan.add(p, label or "qnorm", [q, q_scale])
     return p

@@ -111,8 +111,9 @@ class Unet(nn.Module):
             _unsupported('cond_images_channels')
         if init_conv_to_final_conv_residual and not final_resnet_block:
             _unsupported('init_conv_to_final_conv_residual without final_resnet_block')   # final_conv would need three inputs
-        if attn_dim_head != 64:
-            raise NotImplementedError("the attention kernel is specialised for dim_head = 64 (every reference preset / README config)")
+        if attn_dim_head not in (32, 64):
+            raise NotImplementedError(f"attn_dim_head = {attn_dim_head}: the attention kernels are built for head dims 64 (every README config) "
+                                      "and 32 (the reference's UnetConfig default, configs.py:48-49)")
 
         self.channels = channels
         self.channels_out = channels_out if channels_out is not None else channels

@@ -161,7 +161,8 @@ typedef struct ImagenRowstatParams {
  * similarity scale * log2(e); K rows pre-normalised (KV_PREP); VT is V transposed [d][key].
  *   o[r] = softmax_j(q[r] . k[j]) @ v   for r in rows, j in [0, J)
  * Addressing: q/o row r of (batch b, head h): base + b*q_bs + h*q_hs + r*q_rs ; k: b*k_bs + h*k_hs + j*k_rs ;
- * vt: b*vt_bs + h*vt_hs + d*vt_ds + j.   Head dim is fixed at 64. */
+ * vt: b*vt_bs + h*vt_hs + d*vt_ds + j.   head_dim: 64 (0 means 64) or 32 — the reference's UnetConfig default is 32 x 16 heads
+ * (configs.py:48-49), every README config uses 64. */
 typedef struct ImagenAttentionParams {
   const void* q; const void* k; const void* vt; void* o;
   int32_t B, heads, rows, J;
@@ -169,8 +170,9 @@ typedef struct ImagenAttentionParams {
   int32_t k_bs, k_hs, k_rs;
   int32_t vt_bs, vt_hs, vt_ds;
   int32_t o_bs, o_hs, o_rs;
-  /* optional fused QNORM: q rows arrive raw and are l2-normalised * q_scale[64] * q_mult while they are loaded */
+  /* optional fused QNORM: q rows arrive raw and are l2-normalised * q_scale[head_dim] * q_mult while they are loaded */
   const float* q_scale; float q_mult;
+  int32_t head_dim;
 } ImagenAttentionParams;
 
 /* KV_PREP — k/v rows -> attention operand buffers (null_kv, context kv, self kv; ip.py:545-561, 805-814).
@@ -183,6 +185,7 @@ typedef struct ImagenKvPrepParams {
   int32_t k_bs, k_hs, k_rs;
   int32_t vt_bs, vt_hs, vt_ds;
   int32_t src_is_f32; /* null_kv parameters are fp32 */
+  int32_t head_dim;   /* 64 (0 means 64) or 32 */
 } ImagenKvPrepParams;
 
 /* KV_PREP_MULTI — the per-step context K/V rows of ALL attention sites (2 time tokens each) in one launch instead of one
@@ -215,8 +218,9 @@ typedef struct ImagenTemporalAttentionParams {
 /* QNORM — q[r, h, :] = l2norm(q[r, h, :]) * q_scale * mult   in place (ip.py:559-560, 812-813). */
 typedef struct ImagenQnormParams {
   void* q; const float* q_scale;
-  int32_t rows, heads, ld; /* row stride in elements; head h at column h*64 */
+  int32_t rows, heads, ld; /* row stride in elements; head h at column h*head_dim */
   float mult;
+  int32_t head_dim;        /* 64 (0 means 64) or 32 */
 } ImagenQnormParams;
 
 /* GCA_PARTIAL / GCA_FINAL — GlobalContext ip.py:945-970 on h (NHWC fp16):

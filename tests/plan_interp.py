@@ -282,11 +282,12 @@ class Interpreter:
     def kv_prep(self, p):
         m = self.mem
         dt = f32 if p.src_is_f32 else f16
-        sz = (p.B, p.heads, p.rows, 64)
+        D = 32 if p.head_dim == 32 else 64
+        sz = (p.B, p.heads, p.rows, D)
         st = (p.src_bs, p.src_hs, p.src_rs, 1)
         k = m.strided(p.k_src, dt, sz, st).float()
         v = m.strided(p.v_src, dt, sz, st).float()
-        khat = F.normalize(k, dim=-1, eps=1e-12) * m.view(p.k_scale, f32)[:64]
+        khat = F.normalize(k, dim=-1, eps=1e-12) * m.view(p.k_scale, f32)[:D]
         m.strided(p.khat + 2 * p.r0 * p.k_rs, f16, sz, (p.k_bs, p.k_hs, p.k_rs, 1)).copy_(khat.half())
         m.strided(p.vt + 2 * p.r0, f16, sz, (p.vt_bs, p.vt_hs, 1, p.vt_ds)).copy_(v.half())
 
@@ -299,19 +300,21 @@ class Interpreter:
 
     def qnorm(self, p):
         m = self.mem
-        q = m.strided(p.q, f16, (p.rows, p.heads, 64), (p.ld, 64, 1))
-        q.copy_((F.normalize(q.float(), dim=-1, eps=1e-12) * m.view(p.q_scale, f32)[:64] * p.mult).half())
+        D = 32 if p.head_dim == 32 else 64
+        q = m.strided(p.q, f16, (p.rows, p.heads, D), (p.ld, D, 1))
+        q.copy_((F.normalize(q.float(), dim=-1, eps=1e-12) * m.view(p.q_scale, f32)[:D] * p.mult).half())
 
     def attention(self, p):
         m = self.mem
-        q = m.strided(p.q, f16, (p.B, p.heads, p.rows, 64), (p.q_bs, p.q_hs, p.q_rs, 1)).float()
+        D = 32 if p.head_dim == 32 else 64
+        q = m.strided(p.q, f16, (p.B, p.heads, p.rows, D), (p.q_bs, p.q_hs, p.q_rs, 1)).float()
         if p.q_scale:
-            q = (F.normalize(q, dim=-1, eps=1e-12) * m.view(p.q_scale, f32)[:64] * p.q_mult).half().float()
-        k = m.strided(p.k, f16, (p.B, p.heads, p.J, 64), (p.k_bs, p.k_hs, p.k_rs, 1)).float()
-        v = m.strided(p.vt, f16, (p.B, p.heads, p.J, 64), (p.vt_bs, p.vt_hs, 1, p.vt_ds)).float()
+            q = (F.normalize(q, dim=-1, eps=1e-12) * m.view(p.q_scale, f32)[:D] * p.q_mult).half().float()
+        k = m.strided(p.k, f16, (p.B, p.heads, p.J, D), (p.k_bs, p.k_hs, p.k_rs, 1)).float()
+        v = m.strided(p.vt, f16, (p.B, p.heads, p.J, D), (p.vt_bs, p.vt_hs, 1, p.vt_ds)).float()
         sim = torch.einsum("bhid,bhjd->bhij", q, k) * math.log(2.0)       # the kernel's exponent base is 2
         o = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), v)
-        m.strided(p.o, f16, (p.B, p.heads, p.rows, 64), (p.o_bs, p.o_hs, p.o_rs, 1)).copy_(o.half())
+        m.strided(p.o, f16, (p.B, p.heads, p.rows, D), (p.o_bs, p.o_hs, p.o_rs, 1)).copy_(o.half())
 
     # ------------------------------------------------------------------------------------------------ GlobalContext
     def _gca_gate(self, ctx, w1t, b1, w2t, b2, C, hidden):

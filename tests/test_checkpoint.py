@@ -88,8 +88,12 @@ def test_imagen_from_config_validation(fixture):
         imagen_from_config("original", {**params, "image_sizes": [16, 32]})
     vid = imagen_from_config("original", {**params, "video": True})               # configs.py:87-93: every unet becomes a Unet3D
     assert vid.is_video and type(vid.unets[0]).__name__ == "Unet3D" and vid._config["video"] is True
-    with pytest.raises(NotImplementedError, match="dim_head"):                     # config default attn_dim_head = 32
-        imagen_from_config("original", {**params, "unets": [{k: v for k, v in params["unets"][0].items() if k != "attn_dim_head"}]})
+    dflt = imagen_from_config("original", {**params, "unets": [{k: v for k, v in params["unets"][0].items()
+                                                                if k not in ("attn_dim_head", "attn_heads")}]})
+    att = [m for m in dflt.unets[0].modules() if type(m).__name__ == "AttentionP"]   # config defaults: 16 heads x 32 dims (configs.py:48-49)
+    assert att and all(m.dim_head == 32 and m.heads == 16 for m in att)
+    with pytest.raises(NotImplementedError, match="attn_dim_head"):                # head dims other than 64 / 32 have no kernel
+        imagen_from_config("original", {**params, "unets": [{**params["unets"][0], "attn_dim_head": 48}]})
     el = imagen_from_config("elucidated", {k: v for k, v in fixture["elucidated_config"].items()
                                            if k != "unets"} | {"unets": [params["unets"][0]], "num_sample_steps": 4})
     assert type(el) is ElucidatedImagen and el._config["num_sample_steps"] == 4 and el._config["S_noise"] == 1.003

@@ -240,14 +240,15 @@ def test_igemm_res_conv_gate_addend(ops, dev):
 
 # ------------------------------------------------------------------------------------------------ attention
 
+@pytest.mark.parametrize("D", [64, 32])
 @pytest.mark.parametrize("fused_qnorm", [False, True])
 @pytest.mark.parametrize("B,heads,rows,J,shared", [(2, 1, 8 * 1024, 1065, True), (2, 8, 256, 41, False), (1, 8, 36, 292, False),
-                                                   (2, 1, 8 * 64, 103, True)])
-def test_attention(ops, dev, B, heads, rows, J, shared, fused_qnorm):
+                                                   (2, 1, 8 * 64, 103, True), (2, 8, 256, 80, False), (1, 1, 8 * 64, 20, True),
+                                                   (1, 2, 300, 129, False)])
+def test_attention(ops, dev, B, heads, rows, J, shared, fused_qnorm, D):
     """Cosine-sim attention (ip.py:559-590 / 812-833): QNORM (as its own op, or fused into the q load) + KV_PREP + ATTENTION vs
     softmax(8 * q^ k^T) v in fp32."""
     torch.manual_seed(6)
-    D = 64
     q = h16(torch.randn(B, rows, heads, D))
     k = h16(torch.randn(B, J, heads, D))
     v = h16(torch.randn(B, J, heads, D))
@@ -265,11 +266,11 @@ def test_attention(ops, dev, B, heads, rows, J, shared, fused_qnorm):
     plan = ops.Plan()
     qkw = dict(q_scale=qs.to(dev), q_mult=8 * ops.LOG2E) if fused_qnorm else {}
     if not fused_qnorm:
-        ops.qnorm(plan, qd, qs.to(dev), rows=B * rows, heads=heads, ld=heads * D, mult=8 * ops.LOG2E)
+        ops.qnorm(plan, qd, qs.to(dev), rows=B * rows, heads=heads, ld=heads * D, mult=8 * ops.LOG2E, head_dim=D)
     ops.kv_prep(plan, kd, vd, ks.to(dev), khat, vt, B=B, heads=heads, rows=J, r0=0,
                 src_strides=(J * heads * D, heads * D, D), k_strides=(heads * Jp * D, Jp * D, D),
-                vt_strides=(heads * D * Jp, D * Jp, Jp))
-    ops.attention(plan, qd, khat, vt, o, B=B, heads=heads, rows=rows, J=J,
+                vt_strides=(heads * D * Jp, D * Jp, Jp), head_dim=D)
+    ops.attention(plan, qd, khat, vt, o, B=B, heads=heads, rows=rows, J=J, head_dim=D,
                   q_strides=(rows * heads * D, D, heads * D), k_strides=(heads * Jp * D, Jp * D, D),
                   vt_strides=(heads * D * Jp, D * Jp, Jp), o_strides=(rows * heads * D, D, heads * D), **qkw)
     _run(plan)

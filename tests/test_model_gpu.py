@@ -77,6 +77,7 @@ MEMEFF = dict(dim=32, cond_dim=64, dim_mults=(1, 2, 4), num_resnet_blocks=(1, 2,
               layer_cross_attns=(False, True, True), memory_efficient=True, lowres_cond=True, attn_heads=4)
 
 
+HD32 = dict(README_U1, attn_dim_head=32, attn_heads=16)   # the reference's UnetConfig default head geometry (configs.py:48-49)
 C2_BASE = dict(README_U1, dim=128)   # BASELINE config C2: the base unet at dim 128 (channels 128..1024, 128-channel k-chunks, several cout tiles)
 
 
@@ -94,9 +95,9 @@ def _record(name, **vals):
         json.dump(rec, f, indent=1, sort_keys=True)
 
 
-@pytest.mark.parametrize("kw,S,B", [(README_U1, 64, 2), (README_U2, 64, 2), (README_U2, 256, 4), (MEMEFF, 32, 2), (C2_BASE, 32, 2), (C2_BASE, 64, 2)],
+@pytest.mark.parametrize("kw,S,B", [(README_U1, 64, 2), (README_U2, 64, 2), (README_U2, 256, 4), (MEMEFF, 32, 2), (C2_BASE, 32, 2), (C2_BASE, 64, 2), (HD32, 64, 2)],
                          ids=["readme-unet1@64", "readme-unet2@64", "readme-unet2@256-bench-tiles", "memory-efficient@32", "c2-dim128@32",
-                              "c2-dim128@64"])
+                              "c2-dim128@64", "readme-unet1-heads16x32@64"])
 def test_unet_forward_vs_oracle(kw, S, B, request):
     """README-sized unets (32-channel-chunk MFMA paths, 1024-token attention) vs the fp32 CPU oracle, stage by stage."""
     from imagen_pytorch_amd import Unet

@@ -26,5 +26,10 @@ SWEEP = {
                                            layer_cross_attns=(False, True, True), pixel_shuffle_upsample=False, init_conv_to_final_conv_residual=True),
     "init_residual_memory_efficient": dict(_T, num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True), memory_efficient=True,
                                            init_conv_to_final_conv_residual=True),
+    # the reference's UnetConfig default head geometry (configs.py:48-49: 32-dim heads); the mid-block cross attention keeps 8 x 64
+    "head_dim_32": dict(_T, attn_dim_head=32, attn_heads=4, num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True)),
+    "head_dim_32_three_levels": dict(dim=32, cond_dim=64, text_embed_dim=32, dim_mults=(1, 2, 4), attn_dim_head=32, attn_heads=16, max_text_len=16,
+                                     attn_pool_num_latents=8, num_resnet_blocks=(1, 2, 2), layer_attns=(False, True, True),
+                                     layer_cross_attns=(False, True, True)),
     "channels_out_6": dict(_T, num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True), channels_out=6),
 }

@@ -116,6 +116,23 @@ def main():
     add("gate_residual 16x8x8x256", gate_res(8, 256))
     add("gate_residual 16x64x64x32", gate_res(64, 32))
 
+    def attn(B, heads, rows, J):
+        def b(plan):
+            D = 64
+            Jp = (J + 31) // 32 * 32
+            q = torch.randn(B, rows, heads, D, device=dev).half()
+            khat = torch.nn.functional.normalize(torch.randn(B, heads, Jp, D, device=dev), dim=-1).half()
+            vt = torch.randn(B, heads, D, Jp, device=dev).half()
+            o = torch.empty(B, rows, heads, D, dtype=torch.float16, device=dev)
+            ops.attention(plan, q, khat, vt, o, B=B, heads=heads, rows=rows, J=J, q_strides=(rows * heads * D, D, heads * D),
+                          k_strides=(heads * Jp * D, Jp * D, D), vt_strides=(heads * D * Jp, D * Jp, Jp), o_strides=(rows * heads * D, D, heads * D),
+                          q_scale=torch.ones(D, device=dev), q_mult=8 * ops.LOG2E)
+        return b
+    add("attn self 1024 tok (B16, rows 8192, J 1065) 35.7 GF", attn(16, 1, 8192, 1065))
+    add("attn self 256 tok (B16, rows 2048, J 297)", attn(16, 1, 2048, 297))
+    add("attn self 64 tok (B16, rows 512, J 105)", attn(16, 1, 512, 105))
+    add("attn cross 1024 tok (B16 x 8 heads, rows 1024, J 41)", attn(16, 8, 1024, 41))
+
     for nm, args, kws in [
         ("conv 128->128 k3 @8 raw", (16, 8, 8, 128, 0, 128, 3), {}),
         ("conv 128->128 k3 @8 pro", (16, 8, 8, 128, 0, 128, 3), dict(pro=True)),
