@@ -936,13 +936,21 @@ long imagen_conv_dma_lds_bytes(int idx, int KH, int KW, int TH, int TW);
 int imagen_conv_dma_ring(int idx);
 int launch_conv_dma(const ImagenIgemmParams* p, int idx, hipStream_t s);
 static inline int cfg_base_dma() { return kNumCfgs + imagen_conv_lds_num_configs(); }
+// fourth kernel family (conv_stream.hip): tile cfg ids behind the third family's
+int imagen_conv_stream_num_configs();
+int imagen_conv_stream_config_info(int idx, int* tile_pixels, int* tile_cout, int* kgroups);
+long imagen_conv_stream_lds_bytes(int idx, int KH, int KW, int TH, int TW);
+int launch_conv_stream(const ImagenIgemmParams* p, int idx, hipStream_t s);
+static inline int cfg_base_stream() { return cfg_base_dma() + imagen_conv_dma_num_configs(); }
+static inline int cfg_end() { return cfg_base_stream() + imagen_conv_stream_num_configs(); }
 
 int launch_igemm(const ImagenIgemmParams* pp, hipStream_t s) {
   const ImagenIgemmParams& p = *pp;
-  IMAGEN_CHECK(p.cfg >= 0 && p.cfg < cfg_base_dma() + imagen_conv_dma_num_configs(), "igemm: bad cfg %d", p.cfg);
+  IMAGEN_CHECK(p.cfg >= 0 && p.cfg < cfg_end(), "igemm: bad cfg %d", p.cfg);
   IMAGEN_CHECK(p.x1 && p.w && p.y, "igemm: null x1/w/y");
   IMAGEN_CHECK(!p.addend || p.gate, "igemm: addend requires gate");
   IMAGEN_CHECK(!p.gca_part || p.cfg >= kNumCfgs, "igemm: gca_part is implemented by kernel families 1 and 2 only (cfg %d)", p.cfg);
+  if (p.cfg >= cfg_base_stream()) return launch_conv_stream(pp, p.cfg - cfg_base_stream(), s);
   if (p.cfg >= cfg_base_dma()) return launch_conv_dma(pp, p.cfg - cfg_base_dma(), s);
   if (p.cfg >= kNumCfgs) return launch_conv_lds(pp, p.cfg - kNumCfgs, s);
   switch (p.cfg) {
@@ -966,18 +974,19 @@ int launch_igemm(const ImagenIgemmParams* pp, hipStream_t s) {
   return -1;
 }
 
-extern "C" int imagen_igemm_num_configs(void) { return cfg_base_dma() + imagen_conv_dma_num_configs(); }
+extern "C" int imagen_igemm_num_configs(void) { return cfg_end(); }
 
 extern "C" int imagen_igemm_config_family(int cfg) {   // 0: wave-specialised persistent kernel (this file), 1: LDS-staged kernel (conv_lds.hip)
   if (cfg < 0 || cfg >= imagen_igemm_num_configs()) return -1;
-  return cfg >= cfg_base_dma() ? 2 : cfg >= kNumCfgs ? 1 : 0;
+  return cfg >= cfg_base_stream() ? 3 : cfg >= cfg_base_dma() ? 2 : cfg >= kNumCfgs ? 1 : 0;   // 3: streaming kernel (conv_stream.hip)
 }
 
 extern "C" int imagen_igemm_config_ring(int cfg) {   // weight look-ahead ring depth in stages (family 2; 0 elsewhere)
-  return cfg >= cfg_base_dma() ? imagen_conv_dma_ring(cfg - cfg_base_dma()) : 0;
+  return (cfg >= cfg_base_dma() && cfg < cfg_base_stream()) ? imagen_conv_dma_ring(cfg - cfg_base_dma()) : 0;
 }
 
 extern "C" int imagen_igemm_config_info(int cfg, int* tile_pixels, int* tile_cout, int* kgroups) {
+  if (cfg >= cfg_base_stream()) return imagen_conv_stream_config_info(cfg - cfg_base_stream(), tile_pixels, tile_cout, kgroups);
   if (cfg >= cfg_base_dma()) return imagen_conv_dma_config_info(cfg - cfg_base_dma(), tile_pixels, tile_cout, kgroups);
   if (cfg >= kNumCfgs) return imagen_conv_lds_config_info(cfg - kNumCfgs, tile_pixels, tile_cout, kgroups);
   if (cfg < 0 || cfg >= kNumCfgs) return -1;
@@ -996,7 +1005,7 @@ static constexpr int ksc_of(int G, int ks) {   // the launch_cfg dispatch, as a 
 }
 
 extern "C" int imagen_igemm_stage_slots(int cfg, int KH, int KW) {
-  if (cfg >= cfg_base_dma()) return (KH == 3 && KW == 3) ? 1 << 20 : 0;   // (no register staging: the tile shape is fixed per cfg)
+  if (cfg >= cfg_base_dma()) return (KH == 3 && KW == 3) ? 1 << 20 : 0;   // (no register staging: the tile shape is fixed per cfg; families 2 and 3)
   if (cfg >= kNumCfgs) return imagen_conv_lds_stage_slots(cfg - kNumCfgs, KH, KW);
   if (cfg < 0 || cfg >= kNumCfgs || KH < 1 || KW < 1) return -1;
   const TileCfg& c = kCfgs[cfg];
@@ -1005,6 +1014,7 @@ extern "C" int imagen_igemm_stage_slots(int cfg, int KH, int KW) {
 
 // dynamic LDS bytes of a launch of `cfg` with a KH x KW kernel (at `stride`) and a TH x TW output tile; -1: the combination is not launchable
 extern "C" long imagen_igemm_lds_bytes(int cfg, int KH, int KW, int stride, int TH, int TW) {
+  if (cfg >= cfg_base_stream()) return stride == 1 ? imagen_conv_stream_lds_bytes(cfg - cfg_base_stream(), KH, KW, TH, TW) : -1;
   if (cfg >= cfg_base_dma()) return stride == 1 ? imagen_conv_dma_lds_bytes(cfg - cfg_base_dma(), KH, KW, TH, TW) : -1;
   if (cfg >= kNumCfgs) return stride == 1 ? imagen_conv_lds_lds_bytes(cfg - kNumCfgs, KH, KW, TH, TW) : -1;
   if (cfg < 0 || KH < 1 || KW < 1 || TH < 1 || TW < 1) return -1;

@@ -95,6 +95,7 @@ POST_NORM = int(os.environ.get("IMAGEN_POST_NORM", "1"))   # A/B switch: block2'
 # ACT_PREP + all-DMA conv for the Blocks with at least this many output channels (the MFMA-bound layers: the prologue pass costs one
 # read + one write of the input, the conv kernel drops its staging instruction stream); 0 = never
 ACT_PREP_MIN_COUT = int(os.environ.get("IMAGEN_ACT_PREP_MIN_COUT", "0"))   # (measured in the model: the extra pass costs more than it saves — off)
+FINAL_CONV_G4 = int(os.environ.get("IMAGEN_FINAL_CONV_G4", "1"))   # A/B switch: 32-channel k-chunks for final_conv over cat(x, lowres image)
 KV_BATCH = int(os.environ.get("IMAGEN_KV_BATCH", "1"))     # A/B switch: one launch for the context K/V rows of all attention sites
 
 
@@ -325,7 +326,10 @@ class UnetEngine:
             wp[:, : x.C] = w[:, : x.C]
             # packed image channel layout: [x (C) | lowres (C) | zero pad]; the reference concatenates lowres after the features
             wp[:, x.C + u.channels: x.C + 2 * u.channels] = w[:, x.C:]
-            return ops.pack_weight(wp, u.final_conv.bias.detach().float(), self.dev)
+            # 32-channel k-chunks whenever the feature part allows it (the 8 image channels then occupy one group of a second,
+            # otherwise zero chunk): the 8-channel-chunk path (G = 1) took 100 us for this layer at 256^2, twice a 32->32 conv
+            G = 4 if (x.C % 32 == 0 and FINAL_CONV_G4) else None
+            return ops.pack_weight(wp, u.final_conv.bias.detach().float(), self.dev, G=G)
 
         ops.igemm(plan, x, self.W.get("final_conv", make), self.out, x2=extra, out_mode=OUT_NCHW_F32, label="final_conv")
 

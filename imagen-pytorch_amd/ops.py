@@ -305,6 +305,16 @@ GCA_EPILOGUE_MAX_TILES = int(_os.environ.get("IMAGEN_GCA_EPILOGUE_MAX_TILES", "1
 GCA_IN_EPILOGUE = int(_os.environ.get("IMAGEN_GCA_IN_EPILOGUE", "1"))   # A/B switch: GlobalContext partials from the producing conv's epilogue
 CONV_DMA = int(_os.environ.get("IMAGEN_CONV_DMA", "1"))             # A/B switch: the all-DMA kernel family for prologue-free single-input 3x3 convs
 CONV_LDS_1X1 = int(_os.environ.get("IMAGEN_CONV_LDS_1X1", "0"))     # ... and for 1x1 convs / linears
+CONV_STREAM = int(_os.environ.get("IMAGEN_CONV_STREAM", "1"))       # A/B switch: the streaming kernel family (conv_stream.hip) for the 32-channel 3x3 convs
+STREAM_MIN_TILES = int(_os.environ.get("IMAGEN_STREAM_MIN_TILES", "512"))   # ... of launches with at least this many 16x16 tiles (persistent workgroups need a few tiles each)
+# ... two inputs WITH the prologue stay on the wave-specialised kernel: the in-place transform of 2 x 18 x 18 x 32 values per tile is VALU-bound
+# and one workgroup per CU (137 KB of LDS) cannot hide it (measured 103-117 us against 101-113 at 256^2, tools/stream_probe.py)
+STREAM_CONCAT_PRO = int(_os.environ.get("IMAGEN_STREAM_CONCAT_PRO", "0"))
+
+
+def stream_cfg() -> Optional[int]:
+    """Tile cfg id of the streaming family (family 3), None if the library has none."""
+    return next((i for i, c in enumerate(cfg_table()) if c[3] == 3), None)
 
 
 def _pick_dma(Cout: int, OH: int, OW: int, B: int, full_cout: bool):
@@ -437,6 +447,16 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
     C2 = x2.C if x2 is not None else 0
     assert x1.C + C2 == pw.Cin, f"{label}: input channels {x1.C}+{C2} != weight Cin {pw.Cin}"
     want_gca = gca is not None and GCA_IN_EPILOGUE and out_mode == OUT_NHWC and act_out == ACT_NONE and addend is None and res is None and post is None
+    if cfg is None and CONV_STREAM and KH == 3 and KW == 3 and stride == 1 and pad == 1 and pw.G == 4:
+        # the streaming family: C_out <= 32 from one or two 32-channel inputs, raw or with the ssq-statistics Block prologue
+        no_pro = mu is None and rs is None and pa is None and ps is None and ssq_a is None and act_in == ACT_NONE
+        ssq_pro = mu is None and rs is None and pa is not None and ssq_a is not None and act_in in (ACT_NONE, ACT_SILU)
+        tiles16 = x1.B * math.ceil(OH / 16) * math.ceil(OW / 16)
+        gca_here = want_gca and tiles16 <= GCA_EPILOGUE_MAX_TILES     # (the other families emit the GlobalContext partials of such layers)
+        if (pw.Cout <= 32 and x1.C == 32 and C2 in (0, 32) and pw.Cin_pad == x1.C + C2 and x1.ld % 8 == 0 and (x2 is None or x2.ld % 8 == 0)
+                and (no_pro or (ssq_pro and (C2 == 0 or STREAM_CONCAT_PRO))) and not gca_here and tiles16 >= STREAM_MIN_TILES
+                and stream_cfg() is not None):
+            cfg = (stream_cfg(), 16, 16)
     if cfg is None:
         raw = (x2 is None and mu is None and rs is None and pa is None and ps is None and ssq_a is None and act_in == ACT_NONE
                and x1.C % 32 == 0 and pw.Cin_pad == x1.C and x1.ld % 8 == 0)
@@ -501,7 +521,7 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
     # all Cout); `p.gca_part_t` ([B, chunks, Cout + 2], chunks = tiles per image = `p.gca_chunks`) then feeds GCA_FINAL directly
     p.gca_part_t, p.gca_chunks = None, 0
     chunks = math.ceil(OH / th) * math.ceil(OW / tw)
-    if want_gca and cfg_table()[cid][3] in (1, 2) and pw.Cout <= cfg_table()[cid][1] and x1.B * chunks <= GCA_EPILOGUE_MAX_TILES:
+    if want_gca and cfg_table()[cid][3] in (1, 2) and pw.Cout <= cfg_table()[cid][1] and x1.B * chunks <= GCA_EPILOGUE_MAX_TILES:   # (not family 3)
         part = torch.empty(x1.B, chunks, pw.Cout + 2, dtype=torch.float32, device=x1.t.device)
         p.gca_wk, p.gca_part, p.gca_bk = gca["wk"].data_ptr(), part.data_ptr(), gca["bk"]
         keep += [gca["wk"], part]

@@ -48,7 +48,7 @@ def _shapes(ops, cfg, K, stride, H, W):
 def test_conv3x3_block_every_cfg_and_tile_shape(ops, dev, cfg):
     """Block conv (prologue rs * pa + ps -> SiLU, concat input, bias), plain NHWC output with ssq_out where one tile covers Cout."""
     tp, bn, G, fam = ops.cfg_table()[cfg]
-    if G not in (1, 4) or fam == 2:
+    if G not in (1, 4) or fam in (2, 3):
         pytest.skip("3x3 convs with a prologue use 8- or 32-channel chunks of families 0 / 1")
     C1, C2 = (64, 32) if G == 4 else (16, 8)
     H, W = (40, 36) if tp >= 128 else (20, 24)
@@ -69,7 +69,7 @@ def test_conv3x3_raw_post_and_ssq_prologue_every_cfg(ops, dev, cfg):
     """The two fused forms of a ResnetBlock: conv1 with ssq statistics (ssq_a + wb * ssq_b over the concat) and the output-side
     Block prologue (post_pa); conv2 staging an already activated input with no arithmetic (prologue none)."""
     tp, bn, G, fam = ops.cfg_table()[cfg]
-    if G != 4 or fam == 2:
+    if G != 4 or fam in (2, 3):
         pytest.skip("32-channel chunks of families 0 / 1 only")
     H, W = (32, 48) if tp >= 128 else (16, 24)
     shapes = _shapes(ops, cfg, 3, 1, H, W)
@@ -106,6 +106,35 @@ def test_conv_dma_every_cfg(ops, dev, cfg):
     if bn <= 128:
         r = run_case(ops, dev, B=2, H=H, W=W, C1=32, Cout=3, epilogue="nchw", **raw)
         assert r["err"] < TOL, (cfg, "nchw", r)
+
+
+def test_conv_stream_family(ops, dev):
+    """The streaming family (csrc/conv_stream.hip): 3x3 convs to <= 32 channels from one or two 32-channel inputs — raw inputs and the
+    ssq-statistics Block prologue (per-pixel sums of squares of both inputs, per-channel gain or per-(batch, channel) affine, SiLU),
+    every epilogue, ragged images (partial tiles, zero padding), and a map with more tiles than resident workgroups so that every
+    workgroup walks several tiles (the cross-tile prefetch / double buffer / statistics hand-over)."""
+    sid = ops.stream_cfg()
+    assert sid is not None
+    cfg = (sid, 16, 16)
+    base = dict(K=3, G=4, cfg=cfg, Cout=32)
+    raw = dict(prologue="none", act_in="none")
+    for C2 in (0, 32):
+        for kw in (dict(raw, ssq_out=True), dict(prologue="ssq", affine=False, ssq_out=True), dict(prologue="ssq", affine=True),
+                   dict(prologue="ssq", affine=True, act_in="none"), dict(raw, epilogue="post"), dict(prologue="ssq", affine=False, epilogue="post"),
+                   dict(raw, epilogue="addend"), dict(prologue="ssq", affine=False, epilogue="res")):
+            r = run_case(ops, dev, B=2, H=40, W=36, C1=32, C2=C2, **base, **kw)
+            assert r["err"] < TOL and r.get("err_ssq", 0.0) < 2e-3, (C2, kw, r)
+        r = run_case(ops, dev, B=3, H=27, W=45, C1=32, C2=C2, K=3, G=4, cfg=cfg, Cout=24, prologue="ssq", affine=False)   # couts that do not fill the tile
+        assert r["err"] < TOL, (C2, "ragged", r)
+        r = run_case(ops, dev, B=2, H=33, W=20, C1=32, C2=C2, K=3, G=4, cfg=cfg, Cout=3, epilogue="nchw", **raw)
+        assert r["err"] < TOL, (C2, "nchw", r)
+    # 2 x 17 x 17 = 578 tiles (one input: 512 resident workgroups) / 2 x 23 x 12 = 552 tiles (two inputs: 256)
+    r = run_case(ops, dev, B=2, H=272, W=272, C1=32, C2=0, **base, prologue="ssq", affine=True, ssq_out=True)
+    assert r["err"] < TOL and r["err_ssq"] < 2e-3, ("many tiles", r)
+    r = run_case(ops, dev, B=2, H=360, W=190, C1=32, C2=32, **base, prologue="ssq", affine=False, epilogue="post")
+    assert r["err"] < TOL, ("many tiles, two inputs", r)
+    r = run_case(ops, dev, B=2, H=272, W=272, C1=32, C2=0, **base, **raw, ssq_out=True)
+    assert r["err"] < TOL and r["err_ssq"] < 2e-3, ("many tiles, raw", r)
 
 
 def test_act_prep(ops, dev):

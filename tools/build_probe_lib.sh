@@ -9,5 +9,5 @@ TL=$(python -c "import torch, os; print(os.path.join(os.path.dirname(torch.__fil
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DCL_PROBE -I$ROOT/include -I$P/csrc -c $P/csrc/conv_lds.hip -o $P/build/conv_lds_probe.o &
 hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -DCD_PROBE -I$ROOT/include -I$P/csrc -c $P/csrc/conv_dma.hip -o $P/build/conv_dma_probe.o &
 wait
-hipcc --offload-arch=gfx950 -shared -fPIC -o $P/libimagen_hip_probe.so $P/build/conv_lds_probe.o $P/build/conv_dma_probe.o $P/build/igemm.o $P/build/attention.o $P/build/elementwise.o $P/build/sampler.o $P/build/temporal.o $P/build/codesize.o $P/build/capi.o -L$TL -Wl,-rpath,$TL -Wl,-rpath,/opt/rocm/lib
+hipcc --offload-arch=gfx950 -shared -fPIC -o $P/libimagen_hip_probe.so $P/build/conv_lds_probe.o $P/build/conv_dma_probe.o $P/build/igemm.o $P/build/attention.o $P/build/elementwise.o $P/build/sampler.o $P/build/temporal.o $P/build/conv_stream.o $P/build/codesize.o $P/build/capi.o -L$TL -Wl,-rpath,$TL -Wl,-rpath,/opt/rocm/lib
 echo built $P/libimagen_hip_probe.so

@@ -1,7 +1,8 @@
 cd $GRAFT_REPO_ROOT
-timeout 1200 python -m pytest tests/test_model_gpu.py -m gpu -x -q 2>&1 | tail -4
-python - <<'PY'
-import json
-d=json.load(open('gpurun_out/r02_parity_model.json'))
-for k,v in d.items(): print(k, {kk:(round(vv,5) if isinstance(vv,float) else vv) for kk,vv in v.items() if kk not in ('taps','igemm_cfgs')})
-PY
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -4
+run() { printf "%-40s" "$1"; shift; env "$@" timeout 600 python bench.py --mode sequential --timesteps 200 --steps 4 --warmup 2 --no-cpu-baseline --no-roofline 2>/dev/null | python -c "import json,sys; r=json.loads(sys.stdin.read()); print(r['ms_per_step'], r['value'])"; }
+run "stream off" IMAGEN_CONV_STREAM=0
+run "stream on" IMAGEN_CONV_STREAM=1
+run "stream on + concat pro" IMAGEN_CONV_STREAM=1 IMAGEN_STREAM_CONCAT_PRO=1
+run "stream off" IMAGEN_CONV_STREAM=0
+run "stream on" IMAGEN_CONV_STREAM=1

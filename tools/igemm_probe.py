@@ -65,7 +65,7 @@ def run(name, B, H, W, C1, C2, Cout, K, variant, cfg=None, G=None):
     y = ops.new_act(B, H, W, Cout, dev)
     plan = ops.Plan()
     kw = {}
-    if variant not in ("noprologue", "addend"):
+    if variant not in ("noprologue", "addend") and not variant.startswith("raw"):
         rs = torch.rand(B * H * W, device=dev) + 0.5
         pa = torch.rand(B, pw.Cin_pad, device=dev) + 0.5
         ps = torch.rand(B, pw.Cin_pad, device=dev)
@@ -73,7 +73,7 @@ def run(name, B, H, W, C1, C2, Cout, K, variant, cfg=None, G=None):
     if variant == "addend":    # res_conv form: out = conv(x) + gate[b, c] * addend (no prologue)
         kw = dict(addend=ops.new_act(B, H, W, Cout, dev, zero=True), gate=torch.rand(B, Cout, device=dev))
     p = ops.igemm(plan, x1, pw, y, x2=x2, cfg=cfg, **kw)
-    p.dbg = int(variant[3:]) if variant.startswith("dbg") else 0   # bit mask, see ImagenIgemmParams.dbg
+    p.dbg = int(variant[3:]) if variant.startswith(("dbg", "raw")) and variant[3:] else 0   # bit mask, see ImagenIgemmParams.dbg ("rawN": no prologue + dbg N)
     for _ in range(3):
         plan.run()
     torch.cuda.synchronize()
