@@ -34,12 +34,26 @@ __device__ __forceinline__ float cl_half_reduce(float v) {
   return v;
 }
 
-template <int MI, int NI, int WM, int WN, bool GEN>
+// cl_epilogue_params: the per-channel operands of batch row `b` -> ep_par (called by the threads i < BN; barrier by the caller)
+template <int BN>
+__device__ __forceinline__ void cl_epilogue_params(const ImagenIgemmParams& p, int b, int n0, float* ep_par, int i) {
+  const int co = n0 + i;   // < Cout_pad (the bias is padded by the host; post_pa / post_ps are not)
+  ep_par[i] = p.bias ? p.bias[co] : 0.0f;
+  if (p.post_pa) {
+    ep_par[BN + i] = co < p.Cout ? p.post_pa[(size_t)b * p.post_pstride + co] : 0.0f;
+    ep_par[2 * BN + i] = co < p.Cout ? p.post_ps[(size_t)b * p.post_pstride + co] : 0.0f;
+  }
+  if (p.gca_part) ep_par[3 * BN + i] = co < p.Cout ? p.gca_wk[co] : 0.0f;
+}
+
+// PRELOADED: ep_par already holds the operands of tc.b (persistent kernels refresh it when the batch row changes): the epilogue then
+// contains NO global load — a load here is younger than the caller's in-flight prefetch, and waiting for it drains that whole queue
+template <int MI, int NI, int WM, int WN, bool GEN, bool PRELOADED = false>
 __device__ __forceinline__ void cl_epilogue(const ImagenIgemmParams& p, const ClTile& tc, f32x16 (&acc)[NI][MI], const int (&pix_y)[MI],
                                             const int (&pix_x)[MI], float* ep_red, float* ep_par, int wm, int wn, int half, int l31) {
   constexpr int PXW = 32 * MI;
   constexpr int BN = 32 * NI * WN;
-  {
+  if constexpr (!PRELOADED) {
     const int i = threadIdx.x;
     if (i < BN) {
       const int co = tc.n0 + i;   // < Cout_pad (the bias is padded by the host; post_pa / post_ps are not)

@@ -35,6 +35,7 @@ def build(B, H, C2, pro, post, stream):
     ops.CONV_STREAM = 1 if stream else 0
     try:
         p = ops.igemm(plan, x1, pw, y, x2=x2, **kw)
+        p.dbg = int(os.environ.get("STREAM_PROBE_DBG", "0")) if stream else 0   # probe library: 8 = no output stores
     finally:
         ops.CONV_STREAM = old
     return plan, p
