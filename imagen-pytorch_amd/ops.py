@@ -307,9 +307,9 @@ CONV_DMA = int(_os.environ.get("IMAGEN_CONV_DMA", "1"))             # A/B switch
 CONV_LDS_1X1 = int(_os.environ.get("IMAGEN_CONV_LDS_1X1", "0"))     # ... and for 1x1 convs / linears
 CONV_STREAM = int(_os.environ.get("IMAGEN_CONV_STREAM", "1"))       # A/B switch: the streaming kernel family (conv_stream.hip) for the 32-channel 3x3 convs
 STREAM_MIN_TILES = int(_os.environ.get("IMAGEN_STREAM_MIN_TILES", "512"))   # ... of launches with at least this many 16x16 tiles (persistent workgroups need a few tiles each)
-# ... two inputs WITH the prologue stay on the wave-specialised kernel: the in-place transform of 2 x 18 x 18 x 32 values per tile is VALU-bound
-# and one workgroup per CU (137 KB of LDS) cannot hide it (measured 103-117 us against 101-113 at 256^2, tools/stream_probe.py)
-STREAM_CONCAT_PRO = int(_os.environ.get("IMAGEN_STREAM_CONCAT_PRO", "0"))
+# ... two inputs WITH the prologue: on a par with the wave-specialised kernel (98-109 us against 99-112 at 256^2, tools/stream_probe.py: the in-place
+# transform of 2 x 18 x 18 x 32 values per tile is VALU-bound and one workgroup per CU cannot hide it); A/B switch
+STREAM_CONCAT_PRO = int(_os.environ.get("IMAGEN_STREAM_CONCAT_PRO", "1"))
 
 
 def stream_cfg() -> Optional[int]:
