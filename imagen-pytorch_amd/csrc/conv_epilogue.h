@@ -120,22 +120,34 @@ __device__ __forceinline__ void cl_epilogue(const ImagenIgemmParams& p, const Cl
 #pragma unroll
     for (int mi = 0; mi < MI; ++mi) rsn[mi] = __builtin_amdgcn_rsqf(fmaxf(tot[mi], 1e-24f));
     f16* y = reinterpret_cast<f16*>(p.y) + (size_t)b * p.bsy;
+    const bool wide = (p.Cout & 7) == 0;   // 16-byte pieces (imagen_pair_quads, common.h): quads q and q + 2 are produced together
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
-        if (co >= p.Cout) continue;
-        const float4 pa = *reinterpret_cast<const float4*>(ep_par + BN + (co - n0));
-        const float4 ps = *reinterpret_cast<const float4*>(ep_par + 2 * BN + (co - n0));
-        const float pav[4] = {pa.x, pa.y, pa.z, pa.w}, psv[4] = {ps.x, ps.y, ps.z, ps.w};
+      for (int qp = 0; qp < 2; ++qp) {
+        f16x4 o2[2][MI];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          if (op[mi] < 0) continue;
-          f16x4 o;
+        for (int h = 0; h < 2; ++h) {
+          const int q = qp + 2 * h;
+          const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
+          const int cl = min(co - n0, BN - 4);
+          const float4 pa = *reinterpret_cast<const float4*>(ep_par + BN + cl);
+          const float4 ps = *reinterpret_cast<const float4*>(ep_par + 2 * BN + cl);
+          const float pav[4] = {pa.x, pa.y, pa.z, pa.w}, psv[4] = {ps.x, ps.y, ps.z, ps.w};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (f16)silu_f(acc[ni][mi][4 * q + e] * rsn[mi] * pav[e] + psv[e]);
-          if (!CL_DBG(8)) *reinterpret_cast<f16x4*>(y + (size_t)op[mi] * p.ldy + co) = o;
+          for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) o2[h][mi][e] = (f16)silu_f(acc[ni][mi][4 * q + e] * rsn[mi] * pav[e] + psv[e]);
+            if (!wide && co < p.Cout && op[mi] >= 0 && !CL_DBG(8)) *reinterpret_cast<f16x4*>(y + (size_t)op[mi] * p.ldy + co) = o2[h][mi];
+          }
+        }
+        if (wide) {
+          const int co16 = n0 + (wn * NI + ni) * 32 + 8 * qp + 16 * half;
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            const imagen_u32x4 v = imagen_pair_quads(o2[0][mi], o2[1][mi]);
+            if (co16 < p.Cout && op[mi] >= 0 && !CL_DBG(8)) *reinterpret_cast<imagen_u32x4*>(y + (size_t)op[mi] * p.ldy + co16) = v;
+          }
         }
       }
     return;
@@ -147,28 +159,41 @@ __device__ __forceinline__ void cl_epilogue(const ImagenIgemmParams& p, const Cl
 
   if constexpr (!GEN) {   // plain NHWC output (optionally + ssq_out): branch-free
     f16* y = reinterpret_cast<f16*>(p.y) + (size_t)b * p.bsy;
+    const bool wide = (p.Cout & 7) == 0;   // 16-byte pieces (imagen_pair_quads, common.h): quads q and q + 2 are produced together
 #pragma unroll
     for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        __builtin_amdgcn_sched_barrier(0);   // one channel quad at a time (register footprint)
-        const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
-        const float4 bq = load_bias(co);   // co < Cout_pad always
-        const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
-        const float4 wq = p.gca_part ? *reinterpret_cast<const float4*>(ep_par + 3 * BN + (co - n0)) : make_float4(0.f, 0.f, 0.f, 0.f);
-        const float ww[4] = {wq.x, wq.y, wq.z, wq.w};
+      for (int qp = 0; qp < 2; ++qp) {
+        __builtin_amdgcn_sched_barrier(0);   // one pair of channel quads at a time (register footprint)
+        f16x4 o2[2][MI];
 #pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          f16x4 o;
+        for (int h = 0; h < 2; ++h) {
+          const int q = qp + 2 * h;
+          const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
+          const float4 bq = load_bias(co);   // co < Cout_pad always
+          const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
+          const float4 wq = p.gca_part ? *reinterpret_cast<const float4*>(ep_par + 3 * BN + (co - n0)) : make_float4(0.f, 0.f, 0.f, 0.f);
+          const float ww[4] = {wq.x, wq.y, wq.z, wq.w};
 #pragma unroll
-          for (int e = 0; e < 4; ++e) {
-            o[e] = (f16)(acc[ni][mi][4 * q + e] + bb[e]);
-            const float r = (float)o[e];
-            ssq_px[mi] += r * r;
-            acc[ni][mi][4 * q + e] = r;          // (the GlobalContext block below reads the stored values back from here)
-            gca_k[mi] += r * ww[e];
+          for (int mi = 0; mi < MI; ++mi) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              o2[h][mi][e] = (f16)(acc[ni][mi][4 * q + e] + bb[e]);
+              const float r = (float)o2[h][mi][e];
+              ssq_px[mi] += r * r;
+              acc[ni][mi][4 * q + e] = r;          // (the GlobalContext block below reads the stored values back from here)
+              gca_k[mi] += r * ww[e];
+            }
+            if (!wide && co < p.Cout && op[mi] >= 0 && !CL_DBG(8)) *reinterpret_cast<f16x4*>(y + (size_t)op[mi] * p.ldy + co) = o2[h][mi];
           }
-          if (co < p.Cout && op[mi] >= 0 && !CL_DBG(8)) *reinterpret_cast<f16x4*>(y + (size_t)op[mi] * p.ldy + co) = o;
+        }
+        if (wide) {
+          const int co16 = n0 + (wn * NI + ni) * 32 + 8 * qp + 16 * half;
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            const imagen_u32x4 v = imagen_pair_quads(o2[0][mi], o2[1][mi]);
+            if (co16 < p.Cout && op[mi] >= 0 && !CL_DBG(8)) *reinterpret_cast<imagen_u32x4*>(y + (size_t)op[mi] * p.ldy + co16) = v;
+          }
         }
       }
     if (p.gca_part) {

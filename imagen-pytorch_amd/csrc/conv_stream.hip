@@ -214,9 +214,22 @@ __global__ __launch_bounds__(64 * CS_NW, NCH == 1 ? 4 : 2) void conv_stream_kern
       bA[2 * dx + 1] = a0 ^ 32;   // K step 1 (groups 2 / 3)
     }
   }
-  // output offsets of this lane (bytes from the tile's first output pixel): quad q of the 32 couts at + 16 q
-  const int yoff = ((pix_y[0] * p.OW + pix_x[0]) * p.ldy + 4 * half) * 2;
+  // output offsets of this lane (bytes from the tile's first output pixel).  A lane holds channel quads 8q + 4*half + {0..3}; before
+  // the stores the two half-waves exchange quads (v_permlane32_swap) so that lanes 0-31 own channels 0-15 and lanes 32-63 channels
+  // 16-31 of their pixel as two 16-byte pieces: half the store instructions, twice the bytes per request
+  const int yoff = ((pix_y[0] * p.OW + pix_x[0]) * p.ldy + 16 * half) * 2;
   const int qoff = (pix_y[0] * p.OW + pix_x[0]) * 4;
+  // quads (q, q + 2) are exchanged dword-wise: afterwards a lane of the lower half-wave holds [own q | partner's q] = channels 8q .. 8q+7,
+  // a lane of the upper one [partner's q + 2 | own q + 2] = channels 16 + 8q .. 16 + 8q + 7 — the same register order in both halves
+  auto store_quads = [&](char* yb, const f16x4 (&oq)[4]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const uint2 lo = __builtin_bit_cast(uint2, oq[q]), hi = __builtin_bit_cast(uint2, oq[q + 2]);
+      const auto r0 = __builtin_amdgcn_permlane32_swap(lo.x, hi.x, false, false);
+      const auto r1 = __builtin_amdgcn_permlane32_swap(lo.y, hi.y, false, false);
+      *reinterpret_cast<cs_u32x4*>(yb + 16 * q) = cs_u32x4{r0[0], r1[0], r0[1], r1[1]};
+    }
+  };
 
   Cur c;
   c.t = blockIdx.x;
@@ -238,7 +251,9 @@ __global__ __launch_bounds__(64 * CS_NW, NCH == 1 ? 4 : 2) void conv_stream_kern
   int cur = 0;
   int ep_b = -1;
   int stores_behind = 0;
-  const int quads = (GEN || CL_DBG(8)) ? 0 : min((p.Cout + 7) >> 3, 4);
+  // store instructions of the plain / post epilogue of conv_epilogue.h per wave (a lower bound is what the wait needs): one 16-byte piece
+  // per pair of channel quads when Cout is a multiple of 8, else one 8-byte store per quad below Cout
+  const int quads = (GEN || CL_DBG(8)) ? 0 : ((p.Cout & 7) == 0 ? 1 + (p.Cout > 8 ? 1 : 0) : min((p.Cout + 7) >> 3, 4));
   const bool lean_ok = !GEN && p.Cout == 32 && !CL_DBG(8);   // the lean epilogue writes all four channel quads
 
   while (true) {
@@ -339,29 +354,29 @@ __global__ __launch_bounds__(64 * CS_NW, NCH == 1 ? 4 : 2) void conv_stream_kern
         for (int r = 0; r < 16; ++r) tot += acc[0][0][r] * acc[0][0][r];
         tot += __shfl_xor(tot, 32);
         const float rsn = __builtin_amdgcn_rsqf(fmaxf(tot, 1e-24f));
+        f16x4 oq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           const float4 pa = *reinterpret_cast<const float4*>(ep_par + 32 + 8 * q + 4 * half);
           const float4 ps = *reinterpret_cast<const float4*>(ep_par + 64 + 8 * q + 4 * half);
           const float pav[4] = {pa.x, pa.y, pa.z, pa.w}, psv[4] = {ps.x, ps.y, ps.z, ps.w};
-          f16x4 o;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) o[e] = (f16)silu_f(acc[0][0][4 * q + e] * rsn * pav[e] + psv[e]);
-          *reinterpret_cast<f16x4*>(yb + 16 * q) = o;
+          for (int e = 0; e < 4; ++e) oq[q][e] = (f16)silu_f(acc[0][0][4 * q + e] * rsn * pav[e] + psv[e]);
         }
+        store_quads(yb, oq);
       } else {
         float ssq = 0.f;
+        f16x4 oq[4];
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-          f16x4 o;
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            o[e] = (f16)acc[0][0][4 * q + e];
-            const float r = (float)o[e];
+            oq[q][e] = (f16)acc[0][0][4 * q + e];
+            const float r = (float)oq[q][e];
             ssq += r * r;
           }
-          *reinterpret_cast<f16x4*>(yb + 16 * q) = o;
         }
+        store_quads(yb, oq);
         if (p.ssq_out) {
           ssq += __shfl_xor(ssq, 32);
           if (half == 0)
@@ -373,7 +388,7 @@ __global__ __launch_bounds__(64 * CS_NW, NCH == 1 ? 4 : 2) void conv_stream_kern
     }
 
     if (!more) break;
-    stores_behind = lean ? 4 : ((tc.oy0 + CS_TH <= p.OH && tc.ox0 + CS_TW <= p.OW) ? quads : 0);
+    stores_behind = lean ? 2 : ((tc.oy0 + CS_TH <= p.OH && tc.ox0 + CS_TW <= p.OW) ? quads : 0);
     c = cn;
     tc = tn;
     cur ^= 1;

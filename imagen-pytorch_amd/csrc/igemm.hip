@@ -581,6 +581,20 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
         }
       // stores only after the last load (see the note at the store loop of the plain path below)
       prime_weights(n0_next);
+      if ((p.Cout & 7) == 0) {   // 16-byte pieces (imagen_pair_quads: all lanes take part in the exchange)
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int q = 0; q < 2; ++q) {
+            const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 16 * half;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi) {
+              const imagen_u32x4 v = imagen_pair_quads(pout[ni][q][mi], pout[ni][q + 2][mi]);
+              if (co < p.Cout && opx[mi] >= 0 && !(p.dbg & 8)) *reinterpret_cast<imagen_u32x4*>(y + (size_t)b * p.bsy + (size_t)opx[mi] * p.ldy + co) = v;
+            }
+          }
+        return;
+      }
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
@@ -627,15 +641,29 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
       prime_weights(n0_next);
       TRACE_STAMP(0, tn);   // (trace: ring re-primed)
       f16* y = reinterpret_cast<f16*>(p.y) + (size_t)b * p.bsy;
+      if ((p.Cout & 7) == 0) {   // 16-byte pieces (imagen_pair_quads: all lanes take part in the exchange)
 #pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
+        for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
+          for (int q = 0; q < 2; ++q) {
+            const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 16 * half;
 #pragma unroll
-          for (int mi = 0; mi < MI; ++mi)
-            if (co < p.Cout && op[mi] >= 0 && !(p.dbg & 8)) *reinterpret_cast<f16x4*>(y + (size_t)op[mi] * p.ldy + co) = pv[ni][q][mi];
-        }
+            for (int mi = 0; mi < MI; ++mi) {
+              const imagen_u32x4 v = imagen_pair_quads(pv[ni][q][mi], pv[ni][q + 2][mi]);
+              if (co < p.Cout && op[mi] >= 0 && !(p.dbg & 8)) *reinterpret_cast<imagen_u32x4*>(y + (size_t)op[mi] * p.ldy + co) = v;
+            }
+          }
+      } else {
+#pragma unroll
+        for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
+#pragma unroll
+            for (int mi = 0; mi < MI; ++mi)
+              if (co < p.Cout && op[mi] >= 0 && !(p.dbg & 8)) *reinterpret_cast<f16x4*>(y + (size_t)op[mi] * p.ldy + co) = pv[ni][q][mi];
+          }
+      }
     } else {
     f16x4 outv[NI][4][MI];   // packed outputs (they take over the accumulators' registers as those die)
     // gate + (addend | residual) quads of the channel-quad groups
