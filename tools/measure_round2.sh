@@ -3,9 +3,9 @@
 cd $GRAFT_REPO_ROOT
 R=$GRAFT_REPO_ROOT
 mkdir -p gpurun_out
-rm -f gpurun_out/r02_parity_model.json
+if [ -z "$SKIP_PYTEST" ]; then rm -f gpurun_out/r02_parity_model.json; fi
 echo "=== pytest -m gpu"
-timeout 1500 python -m pytest tests -m gpu -x -q --tb=short 2>&1 | tail -6 | tee gpurun_out/r02_pytest_gpu.txt
+if [ -z "$SKIP_PYTEST" ]; then timeout 1500 python -m pytest tests -m gpu -x -q --tb=short 2>&1 | tail -6 | tee gpurun_out/r02_pytest_gpu.txt; fi
 echo "=== bench (default schedule, 1000 steps) with live PMC passes"
 timeout 1200 python bench.py --steps 3 --warmup 3 > gpurun_out/r02_bench.json 2> gpurun_out/r02_bench.err; tail -12 gpurun_out/r02_bench.err; cut -c1-1500 gpurun_out/r02_bench.json
 cd /tmp && export TMPDIR=/tmp
