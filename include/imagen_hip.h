@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define IMAGEN_ABI_VERSION 2
+#define IMAGEN_ABI_VERSION 3 /* 3: head_dim in the attention / QNORM / KV_PREP params */
 
 typedef void* imagen_stream_t; /* hipStream_t */
 
