@@ -78,6 +78,14 @@ __device__ __forceinline__ imagen_u32x4 imagen_pair_quads(const f16x4& q_lo, con
   const auto r1 = __builtin_amdgcn_permlane32_swap(lo.y, hi.y, false, false);
   return imagen_u32x4{r0[0], r1[0], r0[1], r1[1]};
 }
+// The inverse: a 16-byte piece loaded at the paired position (couts 8q + 16 * half .. + 7) back into the lane's own quads q and q + 2
+// (the swap is an involution).  Must be executed by ALL lanes of the wave.
+__device__ __forceinline__ void imagen_unpair_quads(const imagen_u32x4& v, f16x4& q_lo, f16x4& q_hi) {
+  const auto r0 = __builtin_amdgcn_permlane32_swap(v[0], v[2], false, false);
+  const auto r1 = __builtin_amdgcn_permlane32_swap(v[1], v[3], false, false);
+  q_lo = __builtin_bit_cast(f16x4, uint2{r0[0], r1[0]});
+  q_hi = __builtin_bit_cast(f16x4, uint2{r0[1], r1[1]});
+}
 
 // op launchers (one per translation unit)
 int launch_igemm(const ImagenIgemmParams* p, hipStream_t s);

@@ -686,7 +686,41 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
     // tile instead of one per channel quad — in the graph the res_conv launches (a 1x1 GEMM of 1-3 k-chunks behind this epilogue)
     // cost 1.18 ms of a 10.5 ms step pair with the one-group-ahead form (tools/ablate_step.sh)
     EpiOps E[4 * NI];
-    static_for<4 * NI>([&](auto gc) __attribute__((always_inline)) { load_group(decltype(gc)::value, E[decltype(gc)::value]); });
+    // 16-byte pieces for the NHWC operands and outputs when the channel counts allow it (imagen_pair_quads: a lane's quads q and q + 2
+    // against its half-wave partner's): half the memory instructions of the 8-byte form, each a full 16 bytes per lane
+    const f16* eop = addend ? addend + (size_t)b * p.bs_add : (res ? res + (size_t)b * p.bs_res : nullptr);
+    const int eld = addend ? p.ld_add : p.ld_res;
+    const bool wide = p.out_mode == IMAGEN_OUT_NHWC && ((p.Cout | p.ldy | eld) & 7) == 0 && (p.bsy & 7) == 0 &&
+                      (((size_t)p.y | (size_t)eop) & 15) == 0 && !(p.dbg & 256);
+    if (wide && eop) {
+      imagen_u32x4 raw[NI][2][MI];
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+          const int cx = n0 + (wn * NI + ni) * 32 + 8 * qp + 16 * half;
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            raw[ni][qp][mi] = imagen_u32x4{0u, 0u, 0u, 0u};
+            if (cx < p.Cout) raw[ni][qp][mi] = *reinterpret_cast<const imagen_u32x4*>(eop + (size_t)max(op[mi], 0) * eld + cx);
+          }
+        }
+      if (addend) {
+#pragma unroll
+        for (int g = 0; g < 4 * NI; ++g) {
+          const int co = n0 + (wn * NI + (g >> 2)) * 32 + 8 * (g & 3) + 4 * half;
+          if (co < p.Cout) E[g].g = *reinterpret_cast<const float4*>(p.gate + (size_t)b * p.gate_stride + co);
+        }
+      }
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp)
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) imagen_unpair_quads(raw[ni][qp][mi], E[ni * 4 + qp].ar[mi], E[ni * 4 + qp + 2].ar[mi]);
+    } else {
+      static_for<4 * NI>([&](auto gc) __attribute__((always_inline)) { load_group(decltype(gc)::value, E[decltype(gc)::value]); });
+    }
     static_for<4 * NI>([&](auto gc) __attribute__((always_inline)) {
       constexpr int g = decltype(gc)::value;
       constexpr int ni = g >> 2, q = g & 3;
@@ -700,6 +734,7 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
         const float bb[4] = {bq.x, bq.y, bq.z, bq.w};
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) {
+          outv[ni][q][mi] = f16x4{};   // defined for the lane exchange of the 16-byte stores even where nothing is stored
           if (op[mi] < 0) continue;
           float v[4];
 #pragma unroll
@@ -735,6 +770,9 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
           }
           outv[ni][q][mi] = o;   // stored below, after the last load of this epilogue
         }
+      } else {
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) outv[ni][q][mi] = f16x4{};
       }
     });
     // all stores together: vmcnt retires in issue order and counts stores, so a wait on a load issued AFTER a store also waits
@@ -743,7 +781,20 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
     TRACE_STAMP(0, tn);   // (trace: phase 1 of the epilogue done)
     prime_weights(n0_next);
     TRACE_STAMP(0, tn);   // (trace: ring re-primed)
-    if (p.out_mode != IMAGEN_OUT_NCHW_F32) {
+    if (wide) {
+      f16* y = reinterpret_cast<f16*>(p.y) + (size_t)b * p.bsy;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+          const int cx = n0 + (wn * NI + ni) * 32 + 8 * qp + 16 * half;
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            const imagen_u32x4 v = imagen_pair_quads(outv[ni][qp][mi], outv[ni][qp + 2][mi]);
+            if (cx < p.Cout && op[mi] >= 0 && !(p.dbg & 8)) *reinterpret_cast<imagen_u32x4*>(y + (size_t)op[mi] * p.ldy + cx) = v;
+          }
+        }
+    } else if (p.out_mode != IMAGEN_OUT_NCHW_F32) {
       f16* y = reinterpret_cast<f16*>(p.y);
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)

@@ -1,14 +1,11 @@
-cd $GRAFT_REPO_ROOT
-mkdir -p gpurun_out
-timeout 1500 python -m pytest tests -m gpu -x -q --tb=short 2>&1 | tail -8 > gpurun_out/r02_p_pytest.txt
-cat gpurun_out/r02_p_pytest.txt
-run() { printf "%-50s" "$1"; shift; env "$@" timeout 600 python bench.py --timesteps 200 --steps 4 --warmup 2 --no-cpu-baseline --no-roofline 2>gpurun_out/bench_p.err | python -c "import json,sys; r=json.loads(sys.stdin.read()); print(r['ms_per_step'], r['value'])"; }
-export IMAGEN_CONV_DMA=0 IMAGEN_GCA_IN_EPILOGUE=0
-run "r01path sequential" IMAGEN_BENCH_MODE=sequential
-run "r01path sequential slow-gca-final" IMAGEN_BENCH_MODE=sequential IMAGEN_GCA_FINAL_SLOW=1
-run "r01path pipeline" IMAGEN_BENCH_MODE=pipeline
-run "r01path lanes" IMAGEN_BENCH_MODE=lanes
-export IMAGEN_CONV_DMA=1 IMAGEN_GCA_IN_EPILOGUE=1 IMAGEN_ACT_PREP_MIN_COUT=0
-run "dma sequential" IMAGEN_BENCH_MODE=sequential
-run "dma pipeline" IMAGEN_BENCH_MODE=pipeline
-tail -3 gpurun_out/bench_p.err
+#!/bin/bash
+# round 2, call P: 16-byte operand loads / stores in the generic igemm epilogue — parity, A/B on the res_conv shapes, sequential bench
+cd "$GRAFT_REPO_ROOT"; mkdir -p gpurun_out
+timeout 420 python -m pytest tests -m gpu -x -q 2>&1 | tail -5 > gpurun_out/p_pytest.txt
+for d in 0 256; do
+  echo "== IMAGEN_IGEMM_DBG=$d" >> gpurun_out/p_latency.txt
+  IMAGEN_IGEMM_DBG=$d timeout 200 python tools/latency_probe.py res_conv 2>&1 | grep -v MIX >> gpurun_out/p_latency.txt
+done
+timeout 300 python bench.py --steps 6 --warmup 3 --no-pmc > gpurun_out/p_bench.json 2> gpurun_out/p_bench.err
+IMAGEN_IGEMM_DBG=256 timeout 300 python bench.py --steps 6 --warmup 3 --no-pmc --mode sequential > gpurun_out/p_bench_old.json 2>> gpurun_out/p_bench.err
+tail -3 gpurun_out/p_pytest.txt; cat gpurun_out/p_latency.txt; cut -c1-400 gpurun_out/p_bench.json; cut -c1-300 gpurun_out/p_bench_old.json

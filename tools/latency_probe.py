@@ -148,6 +148,10 @@ def main():
         ("conv 64->64 k3 @64 raw", (16, 64, 64, 64, 0, 64, 3), {}),
         ("res_conv 384->256 k1 @8 addend", (16, 8, 8, 256, 128, 256, 1), dict(addend=True)),
         ("res_conv 192->128 k1 @16 addend", (16, 16, 16, 128, 64, 128, 1), dict(addend=True)),
+        ("res_conv 64->32 k1 @256 addend", (16, 256, 256, 32, 32, 32, 1), dict(addend=True)),
+        ("res_conv 96->64 k1 @128 addend", (16, 128, 128, 64, 32, 64, 1), dict(addend=True)),
+        ("res_conv 192->128 k1 @64 addend", (16, 64, 64, 128, 64, 128, 1), dict(addend=True)),
+        ("res_conv 384->256 k1 @32 addend", (16, 32, 32, 256, 128, 256, 1), dict(addend=True)),
         ("lin 128->128 rows 16 (to_time_cond)", (1, 1, 16, 128, 0, 128, 1), {}),
         ("lin 256->128 rows 16x64 pro (ff.lin2)", (16, 1, 64, 256, 0, 128, 1), dict(pro=True)),
         ("lin 256->128 rows 16x64 raw", (16, 1, 64, 256, 0, 128, 1), {}),
