@@ -198,7 +198,7 @@ class ElucidatedImagen(Imagen):
         return st
 
     @torch.no_grad()
-    def p_sample_loop(self, st, *, noise_fn: Optional[Callable], stage: int, seed: int, use_graph: bool = True, use_tqdm: bool = False,
+    def _run_stage(self, st, *, noise_fn: Optional[Callable], stage: int, seed: int, use_graph: bool = True, use_tqdm: bool = False,
                       max_steps: Optional[int] = None, trace: Optional[list] = None, init_images=None, skip_steps=None):
         """el.py:393-545 for one stage (init_images / skip_steps are rejected by sample())."""
         assert init_images is None and not skip_steps

@@ -165,6 +165,8 @@ class Imagen(nn.Module):
         self.can_classifier_guidance = cond_drop_prob > 0.
         self.auto_normalize_img = auto_normalize_img
         self.input_image_range = (0. if auto_normalize_img else -1., 1.)
+        self.normalize_img = (lambda img: img * 2 - 1) if auto_normalize_img else (lambda img: img)          # ip.py:1885-1888
+        self.unnormalize_img = (lambda img: (img + 1) * 0.5) if auto_normalize_img else (lambda img: img)
         self.dynamic_thresholding = _cast_tuple(dynamic_thresholding, num_unets)
         self.dynamic_thresholding_percentile = dynamic_thresholding_percentile
         min_snr_loss_weight = _cast_tuple(min_snr_loss_weight, num_unets)
@@ -393,7 +395,7 @@ class Imagen(nn.Module):
         return st
 
     @torch.no_grad()
-    def p_sample_loop(self, st, *, noise_fn: Optional[Callable], stage: int, seed: int, use_graph: bool = True, use_tqdm: bool = False,
+    def _run_stage(self, st, *, noise_fn: Optional[Callable], stage: int, seed: int, use_graph: bool = True, use_tqdm: bool = False,
                       max_steps: Optional[int] = None, trace: Optional[list] = None, init_images: Optional[torch.Tensor] = None,
                       skip_steps: Optional[int] = None):
         """ip.py:2167-2289 for one stage: x_T ~ N(0, I) (+ init_images), the ancestral steps from `skip_steps` on (each run
@@ -466,6 +468,114 @@ class Imagen(nn.Module):
         if R:
             out = torch.where(st['mask'] != 0, (st['known'] + 1) * 0.5, out)   # ip.py:2283-2288
         return out
+
+    # ---- the reference's step-level sampler methods (ip.py:2042-2289) ------------------------------------------------------
+    # `sample()` below runs a whole stage as one captured graph per timestep and never calls these.  They are the reference's
+    # per-step API, kept for callers that drive single steps themselves (custom loops, guidance experiments): the denoiser
+    # evaluation goes through the same kernel plan (Unet.forward_with_cond_scale), the O(B*3*S*S) posterior arithmetic around it is
+    # plain device-side tensor code with the reference's signatures, argument meaning and return values.
+    def resize_to(self, img, size, **kwargs):
+        """Nearest-neighbour resize of images (ip.py:152-168; the only resize_mode of this build)."""
+        assert not kwargs or self.is_video, 'frame arguments are for video stages'
+        if img.ndim == 5:
+            _out_of_scope("resize_to for videos outside sample()")
+        return img if img.shape[-1] == size else F.interpolate(img, size, mode='nearest')
+
+    def _step_conditioning_checks(self, unet, cond_images, self_cond, cond_video_frames, post_cond_video_frames, cond_scale):
+        assert not (cond_scale != 1. and not self.can_classifier_guidance), \
+            'imagen was not trained with conditional dropout, and thus one cannot use classifier free guidance (cond_scale anything other than 1)'
+        for name, val in (('cond_images', cond_images), ('self_cond', self_cond), ('cond_video_frames', cond_video_frames),
+                          ('post_cond_video_frames', post_cond_video_frames)):
+            if val is not None:
+                _out_of_scope(f"{name}=...")
+        if isinstance(unet, Unet3D):
+            _out_of_scope("step-level sampling of video stages (use sample(video_frames=...))")
+
+    @torch.no_grad()
+    def p_mean_variance(self, unet, x, t, *, noise_scheduler, text_embeds=None, text_mask=None, cond_images=None, cond_video_frames=None,
+                        post_cond_video_frames=None, lowres_cond_img=None, self_cond=None, lowres_noise_times=None, cond_scale=1.,
+                        model_output=None, t_next=None, pred_objective='noise', dynamic_threshold=True):
+        """ip.py:2042-2110: denoiser output (or `model_output`) -> x_0 estimate -> threshold -> posterior (mean, variance,
+        log variance) of x_{t_next}; returns that triple and the thresholded x_0."""
+        self._step_conditioning_checks(unet, cond_images, self_cond, cond_video_frames, post_cond_video_frames, cond_scale)
+        pred = model_output
+        if pred is None:
+            pred = unet.forward_with_cond_scale(x, noise_scheduler.get_condition(t), text_embeds=text_embeds, text_mask=text_mask,
+                                                cond_scale=cond_scale, lowres_cond_img=lowres_cond_img,
+                                                lowres_noise_times=self.lowres_noise_schedule.get_condition(lowres_noise_times))
+        if pred_objective == 'noise':
+            x_start = noise_scheduler.predict_start_from_noise(x, t=t, noise=pred)
+        elif pred_objective == 'x_start':
+            x_start = pred
+        elif pred_objective == 'v':
+            x_start = noise_scheduler.predict_start_from_v(x, t=t, v=pred)
+        else:
+            raise ValueError(f'unknown objective {pred_objective}')
+        if dynamic_threshold:
+            # per-sample percentile of |x_0|, never below 1: clamp to it and rescale into [-1, 1] (Imagen paper, appendix)
+            s = torch.quantile(x_start.flatten(1).abs(), self.dynamic_thresholding_percentile, dim=-1).clamp(min=1.)
+            s = s.reshape(-1, *((1,) * (x_start.ndim - 1)))
+            x_start = x_start.clamp(-s, s) / s
+        else:
+            x_start = x_start.clamp(-1., 1.)
+        return noise_scheduler.q_posterior(x_start=x_start, x_t=x, t=t, t_next=t_next), x_start
+
+    @torch.no_grad()
+    def p_sample(self, unet, x, t, *, noise_scheduler, t_next=None, text_embeds=None, text_mask=None, cond_images=None,
+                 cond_video_frames=None, post_cond_video_frames=None, cond_scale=1., self_cond=None, lowres_cond_img=None,
+                 lowres_noise_times=None, pred_objective='noise', dynamic_threshold=True):
+        """ip.py:2112-2165: one ancestral step, x_{t_next} = mean + [t_next != 0] * exp(log_var / 2) * eps; returns it and x_0."""
+        (mean, _, log_var), x_start = self.p_mean_variance(
+            unet, x=x, t=t, t_next=t_next, noise_scheduler=noise_scheduler, text_embeds=text_embeds, text_mask=text_mask,
+            cond_images=cond_images, cond_video_frames=cond_video_frames, post_cond_video_frames=post_cond_video_frames,
+            cond_scale=cond_scale, self_cond=self_cond, lowres_cond_img=lowres_cond_img, lowres_noise_times=lowres_noise_times,
+            pred_objective=pred_objective, dynamic_threshold=dynamic_threshold)
+        noise = torch.randn_like(x)
+        last = (t_next == 0) if isinstance(noise_scheduler, GaussianDiffusionContinuousTimes) else (t == 0)
+        nonzero = (1 - last.float()).reshape(x.shape[0], *((1,) * (x.ndim - 1)))
+        return mean + nonzero * (0.5 * log_var).exp() * noise, x_start
+
+    @torch.no_grad()
+    def p_sample_loop(self, unet, shape, *, noise_scheduler, lowres_cond_img=None, lowres_noise_times=None, text_embeds=None,
+                      text_mask=None, cond_images=None, cond_video_frames=None, post_cond_video_frames=None, inpaint_images=None,
+                      inpaint_videos=None, inpaint_masks=None, inpaint_resample_times=5, init_images=None, skip_steps=None, cond_scale=1,
+                      pred_objective='noise', dynamic_threshold=True, use_tqdm=True):
+        """ip.py:2167-2289 with the reference's signature: the loop of one stage, step by step through `p_sample` (torch's
+        generator supplies the noise, in the reference's draw order).  `sample()` is the fast way to run a stage."""
+        if inpaint_videos is not None or len(shape) == 5:
+            _out_of_scope("step-level sampling of videos (use sample(video_frames=...))")
+        device = self.device
+        batch = shape[0]
+        img = torch.randn(shape, device=device)
+        if init_images is not None:
+            img = img + init_images
+        inpainting = inpaint_images is not None and inpaint_masks is not None
+        if inpainting:
+            known = self.resize_to(self.normalize_img(inpaint_images), shape[-1])
+            keep = self.resize_to(inpaint_masks[:, None].float(), shape[-1]).bool()
+        steps = noise_scheduler.get_sampling_timesteps(batch, device=device)[(skip_steps or 0):]
+        if use_tqdm:
+            try:
+                from tqdm.auto import tqdm
+                steps = tqdm(steps, desc='sampling loop time step', total=len(steps))
+            except ImportError:
+                pass
+        for times, times_next in steps:
+            final_step = bool(torch.all(times_next == 0))
+            for r in reversed(range(inpaint_resample_times if inpainting else 1)):
+                if inpainting:       # known region at this step's noise level
+                    img = torch.where(keep, noise_scheduler.q_sample(known, t=times)[0], img)
+                img, _ = self.p_sample(unet, img, times, t_next=times_next, text_embeds=text_embeds, text_mask=text_mask,
+                                       cond_images=cond_images, cond_scale=cond_scale, lowres_cond_img=lowres_cond_img,
+                                       lowres_noise_times=lowres_noise_times, noise_scheduler=noise_scheduler,
+                                       pred_objective=pred_objective, dynamic_threshold=dynamic_threshold,
+                                       cond_video_frames=cond_video_frames, post_cond_video_frames=post_cond_video_frames)
+                if inpainting and r > 0 and not final_step:      # resample: back up to this step's level (RePaint)
+                    img = noise_scheduler.q_sample_from_to(img, times_next, times)
+        img = img.clamp(-1., 1.)
+        if inpainting:
+            img = torch.where(keep, known, img)
+        return self.unnormalize_img(img)
 
     # ---- public sampling API (ip.py:2291-2498) ------------------------------------------------------------------
     @torch.no_grad()
@@ -680,7 +790,7 @@ class Imagen(nn.Module):
                     stream.synchronize()
                     import time as _time
                     t_stage = _time.perf_counter()
-                out = self.p_sample_loop(st, noise_fn=noise_fn, stage=idx, seed=seed, use_graph=use_graph, use_tqdm=use_tqdm,
+                out = self._run_stage(st, noise_fn=noise_fn, stage=idx, seed=seed, use_graph=use_graph, use_tqdm=use_tqdm,
                                          max_steps=max_steps, skip_steps=skip_steps[idx],
                                          init_images=None if init_images[idx] is None else resize(init_images[idx], S))
                 if timing:

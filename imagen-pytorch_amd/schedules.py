@@ -50,10 +50,70 @@ class GaussianDiffusionContinuousTimes(nn.Module):
     def get_condition(self, times):
         return None if times is None else self.log_snr(times)
 
+    def sample_random_times(self, batch_size, *, device=None):
+        """ip.py:239-240."""
+        return torch.rand((batch_size,), device=device, dtype=torch.float32)
+
     def get_sampling_timesteps(self, batch=None, *, device=None):
-        """ip.py:245-250: T consecutive (t, t_next) pairs of linspace(1, 0, T+1), as fp32 scalars."""
-        times = torch.linspace(1., 0., self.num_timesteps + 1)
-        return [(times[i], times[i + 1]) for i in range(self.num_timesteps)]
+        """ip.py:245-250: T consecutive (t, t_next) pairs of linspace(1, 0, T+1).  With `batch` (the reference's call) every
+        element is a (2, batch) tensor that unpacks into the per-sample `times, times_next`; without it (the coefficient tables
+        below) the pairs are fp32 scalars."""
+        times = torch.linspace(1., 0., self.num_timesteps + 1, device=device)
+        if batch is None:
+            return [(times[i], times[i + 1]) for i in range(self.num_timesteps)]
+        pairs = torch.stack((times[:-1], times[1:]))                       # (2, T)
+        return tuple(pairs[:, i, None].expand(2, batch) for i in range(self.num_timesteps))
+
+    # ---- tensor forms of the reference's scheduler API (ip.py:252-318), for callers that drive single steps themselves
+    # (Imagen.p_mean_variance / p_sample below); the sampling loop proper uses the coefficient tables instead
+    @staticmethod
+    def _per_sample(v: torch.Tensor, like: torch.Tensor) -> torch.Tensor:
+        return v.reshape(v.shape + (1,) * (like.ndim - v.ndim)) if v.ndim < like.ndim else v
+
+    def _times(self, t, like: torch.Tensor) -> torch.Tensor:
+        if isinstance(t, (int, float)):
+            t = torch.full((like.shape[0],), float(t), device=like.device, dtype=like.dtype)
+        return t
+
+    def q_posterior(self, x_start, x_t, t, *, t_next=None):
+        """Posterior q(x_{t_next} | x_t, x_0): mean, variance and log(variance clamped at 1e-20) (ip.py:252-270)."""
+        if t_next is None:
+            t_next = (t - 1. / self.num_timesteps).clamp(min=0.)
+        l, ln = self._per_sample(self.log_snr(t), x_t), self._per_sample(self.log_snr(t_next), x_t)
+        alpha, _ = log_snr_to_alpha_sigma(l)
+        alpha_n, sigma_n = log_snr_to_alpha_sigma(ln)
+        c = -torch.special.expm1(l - ln)
+        mean = alpha_n * (x_t * (1 - c) / alpha + c * x_start)
+        var = (sigma_n ** 2) * c
+        return mean, var, torch.log(var.clamp(min=1e-20))
+
+    def q_sample(self, x_start, t, noise=None):
+        """x_t = alpha_t x_0 + sigma_t eps; also returns log_snr (unpadded), alpha, sigma (ip.py:272-284)."""
+        t = self._times(t, x_start)
+        if noise is None:
+            noise = torch.randn_like(x_start)
+        l = self.log_snr(t).type(x_start.dtype)
+        alpha, sigma = log_snr_to_alpha_sigma(self._per_sample(l, x_start))
+        return alpha * x_start + sigma * noise, l, alpha, sigma
+
+    def q_sample_from_to(self, x_from, from_t, to_t, noise=None):
+        """Move a sample between noise levels (the inpainting re-noising, ip.py:286-307)."""
+        from_t, to_t = self._times(from_t, x_from), self._times(to_t, x_from)
+        if noise is None:
+            noise = torch.randn_like(x_from)
+        alpha, sigma = log_snr_to_alpha_sigma(self._per_sample(self.log_snr(from_t), x_from))
+        alpha_to, sigma_to = log_snr_to_alpha_sigma(self._per_sample(self.log_snr(to_t), x_from))
+        return x_from * (alpha_to / alpha) + noise * (sigma_to * alpha - sigma * alpha_to) / alpha
+
+    def predict_start_from_v(self, x_t, t, v):
+        """ip.py:309-313."""
+        alpha, sigma = log_snr_to_alpha_sigma(self._per_sample(self.log_snr(t), x_t))
+        return alpha * x_t - sigma * v
+
+    def predict_start_from_noise(self, x_t, t, noise):
+        """ip.py:315-318."""
+        alpha, sigma = log_snr_to_alpha_sigma(self._per_sample(self.log_snr(t), x_t))
+        return (x_t - sigma * noise) / alpha.clamp(min=1e-8)
 
     def step_coefficients(self) -> torch.Tensor:
         """[T, 8] fp32 table for the sampler kernels: ip.py:256-268 (posterior), 315-318 (x0), 2162-2163 (nonzero mask)."""

@@ -18,6 +18,9 @@ DEFAULT_TEXT_EMBED_DIM = 768  # d_model of the reference's default T5 ('google/t
 _printed_dim_hint = False
 
 
+_ENGINE_DEVICE_TYPES = ('cuda',)   # where plans can be launched; tests/test_sample_cpu_replay.py widens it after replacing the launcher
+
+
 def _cast_tuple(val, length=None):
     if isinstance(val, list):
         val = tuple(val)
@@ -289,7 +292,7 @@ class Unet(nn.Module):
         from .engine import UnetEngine
 
         device = torch.device(device)
-        if device.type != 'cuda':
+        if device.type not in _ENGINE_DEVICE_TYPES:
             raise RuntimeError("imagen_pytorch_amd.Unet runs on MI355X through libimagen_hip.so only; there is no CPU path")
         key = (batch_rows, src_batch, image_size, device.index or 0, bool(with_text))
         eng = self._engines.get(key)

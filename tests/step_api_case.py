@@ -1,0 +1,51 @@
+"""Shared by the CPU replay and the MI355X tests: the tiny two-stage cascade of tests/golden/sample_tiny_cascade.pt sampled through the
+reference's STEP-LEVEL methods (Imagen.p_sample_loop -> p_sample -> p_mean_variance, ip.py:2042-2289) the way the reference's own
+sample() strings them together (ip.py:2436-2472), with torch's Gaussian draws replaced by the recorded ones of the reference run."""
+import contextlib
+
+import torch
+import torch.nn.functional as F
+
+
+@contextlib.contextmanager
+def recorded_noise(monkeypatch, draws, device):
+    """torch.randn / torch.randn_like hand out `draws` in order (shapes checked)."""
+    queue = [d.to(device) for d in draws]
+
+    def take(shape):
+        d = queue.pop(0)
+        assert tuple(d.shape) == tuple(shape), (d.shape, shape)
+        return d.clone()
+
+    with monkeypatch.context() as m:
+        m.setattr(torch, "randn", lambda *shape, **kw: take(shape[0] if len(shape) == 1 and not isinstance(shape[0], int) else shape))
+        m.setattr(torch, "randn_like", lambda t, **kw: take(t.shape))
+        yield queue
+
+
+def run_cascade_by_steps(imagen, g, monkeypatch, device):
+    """Returns the [0, 1] images of both stages."""
+    T = g["timesteps"]
+    te = g["text_embeds"].to(device)
+    mask = torch.any(te != 0., dim=-1)
+    B = te.shape[0]
+    outs = []
+    img = None
+    for idx, (unet, S) in enumerate(zip(imagen.unets, imagen.image_sizes)):
+        sched = imagen.noise_schedulers[idx]
+        kw = {}
+        draws = []
+        if unet.lowres_cond:     # ip.py:2443-2449
+            level = imagen.lowres_sample_noise_level
+            times = imagen.lowres_noise_schedule.get_times(B, level, device=device)
+            low = imagen.normalize_img(F.interpolate(img, S, mode="nearest"))
+            low, *_ = imagen.lowres_noise_schedule.q_sample(x_start=low, t=times, noise=g["noise"][("lowres", idx)].to(device))
+            kw = dict(lowres_cond_img=low, lowres_noise_times=times)
+        draws = [g["noise"][("init", idx)]] + [g["noise"][("step", idx, i)] for i in range(T)]
+        with recorded_noise(monkeypatch, draws, device) as left:
+            img = imagen.p_sample_loop(unet, (B, imagen.channels, S, S), noise_scheduler=sched, text_embeds=te, text_mask=mask,
+                                       cond_scale=g["cond_scale"], pred_objective=imagen.pred_objectives[idx],
+                                       dynamic_threshold=imagen.dynamic_thresholding[idx], use_tqdm=False, **kw)
+            assert not left, "every recorded draw is consumed, in the reference's order"
+        outs.append(img)
+    return outs

@@ -168,6 +168,22 @@ def test_sample_vs_reference_fixture():
         assert torch.equal(a, b), "hipGraph replay must be bit-identical to eager launches"
 
 
+def test_reference_step_level_api(monkeypatch):
+    """The reference's per-step methods (Imagen.p_sample_loop / p_sample / p_mean_variance, ip.py:2042-2289) on the GPU: the cascade
+    strung together from single steps, fed the reference's recorded draws, against the reference's images and the graph path."""
+    from step_api_case import run_cascade_by_steps
+
+    dev = torch.device("cuda:0")
+    g = _load("sample_tiny_cascade.pt")
+    imagen = _tiny_cascade(g, dev, g["timesteps"])
+    outs = run_cascade_by_steps(imagen, g, monkeypatch, dev)
+    errs = [nerr(o, r) for o, r in zip(outs, g["outputs"])]
+    assert max(errs) < 2e-2, errs
+    fused = imagen.sample(text_embeds=g["text_embeds"].to(dev), cond_scale=g["cond_scale"], use_tqdm=False, return_all_unet_outputs=True,
+                          noise_fn=lambda tag, shape: g["noise"][tag].to(dev))
+    assert max(nerr(a, b) for a, b in zip(outs, fused)) < 5e-3
+
+
 def _tiny_cascade(g, dev, timesteps):
     from imagen_pytorch_amd import Imagen, Unet
 

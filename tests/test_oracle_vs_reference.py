@@ -121,3 +121,49 @@ def test_unet_oracle_config_sweep(name):
             o = uo.unet_forward(u.state_dict(), kw, x, t, text_embeds=te, cond_drop_prob=cdp, **extra)
             assert r.abs().mean() > 1e-3
             assert torch.allclose(r, o, atol=2e-5, rtol=1e-4), (name, cdp, (r - o).abs().max())
+
+
+def test_scheduler_tensor_api_is_bit_identical():
+    """GaussianDiffusionContinuousTimes' tensor methods (ip.py:223-318) against the live class: same fp32 expressions, same bits."""
+    from imagen_pytorch_amd.schedules import GaussianDiffusionContinuousTimes as Ours
+
+    ip = ref_shim.load_reference()
+    torch.manual_seed(0)
+    x0, xt, n = torch.randn(3, 3, 8, 8), torch.randn(3, 3, 8, 8), torch.randn(3, 3, 8, 8)
+    t, tn = torch.tensor([0.9, 0.5, 0.02]), torch.tensor([0.85, 0.4, 0.0])
+    calls = [("q_posterior", (x0, xt, t), {}), ("q_posterior", (x0, xt, t), dict(t_next=tn)), ("q_sample", (x0, t, n), {}),
+             ("q_sample", (x0, 0.3, n), {}), ("q_sample_from_to", (x0, tn, t, n), {}), ("q_sample_from_to", (x0, 0.2, 0.6, n), {}),
+             ("predict_start_from_v", (xt, t, n), {}), ("predict_start_from_noise", (xt, t, n), {})]
+    for ns in ("linear", "cosine"):
+        a, b = Ours(noise_schedule=ns, timesteps=37), ip.GaussianDiffusionContinuousTimes(noise_schedule=ns, timesteps=37)
+        for name, args, kw in calls:
+            ra, rb = getattr(a, name)(*args, **kw), getattr(b, name)(*args, **kw)
+            ra, rb = (ra if isinstance(ra, tuple) else (ra,)), (rb if isinstance(rb, tuple) else (rb,))
+            assert len(ra) == len(rb)
+            for u, v in zip(ra, rb):
+                assert u.shape == v.shape and torch.equal(u, v), (ns, name)
+        ta, tb = a.get_sampling_timesteps(4, device="cpu"), b.get_sampling_timesteps(4, device="cpu")
+        assert len(ta) == len(tb)
+        for (x, y), (p, q) in zip(ta, tb):
+            assert torch.equal(x, p) and torch.equal(y, q)
+        assert a.sample_random_times(5, device="cpu").shape == b.sample_random_times(5, device="cpu").shape
+
+
+@pytest.mark.parametrize("objective", ["noise", "x_start", "v"])
+@pytest.mark.parametrize("dyn", [True, False])
+def test_step_level_posterior_math(objective, dyn):
+    """Imagen.p_mean_variance / p_sample around a given model output (no denoiser call): identical to the live reference."""
+    from imagen_pytorch_amd import Imagen, Unet
+
+    ip = ref_shim.load_reference()
+    kw = dict(dim=8, cond_dim=32, dim_mults=(1, 2), num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True), attn_heads=2)
+    ref = ip.Imagen((ip.Unet(**kw),), image_sizes=(16,), timesteps=10, text_embed_dim=768, cond_drop_prob=0.1)
+    ours = Imagen((Unet(**kw),), image_sizes=(16,), timesteps=10, text_embed_dim=768, cond_drop_prob=0.1)
+    torch.manual_seed(1)
+    x, out = torch.randn(2, 3, 16, 16), 2.0 * torch.randn(2, 3, 16, 16)
+    t, tn = torch.tensor([0.6, 0.1]), torch.tensor([0.5, 0.0])
+    common = dict(t_next=tn, model_output=out, pred_objective=objective, dynamic_threshold=dyn)
+    (m1, v1, l1), s1 = ref.p_mean_variance(ref.unets[0], x, t, noise_scheduler=ref.noise_schedulers[0], **common)
+    (m2, v2, l2), s2 = ours.p_mean_variance(ours.unets[0], x, t, noise_scheduler=ours.noise_schedulers[0], **common)
+    for u, v in ((m1, m2), (v1, v2), (l1, l2), (s1, s2)):
+        assert u.shape == v.shape and torch.allclose(u, v, rtol=0, atol=1e-6)

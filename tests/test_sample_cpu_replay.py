@@ -47,6 +47,7 @@ class _Event:
 def cpu_backend(monkeypatch):
     from imagen_pytorch_amd import imagen as imagen_mod
     from imagen_pytorch_amd import ops
+    from imagen_pytorch_amd import unet as unet_mod
     from plan_interp import Interpreter
 
     it = Interpreter()
@@ -62,6 +63,7 @@ def cpu_backend(monkeypatch):
 
     monkeypatch.setattr(ops, "Graph", Graph)
     monkeypatch.setattr(imagen_mod, "_SAMPLING_DEVICE_TYPES", ("cuda", "cpu"))
+    monkeypatch.setattr(unet_mod, "_ENGINE_DEVICE_TYPES", ("cuda", "cpu"))
     monkeypatch.setattr(torch.cuda, "Stream", _Stream)
     monkeypatch.setattr(torch.cuda, "Event", _Event)
     monkeypatch.setattr(torch.cuda, "current_stream", lambda *a, **k: _Stream())
@@ -210,3 +212,23 @@ def test_video_elucidated_sample_driver(cpu_backend):
                          start_at_unet_number=2, start_image_or_video=e["outputs"][0], device="cpu")
     e1 = nerr(alone, e["outputs"][1])
     assert e0 < 3e-2 and e1 < 3e-2, (e0, e1)
+
+
+def test_reference_step_level_api(cpu_backend, monkeypatch):
+    """Imagen.p_sample_loop / p_sample / p_mean_variance with the reference's signatures (ip.py:2042-2289): the cascade strung
+    together from single steps reproduces the reference's recorded run, and agrees with the graph path of sample()."""
+    from step_api_case import run_cascade_by_steps
+
+    g = torch.load(os.path.join(GOLDEN, "sample_tiny_cascade.pt"), weights_only=False)
+    imagen = _cascade(g, timesteps=g["timesteps"])
+    outs = run_cascade_by_steps(imagen, g, monkeypatch, torch.device("cpu"))
+    errs = [nerr(o, r) for o, r in zip(outs, g["outputs"])]
+    assert max(errs) < 2e-2, errs
+    fused = imagen.sample(text_embeds=g["text_embeds"], cond_scale=g["cond_scale"], use_tqdm=False, return_all_unet_outputs=True,
+                          noise_fn=lambda tag, shape: g["noise"][tag], device="cpu")
+    assert max(nerr(a, b) for a, b in zip(outs, fused)) < 5e-3
+    # out-of-scope conditioning is refused, not ignored
+    sched = imagen.noise_schedulers[0]
+    x = torch.zeros(1, 3, 16, 16)
+    with pytest.raises(NotImplementedError):
+        imagen.p_sample(imagen.unets[0], x, torch.ones(1), t_next=torch.zeros(1), noise_scheduler=sched, cond_images=x)
