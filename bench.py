@@ -285,7 +285,9 @@ def main():
     ap.add_argument("--mode", choices=("sequential", "pipeline", "lanes"), default=os.environ.get("IMAGEN_BENCH_MODE", "lanes"),
                     help="how successive batches are scheduled on the GPU: one sample() after the other | cascade stages overlapped across "
                          "batches (Imagen.sample_pipelined) | --lanes whole cascades side by side (one thread + stream each)")
-    ap.add_argument("--lanes", type=int, default=int(os.environ.get("IMAGEN_BENCH_LANES", "3")))
+    ap.add_argument("--lanes", type=int, default=int(os.environ.get("IMAGEN_BENCH_LANES", "0")),
+                    help="concurrent cascades in --mode lanes; 0 = 3..5, whichever wastes the fewest lane-slots in the last round of --steps "
+                         "(throughput is flat from 3 lanes up — DESIGN.md, lanes paragraph — so only the tail matters)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic / mfma_busy_frac = null)")
@@ -295,6 +297,8 @@ def main():
         print(json.dumps(cpu_baseline_leg(None, args.batch)), flush=True)
         return
 
+    if args.lanes <= 0:
+        args.lanes = min(range(3, 6), key=lambda l: (-args.steps % l, l)) if args.steps >= 3 else max(args.steps, 1)
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
