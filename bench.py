@@ -107,7 +107,7 @@ def pmc_traffic_leg(log):
             cmd = [rocprof, "--pmc", *counters, "--output-format", "csv", "-d", os.path.join(tmp, "out"), "--",
                    sys.executable, os.path.join(ROOT, "tools", "graph_profile.py"), "run", "--steps", "5", "--plan-out", plan_path]
             env = dict(os.environ, TMPDIR="/tmp")
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=420)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=150)
             csvs = [os.path.join(d, f) for d, _, fs in os.walk(os.path.join(tmp, "out")) for f in fs if f.endswith("counter_collection.csv")]
             if r.returncode != 0 or not csvs or not os.path.exists(plan_path):
                 log(f"pmc pass {counters}: rocprofv3 failed (rc {r.returncode}): {r.stdout.decode(errors='replace')[-300:]}")
