@@ -142,6 +142,12 @@ class UnetEngine:
         R, S, u = self.R, self.S, self.unet
         self.x_in = self.f32buf(self.src_batch, u.channels, S, S, zero=True)      # fp32 NCHW staging (or the sampler's state)
         self.lowres_in = self.f32buf(self.src_batch, u.channels, S, S, zero=True) if self.lowres else None
+        # conditioning image (Unet(cond_images_channels=...), ip.py:1555-1560): fp32 NCHW staging + its fp16 NHWC copy, packed once per
+        # set_cond_images() — it does not change over the timesteps — and read by the init conv as a second (concatenated) input
+        cc = getattr(u, 'cond_images_channels', 0)
+        self.cond_in = self.f32buf(self.src_batch, cc, S, S, zero=True) if cc else None
+        self.cimg = self.new(R, S, S, (cc + 7) // 8 * 8, zero=True) if cc else None
+        self._cond_pack = None
         self.times = self.f32buf(R, zero=True)          # log-SNR per row (plain forward mode)
         self.lowres_times = self.f32buf(R, zero=True)
         self.out = self.f32buf(R, u.channels_out, S, S)
@@ -291,24 +297,32 @@ class UnetEngine:
         or the plain init conv (ip.py:1198)."""
         u = self.unet
 
+        cc = self.cond_in.shape[1] if self.cond_in is not None else 0
+        ccp = self.cimg.C if cc else 0
+
+        def spread(w):
+            """Reference input channels [cond image | x | lowres] (ip.py:1545-1560) -> ours [x | lowres | 0.. (8) | cond image | 0.. (ccp)]."""
+            wp = torch.zeros(w.shape[0], 8 + ccp, *w.shape[2:])
+            wp[:, : w.shape[1] - cc] = w[:, cc:]
+            wp[:, 8: 8 + cc] = w[:, :cc]
+            return wp
+
         def make():
             if isinstance(u.init_conv, CrossEmbedP):
                 kmax = max(u.init_conv.kernel_sizes)
                 ws, bs = [], []
                 for conv, k in zip(u.init_conv.convs, u.init_conv.kernel_sizes):
-                    w = torch.zeros(conv.weight.shape[0], 8, kmax, kmax)
+                    w = torch.zeros(*conv.weight.shape[:2], kmax, kmax)
                     p = (kmax - k) // 2
-                    w[:, : conv.weight.shape[1], p:p + k, p:p + k] = conv.weight.detach().float()
-                    ws.append(w)
+                    w[:, :, p:p + k, p:p + k] = conv.weight.detach().float()
+                    ws.append(spread(w))
                     bs.append(conv.bias.detach().float())
                 return ops.pack_weight(torch.cat(ws), torch.cat(bs), self.dev, G=1)
             conv = u.init_conv
-            w = torch.zeros(conv.weight.shape[0], 8, *conv.weight.shape[2:])
-            w[:, : conv.weight.shape[1]] = conv.weight.detach().float()
-            return ops.pack_weight(w, conv.bias.detach().float(), self.dev, G=1)
+            return ops.pack_weight(spread(conv.weight.detach().float()), conv.bias.detach().float(), self.dev, G=1)
 
         out.ssq = self.f32buf(out.rows)
-        op = ops.igemm(plan, self.img, self.W.get("init_conv", make), out, ssq_out=out.ssq, label="init_conv")
+        op = ops.igemm(plan, self.img, self.W.get("init_conv", make), out, x2=self.cimg, ssq_out=out.ssq, label="init_conv")
         if not op.ssq_emitted:
             out.ssq = None
 
@@ -830,6 +844,23 @@ class UnetEngine:
         p = self._time_embed_op
         p.times, p.coef, p.step_ptr = None, coef.data_ptr(), step_ptr.data_ptr()
         self.coef, self.step_ptr = coef, step_ptr
+
+    def set_cond_images(self, cond_images: torch.Tensor):
+        """The conditioning image of the following forward / sampling calls: (src_batch, cond_images_channels, h, w), values as given
+        (the reference does not normalise it); nearest-resized to this engine's resolution (ip.py:1558-1559) and packed to fp16 NHWC."""
+        assert self.cond_in is not None, 'this unet was built without cond_images_channels'
+        assert cond_images.shape[1] == self.cond_in.shape[1], \
+            'the number of channels on the conditioning image you are passing in does not match what you specified on initialiation of the unet'
+        assert cond_images.shape[0] == self.src_batch, f'cond_images batch {cond_images.shape[0]} != {self.src_batch}'
+        ci = cond_images.to(self.dev).float()
+        if ci.shape[-2:] != self.cond_in.shape[-2:]:
+            ci = torch.nn.functional.interpolate(ci, self.cond_in.shape[-1], mode='nearest')
+        self.cond_in.copy_(ci)
+        if self._cond_pack is None:
+            self._cond_pack = Plan("cond-image")
+            ops.pack_image(self._cond_pack, self.cond_in, None, self.cimg, brep=self.R // self.src_batch, label="pack_cond_image")
+        if not self.dry:
+            self._cond_pack.run()
 
     def forward(self, x: torch.Tensor, time: torch.Tensor, lowres_cond_img: Optional[torch.Tensor] = None) -> torch.Tensor:
         assert self._cond_ready, "set_conditioning() first"

@@ -7,8 +7,8 @@ captured ONCE into a hipGraph and replayed T times — the step index lives in a
 sampler kernel (and the time embedding) reads, so replay needs no host-side parameter patching.
 
 Implemented options: text embeddings or the T5 hook (`texts=`), classifier-free guidance, dynamic thresholding, init_images /
-skip_steps, inpainting (images), start/stop_at_unet_number, video cascades (Unet3D stages).  Training (`forward`, p_losses),
-cond_images / cond_video_frames / video inpainting raise.  Extensions beyond the reference signature: `noise_fn`,
+skip_steps, inpainting (images), cond_images, start/stop_at_unet_number, video cascades (Unet3D stages).  Training (`forward`, p_losses),
+cond_video_frames / video inpainting raise.  Extensions beyond the reference signature: `noise_fn`,
 `seed`, `sample_offset` (batch sharding), `conditioning` handles, lanes (`with imagen.lane(i)`) and `sample_pipelined`.
 """
 from __future__ import annotations
@@ -484,7 +484,7 @@ class Imagen(nn.Module):
     def _step_conditioning_checks(self, unet, cond_images, self_cond, cond_video_frames, post_cond_video_frames, cond_scale):
         assert not (cond_scale != 1. and not self.can_classifier_guidance), \
             'imagen was not trained with conditional dropout, and thus one cannot use classifier free guidance (cond_scale anything other than 1)'
-        for name, val in (('cond_images', cond_images), ('self_cond', self_cond), ('cond_video_frames', cond_video_frames),
+        for name, val in (('self_cond', self_cond), ('cond_video_frames', cond_video_frames),
                           ('post_cond_video_frames', post_cond_video_frames)):
             if val is not None:
                 _out_of_scope(f"{name}=...")
@@ -501,7 +501,7 @@ class Imagen(nn.Module):
         pred = model_output
         if pred is None:
             pred = unet.forward_with_cond_scale(x, noise_scheduler.get_condition(t), text_embeds=text_embeds, text_mask=text_mask,
-                                                cond_scale=cond_scale, lowres_cond_img=lowres_cond_img,
+                                                cond_images=cond_images, cond_scale=cond_scale, lowres_cond_img=lowres_cond_img,
                                                 lowres_noise_times=self.lowres_noise_schedule.get_condition(lowres_noise_times))
         if pred_objective == 'noise':
             x_start = noise_scheduler.predict_start_from_noise(x, t=t, noise=pred)
@@ -660,10 +660,16 @@ class Imagen(nn.Module):
         if device.type not in _SAMPLING_DEVICE_TYPES:
             raise RuntimeError("imagen_pytorch_amd.Imagen.sample runs on MI355X only (move the module to 'cuda'); there is no CPU path")
         self.reset_unets_all_one_device(device)
-        for name, val in (('cond_images', cond_images), ('cond_video_frames', cond_video_frames),
-                          ('post_cond_video_frames', post_cond_video_frames), ('inpaint_videos', inpaint_videos)):
+        for name, val in (('cond_video_frames', cond_video_frames), ('post_cond_video_frames', post_cond_video_frames),
+                          ('inpaint_videos', inpaint_videos)):
             if val is not None:
                 _out_of_scope(f"sample({name}=...)")
+        if cond_images is not None:
+            if self.is_video:
+                _out_of_scope("sample(cond_images=...) for video")
+            cond_images = cond_images.to(device)
+            if cond_images.dtype == torch.uint8:         # cast_uint8_images_to_float, ip.py:2324
+                cond_images = cond_images.float() / 255
         assert not (self.is_video and video_frames is None), 'video_frames must be passed in on sample time if training on video'   # ip.py:2381
         if self.is_video:
             if inpaint_images is not None or skip_steps is not None or any(i is not None for i in _cast_tuple(init_images)):
@@ -742,6 +748,10 @@ class Imagen(nn.Module):
                 st['sample_offset'] = sample_offset
                 eng = st['eng']
                 S = self.image_sizes[idx]
+                assert not (getattr(unet, 'has_cond_image', False) ^ (cond_images is not None)), \
+                    'you either requested to condition on an image on the unet, but the conditioning image is not supplied, or vice versa'   # ip.py:1555
+                if cond_images is not None:
+                    eng.set_cond_images(cond_images)
                 if known is not None:
                     st['known'].copy_(resize(known, S))
                     st['mask'].copy_(resize(known_mask, S).bool().expand(-1, self.channels, -1, -1))

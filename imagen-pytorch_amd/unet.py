@@ -110,8 +110,6 @@ class Unet(nn.Module):
         for name in ('cross_embed_downsample', 'self_cond', 'combine_upsample_fmaps'):
             if self._locals[name]:
                 _unsupported(name)
-        if cond_images_channels > 0:
-            _unsupported('cond_images_channels')
         if init_conv_to_final_conv_residual and not final_resnet_block:
             _unsupported('init_conv_to_final_conv_residual without final_resnet_block')   # final_conv would need three inputs
         if attn_dim_head not in (32, 64):
@@ -123,8 +121,9 @@ class Unet(nn.Module):
         init_channels = channels * (1 + int(lowres_cond) + int(self_cond))
         init_dim = init_dim if init_dim is not None else dim
         self.self_cond = self_cond
-        self.has_cond_image = False
-        self.cond_images_channels = 0
+        self.has_cond_image = cond_images_channels > 0          # ip.py:1191-1194: extra input channels of the init conv
+        self.cond_images_channels = cond_images_channels
+        init_channels += cond_images_channels
 
         # initial convolution (ip.py:1198)
         self.init_conv = (CrossEmbedP(init_channels, kernel_sizes=init_cross_embed_kernel_sizes, dim_out=init_dim, stride=1)
@@ -317,15 +316,18 @@ class Unet(nn.Module):
     def forward(self, x, time, *, lowres_cond_img=None, lowres_noise_times=None, text_embeds=None, text_mask=None,
                 cond_images=None, self_cond=None, cond_drop_prob=0.):
         """ip.py:1524-1725.  `time` / `lowres_noise_times` are log-SNR conditions.  Returns fp32 NCHW."""
-        assert cond_images is None and self_cond is None, 'cond_images / self_cond are outside the hot-path scope'
+        assert self_cond is None, 'self_cond is outside the hot-path scope'
         return self._run(x, time, lowres_cond_img=lowres_cond_img, lowres_noise_times=lowres_noise_times,
-                         text_embeds=text_embeds, text_mask=text_mask, cond_drop_prob=cond_drop_prob, cfg=False)
+                         text_embeds=text_embeds, text_mask=text_mask, cond_images=cond_images, cond_drop_prob=cond_drop_prob, cfg=False)
 
     @torch.no_grad()
-    def _run(self, x, time, *, lowres_cond_img=None, lowres_noise_times=None, text_embeds=None, text_mask=None,
-             cond_drop_prob=0., cfg=False):
+    def _run(self, x, time, *, lowres_cond_img=None, lowres_noise_times=None, text_embeds=None, text_mask=None, cond_images=None,
+             cond_drop_prob=0., cfg=False, self_cond=None):
+        assert self_cond is None, 'self_cond is outside the hot-path scope'
         assert not (self.lowres_cond and lowres_cond_img is None), 'low resolution conditioning image must be present'
         assert not (self.lowres_cond and lowres_noise_times is None), 'low resolution conditioning noise time must be present'
+        assert not (self.has_cond_image ^ (cond_images is not None)), \
+            'you either requested to condition on an image on the unet, but the conditioning image is not supplied, or vice versa'
         if self.training:
             raise RuntimeError("the MI355X path implements sampling (eval mode) only; call .eval() first")
         B, _, H, W = x.shape
@@ -343,6 +345,8 @@ class Unet(nn.Module):
             keep = torch.rand(B) < (1 - cond_drop_prob)   # ip.py:201-207
         eng.set_conditioning(text_embeds=text_embeds if with_text else None, text_mask=text_mask, keep=keep,
                              lowres_noise_times=lowres_noise_times)
+        if cond_images is not None:
+            eng.set_cond_images(cond_images)
         out = eng.forward(x.float().contiguous(), time.float().contiguous(),
                           lowres_cond_img=None if lowres_cond_img is None else lowres_cond_img.float().contiguous())
         return out.clone()

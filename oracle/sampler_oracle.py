@@ -5,8 +5,8 @@ Restates, in fp32 torch on CPU, the continuous-time Gaussian diffusion helpers
 p_sample_loop / sample` (ip.py:2042-2498) for the options the BASELINE configs use:
 noise-prediction objective, dynamic thresholding, classifier-free guidance, low-res
 noise-conditioning augmentation, plus the p_sample_loop options init_images, skip_steps
-and inpainting with resampling (ip.py:2205-2206, 2228-2229, 2237-2286).  Video,
-cond_images and self-conditioning are out of scope.
+and inpainting with resampling (ip.py:2205-2206, 2228-2229, 2237-2286), and `cond_images`.
+Self-conditioning is out of scope.
 
 All Gaussian noise is drawn through an injectable `noise_fn(tag, shape)` so the HIP
 path and the reference can be fed identical tensors (CPU and GPU RNG streams differ,
@@ -177,8 +177,9 @@ def imagen_sample(
     inpaint_resample_times: int = 5,
     video_frames: Optional[int] = None,        # Imagen-Video: the unets are Unet3D state_dicts, samples are (b, c, f, h, w)
     temporal_downsample_factor=1,              # per stage: stage i samples video_frames // factor[i] frames (ip.py:170-183, 1928-1935)
+    cond_images: Optional[Tensor] = None,      # (B, cond_images_channels, h, w) in [0, 1], handed to every unet as is (ip.py:2324, 2465)
 ):
-    """ip.py:2291-2498 for text_embeds-conditioned image sampling (no video, no cond_images, no self-conditioning)."""
+    """ip.py:2291-2498 for text_embeds-conditioned sampling (no self-conditioning)."""
     n = len(unets)
     timesteps = timesteps if isinstance(timesteps, (list, tuple)) else (timesteps,) * n
     cond_scale = cond_scale if isinstance(cond_scale, (list, tuple)) else (cond_scale,) * n
@@ -212,8 +213,9 @@ def imagen_sample(
         fwd = unet3d_forward_with_cond_scale if video else unet_forward_with_cond_scale
 
         def denoise(x, log_snr, _sd=sd, _kw=kw, _cs=cs, _li=lowres_img, _lt=(lowres_logsnr if lowres_img is not None else None)):
+            extra = {} if cond_images is None else dict(cond_images=cond_images)
             return fwd(_sd, _kw, x, log_snr, cond_scale=_cs, text_embeds=text_embeds, text_mask=text_masks, lowres_cond_img=_li,
-                       lowres_noise_times=_lt)
+                       lowres_noise_times=_lt, **extra)
 
         shape = (b, channels, video_frames // tds[stage], size, size) if video else (b, channels, size, size)
         img = p_sample_loop(denoise, shape, schedule=sched, num_timesteps=T, noise_fn=noise_fn,

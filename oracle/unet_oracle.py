@@ -62,8 +62,6 @@ def resolve_config(kwargs: dict) -> dict:
     for flag in ("cross_embed_downsample", "self_cond", "combine_upsample_fmaps"):
         if cfg[flag]:
             raise NotImplementedError(f"oracle: {flag} is outside the hot-path scope")
-    if cfg["cond_images_channels"]:
-        raise NotImplementedError("oracle: cond_images_channels is outside the hot-path scope")
     dim = cfg["dim"]
     n = len(cfg["dim_mults"])
     cfg["init_dim"] = cfg["init_dim"] or dim
@@ -308,6 +306,7 @@ def unet_forward(
     lowres_noise_times: Optional[Tensor] = None,
     text_embeds: Optional[Tensor] = None,
     text_mask: Optional[Tensor] = None,
+    cond_images: Optional[Tensor] = None,
     cond_drop_prob: float = 0.0,
     taps: Optional[dict] = None,
 ) -> Tensor:
@@ -329,6 +328,13 @@ def unet_forward(
         assert lowres_cond_img is not None and lowres_noise_times is not None  # ip.py:1547-1548
     if lowres_cond_img is not None:
         x = torch.cat((x, lowres_cond_img), dim=1)
+    # conditioning image: nearest-resized to the input's size, IN FRONT of the other channels, not normalised (ip.py:1555-1560)
+    assert (cfg["cond_images_channels"] > 0) == (cond_images is not None)
+    if cond_images is not None:
+        assert cond_images.shape[1] == cfg["cond_images_channels"]
+        if cond_images.shape[-1] != x.shape[-1]:
+            cond_images = F.interpolate(cond_images, x.shape[-1], mode="nearest")
+        x = torch.cat((cond_images, x), dim=1)
 
     # initial convolution (ip.py:1564, 1051-1076 / 1198)
     if cfg["init_cross_embed"]:

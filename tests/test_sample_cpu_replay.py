@@ -231,4 +231,22 @@ def test_reference_step_level_api(cpu_backend, monkeypatch):
     sched = imagen.noise_schedulers[0]
     x = torch.zeros(1, 3, 16, 16)
     with pytest.raises(NotImplementedError):
+        imagen.p_sample(imagen.unets[0], x, torch.ones(1), t_next=torch.zeros(1), noise_scheduler=sched, self_cond=x)
+    with pytest.raises(AssertionError):      # a conditioning image for a unet built without cond_images_channels (ip.py:1555)
         imagen.p_sample(imagen.unets[0], x, torch.ones(1), t_next=torch.zeros(1), noise_scheduler=sched, cond_images=x)
+
+
+def test_cond_images_sampling(cpu_backend):
+    """sample(cond_images=...) (ip.py:2324, 2465 -> Unet.forward ip.py:1555-1560): the image is packed once per stage, resized to the
+    stage's resolution, and read by the init conv as a second input."""
+    from step_api_case import cond_images_cascade
+
+    imagen, te, cond, noise_fn, want, _ = cond_images_cascade(torch.device("cpu"))
+    outs = imagen.sample(text_embeds=te, cond_images=cond, cond_scale=3., use_tqdm=False, return_all_unet_outputs=True, noise_fn=noise_fn,
+                         device="cpu")
+    errs = [nerr(o, w) for o, w in zip(outs, want)]
+    assert max(errs) < 2e-2, errs
+    other = imagen.sample(text_embeds=te, cond_images=cond.flip(0), cond_scale=3., use_tqdm=False, noise_fn=noise_fn, device="cpu")
+    assert nerr(other, want[-1]) > 5e-2, "the conditioning image must matter"
+    with pytest.raises(AssertionError):
+        imagen.sample(text_embeds=te, cond_scale=3., use_tqdm=False, noise_fn=noise_fn, device="cpu")     # unet expects one (ip.py:1555)

@@ -31,5 +31,19 @@ SWEEP = {
     "head_dim_32_three_levels": dict(dim=32, cond_dim=64, text_embed_dim=32, dim_mults=(1, 2, 4), attn_dim_head=32, attn_heads=16, max_text_len=16,
                                      attn_pool_num_latents=8, num_resnet_blocks=(1, 2, 2), layer_attns=(False, True, True),
                                      layer_cross_attns=(False, True, True)),
+    # image conditioning (ip.py:1191-1194, 1555-1560): extra init-conv input channels, given at another resolution (nearest-resized)
+    "cond_images_3": dict(_T, num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True), cond_images_channels=3),
+    "cond_images_10_lowres_plain_init": dict(_T, num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True),
+                                             cond_images_channels=10, lowres_cond=True, init_cross_embed=False),
     "channels_out_6": dict(_T, num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True), channels_out=6),
 }
+
+
+def cond_images_for(kw, B, seed=9):
+    """The conditioning image of a sweep configuration ((B, cond_images_channels, 8, 8): half the 16x16 input's size), or None."""
+    import torch
+    cc = kw.get("cond_images_channels", 0)
+    if not cc:
+        return None
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(B, cc, 8, 8, generator=g)
