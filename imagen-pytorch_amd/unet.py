@@ -107,9 +107,14 @@ class Unet(nn.Module):
             v = self._locals[name]
             if any(_cast_tuple(v)):
                 _unsupported(name)
-        for name in ('cross_embed_downsample', 'self_cond', 'combine_upsample_fmaps'):
+        for name in ('self_cond', 'combine_upsample_fmaps'):
             if self._locals[name]:
                 _unsupported(name)
+        if cross_embed_downsample:
+            # the reference cannot build this either: partial(CrossEmbedLayer, kernel_sizes=...) is called with (dim_in, dim_out)
+            # positionally (ip.py:1315, 1357, 1366), so dim_out collides with kernel_sizes and Unet(...) raises TypeError — no
+            # checkpoint with this flag exists
+            _unsupported('cross_embed_downsample')
         if init_conv_to_final_conv_residual and not final_resnet_block:
             _unsupported('init_conv_to_final_conv_residual without final_resnet_block')   # final_conv would need three inputs
         if attn_dim_head not in (32, 64):

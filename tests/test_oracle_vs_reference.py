@@ -173,3 +173,16 @@ def test_step_level_posterior_math(objective, dyn):
     (m2, v2, l2), s2 = ours.p_mean_variance(ours.unets[0], x, t, noise_scheduler=ours.noise_schedulers[0], **common)
     for u, v in ((m1, m2), (v1, v2), (l1, l2), (s1, s2)):
         assert u.shape == v.shape and torch.allclose(u, v, rtol=0, atol=1e-6)
+
+
+def test_cross_embed_downsample_is_unbuildable_in_the_reference():
+    """Why `Unet(cross_embed_downsample=True)` stays a NotImplementedError here: the reference's own constructor fails on it
+    (`partial(CrossEmbedLayer, kernel_sizes=...)(dim_in, dim_out)`, ip.py:1315 / 1357 / 1366), so no model with that flag exists."""
+    from imagen_pytorch_amd import Unet
+
+    ip = ref_shim.load_reference()
+    kw = dict(dim=8, dim_mults=(1, 2), cross_embed_downsample=True)
+    with pytest.raises(TypeError):
+        ip.Unet(**kw)
+    with pytest.raises(NotImplementedError):
+        Unet(**kw)
