@@ -207,6 +207,7 @@ __global__ __launch_bounds__(256) void ddpm_update_kernel(const ImagenDdpmUpdate
     } else {
       x0 = fminf(fmaxf(x0, -1.0f), 1.0f);                       // ip.py:2107
     }
+    if (p.x0_thr) p.x0_thr[i] = x0;
     const float xt = p.x[i];
     const float mean = alpha_next * (xt * (1.0f - c) / alpha + c * x0);  // ip.py:265
     const float xn = mean + nonzero * stdev * z[e];                       // ip.py:2164

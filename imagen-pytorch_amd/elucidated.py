@@ -124,6 +124,9 @@ class ElucidatedImagen(Imagen):
     def _build_stage(self, idx: int, B: int, device, *, cond_scale: float, with_text: bool, inject_noise: bool, sample_offset: int,
                      resample_times: int = 0, frames: int = 0):
         unet = self.unets[idx]
+        if getattr(unet, 'self_cond', False):
+            from .imagen import _out_of_scope
+            _out_of_scope("ElucidatedImagen sampling with self-conditioning unets (el.py:496, 518)")
         S = self.image_sizes[idx]
         hp = self.hparams[idx]
         cfg = cond_scale != 1.

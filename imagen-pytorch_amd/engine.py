@@ -142,12 +142,18 @@ class UnetEngine:
         R, S, u = self.R, self.S, self.unet
         self.x_in = self.f32buf(self.src_batch, u.channels, S, S, zero=True)      # fp32 NCHW staging (or the sampler's state)
         self.lowres_in = self.f32buf(self.src_batch, u.channels, S, S, zero=True) if self.lowres else None
-        # conditioning image (Unet(cond_images_channels=...), ip.py:1555-1560): fp32 NCHW staging + its fp16 NHWC copy, packed once per
-        # set_cond_images() — it does not change over the timesteps — and read by the init conv as a second (concatenated) input
+        # Extra init-conv inputs, read by the init conv as a second (channel-concatenated) fp16 NHWC tensor `cimg` = [self_cond | cond image]:
+        #  * the conditioning image (Unet(cond_images_channels=...), ip.py:1555-1560): fp32 NCHW staging, packed once per
+        #    set_cond_images() — it does not change over the timesteps;
+        #  * the self-conditioning input (Unet(self_cond=True), ip.py:1541-1543): the previous step's thresholded x0 (zeros at first),
+        #    packed at the start of every step from `self_cond_in`, or from the sampler's buffer once bind_self_cond() has been called.
         cc = getattr(u, 'cond_images_channels', 0)
+        sc = u.channels if getattr(u, 'self_cond', False) else 0
         self.cond_in = self.f32buf(self.src_batch, cc, S, S, zero=True) if cc else None
-        self.cimg = self.new(R, S, S, (cc + 7) // 8 * 8, zero=True) if cc else None
+        self.self_cond_in = self.f32buf(self.src_batch, sc, S, S, zero=True) if sc else None
+        self.cimg = self.new(R, S, S, (sc + cc + 7) // 8 * 8, zero=True) if sc + cc else None
         self._cond_pack = None
+        self._self_cond_op = None
         self.times = self.f32buf(R, zero=True)          # log-SNR per row (plain forward mode)
         self.lowres_times = self.f32buf(R, zero=True)
         self.out = self.f32buf(R, u.channels_out, S, S)
@@ -204,6 +210,8 @@ class UnetEngine:
         assert cin <= 8, "init conv packs the input image into 8 channels"
         self.img = self.new(R, S, S, 8)
         self._pack_op = ops.pack_image(plan, self.x_in, self.lowres_in, self.img, brep=R // self.src_batch, label="pack_image")
+        if self.self_cond_in is not None:
+            self._self_cond_op = ops.pack_image(plan, self.self_cond_in, self.cond_in, self.cimg, brep=R // self.src_batch, label="pack_self_cond")
 
         # ---- time conditioning (ip.py:1573-1578)
         self.hid = self.new(1, 1, R, self.Tc)
@@ -298,13 +306,20 @@ class UnetEngine:
         u = self.unet
 
         cc = self.cond_in.shape[1] if self.cond_in is not None else 0
-        ccp = self.cimg.C if cc else 0
+        sc = self.self_cond_in.shape[1] if self.self_cond_in is not None else 0
+        c = u.channels
+        nl = c if self.lowres else 0
+        auxp = self.cimg.C if self.cimg is not None else 0
 
         def spread(w):
-            """Reference input channels [cond image | x | lowres] (ip.py:1545-1560) -> ours [x | lowres | 0.. (8) | cond image | 0.. (ccp)]."""
-            wp = torch.zeros(w.shape[0], 8 + ccp, *w.shape[2:])
-            wp[:, : w.shape[1] - cc] = w[:, cc:]
-            wp[:, 8: 8 + cc] = w[:, :cc]
+            """Reference input channels [cond image | x | self_cond | lowres] (ip.py:1541-1560) ->
+            ours [x | lowres | 0.. (8)] ++ [self_cond | cond image | 0.. (auxp)]."""
+            assert w.shape[1] == cc + c + sc + nl
+            wp = torch.zeros(w.shape[0], 8 + auxp, *w.shape[2:])
+            wp[:, :c] = w[:, cc: cc + c]
+            wp[:, c: c + nl] = w[:, cc + c + sc:]
+            wp[:, 8: 8 + sc] = w[:, cc + c: cc + c + sc]
+            wp[:, 8 + sc: 8 + sc + cc] = w[:, :cc]
             return wp
 
         def make():
@@ -856,11 +871,28 @@ class UnetEngine:
         if ci.shape[-2:] != self.cond_in.shape[-2:]:
             ci = torch.nn.functional.interpolate(ci, self.cond_in.shape[-1], mode='nearest')
         self.cond_in.copy_(ci)
+        if self._self_cond_op is not None:
+            return                                   # packed together with the self-conditioning input at the start of every step
         if self._cond_pack is None:
             self._cond_pack = Plan("cond-image")
             ops.pack_image(self._cond_pack, self.cond_in, None, self.cimg, brep=self.R // self.src_batch, label="pack_cond_image")
         if not self.dry:
             self._cond_pack.run()
+
+    def set_self_cond(self, self_cond: Optional[torch.Tensor]):
+        """Plain-forward mode: the self-conditioning image of the next forward() (None = zeros, ip.py:1542)."""
+        assert self.self_cond_in is not None, 'this unet was built without self_cond'
+        if self_cond is None:
+            self.self_cond_in.zero_()
+        else:
+            self.self_cond_in.copy_(self_cond)
+
+    def bind_self_cond(self, x0_thr: torch.Tensor):
+        """Sampler mode: every step self-conditions on `x0_thr`, the buffer DDPM_UPDATE leaves the previous step's thresholded x0 in
+        (ip.py:2249: `self_cond = x_start if unet.self_cond else None`)."""
+        assert self._self_cond_op is not None and x0_thr.numel() == self.self_cond_in.numel() and x0_thr.dtype == torch.float32
+        self._self_cond_op.a = x0_thr.data_ptr()
+        self._self_cond_src = x0_thr
 
     def forward(self, x: torch.Tensor, time: torch.Tensor, lowres_cond_img: Optional[torch.Tensor] = None) -> torch.Tensor:
         assert self._cond_ready, "set_conditioning() first"

@@ -7,7 +7,7 @@ captured ONCE into a hipGraph and replayed T times — the step index lives in a
 sampler kernel (and the time embedding) reads, so replay needs no host-side parameter patching.
 
 Implemented options: text embeddings or the T5 hook (`texts=`), classifier-free guidance, dynamic thresholding, init_images /
-skip_steps, inpainting (images), cond_images, start/stop_at_unet_number, video cascades (Unet3D stages).  Training (`forward`, p_losses),
+skip_steps, inpainting (images), cond_images, self-conditioning unets, start/stop_at_unet_number, video cascades (Unet3D stages).  Training (`forward`, p_losses),
 cond_video_frames / video inpainting raise.  Extensions beyond the reference signature: `noise_fn`,
 `seed`, `sample_offset` (batch sharding), `conditioning` handles, lanes (`with imagen.lane(i)`) and `sample_pipelined`.
 """
@@ -383,9 +383,16 @@ class Imagen(nn.Module):
         dyn = bool(self.dynamic_thresholding[idx])
         if dyn:
             ops.quantile(plan, absx0, quant, scratch, B=B, n=n, q=float(self.dynamic_thresholding_percentile))
+        x0_thr = None
+        if getattr(unet, 'self_cond', False):            # ip.py:2249: each step conditions on the previous step's thresholded x0
+            if video:
+                _out_of_scope("self-conditioning video unets")
+            x0_thr = torch.zeros(B, n, device=dev)
+            eng.bind_self_cond(x0_thr)
+            extra['x0_thr'] = x0_thr
         ops.ddpm_update(plan, eng.x_in, x0, quant if dyn else None, coef, noise, final, step_ptr, B=B, n_per_sample=n,
                         dynamic_threshold=dyn, total_steps=T * max(R, 1), seed=0, stream_id=idx, sample_offset=sample_offset,
-                        seed_ptr=seed_dev, advance=not R)
+                        seed_ptr=seed_dev, advance=not R, x0_thr=x0_thr)
         if R:
             ops.lincomb(plan, eng.x_in, eng.x_in, renoise_coef, step_ptr, B=B, n_per_sample=n, t1=extra['noise_renoise'], advance=True,
                         stream_id=idx | 0x200, sample_offset=sample_offset, seed_ptr=seed_dev, label="inpaint.renoise")
@@ -428,6 +435,8 @@ class Imagen(nn.Module):
                 init.run()
             if init_images is not None:
                 eng.x_in.add_(init_images)              # ip.py:2205-2206
+            if st.get('x0_thr') is not None:
+                st['x0_thr'].zero_()                    # no x0 estimate yet: the first step self-conditions on zeros (ip.py:2210, 1542)
             st['step_ptr'].fill_(skip * inner)           # ip.py:2228-2229: the skipped timesteps are simply never run
 
         reset_state()
@@ -481,11 +490,10 @@ class Imagen(nn.Module):
             _out_of_scope("resize_to for videos outside sample()")
         return img if img.shape[-1] == size else F.interpolate(img, size, mode='nearest')
 
-    def _step_conditioning_checks(self, unet, cond_images, self_cond, cond_video_frames, post_cond_video_frames, cond_scale):
+    def _step_conditioning_checks(self, unet, cond_video_frames, post_cond_video_frames, cond_scale):
         assert not (cond_scale != 1. and not self.can_classifier_guidance), \
             'imagen was not trained with conditional dropout, and thus one cannot use classifier free guidance (cond_scale anything other than 1)'
-        for name, val in (('self_cond', self_cond), ('cond_video_frames', cond_video_frames),
-                          ('post_cond_video_frames', post_cond_video_frames)):
+        for name, val in (('cond_video_frames', cond_video_frames), ('post_cond_video_frames', post_cond_video_frames)):
             if val is not None:
                 _out_of_scope(f"{name}=...")
         if isinstance(unet, Unet3D):
@@ -497,11 +505,12 @@ class Imagen(nn.Module):
                         model_output=None, t_next=None, pred_objective='noise', dynamic_threshold=True):
         """ip.py:2042-2110: denoiser output (or `model_output`) -> x_0 estimate -> threshold -> posterior (mean, variance,
         log variance) of x_{t_next}; returns that triple and the thresholded x_0."""
-        self._step_conditioning_checks(unet, cond_images, self_cond, cond_video_frames, post_cond_video_frames, cond_scale)
+        self._step_conditioning_checks(unet, cond_video_frames, post_cond_video_frames, cond_scale)
         pred = model_output
         if pred is None:
             pred = unet.forward_with_cond_scale(x, noise_scheduler.get_condition(t), text_embeds=text_embeds, text_mask=text_mask,
-                                                cond_images=cond_images, cond_scale=cond_scale, lowres_cond_img=lowres_cond_img,
+                                                cond_images=cond_images, self_cond=self_cond, cond_scale=cond_scale,
+                                                lowres_cond_img=lowres_cond_img,
                                                 lowres_noise_times=self.lowres_noise_schedule.get_condition(lowres_noise_times))
         if pred_objective == 'noise':
             x_start = noise_scheduler.predict_start_from_noise(x, t=t, noise=pred)
@@ -560,13 +569,15 @@ class Imagen(nn.Module):
                 steps = tqdm(steps, desc='sampling loop time step', total=len(steps))
             except ImportError:
                 pass
+        x_start = None
         for times, times_next in steps:
             final_step = bool(torch.all(times_next == 0))
             for r in reversed(range(inpaint_resample_times if inpainting else 1)):
                 if inpainting:       # known region at this step's noise level
                     img = torch.where(keep, noise_scheduler.q_sample(known, t=times)[0], img)
-                img, _ = self.p_sample(unet, img, times, t_next=times_next, text_embeds=text_embeds, text_mask=text_mask,
+                img, x_start = self.p_sample(unet, img, times, t_next=times_next, text_embeds=text_embeds, text_mask=text_mask,
                                        cond_images=cond_images, cond_scale=cond_scale, lowres_cond_img=lowres_cond_img,
+                                       self_cond=x_start if getattr(unet, 'self_cond', False) else None,
                                        lowres_noise_times=lowres_noise_times, noise_scheduler=noise_scheduler,
                                        pred_objective=pred_objective, dynamic_threshold=dynamic_threshold,
                                        cond_video_frames=cond_video_frames, post_cond_video_frames=post_cond_video_frames)

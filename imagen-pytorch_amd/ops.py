@@ -802,8 +802,9 @@ def quantile(plan: Plan, absx0, out, scratch, *, B, n, q: float, label: str = ""
 
 def ddpm_update(plan: Plan, x, x0, quant, coef, noise, final_out, step_ptr, *, B, n_per_sample, dynamic_threshold: bool,
                 total_steps: int, seed: int, stream_id: int, sample_offset: int = 0, seed_ptr: Optional[torch.Tensor] = None,
-                advance: bool = True, label: str = ""):
+                advance: bool = True, x0_thr: Optional[torch.Tensor] = None, label: str = ""):
     p = STRUCTS["ImagenDdpmUpdateParams"]()
+    p.x0_thr = ptr(x0_thr)
     p.x, p.x0, p.quant, p.coef, p.noise, p.final_out, p.step_ptr = (x.data_ptr(), x0.data_ptr(), ptr(quant), coef.data_ptr(), ptr(noise),
                                                                    ptr(final_out), step_ptr.data_ptr())
     p.B, p.n_per_sample, p.dynamic_threshold, p.total_steps = B, n_per_sample, int(dynamic_threshold), total_steps
@@ -813,7 +814,7 @@ def ddpm_update(plan: Plan, x, x0, quant, coef, noise, final_out, step_ptr, *, B
     if seed_ptr is not None:
         plan.keep.append(seed_ptr)
     p.seed_lo, p.seed_hi, p.stream_id = seed & 0xFFFFFFFF, (seed >> 32) & 0xFFFFFFFF, stream_id
-    plan.add(p, label or "ddpm_update", [x, x0, quant, coef, noise, final_out, step_ptr])
+    plan.add(p, label or "ddpm_update", [x, x0, quant, coef, noise, final_out, step_ptr, x0_thr])
     return p
 
 

@@ -107,9 +107,8 @@ class Unet(nn.Module):
             v = self._locals[name]
             if any(_cast_tuple(v)):
                 _unsupported(name)
-        for name in ('self_cond', 'combine_upsample_fmaps'):
-            if self._locals[name]:
-                _unsupported(name)
+        if combine_upsample_fmaps:
+            _unsupported('combine_upsample_fmaps')
         if cross_embed_downsample:
             # the reference cannot build this either: partial(CrossEmbedLayer, kernel_sizes=...) is called with (dim_in, dim_out)
             # positionally (ip.py:1315, 1357, 1366), so dim_out collides with kernel_sizes and Unet(...) raises TypeError — no
@@ -321,14 +320,12 @@ class Unet(nn.Module):
     def forward(self, x, time, *, lowres_cond_img=None, lowres_noise_times=None, text_embeds=None, text_mask=None,
                 cond_images=None, self_cond=None, cond_drop_prob=0.):
         """ip.py:1524-1725.  `time` / `lowres_noise_times` are log-SNR conditions.  Returns fp32 NCHW."""
-        assert self_cond is None, 'self_cond is outside the hot-path scope'
-        return self._run(x, time, lowres_cond_img=lowres_cond_img, lowres_noise_times=lowres_noise_times,
-                         text_embeds=text_embeds, text_mask=text_mask, cond_images=cond_images, cond_drop_prob=cond_drop_prob, cfg=False)
+        return self._run(x, time, lowres_cond_img=lowres_cond_img, lowres_noise_times=lowres_noise_times, text_embeds=text_embeds,
+                         text_mask=text_mask, cond_images=cond_images, self_cond=self_cond, cond_drop_prob=cond_drop_prob, cfg=False)
 
     @torch.no_grad()
     def _run(self, x, time, *, lowres_cond_img=None, lowres_noise_times=None, text_embeds=None, text_mask=None, cond_images=None,
              cond_drop_prob=0., cfg=False, self_cond=None):
-        assert self_cond is None, 'self_cond is outside the hot-path scope'
         assert not (self.lowres_cond and lowres_cond_img is None), 'low resolution conditioning image must be present'
         assert not (self.lowres_cond and lowres_noise_times is None), 'low resolution conditioning noise time must be present'
         assert not (self.has_cond_image ^ (cond_images is not None)), \
@@ -352,6 +349,8 @@ class Unet(nn.Module):
                              lowres_noise_times=lowres_noise_times)
         if cond_images is not None:
             eng.set_cond_images(cond_images)
+        if self.self_cond:
+            eng.set_self_cond(self_cond)             # None: zeros (ip.py:1542); a unet built without self_cond ignores the argument, as the reference does
         out = eng.forward(x.float().contiguous(), time.float().contiguous(),
                           lowres_cond_img=None if lowres_cond_img is None else lowres_cond_img.float().contiguous())
         return out.clone()

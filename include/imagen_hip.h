@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define IMAGEN_ABI_VERSION 3 /* 3: head_dim in the attention / QNORM / KV_PREP params */
+#define IMAGEN_ABI_VERSION 4 /* 3: head_dim in the attention / QNORM / KV_PREP params; 4: DDPM_UPDATE x0_thr */
 
 typedef void* imagen_stream_t; /* hipStream_t */
 
@@ -308,6 +308,8 @@ typedef struct ImagenDdpmUpdateParams {
   int32_t sample_offset; /* global index of local sample 0 (batch sharding: noise is keyed by the global sample index) */
   uint32_t seed_lo, seed_hi, stream_id;
   int32_t no_advance; /* != 0: leave *step_ptr alone (inpainting: a LINCOMB re-noising step of the same table row follows, ip.py:2268-2275) */
+  float* x0_thr;      /* optional: the thresholded x0 of this step (ip.py:2094-2107), same layout as x0 — the next step's self-conditioning
+                       * input of a Unet(self_cond=True) (ip.py:2249, 1541-1543) */
 } ImagenDdpmUpdateParams;
 
 /* RANDN — out[b, i] ~ N(0,1), Philox4x32-10 counter (i/4, tag, stream_id, sample_offset + b), key = seed.

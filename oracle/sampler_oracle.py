@@ -5,8 +5,8 @@ Restates, in fp32 torch on CPU, the continuous-time Gaussian diffusion helpers
 p_sample_loop / sample` (ip.py:2042-2498) for the options the BASELINE configs use:
 noise-prediction objective, dynamic thresholding, classifier-free guidance, low-res
 noise-conditioning augmentation, plus the p_sample_loop options init_images, skip_steps
-and inpainting with resampling (ip.py:2205-2206, 2228-2229, 2237-2286), and `cond_images`.
-Self-conditioning is out of scope.
+and inpainting with resampling (ip.py:2205-2206, 2228-2229, 2237-2286), `cond_images` and
+self-conditioning unets.
 
 All Gaussian noise is drawn through an injectable `noise_fn(tag, shape)` so the HIP
 path and the reference can be fed identical tensors (CPU and GPU RNG streams differ,
@@ -109,8 +109,9 @@ def p_sample_loop(denoise: Callable[[Tensor, Tensor], Tensor], shape, *, schedul
                   noise_fn: Callable, stage: int, dynamic_thresholding: bool = True, percentile: float = 0.95,
                   max_steps: Optional[int] = None, trace: Optional[list] = None, init_images: Optional[Tensor] = None,
                   skip_steps: Optional[int] = None, inpaint_images: Optional[Tensor] = None, inpaint_masks: Optional[Tensor] = None,
-                  inpaint_resample_times: int = 5) -> Tensor:
-    """denoise(x_t, log_snr(t)) -> guided eps_hat.  Returns the un-normalised image in [0, 1] (ip.py:2167-2289).
+                  inpaint_resample_times: int = 5, self_cond: bool = False) -> Tensor:
+    """denoise(x_t, log_snr(t)) -> guided eps_hat; with `self_cond` the call is denoise(x_t, log_snr(t), x0_prev) where x0_prev is the
+    thresholded x0 estimate of the previous call (None before the first one; ip.py:2208-2210, 2249-2251).  Returns the un-normalised image in [0, 1] (ip.py:2167-2289).
 
     init_images / inpaint_images arrive NORMALISED to [-1, 1] and at any resolution (resized here, ip.py:2219-2220, 2457);
     inpaint_masks: (B, H, W) bool, True = keep the known pixel.  With inpainting every timestep is run `inpaint_resample_times`
@@ -128,6 +129,7 @@ def p_sample_loop(denoise: Callable[[Tensor, Tensor], Tensor], shape, *, schedul
         mask = resize(inpaint_masks[:, None].float()).bool()               # ip.py:2220
     fn = SCHEDULES[schedule]
     pairs = sampling_time_pairs(num_timesteps)
+    x_start = None
     first = skip_steps or 0                                                 # ip.py:2228-2229
     if max_steps is not None:
         pairs = pairs[:first + max_steps]
@@ -140,9 +142,9 @@ def p_sample_loop(denoise: Callable[[Tensor, Tensor], Tensor], shape, *, schedul
                 a, s_ = alpha_sigma(fn(t).reshape(-1, 1, 1, 1))
                 noised = a * known + s_ * noise_fn(("inpaint", stage, i, r), shape)       # ip.py:2244-2246
                 img = img * ~mask + noised * mask
-            pred = denoise(img, fn(t))
+            pred = denoise(img, fn(t), x_start) if self_cond else denoise(img, fn(t))
             tag = ("step", stage, i, r) if inpainting else ("step", stage, i)
-            img, _ = ddpm_step(img, pred, t, t_next, noise_fn(tag, shape), schedule, dynamic_thresholding, percentile)
+            img, x_start = ddpm_step(img, pred, t, t_next, noise_fn(tag, shape), schedule, dynamic_thresholding, percentile)
             if inpainting and not (r == 0 or last_t):
                 img = q_sample_from_to(img, t_next, t, noise_fn(("renoise", stage, i, r), shape), schedule)   # ip.py:2268-2275
             if trace is not None:
@@ -212,8 +214,10 @@ def imagen_sample(
 
         fwd = unet3d_forward_with_cond_scale if video else unet_forward_with_cond_scale
 
-        def denoise(x, log_snr, _sd=sd, _kw=kw, _cs=cs, _li=lowres_img, _lt=(lowres_logsnr if lowres_img is not None else None)):
+        def denoise(x, log_snr, x0_prev=None, _sd=sd, _kw=kw, _cs=cs, _li=lowres_img, _lt=(lowres_logsnr if lowres_img is not None else None)):
             extra = {} if cond_images is None else dict(cond_images=cond_images)
+            if _kw.get("self_cond", False):
+                extra["self_cond"] = x0_prev
             return fwd(_sd, _kw, x, log_snr, cond_scale=_cs, text_embeds=text_embeds, text_mask=text_masks, lowres_cond_img=_li,
                        lowres_noise_times=_lt, **extra)
 
@@ -221,6 +225,7 @@ def imagen_sample(
         img = p_sample_loop(denoise, shape, schedule=sched, num_timesteps=T, noise_fn=noise_fn,
                             stage=stage, dynamic_thresholding=dynamic_thresholding, percentile=percentile,
                             max_steps=max_steps, init_images=init_images[stage], skip_steps=skip_steps[stage], inpaint_images=known,
-                            inpaint_masks=inpaint_masks, inpaint_resample_times=inpaint_resample_times)
+                            inpaint_masks=inpaint_masks, inpaint_resample_times=inpaint_resample_times,
+                            self_cond=bool(kw.get("self_cond", False)))
         outputs.append(img)
     return outputs if return_all else outputs[-1]

@@ -16,8 +16,7 @@ against fixtures generated from the reference by oracle/make_golden.py
 (tests/golden/*.pt), which travel to the GPU box.
 
 Scope: every constructor flag used by the BASELINE.json configs.  Flags outside that
-scope (linear attention, cross-embed downsample, self-conditioning, conditioning
-images, upsample combiner) raise.
+scope (linear attention, cross-embed downsample, upsample combiner) raise.
 """
 from __future__ import annotations
 
@@ -59,7 +58,7 @@ def resolve_config(kwargs: dict) -> dict:
         v = cfg[flag]
         if any(v) if isinstance(v, (list, tuple)) else v:
             raise NotImplementedError(f"oracle: {flag} is outside the hot-path scope")
-    for flag in ("cross_embed_downsample", "self_cond", "combine_upsample_fmaps"):
+    for flag in ("cross_embed_downsample", "combine_upsample_fmaps"):
         if cfg[flag]:
             raise NotImplementedError(f"oracle: {flag} is outside the hot-path scope")
     dim = cfg["dim"]
@@ -307,6 +306,7 @@ def unet_forward(
     text_embeds: Optional[Tensor] = None,
     text_mask: Optional[Tensor] = None,
     cond_images: Optional[Tensor] = None,
+    self_cond: Optional[Tensor] = None,
     cond_drop_prob: float = 0.0,
     taps: Optional[dict] = None,
 ) -> Tensor:
@@ -324,6 +324,8 @@ def unet_forward(
         if taps is not None:
             taps[name] = val.detach().clone()
 
+    if cfg["self_cond"]:    # ip.py:1541-1543: the previous step's x0 estimate (zeros when there is none yet), right behind x
+        x = torch.cat((x, torch.zeros_like(x) if self_cond is None else self_cond), dim=1)
     if cfg["lowres_cond"]:
         assert lowres_cond_img is not None and lowres_noise_times is not None  # ip.py:1547-1548
     if lowres_cond_img is not None:

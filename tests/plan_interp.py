@@ -411,6 +411,8 @@ class Interpreter:
             x0 = x0.clamp(-s, s) / s
         else:
             x0 = x0.clamp(-1.0, 1.0)
+        if p.x0_thr:
+            m.view(p.x0_thr, f32)[:n].copy_(x0.reshape(-1))
         x = m.view(p.x, f32)[:n].reshape(p.B, -1)
         mean = alpha_next * (x * (1.0 - c) / alpha + c * x0)
         xn = mean + nonzero * (sigma_next * sigma_next * c).clamp(min=1e-20).sqrt() * m.view(p.noise, f32)[:n].reshape(p.B, -1)

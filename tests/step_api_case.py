@@ -51,14 +51,15 @@ def run_cascade_by_steps(imagen, g, monkeypatch, device):
     return outs
 
 
-def cond_images_cascade(device, timesteps=3):
-    """A tiny two-stage cascade whose unets take a 4-channel conditioning image (Unet(cond_images_channels=4), ip.py:1191-1194,
-    1555-1560), its inputs, a recorded-noise function, the oracle's images for them and the oracle's (state_dict, kwargs) per stage."""
+def cond_images_cascade(device, timesteps=3, cond_ch=4, self_cond=False):
+    """A tiny two-stage cascade whose unets take a `cond_ch`-channel conditioning image (Unet(cond_images_channels=...), ip.py:1191-1194,
+    1555-1560; None is returned for it when cond_ch = 0) and / or self-condition (Unet(self_cond=True), ip.py:1541-1543, 2249), its
+    inputs, a recorded-noise function, the oracle's images for them and the oracle's (state_dict, kwargs) per stage."""
     from imagen_pytorch_amd import Imagen, Unet
     from oracle import sampler_oracle as so
 
     base = dict(dim=8, cond_dim=32, text_embed_dim=32, dim_mults=(1, 2), layer_attns=(False, True), layer_cross_attns=(False, True),
-                attn_heads=2, max_text_len=16, attn_pool_num_latents=8, cond_images_channels=4)
+                attn_heads=2, max_text_len=16, attn_pool_num_latents=8, cond_images_channels=cond_ch, self_cond=self_cond)
     k1, k2 = dict(base, num_resnet_blocks=1), dict(base, num_resnet_blocks=(1, 2), memory_efficient=True)
     torch.manual_seed(3)
     unets = [Unet(**k1), Unet(**k2)]
@@ -69,7 +70,7 @@ def cond_images_cascade(device, timesteps=3):
     imagen = imagen.to(device).eval()
     g = torch.Generator().manual_seed(11)
     te = torch.randn(2, 7, 32, generator=g)
-    cond = torch.rand(2, 4, 24, 24, generator=g)      # neither stage's size: both resize it
+    cond = torch.rand(2, cond_ch, 24, 24, generator=g) if cond_ch else None      # neither stage's size: both resize it
     draws = {}
 
     def noise(tag, shape):

@@ -184,6 +184,30 @@ def test_reference_step_level_api(monkeypatch):
     assert max(nerr(a, b) for a, b in zip(outs, fused)) < 5e-3
 
 
+def test_self_conditioned_sampling():
+    """Unet(self_cond=True, cond_images_channels=4) stages on the GPU against the oracle (ip.py:1541-1543, 2249): the graph path reads the
+    previous step's thresholded x0 from the buffer DDPM_UPDATE leaves it in."""
+    from step_api_case import cond_images_cascade
+
+    dev = torch.device("cuda:0")
+    imagen, te, cond, noise_fn, want, sds = cond_images_cascade(dev, self_cond=True)
+    results = {}
+    for use_graph in (False, True):
+        outs = imagen.sample(text_embeds=te.to(dev), cond_images=cond.to(dev), cond_scale=3., use_tqdm=False, return_all_unet_outputs=True,
+                             noise_fn=noise_fn, use_graph=use_graph)
+        errs = [nerr(o, w) for o, w in zip(outs, want)]
+        assert max(errs) < 2e-2, (use_graph, errs)
+        results[use_graph] = outs
+    assert all(torch.equal(a, b) for a, b in zip(results[False], results[True]))
+    # one forward with an explicit self-conditioning image
+    from oracle import unet_oracle as uo
+    u = imagen.unets[0]
+    x, t, sc = torch.randn(2, 3, 16, 16), torch.tensor([0.3, -0.8]), torch.rand(2, 3, 16, 16) * 2 - 1
+    got = u.forward_with_cond_scale(x.to(dev), t.to(dev), text_embeds=te.to(dev), cond_images=cond.to(dev), self_cond=sc.to(dev), cond_scale=3.0)
+    ref = uo.unet_forward_with_cond_scale(*sds[0], x, t, text_embeds=te, cond_images=cond, self_cond=sc, cond_scale=3.0)
+    assert nerr(got, ref) < 2 * UNET_TOL
+
+
 def test_cond_images_sampling():
     """sample(cond_images=...) on the GPU against the oracle (Unet(cond_images_channels=4) stages; ip.py:1555-1560, 2465)."""
     from step_api_case import cond_images_cascade

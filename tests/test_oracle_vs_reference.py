@@ -49,14 +49,15 @@ def test_state_dict_layout_is_interchangeable():
         ours.load_state_dict(ref.state_dict())
 
 
-@pytest.mark.parametrize("cond_ch", [0, 4], ids=["plain", "cond_images"])
-def test_sampler_small_cascade(cond_ch):
+@pytest.mark.parametrize("cond_ch,self_cond", [(0, False), (4, False), (0, True), (4, True)],
+                         ids=["plain", "cond_images", "self_cond", "cond_images+self_cond"])
+def test_sampler_small_cascade(cond_ch, self_cond):
     ip = ref_shim.load_reference()
     torch.manual_seed(0)
     k1 = dict(dim=8, cond_dim=32, dim_mults=(1, 2), num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True), attn_heads=2,
-              cond_images_channels=cond_ch)
+              cond_images_channels=cond_ch, self_cond=self_cond)
     k2 = dict(dim=8, cond_dim=32, dim_mults=(1, 2), num_resnet_blocks=(1, 2), layer_attns=(False, True), layer_cross_attns=(False, True),
-              attn_heads=2, memory_efficient=True, cond_images_channels=cond_ch)
+              attn_heads=2, memory_efficient=True, cond_images_channels=cond_ch, self_cond=self_cond)
     extra = dict(cond_images=torch.rand(2, cond_ch, 24, 24)) if cond_ch else {}
     im = ip.Imagen((ip.Unet(**k1), ip.Unet(**k2)), image_sizes=(16, 32), timesteps=4, text_embed_dim=768, cond_drop_prob=0.1)
     for u in im.unets:
@@ -99,9 +100,11 @@ def _sweep_inputs(kw, seed=5):
     x, t = torch.randn(B, kw.get("channels", 3), S, S), torch.tensor([0.4, -1.7])
     te = torch.randn(B, 7, kw["text_embed_dim"]) if kw.get("cond_on_text", True) else None
     extra = dict(lowres_cond_img=torch.randn(B, 3, S, S), lowres_noise_times=torch.tensor([0.9, 0.9])) if kw.get("lowres_cond") else {}
-    from unet_config_sweep import cond_images_for
+    from unet_config_sweep import cond_images_for, self_cond_for
     if kw.get("cond_images_channels", 0):
         extra["cond_images"] = cond_images_for(kw, B)
+    if kw.get("self_cond", False):
+        extra["self_cond"] = self_cond_for(kw, B)
     return x, t, te, extra
 
 

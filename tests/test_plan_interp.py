@@ -172,7 +172,7 @@ def test_unet_plan_config_sweep(name, reference_weights):
     from imagen_pytorch_amd.engine import UnetEngine
     from oracle import unet_oracle as uo
     from plan_interp import Interpreter
-    from unet_config_sweep import SWEEP, cond_images_for
+    from unet_config_sweep import SWEEP, cond_images_for, self_cond_for
 
     kw = SWEEP[name]
     torch.manual_seed(1)
@@ -193,13 +193,18 @@ def test_unet_plan_config_sweep(name, reference_weights):
     for buf in (eng.x_in, eng.lowres_in, eng.times, eng.lowres_times, eng.out, eng.keep_u8, eng.src_idx, eng.arange_idx, eng.t_const.t):
         it.mem.register(buf)
     it.run(eng._static_plans[te.shape[1] if with_text else 0][0])
-    cond_images = cond_images_for(kw, B)
+    cond_images, self_cond = cond_images_for(kw, B), self_cond_for(kw, B)
+    for buf in (eng.cond_in, eng.self_cond_in, eng.cimg.t if eng.cimg is not None else None):
+        if buf is not None:
+            it.mem.register(buf)
     if cond_images is not None:
         eng.set_cond_images(cond_images)
-        for buf in (eng.cond_in, eng.cimg.t):
-            it.mem.register(buf)
-        it.run(eng._cond_pack)
+        if eng._cond_pack is not None:       # (with self-conditioning the step plan packs both)
+            it.run(eng._cond_pack)
         extra["cond_images"] = cond_images
+    if self_cond is not None:
+        eng.set_self_cond(self_cond)
+        extra["self_cond"] = self_cond
     eng.x_in.copy_(x)
     if eng.lowres:
         eng.lowres_in.copy_(extra["lowres_cond_img"])

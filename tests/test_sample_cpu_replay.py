@@ -231,9 +231,31 @@ def test_reference_step_level_api(cpu_backend, monkeypatch):
     sched = imagen.noise_schedulers[0]
     x = torch.zeros(1, 3, 16, 16)
     with pytest.raises(NotImplementedError):
-        imagen.p_sample(imagen.unets[0], x, torch.ones(1), t_next=torch.zeros(1), noise_scheduler=sched, self_cond=x)
+        imagen.p_sample(imagen.unets[0], x, torch.ones(1), t_next=torch.zeros(1), noise_scheduler=sched, cond_video_frames=x[:, :, None])
     with pytest.raises(AssertionError):      # a conditioning image for a unet built without cond_images_channels (ip.py:1555)
         imagen.p_sample(imagen.unets[0], x, torch.ones(1), t_next=torch.zeros(1), noise_scheduler=sched, cond_images=x)
+
+
+@pytest.mark.parametrize("cond_ch,self_cond", [(0, True), (4, True)], ids=["self_cond", "cond_images+self_cond"])
+def test_self_conditioned_sampling(cpu_backend, monkeypatch, cond_ch, self_cond):
+    """Unet(self_cond=True) stages (ip.py:1541-1543, 2249): every step's denoiser reads the previous step's thresholded x0 — in the graph
+    path from the buffer DDPM_UPDATE leaves it in, in the step-level API from p_sample's second return value."""
+    from step_api_case import cond_images_cascade, recorded_noise
+
+    imagen, te, cond, noise_fn, want, _ = cond_images_cascade(torch.device("cpu"), cond_ch=cond_ch, self_cond=self_cond)
+    extra = {} if cond is None else dict(cond_images=cond)
+    outs = imagen.sample(text_embeds=te, cond_scale=3., use_tqdm=False, return_all_unet_outputs=True, noise_fn=noise_fn, device="cpu", **extra)
+    errs = [nerr(o, w) for o, w in zip(outs, want)]
+    assert max(errs) < 2e-2, errs
+    again = imagen.sample(text_embeds=te, cond_scale=3., use_tqdm=False, noise_fn=noise_fn, device="cpu", **extra)
+    assert torch.equal(again, outs[-1]), "the self-conditioning buffer is reset at the start of every loop"
+    # stage 1 step by step through the reference's API
+    T = imagen.noise_schedulers[0].num_timesteps
+    draws = [noise_fn(("init", 0), (2, 3, 16, 16))] + [noise_fn(("step", 0, i), (2, 3, 16, 16)) for i in range(T)]
+    with recorded_noise(monkeypatch, draws, torch.device("cpu")):
+        img = imagen.p_sample_loop(imagen.unets[0], (2, 3, 16, 16), noise_scheduler=imagen.noise_schedulers[0], text_embeds=te,
+                                   text_mask=torch.any(te != 0., dim=-1), cond_scale=3., use_tqdm=False, **extra)
+    assert nerr(img, want[0]) < 2e-2
 
 
 def test_cond_images_sampling(cpu_backend):

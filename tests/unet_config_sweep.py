@@ -35,6 +35,10 @@ SWEEP = {
     "cond_images_3": dict(_T, num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True), cond_images_channels=3),
     "cond_images_10_lowres_plain_init": dict(_T, num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True),
                                              cond_images_channels=10, lowres_cond=True, init_cross_embed=False),
+    # self-conditioning (ip.py:1541-1543): the previous x0 estimate as three more init-conv input channels
+    "self_cond": dict(_T, num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True), self_cond=True),
+    "self_cond_lowres_cond_images_5": dict(_T, num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True), self_cond=True,
+                                           lowres_cond=True, cond_images_channels=5),
     "channels_out_6": dict(_T, num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True), channels_out=6),
 }
 
@@ -47,3 +51,12 @@ def cond_images_for(kw, B, seed=9):
         return None
     g = torch.Generator().manual_seed(seed)
     return torch.rand(B, cc, 8, 8, generator=g)
+
+
+def self_cond_for(kw, B, S=16, seed=10):
+    """The self-conditioning image of a sweep configuration, or None."""
+    import torch
+    if not kw.get("self_cond", False):
+        return None
+    g = torch.Generator().manual_seed(seed)
+    return torch.rand(B, kw.get("channels", 3), S, S, generator=g) * 2 - 1
