@@ -259,6 +259,79 @@ def make_video_sample_fixture(ip, iv, path, seed=23, T=2, frames=4):
     print(f"wrote {path}: outputs {[tuple(o.shape) for o in outs]}, std {outs[-1].std():.4f}, {len(draws)} draws")
 
 
+def make_video_options_fixture(ip, iv, path, T=2, R=2, frames=4):
+    """Video-stage options of Imagen.sample on the two Unet3D stages of sample_tiny_video.pt (same weights — only inputs, draws and
+    outputs are stored here): prompt frames (`cond_video_frames`, `post_cond_video_frames`, both; iv.py:1682-1718, 1933-1939,
+    ip.py:2417-2434), init videos + skip_steps, and video inpainting with resampling (ip.py:2196-2289)."""
+    base = torch.load(os.path.join(GOLDEN, "sample_tiny_video.pt"), weights_only=False)
+    assert base["frames"] == frames and base["timesteps"] == T
+    unets = []
+    for spec in base["unets"]:
+        u = iv.Unet3D(**{k: v for k, v in spec["kwargs"].items() if k != "lowres_cond"}, lowres_cond=spec["kwargs"]["lowres_cond"])
+        u.load_state_dict(spec["state_dict"])
+        unets.append(u)
+    imagen = ip.Imagen(tuple(unets), image_sizes=base["image_sizes"], timesteps=T, text_embed_dim=32, cond_drop_prob=0.1).eval()
+    for u, spec in zip(imagen.unets, base["unets"]):       # cast_model_parameters may have re-instantiated (ip.py:1897-1903)
+        u.load_state_dict(spec["state_dict"])
+    text_embeds = base["text_embeds"]
+    g = torch.Generator().manual_seed(29)
+    S = base["image_sizes"][-1]
+    pre = torch.rand(2, 3, 2, S, S, generator=g)           # at the last stage's size: that stage concatenates them with its low-res clip
+    post = torch.rand(2, 3, 2, S, S, generator=g)
+    init_video = torch.rand(2, 3, frames, base["image_sizes"][0], base["image_sizes"][0], generator=g)
+    inpaint_videos = torch.rand(2, 3, frames, S, S, generator=g)
+    inpaint_masks = torch.rand(2, frames, S, S, generator=g) > 0.5
+    inpaint_masks[:, :, 4:10, 2:12] = True
+
+    def plain_tags(draws, first=0):
+        noise, it = {}, iter(draws)
+        for stage in range(2):
+            if stage > 0:
+                noise[("lowres", stage)] = next(it)
+            noise[("init", stage)] = next(it)
+            for i in range(first, T):
+                noise[("step", stage, i)] = next(it)
+        assert next(it, None) is None
+        return noise
+
+    common = dict(text_embeds=text_embeds, video_frames=frames, cond_scale=base["cond_scale"], use_tqdm=False, return_all_unet_outputs=True)
+    runs = {}
+    torch.manual_seed(31)
+    for tag, kw in (("cond_pre", dict(cond_video_frames=pre)), ("cond_post", dict(post_cond_video_frames=post)),
+                    ("cond_both", dict(cond_video_frames=pre, post_cond_video_frames=post))):
+        outs, draws = _record_draws(lambda: imagen.sample(**common, **kw))
+        runs[tag] = dict(kwargs=kw, noise=plain_tags(draws), outputs=[o.clone() for o in outs])
+    outs, draws = _record_draws(lambda: imagen.sample(**common, init_images=init_video, skip_steps=1))
+    runs["init_skip"] = dict(kwargs=dict(init_images=init_video, skip_steps=1), noise=plain_tags(draws, first=1), outputs=[o.clone() for o in outs])
+    kw = dict(inpaint_videos=inpaint_videos, inpaint_masks=inpaint_masks, inpaint_resample_times=R)
+    outs, draws = _record_draws(lambda: imagen.sample(**common, **kw))
+    noise, it = {}, iter(draws)
+    for stage in range(2):
+        if stage > 0:
+            noise[("lowres", stage)] = next(it)
+        noise[("init", stage)] = next(it)
+        for i in range(T):
+            for r in reversed(range(R)):
+                noise[("inpaint", stage, i, r)] = next(it)
+                noise[("step", stage, i, r)] = next(it)
+                if r > 0 and i < T - 1:
+                    noise[("renoise", stage, i, r)] = next(it)
+    assert next(it, None) is None
+    runs["inpaint"] = dict(kwargs=kw, noise=noise, outputs=[o.clone() for o in outs])
+    # same prompt frames with the first stage at half the frame rate: the prompt is resized over time per stage (scale_video_time)
+    imagen2 = ip.Imagen(tuple(imagen.unets), image_sizes=base["image_sizes"], timesteps=T, text_embed_dim=32, cond_drop_prob=0.1,
+                        temporal_downsample_factor=(2, 1)).eval()
+    pre4 = torch.rand(2, 3, 4, S, S, generator=g)
+    outs, draws = _record_draws(lambda: imagen2.sample(**common, cond_video_frames=pre4))
+    runs["cond_pre_tds"] = dict(kwargs=dict(cond_video_frames=pre4), temporal_downsample_factor=(2, 1), noise=plain_tags(draws),
+                                outputs=[o.clone() for o in outs])
+    torch.save(dict(weights_from="sample_tiny_video.pt", timesteps=T, frames=frames, runs=runs, generator="oracle/make_golden.py --video-options",
+                    reference="lucidrains/imagen-pytorch v2.0.0 Imagen.sample over Unet3D stages with cond_video_frames / "
+                              "post_cond_video_frames / init_images + skip_steps / inpaint_videos (ip.py:2167-2498, imagen_video.py:1682-1718)"), path)
+    for k, r in runs.items():
+        print(f"wrote {path} [{k}]: outputs {[tuple(o.shape) for o in r['outputs']]}, std {r['outputs'][-1].std():.4f}, {len(r['noise'])} draws")
+
+
 def _record_draws(fn):
     """Run fn() with torch.randn / randn_like recording every Gaussian draw, in call order."""
     draws = []
@@ -376,6 +449,9 @@ def main():
     ip = load_reference()
     if "--video" in sys.argv:        # only the video sampling fixture
         make_video_sample_fixture(ip, load_reference("imagen_video"), os.path.join(GOLDEN, "sample_tiny_video.pt"))
+        return
+    if "--video-options" in sys.argv:   # only the video-stage options fixture (weights are those of sample_tiny_video.pt)
+        make_video_options_fixture(ip, load_reference("imagen_video"), os.path.join(GOLDEN, "sample_tiny_video_options.pt"))
         return
     if "--unet3d" in sys.argv:       # only the Imagen-Video denoiser fixture (SURVEY §8(f) NEXT-2 groundwork)
         make_unet3d_fixture(load_reference("imagen_video"), os.path.join(GOLDEN, "unet3d_tiny.pt"))

@@ -5,8 +5,9 @@ Restates, in fp32 torch on CPU, the continuous-time Gaussian diffusion helpers
 p_sample_loop / sample` (ip.py:2042-2498) for the options the BASELINE configs use:
 noise-prediction objective, dynamic thresholding, classifier-free guidance, low-res
 noise-conditioning augmentation, plus the p_sample_loop options init_images, skip_steps
-and inpainting with resampling (ip.py:2205-2206, 2228-2229, 2237-2286), `cond_images` and
-self-conditioning unets.
+and inpainting with resampling (ip.py:2205-2206, 2228-2229, 2237-2286), `cond_images`,
+self-conditioning unets, and for video stages `cond_video_frames` / `post_cond_video_frames`
+(ip.py:2417-2434) and inpaint_videos / init videos (resize over frames too, ip.py:2196-2220).
 
 All Gaussian noise is drawn through an injectable `noise_fn(tag, shape)` so the HIP
 path and the reference can be fed identical tensors (CPU and GPU RNG streams differ,
@@ -118,7 +119,10 @@ def p_sample_loop(denoise: Callable[[Tensor, Tensor], Tensor], shape, *, schedul
     times (RePaint); the draws are tagged ("inpaint", stage, i, r), ("step", stage, i, r), ("renoise", stage, i, r) in the
     reference's call order; without it the step draw keeps its 3-tuple tag ("step", stage, i)."""
     b, size = shape[0], shape[-1]
-    resize = lambda im: im if im.shape[-1] == size else F.interpolate(im, size, mode="nearest")   # ip.py:152-168
+    if len(shape) == 5:     # video: resize_video_to with target_frames = this stage's frame count (ip.py:2198-2200, iv.py:134-156)
+        resize = lambda im: im if tuple(im.shape[-3:]) == tuple(shape[-3:]) else F.interpolate(im, tuple(shape[-3:]), mode="nearest")
+    else:
+        resize = lambda im: im if im.shape[-1] == size else F.interpolate(im, size, mode="nearest")   # ip.py:152-168
     img = noise_fn(("init", stage), shape)
     if init_images is not None:
         img = img + resize(init_images)                                     # ip.py:2205-2206 (+ the resize of :2457)
@@ -139,7 +143,7 @@ def p_sample_loop(denoise: Callable[[Tensor, Tensor], Tensor], shape, *, schedul
         last_t = bool((t_next == 0).all())
         for r in reversed(range(R)):
             if inpainting:
-                a, s_ = alpha_sigma(fn(t).reshape(-1, 1, 1, 1))
+                a, s_ = alpha_sigma(fn(t).reshape(-1, *([1] * (len(shape) - 1))))
                 noised = a * known + s_ * noise_fn(("inpaint", stage, i, r), shape)       # ip.py:2244-2246
                 img = img * ~mask + noised * mask
             pred = denoise(img, fn(t), x_start) if self_cond else denoise(img, fn(t))
@@ -175,11 +179,14 @@ def imagen_sample(
     init_images=None,                 # one [0, 1] image batch (or None) per unet, or a single batch for all   (ip.py:2390-2393)
     skip_steps=None,                  # int (or None) per unet
     inpaint_images: Optional[Tensor] = None,   # [0, 1] images, same for every stage
-    inpaint_masks: Optional[Tensor] = None,    # (B, H, W) bool
+    inpaint_masks: Optional[Tensor] = None,    # (B, H, W) bool; videos: (B, F, H, W), or (B, H, W) repeated over the frames (ip.py:2376)
     inpaint_resample_times: int = 5,
     video_frames: Optional[int] = None,        # Imagen-Video: the unets are Unet3D state_dicts, samples are (b, c, f, h, w)
     temporal_downsample_factor=1,              # per stage: stage i samples video_frames // factor[i] frames (ip.py:170-183, 1928-1935)
     cond_images: Optional[Tensor] = None,      # (B, cond_images_channels, h, w) in [0, 1], handed to every unet as is (ip.py:2324, 2465)
+    cond_video_frames: Optional[Tensor] = None,        # (b, c, f', h, w) prompt frames, handed to every Unet3D as they are — not
+    post_cond_video_frames: Optional[Tensor] = None,   # normalised — after the per-stage temporal resize (ip.py:2417-2434)
+    resize_cond_video_frames: bool = True,
 ):
     """ip.py:2291-2498 for text_embeds-conditioned sampling (no self-conditioning)."""
     n = len(unets)
@@ -197,6 +204,8 @@ def imagen_sample(
     init_images = [None if im is None else im * 2 - 1 for im in as_tuple(init_images)]   # normalize_img, ip.py:2391
     skip_steps = as_tuple(skip_steps)
     known = None if inpaint_images is None else inpaint_images * 2 - 1                   # ip.py:2218
+    if video and inpaint_masks is not None and inpaint_masks.ndim == 3:                  # ip.py:2376-2377
+        inpaint_masks = inpaint_masks[:, None].expand(-1, video_frames, -1, -1)
     outputs, img = [], None
     for stage, ((sd, kw), size, T, cs, sched) in enumerate(zip(unets, image_sizes, timesteps, cond_scale, schedules)):
         lowres_img = lowres_times = None
@@ -213,9 +222,17 @@ def imagen_sample(
             lowres_logsnr = SCHEDULES[lowres_noise_schedule](lowres_times)       # ip.py:2081
 
         fwd = unet3d_forward_with_cond_scale if video else unet_forward_with_cond_scale
+        video_kw = {}
+        for name, v in (("cond_video_frames", cond_video_frames), ("post_cond_video_frames", post_cond_video_frames)):
+            if video and v is not None:
+                if resize_cond_video_frames and tds[stage] != 1:   # scale_video_time (iv.py:158-178): nearest over the frame axis
+                    assert v.shape[2] % tds[stage] == 0
+                    v = F.interpolate(v, (v.shape[2] // tds[stage], v.shape[-2], v.shape[-1]), mode="nearest")
+                video_kw[name] = v
 
-        def denoise(x, log_snr, x0_prev=None, _sd=sd, _kw=kw, _cs=cs, _li=lowres_img, _lt=(lowres_logsnr if lowres_img is not None else None)):
-            extra = {} if cond_images is None else dict(cond_images=cond_images)
+        def denoise(x, log_snr, x0_prev=None, _sd=sd, _kw=kw, _cs=cs, _li=lowres_img, _lt=(lowres_logsnr if lowres_img is not None else None),
+                    _vk=video_kw):
+            extra = dict(_vk) if cond_images is None else dict(_vk, cond_images=cond_images)
             if _kw.get("self_cond", False):
                 extra["self_cond"] = x0_prev
             return fwd(_sd, _kw, x, log_snr, cond_scale=_cs, text_embeds=text_embeds, text_mask=text_masks, lowres_cond_img=_li,

@@ -272,8 +272,13 @@ def temporal_pixel_shuffle_up(p: _SD, x: Tensor, stride: int) -> Tensor:
 
 def unet3d_forward(sd: Dict[str, Tensor], kwargs: dict, x: Tensor, time: Tensor, *, lowres_cond_img: Optional[Tensor] = None,
                    lowres_noise_times: Optional[Tensor] = None, text_embeds: Optional[Tensor] = None, text_mask: Optional[Tensor] = None,
-                   cond_drop_prob: float = 0.0, ignore_time: bool = False, taps: Optional[dict] = None) -> Tensor:
-    """iv.py:1650-1941.  x: (b, c, f, h, w); `time` / `lowres_noise_times` are log-SNR values."""
+                   cond_drop_prob: float = 0.0, ignore_time: bool = False, taps: Optional[dict] = None,
+                   cond_video_frames: Optional[Tensor] = None, post_cond_video_frames: Optional[Tensor] = None) -> Tensor:
+    """iv.py:1650-1941.  x: (b, c, f, h, w); `time` / `lowres_noise_times` are log-SNR values.
+
+    cond_video_frames / post_cond_video_frames (iv.py:1682-1718, 1933-1939) are restated as the reference executes them, including
+    its frame order: BOTH prompts are concatenated in FRONT of x ([post, pre, x] — iv.py:1716 prepends the succeeding frames too)
+    while the low-res clip read by final_conv is extended as [pre, lowres, post]; the output keeps frames [len(pre), len(pre) + f)."""
     cfg = resolve_config3d(kwargs)
     p = _SD(sd)
     heads = cfg["attn_heads"]
@@ -291,6 +296,26 @@ def unet3d_forward(sd: Dict[str, Tensor], kwargs: dict, x: Tensor, time: Tensor,
         assert lowres_cond_img is not None and lowres_noise_times is not None
     if lowres_cond_img is not None:
         x = torch.cat((x, lowres_cond_img), dim=1)
+        if cond_video_frames is not None:                          # iv.py:1686-1688
+            lowres_cond_img = torch.cat((cond_video_frames, lowres_cond_img), dim=2)
+            cond_video_frames = torch.cat((cond_video_frames, cond_video_frames), dim=1)
+        if post_cond_video_frames is not None:                     # iv.py:1690-1692
+            lowres_cond_img = torch.cat((lowres_cond_img, post_cond_video_frames), dim=2)
+            post_cond_video_frames = torch.cat((post_cond_video_frames, post_cond_video_frames), dim=1)
+
+    def to_size(v):                                                # resize_video_to, frame count unchanged (iv.py:134-156)
+        size = x.shape[-1]
+        return v if v.shape[-1] == size and v.shape[-2] == size else F.interpolate(v, (v.shape[2], size, size), mode="nearest")
+
+    num_preceding = num_succeeding = 0
+    if cond_video_frames is not None:                              # iv.py:1697-1705
+        num_preceding = cond_video_frames.shape[2]
+        assert num_preceding % cfg["total_temporal_divisor"] == 0
+        x = torch.cat((to_size(cond_video_frames), x), dim=2)
+    if post_cond_video_frames is not None:                         # iv.py:1710-1718 (prepended as well — reproduced, not corrected)
+        num_succeeding = post_cond_video_frames.shape[2]
+        assert num_succeeding % cfg["total_temporal_divisor"] == 0
+        x = torch.cat((to_size(post_cond_video_frames), x), dim=2)
 
     if cfg["init_cross_embed"]:                                   # iv.py:1121-1146, 1751
         fmaps = [conv_frames(x, p(f"init_conv.convs.{i}.weight"), p(f"init_conv.convs.{i}.bias"), padding=(ksz - 1) // 2)
@@ -407,7 +432,12 @@ def unet3d_forward(sd: Dict[str, Tensor], kwargs: dict, x: Tensor, time: Tensor,
         x = resnet_block3d(p.sub("final_res_block"), x, t, None, ignore_time)
     if lowres_cond_img is not None:
         x = torch.cat((x, lowres_cond_img), dim=1)
-    return conv_frames(x, p("final_conv.weight"), p("final_conv.bias"), padding=cfg["final_conv_kernel_size"] // 2)
+    out = conv_frames(x, p("final_conv.weight"), p("final_conv.bias"), padding=cfg["final_conv_kernel_size"] // 2)
+    if num_preceding > 0:                                          # iv.py:1933-1939
+        out = out[:, :, num_preceding:]
+    if num_succeeding > 0:
+        out = out[:, :, :-num_succeeding]
+    return out
 
 
 def unet3d_forward_with_cond_scale(sd, kwargs, x, time, *, cond_scale: float = 1.0, **kw) -> Tensor:

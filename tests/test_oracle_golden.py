@@ -183,3 +183,32 @@ def test_video_elucidated_oracle_matches_reference_fixture():
     assert torch.allclose(outs[0], e["outputs"][0], atol=1e-3), (outs[0] - e["outputs"][0]).abs().max()
     assert torch.allclose(outs[1], e["outputs"][1], atol=5e-3), (outs[1] - e["outputs"][1]).abs().max()
     assert (outs[1] - e["outputs"][1]).abs().mean() < 5e-5
+
+
+VIDEO_OPTION_RUNS = ["cond_pre", "cond_post", "cond_both", "init_skip", "inpaint", "cond_pre_tds"]
+
+
+def video_option_kwargs(run):
+    """Oracle / product keyword arguments of one recorded run of sample_tiny_video_options.pt."""
+    kw = dict(run["kwargs"])
+    if "inpaint_videos" in kw:
+        kw["inpaint_images"] = kw.pop("inpaint_videos")
+    return kw
+
+
+@pytest.mark.parametrize("tag", VIDEO_OPTION_RUNS)
+def test_video_sampler_oracle_options_match_reference_fixture(tag):
+    """Video-stage options of Imagen.sample — prompt frames before / after the clip (with the reference's own frame order, iv.py:1703,
+    1716), init videos + skip_steps, video inpainting with resampling, prompt frames under a per-stage frame rate — vs recorded runs
+    of the live reference on the weights of sample_tiny_video.pt."""
+    o = _load("sample_tiny_video_options.pt")
+    g = _load(o["weights_from"])
+    run = o["runs"][tag]
+    unets = [(u["state_dict"], u["kwargs"]) for u in g["unets"]]
+    with torch.no_grad():
+        outs = so.imagen_sample(unets, g["image_sizes"], g["text_embeds"], timesteps=o["timesteps"], cond_scale=g["cond_scale"],
+                                noise_fn=lambda t, shape: run["noise"][t], return_all=True, video_frames=o["frames"],
+                                temporal_downsample_factor=run.get("temporal_downsample_factor", 1), **video_option_kwargs(run))
+    for got, ref in zip(outs, run["outputs"]):
+        assert got.shape == ref.shape
+        assert torch.allclose(got, ref, atol=2e-4), (got - ref).abs().max()
