@@ -122,7 +122,7 @@ class ElucidatedImagen(Imagen):
 
     # ---- per-stage plans --------------------------------------------------------------------------------------------------
     def _build_stage(self, idx: int, B: int, device, *, cond_scale: float, with_text: bool, inject_noise: bool, sample_offset: int,
-                     resample_times: int = 0, frames: int = 0):
+                     resample_times: int = 0, frames: int = 0, prompt_frames: tuple = (0, 0)):
         unet = self.unets[idx]
         if getattr(unet, 'self_cond', False):
             from .imagen import _out_of_scope
@@ -131,7 +131,7 @@ class ElucidatedImagen(Imagen):
         hp = self.hparams[idx]
         cfg = cond_scale != 1.
         key = ("edm", idx, B, S, str(device), float(cond_scale), with_text, inject_noise, sample_offset, self.dynamic_thresholding[idx],
-               self.dynamic_thresholding_percentile, tuple(hp), frames, self._lane)
+               self.dynamic_thresholding_percentile, tuple(hp), frames, prompt_frames, self._lane)
         st = self._stages.get(key)
         if st is not None and not st['eng'].stale():
             return st
@@ -140,7 +140,8 @@ class ElucidatedImagen(Imagen):
         if video:      # as in Imagen._stage: the state is the engine's frame-major clip, every update below is elementwise per sample
             assert frames > 0, 'video_frames must be passed in on sample time if training on video'
             from . import engine3d
-            eng = engine3d.UnetEngine3D(unet, rows, B, frames, S, device, with_text=with_text)
+            eng = engine3d.UnetEngine3D(unet, rows, B, frames, S, device, with_text=with_text, pre_frames=prompt_frames[0],
+                                        post_frames=prompt_frames[1])
         else:
             from . import engine
             eng = engine.UnetEngine(unet, rows, B, S, device, with_text=with_text)
@@ -294,7 +295,7 @@ class ElucidatedImagen(Imagen):
     ):
         if sigma_min is not None or sigma_max is not None:
             _out_of_scope("sample(sigma_min=/sigma_max=) per-call overrides (set them on the constructor)")
-        if inpaint_images is not None or inpaint_masks is not None or skip_steps is not None or any(
+        if inpaint_images is not None or inpaint_videos is not None or inpaint_masks is not None or skip_steps is not None or any(
                 i is not None for i in _cast_tuple(init_images)):
             _out_of_scope("ElucidatedImagen.sample(inpaint_images= / init_images= / skip_steps=) (el.py:446-452, 497-533)")
         with self._eval_mode():

@@ -1,7 +1,7 @@
 """UnetEngine3D — kernel planner of the drop-in `Unet3D` (Imagen-Video denoiser, imagen_pytorch/imagen_video.py:1650-1941 = iv.py).
 
-STATUS: host logic only so far — the plan is checked on CPU against oracle/unet3d_oracle.py through tests/plan_interp.py; it has
-NOT been launched on a GPU yet (DESIGN.md §8 NEXT-2).  The two kernels it needs beyond the image path live in csrc/temporal.hip.
+The two kernels it needs beyond the image path live in csrc/temporal.hip.  Checked on CPU against oracle/unet3d_oracle.py through
+tests/plan_interp.py and on MI355X by tests/test_video_gpu.py (DESIGN.md §8 NEXT-2).
 
 Layout: a clip is fp16 [R, F, H, W, C] — F consecutive NHWC frames per row — so the same memory serves three views:
   frames  Act(R*F, H, W, C)     per-frame ops of the image path (3x3 conv, down / up-sampling, CrossEmbed) with batch R*F
@@ -15,6 +15,12 @@ temporal conv1d (k = 3).  The temporal conv is three accumulating 1x1 GEMMs over
 launches and ~2x the minimal traffic per temporal conv; a dedicated (3 x 1)-tap staging path is the obvious next optimisation.
 Everything input-independent is prepared at plan build: the relative position bias table of every temporal attention
 (DynamicPositionBias MLP on the 2F-1 frame distances, iv.py:1182-1223) and the depthwise PEG taps.
+
+Prompt frames (`cond_video_frames` / `post_cond_video_frames`, iv.py:1682-1718, 1933-1939): the network then runs on
+F = len(post) + len(pre) + Fx frames per clip — the reference concatenates BOTH prompts in front of the Fx frames being denoised —
+while the sampler state `x_in` / `out` keep Fx frames.  The prompt slots of the packed input clip are static (written once by
+set_cond_video_frames); per step the Fx packed frames are copied behind them and the final conv's F output frames are cut back to
+frames [len(pre), len(pre) + Fx) — two strided row copies around the unchanged plan.
 """
 from __future__ import annotations
 
@@ -44,10 +50,14 @@ def _w2d(mod):
 
 class UnetEngine3D(UnetEngine):
     def __init__(self, unet, rows: int, src_batch: int, frames: int, size: int, device, with_text: bool = True, ignore_time: bool = False,
-                 dry: bool = False):
-        self.F = frames
+                 dry: bool = False, pre_frames: int = 0, post_frames: int = 0):
+        self.Fx, self.Fpre, self.Fpost = frames, pre_frames, post_frames   # frames of the sampler state / of the two prompts
+        self.F = frames + pre_frames + post_frames                         # frames the network runs on
         self.ignore_time = ignore_time
-        assert frames <= 32, "the temporal attention kernel holds at most 32 frames per pixel"
+        assert self.F <= 32, "the temporal attention kernel holds at most 32 frames per pixel"
+        div = getattr(unet, 'total_temporal_divisor', 1)
+        assert pre_frames % div == 0 and post_frames % div == 0, \
+            f'the number of conditioning frames must be divisible by {div}'                     # iv.py:1700, 1713
         super().__init__(unet, rows, src_batch, size, device, with_text=with_text, dry=dry)
 
     # ------------------------------------------------------------------------------------------ views
@@ -66,11 +76,12 @@ class UnetEngine3D(UnetEngine):
 
     def _alloc_io(self):
         super()._alloc_io()
-        R, S, u, F = self.R, self.S, self.unet, self.F
-        # frame-major fp32 images: (b, f, c, h, w)
-        self.x_in = self.f32buf(self.src_batch, F, u.channels, S, S, zero=True)
-        self.lowres_in = self.f32buf(self.src_batch, F, u.channels, S, S, zero=True) if self.lowres else None
-        self.out = self.f32buf(R, F, u.channels_out, S, S)
+        R, S, u, F, Fx = self.R, self.S, self.unet, self.F, self.Fx
+        # frame-major fp32 images: (b, f, c, h, w); the sampler's state and the prediction it reads hold the Fx denoised frames only
+        self.x_in = self.f32buf(self.src_batch, Fx, u.channels, S, S, zero=True)
+        self.lowres_in = self.f32buf(self.src_batch, Fx, u.channels, S, S, zero=True) if self.lowres else None
+        self.out = self.f32buf(R, Fx, u.channels_out, S, S)
+        self.out_full = self.f32buf(R, F, u.channels_out, S, S) if F != Fx else self.out   # what final_conv writes
 
     # ------------------------------------------------------------------------------------------ step plan
     def _build_step_plan(self) -> Plan:
@@ -80,11 +91,25 @@ class UnetEngine3D(UnetEngine):
         it = self.ignore_time
         cin = u.channels * (2 if self.lowres else 1)
         assert cin <= 8, "init conv packs the input frames into 8 channels"
-        self.img = self.new(R * F, S, S, 8)
-        xin = self.x_in.view(self.src_batch * F, u.channels, S, S)
-        lin = self.lowres_in.view(self.src_batch * F, u.channels, S, S) if self.lowres else None
-        self._pack_op = ops.pack_image(plan, xin, lin, self.img, brep=R // self.src_batch, label="pack_frames")
+        Fx = self.Fx
+        self.img = self.new(R * F, S, S, 8, zero=True)
+        xin = self.x_in.view(self.src_batch * Fx, u.channels, S, S)
+        lin = self.lowres_in.view(self.src_batch * Fx, u.channels, S, S) if self.lowres else None
+        self.img_x = self.img if F == Fx else self.new(R * Fx, S, S, 8)       # the packed Fx frames [x | lowres | zero pad]
+        self._pack_op = ops.pack_image(plan, xin, lin, self.img_x, brep=R // self.src_batch, label="pack_frames")
         plan.keep += [self.x_in, self.lowres_in] if self.lowres else [self.x_in]
+        self.fin2 = None
+        if F != Fx:
+            # prompt frames: clip = [post | pre | x] (iv.py:1703, 1716); the prompt slots are static, the Fx frames land behind them
+            fr = S * S * 8
+            ops.rows_copy(plan, self.img_x.t, self.img.t, B=R, rows=1, C=Fx * fr, src_bs=Fx * fr, src_rs=0, dst_bs=F * fr, dst_rs=0,
+                          dst_off=(self.Fpost + self.Fpre) * fr, label="place_frames")
+            if self.lowres and self.Fpost:
+                # final_conv reads the low-res clip extended as [pre | lowres | post] (iv.py:1687, 1691) — another frame order than
+                # the input clip's once there are succeeding prompt frames: its own buffer, same channel slots as `img`
+                self.fin2 = self.new(R * F, S, S, 8, zero=True)
+                ops.rows_copy(plan, self.img_x.t, self.fin2.t, B=R, rows=1, C=Fx * fr, src_bs=Fx * fr, src_rs=0, dst_bs=F * fr, dst_rs=0,
+                              dst_off=self.Fpre * fr, label="place_lowres_frames")
 
         # ---- time conditioning: identical to the image Unet (iv.py:1764-1781)
         self.hid = self.new(1, 1, R, self.Tc)
@@ -225,7 +250,7 @@ class UnetEngine3D(UnetEngine):
     def _final_conv3d(self, plan, x: Act):
         """final_conv over cat(x, lowres_cond_img) per frame (iv.py:1928-1931) -> fp32 (R, F, C, H, W)."""
         u = self.unet
-        extra = self.img if self.lowres else None
+        extra = (self.fin2 if self.fin2 is not None else self.img) if self.lowres else None
         cw = _w2d(u.final_conv)
 
         def make():
@@ -238,9 +263,46 @@ class UnetEngine3D(UnetEngine):
             wp[:, x.C + u.channels: x.C + 2 * u.channels] = w[:, x.C:]      # packed frame = [x | lowres | zero pad]
             return ops.pack_weight(wp, cw.bias, self.dev)
 
-        out4 = self.out.view(self.R * self.F, u.channels_out, self.S, self.S)
+        out4 = self.out_full.view(self.R * self.F, u.channels_out, self.S, self.S)
         ops.igemm(plan, x, self.W.get("final_conv", make), out4, x2=extra, out_mode=OUT_NCHW_F32, label="final_conv")
-        plan.keep.append(self.out)
+        plan.keep.append(self.out_full)
+        if self.F != self.Fx:
+            # out[:, :, len(pre):][:, :, :-len(post)] (iv.py:1933-1939): frames [Fpre, Fpre + Fx) of every clip; fp32 moved as fp16 pairs
+            fr = 2 * u.channels_out * self.S * self.S
+            ops.rows_copy(plan, self.out_full, self.out, B=self.R, rows=1, C=self.Fx * fr, src_bs=self.F * fr, src_rs=0,
+                          dst_bs=self.Fx * fr, dst_rs=0, src_off=self.Fpre * fr, label="cut_frames")
+            plan.keep.append(self.out)
+
+    def set_cond_video_frames(self, cond_video_frames: Optional[torch.Tensor], post_cond_video_frames: Optional[torch.Tensor]):
+        """The prompt frames of the following forward / sampling calls, each (src_batch, c, f', h, w) with values as given (the
+        reference does not normalise them): nearest-resized to this engine's resolution, frame count unchanged (resize_video_to,
+        iv.py:1702, 1715), and written to the static slots of the packed input clip — and of the final conv's low-res clip, where a
+        low-res stage sees them as extra low-res frames (iv.py:1686-1692; there the reference needs them at the stage's size)."""
+        u, R, S, F = self.unet, self.R, self.S, self.F
+        c = u.channels
+        img = self.img.t.view(R, F, S, S, 8)
+        fin2 = self.fin2.t.view(R, F, S, S, 8) if self.fin2 is not None else None
+        for v, n, at_in, at_fin in ((cond_video_frames, self.Fpre, self.Fpost, 0), (post_cond_video_frames, self.Fpost, 0, self.Fpre + self.Fx)):
+            assert (v is None) == (n == 0), 'this engine was planned for another number of conditioning frames'
+            if v is None:
+                continue
+            assert v.ndim == 5 and v.shape[0] == self.src_batch and v.shape[1] == c and v.shape[2] == n, \
+                f'conditioning frames must be ({self.src_batch}, {c}, {n}, h, w), got {tuple(v.shape)}'
+            v = v.to(self.dev).float()
+            if self.lowres:
+                assert v.shape[-1] == S and v.shape[-2] == S, \
+                    'a low-res-conditioned Unet3D concatenates the conditioning frames with its low-res clip: they must have its size'
+            elif tuple(v.shape[-2:]) != (S, S):
+                v = TF.interpolate(v, (n, S, S), mode='nearest')
+            fm = v.permute(0, 2, 3, 4, 1)                                   # (b, f', h, w, c)
+            packed = torch.zeros(self.src_batch, n, S, S, 8, device=self.dev)
+            packed[..., :c] = fm
+            if self.lowres:
+                packed[..., c:2 * c] = fm                                   # cat((frames, frames), dim = 1), iv.py:1688, 1692
+            packed = packed.to(torch.float16).repeat(R // self.src_batch, 1, 1, 1, 1)
+            img[:, at_in:at_in + n] = packed
+            if fin2 is not None:
+                fin2[:, at_fin:at_fin + n] = packed
 
     def _temporal_conv(self, plan, x: Act, conv, name: str, f: int) -> Act:
         """Causal Conv1d(k = 3) over the frames of every pixel (iv.py:436-449) as three accumulating 1x1 GEMMs on frame-shifted views."""

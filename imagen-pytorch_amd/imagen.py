@@ -7,8 +7,9 @@ captured ONCE into a hipGraph and replayed T times — the step index lives in a
 sampler kernel (and the time embedding) reads, so replay needs no host-side parameter patching.
 
 Implemented options: text embeddings or the T5 hook (`texts=`), classifier-free guidance, dynamic thresholding, init_images /
-skip_steps, inpainting (images), cond_images, self-conditioning unets, start/stop_at_unet_number, video cascades (Unet3D stages).  Training (`forward`, p_losses),
-cond_video_frames / video inpainting raise.  Extensions beyond the reference signature: `noise_fn`,
+skip_steps, inpainting (images and videos), cond_images, self-conditioning unets, start/stop_at_unet_number, video cascades (Unet3D
+stages) with cond_video_frames / post_cond_video_frames.  Training (`forward`, p_losses) raises.  Extensions beyond
+the reference signature: `noise_fn`,
 `seed`, `sample_offset` (batch sharding), `conditioning` handles, lanes (`with imagen.lane(i)`) and `sample_pipelined`.
 """
 from __future__ import annotations
@@ -151,6 +152,7 @@ class Imagen(nn.Module):
         if resize_mode != 'nearest':
             _out_of_scope(f"resize_mode='{resize_mode}'")
         self.temporal_downsample_factor = _cast_tuple(temporal_downsample_factor, num_unets)
+        self.resize_cond_video_frames = resize_cond_video_frames                                                           # ip.py:1931
         assert self.temporal_downsample_factor[-1] == 1, 'downsample factor of last stage must be 1'                       # ip.py:1934
         assert tuple(sorted(self.temporal_downsample_factor, reverse=True)) == self.temporal_downsample_factor, \
             'temporal downsample factor must be in order of descending'                                                   # ip.py:1935
@@ -321,7 +323,7 @@ class Imagen(nn.Module):
             return st
 
     def _build_stage(self, idx: int, B: int, device, *, cond_scale: float, with_text: bool, inject_noise: bool, sample_offset: int,
-                     resample_times: int = 0, frames: int = 0):
+                     resample_times: int = 0, frames: int = 0, prompt_frames: tuple = (0, 0)):
         """Build (or fetch) the per-timestep plan + graph of stage `idx` for batch B.
 
         resample_times = R > 0 selects the inpainting plan (ip.py:2237-2275): the device counter then counts INNER iterations
@@ -334,7 +336,7 @@ class Imagen(nn.Module):
         T = sched.num_timesteps
         cfg = cond_scale != 1.
         key = (idx, B, S, str(device), float(cond_scale), with_text, inject_noise, sample_offset, self.dynamic_thresholding[idx],
-               self.pred_objectives[idx], self.dynamic_thresholding_percentile, resample_times, frames, self._lane)
+               self.pred_objectives[idx], self.dynamic_thresholding_percentile, resample_times, frames, prompt_frames, self._lane)
         st = self._stages.get(key)
         if st is not None and not st['eng'].stale():
             return st
@@ -345,9 +347,9 @@ class Imagen(nn.Module):
             # elementwise per sample (the dynamic threshold is one quantile over the whole clip, ip.py:1921, 2097-2101), so only
             # the sample size changes.  sample() converts from / to the reference's (b, c, f, h, w) at the API boundary.
             assert frames > 0, 'video_frames must be passed in on sample time if training on video'
-            assert not resample_times, 'inpainting of videos is outside this build'
             from . import engine3d
-            eng = engine3d.UnetEngine3D(unet, rows, B, frames, S, device, with_text=with_text)
+            eng = engine3d.UnetEngine3D(unet, rows, B, frames, S, device, with_text=with_text, pre_frames=prompt_frames[0],
+                                        post_frames=prompt_frames[1])
         else:
             from . import engine
             eng = engine.UnetEngine(unet, rows, B, S, device, with_text=with_text)
@@ -370,8 +372,8 @@ class Imagen(nn.Module):
         plan = Plan(f"stage{idx}-step")
         extra = {}
         if R:
-            known = torch.zeros(B, self.channels, S, S, device=dev)      # the known image, normalised, at this stage's size
-            mask = torch.zeros(B, self.channels, S, S, device=dev)       # 1.0 where the known pixel is kept
+            known = torch.zeros_like(eng.x_in)           # the known image (video: frame-major clip), normalised, at this stage's size
+            mask = torch.zeros_like(eng.x_in)            # 1.0 where the known pixel is kept
             noise_blend = torch.zeros_like(known) if inject_noise else None
             noise_renoise = torch.zeros_like(known) if inject_noise else None
             ops.lincomb(plan, known, eng.x_in, blend_coef, step_ptr, B=B, n_per_sample=n, t1=noise_blend, mask=mask, mask_else=eng.x_in,
@@ -671,10 +673,10 @@ class Imagen(nn.Module):
         if device.type not in _SAMPLING_DEVICE_TYPES:
             raise RuntimeError("imagen_pytorch_amd.Imagen.sample runs on MI355X only (move the module to 'cuda'); there is no CPU path")
         self.reset_unets_all_one_device(device)
-        for name, val in (('cond_video_frames', cond_video_frames), ('post_cond_video_frames', post_cond_video_frames),
-                          ('inpaint_videos', inpaint_videos)):
-            if val is not None:
-                _out_of_scope(f"sample({name}=...)")
+        if inpaint_videos is not None:                   # ip.py:2342: the video argument wins
+            inpaint_images = inpaint_videos
+        if not self.is_video:                            # ip.py:2417-2427: only video cascades hand the prompt frames to their unets
+            cond_video_frames = post_cond_video_frames = None
         if cond_images is not None:
             if self.is_video:
                 _out_of_scope("sample(cond_images=...) for video")
@@ -683,8 +685,6 @@ class Imagen(nn.Module):
                 cond_images = cond_images.float() / 255
         assert not (self.is_video and video_frames is None), 'video_frames must be passed in on sample time if training on video'   # ip.py:2381
         if self.is_video:
-            if inpaint_images is not None or skip_steps is not None or any(i is not None for i in _cast_tuple(init_images)):
-                _out_of_scope("inpainting / init_images / skip_steps for video")
             for f in self.temporal_downsample_factor:                       # calc_all_frame_dims, ip.py:170-183
                 assert int(video_frames) % f == 0, f'video_frames {video_frames} must be divisible by the temporal downsample factor {f}'
         frames = int(video_frames) if self.is_video else 0
@@ -712,10 +712,24 @@ class Imagen(nn.Module):
         num_unets = len(self.unets)
         normalize = (lambda im: im * 2 - 1) if self.auto_normalize_img else (lambda im: im)             # ip.py:1885-1888
         resize = lambda im, size: im if im.shape[-1] == size else F.interpolate(im, size, mode='nearest')   # ip.py:152-168
+
+        def resize_clip(v, size, f):
+            """resize_video_to (iv.py:134-156) of a (b, c, f', h, w) clip to f frames of size x size — nearest over all three axes —
+            returned in the internal frame-major layout."""
+            if tuple(v.shape[-3:]) != (f, size, size):
+                v = F.interpolate(v, (f, size, size), mode='nearest')
+            return to_internal(v)
+
         known = known_mask = None
         if inpaint_images is not None:                   # ip.py:2217-2220
             known = normalize(inpaint_images.to(device).float())
-            known_mask = inpaint_masks.to(device)[:, None].float()
+            known_mask = inpaint_masks.to(device)
+            if self.is_video:                            # ip.py:2373-2379
+                assert known.ndim == 5, 'inpaint_videos must be (b, c, f, h, w)'
+                if known_mask.ndim == 3:
+                    known_mask = known_mask[:, None].expand(-1, frames, -1, -1)
+                assert known_mask.shape[1] == frames
+            known_mask = known_mask[:, None].float()
         init_images = [None if im is None else normalize(im.to(device).float()) for im in _cast_tuple(init_images, num_unets)]  # ip.py:2390-2391
         skip_steps = _cast_tuple(skip_steps, num_unets)
         level = lowres_sample_noise_level if lowres_sample_noise_level is not None else self.lowres_sample_noise_level
@@ -753,9 +767,19 @@ class Imagen(nn.Module):
                 assert not (cs != 1. and not self.can_classifier_guidance), \
                     'imagen was not trained with conditional dropout, and thus one cannot use classifier free guidance (cond_scale anything other than 1)'
                 with_text = text_embeds is not None and unet.cond_on_text
+                prompts = [None, None]
+                if isinstance(unet, Unet3D):                # ip.py:2417-2434: the same prompt frames for every stage, at the stage's frame rate
+                    tds = self.temporal_downsample_factor[idx]
+                    for k, v in enumerate((cond_video_frames, post_cond_video_frames)):
+                        if v is not None and self.resize_cond_video_frames and tds != 1:     # scale_video_time, iv.py:158-178
+                            assert v.shape[2] % tds == 0, f'trying to temporally downsample a conditioning video frames of length ' \
+                                                          f'{v.shape[2]} by {tds}, however it is not neatly divisible'
+                            v = F.interpolate(v.float(), (v.shape[2] // tds, v.shape[-2], v.shape[-1]), mode='nearest')
+                        prompts[k] = v
                 st = self._stage(idx, batch_size, device, cond_scale=cs, with_text=with_text, inject_noise=noise_fn is not None,
                                  sample_offset=sample_offset, resample_times=inpaint_resample_times if known is not None else 0,
-                                 frames=frames // self.temporal_downsample_factor[idx] if isinstance(unet, Unet3D) else 0)
+                                 frames=frames // self.temporal_downsample_factor[idx] if isinstance(unet, Unet3D) else 0,
+                                 prompt_frames=tuple(0 if v is None else v.shape[2] for v in prompts))
                 st['sample_offset'] = sample_offset
                 eng = st['eng']
                 S = self.image_sizes[idx]
@@ -763,7 +787,13 @@ class Imagen(nn.Module):
                     'you either requested to condition on an image on the unet, but the conditioning image is not supplied, or vice versa'   # ip.py:1555
                 if cond_images is not None:
                     eng.set_cond_images(cond_images)
-                if known is not None:
+                if prompts[0] is not None or prompts[1] is not None:
+                    eng.set_cond_video_frames(*prompts)
+                stage_frames = st['frames']
+                if known is not None and st['video']:
+                    st['known'].copy_(resize_clip(known, S, stage_frames))
+                    st['mask'].copy_(resize_clip(known_mask, S, stage_frames).bool().expand(-1, -1, self.channels, -1, -1))
+                elif known is not None:
                     st['known'].copy_(resize(known, S))
                     st['mask'].copy_(resize(known_mask, S).bool().expand(-1, self.channels, -1, -1))
                 lowres_logsnr = None
@@ -813,7 +843,8 @@ class Imagen(nn.Module):
                     t_stage = _time.perf_counter()
                 out = self._run_stage(st, noise_fn=noise_fn, stage=idx, seed=seed, use_graph=use_graph, use_tqdm=use_tqdm,
                                          max_steps=max_steps, skip_steps=skip_steps[idx],
-                                         init_images=None if init_images[idx] is None else resize(init_images[idx], S))
+                                         init_images=None if init_images[idx] is None else
+                                         (resize_clip(init_images[idx], S, stage_frames) if st['video'] else resize(init_images[idx], S)))
                 if timing:
                     stream.synchronize()
                     dt = _time.perf_counter() - t_stage

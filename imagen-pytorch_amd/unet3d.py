@@ -246,16 +246,18 @@ class Unet3D(nn.Module):
         return unet
 
     # ---- execution ------------------------------------------------------------------------------------
-    def engine(self, batch_rows: int, src_batch: int, frames: int, image_size: int, device, with_text: bool = True, ignore_time: bool = False):
+    def engine(self, batch_rows: int, src_batch: int, frames: int, image_size: int, device, with_text: bool = True, ignore_time: bool = False,
+               pre_frames: int = 0, post_frames: int = 0):
         from .engine3d import UnetEngine3D
 
         device = torch.device(device)
         if device.type != 'cuda':
             raise RuntimeError("imagen_pytorch_amd.Unet3D runs on MI355X through libimagen_hip.so only; there is no CPU path")
-        key = (batch_rows, src_batch, frames, image_size, device.index or 0, bool(with_text), bool(ignore_time))
+        key = (batch_rows, src_batch, frames, image_size, device.index or 0, bool(with_text), bool(ignore_time), pre_frames, post_frames)
         eng = self._engines.get(key)
         if eng is None or eng.stale():
-            eng = UnetEngine3D(self, batch_rows, src_batch, frames, image_size, device, with_text=with_text, ignore_time=ignore_time)
+            eng = UnetEngine3D(self, batch_rows, src_batch, frames, image_size, device, with_text=with_text, ignore_time=ignore_time,
+                               pre_frames=pre_frames, post_frames=post_frames)
             self._engines[key] = eng
         return eng
 
@@ -275,14 +277,15 @@ class Unet3D(nn.Module):
     def forward(self, x, time, *, lowres_cond_img=None, lowres_noise_times=None, text_embeds=None, text_mask=None, cond_images=None,
                 cond_video_frames=None, post_cond_video_frames=None, self_cond=None, cond_drop_prob=0., ignore_time=False):
         """iv.py:1650-1941.  x: (b, c, f, h, w); returns fp32 (b, c_out, f, h, w)."""
-        assert cond_images is None and self_cond is None and cond_video_frames is None and post_cond_video_frames is None, \
-            'cond_images / cond_video_frames / post_cond_video_frames / self_cond are outside the scope of this build'
         return self._run(x, time, lowres_cond_img=lowres_cond_img, lowres_noise_times=lowres_noise_times, text_embeds=text_embeds,
-                         text_mask=text_mask, cond_drop_prob=cond_drop_prob, ignore_time=ignore_time, cfg=False)
+                         text_mask=text_mask, cond_drop_prob=cond_drop_prob, ignore_time=ignore_time, cfg=False, cond_images=cond_images,
+                         cond_video_frames=cond_video_frames, post_cond_video_frames=post_cond_video_frames, self_cond=self_cond)
 
     @torch.no_grad()
     def _run(self, x, time, *, lowres_cond_img=None, lowres_noise_times=None, text_embeds=None, text_mask=None, cond_drop_prob=0.,
-             ignore_time=False, cfg=False):
+             ignore_time=False, cfg=False, cond_images=None, cond_video_frames=None, post_cond_video_frames=None, self_cond=None):
+        assert cond_images is None and self_cond is None, \
+            'cond_images / self_cond: Unet3D is built without cond_images_channels / self_cond in this build'
         assert x.ndim == 5, 'input to 3d unet must have 5 dimensions (batch, channels, time, height, width)'
         assert not (self.lowres_cond and lowres_cond_img is None), 'low resolution conditioning image must be present'
         assert not (self.lowres_cond and lowres_noise_times is None), 'low resolution conditioning noise time must be present'
@@ -294,7 +297,11 @@ class Unet3D(nn.Module):
             f'number of input frames {Fr} must be divisible by {self.total_temporal_divisor}'
         rows = 2 * B if cfg else B
         with_text = bool(self.cond_on_text and text_embeds is not None)
-        eng = self.engine(rows, B, Fr, H, x.device, with_text=with_text, ignore_time=ignore_time)
+        n_pre = 0 if cond_video_frames is None else cond_video_frames.shape[2]
+        n_post = 0 if post_cond_video_frames is None else post_cond_video_frames.shape[2]
+        eng = self.engine(rows, B, Fr, H, x.device, with_text=with_text, ignore_time=ignore_time, pre_frames=n_pre, post_frames=n_post)
+        if n_pre or n_post:
+            eng.set_cond_video_frames(cond_video_frames, post_cond_video_frames)
         if cfg:
             keep = torch.cat((torch.ones(B, dtype=torch.bool), torch.zeros(B, dtype=torch.bool)))
         elif cond_drop_prob == 0:

@@ -100,9 +100,11 @@ def elucidated_sample(unets: Sequence[tuple], image_sizes: Sequence[int], text_e
                       cond_scale=1.0, lowres_noise_schedule: str = "linear", lowres_sample_noise_level: float = 0.2,
                       dynamic_thresholding: bool = True, percentile: float = 0.95, channels: int = 3, text_masks: Optional[Tensor] = None,
                       noise_fn: Optional[Callable] = None, max_steps: Optional[int] = None, return_all: bool = False,
-                      video_frames: Optional[int] = None):
+                      video_frames: Optional[int] = None, cond_video_frames: Optional[Tensor] = None,
+                      post_cond_video_frames: Optional[Tensor] = None):
     """el.py:547-745.  `unets`: [(state_dict, ctor_kwargs), ...]; `hparams`: overrides of DEFAULT_HPARAMS (same for every stage).
-    video_frames: the unets are Unet3D state_dicts and every stage samples (b, c, video_frames, h, w) clips."""
+    video_frames: the unets are Unet3D state_dicts and every stage samples (b, c, video_frames, h, w) clips; the prompt frames
+    (el.py:679-695) are handed to every stage as they are (temporal_downsample_factor 1 only here)."""
     n = len(unets)
     hp = dict(DEFAULT_HPARAMS, **(hparams or {}))
     cond_scale = cond_scale if isinstance(cond_scale, (list, tuple)) else (cond_scale,) * n
@@ -126,9 +128,12 @@ def elucidated_sample(unets: Sequence[tuple], image_sizes: Sequence[int], text_e
 
         fwd = unet3d_forward_with_cond_scale if video_frames is not None else unet_forward_with_cond_scale
 
+        video_kw = {k: v for k, v in (("cond_video_frames", cond_video_frames), ("post_cond_video_frames", post_cond_video_frames))
+                    if v is not None and video_frames is not None}
+
         def net(x, c_noise, _sd=sd, _kw=kw, _cs=cs, _li=lowres_img, _lt=lowres_times):
             return fwd(_sd, _kw, x, c_noise, cond_scale=_cs, text_embeds=text_embeds, text_mask=text_masks, lowres_cond_img=_li,
-                       lowres_noise_times=_lt)
+                       lowres_noise_times=_lt, **video_kw)
 
         shape = (b, channels, video_frames, size, size) if video_frames is not None else (b, channels, size, size)
         img = one_unet_sample(net, shape, hp, noise_fn=noise_fn, stage=stage, dynamic_threshold=dynamic_thresholding,

@@ -325,6 +325,20 @@ def make_video_options_fixture(ip, iv, path, T=2, R=2, frames=4):
     outs, draws = _record_draws(lambda: imagen2.sample(**common, cond_video_frames=pre4))
     runs["cond_pre_tds"] = dict(kwargs=dict(cond_video_frames=pre4), temporal_downsample_factor=(2, 1), noise=plain_tags(draws),
                                 outputs=[o.clone() for o in outs])
+    # prompt frames under the Karras et al. sampler (el.py:679-695), hyper-parameters of sample_tiny_video.pt's EDM run
+    el = load_reference("elucidated_imagen")
+    hp = base["edm"]["hparams"]
+    edm_model = el.ElucidatedImagen(tuple(imagen.unets), image_sizes=base["image_sizes"], text_embed_dim=32, cond_drop_prob=0.1, **hp).eval()
+    outs, draws = _record_draws(lambda: edm_model.sample(**common, cond_video_frames=pre))
+    noise, it = {}, iter(draws)
+    for stage in range(2):
+        if stage > 0:
+            noise[("lowres", stage)] = next(it)
+        noise[("init", stage)] = next(it)
+        for i in range(hp["num_sample_steps"]):
+            noise[("step", stage, i)] = next(it)
+    assert next(it, None) is None
+    runs["edm_cond_pre"] = dict(kwargs=dict(cond_video_frames=pre), hparams=hp, noise=noise, outputs=[o.clone() for o in outs])
     torch.save(dict(weights_from="sample_tiny_video.pt", timesteps=T, frames=frames, runs=runs, generator="oracle/make_golden.py --video-options",
                     reference="lucidrains/imagen-pytorch v2.0.0 Imagen.sample over Unet3D stages with cond_video_frames / "
                               "post_cond_video_frames / init_images + skip_steps / inpaint_videos (ip.py:2167-2498, imagen_video.py:1682-1718)"), path)

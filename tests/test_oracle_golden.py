@@ -185,6 +185,23 @@ def test_video_elucidated_oracle_matches_reference_fixture():
     assert (outs[1] - e["outputs"][1]).abs().mean() < 5e-5
 
 
+def test_video_elucidated_oracle_prompt_frames_match_reference_fixture():
+    """ElucidatedImagen.sample over the Unet3D stages with cond_video_frames vs the recorded reference run (tolerances of the plain
+    EDM video test above: fp32 round-off through the sigma_max = 80 loop)."""
+    from oracle import elucidated_oracle as eo
+
+    o = _load("sample_tiny_video_options.pt")
+    g = _load(o["weights_from"])
+    run = o["runs"]["edm_cond_pre"]
+    unets = [(u["state_dict"], u["kwargs"]) for u in g["unets"]]
+    with torch.no_grad():
+        outs = eo.elucidated_sample(unets, g["image_sizes"], g["text_embeds"], hparams=run["hparams"], cond_scale=g["cond_scale"],
+                                    noise_fn=lambda tag, shape: run["noise"][tag], return_all=True, video_frames=o["frames"], **run["kwargs"])
+    assert torch.allclose(outs[0], run["outputs"][0], atol=1e-3), (outs[0] - run["outputs"][0]).abs().max()
+    assert torch.allclose(outs[1], run["outputs"][1], atol=5e-3), (outs[1] - run["outputs"][1]).abs().max()
+    assert (outs[1] - run["outputs"][1]).abs().mean() < 5e-5
+
+
 VIDEO_OPTION_RUNS = ["cond_pre", "cond_post", "cond_both", "init_skip", "inpaint", "cond_pre_tds"]
 
 

@@ -94,6 +94,34 @@ def test_unet3d_forward_readme_config():
             assert torch.allclose(r, o, atol=1e-4, rtol=1e-4), (r - o).abs().max()
 
 
+@pytest.mark.parametrize("lowres", [False, True], ids=["base", "lowres"])
+@pytest.mark.parametrize("prompts", ["pre", "post", "both"])
+def test_unet3d_forward_with_prompt_frames(lowres, prompts):
+    """Unet3D.forward(cond_video_frames=, post_cond_video_frames=) of the live reference vs the oracle's restatement (iv.py:1682-1718,
+    1933-1939), including the reference's frame order for succeeding frames and the low-res clip it extends for final_conv."""
+    from oracle import unet3d_oracle as u3
+    from oracle.make_golden import TINY_3D, derandomise_unet3d
+
+    iv = ref_shim.load_reference("imagen_video")
+    kw = {**TINY_3D, "lowres_cond": lowres}
+    torch.manual_seed(3)
+    u = iv.Unet3D(**kw).eval()
+    derandomise_unet3d(u)
+    B, Fr, S = 2, 4, 16
+    x, t, te = torch.randn(B, 3, Fr, S, S), torch.tensor([0.3, -1.1]), torch.randn(B, 9, 32)
+    size = S if lowres else S // 2
+    pre = torch.rand(B, 3, 2, size, size) if prompts in ("pre", "both") else None
+    post = torch.rand(B, 3, 4, size, size) if prompts in ("post", "both") else None
+    extra = dict(lowres_cond_img=torch.randn(B, 3, Fr, S, S), lowres_noise_times=torch.tensor([0.9, 0.9])) if lowres else {}
+    with torch.no_grad():
+        for cdp in (0.0, 1.0):
+            r = u(x, t, text_embeds=te, cond_drop_prob=cdp, cond_video_frames=pre, post_cond_video_frames=post, **extra)
+            o = u3.unet3d_forward(u.state_dict(), kw, x, t, text_embeds=te, cond_drop_prob=cdp, cond_video_frames=pre,
+                                  post_cond_video_frames=post, **extra)
+            assert r.shape == x.shape and r.abs().mean() > 0.05
+            assert torch.allclose(r, o, atol=1e-4, rtol=1e-4), (r - o).abs().max()
+
+
 def _sweep_inputs(kw, seed=5):
     torch.manual_seed(seed)
     B, S = 2, 16

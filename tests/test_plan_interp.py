@@ -98,6 +98,50 @@ def test_unet3d_plan_on_cpu_matches_reference_fixture(tag, mode, reference_weigh
         assert e_null < 5e-3, e_null
 
 
+@pytest.mark.parametrize("tag", ["base", "sr"])
+@pytest.mark.parametrize("prompts", ["pre", "post", "both"])
+def test_unet3d_plan_with_prompt_frames_vs_oracle(tag, prompts, reference_weights):
+    """Unet3D.forward(cond_video_frames=, post_cond_video_frames=) (iv.py:1682-1718, 1933-1939): the planner's static prompt slots,
+    the per-step frame placement, the final conv's own low-res frame order and the output cut, executed by the interpreter, against
+    the oracle (itself pinned to recorded runs of the live reference with these arguments)."""
+    from imagen_pytorch_amd import Unet3D
+    from imagen_pytorch_amd.engine3d import UnetEngine3D
+    from oracle import unet3d_oracle as u3
+    from plan_interp import Interpreter
+
+    g = torch.load(os.path.join(GOLDEN, "unet3d_tiny.pt"), weights_only=False)["runs"][tag]
+    u = Unet3D(**g["kwargs"]).eval()
+    u.load_state_dict(g["state_dict"])
+    B, _, Fr, S, _ = g["x"].shape
+    gen = torch.Generator().manual_seed(5)
+    size = S if tag == "sr" else S // 2                   # the base unet resizes its prompt frames, the low-res one needs them at its size
+    pre = torch.rand(B, 3, 2, size, size, generator=gen) if prompts in ("pre", "both") else None
+    post = torch.rand(B, 3, 4, size, size, generator=gen) if prompts in ("post", "both") else None
+    rows = 2 * B
+    eng = UnetEngine3D(u, rows, B, Fr, S, "cpu", dry=True, pre_frames=0 if pre is None else 2, post_frames=0 if post is None else 4)
+    keep = torch.ones(rows, dtype=torch.bool)
+    keep[B:] = False
+    eng.set_conditioning(text_embeds=g["text_embeds"], text_mask=g["text_mask"], keep=keep, lowres_noise_times=g["extra"].get("lowres_noise_times"))
+    eng.set_cond_video_frames(pre, post)
+    it = Interpreter()
+    for t in (eng.x_in, eng.lowres_in, eng.times, eng.lowres_times, eng.out, eng.out_full, eng.keep_u8, eng.src_idx, eng.arange_idx, eng.t_const.t):
+        it.mem.register(t)
+    it.run(eng._static_plans[g["text_embeds"].shape[1]][0])
+    fm = lambda t: t.permute(0, 2, 1, 3, 4).contiguous()
+    eng.x_in.copy_(fm(g["x"]))
+    if eng.lowres:
+        eng.lowres_in.copy_(fm(g["extra"]["lowres_cond_img"]))
+    eng.times.copy_(g["time"].repeat(rows // B))
+    it.run(eng.step_plan)
+    out = fm(eng.out)
+    kw = dict(text_embeds=g["text_embeds"], text_mask=g["text_mask"], cond_video_frames=pre, post_cond_video_frames=post, **g["extra"])
+    with torch.no_grad():
+        ref = u3.unet3d_forward(g["state_dict"], g["kwargs"], g["x"], g["time"], **kw)
+        ref_null = u3.unet3d_forward(g["state_dict"], g["kwargs"], g["x"], g["time"], cond_drop_prob=1.0, **kw)
+    assert out.shape[2] == Fr and tuple(ref.shape) == tuple(out[:B].shape)
+    assert nerr(out[:B], ref) < 5e-3 and nerr(out[B:], ref_null) < 5e-3, (nerr(out[:B], ref), nerr(out[B:], ref_null))
+
+
 def test_unet3d_plan_readme_structure_vs_oracle(reference_weights):
     """The README video config's structure (`Unet3D(dim = ..., dim_mults = (1, 2, 4, 8))`, README.md:587; dim 16 here) with temporal
     strides on two levels, a transformer block on the last level and memory_efficient off: planner + interpreter vs the fp32 oracle on

@@ -154,6 +154,24 @@ def test_video_sample_driver(cpu_backend, tds):
     assert max(errs) < 2e-2, errs
 
 
+@pytest.mark.parametrize("tag", ["cond_pre", "cond_post", "cond_both", "init_skip", "inpaint", "cond_pre_tds"])
+def test_video_sample_options_driver(cpu_backend, tag):
+    """Video-stage options of sample() — prompt frames (cond_video_frames / post_cond_video_frames), init videos + skip_steps, video
+    inpainting — through the real driver and the planner's strided frame copies, against recorded runs of the live reference."""
+    o = torch.load(os.path.join(GOLDEN, "sample_tiny_video_options.pt"), weights_only=False)
+    g = torch.load(os.path.join(GOLDEN, o["weights_from"]), weights_only=False)
+    run = o["runs"][tag]
+    imagen = _cascade(g, timesteps=o["timesteps"], temporal_downsample_factor=run.get("temporal_downsample_factor", 1))
+    outs = imagen.sample(text_embeds=g["text_embeds"], video_frames=o["frames"], cond_scale=g["cond_scale"], use_tqdm=False,
+                         return_all_unet_outputs=True, noise_fn=lambda t, shape: run["noise"][t], device="cpu", **run["kwargs"])
+    assert [tuple(x.shape) for x in outs] == [tuple(x.shape) for x in run["outputs"]]
+    errs = [nerr(a, ref) for a, ref in zip(outs, run["outputs"])]
+    assert max(errs) < 2e-2, errs
+    if tag == "inpaint":
+        m = run["kwargs"]["inpaint_masks"][:, None].expand(-1, 3, -1, -1, -1)
+        assert torch.allclose(outs[-1][m], run["kwargs"]["inpaint_videos"][m], atol=1e-6)
+
+
 def test_elucidated_sample_driver(cpu_backend):
     from imagen_pytorch_amd import ElucidatedImagen
 
@@ -211,6 +229,24 @@ def test_video_elucidated_sample_driver(cpu_backend):
     alone = model.sample(text_embeds=g["text_embeds"], video_frames=g["frames"], cond_scale=g["cond_scale"], use_tqdm=False, noise_fn=nf,
                          start_at_unet_number=2, start_image_or_video=e["outputs"][0], device="cpu")
     e1 = nerr(alone, e["outputs"][1])
+    assert e0 < 3e-2 and e1 < 3e-2, (e0, e1)
+
+
+def test_video_elucidated_prompt_frames_driver(cpu_backend):
+    """ElucidatedImagen over Unet3D stages with cond_video_frames (el.py:679-695) vs a recorded run of the live reference."""
+    from imagen_pytorch_amd import ElucidatedImagen
+
+    o = torch.load(os.path.join(GOLDEN, "sample_tiny_video_options.pt"), weights_only=False)
+    g = torch.load(os.path.join(GOLDEN, o["weights_from"]), weights_only=False)
+    run = o["runs"]["edm_cond_pre"]
+    model = _cascade(g, klass=ElucidatedImagen, **run["hparams"])
+    nf = lambda tag, shape: run["noise"][tag]
+    common = dict(text_embeds=g["text_embeds"], video_frames=o["frames"], cond_scale=g["cond_scale"], use_tqdm=False, noise_fn=nf,
+                  device="cpu", **run["kwargs"])
+    outs = model.sample(return_all_unet_outputs=True, **common)
+    e0 = nerr(outs[0], run["outputs"][0])
+    alone = model.sample(start_at_unet_number=2, start_image_or_video=run["outputs"][0], **common)
+    e1 = nerr(alone, run["outputs"][1])
     assert e0 < 3e-2 and e1 < 3e-2, (e0, e1)
 
 

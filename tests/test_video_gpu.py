@@ -182,3 +182,34 @@ def test_video_elucidated_sample_vs_reference_fixture():
     e1 = nerr(alone, e["outputs"][1])
     print(f"video EDM vs reference: stage1 {e0:.2e}, stage 2 alone {e1:.2e}")
     assert e0 < 3e-2 and e1 < 3e-2
+
+
+@pytest.mark.parametrize("tag", ["cond_both", "cond_pre_tds", "init_skip", "inpaint"])
+def test_video_sample_options_vs_reference_fixture(tag):
+    """Video-stage options of Imagen.sample on the GPU — prompt frames before and after the clip (static slots of the packed input clip,
+    per-step frame placement, final conv's own low-res frame order, output cut), prompt frames under a per-stage frame rate, init videos +
+    skip_steps, video inpainting — vs recorded runs of the live reference (same draws); graph == eager."""
+    from imagen_pytorch_amd import Imagen, Unet3D
+
+    dev = torch.device("cuda:0")
+    o = torch.load(os.path.join(GOLDEN, "sample_tiny_video_options.pt"), weights_only=False)
+    g = torch.load(os.path.join(GOLDEN, o["weights_from"]), weights_only=False)
+    run = o["runs"][tag]
+    unets = [Unet3D(**spec["kwargs"]).eval() for spec in g["unets"]]
+    imagen = Imagen(unets, image_sizes=g["image_sizes"], timesteps=o["timesteps"], text_embed_dim=32, cond_drop_prob=0.1,
+                    temporal_downsample_factor=run.get("temporal_downsample_factor", 1)).to(dev)
+    for u, spec in zip(imagen.unets, g["unets"]):
+        u.load_state_dict(spec["state_dict"])
+    kw = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in run["kwargs"].items()}
+    res = {}
+    for use_graph in (False, True):
+        outs = imagen.sample(text_embeds=g["text_embeds"].to(dev), video_frames=o["frames"], cond_scale=g["cond_scale"], use_tqdm=False,
+                             return_all_unet_outputs=True, noise_fn=lambda t, shape: run["noise"][t].to(dev), use_graph=use_graph, **kw)
+        errs = [nerr(a, r) for a, r in zip(outs, run["outputs"])]
+        print("video options", tag, "graph" if use_graph else "eager", errs)
+        assert all(a.shape == r.shape for a, r in zip(outs, run["outputs"])) and max(errs) < 2e-2
+        res[use_graph] = outs
+    assert all(torch.equal(a, b) for a, b in zip(res[False], res[True]))
+    if tag == "inpaint":
+        m = run["kwargs"]["inpaint_masks"][:, None].expand(-1, 3, -1, -1, -1)
+        assert torch.allclose(res[True][-1].cpu()[m], run["kwargs"]["inpaint_videos"][m], atol=1e-6)
