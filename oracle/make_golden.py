@@ -259,6 +259,69 @@ def make_video_sample_fixture(ip, iv, path, seed=23, T=2, frames=4):
     print(f"wrote {path}: outputs {[tuple(o.shape) for o in outs]}, std {outs[-1].std():.4f}, {len(draws)} draws")
 
 
+def make_elucidated_options_fixture(ip, el, path, R=2, skip=1):
+    """one_unet_sample options of the Karras et al. sampler (el.py:393-545) on the weights of sample_tiny_elucidated.pt (only inputs,
+    draws and outputs are stored): (A) init_images + skip_steps, (B) inpainting with `inpaint_resample_times = R`, (C) per-call
+    sigma_min / sigma_max overrides."""
+    base = torch.load(os.path.join(GOLDEN, "sample_tiny_elucidated.pt"), weights_only=False)
+    hp = base["hparams"]
+    T = hp["num_sample_steps"]
+    unets = []
+    for spec in base["unets"]:
+        u = ip.Unet(**spec["kwargs"])
+        u.load_state_dict(spec["state_dict"])
+        unets.append(u)
+    model = el.ElucidatedImagen(tuple(unets), image_sizes=base["image_sizes"], text_embed_dim=32, cond_drop_prob=0.1, **hp).eval()
+    for u, spec in zip(model.unets, base["unets"]):
+        u.load_state_dict(spec["state_dict"])
+    g = torch.Generator().manual_seed(37)
+    S0, S1 = base["image_sizes"]
+    init_images = torch.rand(2, 3, S0, S0, generator=g)
+    inpaint_images = torch.rand(2, 3, S1, S1, generator=g)
+    inpaint_masks = torch.rand(2, S1, S1, generator=g) > 0.5
+    inpaint_masks[:, 8:20, 4:24] = True
+    common = dict(text_embeds=base["text_embeds"], cond_scale=base["cond_scale"], use_tqdm=False, return_all_unet_outputs=True)
+    torch.manual_seed(41)
+    runs = {}
+
+    def plain_tags(draws, first=0):
+        noise, it = {}, iter(draws)
+        for stage in range(2):
+            if stage > 0:
+                noise[("lowres", stage)] = next(it)
+            noise[("init", stage)] = next(it)
+            for i in range(first, T):
+                noise[("step", stage, i)] = next(it)
+        assert next(it, None) is None
+        return noise
+
+    kw = dict(init_images=init_images, skip_steps=skip)
+    outs, draws = _record_draws(lambda: model.sample(**common, **kw))
+    runs["init_skip"] = dict(kwargs=kw, noise=plain_tags(draws, first=skip), outputs=[o.clone() for o in outs])
+    kw = dict(inpaint_images=inpaint_images, inpaint_masks=inpaint_masks, inpaint_resample_times=R)
+    outs, draws = _record_draws(lambda: model.sample(**common, **kw))
+    noise, it = {}, iter(draws)
+    for stage in range(2):
+        if stage > 0:
+            noise[("lowres", stage)] = next(it)
+        noise[("init", stage)] = next(it)
+        for i in range(T):
+            for r in reversed(range(R)):
+                noise[("step", stage, i, r)] = next(it)
+                if r > 0 and i < T - 1:
+                    noise[("renoise", stage, i, r)] = next(it)
+    assert next(it, None) is None
+    runs["inpaint"] = dict(kwargs=kw, noise=noise, outputs=[o.clone() for o in outs])
+    kw = dict(sigma_min=(0.01, 0.004), sigma_max=(40., 60.))
+    outs, draws = _record_draws(lambda: model.sample(**common, **kw))
+    runs["sigma"] = dict(kwargs=kw, noise=plain_tags(draws), outputs=[o.clone() for o in outs])
+    torch.save(dict(weights_from="sample_tiny_elucidated.pt", runs=runs, generator="oracle/make_golden.py --elucidated-options",
+                    reference="lucidrains/imagen-pytorch v2.0.0 ElucidatedImagen.sample with init_images / skip_steps / inpainting / "
+                              "sigma overrides (elucidated_imagen.py:393-545, 547-745)"), path)
+    for k, r in runs.items():
+        print(f"wrote {path} [{k}]: out std {r['outputs'][-1].std():.4f}, {len(r['noise'])} draws")
+
+
 def make_video_options_fixture(ip, iv, path, T=2, R=2, frames=4):
     """Video-stage options of Imagen.sample on the two Unet3D stages of sample_tiny_video.pt (same weights — only inputs, draws and
     outputs are stored here): prompt frames (`cond_video_frames`, `post_cond_video_frames`, both; iv.py:1682-1718, 1933-1939,
@@ -466,6 +529,9 @@ def main():
         return
     if "--video-options" in sys.argv:   # only the video-stage options fixture (weights are those of sample_tiny_video.pt)
         make_video_options_fixture(ip, load_reference("imagen_video"), os.path.join(GOLDEN, "sample_tiny_video_options.pt"))
+        return
+    if "--elucidated-options" in sys.argv:   # only the EDM sampler-options fixture (weights are those of sample_tiny_elucidated.pt)
+        make_elucidated_options_fixture(ip, load_reference("elucidated_imagen"), os.path.join(GOLDEN, "sample_tiny_elucidated_options.pt"))
         return
     if "--unet3d" in sys.argv:       # only the Imagen-Video denoiser fixture (SURVEY §8(f) NEXT-2 groundwork)
         make_unet3d_fixture(load_reference("imagen_video"), os.path.join(GOLDEN, "unet3d_tiny.pt"))

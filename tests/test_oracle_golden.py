@@ -185,6 +185,25 @@ def test_video_elucidated_oracle_matches_reference_fixture():
     assert (outs[1] - e["outputs"][1]).abs().mean() < 5e-5
 
 
+@pytest.mark.parametrize("tag", ["init_skip", "inpaint", "sigma"])
+def test_elucidated_oracle_options_match_reference_fixture(tag):
+    """one_unet_sample options of the Karras et al. sampler (init_images + skip_steps, inpainting with resampling, per-call sigma
+    overrides; el.py:393-545) vs recorded runs of the live reference on the weights of sample_tiny_elucidated.pt."""
+    from oracle import elucidated_oracle as eo
+
+    o = _load("sample_tiny_elucidated_options.pt")
+    g = _load(o["weights_from"])
+    run = o["runs"][tag]
+    unets = [(u["state_dict"], u["kwargs"]) for u in g["unets"]]
+    with torch.no_grad():
+        outs = eo.elucidated_sample(unets, g["image_sizes"], g["text_embeds"], hparams=g["hparams"], cond_scale=g["cond_scale"],
+                                    noise_fn=lambda t, shape: run["noise"][t], return_all=True, **run["kwargs"])
+    # tolerances of the plain EDM test above (fp32 round-off through the sigma_max = 80 loop)
+    assert torch.allclose(outs[0], run["outputs"][0], atol=1e-3), (outs[0] - run["outputs"][0]).abs().max()
+    assert torch.allclose(outs[1], run["outputs"][1], atol=5e-3), (outs[1] - run["outputs"][1]).abs().max()
+    assert (outs[1] - run["outputs"][1]).abs().mean() < 1e-4
+
+
 def test_video_elucidated_oracle_prompt_frames_match_reference_fixture():
     """ElucidatedImagen.sample over the Unet3D stages with cond_video_frames vs the recorded reference run (tolerances of the plain
     EDM video test above: fp32 round-off through the sigma_max = 80 loop)."""
