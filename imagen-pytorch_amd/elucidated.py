@@ -9,8 +9,12 @@ scalars (c_skip, c_out, c_in, c_noise, step weights) live in device tables index
 patching.  Preconditioning is expressed through the existing CFG_X0 "noise" form: c_skip*x + c_out*F = (x - sigma'*F) / alpha'
 with alpha' = 1/c_skip, sigma' = -c_out/c_skip.
 
-Training (`forward`), T5 text encoding, video, inpainting, init_images / skip_steps and per-call sigma_min / sigma_max overrides are
-outside the hot-path scope and raise.
+The one_unet_sample options ride on the same tables: `skip_steps` moves the counter's start row, `init_images` is one add on the
+initial noise, per-call `sigma_min` / `sigma_max` select another table set, and inpainting (RePaint resampling, el.py:459-470, 486-545)
+repeats every timestep's rows `inpaint_resample_times` times with two extra LINCOMB launches in the same captured sequence — the known
+pixels blended into x before the churn noise (x_hat = where(mask, known, x) + noise, el.py:497-498) and x += (sigma - sigma_next) * z
+after the Heun combination, with identity weights on the rows where the reference skips it.  Video stages (Unet3D, prompt frames)
+as in `Imagen`.  Training (`forward`) and self-conditioning unets raise.
 """
 from __future__ import annotations
 
@@ -87,16 +91,27 @@ class ElucidatedImagen(Imagen):
         sigmas = (sigma_max ** inv_rho + steps / (N - 1) * (sigma_min ** inv_rho - sigma_max ** inv_rho)) ** rho
         return torch.nn.functional.pad(sigmas, (0, 1), value=0.)
 
-    def _tables(self, hp: Hparams):
-        """Per-evaluation device tables (row 2i: first evaluation of step i at sigma_hat, row 2i+1: second at sigma_next), fp32
-        [2N, 8] each: `coef` (CFG_X0 / time embedding: 1/c_skip, -c_out/c_skip, ..., col 6 = c_noise), `w_hat` (x_hat op),
-        `w_euler`, `w_heun` (LINCOMB weights w0..w5)."""
+    @staticmethod
+    def _row(i: int, r: int, N: int, R: int) -> int:
+        """First table row of inner iteration (timestep i, resample r = R-1..0): two rows per iteration (the evaluations at sigma_hat
+        and sigma_next) up to the last timestep, whose iterations have no second evaluation and take one row each."""
+        k = R - 1 - r
+        return 2 * (i * R + k) if i < N - 1 else 2 * (N - 1) * R + k
+
+    def _tables(self, hp: Hparams, R: int = 1):
+        """Per-evaluation device tables, fp32 [rows, 8] each: `coef` (CFG_X0 / time embedding: 1/c_skip, -c_out/c_skip, ..., col 6 =
+        c_noise), `w_hat` (x_hat op), `w_euler`, `w_heun`, `w_renoise` (LINCOMB weights w0..w5).  Row layout: `_row` — every timestep
+        is repeated R times (inpainting with resampling, el.py:486-535; R = 1 otherwise: row 2i / 2i+1 = first / second evaluation of
+        step i).  `w_renoise` is read right after the Euler op's advance (second row of an iteration): x += (sigma - sigma_next) * z
+        unless r == 0, the identity there."""
         sigmas = self.sample_schedule(hp.num_sample_steps, hp.rho, hp.sigma_min, hp.sigma_max)
         gammas = torch.where((sigmas >= hp.S_tmin) & (sigmas <= hp.S_tmax), min(hp.S_churn / hp.num_sample_steps, math.sqrt(2) - 1), 0.)
         N = hp.num_sample_steps
         sd = hp.sigma_data
-        coef = torch.zeros(2 * N, 8, dtype=torch.float64)
-        w_hat, w_euler, w_heun = (torch.zeros(2 * N, 8, dtype=torch.float64) for _ in range(3))
+        rows = 2 * (N - 1) * R + 2 * R
+        coef = torch.zeros(rows, 8, dtype=torch.float64)
+        w_hat, w_euler, w_heun, w_renoise = (torch.zeros(rows, 8, dtype=torch.float64) for _ in range(4))
+        w_renoise[:, 0] = 1.0
 
         def precond(row, sigma):   # el.py:323-336
             c_skip = sd ** 2 / (sigma ** 2 + sd ** 2)
@@ -106,19 +121,23 @@ class ElucidatedImagen(Imagen):
         for i in range(N):
             sigma, sigma_next, gamma = sigmas[i].item(), sigmas[i + 1].item(), gammas[i].item()
             sigma_hat = sigma + gamma * sigma
-            precond(2 * i, sigma_hat)
-            w_hat[2 * i, 0] = 1.0
-            w_hat[2 * i, 4] = math.sqrt(sigma_hat ** 2 - sigma ** 2) * hp.S_noise          # el.py:489-492
-            w_hat[2 * i, 5] = (sigma_hat ** 2 + sd ** 2) ** -0.5                              # c_in(sigma_hat)
-            r = sigma_next / sigma_hat
-            w_euler[2 * i, 0], w_euler[2 * i, 1] = r, 1.0 - r                                 # x_hat + (s_n - s_h)(x_hat - x0)/s_h
-            if sigma_next != 0:
-                precond(2 * i + 1, sigma_next)
-                w_euler[2 * i, 5] = (sigma_next ** 2 + sd ** 2) ** -0.5                       # c_in(sigma_next)
-                d = 0.5 * (sigma_next - sigma_hat)
-                w_heun[2 * i + 1, 0], w_heun[2 * i + 1, 1] = 1.0 + d / sigma_hat, -d / sigma_hat
-                w_heun[2 * i + 1, 2], w_heun[2 * i + 1, 3] = d / sigma_next, -d / sigma_next  # el.py:528-529
-        return sigmas[0].item(), [t.float().contiguous() for t in (coef, w_hat, w_euler, w_heun)]
+            for rs in range(R):
+                e = self._row(i, rs, N, R)
+                precond(e, sigma_hat)
+                w_hat[e, 0] = 1.0
+                w_hat[e, 4] = math.sqrt(sigma_hat ** 2 - sigma ** 2) * hp.S_noise          # el.py:489-492
+                w_hat[e, 5] = (sigma_hat ** 2 + sd ** 2) ** -0.5                              # c_in(sigma_hat)
+                ratio = sigma_next / sigma_hat
+                w_euler[e, 0], w_euler[e, 1] = ratio, 1.0 - ratio                             # x_hat + (s_n - s_h)(x_hat - x0)/s_h
+                if sigma_next != 0:
+                    precond(e + 1, sigma_next)
+                    w_euler[e, 5] = (sigma_next ** 2 + sd ** 2) ** -0.5                       # c_in(sigma_next)
+                    d = 0.5 * (sigma_next - sigma_hat)
+                    w_heun[e + 1, 0], w_heun[e + 1, 1] = 1.0 + d / sigma_hat, -d / sigma_hat
+                    w_heun[e + 1, 2], w_heun[e + 1, 3] = d / sigma_next, -d / sigma_next      # el.py:528-529
+                    if rs > 0:                                                                # el.py:532-535 (never at the last timestep)
+                        w_renoise[e + 1, 4] = sigma - sigma_next
+        return sigmas[0].item(), [t.float().contiguous() for t in (coef, w_hat, w_euler, w_heun, w_renoise)]
 
     # ---- per-stage plans --------------------------------------------------------------------------------------------------
     def _build_stage(self, idx: int, B: int, device, *, cond_scale: float, with_text: bool, inject_noise: bool, sample_offset: int,
@@ -129,9 +148,13 @@ class ElucidatedImagen(Imagen):
             _out_of_scope("ElucidatedImagen sampling with self-conditioning unets (el.py:496, 518)")
         S = self.image_sizes[idx]
         hp = self.hparams[idx]
+        over = getattr(self._tls, 'sigma_overrides', None)          # sample(sigma_min=, sigma_max=), el.py:425-426, 647-648
+        if over is not None:
+            hp = hp._replace(**{k: v[idx] for k, v in over.items() if v[idx] is not None})
         cfg = cond_scale != 1.
+        R = resample_times
         key = ("edm", idx, B, S, str(device), float(cond_scale), with_text, inject_noise, sample_offset, self.dynamic_thresholding[idx],
-               self.dynamic_thresholding_percentile, tuple(hp), frames, prompt_frames, self._lane)
+               self.dynamic_thresholding_percentile, tuple(hp), frames, prompt_frames, R, self._lane)
         st = self._stages.get(key)
         if st is not None and not st['eng'].stale():
             return st
@@ -147,11 +170,12 @@ class ElucidatedImagen(Imagen):
             eng = engine.UnetEngine(unet, rows, B, S, device, with_text=with_text)
         n = eng.x_in[0].numel()
         dev = device
-        init_sigma, (coef, w_hat, w_euler, w_heun) = self._tables(hp)
-        coef, w_hat, w_euler, w_heun = (t.to(dev) for t in (coef, w_hat, w_euler, w_heun))
+        init_sigma, (coef, w_hat, w_euler, w_heun, w_renoise) = self._tables(hp, max(R, 1))
+        coef, w_hat, w_euler, w_heun, w_renoise = (t.to(dev) for t in (coef, w_hat, w_euler, w_heun, w_renoise))
         if inject_noise:   # the churn noise comes in through t1 (weight col 1) instead of the in-kernel Philox stream (col 4)
-            w_hat[:, 1] = w_hat[:, 4]
-            w_hat[:, 4] = 0
+            for w in (w_hat, w_renoise):
+                w[:, 1] = w[:, 4]
+                w[:, 4] = 0
         step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
         seed_dev = torch.zeros(2, dtype=torch.int32, device=dev)
         eng.bind_step_counter(coef, step_ptr)
@@ -166,7 +190,17 @@ class ElucidatedImagen(Imagen):
         q = float(self.dynamic_thresholding_percentile)
         kw = dict(B=B, n_per_sample=n, stream_id=idx, sample_offset=sample_offset, seed_ptr=seed_dev)
 
+        w_one = torch.zeros(1, 8, device=dev)
+        w_one[0, 0] = 1.0
+        zero_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
+        extra = {}
+        if R:   # inpainting (el.py:459-470, 497-498): x_hat = where(mask, known, x) + added noise — the known pixels go into x first
+            extra = dict(known=torch.zeros_like(eng.x_in), mask=torch.zeros_like(eng.x_in),
+                         noise_renoise=mk() if inject_noise else None)
+
         def first_eval(plan):
+            if R:
+                ops.lincomb(plan, extra['known'], x, w_one, zero_ptr, mask=extra['mask'], mask_else=x, label="edm.inpaint.blend", **kw)
             ops.lincomb(plan, x, xhat, w_hat, step_ptr, t1=noise, out2=eng.x_in, label="edm.x_hat", **kw)
             plan.extend(eng.step_plan)
             ops.cfg_x0(plan, xhat, eng.out, coef, step_ptr, x0a, absx0, B=B, n_per_sample=n, cfg=cfg, cond_scale=float(cond_scale),
@@ -184,7 +218,10 @@ class ElucidatedImagen(Imagen):
         if dyn:
             ops.quantile(full, absx0, qb, scr_b, B=B, n=n, q=q)
         ops.lincomb(full, xhat, x, w_heun, step_ptr, t1=x0a, t2=xnext, t3=x0b, q1=qa if dyn else None, q3=qb if dyn else None,
-                    thr_mode=thr, advance=True, label="edm.heun", **kw)
+                    thr_mode=thr, advance=not R, label="edm.heun", **kw)
+        if R:   # RePaint re-noising before the next resample of the same timestep (identity weights where the reference skips it)
+            ops.lincomb(full, x, x, w_renoise, step_ptr, t1=extra['noise_renoise'], advance=True, label="edm.inpaint.renoise",
+                        **{**kw, "stream_id": idx | 0x200})
 
         last = Plan(f"edm-stage{idx}-last")       # sigma_next = 0: Euler step only, then clamp + unnormalise (el.py:515, 540-545)
         first_eval(last)
@@ -193,20 +230,23 @@ class ElucidatedImagen(Imagen):
 
         w_init = torch.zeros(1, 8, device=dev)
         w_init[0, 0] = init_sigma
-        zero_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
         st = dict(eng=eng, plan=full, last=last, graph=None, graph_last=None, coef=coef, step_ptr=step_ptr, seed_dev=seed_dev, noise=noise,
-                  final=final, T=hp.num_sample_steps, S=S, x=x, w_init=w_init, zero_ptr=zero_ptr, tables=(w_hat, w_euler, w_heun),
-                  video=video, frames=frames,
-                  bufs=(xhat, xnext, x0a, x0b, absx0, qa, qb, scr_a, scr_b))
+                  final=final, T=hp.num_sample_steps, S=S, x=x, w_init=w_init, zero_ptr=zero_ptr,
+                  tables=(w_hat, w_euler, w_heun, w_renoise, w_one), video=video, frames=frames, R=R,
+                  bufs=(xhat, xnext, x0a, x0b, absx0, qa, qb, scr_a, scr_b), **extra)
         self._stages[key] = st
         return st
 
     @torch.no_grad()
     def _run_stage(self, st, *, noise_fn: Optional[Callable], stage: int, seed: int, use_graph: bool = True, use_tqdm: bool = False,
                       max_steps: Optional[int] = None, trace: Optional[list] = None, init_images=None, skip_steps=None):
-        """el.py:393-545 for one stage (init_images / skip_steps are rejected by sample())."""
-        assert init_images is None and not skip_steps
-        eng, T, x = st['eng'], st['T'], st['x']
+        """el.py:393-545 for one stage: x = sigma_0 * randn (+ init_images), the Karras steps from `skip_steps` on (each run
+        `inpaint_resample_times` times when st is an inpainting stage), clamp + unnormalise (the last step's kernel) and the final
+        paste of the known pixels."""
+        eng, T, x, R = st['eng'], st['T'], st['x'], st['R']
+        skip = skip_steps or 0
+        assert 0 <= skip < T, 'skip_steps must leave at least one step'
+        inner = max(R, 1)
         stream = torch.cuda.current_stream()
         B = eng.src_batch
         n = x[0].numel()
@@ -224,16 +264,20 @@ class ElucidatedImagen(Imagen):
                 pl = Plan("edm-init-noise")
                 ops.randn(pl, x, seed=seed, stream_id=stage, tag=TAG_INIT, sample_offset=st.get('sample_offset', 0))
                 pl.run()
-            pl = Plan("edm-init-scale")                      # images = init_sigma * randn (el.py:440-442)
+            pl = Plan("edm-init-scale")                      # images = init_sigma * randn (el.py:440-442; sigma_0 also when steps are skipped)
             ops.lincomb(pl, x, x, st['w_init'], st['zero_ptr'], B=B, n_per_sample=n)
             pl.run()
-            st['step_ptr'].zero_()
+            if init_images is not None:
+                x.add_(init_images)                          # el.py:446-447
+            st['step_ptr'].fill_(self._row(skip, inner - 1, T, inner))   # el.py:477-479: the skipped steps are never run
 
         st['seed_dev'].copy_(torch.tensor([seed & 0x7FFFFFFF, (seed >> 31) & 0x7FFFFFFF], dtype=torch.int32))
-        steps = T if max_steps is None else min(T, max_steps)
+        steps = T - skip if max_steps is None else min(T - skip, max_steps)
         if use_graph and st['graph'] is None:
             if noise_fn is not None:
                 st['noise'].zero_()
+                if R:
+                    st['noise_renoise'].zero_()
             init_state()
             st['plan'].run()                                 # warm-up outside capture (kernel attributes), then rewind
             st['last'].run()
@@ -241,19 +285,26 @@ class ElucidatedImagen(Imagen):
             st['graph'] = ops.Graph(st['plan'], stream)
             st['graph_last'] = ops.Graph(st['last'], stream)
         init_state()
-        for i in range(steps):
-            if noise_fn is not None:
-                st['noise'].copy_(draw(("step", stage, i), st['noise']))
+        for i in range(skip, skip + steps):
             is_last = i == T - 1
-            if use_graph:
-                (st['graph_last'] if is_last else st['graph']).launch()
-            else:
-                (st['last'] if is_last else st['plan']).run()
-            if trace is not None:
-                trace.append(x.clone())
-        if steps == T:
-            return st['final']
-        return (x.clamp(-1., 1.) + 1) * 0.5                   # truncated loop (tests)
+            for r in reversed(range(inner)):
+                if noise_fn is not None:
+                    st['noise'].copy_(draw(("step", stage, i, r) if R else ("step", stage, i), st['noise']))
+                    if R and r > 0 and not is_last:           # the reference draws no re-noising sample otherwise (el.py:532)
+                        st['noise_renoise'].copy_(draw(("renoise", stage, i, r), st['noise']))
+                if use_graph:
+                    (st['graph_last'] if is_last else st['graph']).launch()
+                else:
+                    (st['last'] if is_last else st['plan']).run()
+                if trace is not None:
+                    trace.append(x.clone())
+        if skip + steps == T:
+            out = st['final']
+        else:
+            out = (x.clamp(-1., 1.) + 1) * 0.5                # truncated loop (tests)
+        if R:
+            out = torch.where(st['mask'] != 0, (st['known'] + 1) * 0.5, out)   # el.py:542-545
+        return out
 
     # ---- public sampling API (el.py:547-745) ---------------------------------------------------------------------------------
     @torch.no_grad()
@@ -293,14 +344,12 @@ class ElucidatedImagen(Imagen):
         max_steps: Optional[int] = None,
         conditioning=None,
     ):
-        if sigma_min is not None or sigma_max is not None:
-            _out_of_scope("sample(sigma_min=/sigma_max=) per-call overrides (set them on the constructor)")
-        if inpaint_images is not None or inpaint_videos is not None or inpaint_masks is not None or skip_steps is not None or any(
-                i is not None for i in _cast_tuple(init_images)):
-            _out_of_scope("ElucidatedImagen.sample(inpaint_images= / init_images= / skip_steps=) (el.py:446-452, 497-533)")
         with self._eval_mode():
             try:
                 self._tls.conditioning = conditioning
+                n_unets = len(self.unets)
+                self._tls.sigma_overrides = None if sigma_min is None and sigma_max is None else dict(
+                    sigma_min=_cast_tuple(sigma_min, n_unets), sigma_max=_cast_tuple(sigma_max, n_unets))
                 if conditioning is not None:
                     assert texts is None and text_embeds is None and text_masks is None, 'pass either `conditioning` or texts / text_embeds'
                     text_embeds, text_masks = conditioning.text_embeds, conditioning.text_masks
@@ -313,3 +362,4 @@ class ElucidatedImagen(Imagen):
                                     max_steps)
             finally:
                 self._tls.conditioning = None
+                self._tls.sigma_overrides = None

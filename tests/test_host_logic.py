@@ -241,9 +241,27 @@ def test_elucidated_step_tables_match_oracle():
              layer_cross_attns=(False, True), attn_heads=2, max_text_len=16, attn_pool_num_latents=8)
     hp = dict(eo.DEFAULT_HPARAMS, num_sample_steps=7)
     m = ElucidatedImagen((u,), image_sizes=(16,), text_embed_dim=32, **{k: v for k, v in hp.items()})
-    init_sigma, (coef, w_hat, w_euler, w_heun) = m._tables(m.hparams[0])
+    init_sigma, (coef, w_hat, w_euler, w_heun, w_renoise) = m._tables(m.hparams[0])
     table, init_ref = eo.step_table(hp)
     assert init_sigma == init_ref and coef.shape == (14, 8)
+    assert torch.equal(w_renoise[:, 0], torch.ones(14)) and not w_renoise[:, 1:].any()      # no resampling: the identity everywhere
+    # inpainting with R = 3 resamples: every timestep's rows repeated (two per inner iteration, one at the last timestep), the
+    # re-noising weight sigma - sigma_next on the second row of every iteration but the last resample (el.py:532-535)
+    R, N = 3, 7
+    _, (coef3, w_hat3, w_euler3, w_heun3, w_ren3) = m._tables(m.hparams[0], R)
+    assert coef3.shape == (2 * (N - 1) * R + 2 * R, 8)        # R single rows for the last timestep + R spare (row count 2N at R = 1)
+    for i, (sigma, sigma_next, gamma) in enumerate(table):
+        for r in range(R):
+            e = m._row(i, r, N, R)
+            assert torch.equal(coef3[e], coef[2 * i]) and torch.equal(w_hat3[e], w_hat[2 * i]) and torch.equal(w_euler3[e], w_euler[2 * i])
+            if i < N - 1:
+                assert e == 2 * (i * R + (R - 1 - r))
+                assert torch.equal(coef3[e + 1], coef[2 * i + 1]) and torch.equal(w_heun3[e + 1], w_heun[2 * i + 1])
+                want = (sigma - sigma_next) if r > 0 else 0.0
+                assert math.isclose(w_ren3[e + 1, 4].item(), want, rel_tol=1e-6) and w_ren3[e + 1, 0].item() == 1.0
+            else:
+                assert e == 2 * (N - 1) * R + (R - 1 - r)
+    assert not w_ren3[2 * (N - 1) * R:, 1:].any()
     sd = hp["sigma_data"]
     for i, (sigma, sigma_next, gamma) in enumerate(table):
         sh = sigma + gamma * sigma

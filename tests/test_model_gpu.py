@@ -414,3 +414,41 @@ def test_elucidated_sample_vs_reference_fixture():
     b = model.sample(text_embeds=te, cond_scale=3., use_tqdm=False, seed=5)
     c = model.sample(text_embeds=te, cond_scale=3., use_tqdm=False, seed=6)
     assert torch.equal(a, b) and not torch.equal(a, c) and torch.isfinite(a).all()
+
+
+# Tests written after the round's GPU budget was spent: they only use kernels and launch parameters the tests above already cover, and
+# their host logic is checked on CPU (tests/test_sample_cpu_replay.py), but their tolerances have never met hardware.  They run with
+# IMAGEN_UNVERIFIED_GPU_TESTS=1; the first GPU call of the next round runs them once and drops the gate.
+unverified_on_hardware = pytest.mark.skipif(os.environ.get("IMAGEN_UNVERIFIED_GPU_TESTS") != "1",
+                                            reason="not yet run on hardware: set IMAGEN_UNVERIFIED_GPU_TESTS=1")
+
+
+@unverified_on_hardware
+@pytest.mark.parametrize("tag", ["init_skip", "inpaint", "sigma"])
+def test_elucidated_sample_options_vs_reference_fixture(tag):
+    """ElucidatedImagen.sample options (init_images + skip_steps, inpainting with resampling, per-call sigma overrides; el.py:393-545)
+    vs recorded runs of the live reference with identical draws; hipGraph replay == eager; known pixels returned exactly."""
+    from imagen_pytorch_amd import ElucidatedImagen, Unet
+
+    dev = torch.device("cuda:0")
+    o = _load("sample_tiny_elucidated_options.pt")
+    g = _load(o["weights_from"])
+    run = o["runs"][tag]
+    unets = [Unet(**u["kwargs"]).eval() for u in g["unets"]]
+    model = ElucidatedImagen(tuple(unets), image_sizes=g["image_sizes"], text_embed_dim=32, cond_drop_prob=0.1, **g["hparams"]).to(dev).eval()
+    for m, u in zip(model.unets, g["unets"]):
+        m.load_state_dict(u["state_dict"])
+    kw = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in run["kwargs"].items()}
+    common = dict(text_embeds=g["text_embeds"].to(dev), cond_scale=g["cond_scale"], use_tqdm=False,
+                  noise_fn=lambda t, shape: run["noise"][t].to(dev), **kw)
+    outs = model.sample(return_all_unet_outputs=True, **common)
+    eager = model.sample(return_all_unet_outputs=True, use_graph=False, **common)
+    assert all(torch.equal(a, b) for a, b in zip(outs, eager))
+    e0 = nerr(outs[0], run["outputs"][0])
+    alone = model.sample(start_at_unet_number=2, start_image_or_video=run["outputs"][0].to(dev), **common)
+    e1 = nerr(alone, run["outputs"][1])
+    print(f"elucidated options [{tag}]: stage 1 {e0:.2e}, stage 2 alone {e1:.2e}")
+    assert e0 < 3e-2 and e1 < 3e-2, (e0, e1)
+    if tag == "inpaint":
+        m = run["kwargs"]["inpaint_masks"][:, None].expand(-1, 3, -1, -1)
+        assert torch.allclose(alone.cpu()[m], run["kwargs"]["inpaint_images"][m], atol=1e-6)

@@ -232,6 +232,31 @@ def test_video_elucidated_sample_driver(cpu_backend):
     assert e0 < 3e-2 and e1 < 3e-2, (e0, e1)
 
 
+@pytest.mark.parametrize("tag", ["init_skip", "inpaint", "sigma"])
+def test_elucidated_sample_options_driver(cpu_backend, tag):
+    """ElucidatedImagen.sample(init_images= + skip_steps= | inpaint_images= ... | sigma_min= / sigma_max=) through the real driver:
+    table rows per inner iteration, the blend / re-noising launches, the step-counter start — vs recorded runs of the live reference."""
+    from imagen_pytorch_amd import ElucidatedImagen
+
+    o = torch.load(os.path.join(GOLDEN, "sample_tiny_elucidated_options.pt"), weights_only=False)
+    g = torch.load(os.path.join(GOLDEN, o["weights_from"]), weights_only=False)
+    run = o["runs"][tag]
+    model = _cascade(g, klass=ElucidatedImagen, **g["hparams"])
+    nf = lambda t, shape: run["noise"][t]
+    for use_graph in (True, False):
+        outs = model.sample(text_embeds=g["text_embeds"], cond_scale=g["cond_scale"], use_tqdm=False, return_all_unet_outputs=True,
+                            noise_fn=nf, device="cpu", use_graph=use_graph, **run["kwargs"])
+        e0 = nerr(outs[0], run["outputs"][0])
+        assert e0 < 3e-2, (tag, use_graph, e0)
+    alone = model.sample(text_embeds=g["text_embeds"], cond_scale=g["cond_scale"], use_tqdm=False, noise_fn=nf, device="cpu",
+                         start_at_unet_number=2, start_image_or_video=run["outputs"][0], **run["kwargs"])
+    e1 = nerr(alone, run["outputs"][1])
+    assert e1 < 3e-2, (tag, e1)
+    if tag == "inpaint":
+        m = run["kwargs"]["inpaint_masks"][:, None].expand(-1, 3, -1, -1)
+        assert torch.allclose(alone[m], run["kwargs"]["inpaint_images"][m], atol=1e-6)
+
+
 def test_video_elucidated_prompt_frames_driver(cpu_backend):
     """ElucidatedImagen over Unet3D stages with cond_video_frames (el.py:679-695) vs a recorded run of the live reference."""
     from imagen_pytorch_amd import ElucidatedImagen
