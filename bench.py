@@ -85,7 +85,7 @@ def igemm_bytes(p) -> float:
     return by + 2.0 * p.B * p.OH * p.OW * p.Cout * (bool(p.res) + bool(p.addend))
 
 
-def pmc_traffic_leg(log):
+def pmc_traffic_leg(log, budget_s: float = 300.0):
     """HBM traffic / MFMA-busy counters of every igemm launch of the denoiser steps, measured NOW: separate `rocprofv3 --pmc`
     passes (FETCH_SIZE | WRITE_SIZE | SQ MFMA-busy) over a short sampling run in a child process (tools/graph_profile.py run),
     joined with the plan by dispatch order.  Returns {(stage index, label): {counter: value per launch}} or None."""
@@ -100,14 +100,19 @@ def pmc_traffic_leg(log):
         return None
     out = {}
     passes = (["FETCH_SIZE"], ["WRITE_SIZE"], ["SQ_VALU_MFMA_BUSY_CYCLES", "SQ_BUSY_CYCLES", "SQ_WAVE_CYCLES", "GRBM_GUI_ACTIVE"])
+    t_leg = time.perf_counter()
     for counters in passes:
+        left = budget_s - (time.perf_counter() - t_leg)      # the three passes share one wall-clock budget (a pass takes ~40 s)
+        if left < 30:
+            log(f"pmc pass {counters} skipped: {budget_s:.0f} s counter budget spent")
+            continue
         tmp = tempfile.mkdtemp(prefix="imagen_pmc_", dir="/tmp")
         try:
             plan_path = os.path.join(tmp, "plan.json")
             cmd = [rocprof, "--pmc", *counters, "--output-format", "csv", "-d", os.path.join(tmp, "out"), "--",
                    sys.executable, os.path.join(ROOT, "tools", "graph_profile.py"), "run", "--steps", "5", "--plan-out", plan_path]
             env = dict(os.environ, TMPDIR="/tmp")
-            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=150)
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=min(150, left))
             csvs = [os.path.join(d, f) for d, _, fs in os.walk(os.path.join(tmp, "out")) for f in fs if f.endswith("counter_collection.csv")]
             if r.returncode != 0 or not csvs or not os.path.exists(plan_path):
                 log(f"pmc pass {counters}: rocprofv3 failed (rc {r.returncode}): {r.stdout.decode(errors='replace')[-300:]}")
