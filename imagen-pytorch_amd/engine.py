@@ -869,7 +869,7 @@ class UnetEngine:
         assert cond_images.shape[0] == self.src_batch, f'cond_images batch {cond_images.shape[0]} != {self.src_batch}'
         ci = cond_images.to(self.dev).float()
         if ci.shape[-2:] != self.cond_in.shape[-2:]:
-            ci = torch.nn.functional.interpolate(ci, self.cond_in.shape[-1], mode='nearest')
+            ci = torch.nn.functional.interpolate(ci, self.cond_in.shape[-1], mode=getattr(self.unet, 'resize_mode', 'nearest'))   # ip.py:1559
         self.cond_in.copy_(ci)
         if self._self_cond_op is not None:
             return                                   # packed together with the self-conditioning input at the start of every step

@@ -56,6 +56,16 @@ def _pad_tuple(t, length, fill):
     return t if len(t) >= length else (*t, *((fill,) * (length - len(t))))
 
 
+def _to_pil_images(batch: torch.Tensor) -> list:
+    """torchvision's ToPILImage for float (c, h, w) tensors in [0, 1] (`pic.mul(255).byte()`, HWC; ip.py:2496), without torchvision."""
+    from PIL import Image
+
+    modes = {1: 'L', 3: 'RGB', 4: 'RGBA'}
+    assert batch.ndim == 4 and batch.shape[1] in modes, 'PIL conversion needs (b, 1 | 3 | 4, h, w) images'
+    arr = batch.detach().mul(255).byte().permute(0, 2, 3, 1).cpu().numpy()
+    return [Image.fromarray(a[..., 0] if a.shape[-1] == 1 else a, mode=modes[a.shape[-1]]) for a in arr]
+
+
 def _out_of_scope(what):
     raise NotImplementedError(f"{what} is outside the MI355X sampling hot path of this build (SURVEY.md §2 / §8)")
 
@@ -148,9 +158,7 @@ class Imagen(nn.Module):
         assert num_unets == len(image_sizes), f'you did not supply the correct number of u-nets ({len(unets)}) for resolutions {image_sizes}'
         self.sample_channels = _cast_tuple(self.channels, num_unets)
         self.is_video = any(isinstance(u, Unet3D) for u in self.unets)     # ip.py:1918-1919
-        self.resize_mode = resize_mode
-        if resize_mode != 'nearest':
-            _out_of_scope(f"resize_mode='{resize_mode}'")
+        self.resize_mode = resize_mode                    # ip.py:1924: every image resize of the cascade goes through this mode
         self.temporal_downsample_factor = _cast_tuple(temporal_downsample_factor, num_unets)
         self.resize_cond_video_frames = resize_cond_video_frames                                                           # ip.py:1931
         assert self.temporal_downsample_factor[-1] == 1, 'downsample factor of last stage must be 1'                       # ip.py:1934
@@ -486,11 +494,11 @@ class Imagen(nn.Module):
     # evaluation goes through the same kernel plan (Unet.forward_with_cond_scale), the O(B*3*S*S) posterior arithmetic around it is
     # plain device-side tensor code with the reference's signatures, argument meaning and return values.
     def resize_to(self, img, size, **kwargs):
-        """Nearest-neighbour resize of images (ip.py:152-168; the only resize_mode of this build)."""
+        """resize_image_to with this model's resize_mode (ip.py:152-168, 1924)."""
         assert not kwargs or self.is_video, 'frame arguments are for video stages'
         if img.ndim == 5:
             _out_of_scope("resize_to for videos outside sample()")
-        return img if img.shape[-1] == size else F.interpolate(img, size, mode='nearest')
+        return img if img.shape[-1] == size else F.interpolate(img, size, mode=self.resize_mode)
 
     def _step_conditioning_checks(self, unet, cond_video_frames, post_cond_video_frames, cond_scale):
         assert not (cond_scale != 1. and not self.can_classifier_guidance), \
@@ -689,8 +697,7 @@ class Imagen(nn.Module):
                 assert int(video_frames) % f == 0, f'video_frames {video_frames} must be divisible by the temporal downsample factor {f}'
         frames = int(video_frames) if self.is_video else 0
         to_internal = (lambda t: t.permute(0, 2, 1, 3, 4).contiguous()) if self.is_video else (lambda t: t)   # (b,c,f,h,w) <-> (b,f,c,h,w)
-        if return_pil_images:
-            _out_of_scope("return_pil_images (torchvision is not part of this stack)")
+        assert not (return_pil_images and self.is_video), 'converting sampled video tensor to video file is not supported yet'   # ip.py:2494
 
         text_embeds, text_masks = self._resolve_text(texts, text_embeds, text_masks, device)
         if not self.unconditional:
@@ -711,7 +718,8 @@ class Imagen(nn.Module):
             'inpaint images and masks must be both passed in to do inpainting'
         num_unets = len(self.unets)
         normalize = (lambda im: im * 2 - 1) if self.auto_normalize_img else (lambda im: im)             # ip.py:1885-1888
-        resize = lambda im, size: im if im.shape[-1] == size else F.interpolate(im, size, mode='nearest')   # ip.py:152-168
+        assert not (self.is_video and self.resize_mode != 'nearest'), 'video cascades resize with nearest only in this build'
+        resize = lambda im, size: im if im.shape[-1] == size else F.interpolate(im, size, mode=self.resize_mode)   # ip.py:152-168, 1924
 
         def resize_clip(v, size, f):
             """resize_video_to (iv.py:134-156) of a (b, c, f', h, w) clip to f frames of size x size — nearest over all three axes —
@@ -819,6 +827,10 @@ class Imagen(nn.Module):
                         # iv.py:134-156; F.interpolate 'nearest' takes source index floor(dst * F_in / F_out)); once per stage
                         f_in, f_out = src.shape[1], aug.shape[1]
                         src = src[:, (torch.arange(f_out, device=src.device) * f_in) // f_out]
+                    if self.resize_mode != 'nearest' and src.shape[-1] != S:
+                        # LOWRES_PREP resizes with nearest in-kernel; any other mode is resized here, once per stage, and the kernel's
+                        # own resize becomes the identity.  The resize acts on the [0, 1] image as in ip.py:2444-2446 (normalisation after).
+                        src = resize(img, S) if self.auto_normalize_img else (resize(img, S) + 1) * 0.5
                     src = src.contiguous()
                     # frames are independent images for the nearest resize (resize_video_to with unchanged frame count, iv.py:134-156)
                     as_images = lambda t: t.reshape(-1, *t.shape[-3:])
@@ -859,4 +871,7 @@ class Imagen(nn.Module):
                 if stop_at_unet_number is not None and stop_at_unet_number == unet_number:
                     break
         stream.synchronize()
+        if return_pil_images:                                # ip.py:2488-2498: a list of PIL images (one list per unet with return_all_unet_outputs)
+            pil = [_to_pil_images(o) for o in (outputs if return_all_unet_outputs else outputs[-1:])]
+            return pil if return_all_unet_outputs else pil[-1]
         return outputs if return_all_unet_outputs else outputs[-1]

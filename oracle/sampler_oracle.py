@@ -110,7 +110,7 @@ def p_sample_loop(denoise: Callable[[Tensor, Tensor], Tensor], shape, *, schedul
                   noise_fn: Callable, stage: int, dynamic_thresholding: bool = True, percentile: float = 0.95,
                   max_steps: Optional[int] = None, trace: Optional[list] = None, init_images: Optional[Tensor] = None,
                   skip_steps: Optional[int] = None, inpaint_images: Optional[Tensor] = None, inpaint_masks: Optional[Tensor] = None,
-                  inpaint_resample_times: int = 5, self_cond: bool = False) -> Tensor:
+                  inpaint_resample_times: int = 5, self_cond: bool = False, resize_mode: str = "nearest") -> Tensor:
     """denoise(x_t, log_snr(t)) -> guided eps_hat; with `self_cond` the call is denoise(x_t, log_snr(t), x0_prev) where x0_prev is the
     thresholded x0 estimate of the previous call (None before the first one; ip.py:2208-2210, 2249-2251).  Returns the un-normalised image in [0, 1] (ip.py:2167-2289).
 
@@ -122,7 +122,7 @@ def p_sample_loop(denoise: Callable[[Tensor, Tensor], Tensor], shape, *, schedul
     if len(shape) == 5:     # video: resize_video_to with target_frames = this stage's frame count (ip.py:2198-2200, iv.py:134-156)
         resize = lambda im: im if tuple(im.shape[-3:]) == tuple(shape[-3:]) else F.interpolate(im, tuple(shape[-3:]), mode="nearest")
     else:
-        resize = lambda im: im if im.shape[-1] == size else F.interpolate(im, size, mode="nearest")   # ip.py:152-168
+        resize = lambda im: im if im.shape[-1] == size else F.interpolate(im, size, mode=resize_mode)   # ip.py:152-168, 1924
     img = noise_fn(("init", stage), shape)
     if init_images is not None:
         img = img + resize(init_images)                                     # ip.py:2205-2206 (+ the resize of :2457)
@@ -187,6 +187,7 @@ def imagen_sample(
     cond_video_frames: Optional[Tensor] = None,        # (b, c, f', h, w) prompt frames, handed to every Unet3D as they are — not
     post_cond_video_frames: Optional[Tensor] = None,   # normalised — after the per-stage temporal resize (ip.py:2417-2434)
     resize_cond_video_frames: bool = True,
+    resize_mode: str = "nearest",              # Imagen(resize_mode=...): every image resize of the cascade (ip.py:1924); images only here
 ):
     """ip.py:2291-2498 for text_embeds-conditioned sampling (no self-conditioning)."""
     n = len(unets)
@@ -215,7 +216,7 @@ def imagen_sample(
                 target = (video_frames // tds[stage], size, size)
                 up = img if tuple(img.shape[-3:]) == target else F.interpolate(img, target, mode="nearest")
             else:
-                up = img if img.shape[-1] == size else F.interpolate(img, size, mode="nearest")  # ip.py:152-168
+                up = img if img.shape[-1] == size else F.interpolate(img, size, mode=resize_mode)  # ip.py:152-168
             up = up * 2 - 1
             a, s = alpha_sigma(SCHEDULES[lowres_noise_schedule](lowres_times).reshape(-1, *([1] * (up.ndim - 1))))
             lowres_img = a * up + s * noise_fn(("lowres", stage), up.shape)       # ip.py:272-284, 2449
@@ -243,6 +244,6 @@ def imagen_sample(
                             stage=stage, dynamic_thresholding=dynamic_thresholding, percentile=percentile,
                             max_steps=max_steps, init_images=init_images[stage], skip_steps=skip_steps[stage], inpaint_images=known,
                             inpaint_masks=inpaint_masks, inpaint_resample_times=inpaint_resample_times,
-                            self_cond=bool(kw.get("self_cond", False)))
+                            self_cond=bool(kw.get("self_cond", False)), resize_mode=resize_mode)
         outputs.append(img)
     return outputs if return_all else outputs[-1]

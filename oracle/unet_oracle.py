@@ -335,7 +335,7 @@ def unet_forward(
     if cond_images is not None:
         assert cond_images.shape[1] == cfg["cond_images_channels"]
         if cond_images.shape[-1] != x.shape[-1]:
-            cond_images = F.interpolate(cond_images, x.shape[-1], mode="nearest")
+            cond_images = F.interpolate(cond_images, x.shape[-1], mode=kwargs.get("resize_mode", "nearest"))   # ip.py:1559
         x = torch.cat((cond_images, x), dim=1)
 
     # initial convolution (ip.py:1564, 1051-1076 / 1198)

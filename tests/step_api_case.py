@@ -51,7 +51,7 @@ def run_cascade_by_steps(imagen, g, monkeypatch, device):
     return outs
 
 
-def cond_images_cascade(device, timesteps=3, cond_ch=4, self_cond=False):
+def cond_images_cascade(device, timesteps=3, cond_ch=4, self_cond=False, resize_mode="nearest"):
     """A tiny two-stage cascade whose unets take a `cond_ch`-channel conditioning image (Unet(cond_images_channels=...), ip.py:1191-1194,
     1555-1560; None is returned for it when cond_ch = 0) and / or self-condition (Unet(self_cond=True), ip.py:1541-1543, 2249), its
     inputs, a recorded-noise function, the oracle's images for them and the oracle's (state_dict, kwargs) per stage."""
@@ -59,11 +59,11 @@ def cond_images_cascade(device, timesteps=3, cond_ch=4, self_cond=False):
     from oracle import sampler_oracle as so
 
     base = dict(dim=8, cond_dim=32, text_embed_dim=32, dim_mults=(1, 2), layer_attns=(False, True), layer_cross_attns=(False, True),
-                attn_heads=2, max_text_len=16, attn_pool_num_latents=8, cond_images_channels=cond_ch, self_cond=self_cond)
+                attn_heads=2, max_text_len=16, attn_pool_num_latents=8, cond_images_channels=cond_ch, self_cond=self_cond, resize_mode=resize_mode)
     k1, k2 = dict(base, num_resnet_blocks=1), dict(base, num_resnet_blocks=(1, 2), memory_efficient=True)
     torch.manual_seed(3)
     unets = [Unet(**k1), Unet(**k2)]
-    imagen = Imagen(unets, image_sizes=(16, 32), timesteps=timesteps, text_embed_dim=32, cond_drop_prob=0.1)
+    imagen = Imagen(unets, image_sizes=(16, 32), timesteps=timesteps, text_embed_dim=32, cond_drop_prob=0.1, resize_mode=resize_mode)
     for u in imagen.unets:                  # zero-initialised final conv: give it weights, or the test says nothing
         torch.nn.init.normal_(u.final_conv.weight, std=0.05)
         torch.nn.init.normal_(u.final_conv.bias, std=0.05)
@@ -81,5 +81,6 @@ def cond_images_cascade(device, timesteps=3, cond_ch=4, self_cond=False):
     sds = [({k: v.detach().cpu() for k, v in u.state_dict().items()}, {**kw, "lowres_cond": i > 0})
            for i, (u, kw) in enumerate(zip(imagen.unets, (k1, k2)))]
     with torch.no_grad():
-        want = so.imagen_sample(sds, (16, 32), te, timesteps=timesteps, cond_scale=3., return_all=True, noise_fn=noise, cond_images=cond)
+        want = so.imagen_sample(sds, (16, 32), te, timesteps=timesteps, cond_scale=3., return_all=True, noise_fn=noise, cond_images=cond,
+                                resize_mode=resize_mode)
     return imagen, te, cond, (lambda tag, shape: noise(tag, shape).to(device)), want, sds

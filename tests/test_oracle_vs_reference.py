@@ -49,17 +49,18 @@ def test_state_dict_layout_is_interchangeable():
         ours.load_state_dict(ref.state_dict())
 
 
-@pytest.mark.parametrize("cond_ch,self_cond", [(0, False), (4, False), (0, True), (4, True)],
-                         ids=["plain", "cond_images", "self_cond", "cond_images+self_cond"])
-def test_sampler_small_cascade(cond_ch, self_cond):
+@pytest.mark.parametrize("cond_ch,self_cond,mode", [(0, False, "nearest"), (4, False, "nearest"), (0, True, "nearest"), (4, True, "nearest"),
+                                                    (4, False, "bilinear")],
+                         ids=["plain", "cond_images", "self_cond", "cond_images+self_cond", "cond_images-bilinear"])
+def test_sampler_small_cascade(cond_ch, self_cond, mode):
     ip = ref_shim.load_reference()
     torch.manual_seed(0)
     k1 = dict(dim=8, cond_dim=32, dim_mults=(1, 2), num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True), attn_heads=2,
-              cond_images_channels=cond_ch, self_cond=self_cond)
+              cond_images_channels=cond_ch, self_cond=self_cond, resize_mode=mode)
     k2 = dict(dim=8, cond_dim=32, dim_mults=(1, 2), num_resnet_blocks=(1, 2), layer_attns=(False, True), layer_cross_attns=(False, True),
-              attn_heads=2, memory_efficient=True, cond_images_channels=cond_ch, self_cond=self_cond)
+              attn_heads=2, memory_efficient=True, cond_images_channels=cond_ch, self_cond=self_cond, resize_mode=mode)
     extra = dict(cond_images=torch.rand(2, cond_ch, 24, 24)) if cond_ch else {}
-    im = ip.Imagen((ip.Unet(**k1), ip.Unet(**k2)), image_sizes=(16, 32), timesteps=4, text_embed_dim=768, cond_drop_prob=0.1)
+    im = ip.Imagen((ip.Unet(**k1), ip.Unet(**k2)), image_sizes=(16, 32), timesteps=4, text_embed_dim=768, cond_drop_prob=0.1, resize_mode=mode)
     for u in im.unets:
         _dezero(u)
     te = torch.randn(2, 7, 768)
@@ -67,7 +68,7 @@ def test_sampler_small_cascade(cond_ch, self_cond):
     ref = im.sample(text_embeds=te, cond_scale=3., use_tqdm=False, return_all_unet_outputs=True, **extra)
     torch.manual_seed(123)  # identical CPU RNG stream: the oracle draws in the reference's order
     unets = [(u.state_dict(), {**kw, "lowres_cond": i > 0}) for i, (u, kw) in enumerate(zip(im.unets, (k1, k2)))]
-    got = so.imagen_sample(unets, (16, 32), te, timesteps=4, cond_scale=3., return_all=True, **extra)
+    got = so.imagen_sample(unets, (16, 32), te, timesteps=4, cond_scale=3., return_all=True, resize_mode=mode, **extra)
     for a, b in zip(ref, got):
         assert torch.allclose(a, b, atol=5e-4), (a - b).abs().max()
 

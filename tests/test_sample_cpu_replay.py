@@ -97,6 +97,12 @@ def test_cascade_sample_driver(cpu_backend, use_graph):
                          noise_fn=lambda tag, shape: g["noise"][tag], use_graph=use_graph, device="cpu")
     errs = [nerr(o, r) for o, r in zip(outs, g["outputs"])]
     assert max(errs) < 2e-2, errs
+    # PIL output (ip.py:2488-2498): torchvision's ToPILImage semantics — mul(255).byte(), HWC, RGB
+    pil = imagen.sample(text_embeds=g["text_embeds"], cond_scale=g["cond_scale"], use_tqdm=False, noise_fn=lambda tag, shape: g["noise"][tag],
+                        use_graph=use_graph, device="cpu", return_pil_images=True)
+    assert len(pil) == outs[-1].shape[0] and pil[0].mode == "RGB" and pil[0].size == (outs[-1].shape[-1], outs[-1].shape[-2])
+    import numpy as np
+    assert np.array_equal(np.asarray(pil[1]), outs[-1][1].mul(255).byte().permute(1, 2, 0).numpy())
     # a second call reuses the cached stages / graphs and gives the same images
     again = imagen.sample(text_embeds=g["text_embeds"], cond_scale=g["cond_scale"], use_tqdm=False, noise_fn=lambda tag, shape: g["noise"][tag],
                           use_graph=use_graph, device="cpu")
@@ -317,6 +323,20 @@ def test_self_conditioned_sampling(cpu_backend, monkeypatch, cond_ch, self_cond)
         img = imagen.p_sample_loop(imagen.unets[0], (2, 3, 16, 16), noise_scheduler=imagen.noise_schedulers[0], text_embeds=te,
                                    text_mask=torch.any(te != 0., dim=-1), cond_scale=3., use_tqdm=False, **extra)
     assert nerr(img, want[0]) < 2e-2
+
+
+def test_bilinear_resize_mode_sampling(cpu_backend):
+    """Imagen(resize_mode='bilinear') / Unet(resize_mode='bilinear') (ip.py:1559, 1924): the low-res conditioning image and the
+    conditioning image are resized on the host with that mode (the in-kernel nearest resize becomes the identity)."""
+    from step_api_case import cond_images_cascade
+
+    imagen, te, cond, noise_fn, want, _ = cond_images_cascade(torch.device("cpu"), resize_mode="bilinear")
+    outs = imagen.sample(text_embeds=te, cond_images=cond, cond_scale=3., use_tqdm=False, return_all_unet_outputs=True, noise_fn=noise_fn,
+                         device="cpu")
+    errs = [nerr(o, w) for o, w in zip(outs, want)]
+    assert max(errs) < 2e-2, errs
+    _, _, _, _, want_nearest, _ = cond_images_cascade(torch.device("cpu"))
+    assert nerr(want[-1], want_nearest[-1]) > 1e-2, "the mode must matter for this test to say anything"
 
 
 def test_cond_images_sampling(cpu_backend):
