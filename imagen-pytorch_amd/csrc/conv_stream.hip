@@ -413,7 +413,8 @@ int cs_launch_gen(const ImagenIgemmParams& p, hipStream_t s) {
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
   static const int per_cu_env = [] { const char* e = getenv("IMAGEN_STREAM_WG_PER_CU"); return e ? atoi(e) : 0; }();   // probe knob
   const int per_cu = per_cu_env > 0 ? per_cu_env : (NCH == 1 ? 2 : 1);
-  const int resident = std::max(1, cus) * per_cu;
+  static const int grid_pct = [] { const char* e = getenv("IMAGEN_GRID_PCT"); const int v = e ? atoi(e) : 100; return v >= 10 && v <= 100 ? v : 100; }();   // probe knob, see igemm.hip
+  const int resident = std::max(1, std::max(1, cus) * per_cu * grid_pct / 100);
   int gx = total;
   if (total > resident) {   // even rounds: every workgroup walks the same number of tiles (+-1)
     const int rounds = (total + resident - 1) / resident;

@@ -964,7 +964,10 @@ int launch_gen(const ImagenIgemmParams& p, hipStream_t s) {
   }
   static const int forced_per_cu = [] { const char* e = getenv("IMAGEN_IGEMM_WG_PER_CU"); return e ? atoi(e) : 0; }();   // probe knob
   const int per_cu = forced_per_cu > 0 ? forced_per_cu : occ_blocks;
-  const int resident = num_cus() * per_cu;
+  // probe knob for concurrent lanes: a persistent grid below 100 % of the resident slots leaves room for the other streams' small
+  // launches while this one runs (they otherwise wait for a whole-chip kernel to drain)
+  static const int grid_pct = [] { const char* e = getenv("IMAGEN_GRID_PCT"); const int v = e ? atoi(e) : 100; return v >= 10 && v <= 100 ? v : 100; }();
+  const int resident = std::max(8, num_cus() * per_cu * grid_pct / 100 / 8 * 8);
   int gx;
   if ((p.dbg & 32) || total <= resident) {
     gx = total;                                    // dbg 32: one tile per workgroup (no cross-tile pipelining)
