@@ -511,6 +511,28 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
   };
   auto epilogue = [&](const TileCoord& tc, int n0_next) __attribute__((always_inline)) {
     const int b = tc.b, n0 = tc.n0;
+#ifdef IGEMM_EPI_REMAT
+    // A/B build (tools/build_remat_lib.sh): rematerialise the per-lane constants of the epilogue here instead of keeping
+    // them live across the k loop.  At the 128-VGPR budget the compiler hoists them out of the tile loop and spills them; every reload
+    // in the epilogue is a scratch_load followed by s_waitcnt vmcnt(0), i.e. a full drain of the re-primed weight ring (19 per tile in
+    // <2,1,1,4,4,18,false>, 46 in its GEN twin — none with this block).  The empty asm makes the thread id opaque inside the tile
+    // loop, so nothing derived from it can be hoisted; the names shadow the outer ones for the rest of the epilogue.
+    int tid_e = threadIdx.x;
+    asm volatile("" : "+v"(tid_e));
+    const int half = (tid_e >> 5) & 1, l31 = tid_e & 31;
+    const int wave_e = __builtin_amdgcn_readfirstlane(tid_e >> 6);
+    const int wm = wave_e / WN, wn = wave_e % WN;
+    int pix_y[MI], pix_x[MI];
+    {
+      const int tw_sh = __builtin_ctz(p.TW);   // launcher-checked in this build: TW is a power of two (every host-side tile shape is)
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) {
+        const int tp = (wm * MI + mi) * 32 + l31;
+        pix_y[mi] = tp >> tw_sh;
+        pix_x[mi] = tp & (p.TW - 1);
+      }
+    }
+#endif
     if (p.post_pa) {
       // ---- output-side Block prologue: two passes over the accumulators (norm over all Cout of the pixel, then activate + store)
       float tot[MI];
@@ -1031,6 +1053,9 @@ int launch_igemm(const ImagenIgemmParams* pp, hipStream_t s) {
   IMAGEN_CHECK(p.cfg >= 0 && p.cfg < cfg_end(), "igemm: bad cfg %d", p.cfg);
   IMAGEN_CHECK(p.x1 && p.w && p.y, "igemm: null x1/w/y");
   IMAGEN_CHECK(!p.addend || p.gate, "igemm: addend requires gate");
+#ifdef IGEMM_EPI_REMAT
+  IMAGEN_CHECK(p.cfg >= kNumCfgs || (p.TW > 0 && (p.TW & (p.TW - 1)) == 0), "igemm (IGEMM_EPI_REMAT build): tile width %d is not a power of two", p.TW);
+#endif
   IMAGEN_CHECK(!p.gca_part || p.cfg >= kNumCfgs, "igemm: gca_part is implemented by kernel families 1 and 2 only (cfg %d)", p.cfg);
   if (p.cfg >= cfg_base_stream()) return launch_conv_stream(pp, p.cfg - cfg_base_stream(), s);
   if (p.cfg >= cfg_base_dma()) return launch_conv_dma(pp, p.cfg - cfg_base_dma(), s);
