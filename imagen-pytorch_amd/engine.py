@@ -273,6 +273,7 @@ class UnetEngine:
             x = self._transformer(plan, x, u.mid_attn, "mid_attn", with_context=False)
         x = self._resnet(plan, x, None, u.mid_block2, "mid_block2", with_cond=True)
         self.taps['mid'] = x
+        up_hiddens: List[Act] = []
         for i, lvl in enumerate(u.ups):
             init_block, res_blocks, attn_block, upsample = lvl
             x = self._resnet(plan, x, hiddens.pop(), init_block, f"ups.{i}.0", with_cond=True)
@@ -280,12 +281,15 @@ class UnetEngine:
                 x = self._resnet(plan, x, hiddens.pop(), rb, f"ups.{i}.1.{j}", with_cond=False)
             if isinstance(attn_block, TransformerBlockP):
                 x = self._transformer(plan, x, attn_block, f"ups.{i}.2", with_context=True)
+            up_hiddens.append(x)                                            # ip.py:1707
             if isinstance(upsample, PixelShuffleUpsampleP):
                 x = self._upsample(plan, x, upsample, f"ups.{i}.3")
             elif isinstance(upsample, nn.Sequential):
                 x = self._upsample_nearest_conv(plan, x, upsample, f"ups.{i}.3")
             self.taps[f'up{i}'] = x
         assert not hiddens
+        if getattr(u.upsample_combiner, 'enabled', False):
+            x = self._combine_upsample_fmaps(plan, x, up_hiddens)
         if u.final_res_block is not None:   # with init_conv_to_final_conv_residual its input is cat(x, init conv output), unscaled (ip.py:1716-1720)
             x = self._resnet(plan, x, init_res, u.final_res_block, "final_res_block", with_cond=False, skip_scale=1.0)
         self.taps['final_res'] = x
@@ -361,6 +365,43 @@ class UnetEngine:
             return ops.pack_weight(wp, u.final_conv.bias.detach().float(), self.dev, G=G)
 
         ops.igemm(plan, x, self.W.get("final_conv", make), self.out, x2=extra, out_mode=OUT_NCHW_F32, label="final_conv")
+
+    def _combine_upsample_fmaps(self, plan, x: Act, fmaps: List[Act]) -> Act:
+        """UpsampleCombiner (ip.py:1078-1110, 1712): cat(x, Block_i(nearest-resize(fmap_i))) over the up levels.  Kernels of the image
+        path only: the nearest resize by an integer factor f is f*f strided row copies (output pixel (y*f + dy, x*f + dx) takes input
+        pixel (y, x): one copy per (dy, dx) with the input rows as the batch), the Block is the fused norm -> SiLU -> 3x3 conv, each
+        writing its channel slice of the concatenated tensor directly.  A non-default flag: nothing here is tuned."""
+        u, R = self.unet, self.R
+        comb = u.upsample_combiner
+        S, dim = x.H, x.C
+        douts = [blk.project.weight.shape[0] for blk in comb.fmap_convs]
+        Ctot = dim + sum(douts)
+        assert Ctot == comb.dim_out and dim % 8 == 0 and all(d % 8 == 0 for d in douts), "combiner slices must be 8-channel aligned"
+        cat = self.new(R, S, S, Ctot)
+        ops.rows_copy(plan, x.t, cat.t, B=1, rows=R * S * S, C=dim, src_bs=0, src_rs=x.ld, dst_bs=0, dst_rs=Ctot, src_off=x.off,
+                      label="upsample_combiner.x")
+        off = dim
+        for i, (f_act, blk, dout) in enumerate(zip(fmaps, comb.fmap_convs, douts)):
+            name = f"upsample_combiner.fmap_convs.{i}"
+            C = f_act.C
+            assert f_act.ld == C and C % 8 == 0
+            if f_act.H != S:
+                assert S % f_act.H == 0 and f_act.H == f_act.W, "nearest resize by an integer factor only"
+                f, h = S // f_act.H, f_act.H
+                up = self.new(R, S, S, C)
+                for dy in range(f):
+                    for dx in range(f):
+                        ops.rows_copy(plan, f_act.t, up.t, B=R * h, rows=h, C=C, src_bs=h * C, src_rs=C, dst_bs=f * S * C, dst_rs=f * C,
+                                      src_off=f_act.off, dst_off=(dy * S + dx) * C, label=f"{name}.resize")
+            else:
+                up = f_act
+            ssq = self._ssq_of(plan, up, name + ".stat")
+            w = self.W.conv(name, blk.project)
+            pa = self.W.f32(name + ".pa", lambda blk=blk, C=C, w=w: _pad_vec(blk.norm.gamma.detach().float().flatten().cpu() * math.sqrt(C), w.Cin_pad))
+            dst = Act(cat.t, R, S, S, dout, Ctot, S * S * Ctot, off)
+            ops.igemm(plan, up, w, dst, ssq_a=ssq, pa=pa, pstride=0, act_in=ACT_SILU, label=name)
+            off += dout
+        return cat
 
     # ---- ResnetBlock (ip.py:693-757)
     def _resnet(self, plan, x: Act, skip: Optional[Act], rb: ResnetBlockP, name: str, with_cond: bool, skip_scale: Optional[float] = None) -> Act:

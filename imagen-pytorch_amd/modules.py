@@ -57,6 +57,21 @@ class BlockP(Holder):
         self.project = nn.Conv2d(dim, dim_out, 3, padding=1)
 
 
+class UpsampleCombinerP(Holder):
+    """ip.py:1078-1110: one Block(dim_in -> dim) per up level when enabled (no parameters otherwise)."""
+
+    def __init__(self, dim, *, enabled=False, dim_ins=(), dim_outs=()):
+        super().__init__()
+        dim_outs = tuple(dim_outs) if isinstance(dim_outs, (tuple, list)) else (dim_outs,) * len(dim_ins)
+        assert len(dim_ins) == len(dim_outs)
+        self.enabled = enabled
+        if not enabled:
+            self.dim_out = dim
+            return
+        self.fmap_convs = nn.ModuleList([BlockP(di, do) for di, do in zip(dim_ins, dim_outs)])
+        self.dim_out = dim + sum(dim_outs)
+
+
 class CrossAttentionP(Holder):
     """ip.py:759-791."""
 

@@ -11,7 +11,7 @@ import torch
 from torch import nn
 
 from .modules import (CrossEmbedP, Holder, ParallelP, PerceiverResamplerP, PixelShuffleUpsampleP,
-                      ResnetBlockP, SinuPosEmbP, TransformerBlockP, downsample_p, upsample_conv_p)
+                      ResnetBlockP, SinuPosEmbP, TransformerBlockP, UpsampleCombinerP, downsample_p, upsample_conv_p)
 
 DEFAULT_TEXT_EMBED_DIM = 768  # d_model of the reference's default T5 ('google/t5-v1_1-base', t5.py:47-58, ip.py:1117)
 
@@ -107,8 +107,6 @@ class Unet(nn.Module):
             v = self._locals[name]
             if any(_cast_tuple(v)):
                 _unsupported(name)
-        if combine_upsample_fmaps:
-            _unsupported('combine_upsample_fmaps')
         if cross_embed_downsample:
             # the reference cannot build this either: partial(CrossEmbedLayer, kernel_sizes=...) is called with (dim_in, dim_out)
             # positionally (ip.py:1315, 1357, 1366), so dim_out collides with kernel_sizes and Unet(...) raises TypeError — no
@@ -222,12 +220,14 @@ class Unet(nn.Module):
         self.mid_block2 = ResnetBlockP(mid_dim, mid_dim, cond_dim=cond_dim, time_cond_dim=time_cond_dim)
 
         # up path (ip.py:1392-1413)
+        upsample_fmap_dims = []
         for ind, ((dim_in, dim_out), n_blocks, l_attn, l_depth, l_cross) in enumerate(
                 zip(reversed(in_out), reversed(num_resnet_blocks), reversed(layer_attns), reversed(layer_attns_depth),
                     reversed(layer_cross_attns))):
             is_last = ind == (num_layers - 1)
             layer_cond_dim = cond_dim if l_cross else None
             skip_connect_dim = skip_connect_dims.pop()
+            upsample_fmap_dims.append(dim_out)
             self.ups.append(nn.ModuleList([
                 resnet(dim_out + skip_connect_dim, dim_out, cond_dim=layer_cond_dim, time_cond_dim=time_cond_dim),
                 nn.ModuleList([ResnetBlockP(dim_out + skip_connect_dim, dim_out, time_cond_dim=time_cond_dim, use_gca=use_global_context_attn)
@@ -238,11 +238,12 @@ class Unet(nn.Module):
                  if (not is_last or memory_efficient) else nn.Identity()),
             ]))
 
-        self.upsample_combiner = Holder()  # disabled combiner has no parameters (ip.py:1093-1095)
+        # whether to combine the feature maps of all up levels before the final resnet block (ip.py:1415-1422)
+        self.upsample_combiner = UpsampleCombinerP(dim, enabled=combine_upsample_fmaps, dim_ins=upsample_fmap_dims, dim_outs=dim)
         self.init_conv_to_final_conv_residual = init_conv_to_final_conv_residual          # ip.py:1426-1427
         if init_conv_to_final_conv_residual:
             assert init_dim == dim, 'init_conv_to_final_conv_residual needs init_dim == dim (the reference concatenates `dim` channels)'
-        final_conv_dim = dim + (dim if init_conv_to_final_conv_residual else 0)
+        final_conv_dim = self.upsample_combiner.dim_out + (dim if init_conv_to_final_conv_residual else 0)
 
         self.final_res_block = ResnetBlockP(final_conv_dim, dim, time_cond_dim=time_cond_dim, use_gca=True) if final_resnet_block else None
         final_conv_dim_in = dim if final_resnet_block else final_conv_dim

@@ -58,7 +58,7 @@ def resolve_config(kwargs: dict) -> dict:
         v = cfg[flag]
         if any(v) if isinstance(v, (list, tuple)) else v:
             raise NotImplementedError(f"oracle: {flag} is outside the hot-path scope")
-    for flag in ("cross_embed_downsample", "combine_upsample_fmaps"):
+    for flag in ("cross_embed_downsample",):
         if cfg[flag]:
             raise NotImplementedError(f"oracle: {flag} is outside the hot-path scope")
     dim = cfg["dim"]
@@ -422,6 +422,7 @@ def unet_forward(
     tap("mid", x)
 
     s = cfg["skip_scale"]
+    up_hiddens = []
     for i in range(n_levels):
         lvl = n_levels - 1 - i
         lp = p.sub(f"ups.{i}")
@@ -432,6 +433,7 @@ def unet_forward(
             x = resnet_block(lp.sub(f"1.{j}"), x, t, None, heads)
         if cfg["layer_attns_t"][lvl]:
             x = transformer_block(lp.sub("2"), x, c, heads, cfg["layer_attns_depth_t"][lvl])
+        up_hiddens.append(x)                                                              # ip.py:1707
         if i < n_levels - 1 or cfg["memory_efficient"]:
             if cfg["pixel_shuffle_upsample"]:
                 x = pixel_shuffle_up(lp.sub("3"), x)
@@ -439,6 +441,11 @@ def unet_forward(
                 x = F.conv2d(F.interpolate(x, scale_factor=2, mode="nearest"), lp("3.1.weight"), lp("3.1.bias"), padding=1)
         tap(f"up{i}", x)
 
+    if cfg["combine_upsample_fmaps"]:       # UpsampleCombiner (ip.py:1078-1110, 1712): every up level's feature map, resized
+        size = x.shape[-1]                                # to the output resolution (nearest) and passed through its own Block
+        outs = [block(p.sub(f"upsample_combiner.fmap_convs.{i}"), f if f.shape[-1] == size else F.interpolate(f, size, mode="nearest"))
+                for i, f in enumerate(up_hiddens)]
+        x = torch.cat((x, *outs), dim=1)
     if init_conv_residual is not None:                                                    # ip.py:1716-1717
         x = torch.cat((x, init_conv_residual), dim=1)
     if cfg["final_resnet_block"]:

@@ -452,3 +452,32 @@ def test_elucidated_sample_options_vs_reference_fixture(tag):
     if tag == "inpaint":
         m = run["kwargs"]["inpaint_masks"][:, None].expand(-1, 3, -1, -1)
         assert torch.allclose(alone.cpu()[m], run["kwargs"]["inpaint_images"][m], atol=1e-6)
+
+
+@unverified_on_hardware
+@pytest.mark.parametrize("name", ["combine_upsample_fmaps", "combine_fmaps_init_residual_memory_efficient"])
+def test_upsample_combiner_vs_oracle(name):
+    """Unet(combine_upsample_fmaps=True) (ip.py:1078-1110): strided row copies for the nearest resize, Blocks writing channel slices of the
+    concatenated tensor — on the GPU against the oracle (CPU: planner vs oracle in tests/test_plan_interp.py)."""
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from unet_config_sweep import SWEEP
+
+    from imagen_pytorch_amd import Unet
+    from oracle import unet_oracle as uo
+
+    dev = torch.device("cuda:0")
+    kw = SWEEP[name]
+    torch.manual_seed(2)
+    u = Unet(**kw).eval()
+    torch.nn.init.normal_(u.final_conv.weight, std=0.05)
+    torch.nn.init.normal_(u.final_conv.bias, std=0.05)
+    sd = {k: v.detach().clone() for k, v in u.state_dict().items()}
+    u = u.to(dev)
+    B, S = 2, 16
+    x, t, te = torch.randn(B, 3, S, S), torch.tensor([0.4, -1.7]), torch.randn(B, 7, kw["text_embed_dim"])
+    extra = dict(lowres_cond_img=torch.randn(B, 3, S, S), lowres_noise_times=torch.tensor([0.9, 0.9])) if kw.get("lowres_cond") else {}
+    got = u.forward_with_cond_scale(x.to(dev), t.to(dev), text_embeds=te.to(dev), cond_scale=3.0, **{k: v.to(dev) for k, v in extra.items()})
+    with torch.no_grad():
+        ref = uo.unet_forward_with_cond_scale(sd, kw, x, t, text_embeds=te, cond_scale=3.0, **extra)
+    assert nerr(got, ref) < 1e-2, nerr(got, ref)     # dim-8 toy unet: the tolerance class of the tiny fixtures

@@ -39,6 +39,12 @@ SWEEP = {
     "self_cond": dict(_T, num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True), self_cond=True),
     "self_cond_lowres_cond_images_5": dict(_T, num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True), self_cond=True,
                                            lowres_cond=True, cond_images_channels=5),
+    # UpsampleCombiner (ip.py:1078-1110): every up level's feature map resized to the output resolution, through its own Block, concatenated
+    "combine_upsample_fmaps": dict(_T, dim_mults=(1, 2, 4), num_resnet_blocks=(1, 1, 2), layer_attns=(False, False, True),
+                                   layer_cross_attns=(False, True, True), combine_upsample_fmaps=True),
+    "combine_fmaps_init_residual_memory_efficient": dict(_T, num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True),
+                                                         memory_efficient=True, init_conv_to_final_conv_residual=True, combine_upsample_fmaps=True,
+                                                         lowres_cond=True),
     "channels_out_6": dict(_T, num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True), channels_out=6),
 }
 
