@@ -1,0 +1,42 @@
+#!/bin/bash
+# First GPU call of round 3 (prepared at the end of round 2, when the GPU budget was spent): everything that was written or found
+# without hardware, in one call.  Build both libraries BEFORE the call, in the build container (the .so files travel with the snapshot):
+#     python -c "import __graft_entry__ as g; g.build()" && bash tools/build_remat_lib.sh
+#     gpurun --timeout 1500 -- 'bash tools/r03_calls/first_call.sh'
+# Output: gpurun_out/r03_first/*.log|json.  Budget: ~12 GPU-minutes.
+set -u
+cd "$(dirname "$0")/../.."
+OUT=gpurun_out/r03_first
+mkdir -p $OUT
+REMAT=$PWD/imagen-pytorch_amd/libimagen_hip_remat.so
+B="python bench.py --steps 8 --warmup 4 --no-roofline --no-cpu-baseline"
+
+# 1. the tests that have not met hardware (ElucidatedImagen sampler options, upsample combiner)
+IMAGEN_UNVERIFIED_GPU_TESTS=1 timeout 300 python -m pytest tests/test_model_gpu.py -q -k "elucidated_sample_options or upsample_combiner" -s > $OUT/unverified_tests.log 2>&1
+tail -n 3 $OUT/unverified_tests.log
+
+# 2. parity of the -DIGEMM_EPI_REMAT library: every tile configuration x k-step path, and every distinct igemm launch of the benchmark's plans
+if [ -f "$REMAT" ]; then
+  IMAGEN_LIB_PATH=$REMAT timeout 400 python -m pytest tests/test_igemm_cfgs_gpu.py tests/test_bench_shapes_gpu.py tests/test_fusion_gpu.py -q -x > $OUT/remat_parity.log 2>&1
+  tail -n 3 $OUT/remat_parity.log
+else
+  echo "no $REMAT: run tools/build_remat_lib.sh before the call" | tee $OUT/remat_parity.log
+fi
+
+# 3. bench A/B, same box, same call (boxes of the pool differ by +-20 %): product | remat | persistent grids below the resident slot count
+timeout 240 $B > $OUT/bench_default.json 2> $OUT/bench_default.err
+[ -f "$REMAT" ] && IMAGEN_LIB_PATH=$REMAT timeout 240 $B > $OUT/bench_remat.json 2> $OUT/bench_remat.err
+for pct in 94 88 80; do
+  IMAGEN_GRID_PCT=$pct timeout 240 $B > $OUT/bench_grid$pct.json 2> $OUT/bench_grid$pct.err
+done
+[ -f "$REMAT" ] && IMAGEN_LIB_PATH=$REMAT IMAGEN_GRID_PCT=88 timeout 240 $B > $OUT/bench_remat_grid88.json 2> $OUT/bench_remat_grid88.err
+timeout 240 $B > $OUT/bench_default_again.json 2> $OUT/bench_default_again.err      # drift of the box over the call
+python - <<'PY'
+import glob, json, os
+for f in sorted(glob.glob("gpurun_out/r03_first/bench_*.json")):
+    try:
+        r = json.loads(open(f).read().strip().splitlines()[-1])
+        print(f"{os.path.basename(f):32s} {r['value']:.4f} images/s  (sequential {r.get('sequential', {}).get('value')})")
+    except Exception as e:   # noqa: BLE001
+        print(f"{os.path.basename(f):32s} failed: {e}")
+PY
