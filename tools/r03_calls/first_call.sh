@@ -3,7 +3,7 @@
 # without hardware, in one call.  Build both libraries BEFORE the call, in the build container (the .so files travel with the snapshot):
 #     python -c "import __graft_entry__ as g; g.build()" && bash tools/build_remat_lib.sh
 #     gpurun --timeout 1500 -- 'bash tools/r03_calls/first_call.sh'
-# Output: gpurun_out/r03_first/*.log|json.  Budget: ~12 GPU-minutes.
+# Output: gpurun_out/r03_first/*.log|json.  Budget: ~15 GPU-minutes.
 set -u
 cd "$(dirname "$0")/../.."
 OUT=gpurun_out/r03_first
@@ -29,6 +29,7 @@ timeout 240 $B > $OUT/bench_default.json 2> $OUT/bench_default.err
 for pct in 94 88 80; do
   IMAGEN_GRID_PCT=$pct timeout 240 $B > $OUT/bench_grid$pct.json 2> $OUT/bench_grid$pct.err
 done
+IMAGEN_IGEMM_DBG=32 timeout 240 $B > $OUT/bench_one_tile_per_wg.json 2> $OUT/bench_one_tile_per_wg.err   # igemm grids non-persistent: other lanes' launches interleave as slots free up
 [ -f "$REMAT" ] && IMAGEN_LIB_PATH=$REMAT IMAGEN_GRID_PCT=88 timeout 240 $B > $OUT/bench_remat_grid88.json 2> $OUT/bench_remat_grid88.err
 timeout 240 $B > $OUT/bench_default_again.json 2> $OUT/bench_default_again.err      # drift of the box over the call
 python - <<'PY'
