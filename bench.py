@@ -348,22 +348,27 @@ def main():
                                            sample_offset=rank * B)
         else:
             import threading
-            outs, nxt, lock = [None] * count, [0], threading.Lock()
+            outs, nxt, lock, errors = [None] * count, [0], threading.Lock(), []
 
             def run(lane):
-                with imagen.lane(lane), torch.cuda.device(device):
-                    while True:
-                        with lock:
-                            i = nxt[0]
-                            nxt[0] += 1
-                        if i >= count:
-                            return
-                        outs[i] = imagen.sample(text_embeds=text_embeds, cond_scale=3.0, use_tqdm=False, seed=1000 + first + i,
-                                                sample_offset=rank * B)
+                try:
+                    with imagen.lane(lane), torch.cuda.device(device):
+                        while not errors:
+                            with lock:
+                                i = nxt[0]
+                                nxt[0] += 1
+                            if i >= count:
+                                return
+                            outs[i] = imagen.sample(text_embeds=text_embeds, cond_scale=3.0, use_tqdm=False, seed=1000 + first + i,
+                                                    sample_offset=rank * B)
+                except BaseException as e:   # noqa: BLE001 — re-raised in the main thread: a dead lane must fail the bench loudly
+                    errors.append(e)
 
             th = [threading.Thread(target=run, args=(1 + l,)) for l in range(args.lanes)]
             [t.start() for t in th]
             [t.join() for t in th]
+            if errors:
+                raise errors[0]
         if world > 1:
             outs = [all_gather_images(o, B * world) for o in outs]
         return outs[-1]
