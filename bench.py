@@ -428,7 +428,11 @@ def main():
         # the extra legs must never cost the headline line: a failure is reported in the record instead
         if world == 1 and not args.no_roofline:
             try:
-                pmc = None if args.no_pmc else pmc_traffic_leg(log)
+                # the counter passes are evidence beside the headline, never at its expense: skipped when the run is already long
+                spent = time.perf_counter() - t_start
+                if not args.no_pmc and spent > 480:
+                    log(f"pmc passes skipped: {spent:.0f} s into the run")
+                pmc = None if (args.no_pmc or spent > 480) else pmc_traffic_leg(log)
                 rec["roofline"], rec["roofline_other_bound"] = roofline_leg(imagen, B, device, pmc)
                 log("roofline leg done")
             except Exception as e:  # noqa: BLE001
