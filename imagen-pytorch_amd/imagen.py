@@ -496,18 +496,18 @@ class Imagen(nn.Module):
     def resize_to(self, img, size, **kwargs):
         """resize_image_to with this model's resize_mode (ip.py:152-168, 1924)."""
         assert not kwargs or self.is_video, 'frame arguments are for video stages'
-        if img.ndim == 5:
-            _out_of_scope("resize_to for videos outside sample()")
+        if img.ndim == 5:                                # resize_video_to (iv.py:134-156): (b, c, f, h, w), optional target_frames
+            frames = kwargs.get('target_frames') or img.shape[2]
+            if tuple(img.shape[-3:]) == (frames, size, size):
+                return img
+            return F.interpolate(img, (frames, size, size), mode=self.resize_mode)
         return img if img.shape[-1] == size else F.interpolate(img, size, mode=self.resize_mode)
 
     def _step_conditioning_checks(self, unet, cond_video_frames, post_cond_video_frames, cond_scale):
         assert not (cond_scale != 1. and not self.can_classifier_guidance), \
             'imagen was not trained with conditional dropout, and thus one cannot use classifier free guidance (cond_scale anything other than 1)'
-        for name, val in (('cond_video_frames', cond_video_frames), ('post_cond_video_frames', post_cond_video_frames)):
-            if val is not None:
-                _out_of_scope(f"{name}=...")
-        if isinstance(unet, Unet3D):
-            _out_of_scope("step-level sampling of video stages (use sample(video_frames=...))")
+        assert isinstance(unet, Unet3D) or (cond_video_frames is None and post_cond_video_frames is None), \
+            'cond_video_frames / post_cond_video_frames condition Unet3D stages only'
 
     @torch.no_grad()
     def p_mean_variance(self, unet, x, t, *, noise_scheduler, text_embeds=None, text_mask=None, cond_images=None, cond_video_frames=None,
@@ -518,10 +518,12 @@ class Imagen(nn.Module):
         self._step_conditioning_checks(unet, cond_video_frames, post_cond_video_frames, cond_scale)
         pred = model_output
         if pred is None:
+            video_kwargs = dict(cond_video_frames=cond_video_frames, post_cond_video_frames=post_cond_video_frames) if self.is_video else {}
             pred = unet.forward_with_cond_scale(x, noise_scheduler.get_condition(t), text_embeds=text_embeds, text_mask=text_mask,
                                                 cond_images=cond_images, self_cond=self_cond, cond_scale=cond_scale,
                                                 lowres_cond_img=lowres_cond_img,
-                                                lowres_noise_times=self.lowres_noise_schedule.get_condition(lowres_noise_times))
+                                                lowres_noise_times=self.lowres_noise_schedule.get_condition(lowres_noise_times),
+                                                **video_kwargs)                      # ip.py:2057-2070
         if pred_objective == 'noise':
             x_start = noise_scheduler.predict_start_from_noise(x, t=t, noise=pred)
         elif pred_objective == 'x_start':
@@ -561,17 +563,18 @@ class Imagen(nn.Module):
                       pred_objective='noise', dynamic_threshold=True, use_tqdm=True):
         """ip.py:2167-2289 with the reference's signature: the loop of one stage, step by step through `p_sample` (torch's
         generator supplies the noise, in the reference's draw order).  `sample()` is the fast way to run a stage."""
-        if inpaint_videos is not None or len(shape) == 5:
-            _out_of_scope("step-level sampling of videos (use sample(video_frames=...))")
         device = self.device
         batch = shape[0]
+        resize_kwargs = dict(target_frames=shape[-3]) if len(shape) == 5 else {}      # ip.py:2198-2200
         img = torch.randn(shape, device=device)
         if init_images is not None:
             img = img + init_images
+        if inpaint_videos is not None:                   # ip.py:2214
+            inpaint_images = inpaint_videos
         inpainting = inpaint_images is not None and inpaint_masks is not None
         if inpainting:
-            known = self.resize_to(self.normalize_img(inpaint_images), shape[-1])
-            keep = self.resize_to(inpaint_masks[:, None].float(), shape[-1]).bool()
+            known = self.resize_to(self.normalize_img(inpaint_images), shape[-1], **resize_kwargs)
+            keep = self.resize_to(inpaint_masks[:, None].float(), shape[-1], **resize_kwargs).bool()
         steps = noise_scheduler.get_sampling_timesteps(batch, device=device)[(skip_steps or 0):]
         if use_tqdm:
             try:

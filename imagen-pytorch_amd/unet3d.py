@@ -250,8 +250,9 @@ class Unet3D(nn.Module):
                pre_frames: int = 0, post_frames: int = 0):
         from .engine3d import UnetEngine3D
 
+        from . import unet as _unet_mod
         device = torch.device(device)
-        if device.type != 'cuda':
+        if device.type not in _unet_mod._ENGINE_DEVICE_TYPES:       # ('cuda',) in the product; the CPU replay tests widen it
             raise RuntimeError("imagen_pytorch_amd.Unet3D runs on MI355X through libimagen_hip.so only; there is no CPU path")
         key = (batch_rows, src_batch, frames, image_size, device.index or 0, bool(with_text), bool(ignore_time), pre_frames, post_frames)
         eng = self._engines.get(key)

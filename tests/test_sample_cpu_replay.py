@@ -389,3 +389,36 @@ def test_trainer_facade_sampling(cpu_backend, tmp_path):
     assert chunked.shape == whole.shape and torch.allclose(chunked, whole, atol=1e-6)
     with pytest.raises(NotImplementedError):
         trainer(torch.zeros(1, 3, 16, 16), unet_number=1)
+
+
+@pytest.mark.parametrize("tag", ["plain", "cond_pre", "inpaint"])
+def test_video_step_level_api(cpu_backend, monkeypatch, tag):
+    """The reference's step-level methods on a video stage (ip.py:2042-2289 with 5-D shapes): the base Unet3D stage of the tiny video
+    cascade run by p_sample_loop with the recorded draws of the reference's sample() — plain, with prompt frames, with video inpainting."""
+    from step_api_case import recorded_noise
+
+    o = torch.load(os.path.join(GOLDEN, "sample_tiny_video_options.pt"), weights_only=False)
+    g = torch.load(os.path.join(GOLDEN, o["weights_from"]), weights_only=False)
+    run = g if tag == "plain" else o["runs"][tag]
+    kw = {} if tag == "plain" else dict(run["kwargs"])
+    imagen = _cascade(g, timesteps=g["timesteps"])
+    from imagen_pytorch_amd import imagen as imagen_mod
+    monkeypatch.setattr(imagen_mod.Imagen, "device", property(lambda self: torch.device("cpu")))
+    T, B, Fr, S = g["timesteps"], g["text_embeds"].shape[0], g["frames"], g["image_sizes"][0]
+    R = kw.get("inpaint_resample_times", 1)
+    draws = [run["noise"][("init", 0)]]
+    for i in range(T):
+        for r in reversed(range(R)):
+            if tag == "inpaint":
+                draws.append(run["noise"][("inpaint", 0, i, r)])
+                draws.append(run["noise"][("step", 0, i, r)])
+                if r > 0 and i < T - 1:
+                    draws.append(run["noise"][("renoise", 0, i, r)])
+            else:
+                draws.append(run["noise"][("step", 0, i)])
+    te = g["text_embeds"]
+    with recorded_noise(monkeypatch, draws, torch.device("cpu")) as left:
+        img = imagen.p_sample_loop(imagen.unets[0], (B, 3, Fr, S, S), noise_scheduler=imagen.noise_schedulers[0], text_embeds=te,
+                                   text_mask=torch.any(te != 0., dim=-1), cond_scale=g["cond_scale"], use_tqdm=False, **kw)
+        assert not left
+    assert nerr(img, run["outputs"][0]) < 2e-2
