@@ -98,7 +98,11 @@ __device__ __attribute__((aligned(16))) float kZeros8[8] = {0.f, 0.f, 0.f, 0.f, 
 // LDS hand-over between the roles: LDS traffic of this wave retired, then the workgroup barrier.  Deliberately NOT
 // __syncthreads(): global loads stay in flight across it.
 __device__ __forceinline__ void lds_barrier() {
+#ifdef IMAGEN_EMUL   // CPU functional emulation (tools/emul): memory is coherent there, the barrier is the fiber rendezvous
+  __syncthreads();
+#else
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
 }
 
 // -DIGEMM_TRACE (tools/igemm_probe.py --timeline builds and loads a separate library): with dbg bit 128, lane 0 of the first
@@ -518,7 +522,9 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
     // <2,1,1,4,4,18,false>, 46 in its GEN twin — none with this block).  The empty asm makes the thread id opaque inside the tile
     // loop, so nothing derived from it can be hoisted; the names shadow the outer ones for the rest of the epilogue.
     int tid_e = threadIdx.x;
+#ifndef IMAGEN_EMUL
     asm volatile("" : "+v"(tid_e));
+#endif
     const int half = (tid_e >> 5) & 1, l31 = tid_e & 31;
     const int wave_e = __builtin_amdgcn_readfirstlane(tid_e >> 6);
     const int wm = wave_e / WN, wn = wave_e % WN;

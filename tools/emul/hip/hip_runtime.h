@@ -1,0 +1,112 @@
+// CPU functional emulation of the HIP device environment for csrc/igemm.hip (TEST INFRASTRUCTURE: tools/emul/README.md).
+// Included INSTEAD of <hip/hip_runtime.h> (-Itools/emul ahead of the ROCm include path, -DIMAGEN_EMUL): the kernel source is
+// compiled as plain host C++ by clang, every workgroup runs as 512 cooperative fibers of one OS thread (emul_runtime.cpp), and the
+// device builtins the kernel uses are restated here from the ISA documentation:
+//   v_mfma_f32_32x32x16_f16   A: lane l holds row l%32, k = 8*(l/32) .. +7;  B: lane l holds column l%32, k = 8*(l/32) .. +7;
+//                             D: register r of lane l is element (row 8*(r/4) + 4*(l/32) + r%4, column l%32)
+//   v_permlane32_swap         the upper half-wave of the first operand is exchanged with the lower half-wave of the second
+//   ds_bpermute-style shuffles, s_barrier, readfirstlane (identity: only ever applied to wave-uniform values here)
+// Nothing here is tuned and nothing of it ships: it exists so that a kernel change can be executed and compared WITHOUT a GPU.
+// The restatement is validated by the product build itself: the kernels are known-good on MI355X (tests/test_igemm_cfgs_gpu.py), so
+// the emulated product build has to reproduce fp32 torch on the same cases (tests/test_igemm_emulated.py) before anything else is
+// concluded from it.
+#pragma once
+#ifndef IMAGEN_EMUL
+#error "tools/emul/hip/hip_runtime.h is the emulation shim: compile with -DIMAGEN_EMUL"
+#endif
+#include <algorithm>
+#include <cmath>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+#define __global__
+#define __device__
+#define __host__
+#define __forceinline__ inline __attribute__((always_inline))
+#define __launch_bounds__(...)
+#define __shared__
+
+struct emul_uint3 { unsigned x, y, z; };
+struct dim3 {
+  unsigned x, y, z;
+  dim3(unsigned x_ = 1, unsigned y_ = 1, unsigned z_ = 1) : x(x_), y(y_), z(z_) {}
+};
+struct alignas(16) float4 { float x, y, z, w; };
+struct alignas(8) float2 { float x, y; };
+struct alignas(8) uint2 { unsigned x, y; };
+struct alignas(16) uint4 { unsigned x, y, z, w; };
+static inline uint4 make_uint4(unsigned x, unsigned y, unsigned z, unsigned w) { return uint4{x, y, z, w}; }
+static inline float4 make_float4(float x, float y, float z, float w) { return float4{x, y, z, w}; }
+static inline float2 make_float2(float x, float y) { return float2{x, y}; }
+using std::max;
+using std::min;
+
+typedef int hipError_t;
+typedef void* hipStream_t;
+enum { hipSuccess = 0 };
+enum { hipDeviceAttributeMultiprocessorCount = 1, hipFuncAttributeMaxDynamicSharedMemorySize = 2 };
+static inline hipError_t hipGetLastError() { return hipSuccess; }
+static inline const char* hipGetErrorString(hipError_t) { return "emulated"; }
+static inline hipError_t hipGetDevice(int* d) { *d = 0; return hipSuccess; }
+hipError_t hipDeviceGetAttribute(int* v, int attr, int dev);   // emul_runtime.cpp: IMAGEN_EMUL_CUS compute units (default 2)
+static inline hipError_t hipFuncSetAttribute(const void*, int, int) { return hipSuccess; }
+template <class K> static inline hipError_t hipOccupancyMaxActiveBlocksPerMultiprocessor(int* nb, K, int, size_t) { *nb = 2; return hipSuccess; }
+
+namespace emul {
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef float f16v __attribute__((ext_vector_type(16)));
+const emul_uint3& thread_idx();
+const emul_uint3& block_idx();
+const emul_uint3& block_dim();
+const emul_uint3& grid_dim();
+void workgroup_barrier();                       // s_barrier / __syncthreads
+void wave_exchange(const void* mine, void* all, size_t bytes);   // every lane of the wave deposits `bytes`, then sees all 64 deposits
+void wave_release();                            // second half of the rendezvous: nobody overwrites the deposits before all have read
+f16v mfma_f32_32x32x16_f16(h8 a, h8 b, f16v c);
+u32x2 permlane32_swap(unsigned old_v, unsigned src_v);
+void launch(dim3 grid, dim3 block, size_t lds_bytes, void (*body)(void*), void* arg, char* lds, size_t lds_cap);
+
+template <class T> static inline T shfl_xor(T v, int mask) {
+  T all[64];
+  wave_exchange(&v, all, sizeof(T));
+  const T r = all[(thread_idx().x & 63) ^ mask];
+  wave_release();
+  return r;
+}
+template <class T> static inline T shfl(T v, int src) {
+  T all[64];
+  wave_exchange(&v, all, sizeof(T));
+  const T r = all[src & 63];
+  wave_release();
+  return r;
+}
+}  // namespace emul
+
+// one LDS image per translation unit; a block-scope `extern __shared__ char smem[]` of a kernel in this TU's unnamed namespace binds to it
+namespace { alignas(16) char smem[192 * 1024]; }
+
+#define threadIdx (emul::thread_idx())
+#define blockIdx (emul::block_idx())
+#define blockDim (emul::block_dim())
+#define gridDim (emul::grid_dim())
+#define __syncthreads() emul::workgroup_barrier()
+#define __shfl_xor(v, m) emul::shfl_xor((v), (m))
+#define __shfl(v, s) emul::shfl((v), (s))
+#define __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, x, y, z) emul::mfma_f32_32x32x16_f16((a), (b), (c))
+#define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) emul::permlane32_swap((a), (b))
+#define __builtin_amdgcn_readfirstlane(v) (v)
+#define __builtin_amdgcn_sched_barrier(m) ((void)0)
+#define __builtin_amdgcn_s_getpc() (0ull)
+#define __builtin_amdgcn_rcpf(v) (1.0f / (v))
+#define __builtin_amdgcn_rsqf(v) (1.0f / sqrtf(v))
+#define __builtin_amdgcn_exp2f(v) exp2f(v)
+
+// hipLaunchKernelGGL(kernel, grid, block, lds, stream, params): the kernels of this library take ONE by-value params struct
+#define hipLaunchKernelGGL(kern, grid, block, lds, stream, params)                                   \
+  do {                                                                                               \
+    struct EmulCall { decltype(kern) k; std::remove_cv_t<std::remove_reference_t<decltype(params)>> p; } call_{kern, params}; \
+    emul::launch(grid, block, lds, [](void* a) { auto* c = static_cast<EmulCall*>(a); c->k(c->p); }, &call_, smem, sizeof(smem)); \
+  } while (0)
