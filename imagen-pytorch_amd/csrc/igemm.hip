@@ -140,6 +140,13 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
   const bool producer = tid >= 256;   // wave-uniform role
   const int rtid = tid & 255;         // thread index inside the role
   const unsigned warm = imagen_code_warm(((unsigned)p.dbg >> 16) << 8, tid, 512);   // (code size / 256 rides in the upper half of dbg)
+#ifdef IGEMM_PRIO
+  // A/B builds only (-DIGEMM_PRIO=1: consumers, =2: producers): a static issue priority for one role.  The two roles of a SIMD's waves
+  // share its VALU issue bandwidth by priority, then age (MI355X_MICROARCH.md, "Two waves per SIMD", item 4: one s_setprio for the
+  // losing half, no flips).  Compile-time on purpose: as a run-time switch (two scalar branches here) it changed the register
+  // allocation of the whole kernel at the 128-VGPR budget — spill instructions inside the tile loops 342 -> 474 (tools/scratch_report.py).
+  if (IGEMM_PRIO == 1 ? !producer : producer) __builtin_amdgcn_s_setprio(1);
+#endif
 
   // ---- the tile list of this workgroup
   const int tilesX = (p.OW + p.TW - 1) / p.TW;

@@ -99,6 +99,7 @@ namespace { alignas(16) char smem[192 * 1024]; }
 #define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) emul::permlane32_swap((a), (b))
 #define __builtin_amdgcn_readfirstlane(v) (v)
 #define __builtin_amdgcn_sched_barrier(m) ((void)0)
+#define __builtin_amdgcn_s_setprio(n) ((void)0)
 #define __builtin_amdgcn_s_getpc() (0ull)
 #define __builtin_amdgcn_rcpf(v) (1.0f / (v))
 #define __builtin_amdgcn_rsqf(v) (1.0f / sqrtf(v))
