@@ -124,8 +124,15 @@ __device__ __forceinline__ void lds_barrier() {
 // GEN = false instantiation for plain NHWC outputs (optionally with ssq_out or the post_pa output-side prologue): its epilogue is
 // one branch-free block — the generic one tests act_out / out_mode / addend / res per element and quad, ~100 scalar branches
 // per tile that were measured (s_memtime stamps) at 7k of a tile's 13k cycles on the 32-channel 256^2 layers.
+// (A/B builds: -DIGEMM_ONE_WG gives every instantiation the 256-VGPR budget of ONE workgroup per CU — no spills, room for the deep
+// weight rings -DIGEMM_LA1 / -DIGEMM_LA2 that only cost registers at the product's 128 — at half the waves per SIMD)
+#ifdef IGEMM_ONE_WG
+#define IGEMM_MIN_WAVES(MI, NI) 2
+#else
+#define IGEMM_MIN_WAVES(MI, NI) ((MI) * (NI) <= 2 ? 4 : 2)
+#endif
 template <int MI, int NI, int WM, int WN, int G, int KSC, bool GEN>
-__global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(const ImagenIgemmParams p) {
+__global__ __launch_bounds__(512, IGEMM_MIN_WAVES(MI, NI)) void igemm_kernel(const ImagenIgemmParams p) {
   static_assert(WM * WN == 4, "4 consumer waves per workgroup");
   constexpr int BN = 32 * NI * WN;
   constexpr int KC = Geo<G>::KC;

@@ -1,6 +1,6 @@
 #!/bin/bash
 # Builds the CPU functional emulation of csrc/igemm.hip: imagen-pytorch_amd/libimagen_emul.so, and with "remat" as the first argument
-# libimagen_emul_remat.so (-DIGEMM_EPI_REMAT).  Host clang (the ROCm toolchain's), no GPU code; skipped when the library is newer than
+# libimagen_emul_remat.so (-DIGEMM_EPI_REMAT); `NAME -Dflags...` builds libimagen_emul_NAME.so with those flags.  Host clang (the ROCm toolchain's), no GPU code; skipped when the library is newer than
 # its sources.  See tools/emul/README.md.
 set -e
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
@@ -9,7 +9,8 @@ CL=/opt/rocm/lib/llvm/bin/clang++
 OUT=$P/build/emul
 mkdir -p $OUT
 TAG=""; DEFS=""
-if [ "${1:-}" = "remat" ]; then TAG="_remat"; DEFS="-DIGEMM_EPI_REMAT"; fi
+if [ "${1:-}" = "remat" ]; then TAG="_remat"; DEFS="-DIGEMM_EPI_REMAT";
+elif [ -n "${1:-}" ]; then TAG="_$1"; shift; DEFS="$*"; fi       # any other name: the remaining arguments are the -D flags of that variant
 LIB=$P/libimagen_emul$TAG.so
 SRCS="$P/csrc/igemm.hip $P/csrc/common.h $ROOT/include/imagen_hip.h $ROOT/tools/emul/emul_runtime.cpp $ROOT/tools/emul/hip/hip_runtime.h $ROOT/tools/emul/build_emul_lib.sh"
 if [ -f "$LIB" ]; then

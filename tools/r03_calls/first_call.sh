@@ -1,14 +1,16 @@
 #!/bin/bash
 # First GPU call of round 3 (prepared at the end of round 2, when the GPU budget was spent): everything that was written or found
 # without hardware, in one call.  Build both libraries BEFORE the call, in the build container (the .so files travel with the snapshot):
-#     python -c "import __graft_entry__ as g; g.build()" && bash tools/build_remat_lib.sh
+#     python -c "import __graft_entry__ as g; g.build()" && bash tools/build_remat_lib.sh && \
+#         bash tools/build_variant_lib.sh onewg -DIGEMM_ONE_WG -DIGEMM_LA1=12 -DIGEMM_LA2=10
 #     gpurun --timeout 1500 -- 'bash tools/r03_calls/first_call.sh'
-# Output: gpurun_out/r03_first/*.log|json.  Budget: ~15 GPU-minutes.
+# Output: gpurun_out/r03_first/*.log|json.  Budget: ~18 GPU-minutes.
 set -u
 cd "$(dirname "$0")/../.."
 OUT=gpurun_out/r03_first
 mkdir -p $OUT
 REMAT=$PWD/imagen-pytorch_amd/libimagen_hip_remat.so
+ONEWG=$PWD/imagen-pytorch_amd/libimagen_hip_onewg.so      # 256-VGPR budget (one workgroup per CU), weight rings 12 / 10 deep: spill-free everywhere
 B="python bench.py --steps 8 --warmup 4 --no-roofline --no-cpu-baseline"
 
 # 1. the tests that have not met hardware (ElucidatedImagen sampler options, upsample combiner)
@@ -23,12 +25,18 @@ else
   echo "no $REMAT: run tools/build_remat_lib.sh before the call" | tee $OUT/remat_parity.log
 fi
 
+if [ -f "$ONEWG" ]; then
+  IMAGEN_LIB_PATH=$ONEWG timeout 300 python -m pytest tests/test_igemm_cfgs_gpu.py tests/test_bench_shapes_gpu.py -q -x > $OUT/onewg_parity.log 2>&1
+  tail -n 3 $OUT/onewg_parity.log
+fi
+
 # 3. bench A/B, same box, same call (boxes of the pool differ by +-20 %): product | remat | persistent grids below the resident slot count
 timeout 240 $B > $OUT/bench_default.json 2> $OUT/bench_default.err
 [ -f "$REMAT" ] && IMAGEN_LIB_PATH=$REMAT timeout 240 $B > $OUT/bench_remat.json 2> $OUT/bench_remat.err
 for pct in 94 88 80; do
   IMAGEN_GRID_PCT=$pct timeout 240 $B > $OUT/bench_grid$pct.json 2> $OUT/bench_grid$pct.err
 done
+[ -f "$ONEWG" ] && IMAGEN_LIB_PATH=$ONEWG timeout 240 $B > $OUT/bench_onewg.json 2> $OUT/bench_onewg.err
 IMAGEN_IGEMM_DBG=32 timeout 240 $B > $OUT/bench_one_tile_per_wg.json 2> $OUT/bench_one_tile_per_wg.err   # igemm grids non-persistent: other lanes' launches interleave as slots free up
 [ -f "$REMAT" ] && IMAGEN_LIB_PATH=$REMAT IMAGEN_GRID_PCT=88 timeout 240 $B > $OUT/bench_remat_grid88.json 2> $OUT/bench_remat_grid88.err
 timeout 240 $B > $OUT/bench_default_again.json 2> $OUT/bench_default_again.err      # drift of the box over the call
