@@ -506,8 +506,7 @@ class Imagen(nn.Module):
     def _step_conditioning_checks(self, unet, cond_video_frames, post_cond_video_frames, cond_scale):
         assert not (cond_scale != 1. and not self.can_classifier_guidance), \
             'imagen was not trained with conditional dropout, and thus one cannot use classifier free guidance (cond_scale anything other than 1)'
-        assert isinstance(unet, Unet3D) or (cond_video_frames is None and post_cond_video_frames is None), \
-            'cond_video_frames / post_cond_video_frames condition Unet3D stages only'
+        # (prompt frames given to an image cascade are ignored, as in the reference: ip.py:2057-2070 builds video_kwargs only if is_video)
 
     @torch.no_grad()
     def p_mean_variance(self, unet, x, t, *, noise_scheduler, text_embeds=None, text_mask=None, cond_images=None, cond_video_frames=None,

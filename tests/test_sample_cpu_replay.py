@@ -294,11 +294,14 @@ def test_reference_step_level_api(cpu_backend, monkeypatch):
     fused = imagen.sample(text_embeds=g["text_embeds"], cond_scale=g["cond_scale"], use_tqdm=False, return_all_unet_outputs=True,
                           noise_fn=lambda tag, shape: g["noise"][tag], device="cpu")
     assert max(nerr(a, b) for a, b in zip(outs, fused)) < 5e-3
-    # out-of-scope conditioning is refused, not ignored
+    # prompt frames handed to an image cascade are ignored, as in the reference (ip.py:2057-2070: video_kwargs only if is_video)
     sched = imagen.noise_schedulers[0]
     x = torch.zeros(1, 3, 16, 16)
-    with pytest.raises(NotImplementedError):
-        imagen.p_sample(imagen.unets[0], x, torch.ones(1), t_next=torch.zeros(1), noise_scheduler=sched, cond_video_frames=x[:, :, None])
+    te1 = g["text_embeds"][:1]
+    kw = dict(t=torch.ones(1), t_next=torch.full((1,), 0.5), noise_scheduler=sched, text_embeds=te1, text_mask=torch.any(te1 != 0., dim=-1))
+    (m0, _, _), x0 = imagen.p_mean_variance(imagen.unets[0], x, **kw)
+    (m1, _, _), x1 = imagen.p_mean_variance(imagen.unets[0], x, cond_video_frames=x[:, :, None], **kw)
+    assert torch.equal(m0, m1) and torch.equal(x0, x1)
     with pytest.raises(AssertionError):      # a conditioning image for a unet built without cond_images_channels (ip.py:1555)
         imagen.p_sample(imagen.unets[0], x, torch.ones(1), t_next=torch.zeros(1), noise_scheduler=sched, cond_images=x)
 
