@@ -32,9 +32,19 @@ __device__ __forceinline__ void cd_static_for(F&& f) {
 }
 
 // one 1-KiB direct-to-LDS copy: lane l writes LDS bytes [dst + 16 l, +16) from its own global address
+#ifdef IMAGEN_EMUL   // CPU functional emulation (tools/emul): the copy is queued and lands at the covering vmcnt wait, in issue order
+__device__ __forceinline__ void cd_dma16(const void* gsrc, unsigned lds_dst) { emul::dma16(gsrc, lds_dst, smem); }
+#define CD_LDS_BASE(ptr) 0u
+#define CD_VM0_BARRIER() do { emul::wait_vm(0); __syncthreads(); } while (0)
+#define CD_LGKM0_BARRIER() __syncthreads()
+#else
 __device__ __forceinline__ void cd_dma16(const void* gsrc, unsigned lds_dst) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory");
 }
+#define CD_LDS_BASE(ptr) ((unsigned)(size_t)(__attribute__((address_space(3))) char*)(ptr))
+#define CD_VM0_BARRIER() asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory")
+#define CD_LGKM0_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
 // s_waitcnt vmcnt(n) only (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14]) + a compiler-level fence
 #define CD_WAIT_VM(n)                                                                         \
   do {                                                                                        \
@@ -89,7 +99,7 @@ __global__ __launch_bounds__(256, (MI * NI <= 2 ? 3 : 2)) void conv_dma_kernel(c
     tc.n0 = nt * BN;
   }
   const int NC = p.Cin_pad >> 5;
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned lds0 = CD_LDS_BASE(smem);
   const unsigned ring0 = lds0 + 2 * ABUF + wave * (RW * SLOTW);
   float* const ep_red = reinterpret_cast<float*>(smem + 2 * ABUF + 4 * RW * SLOTW);
 
@@ -207,13 +217,17 @@ __global__ __launch_bounds__(256, (MI * NI <= 2 ? 3 : 2)) void conv_dma_kernel(c
     // (a direct-to-LDS load into the epilogue scratch, 4 bytes per lane: an asm load with a VGPR destination would land in a register
     // the compiler has long since reused)
     const unsigned sink = __builtin_amdgcn_readfirstlane(lds0 + 2 * ABUF + 4 * RW * SLOTW);   // 256 bytes, every wave the same (never read)
+#ifndef IMAGEN_EMUL   // (a cache warm-up: nothing to emulate)
     for (size_t off = (size_t)tid * 128; off < lim; off += 256 * 128)
       asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(base + off), "s"(sink) : "memory");
+#else
+    (void)base; (void)lim; (void)sink;
+#endif
   }
   dma_acts(0, false);
 #pragma unroll
   for (int j = 0; j < RW - 1; ++j) dma_weights(j);
-  asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  CD_VM0_BARRIER();
   cd_static_for<NS>([&](auto kc) __attribute__((always_inline)) {   // (set PF is overwritten by the first loop step; read here for the probe builds)
     constexpr int k = decltype(kc)::value;
     read_frags(F[k % NS], 0, k / 2, (k / 2) % RW, k % 2);
@@ -259,7 +273,7 @@ __global__ __launch_bounds__(256, (MI * NI <= 2 ? 3 : 2)) void conv_dma_kernel(c
         if constexpr (g == 0) {
           if constexpr (new_stage && !(DBG & (64 | 1 | 2))) CD_WAIT_VM(N);
           // chunk boundary: every wave's part of the next halo tile has landed, everybody is done reading this one
-          if constexpr (kk == 18 && !(DBG & 32)) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+          if constexpr (kk == 18 && !(DBG & 32)) CD_LGKM0_BARRIER();
         }
         cd_static_for<per>([&](auto fc) __attribute__((always_inline)) {
           constexpr int f = g * per + decltype(fc)::value;

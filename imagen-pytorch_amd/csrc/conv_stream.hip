@@ -37,15 +37,26 @@ constexpr int CS_EP_PAR = 5 * 32 + 8 * 32 * 2;   // floats (conv_epilogue.h: 5 *
 
 typedef unsigned cs_u32x4 __attribute__((ext_vector_type(4)));
 
+#ifdef IMAGEN_EMUL   // CPU functional emulation (tools/emul): the copy is queued and lands at the covering vmcnt wait, in issue order
+__device__ __forceinline__ void cs_dma16(const void* gsrc, unsigned lds_dst) { emul::dma16(gsrc, lds_dst, smem); }
+#define CS_LDS_BASE(ptr) 0u
+#else
 __device__ __forceinline__ void cs_dma16(const void* gsrc, unsigned lds_dst) {   // lane l -> LDS bytes [dst + 16 l, +16)
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory");
 }
+#define CS_LDS_BASE(ptr) ((unsigned)(size_t)(__attribute__((address_space(3))) char*)(ptr))
+#endif
 
 constexpr size_t cs_lds_bytes(int nch) {
   return (size_t)2 * nch * CS_ABUF + (size_t)nch * CS_WCH + (size_t)(CS_EP_RED + CS_EP_PAR) * sizeof(float) + (size_t)2 * 2 * 64 * sizeof(float) + 16;
 }
 
 __device__ __forceinline__ void cs_wait_vm(int n) {   // s_waitcnt vmcnt(min(n, 12)): fewer outstanding than allowed is always safe
+#ifdef IMAGEN_EMUL   // the allowance n counts this lane's output STORES behind the copies; the emulation queues copies only, so it drains them all
+  (void)n;
+  emul::wait_vm(0);
+  return;
+#else
   switch (n < 12 ? n : 12) {
     case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
@@ -61,6 +72,7 @@ __device__ __forceinline__ void cs_wait_vm(int n) {   // s_waitcnt vmcnt(min(n, 
     case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
     default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
   }
+#endif
 }
 
 // NCH: 32-channel inputs (1: x1 only; 2: x1 | x2).  PRO: Block prologue on the inputs.  GEN: generic epilogue (conv_epilogue.h).
@@ -85,7 +97,7 @@ __global__ __launch_bounds__(64 * CS_NW, NCH == 1 ? 4 : 2) void conv_stream_kern
   float* const ep_red = reinterpret_cast<float*>(wlds + NCH * CS_WCH);
   float* const ep_par = ep_red + CS_EP_RED;                      // [bias 32 | post_pa 32 | post_ps 32 | ...]
   float* const aff = ep_par + CS_EP_PAR;                         // [2 tiles][pa 64 | ps 64]
-  const unsigned lds0 = (unsigned)(size_t)(__attribute__((address_space(3))) char*)smem;
+  const unsigned lds0 = CS_LDS_BASE(smem);
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);

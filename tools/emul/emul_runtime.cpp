@@ -15,11 +15,13 @@
 namespace emul {
 namespace {
 constexpr size_t kStack = 1 << 20;
+struct Dma { const void* src; char* dst; };
 struct Fiber {
   ucontext_t ctx;
   char* stack = nullptr;
   emul_uint3 tid{0, 0, 0};
   bool done = false;
+  std::deque<Dma> dma;            // this lane's direct-to-LDS copies in flight, oldest first
 };
 struct Group {
   int size = 0, count = 0;
@@ -98,6 +100,48 @@ u32x2 permlane32_swap(unsigned old_v, unsigned src_v) {
   return r;
 }
 
+int update_dpp(int old_v, int src_v, int ctrl, int row_mask, int, bool) {
+  int all[64];
+  wave_exchange(&src_v, all, sizeof(int));
+  const int l = fibers[cur].tid.x & 63, row = l >> 4, i = l & 15;
+  int r = old_v;
+  if ((row_mask >> row) & 1) {
+    if (ctrl >= 0x111 && ctrl <= 0x11f) {                 // row_shr:n — lane i of a 16-lane row reads lane i - n of the same row
+      const int n = ctrl - 0x110;
+      if (i >= n) r = all[l - n];
+    } else if (ctrl == 0x142) {                            // row_bcast:15 — lane 15 of the previous row to every lane of this row
+      if (row > 0) r = all[16 * row - 1];
+    } else {
+      fprintf(stderr, "emul: DPP control %#x is not emulated\n", ctrl);
+      abort();
+    }
+  }
+  wave_release();
+  return r;
+}
+int readlane(int v, int lane) {
+  int all[64];
+  wave_exchange(&v, all, sizeof(int));
+  const int r = all[lane & 63];
+  wave_release();
+  return r;
+}
+void dma16(const void* gsrc, unsigned lds_dst, char* lds) {
+  Fiber& f = fibers[cur];
+  f.dma.push_back(Dma{gsrc, lds + lds_dst + 16 * (f.tid.x & 63)});
+}
+void wait_vm(int n) {
+  Fiber& f = fibers[cur];
+  while ((int)f.dma.size() > n) {
+    memcpy(f.dma.front().dst, f.dma.front().src, 16);
+    f.dma.pop_front();
+  }
+}
+void s_waitcnt(int imm) {
+  const int vm = (imm & 15) | (((imm >> 14) & 3) << 4);
+  if (vm < 63) wait_vm(vm);
+}
+
 void launch(dim3 grid, dim3 block, size_t lds_bytes, void (*body)(void*), void* arg, char* lds, size_t lds_cap) {
   if (lds_bytes > lds_cap) { fprintf(stderr, "emul: %zu bytes of LDS requested, %zu available\n", lds_bytes, lds_cap); abort(); }
   const int n = (int)block.x;
@@ -125,6 +169,7 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, void (*body)(void*), void* 
       Fiber& f = fibers[i];
       f.tid = emul_uint3{(unsigned)i, 0, 0};
       f.done = false;
+      f.dma.clear();
       getcontext(&f.ctx);
       f.ctx.uc_stack.ss_sp = f.stack;
       f.ctx.uc_stack.ss_size = kStack;
@@ -145,7 +190,14 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, void (*body)(void*), void* 
       cur = runq.front();
       runq.pop_front();
       swapcontext(&sched_ctx, &fibers[cur].ctx);
-      if (fibers[cur].done) ++done;
+      if (fibers[cur].done) {
+        ++done;
+        if (!fibers[cur].dma.empty()) {
+          fprintf(stderr, "emul: thread %u of workgroup %u ended with %zu direct-to-LDS copies in flight (they would land in another "
+                          "workgroup's LDS)\n", fibers[cur].tid.x, b, fibers[cur].dma.size());
+          abort();
+        }
+      }
     }
     cur = -1;
   }
@@ -168,20 +220,21 @@ void imagen_set_error(const char* fmt, ...) {
 }
 unsigned imagen_kernel_code_bytes(const char*) { return 0; }   // no instruction warm-up in the emulation
 int launch_igemm(const ImagenIgemmParams* p, hipStream_t s);
-int imagen_conv_lds_num_configs() { return 0; }                // only the wave-specialised family (igemm.hip) is emulated
+#define WEAK __attribute__((weak))   // the other families' translation units override these when they are part of the emulated library
+int imagen_conv_lds_num_configs() { return 0; }                // (conv_lds.hip is not emulated)
 int imagen_conv_lds_config_info(int, int*, int*, int*) { return -1; }
 int imagen_conv_lds_stage_slots(int, int, int) { return -1; }
 long imagen_conv_lds_lds_bytes(int, int, int, int, int) { return -1; }
 int launch_conv_lds(const ImagenIgemmParams*, int, hipStream_t) { return -1; }
-int imagen_conv_dma_num_configs() { return 0; }
-int imagen_conv_dma_config_info(int, int*, int*, int*) { return -1; }
-long imagen_conv_dma_lds_bytes(int, int, int, int, int) { return -1; }
-int imagen_conv_dma_ring(int) { return 0; }
-int launch_conv_dma(const ImagenIgemmParams*, int, hipStream_t) { return -1; }
-int imagen_conv_stream_num_configs() { return 0; }
-int imagen_conv_stream_config_info(int, int*, int*, int*) { return -1; }
-long imagen_conv_stream_lds_bytes(int, int, int, int, int) { return -1; }
-int launch_conv_stream(const ImagenIgemmParams*, int, hipStream_t) { return -1; }
+WEAK int imagen_conv_dma_num_configs() { return 0; }
+WEAK int imagen_conv_dma_config_info(int, int*, int*, int*) { return -1; }
+WEAK long imagen_conv_dma_lds_bytes(int, int, int, int, int) { return -1; }
+WEAK int imagen_conv_dma_ring(int) { return 0; }
+WEAK int launch_conv_dma(const ImagenIgemmParams*, int, hipStream_t) { return -1; }
+WEAK int imagen_conv_stream_num_configs() { return 0; }
+WEAK int imagen_conv_stream_config_info(int, int*, int*, int*) { return -1; }
+WEAK long imagen_conv_stream_lds_bytes(int, int, int, int, int) { return -1; }
+WEAK int launch_conv_stream(const ImagenIgemmParams*, int, hipStream_t) { return -1; }
 
 extern "C" int imagen_abi_version(void) { return IMAGEN_ABI_VERSION; }
 extern "C" const char* imagen_last_error(void) { return g_err; }

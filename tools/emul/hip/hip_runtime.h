@@ -67,6 +67,14 @@ void wave_exchange(const void* mine, void* all, size_t bytes);   // every lane o
 void wave_release();                            // second half of the rendezvous: nobody overwrites the deposits before all have read
 f16v mfma_f32_32x32x16_f16(h8 a, h8 b, f16v c);
 u32x2 permlane32_swap(unsigned old_v, unsigned src_v);
+int update_dpp(int old_v, int src_v, int ctrl, int row_mask, int bank_mask, bool bound_ctrl);   // row_shr:1..15 and row_bcast:15 only
+int readlane(int v, int lane);
+// direct-to-LDS copies (global_load_lds_dwordx4: lane l writes 16 bytes at lds_dst + 16 l) with the hardware's ordering: a copy lands
+// when a covering s_waitcnt vmcnt(n) of ITS wave-lane retires it — in issue order, the n youngest may stay in flight.  A kernel that
+// reads LDS before the covering wait sees the poison (or the previous tile), exactly as it would see stale bytes on the GPU.
+void dma16(const void* gsrc, unsigned lds_dst, char* lds);
+void wait_vm(int n);
+void s_waitcnt(int imm);                        // gfx9 encoding: vmcnt = imm[3:0] | imm[15:14] << 4; the other counters need no emulation
 void launch(dim3 grid, dim3 block, size_t lds_bytes, void (*body)(void*), void* arg, char* lds, size_t lds_cap);
 
 template <class T> static inline T shfl_xor(T v, int mask) {
@@ -92,6 +100,8 @@ namespace { alignas(16) char smem[192 * 1024]; }
 #define blockIdx (emul::block_idx())
 #define blockDim (emul::block_dim())
 #define gridDim (emul::grid_dim())
+#define __expf(v) expf(v)   // HIP device intrinsics the kernels call by name (glibc declares, but does not export, these names)
+#define __logf(v) logf(v)
 #define __syncthreads() emul::workgroup_barrier()
 #define __shfl_xor(v, m) emul::shfl_xor((v), (m))
 #define __shfl(v, s) emul::shfl((v), (s))
@@ -100,6 +110,9 @@ namespace { alignas(16) char smem[192 * 1024]; }
 #define __builtin_amdgcn_readfirstlane(v) (v)
 #define __builtin_amdgcn_sched_barrier(m) ((void)0)
 #define __builtin_amdgcn_s_setprio(n) ((void)0)
+#define __builtin_amdgcn_s_waitcnt(imm) emul::s_waitcnt(imm)
+#define __builtin_amdgcn_update_dpp(o, s, ctrl, rm, bm, bc) emul::update_dpp((o), (s), (ctrl), (rm), (bm), (bc))
+#define __builtin_amdgcn_readlane(v, l) emul::readlane((v), (l))
 #define __builtin_amdgcn_s_getpc() (0ull)
 #define __builtin_amdgcn_rcpf(v) (1.0f / (v))
 #define __builtin_amdgcn_rsqf(v) (1.0f / sqrtf(v))

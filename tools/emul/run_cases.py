@@ -40,7 +40,30 @@ CASES = {
     "cfg10_linear": dict(B=1, H=1, W=100, C1=256, Cout=128, K=1, G=16, cfg=(10, 1, 64), prologue="ln", act_in="none", act_out="gelu"),
     "cfg14_addend": dict(B=2, H=8, W=16, C1=128, C2=64, Cout=128, K=1, G=8, cfg=(14, 4, 16), prologue="none", act_in="none", epilogue="addend", ssq_out=True),
     "cfg13_resconv": dict(B=1, H=16, W=32, C1=32, C2=32, Cout=32, K=1, G=8, cfg=(13, 2, 64), prologue="none", act_in="none", epilogue="addend", ssq_out=True),
+    # the all-DMA family (conv_dma.hip; direct-to-LDS copies land at the covering vmcnt wait, in issue order) and the streaming family
+    # (conv_stream.hip: persistent tile walk, in-place LDS prologue); cfg = "dma:<tile px>x<tile couts>" | "stream" is resolved at run time
+    "dma_64x128_gca": dict(B=2, H=16, W=16, C1=64, Cout=128, K=3, G=4, cfg="dma:64x128", prologue="none", act_in="none", gca=True),
+    "dma_128x128_post": dict(B=1, H=16, W=32, C1=128, Cout=128, K=3, G=4, cfg="dma:128x128", prologue="none", act_in="none", epilogue="post"),
+    "dma_256x32_ssq": dict(B=1, H=20, W=36, C1=32, Cout=32, K=3, G=4, cfg="dma:256x32", prologue="none", act_in="none", ssq_out=True),
+    "stream_raw": dict(B=2, H=40, W=36, C1=32, Cout=32, K=3, G=4, cfg="stream", prologue="none", act_in="none", ssq_out=True),
+    "stream_pro_concat_post": dict(B=2, H=40, W=36, C1=32, C2=32, Cout=32, K=3, G=4, cfg="stream", prologue="ssq", affine=False, epilogue="post"),
+    "stream_pro_affine_ragged": dict(B=3, H=27, W=45, C1=32, Cout=24, K=3, G=4, cfg="stream", prologue="ssq", affine=True),
 }
+
+
+def resolve_cfg(ops, spec, kw):
+    """'stream' | 'dma:<tp>x<bn>' -> (cfg id, th, tw) of this library (family cfg ids depend on which families a library holds)."""
+    if not isinstance(spec, str):
+        return spec
+    if spec == "stream":
+        return (ops.stream_cfg(), 16, 16)
+    tp, bn = map(int, spec.split(":")[1].split("x"))
+    for i, (t, b, g, fam) in enumerate(ops.cfg_table()):
+        if fam == 2 and (t, b) == (tp, bn):
+            sh = ops.launchable_shapes(i, kw["H"], kw["W"], 3, 3, 1)
+            if sh:
+                return (i, sh[0][2], sh[0][3])
+    raise KeyError(spec)
 
 
 def main():
@@ -74,7 +97,7 @@ def main():
 
         ops.act_to_nchw, ops.igemm = grab, grab_y
         try:
-            r = run_case(ops, dev, **kw)
+            r = run_case(ops, dev, **dict(kw, cfg=resolve_cfg(ops, kw["cfg"], kw)))
         finally:
             ops.act_to_nchw, ops.igemm = real_to_nchw, real_igemm
         r["y"] = captured["y"] if "y" in captured else captured["y_t"].clone()
