@@ -37,6 +37,8 @@ for pct in 94 88 80; do
   IMAGEN_GRID_PCT=$pct timeout 240 $B > $OUT/bench_grid$pct.json 2> $OUT/bench_grid$pct.err
 done
 [ -f "$ONEWG" ] && IMAGEN_LIB_PATH=$ONEWG timeout 240 $B > $OUT/bench_onewg.json 2> $OUT/bench_onewg.err
+# ... and with the 128 px x 128 co tiles for the C_out >= 128 layers (half the weight bytes per MFMA; a loss of 3 % in the model under the product build)
+[ -f "$ONEWG" ] && IMAGEN_LIB_PATH=$ONEWG IMAGEN_PICK_128=1 timeout 240 $B > $OUT/bench_onewg_pick128.json 2> $OUT/bench_onewg_pick128.err
 IMAGEN_IGEMM_DBG=32 timeout 240 $B > $OUT/bench_one_tile_per_wg.json 2> $OUT/bench_one_tile_per_wg.err   # igemm grids non-persistent: other lanes' launches interleave as slots free up
 [ -f "$REMAT" ] && IMAGEN_LIB_PATH=$REMAT IMAGEN_GRID_PCT=88 timeout 240 $B > $OUT/bench_remat_grid88.json 2> $OUT/bench_remat_grid88.err
 timeout 240 $B > $OUT/bench_default_again.json 2> $OUT/bench_default_again.err      # drift of the box over the call
