@@ -82,6 +82,27 @@ class UnetEngine3D(UnetEngine):
         self.lowres_in = self.f32buf(self.src_batch, Fx, u.channels, S, S, zero=True) if self.lowres else None
         self.out = self.f32buf(R, Fx, u.channels_out, S, S)
         self.out_full = self.f32buf(R, F, u.channels_out, S, S) if F != Fx else self.out   # what final_conv writes
+        # conditioning image (Unet3D(cond_images_channels=...), iv.py:1722-1731): ONE image per sample, repeated over every frame the
+        # network runs on; the init conv reads it as a second, channel-concatenated input like the image Unet does
+        cc = getattr(u, 'cond_images_channels', 0)
+        self.cimg = self.new(R * F, S, S, (cc + 7) // 8 * 8, zero=True) if cc else None
+
+    def set_cond_images(self, cond_images: torch.Tensor):
+        """(src_batch, cond_images_channels, h, w), values as given: resized to this engine's resolution with the unet's resize_mode
+        (resize_video_to after the repeat over frames, iv.py:1728-1729: the frames are identical, so one 2-D resize), packed to fp16
+        NHWC and written to every frame of every row — static over the timesteps."""
+        u, R, S, F = self.unet, self.R, self.S, self.F
+        cc = u.cond_images_channels
+        assert self.cimg is not None, 'this unet was built without cond_images_channels'
+        assert cond_images.ndim == 4 and cond_images.shape[0] == self.src_batch and cond_images.shape[1] == cc, \
+            'the number of channels on the conditioning image you are passing in does not match what you specified on initialiation of the unet'
+        ci = cond_images.to(self.dev).float()
+        if tuple(ci.shape[-2:]) != (S, S):
+            ci = TF.interpolate(ci, S, mode=getattr(u, 'resize_mode', 'nearest'))
+        packed = torch.zeros(self.src_batch, S, S, self.cimg.C, device=self.dev)
+        packed[..., :cc] = ci.permute(0, 2, 3, 1)
+        packed = packed.to(torch.float16).repeat(R // self.src_batch, 1, 1, 1)                       # rows: [cond..., null...]
+        self.cimg.t.view(R, F, S, S, self.cimg.C).copy_(packed[:, None].expand(-1, F, -1, -1, -1))
 
     # ------------------------------------------------------------------------------------------ step plan
     def _build_step_plan(self) -> Plan:
@@ -224,26 +245,34 @@ class UnetEngine3D(UnetEngine):
         """CrossEmbedLayer per frame (iv.py:1121-1146) as ONE kmax x kmax conv, or the plain init conv."""
         u = self.unet
 
+        cc = getattr(u, 'cond_images_channels', 0)
+        auxp = self.cimg.C if self.cimg is not None else 0
+
+        def spread(w):
+            """Reference input channels [cond image | x | lowres] (iv.py:1685, 1731) -> ours [x | lowres | 0.. (8)] ++ [cond image | 0.. (auxp)]."""
+            wp = torch.zeros(w.shape[0], 8 + auxp, *w.shape[2:])
+            wp[:, : w.shape[1] - cc] = w[:, cc:]
+            wp[:, 8: 8 + cc] = w[:, :cc]
+            return wp
+
         def make():
             if isinstance(u.init_conv, CrossEmbed3dP):
                 kmax = max(u.init_conv.kernel_sizes)
                 ws, bs = [], []
                 for conv, k in zip(u.init_conv.convs, u.init_conv.kernel_sizes):
                     cw = _w2d(conv)
-                    w = torch.zeros(cw.weight.shape[0], 8, kmax, kmax)
+                    w = torch.zeros(*cw.weight.shape[:2], kmax, kmax)
                     p = (kmax - k) // 2
-                    w[:, : cw.weight.shape[1], p:p + k, p:p + k] = cw.weight
-                    ws.append(w)
+                    w[:, :, p:p + k, p:p + k] = cw.weight
+                    ws.append(spread(w))
                     bs.append(cw.bias)
                 return ops.pack_weight(torch.cat(ws), torch.cat(bs), self.dev, G=1)
             cw = _w2d(u.init_conv)
-            w = torch.zeros(cw.weight.shape[0], 8, *cw.weight.shape[2:])
-            w[:, : cw.weight.shape[1]] = cw.weight
-            return ops.pack_weight(w, cw.bias, self.dev, G=1)
+            return ops.pack_weight(spread(cw.weight), cw.bias, self.dev, G=1)
 
         out = self.new(self.R * self.F, self.S, self.S, self.lc["init_dim"])
         out.ssq = self.f32buf(out.rows)
-        if not ops.igemm(plan, self.img, self.W.get("init_conv", make), out, ssq_out=out.ssq, label="init_conv").ssq_emitted:
+        if not ops.igemm(plan, self.img, self.W.get("init_conv", make), out, x2=self.cimg, ssq_out=out.ssq, label="init_conv").ssq_emitted:
             out.ssq = None
         return out
 

@@ -688,8 +688,6 @@ class Imagen(nn.Module):
         if not self.is_video:                            # ip.py:2417-2427: only video cascades hand the prompt frames to their unets
             cond_video_frames = post_cond_video_frames = None
         if cond_images is not None:
-            if self.is_video:
-                _out_of_scope("sample(cond_images=...) for video")
             cond_images = cond_images.to(device)
             if cond_images.dtype == torch.uint8:         # cast_uint8_images_to_float, ip.py:2324
                 cond_images = cond_images.float() / 255

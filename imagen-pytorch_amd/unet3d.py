@@ -89,8 +89,6 @@ class Unet3D(nn.Module):
         for name in ('cross_embed_downsample', 'self_cond', 'combine_upsample_fmaps', 'init_conv_to_final_conv_residual'):
             if self._locals[name]:
                 _unsupported(name)
-        if cond_images_channels > 0:
-            _unsupported('cond_images_channels')
         if not pixel_shuffle_upsample:
             _unsupported('pixel_shuffle_upsample=False')
         if attn_dim_head != 64:
@@ -101,8 +99,9 @@ class Unet3D(nn.Module):
         self.channels_out = channels_out if channels_out is not None else channels
         init_channels = channels * (1 + int(lowres_cond))
         init_dim = init_dim if init_dim is not None else dim
-        self.has_cond_image = False
-        self.cond_images_channels = 0
+        self.has_cond_image = cond_images_channels > 0            # iv.py:1307-1310: extra input channels of the init conv
+        self.cond_images_channels = cond_images_channels
+        init_channels += cond_images_channels
 
         self.init_conv = (CrossEmbed3dP(init_channels, kernel_sizes=init_cross_embed_kernel_sizes, dim_out=init_dim, stride=1)
                           if init_cross_embed else conv_frames_p(init_channels, init_dim, init_conv_kernel_size, padding=init_conv_kernel_size // 2))
@@ -285,8 +284,12 @@ class Unet3D(nn.Module):
     @torch.no_grad()
     def _run(self, x, time, *, lowres_cond_img=None, lowres_noise_times=None, text_embeds=None, text_mask=None, cond_drop_prob=0.,
              ignore_time=False, cfg=False, cond_images=None, cond_video_frames=None, post_cond_video_frames=None, self_cond=None):
-        assert cond_images is None and self_cond is None, \
-            'cond_images / self_cond: Unet3D is built without cond_images_channels / self_cond in this build'
+        assert self_cond is None, 'self_cond: Unet3D is built without self-conditioning in this build'
+        assert not (self.has_cond_image ^ (cond_images is not None)), \
+            'you either requested to condition on an image on the unet, but the conditioning image is not supplied, or vice versa'   # iv.py:1722
+        if cond_images is not None:
+            assert cond_images.ndim == 4, 'conditioning images must have 4 dimensions only, if you want to condition on frames of video, ' \
+                                          'use `cond_video_frames` instead'                                                   # iv.py:1725
         assert x.ndim == 5, 'input to 3d unet must have 5 dimensions (batch, channels, time, height, width)'
         assert not (self.lowres_cond and lowres_cond_img is None), 'low resolution conditioning image must be present'
         assert not (self.lowres_cond and lowres_noise_times is None), 'low resolution conditioning noise time must be present'
@@ -303,6 +306,8 @@ class Unet3D(nn.Module):
         eng = self.engine(rows, B, Fr, H, x.device, with_text=with_text, ignore_time=ignore_time, pre_frames=n_pre, post_frames=n_post)
         if n_pre or n_post:
             eng.set_cond_video_frames(cond_video_frames, post_cond_video_frames)
+        if cond_images is not None:
+            eng.set_cond_images(cond_images)
         if cfg:
             keep = torch.cat((torch.ones(B, dtype=torch.bool), torch.zeros(B, dtype=torch.bool)))
         elif cond_drop_prob == 0:

@@ -45,8 +45,8 @@ def resolve_config3d(kwargs: dict) -> dict:
     for flag in ("cross_embed_downsample", "self_cond", "combine_upsample_fmaps", "init_conv_to_final_conv_residual"):
         if cfg[flag]:
             raise NotImplementedError(f"oracle: {flag} is outside the scope")
-    if cfg["cond_images_channels"] or not cfg["pixel_shuffle_upsample"]:
-        raise NotImplementedError("oracle: cond_images / nearest+conv upsample are outside the scope")
+    if not cfg["pixel_shuffle_upsample"]:
+        raise NotImplementedError("oracle: nearest+conv upsample is outside the scope")
     dim, n = cfg["dim"], len(cfg["dim_mults"])
     cfg["init_dim"] = cfg["init_dim"] or dim
     cfg["cond_dim"] = cfg["cond_dim"] or dim
@@ -273,7 +273,8 @@ def temporal_pixel_shuffle_up(p: _SD, x: Tensor, stride: int) -> Tensor:
 def unet3d_forward(sd: Dict[str, Tensor], kwargs: dict, x: Tensor, time: Tensor, *, lowres_cond_img: Optional[Tensor] = None,
                    lowres_noise_times: Optional[Tensor] = None, text_embeds: Optional[Tensor] = None, text_mask: Optional[Tensor] = None,
                    cond_drop_prob: float = 0.0, ignore_time: bool = False, taps: Optional[dict] = None,
-                   cond_video_frames: Optional[Tensor] = None, post_cond_video_frames: Optional[Tensor] = None) -> Tensor:
+                   cond_video_frames: Optional[Tensor] = None, post_cond_video_frames: Optional[Tensor] = None,
+                   cond_images: Optional[Tensor] = None) -> Tensor:
     """iv.py:1650-1941.  x: (b, c, f, h, w); `time` / `lowres_noise_times` are log-SNR values.
 
     cond_video_frames / post_cond_video_frames (iv.py:1682-1718, 1933-1939) are restated as the reference executes them, including
@@ -316,6 +317,14 @@ def unet3d_forward(sd: Dict[str, Tensor], kwargs: dict, x: Tensor, time: Tensor,
         num_succeeding = post_cond_video_frames.shape[2]
         assert num_succeeding % cfg["total_temporal_divisor"] == 0
         x = torch.cat((to_size(post_cond_video_frames), x), dim=2)
+
+    assert (cfg["cond_images_channels"] > 0) == (cond_images is not None)                           # iv.py:1722
+    if cond_images is not None:                                   # iv.py:1724-1731: one image per sample, repeated over the frames
+        assert cond_images.ndim == 4 and cond_images.shape[1] == cfg["cond_images_channels"]
+        ci = cond_images[:, :, None].expand(-1, -1, x.shape[2], -1, -1)
+        if ci.shape[-1] != x.shape[-1]:
+            ci = F.interpolate(ci, (x.shape[2], x.shape[-1], x.shape[-1]), mode=kwargs.get("resize_mode", "nearest"))
+        x = torch.cat((ci, x), dim=1)
 
     if cfg["init_cross_embed"]:                                   # iv.py:1121-1146, 1751
         fmaps = [conv_frames(x, p(f"init_conv.convs.{i}.weight"), p(f"init_conv.convs.{i}.bias"), padding=(ksz - 1) // 2)

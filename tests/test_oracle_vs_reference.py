@@ -123,6 +123,34 @@ def test_unet3d_forward_with_prompt_frames(lowres, prompts):
             assert torch.allclose(r, o, atol=1e-4, rtol=1e-4), (r - o).abs().max()
 
 
+@pytest.mark.parametrize("lowres,prompt", [(False, False), (True, False), (True, True)], ids=["base", "lowres", "lowres+prompt"])
+def test_unet3d_forward_with_cond_images(lowres, prompt):
+    """Unet3D(cond_images_channels=...) (iv.py:1307-1310, 1722-1731) of the live reference vs the oracle: one conditioning image per sample,
+    repeated over the frames (also the prompt frames'), resized, concatenated in front of the input channels."""
+    from oracle import unet3d_oracle as u3
+    from oracle.make_golden import TINY_3D, derandomise_unet3d
+
+    iv = ref_shim.load_reference("imagen_video")
+    kw = {**TINY_3D, "lowres_cond": lowres, "cond_images_channels": 5}
+    torch.manual_seed(4)
+    u = iv.Unet3D(**kw).eval()
+    derandomise_unet3d(u)
+    B, Fr, S = 2, 4, 16
+    x, t, te = torch.randn(B, 3, Fr, S, S), torch.tensor([0.3, -1.1]), torch.randn(B, 9, 32)
+    ci = torch.rand(B, 5, 8, 8)
+    extra = dict(lowres_cond_img=torch.randn(B, 3, Fr, S, S), lowres_noise_times=torch.tensor([0.9, 0.9])) if lowres else {}
+    if prompt:
+        extra["cond_video_frames"] = torch.rand(B, 3, 2, S, S)
+    with torch.no_grad():
+        for cdp in (0.0, 1.0):
+            r = u(x, t, text_embeds=te, cond_drop_prob=cdp, cond_images=ci, **extra)
+            o = u3.unet3d_forward(u.state_dict(), kw, x, t, text_embeds=te, cond_drop_prob=cdp, cond_images=ci, **extra)
+            assert r.shape == x.shape and torch.allclose(r, o, atol=1e-4, rtol=1e-4), (r - o).abs().max()
+    from imagen_pytorch_amd import Unet3D
+    ours = Unet3D(**kw).state_dict()
+    assert list(ours.keys()) == list(u.state_dict().keys()) and all(ours[k].shape == v.shape for k, v in u.state_dict().items())
+
+
 def _sweep_inputs(kw, seed=5):
     torch.manual_seed(seed)
     B, S = 2, 16

@@ -142,6 +142,57 @@ def test_unet3d_plan_with_prompt_frames_vs_oracle(tag, prompts, reference_weight
     assert nerr(out[:B], ref) < 5e-3 and nerr(out[B:], ref_null) < 5e-3, (nerr(out[:B], ref), nerr(out[B:], ref_null))
 
 
+@pytest.mark.parametrize("tag", ["base", "sr"])
+def test_unet3d_plan_with_cond_images_vs_oracle(tag, reference_weights):
+    """Unet3D(cond_images_channels=5): the static second input of the init conv (one image per sample on every frame, prompt frames
+    included) and the permuted weight slice, executed by the interpreter, against the oracle (pinned to the live reference)."""
+    from imagen_pytorch_amd import Unet3D
+    from imagen_pytorch_amd.engine3d import UnetEngine3D
+    from oracle import unet3d_oracle as u3
+    from plan_interp import Interpreter
+
+    g = torch.load(os.path.join(GOLDEN, "unet3d_tiny.pt"), weights_only=False)["runs"][tag]
+    kw = {**g["kwargs"], "cond_images_channels": 5}
+    torch.manual_seed(6)
+    u = Unet3D(**kw).eval()
+    sd = {k: v.clone() for k, v in u.state_dict().items()}
+    for k, v in g["state_dict"].items():          # the recorded weights wherever the shapes agree (everything but the init conv)
+        if sd[k].shape == v.shape:
+            sd[k] = v.clone()
+    u.load_state_dict(sd)
+    B, _, Fr, S, _ = g["x"].shape
+    gen = torch.Generator().manual_seed(7)
+    ci = torch.rand(B, 5, 8, 8, generator=gen)
+    pre = torch.rand(B, 3, 2, S, S, generator=gen) if tag == "sr" else None
+    rows = 2 * B
+    eng = UnetEngine3D(u, rows, B, Fr, S, "cpu", dry=True, pre_frames=0 if pre is None else 2)
+    keep = torch.ones(rows, dtype=torch.bool)
+    keep[B:] = False
+    eng.set_conditioning(text_embeds=g["text_embeds"], text_mask=g["text_mask"], keep=keep, lowres_noise_times=g["extra"].get("lowres_noise_times"))
+    if pre is not None:
+        eng.set_cond_video_frames(pre, None)
+    eng.set_cond_images(ci)
+    it = Interpreter()
+    for t in (eng.x_in, eng.lowres_in, eng.times, eng.lowres_times, eng.out, eng.out_full, eng.keep_u8, eng.src_idx, eng.arange_idx, eng.t_const.t):
+        it.mem.register(t)
+    it.run(eng._static_plans[g["text_embeds"].shape[1]][0])
+    fm = lambda t: t.permute(0, 2, 1, 3, 4).contiguous()
+    eng.x_in.copy_(fm(g["x"]))
+    if eng.lowres:
+        eng.lowres_in.copy_(fm(g["extra"]["lowres_cond_img"]))
+    eng.times.copy_(g["time"].repeat(rows // B))
+    it.run(eng.step_plan)
+    out = fm(eng.out)
+    okw = dict(text_embeds=g["text_embeds"], text_mask=g["text_mask"], cond_images=ci, cond_video_frames=pre, **g["extra"])
+    with torch.no_grad():
+        ref = u3.unet3d_forward(sd, kw, g["x"], g["time"], **okw)
+        ref_null = u3.unet3d_forward(sd, kw, g["x"], g["time"], cond_drop_prob=1.0, **okw)
+    assert nerr(out[:B], ref) < 5e-3 and nerr(out[B:], ref_null) < 5e-3, (nerr(out[:B], ref), nerr(out[B:], ref_null))
+    eng.set_cond_images(ci.flip(0))
+    it.run(eng.step_plan)
+    assert nerr(fm(eng.out)[:B], ref) > 1e-2, "the conditioning image must matter"
+
+
 def test_unet3d_plan_readme_structure_vs_oracle(reference_weights):
     """The README video config's structure (`Unet3D(dim = ..., dim_mults = (1, 2, 4, 8))`, README.md:587; dim 16 here) with temporal
     strides on two levels, a transformer block on the last level and memory_efficient off: planner + interpreter vs the fp32 oracle on

@@ -425,3 +425,39 @@ def test_video_step_level_api(cpu_backend, monkeypatch, tag):
                                    text_mask=torch.any(te != 0., dim=-1), cond_scale=g["cond_scale"], use_tqdm=False, **kw)
         assert not left
     assert nerr(img, run["outputs"][0]) < 2e-2
+
+
+def test_video_cond_images_sampling(cpu_backend):
+    """sample(video_frames=..., cond_images=...) over Unet3D(cond_images_channels=4) stages (iv.py:1722-1731, ip.py:2465): the image is packed
+    once per stage onto every frame; the real driver replayed against the oracle (itself pinned to the live reference)."""
+    from imagen_pytorch_amd import Imagen, Unet3D
+    from oracle import sampler_oracle as so
+    from oracle.make_golden import TINY_3D, derandomise_unet3d
+
+    k1 = {**TINY_3D, "cond_images_channels": 4}
+    k2 = {**TINY_3D, "cond_images_channels": 4, "temporal_strides": (2, 1), "num_resnet_blocks": (1, 2)}
+    torch.manual_seed(8)
+    unets = [Unet3D(**k1), Unet3D(**k2)]
+    imagen = Imagen(unets, image_sizes=(8, 16), timesteps=2, text_embed_dim=32, cond_drop_prob=0.1).eval()
+    for u in imagen.unets:
+        derandomise_unet3d(u)
+    g = torch.Generator().manual_seed(12)
+    te = torch.randn(2, 9, 32, generator=g)
+    cond = torch.rand(2, 4, 12, 12, generator=g)              # neither stage's size: both resize it
+    draws = {}
+
+    def noise(tag, shape):
+        if tag not in draws:
+            draws[tag] = torch.randn(tuple(shape), generator=g)
+        return draws[tag]
+
+    sds = [({k: v.detach().clone() for k, v in u.state_dict().items()}, {**kw, "lowres_cond": i > 0})
+           for i, (u, kw) in enumerate(zip(imagen.unets, (k1, k2)))]
+    with torch.no_grad():
+        want = so.imagen_sample(sds, (8, 16), te, timesteps=2, cond_scale=3., return_all=True, noise_fn=noise, cond_images=cond, video_frames=4)
+    outs = imagen.sample(text_embeds=te, video_frames=4, cond_images=cond, cond_scale=3., use_tqdm=False, return_all_unet_outputs=True,
+                         noise_fn=noise, device="cpu")
+    errs = [nerr(o, w) for o, w in zip(outs, want)]
+    assert max(errs) < 2e-2, errs
+    other = imagen.sample(text_embeds=te, video_frames=4, cond_images=cond.flip(0), cond_scale=3., use_tqdm=False, noise_fn=noise, device="cpu")
+    assert nerr(other, want[-1]) > 2e-2, "the conditioning image must matter"

@@ -213,3 +213,31 @@ def test_video_sample_options_vs_reference_fixture(tag):
     if tag == "inpaint":
         m = run["kwargs"]["inpaint_masks"][:, None].expand(-1, 3, -1, -1, -1)
         assert torch.allclose(res[True][-1].cpu()[m], run["kwargs"]["inpaint_videos"][m], atol=1e-6)
+
+
+@pytest.mark.skipif(os.environ.get("IMAGEN_UNVERIFIED_GPU_TESTS") != "1", reason="not yet run on hardware: set IMAGEN_UNVERIFIED_GPU_TESTS=1")
+def test_unet3d_cond_images_vs_oracle():
+    """Unet3D(cond_images_channels=5).forward_with_cond_scale on the GPU against the oracle (iv.py:1722-1731): the static second input of the
+    init conv on every frame (written after the round's GPU budget: gated until it has met hardware; CPU: tests/test_plan_interp.py)."""
+    from imagen_pytorch_amd import Unet3D
+    from oracle import unet3d_oracle as u3
+
+    dev = torch.device("cuda:0")
+    g = torch.load(os.path.join(GOLDEN, "unet3d_tiny.pt"), weights_only=False)["runs"]["sr"]
+    kw = {**g["kwargs"], "cond_images_channels": 5}
+    torch.manual_seed(6)
+    u = Unet3D(**kw).eval()
+    sd = {k: v.clone() for k, v in u.state_dict().items()}
+    for k, v in g["state_dict"].items():
+        if sd[k].shape == v.shape:
+            sd[k] = v.clone()
+    u.load_state_dict(sd)
+    u = u.to(dev)
+    ci = torch.rand(g["x"].shape[0], 5, 8, 8)
+    extra = {k: v for k, v in g["extra"].items()}
+    got = u.forward_with_cond_scale(g["x"].to(dev), g["time"].to(dev), text_embeds=g["text_embeds"].to(dev), text_mask=g["text_mask"].to(dev),
+                                    cond_images=ci.to(dev), cond_scale=3.0, **{k: v.to(dev) for k, v in extra.items()})
+    with torch.no_grad():
+        ref = u3.unet3d_forward_with_cond_scale(sd, kw, g["x"], g["time"], text_embeds=g["text_embeds"], text_mask=g["text_mask"], cond_images=ci,
+                                                cond_scale=3.0, **extra)
+    assert nerr(got, ref) < 1e-2, nerr(got, ref)

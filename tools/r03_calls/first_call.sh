@@ -16,6 +16,8 @@ B="python bench.py --steps 8 --warmup 4 --no-roofline --no-cpu-baseline"
 # 1. the tests that have not met hardware (ElucidatedImagen sampler options, upsample combiner)
 IMAGEN_UNVERIFIED_GPU_TESTS=1 timeout 300 python -m pytest tests/test_model_gpu.py -q -k "elucidated_sample_options or upsample_combiner" -s > $OUT/unverified_tests.log 2>&1
 tail -n 3 $OUT/unverified_tests.log
+IMAGEN_UNVERIFIED_GPU_TESTS=1 timeout 120 python -m pytest tests/test_video_gpu.py -q -k "cond_images" -s > $OUT/unverified_video_tests.log 2>&1
+tail -n 2 $OUT/unverified_video_tests.log
 
 # 2. parity of the -DIGEMM_EPI_REMAT library: every tile configuration x k-step path, and every distinct igemm launch of the benchmark's plans
 if [ -f "$REMAT" ]; then
