@@ -2,14 +2,16 @@
 # First GPU call of round 3 (prepared at the end of round 2, when the GPU budget was spent): everything that was written or found
 # without hardware, in one call.  Build both libraries BEFORE the call, in the build container (the .so files travel with the snapshot):
 #     python -c "import __graft_entry__ as g; g.build()" && bash tools/build_remat_lib.sh && \
-#         bash tools/build_variant_lib.sh onewg -DIGEMM_ONE_WG -DIGEMM_LA1=12 -DIGEMM_LA2=10
+#         bash tools/build_variant_lib.sh onewg -DIGEMM_ONE_WG -DIGEMM_LA1=12 -DIGEMM_LA2=10 && \
+#         bash tools/build_variant_lib.sh remat8 -DIGEMM_EPI_REMAT -DIGEMM_LA2=8
 #     gpurun --timeout 1500 -- 'bash tools/r03_calls/first_call.sh'
-# Output: gpurun_out/r03_first/*.log|json.  Budget: ~18 GPU-minutes.
+# Output: gpurun_out/r03_first/*.log|json.  Budget: ~22 GPU-minutes.
 set -u
 cd "$(dirname "$0")/../.."
 OUT=gpurun_out/r03_first
 mkdir -p $OUT
 REMAT=$PWD/imagen-pytorch_amd/libimagen_hip_remat.so
+REMAT8=$PWD/imagen-pytorch_amd/libimagen_hip_remat8.so    # remat + the 8-deep weight ring for the 2-MFMA-per-step tilings (fits the 128-VGPR budget once the epilogue constants are gone)
 ONEWG=$PWD/imagen-pytorch_amd/libimagen_hip_onewg.so      # 256-VGPR budget (one workgroup per CU), weight rings 12 / 10 deep: spill-free everywhere
 B="python bench.py --steps 8 --warmup 4 --no-roofline --no-cpu-baseline"
 
@@ -35,6 +37,7 @@ fi
 # 3. bench A/B, same box, same call (boxes of the pool differ by +-20 %): product | remat | persistent grids below the resident slot count
 timeout 240 $B > $OUT/bench_default.json 2> $OUT/bench_default.err
 [ -f "$REMAT" ] && IMAGEN_LIB_PATH=$REMAT timeout 240 $B > $OUT/bench_remat.json 2> $OUT/bench_remat.err
+[ -f "$REMAT8" ] && IMAGEN_LIB_PATH=$REMAT8 timeout 240 $B > $OUT/bench_remat8.json 2> $OUT/bench_remat8.err   # (its parity rides on the remat library's: same code, one constant)
 for pct in 94 88 80; do
   IMAGEN_GRID_PCT=$pct timeout 240 $B > $OUT/bench_grid$pct.json 2> $OUT/bench_grid$pct.err
 done
