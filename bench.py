@@ -415,6 +415,12 @@ def main():
             "path_tflops_reference_count": round(value * FLOPS_PER_IMAGE_REFERENCE * (args.timesteps / 1000) / 1e12, 1),
             "path_frac_of_mfma_peak": round(value * FLOPS_PER_IMAGE_REFERENCE * (args.timesteps / 1000) / 1e12 / (MFMA_PEAK_TFLOPS * world), 4),
         }
+        # A/B runs describe themselves: which kernel library was loaded and which probe knobs were set (none in a production run)
+        from imagen_pytorch_amd import _abi as _abi_mod
+        knobs = {k: v for k, v in os.environ.items() if k.startswith("IMAGEN_") and k not in ("IMAGEN_LIB_PATH",)}
+        if os.path.basename(_abi_mod.LIB_PATH) != "libimagen_hip.so" or knobs:
+            rec["config"]["kernel_library"] = os.path.basename(_abi_mod.LIB_PATH)
+            rec["config"]["probe_knobs"] = knobs
         if world == 1 and args.mode != "sequential":
             # the same cascade as ONE request at a time (latency view): a single sequential pass, outside the timed region
             torch.cuda.synchronize()
