@@ -5,7 +5,7 @@
 #         bash tools/build_variant_lib.sh onewg -DIGEMM_ONE_WG -DIGEMM_LA1=12 -DIGEMM_LA2=10 && \
 #         bash tools/build_variant_lib.sh remat8 -DIGEMM_EPI_REMAT -DIGEMM_LA2=8
 #     gpurun --timeout 1500 -- 'bash tools/r03_calls/first_call.sh'
-# Output: gpurun_out/r03_first/*.log|json.  Budget: ~22 GPU-minutes.
+# Output: gpurun_out/r03_first/*.log|json.  Budget: ~25 GPU-minutes.
 set -u
 cd "$(dirname "$0")/../.."
 OUT=gpurun_out/r03_first
@@ -46,6 +46,10 @@ done
 [ -f "$ONEWG" ] && IMAGEN_LIB_PATH=$ONEWG IMAGEN_PICK_128=1 timeout 240 $B > $OUT/bench_onewg_pick128.json 2> $OUT/bench_onewg_pick128.err
 IMAGEN_IGEMM_DBG=32 timeout 240 $B > $OUT/bench_one_tile_per_wg.json 2> $OUT/bench_one_tile_per_wg.err   # igemm grids non-persistent: other lanes' launches interleave as slots free up
 [ -f "$REMAT" ] && IMAGEN_LIB_PATH=$REMAT IMAGEN_GRID_PCT=88 timeout 240 $B > $OUT/bench_remat_grid88.json 2> $OUT/bench_remat_grid88.err
+# more hardware queues for the lanes' streams (the HIP runtime's default is 4 per process: lanes beyond that share a queue and serialise —
+# a candidate reading of "three to four lanes, then flat"), alone and with room left on the chip
+GPU_MAX_HW_QUEUES=8 timeout 300 $B --lanes 6 > $OUT/bench_hwq8_lanes6.json 2> $OUT/bench_hwq8_lanes6.err
+GPU_MAX_HW_QUEUES=8 IMAGEN_GRID_PCT=88 timeout 300 $B --lanes 6 > $OUT/bench_hwq8_lanes6_grid88.json 2> $OUT/bench_hwq8_lanes6_grid88.err
 timeout 240 $B > $OUT/bench_default_again.json 2> $OUT/bench_default_again.err      # drift of the box over the call
 python - <<'PY'
 import glob, json, os
