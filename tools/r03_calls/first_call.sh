@@ -48,8 +48,8 @@ IMAGEN_IGEMM_DBG=32 timeout 240 $B > $OUT/bench_one_tile_per_wg.json 2> $OUT/ben
 [ -f "$REMAT" ] && IMAGEN_LIB_PATH=$REMAT IMAGEN_GRID_PCT=88 timeout 240 $B > $OUT/bench_remat_grid88.json 2> $OUT/bench_remat_grid88.err
 # more hardware queues for the lanes' streams (the HIP runtime's default is 4 per process: lanes beyond that share a queue and serialise —
 # a candidate reading of "three to four lanes, then flat"), alone and with room left on the chip
-GPU_MAX_HW_QUEUES=8 timeout 300 $B --lanes 6 > $OUT/bench_hwq8_lanes6.json 2> $OUT/bench_hwq8_lanes6.err
-GPU_MAX_HW_QUEUES=8 IMAGEN_GRID_PCT=88 timeout 300 $B --lanes 6 > $OUT/bench_hwq8_lanes6_grid88.json 2> $OUT/bench_hwq8_lanes6_grid88.err
+GPU_MAX_HW_QUEUES=8 timeout 300 $B --lanes 6 --steps 12 > $OUT/bench_hwq8_lanes6.json 2> $OUT/bench_hwq8_lanes6.err
+GPU_MAX_HW_QUEUES=8 IMAGEN_GRID_PCT=88 timeout 300 $B --lanes 6 --steps 12 > $OUT/bench_hwq8_lanes6_grid88.json 2> $OUT/bench_hwq8_lanes6_grid88.err
 timeout 240 $B > $OUT/bench_default_again.json 2> $OUT/bench_default_again.err      # drift of the box over the call
 python - <<'PY'
 import glob, json, os
