@@ -292,6 +292,12 @@ class UnetEngine:
             x = self._combine_upsample_fmaps(plan, x, up_hiddens)
         if u.final_res_block is not None:   # with init_conv_to_final_conv_residual its input is cat(x, init conv output), unscaled (ip.py:1716-1720)
             x = self._resnet(plan, x, init_res, u.final_res_block, "final_res_block", with_cond=False, skip_scale=1.0)
+        elif init_res is not None:          # no final resnet block: final_conv itself reads cat(x, init conv output[, lowres image]) — the two
+            cat = self.new(R, x.H, x.W, x.C + init_res.C)      # feature tensors are joined first (two strided row copies), the image rides as x2
+            for src, off in ((x, 0), (init_res, x.C)):
+                ops.rows_copy(plan, src.t, cat.t, B=1, rows=R * x.H * x.W, C=src.C, src_bs=0, src_rs=src.ld, dst_bs=0, dst_rs=cat.C,
+                              src_off=src.off, dst_off=off, label="final_conv.cat")
+            x = cat
         self.taps['final_res'] = x
         self._final_conv(plan, x)
 

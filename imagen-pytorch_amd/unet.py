@@ -112,8 +112,6 @@ class Unet(nn.Module):
             # positionally (ip.py:1315, 1357, 1366), so dim_out collides with kernel_sizes and Unet(...) raises TypeError — no
             # checkpoint with this flag exists
             _unsupported('cross_embed_downsample')
-        if init_conv_to_final_conv_residual and not final_resnet_block:
-            _unsupported('init_conv_to_final_conv_residual without final_resnet_block')   # final_conv would need three inputs
         if attn_dim_head not in (32, 64):
             raise NotImplementedError(f"attn_dim_head = {attn_dim_head}: the attention kernels are built for head dims 64 (every README config) "
                                       "and 32 (the reference's UnetConfig default, configs.py:48-49)")

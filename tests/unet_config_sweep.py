@@ -45,6 +45,8 @@ SWEEP = {
     "combine_fmaps_init_residual_memory_efficient": dict(_T, num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True),
                                                          memory_efficient=True, init_conv_to_final_conv_residual=True, combine_upsample_fmaps=True,
                                                          lowres_cond=True),
+    "init_residual_no_final_resnet_lowres": dict(_T, num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True),
+                                                 init_conv_to_final_conv_residual=True, final_resnet_block=False, lowres_cond=True),
     "channels_out_6": dict(_T, num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True), channels_out=6),
 }
 
