@@ -35,4 +35,9 @@ PY
 shift $(( $# > 0 ? 1 : 0 )) || true
 python tools/scratch_report.py $P/csrc/igemm.hip "$@" | tail -n 1
 echo "(last version that met hardware: $(tail -n 1 profiles/r02_static_spills_igemm_default.txt))"
+echo "device code of the PRODUCT sources vs the versions that met hardware (profiles/r02_device_code_hashes.txt):"
+for f in igemm conv_dma conv_stream; do
+  h=$(python tools/scratch_report.py $P/csrc/$f.hip | tail -n 1 | awk '{print $4}')
+  grep -q "$f.hip $h" profiles/r02_device_code_hashes.txt && echo "  $f.hip unchanged" || echo "  $f.hip CHANGED ($h): its kernels have to meet hardware again before their numbers are quoted"
+done
 python -m pytest tests/test_host_logic.py tests/test_plan_interp.py -q -x 2>&1 | tail -n 1

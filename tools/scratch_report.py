@@ -37,6 +37,15 @@ def report(asm_path):
     return rows
 
 
+def device_code_hash(asm_path):
+    """sha256 of the device assembly without what changes with the source TEXT but not with the code: the compilation-unit id symbol,
+    .file / .ident lines, comments.  Equal hash = the same instructions, registers and metadata as the compared build."""
+    import hashlib
+    text = re.sub(r"__hip_cuid_[0-9a-f]+", "__hip_cuid_X", open(asm_path).read())
+    lines = [l for l in text.split("\n") if not l.strip().startswith((".file", ".ident", ";")) and ".loc" not in l]
+    return hashlib.sha256("\n".join(lines).encode()).hexdigest()
+
+
 def main():
     src = sys.argv[1]
     flags = sys.argv[2:]
@@ -46,11 +55,13 @@ def main():
                "-I" + os.path.join(ROOT, "imagen-pytorch_amd", "csrc"), "--cuda-device-only", "-S", src, "-o", out, *flags]
         subprocess.run(cmd, check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
         rows = report(out)
+        digest = device_code_hash(out)
     print(f"{'kernel':100s} {'lines':>6s} {'scratch':>8s} {'in MFMA loops':>14s} {'reload+vmcnt(0)':>16s}")
     for name, n, s, l, d in rows:
         if s:
             print(f"{name[:100]:100s} {n:6d} {s:8d} {l:14d} {d:16d}")
     print(f"{len(rows)} kernels, {sum(1 for r in rows if r[2])} with scratch, {sum(r[3] for r in rows)} scratch instructions inside MFMA loops")
+    print(f"device code sha256 {digest}  (profiles/r02_device_code_hashes.txt holds the versions that met hardware)")
 
 
 if __name__ == "__main__":
