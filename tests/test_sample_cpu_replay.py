@@ -461,3 +461,40 @@ def test_video_cond_images_sampling(cpu_backend):
     assert max(errs) < 2e-2, errs
     other = imagen.sample(text_embeds=te, video_frames=4, cond_images=cond.flip(0), cond_scale=3., use_tqdm=False, noise_fn=noise, device="cpu")
     assert nerr(other, want[-1]) > 2e-2, "the conditioning image must matter"
+
+
+def test_video_elucidated_inpainting_driver(cpu_backend):
+    """ElucidatedImagen over Unet3D stages with inpaint_videos + resampling and an init video + skip_steps: the driver against the oracle
+    (whose image-stage EDM options and video stages are each pinned to recorded runs of the live reference; this is their combination)."""
+    from imagen_pytorch_amd import ElucidatedImagen
+    from oracle import elucidated_oracle as eo
+
+    g = torch.load(os.path.join(GOLDEN, "sample_tiny_video.pt"), weights_only=False)
+    hp = g["edm"]["hparams"]
+    model = _cascade(g, klass=ElucidatedImagen, **hp)
+    gen = torch.Generator().manual_seed(21)
+    B, Fr, S0, S1 = g["text_embeds"].shape[0], g["frames"], *g["image_sizes"]
+    known = torch.rand(B, 3, Fr, S1, S1, generator=gen)
+    keep = torch.rand(B, Fr, S1, S1, generator=gen) > 0.5
+    init = torch.rand(B, 3, Fr, S0, S0, generator=gen)
+    draws = {}
+
+    def noise(tag, shape):
+        if tag not in draws:
+            draws[tag] = torch.randn(tuple(shape), generator=gen)
+        return draws[tag]
+
+    unets = [(u["state_dict"], u["kwargs"]) for u in g["unets"]]
+    for kw in (dict(inpaint_images=known, inpaint_masks=keep, inpaint_resample_times=2), dict(init_images=init, skip_steps=1)):
+        with torch.no_grad():
+            want = eo.elucidated_sample(unets, g["image_sizes"], g["text_embeds"], hparams=hp, cond_scale=g["cond_scale"], noise_fn=noise,
+                                        return_all=True, video_frames=Fr, **kw)
+        pkw = {("inpaint_videos" if k == "inpaint_images" else k): v for k, v in kw.items()}
+        outs = model.sample(text_embeds=g["text_embeds"], video_frames=Fr, cond_scale=g["cond_scale"], use_tqdm=False, return_all_unet_outputs=True,
+                            noise_fn=noise, device="cpu", **pkw)
+        e0 = nerr(outs[0], want[0])
+        assert e0 < 3e-2, (list(kw), e0)
+        assert outs[1].shape == want[1].shape
+        if "inpaint_images" in kw:
+            m = keep[:, None].expand(-1, 3, -1, -1, -1)
+            assert torch.allclose(outs[1][m], known[m], atol=1e-6)
