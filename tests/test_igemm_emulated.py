@@ -52,3 +52,14 @@ def test_emulated_igemm_matches_contract_and_remat_build_is_bit_identical(tmp_pa
     for name in product:
         a, b = product[name]["y"], remat[name]["y"]
         assert a is not None and b is not None and torch.equal(a, b), name
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="host clang of the ROCm toolchain not present")
+def test_emulated_channel_slice_outputs():
+    """Output stride != Cout (a conv writing its channel slice of a concatenated tensor: the UpsampleCombiner plan) on the emulated product
+    kernels: right values, neighbouring channels untouched, wave-specialised and streaming family (tools/emul/run_slice_cases.py)."""
+    env = dict(os.environ, IMAGEN_LIB_PATH=_lib(""))
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "emul", "run_slice_cases.py")], env=env, stdout=subprocess.PIPE,
+                       stderr=subprocess.STDOUT, timeout=600)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and out.count("neighbours untouched: True") == 6, out[-2000:]
