@@ -405,12 +405,17 @@ __global__ __launch_bounds__(256) void gca_partial_online_kernel(const ImagenGca
     return;
   }
   // last workgroup of this image finalises (agent-scope release / acquire ticket; placement-independent)
+#ifdef IMAGEN_EMUL   // (tools/emul: host compile, no GPU assembler — loads complete in program order there)
+#define EW_WAIT_VM0() ((void)0)
+#else
+#define EW_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
+#endif
   __shared__ int s_last;
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  EW_WAIT_VM0();
   __syncthreads();
   if (threadIdx.x == 0) {
     __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    EW_WAIT_VM0();
     const int old = __hip_atomic_fetch_add(p.counter + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = (old == p.chunks - 1) ? 1 : 0;
     if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");

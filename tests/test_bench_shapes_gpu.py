@@ -14,6 +14,8 @@ import os
 import pytest
 import torch
 
+from conftest import gpu_device
+
 from igemm_case import run_case
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -70,7 +72,7 @@ def test_bench_descriptors_are_enumerable():
 def test_every_bench_igemm_launch_matches_the_reference():
     from imagen_pytorch_amd import ops
 
-    dev = torch.device("cuda:0")
+    dev = gpu_device()
     tab = ops.cfg_table()
     report, worst = [], 0.0
     for d, label, count in bench_descriptors():

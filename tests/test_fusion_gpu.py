@@ -4,6 +4,8 @@ import math
 
 import pytest
 import torch
+
+from conftest import gpu_device
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
@@ -26,7 +28,7 @@ def test_ssq_chain(B, H, W, C1, C2, Cmid, Cout):
     """conv_a emits ssq of its output; conv_b consumes (ssq_a, ssq_b over a concat) instead of a ROWSTAT pass."""
     from imagen_pytorch_amd import ops
 
-    dev = torch.device("cuda:0")
+    dev = gpu_device()
     torch.manual_seed(0)
     sk = 2 ** -0.5
     x1 = torch.randn(B, C1, H, W).half().float()
@@ -70,7 +72,7 @@ def test_ssq_chain(B, H, W, C1, C2, Cmid, Cout):
 def test_tail_kernels_emit_raw_ssq():
     from imagen_pytorch_amd import ops
 
-    dev = torch.device("cuda:0")
+    dev = gpu_device()
     torch.manual_seed(1)
     B, H, W, C = 2, 16, 16, 64
     h = torch.randn(B, C, H, W).half().float()
@@ -101,7 +103,7 @@ def test_global_context_of_conv_output(B, S, C, single, monkeypatch):
 
     monkeypatch.setattr(ops, "GCA_SINGLE_LAUNCH", int(single == 1))
 
-    dev = torch.device("cuda:0")
+    dev = gpu_device()
     torch.manual_seed(3)
     x = torch.randn(B, C, S, S).half().float()
     w = torch.randn(C, C, 3, 3) / math.sqrt(9 * C)
@@ -138,7 +140,7 @@ def test_post_norm_epilogue_feeds_plain_conv(B, S, C1, C):
     output (post_pa / post_ps), conv2 then stages that tensor with no prologue; vs fp32 torch with the norm on conv1's fp32 output."""
     from imagen_pytorch_amd import ops
 
-    dev = torch.device("cuda:0")
+    dev = gpu_device()
     torch.manual_seed(5)
     x = torch.randn(B, C1, S, S).half().float()
     w1 = (torch.randn(C, C1, 3, 3) / math.sqrt(9 * C1)).half().float()

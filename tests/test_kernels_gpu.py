@@ -8,6 +8,8 @@ import math
 
 import pytest
 import torch
+
+from conftest import gpu_device
 import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
@@ -26,7 +28,7 @@ def h16(t):
 
 @pytest.fixture(scope="module")
 def dev():
-    return torch.device("cuda:0")
+    return gpu_device()
 
 
 @pytest.fixture(scope="module")

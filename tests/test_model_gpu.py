@@ -15,6 +15,8 @@ import os
 import pytest
 import torch
 
+from conftest import gpu_device
+
 pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
@@ -53,7 +55,7 @@ def _tap_report(eng, taps_ref):
 
 @pytest.mark.parametrize("name", ["unet_tiny_base.pt", "unet_tiny_sr.pt"])
 def test_unet_forward_vs_reference_fixture(name):
-    dev = torch.device("cuda:0")
+    dev = gpu_device()
     g = _load(name)
     u = _build(g["kwargs"], g["state_dict"], dev)
     ex = {k: v.to(dev) for k, v in g["extra"].items()}
@@ -103,7 +105,7 @@ def test_unet_forward_vs_oracle(kw, S, B, request):
     from imagen_pytorch_amd import Unet
     from oracle import unet_oracle as uo
 
-    dev = torch.device("cuda:0")
+    dev = gpu_device()
     torch.manual_seed(0)
     u = Unet(**kw).eval()
     torch.nn.init.normal_(u.final_conv.weight, std=0.05)
@@ -144,7 +146,7 @@ def test_sample_vs_reference_fixture():
     """Imagen.sample (2-stage cascade, CFG 3, dynamic thresholding) fed the reference's recorded Gaussian draws."""
     from imagen_pytorch_amd import Imagen, Unet
 
-    dev = torch.device("cuda:0")
+    dev = gpu_device()
     g = _load("sample_tiny_cascade.pt")
     unets = []
     for spec in g["unets"]:
@@ -173,7 +175,7 @@ def test_reference_step_level_api(monkeypatch):
     strung together from single steps, fed the reference's recorded draws, against the reference's images and the graph path."""
     from step_api_case import run_cascade_by_steps
 
-    dev = torch.device("cuda:0")
+    dev = gpu_device()
     g = _load("sample_tiny_cascade.pt")
     imagen = _tiny_cascade(g, dev, g["timesteps"])
     outs = run_cascade_by_steps(imagen, g, monkeypatch, dev)
@@ -189,7 +191,7 @@ def test_self_conditioned_sampling():
     previous step's thresholded x0 from the buffer DDPM_UPDATE leaves it in."""
     from step_api_case import cond_images_cascade
 
-    dev = torch.device("cuda:0")
+    dev = gpu_device()
     imagen, te, cond, noise_fn, want, sds = cond_images_cascade(dev, self_cond=True)
     results = {}
     for use_graph in (False, True):
@@ -212,7 +214,7 @@ def test_cond_images_sampling():
     """sample(cond_images=...) on the GPU against the oracle (Unet(cond_images_channels=4) stages; ip.py:1555-1560, 2465)."""
     from step_api_case import cond_images_cascade
 
-    dev = torch.device("cuda:0")
+    dev = gpu_device()
     imagen, te, cond, noise_fn, want, sds = cond_images_cascade(dev)
     outs = imagen.sample(text_embeds=te.to(dev), cond_images=cond.to(dev), cond_scale=3., use_tqdm=False, return_all_unet_outputs=True,
                          noise_fn=noise_fn)
@@ -241,7 +243,7 @@ def _tiny_cascade(g, dev, timesteps):
 def test_sample_options_vs_reference_fixture(run):
     """The p_sample_loop options outside the BASELINE configs (ip.py:2167-2289): init_images + skip_steps, and
     RePaint-style inpainting with resampling, vs recorded runs of the live reference fed the same Gaussian draws."""
-    dev = torch.device("cuda:0")
+    dev = gpu_device()
     g = _load("sample_tiny_options.pt")
     r = g["runs"][run]
     imagen = _tiny_cascade(g, dev, g["timesteps"])
@@ -278,7 +280,7 @@ def test_sample_from_reference_trainer_checkpoint(which, tmp_path):
     load_imagen_from_checkpoint and sampled on the HIP path; the image matches what the reference sampled from the same weights."""
     from imagen_pytorch_amd import load_imagen_from_checkpoint
 
-    dev = torch.device("cuda:0")
+    dev = gpu_device()
     g = _load("checkpoint_tiny.pt")
     path = tmp_path / "ckpt.pt"
     torch.save(g["checkpoint"], str(path))
@@ -295,7 +297,7 @@ def test_sample_from_reference_trainer_checkpoint(which, tmp_path):
 def test_conditioning_handle_skips_static_plan():
     """SURVEY §8(f) NEXT-3: the same Conditioning handle over several sample() calls runs each stage's timestep-invariant plan
     once; images are bit-identical to passing text_embeds every time.  texts= goes through the encode_text hook."""
-    dev = torch.device("cuda:0")
+    dev = gpu_device()
     g = _load("sample_tiny_cascade.pt")
     imagen = _tiny_cascade(g, dev, 3)
     te = g["text_embeds"].to(dev)
@@ -326,7 +328,7 @@ def test_sample_philox_determinism_and_sharding():
     shard (sample_offset) reproduces the corresponding rows of the unsharded run (SURVEY.md §8e parity test)."""
     from imagen_pytorch_amd import Imagen, Unet
 
-    dev = torch.device("cuda:0")
+    dev = gpu_device()
     g = _load("sample_tiny_cascade.pt")
     unets = [Unet(**spec["kwargs"]).eval() for spec in g["unets"]]
     imagen = Imagen(unets, image_sizes=g["image_sizes"], timesteps=4, text_embed_dim=32, cond_drop_prob=0.1).to(dev)
@@ -349,7 +351,7 @@ def test_pipelined_and_lane_sampling_match_sequential():
     import threading
     from imagen_pytorch_amd import Imagen, Unet
 
-    dev = torch.device("cuda:0")
+    dev = gpu_device()
     g = _load("sample_tiny_cascade.pt")
     unets = [Unet(**spec["kwargs"]).eval() for spec in g["unets"]]
     imagen = Imagen(unets, image_sizes=g["image_sizes"], timesteps=12, text_embed_dim=32, cond_drop_prob=0.1).to(dev)
@@ -383,7 +385,7 @@ def test_elucidated_sample_vs_reference_fixture():
     hipGraph replay == eager.  Tolerances as for the DDPM cascade (stage 1 alone; the chained second stage amplifies)."""
     from imagen_pytorch_amd import ElucidatedImagen, Unet
 
-    dev = torch.device("cuda:0")
+    dev = gpu_device()
     g = _load("sample_tiny_elucidated.pt")
     unets = []
     for u in g["unets"]:
@@ -430,7 +432,7 @@ def test_elucidated_sample_options_vs_reference_fixture(tag):
     vs recorded runs of the live reference with identical draws; hipGraph replay == eager; known pixels returned exactly."""
     from imagen_pytorch_amd import ElucidatedImagen, Unet
 
-    dev = torch.device("cuda:0")
+    dev = gpu_device()
     o = _load("sample_tiny_elucidated_options.pt")
     g = _load(o["weights_from"])
     run = o["runs"][tag]
@@ -466,7 +468,7 @@ def test_upsample_combiner_vs_oracle(name):
     from imagen_pytorch_amd import Unet
     from oracle import unet_oracle as uo
 
-    dev = torch.device("cuda:0")
+    dev = gpu_device()
     kw = SWEEP[name]
     torch.manual_seed(2)
     u = Unet(**kw).eval()

@@ -11,6 +11,8 @@ import sys
 import pytest
 import torch
 
+from conftest import gpu_device
+
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
 
 pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("IMAGEN_VIDEO_GPU_TESTS") == "0",
@@ -125,7 +127,7 @@ def test_temporal_attention_kernel(Fr, causal):
 def test_unet3d_forward_vs_reference_fixture(tag):
     from imagen_pytorch_amd import Unet3D
 
-    dev = torch.device("cuda:0")
+    dev = gpu_device()
     g = torch.load(os.path.join(GOLDEN, "unet3d_tiny.pt"), weights_only=False)["runs"][tag]
     u = Unet3D(**g["kwargs"]).eval()
     u.load_state_dict(g["state_dict"])
@@ -145,7 +147,7 @@ def test_video_cascade_sample_vs_reference_fixture():
     """Imagen.sample(video_frames=4) over two Unet3D stages vs the recorded reference run (same draws); graph == eager."""
     from imagen_pytorch_amd import Imagen, Unet3D
 
-    dev = torch.device("cuda:0")
+    dev = gpu_device()
     g = torch.load(os.path.join(GOLDEN, "sample_tiny_video.pt"), weights_only=False)
     unets = [Unet3D(**spec["kwargs"]).eval() for spec in g["unets"]]
     imagen = Imagen(unets, image_sizes=g["image_sizes"], timesteps=g["timesteps"], text_embed_dim=32, cond_drop_prob=0.1).to(dev)
@@ -166,7 +168,7 @@ def test_video_cascade_sample_vs_reference_fixture():
 def test_video_elucidated_sample_vs_reference_fixture():
     from imagen_pytorch_amd import ElucidatedImagen, Unet3D
 
-    dev = torch.device("cuda:0")
+    dev = gpu_device()
     g = torch.load(os.path.join(GOLDEN, "sample_tiny_video.pt"), weights_only=False)
     e = g["edm"]
     unets = [Unet3D(**spec["kwargs"]).eval() for spec in g["unets"]]
@@ -191,7 +193,7 @@ def test_video_sample_options_vs_reference_fixture(tag):
     skip_steps, video inpainting — vs recorded runs of the live reference (same draws); graph == eager."""
     from imagen_pytorch_amd import Imagen, Unet3D
 
-    dev = torch.device("cuda:0")
+    dev = gpu_device()
     o = torch.load(os.path.join(GOLDEN, "sample_tiny_video_options.pt"), weights_only=False)
     g = torch.load(os.path.join(GOLDEN, o["weights_from"]), weights_only=False)
     run = o["runs"][tag]
@@ -222,7 +224,7 @@ def test_unet3d_cond_images_vs_oracle():
     from imagen_pytorch_amd import Unet3D
     from oracle import unet3d_oracle as u3
 
-    dev = torch.device("cuda:0")
+    dev = gpu_device()
     g = torch.load(os.path.join(GOLDEN, "unet3d_tiny.pt"), weights_only=False)["runs"]["sr"]
     kw = {**g["kwargs"], "cond_images_channels": 5}
     torch.manual_seed(6)

@@ -5,6 +5,9 @@
 #include <sys/mman.h>
 
 #include <cstdarg>
+#include <ctime>
+#include <functional>
+#include <mutex>
 #include <deque>
 #include <type_traits>
 #include <vector>
@@ -35,6 +38,7 @@ emul_uint3 g_block{0, 0, 0}, g_bdim{1, 1, 1}, g_gdim{1, 1, 1};
 Group wg_group;
 struct Wave {
   Group arrive, release;
+  unsigned long long alive = 0;    // lanes that exist and have not returned
   alignas(64) char buf[64 * 64];   // 64 lanes x up to 64 bytes
 };
 std::vector<Wave> waves;
@@ -52,9 +56,23 @@ void rendezvous(Group& g) {
     block_here();
   }
 }
+// a thread that has returned no longer takes part in barriers or wave operations (the hardware counts live waves / executes with the
+// remaining lanes): shrink the groups and let a rendezvous go that was only waiting for this thread
+void leave(Group& g) {
+  --g.size;
+  if (g.size > 0 && g.count == g.size) {
+    g.count = 0;
+    for (int w : g.waiters) runq.push_back(w);
+    g.waiters.clear();
+  }
+}
 void fiber_main() {
   g_body(g_arg);
   fibers[cur].done = true;
+  leave(wg_group);
+  leave(waves[fibers[cur].tid.x >> 6].arrive);
+  leave(waves[fibers[cur].tid.x >> 6].release);
+  waves[fibers[cur].tid.x >> 6].alive &= ~(1ull << (fibers[cur].tid.x & 63));
   swapcontext(&fibers[cur].ctx, &sched_ctx);
 }
 }  // namespace
@@ -72,6 +90,15 @@ void wave_exchange(const void* mine, void* all, size_t bytes) {
   for (int l = 0; l < 64; ++l) memcpy(static_cast<char*>(all) + l * bytes, w.buf + l * 64, bytes);
 }
 void wave_release() { rendezvous(waves[fibers[cur].tid.x >> 6].release); }
+bool wave_any(bool pred) {
+  int mine = pred, all[64];
+  wave_exchange(&mine, all, sizeof(int));
+  const unsigned long long alive = waves[fibers[cur].tid.x >> 6].alive;
+  bool r = false;
+  for (int l = 0; l < 64; ++l) r |= ((alive >> l) & 1) && all[l] != 0;
+  wave_release();
+  return r;
+}
 
 f16v mfma_f32_32x32x16_f16(h8 a, h8 b, f16v c) {
   struct AB { h8 a, b; };
@@ -143,13 +170,15 @@ void s_waitcnt(int imm) {
 }
 
 void launch(dim3 grid, dim3 block, size_t lds_bytes, void (*body)(void*), void* arg, char* lds, size_t lds_cap) {
+  static std::mutex mu;                       // one launch at a time (sampling lanes call in from their own threads); fibers run on the caller's thread
+  std::lock_guard<std::mutex> lock(mu);
   if (lds_bytes > lds_cap) { fprintf(stderr, "emul: %zu bytes of LDS requested, %zu available\n", lds_bytes, lds_cap); abort(); }
   const int n = (int)block.x;
-  if (n % 64 != 0 || block.y != 1 || block.z != 1 || grid.y != 1 || grid.z != 1) { fprintf(stderr, "emul: 1-D launches of whole waves only\n"); abort(); }
+  if (block.y != 1 || block.z != 1) { fprintf(stderr, "emul: 1-D workgroups only\n"); abort(); }
   g_body = body;
   g_arg = arg;
   g_bdim = emul_uint3{block.x, 1, 1};
-  g_gdim = emul_uint3{grid.x, 1, 1};
+  g_gdim = emul_uint3{grid.x, grid.y, grid.z};
   if ((int)fibers.size() < n) {
     const size_t old = fibers.size();
     fibers.resize(n);
@@ -158,12 +187,17 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, void (*body)(void*), void* 
       if (fibers[i].stack == MAP_FAILED) { perror("emul: mmap"); abort(); }
     }
   }
-  for (unsigned b = 0; b < grid.x; ++b) {
-    g_block = emul_uint3{b, 0, 0};
-    memset(lds, 0xCD, lds_cap);                 // LDS content is undefined at workgroup start: fp16 0xCDCD = -23.2, fp32 -4.3e8 (loud, finite)
+  const unsigned nblocks = grid.x * grid.y * grid.z;
+  for (unsigned b = 0; b < nblocks; ++b) {
+    g_block = emul_uint3{b % grid.x, (b / grid.x) % grid.y, b / (grid.x * grid.y)};
+    memset(lds, 0xCD, std::min(lds_cap, lds_bytes + 4096));   // LDS content is undefined at workgroup start: fp16 0xCDCD = -23.2, fp32 -4.3e8 (loud, finite)
     wg_group = Group{n, 0, {}};
-    waves.assign(n / 64, Wave{});
-    for (auto& w : waves) { w.arrive.size = 64; w.release.size = 64; }
+    waves.assign((n + 63) / 64, Wave{});
+    for (size_t w = 0; w < waves.size(); ++w) {   // (a partial last wave)
+      const int lanes = std::min(64, n - 64 * (int)w);
+      waves[w].arrive.size = waves[w].release.size = lanes;
+      waves[w].alive = lanes == 64 ? ~0ull : (1ull << lanes) - 1;
+    }
     runq.clear();
     for (int i = 0; i < n; ++i) {
       Fiber& f = fibers[i];
@@ -210,22 +244,14 @@ hipError_t hipDeviceGetAttribute(int* v, int attr, int) {
   return hipSuccess;
 }
 
-// ---- the rest of the C ABI the host side needs to drive IGEMM launches (capi.hip / codesize.hip / the other kernel families, reduced)
-static thread_local char g_err[512] = "";
-void imagen_set_error(const char* fmt, ...) {
-  va_list ap;
-  va_start(ap, fmt);
-  vsnprintf(g_err, sizeof(g_err), fmt, ap);
-  va_end(ap);
-}
-unsigned imagen_kernel_code_bytes(const char*) { return 0; }   // no instruction warm-up in the emulation
-int launch_igemm(const ImagenIgemmParams* p, hipStream_t s);
+void imagen_set_error(const char* fmt, ...);   // capi.hip
+// ---- what the emulated library does not compile from csrc/: conv_lds.hip (superseded family, hand-scheduled asm throughout)
 #define WEAK __attribute__((weak))   // the other families' translation units override these when they are part of the emulated library
-int imagen_conv_lds_num_configs() { return 0; }                // (conv_lds.hip is not emulated)
+int imagen_conv_lds_num_configs() { return 0; }
 int imagen_conv_lds_config_info(int, int*, int*, int*) { return -1; }
 int imagen_conv_lds_stage_slots(int, int, int) { return -1; }
 long imagen_conv_lds_lds_bytes(int, int, int, int, int) { return -1; }
-int launch_conv_lds(const ImagenIgemmParams*, int, hipStream_t) { return -1; }
+int launch_conv_lds(const ImagenIgemmParams*, int, hipStream_t) { imagen_set_error("emulated library: conv_lds is not emulated"); return -1; }
 WEAK int imagen_conv_dma_num_configs() { return 0; }
 WEAK int imagen_conv_dma_config_info(int, int*, int*, int*) { return -1; }
 WEAK long imagen_conv_dma_lds_bytes(int, int, int, int, int) { return -1; }
@@ -236,55 +262,35 @@ WEAK int imagen_conv_stream_config_info(int, int*, int*, int*) { return -1; }
 WEAK long imagen_conv_stream_lds_bytes(int, int, int, int, int) { return -1; }
 WEAK int launch_conv_stream(const ImagenIgemmParams*, int, hipStream_t) { return -1; }
 
-extern "C" int imagen_abi_version(void) { return IMAGEN_ABI_VERSION; }
-extern "C" const char* imagen_last_error(void) { return g_err; }
-extern "C" size_t imagen_sizeof(int kind) {
-  switch (kind) {
-    case IMAGEN_OP_IGEMM: return sizeof(ImagenIgemmParams);
-    case IMAGEN_OP_ROWSTAT: return sizeof(ImagenRowstatParams);
-    case IMAGEN_OP_ATTENTION: return sizeof(ImagenAttentionParams);
-    case IMAGEN_OP_KV_PREP: return sizeof(ImagenKvPrepParams);
-    case IMAGEN_OP_QNORM: return sizeof(ImagenQnormParams);
-    case IMAGEN_OP_GCA_PARTIAL: return sizeof(ImagenGcaPartialParams);
-    case IMAGEN_OP_GCA_FINAL: return sizeof(ImagenGcaFinalParams);
-    case IMAGEN_OP_GATE_RESIDUAL: return sizeof(ImagenGateResidualParams);
-    case IMAGEN_OP_LN_RESIDUAL: return sizeof(ImagenLnResidualParams);
-    case IMAGEN_OP_TIME_EMBED: return sizeof(ImagenTimeEmbedParams);
-    case IMAGEN_OP_SCALE_SHIFT: return sizeof(ImagenScaleShiftParams);
-    case IMAGEN_OP_PACK_IMAGE: return sizeof(ImagenPackImageParams);
-    case IMAGEN_OP_CFG_X0: return sizeof(ImagenCfgX0Params);
-    case IMAGEN_OP_QUANTILE: return sizeof(ImagenQuantileParams);
-    case IMAGEN_OP_DDPM_UPDATE: return sizeof(ImagenDdpmUpdateParams);
-    case IMAGEN_OP_ROWS_COPY: return sizeof(ImagenRowsCopyParams);
-    case IMAGEN_OP_MEMSET32: return sizeof(ImagenMemset32Params);
-    case IMAGEN_OP_SELECT_ROWS: return sizeof(ImagenSelectRowsParams);
-    case IMAGEN_OP_MEAN_ROWS: return sizeof(ImagenMeanRowsParams);
-    case IMAGEN_OP_RANDN: return sizeof(ImagenRandnParams);
-    case IMAGEN_OP_LOWRES_PREP: return sizeof(ImagenLowresPrepParams);
-    case IMAGEN_OP_LINCOMB: return sizeof(ImagenLincombParams);
-    case IMAGEN_OP_KV_PREP_MULTI: return sizeof(ImagenKvPrepMultiParams);
-    case IMAGEN_OP_TEMPORAL_PEG: return sizeof(ImagenTemporalPegParams);
-    case IMAGEN_OP_TEMPORAL_ATTENTION: return sizeof(ImagenTemporalAttentionParams);
-    case IMAGEN_OP_ACT_PREP: return sizeof(ImagenActPrepParams);
-    default: return 0;
-  }
+// ---- graphs and events for capi.hip: a graph is the list of recorded launches (each with its by-value kernel arguments)
+struct EmulGraph { std::vector<std::function<void()>> nodes; };
+struct EmulEvent { double t = 0; };
+namespace { thread_local EmulGraph* g_capture = nullptr; }   // (hipStreamCaptureModeThreadLocal: sampling lanes capture from their own threads)
+namespace emul {
+bool capturing() { return g_capture != nullptr; }
+void record(std::function<void()> node) { g_capture->nodes.push_back(std::move(node)); }
 }
-extern "C" int imagen_launch(int kind, const void* params, imagen_stream_t stream) {
-  if (kind != IMAGEN_OP_IGEMM) { imagen_set_error("emulated library: op kind %d is not emulated (IGEMM only)", kind); return -1; }
-  return launch_igemm(static_cast<const ImagenIgemmParams*>(params), static_cast<hipStream_t>(stream));
+hipError_t hipStreamBeginCapture(hipStream_t, int) {
+  if (g_capture) return 1;
+  g_capture = new EmulGraph();
+  return hipSuccess;
 }
-extern "C" int imagen_plan_run(const ImagenOpRef* ops, int n, imagen_stream_t stream) {
-  for (int i = 0; i < n; ++i) {
-    const int rc = imagen_launch(ops[i].kind, ops[i].params, stream);
-    if (rc != 0) return rc;
-  }
-  return 0;
+hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t* g) {
+  if (!g_capture) return 1;
+  *g = g_capture;
+  g_capture = nullptr;
+  return hipSuccess;
 }
-extern "C" int imagen_graph_begin(imagen_stream_t) { imagen_set_error("emulated library: no graphs"); return -1; }
-extern "C" int imagen_graph_end(imagen_stream_t, void**) { return -1; }
-extern "C" int imagen_graph_launch(void*, imagen_stream_t) { return -1; }
-extern "C" int imagen_graph_destroy(void*) { return -1; }
-extern "C" int imagen_event_create(void**) { return -1; }
-extern "C" int imagen_event_record(void*, imagen_stream_t) { return -1; }
-extern "C" int imagen_event_elapsed_ms(void*, void*, float*) { return -1; }
-extern "C" int imagen_event_destroy(void*) { return -1; }
+hipError_t hipGraphInstantiate(hipGraphExec_t* e, hipGraph_t g, void*, void*, size_t) { *e = new EmulGraph(*g); return hipSuccess; }
+hipError_t hipGraphDestroy(hipGraph_t g) { delete g; return hipSuccess; }
+hipError_t hipGraphLaunch(hipGraphExec_t e, hipStream_t) {
+  for (auto& n : e->nodes) n();
+  return hipSuccess;
+}
+hipError_t hipGraphExecDestroy(hipGraphExec_t e) { delete e; return hipSuccess; }
+static double now_ms() { timespec ts; clock_gettime(CLOCK_MONOTONIC, &ts); return ts.tv_sec * 1e3 + ts.tv_nsec * 1e-6; }
+hipError_t hipEventCreate(hipEvent_t* e) { *e = new EmulEvent(); return hipSuccess; }
+hipError_t hipEventRecord(hipEvent_t e, hipStream_t) { e->t = now_ms(); return hipSuccess; }
+hipError_t hipEventSynchronize(hipEvent_t) { return hipSuccess; }
+hipError_t hipEventElapsedTime(float* ms, hipEvent_t a, hipEvent_t b) { *ms = (float)(b->t - a->t); return hipSuccess; }
+hipError_t hipEventDestroy(hipEvent_t e) { delete e; return hipSuccess; }

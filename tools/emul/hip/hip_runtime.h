@@ -20,13 +20,18 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <tuple>
+#include <functional>
+#include <type_traits>
 
 #define __global__
 #define __device__
 #define __host__
 #define __forceinline__ inline __attribute__((always_inline))
 #define __launch_bounds__(...)
-#define __shared__
+// one OS thread runs every fiber, so thread-local storage IS workgroup-shared storage: a kernel's `__shared__ T x[N]` becomes a
+// block-scope thread_local (implicitly static) array, `extern __shared__ char smem[]` an extern thread_local one defined below
+#define __shared__ thread_local
 
 struct emul_uint3 { unsigned x, y, z; };
 struct dim3 {
@@ -76,6 +81,30 @@ void dma16(const void* gsrc, unsigned lds_dst, char* lds);
 void wait_vm(int n);
 void s_waitcnt(int imm);                        // gfx9 encoding: vmcnt = imm[3:0] | imm[15:14] << 4; the other counters need no emulation
 void launch(dim3 grid, dim3 block, size_t lds_bytes, void (*body)(void*), void* arg, char* lds, size_t lds_cap);
+template <class Tup> static void call_tuple(void* p) {
+  std::apply([](auto k, auto... a) { k(a...); }, *static_cast<Tup*>(p));
+}
+// stream capture (capi.hip's imagen_graph_*): while a capture is open a launch is RECORDED with its by-value arguments, exactly what a
+// hipGraph kernel node holds, and runs when the graph is launched
+bool capturing();
+void record(std::function<void()> node);
+template <class K, class... A> static inline void launch_k(dim3 grid, dim3 block, size_t lds_bytes, char* lds, size_t cap, K kern, A... args) {
+  auto tup = std::make_tuple(kern, args...);
+  if (capturing()) {
+    record([=]() mutable { launch(grid, block, lds_bytes, &call_tuple<decltype(tup)>, &tup, lds, cap); });
+    return;
+  }
+  launch(grid, block, lds_bytes, &call_tuple<decltype(tup)>, &tup, lds, cap);
+}
+bool wave_any(bool pred);
+template <class T> static inline T shfl_up(T v, int delta) {
+  T all[64];
+  wave_exchange(&v, all, sizeof(T));
+  const int l = thread_idx().x & 63;
+  const T r = l >= delta ? all[l - delta] : v;
+  wave_release();
+  return r;
+}
 
 template <class T> static inline T shfl_xor(T v, int mask) {
   T all[64];
@@ -93,13 +122,52 @@ template <class T> static inline T shfl(T v, int src) {
 }
 }  // namespace emul
 
-// one LDS image per translation unit; a block-scope `extern __shared__ char smem[]` of a kernel in this TU's unnamed namespace binds to it
-namespace { alignas(16) char smem[192 * 1024]; }
+// the dynamic LDS images of a translation unit, one per name the kernels declare (`extern __shared__ ... smem[] | smem_dyn[] | sm[] | lds[]`):
+// a block-scope extern declaration in this TU's unnamed namespace binds to the variable of that name
+namespace {
+alignas(16) thread_local char smem[192 * 1024];
+alignas(16) thread_local char smem_dyn[192 * 1024];
+alignas(16) thread_local float sm[48 * 1024];
+alignas(16) thread_local float lds[48 * 1024];
+}
+// single-threaded execution: atomics are plain read-modify-writes, fences are nothing
+template <class T, class U> static inline T atomicAdd(T* p, U v) { const T o = *p; *p = o + (T)v; return o; }
+template <class T, class U> static inline T atomicMin(T* p, U v) { const T o = *p; if ((T)v < o) *p = (T)v; return o; }
+template <class T, class U> static inline T atomicMax(T* p, U v) { const T o = *p; if ((T)v > o) *p = (T)v; return o; }
+#define __HIP_MEMORY_SCOPE_AGENT 0
+#define __hip_atomic_fetch_add(p, v, order, scope) atomicAdd((p), (v))
+#define __hip_atomic_store(p, v, order, scope) ((void)(*(p) = (v)))
+#define __builtin_amdgcn_fence(order, scope) ((void)0)
+#define __shfl_up(v, d) emul::shfl_up((v), (d))
+#define __any(p) emul::wave_any((p) != 0)
+static inline float rsqrtf(float v) { return 1.0f / sqrtf(v); }
+static inline float __uint_as_float(unsigned u) { float f; memcpy(&f, &u, 4); return f; }
+static inline unsigned __float_as_uint(float f) { unsigned u; memcpy(&u, &f, 4); return u; }
+static inline unsigned __umulhi(unsigned a, unsigned b) { return (unsigned)(((unsigned long long)a * b) >> 32); }
+static inline uint2 make_uint2(unsigned x, unsigned y) { return uint2{x, y}; }
+// graphs and events (capi.hip): emul_runtime.cpp
+typedef struct EmulGraph* hipGraph_t;
+typedef struct EmulGraph* hipGraphExec_t;
+typedef struct EmulEvent* hipEvent_t;
+enum { hipStreamCaptureModeThreadLocal = 1 };
+hipError_t hipStreamBeginCapture(hipStream_t, int);
+hipError_t hipStreamEndCapture(hipStream_t, hipGraph_t*);
+hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*, size_t);
+hipError_t hipGraphDestroy(hipGraph_t);
+hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t);
+hipError_t hipGraphExecDestroy(hipGraphExec_t);
+hipError_t hipEventCreate(hipEvent_t*);
+hipError_t hipEventRecord(hipEvent_t, hipStream_t);
+hipError_t hipEventSynchronize(hipEvent_t);
+hipError_t hipEventElapsedTime(float*, hipEvent_t, hipEvent_t);
+hipError_t hipEventDestroy(hipEvent_t);
 
 #define threadIdx (emul::thread_idx())
 #define blockIdx (emul::block_idx())
 #define blockDim (emul::block_dim())
 #define gridDim (emul::grid_dim())
+#define __logf(v) logf(v)
+#define __sincosf(a, s, c) sincosf((a), (s), (c))
 #define __expf(v) expf(v)   // HIP device intrinsics the kernels call by name (glibc declares, but does not export, these names)
 #define __logf(v) logf(v)
 #define __syncthreads() emul::workgroup_barrier()
@@ -118,9 +186,4 @@ namespace { alignas(16) char smem[192 * 1024]; }
 #define __builtin_amdgcn_rsqf(v) (1.0f / sqrtf(v))
 #define __builtin_amdgcn_exp2f(v) exp2f(v)
 
-// hipLaunchKernelGGL(kernel, grid, block, lds, stream, params): the kernels of this library take ONE by-value params struct
-#define hipLaunchKernelGGL(kern, grid, block, lds, stream, params)                                   \
-  do {                                                                                               \
-    struct EmulCall { decltype(kern) k; std::remove_cv_t<std::remove_reference_t<decltype(params)>> p; } call_{kern, params}; \
-    emul::launch(grid, block, lds, [](void* a) { auto* c = static_cast<EmulCall*>(a); c->k(c->p); }, &call_, smem, sizeof(smem)); \
-  } while (0)
+#define hipLaunchKernelGGL(kern, grid, block, lds_bytes, stream, ...) emul::launch_k(grid, block, lds_bytes, smem, sizeof(smem), kern, __VA_ARGS__)
