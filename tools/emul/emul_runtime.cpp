@@ -43,6 +43,7 @@ struct Wave {
 };
 std::vector<Wave> waves;
 void (*g_body)(void*) = nullptr;
+long g_divergent_wave_ops = 0;   // wave operations completed with part of the wave (see launch())
 void* g_arg = nullptr;
 
 void block_here() { swapcontext(&fibers[cur].ctx, &sched_ctx); }
@@ -214,6 +215,22 @@ void launch(dim3 grid, dim3 block, size_t lds_bytes, void (*body)(void*), void* 
     int done = 0;
     while (done < n) {
       if (runq.empty()) {
+        // a wave operation inside a divergent branch (a sub-group of the wave reduces with __shfl_xor while the other lanes have moved on
+        // to the workgroup barrier): the hardware executes it with the lanes present.  When nothing else can run, let the oldest such
+        // partial exchange go with the lanes it has (absent lanes' deposits are stale — a kernel that needed them shows it in its output)
+        bool forced = false;
+        for (auto& w : waves) {
+          for (Group* g : {&w.arrive, &w.release}) {
+            if (!forced && g->count > 0 && !g->waiters.empty()) {
+              g->count = 0;
+              for (int f : g->waiters) runq.push_back(f);
+              g->waiters.clear();
+              forced = true;
+              ++g_divergent_wave_ops;
+            }
+          }
+        }
+        if (forced) continue;
         fprintf(stderr, "emul: DEADLOCK in workgroup %u: %d of %d threads finished, the rest wait at a rendezvous the others never reach "
                         "(workgroup barrier %d/%d", b, done, n, wg_group.count, wg_group.size);
         for (size_t w = 0; w < waves.size(); ++w)
