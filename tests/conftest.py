@@ -24,6 +24,46 @@ def gpu_device():
     return torch.device("cpu" if EMULATED else "cuda:0")
 
 
+PARITY_LOG = []   # (test id, {name: measured error}) — filled by record_parity(), printed in the terminal summary so the driver's pytest.log carries the figures
+
+
+def record_parity(test_id, **vals):
+    """Keep measured parity figures of a passing test: printed at the end of the run (also with -q) and written to
+    gpurun_out/parity_measured.json (copied to profiles/ by the round's measurement script)."""
+    import json
+    PARITY_LOG.append((test_id, vals))
+    path = os.path.join(ROOT, "gpurun_out", "parity_measured.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        try:
+            rec = json.load(open(path))
+        except (OSError, ValueError):
+            rec = {}
+        rec[test_id] = vals
+        with open(path, "w") as f:
+            json.dump(rec, f, indent=1, sort_keys=True, default=str)
+    except OSError:
+        pass
+
+
+def pytest_terminal_summary(terminalreporter):
+    if not PARITY_LOG:
+        return
+    terminalreporter.write_sep("=", "measured parity (normwise relative error vs the oracle / reference fixtures)")
+    for tid, vals in PARITY_LOG:
+        parts = []
+        for k, v in vals.items():
+            if isinstance(v, float):
+                parts.append(f"{k}={v:.2e}")
+            elif isinstance(v, dict):
+                fl = [x for x in v.values() if isinstance(x, float)]
+                if fl:
+                    parts.append(f"max({k})={max(fl):.2e}")
+            else:
+                parts.append(f"{k}={v}")
+        terminalreporter.write_line(f"{tid}: " + " ".join(parts))
+
+
 def pytest_collection_modifyitems(config, items):
     import torch
 
