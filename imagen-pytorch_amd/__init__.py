@@ -18,10 +18,9 @@ try:  # the model classes need the ops layer; keep the ABI importable on its own
     from .schedules import GaussianDiffusionContinuousTimes  # noqa: F401
     from .checkpoint import (ElucidatedImagenConfig, ImagenConfig, NullUnetConfig, Unet3DConfig, UnetConfig,  # noqa: F401
                              load_imagen_from_checkpoint, load_trainer_checkpoint, save_checkpoint)
-    from .trainer import ImagenTrainer  # noqa: F401  (sampling half: load / sample / save)
     __all__ += ["Unet", "Unet3D", "NullUnet", "BaseUnet64", "SRUnet256", "SRUnet1024", "Imagen", "Conditioning", "ElucidatedImagen", "GaussianDiffusionContinuousTimes",
                 "load_imagen_from_checkpoint", "load_trainer_checkpoint", "save_checkpoint", "ImagenConfig", "ElucidatedImagenConfig", "UnetConfig",
-                "Unet3DConfig", "NullUnetConfig", "ImagenTrainer"]
+                "Unet3DConfig", "NullUnetConfig"]
 except ModuleNotFoundError as _e:  # pragma: no cover - only while the package is being bootstrapped
     if _e.name not in ("imagen_pytorch_amd.unet", "imagen_pytorch_amd.imagen", "imagen_pytorch_amd.schedules"):
         raise

@@ -106,6 +106,7 @@ OP_STRUCT = {
     ENUMS["IMAGEN_OP_TEMPORAL_PEG"]: STRUCTS["ImagenTemporalPegParams"],
     ENUMS["IMAGEN_OP_TEMPORAL_ATTENTION"]: STRUCTS["ImagenTemporalAttentionParams"],
     ENUMS["IMAGEN_OP_ACT_PREP"]: STRUCTS["ImagenActPrepParams"],
+    ENUMS["IMAGEN_OP_GCA_TAIL"]: STRUCTS["ImagenGcaTailParams"],
 }
 STRUCT_KIND = {v: k for k, v in OP_STRUCT.items()}
 

@@ -356,202 +356,14 @@ __global__ __launch_bounds__(512, MINW) void attention_kernel_w8(const ImagenAtt
   }
 }
 
-// ---- third tiling: the 8-wave / 64-key kernel software-pipelined INSIDE each wave.
-// The softmax of a tile is ~0.9k VALU cycles per wave (32 quarter-rate v_exp_f32 + adds + converts), its 16 MFMAs 0.5k matrix-pipe
-// cycles; issued one after the other (kernel above) the two pipes take turns.  Here the 8 S^T MFMAs of tile t+1 are issued between
-// the exponentials of tile t, and the running-max bookkeeping of tile t+1 between the 8 PV MFMAs of tile t: an in-order wave keeps
-// issuing VALU while its MFMA executes, so both pipes work at once.  Further:
-//   * the S^T accumulators start at -m_run (the C operand of the first MFMA), so exp2 takes them as they come — the subtraction of
-//     the running maximum costs nothing unless a row sees a NEW maximum in this tile (wave-uniform check, rare after the first tiles);
-//   * K / V^T tiles sit in a ring of three LDS slots (tile t+1 must be resident while tile t is being consumed), global loads run
-//     two tiles ahead in registers.
-// One workgroup per CU (the two S^T accumulator sets + O^T need ~160 registers).
-__global__ __launch_bounds__(512, 2) void attention_kernel_w8p(const ImagenAttentionParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem_dyn[];
-  constexpr int SLOT = KBYTES2 + VBYTES2;
-  char* smem = smem_dyn;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int half = lane >> 5, l31 = lane & 31;
-  const int b = blockIdx.z, hd = blockIdx.y;
-  const int row = blockIdx.x * 256 + wave * 32 + l31;
-  const int row_c = row < p.rows ? row : p.rows - 1;
-
-  const f16* q = reinterpret_cast<const f16*>(p.q) + (size_t)b * p.q_bs + (size_t)hd * p.q_hs + (size_t)row_c * p.q_rs;
-  f16x8 qf[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const f16x8*>(q + 16 * s + 8 * half);
-  if (p.q_scale) {   // fused QNORM (ip.py:559-560)
-    float ssq = 0.f;
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) ssq += (float)qf[s][j] * (float)qf[s][j];
-    ssq += __shfl_xor(ssq, 32);
-    const float inv = p.q_mult / fmaxf(sqrtf(ssq), 1e-12f);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const float4 g0 = *reinterpret_cast<const float4*>(p.q_scale + 16 * s + 8 * half);
-      const float4 g1 = *reinterpret_cast<const float4*>(p.q_scale + 16 * s + 8 * half + 4);
-      const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-#pragma unroll
-      for (int j = 0; j < 8; ++j) qf[s][j] = (f16)((float)qf[s][j] * inv * g[j]);
-    }
-  }
-
-  const f16* kg = reinterpret_cast<const f16*>(p.k) + (size_t)b * p.k_bs + (size_t)hd * p.k_hs;
-  const f16* vg = reinterpret_cast<const f16*>(p.vt) + (size_t)b * p.vt_bs + (size_t)hd * p.vt_hs;
-  const int sk_key = tid >> 3, sk_dg = tid & 7;
-  const int sv_d = tid >> 3, sv_kg = tid & 7;
-  const int Jpad = (p.J + 31) & ~31;
-  const int ntiles = (p.J + KT2 - 1) / KT2;
-
-  uint4 k_stage, v_stage;
-  auto tile_load = [&](int t) {   // tiles past the end re-read tile 0 (never consumed)
-    const int kt0 = t < ntiles ? t * KT2 : 0;
-    const int kk = kt0 + sk_key < Jpad ? kt0 + sk_key : kt0;
-    const int kv = kt0 + sv_kg * 8 < Jpad ? kt0 + sv_kg * 8 : kt0;
-    k_stage = *reinterpret_cast<const uint4*>(kg + (size_t)kk * p.k_rs + sk_dg * 8);
-    v_stage = *reinterpret_cast<const uint4*>(vg + (size_t)sv_d * p.vt_ds + kv);
-  };
-  auto tile_store = [&](char* buf) {
-    *reinterpret_cast<uint4*>(buf + sk_key * KSTR + sk_dg * 16) = k_stage;
-    char* vrow = buf + KBYTES2 + sv_d * VSTR2 + (sv_kg >> 1) * 32 + (sv_kg & 1) * 8;   // key order [0-3, 8-11, 4-7, 12-15] per 16 keys
-    *reinterpret_cast<uint2*>(vrow) = make_uint2(v_stage.x, v_stage.y);
-    *reinterpret_cast<uint2*>(vrow + 16) = make_uint2(v_stage.z, v_stage.w);
-  };
-  auto k_frag = [&](const char* kb, int h2, int s) __attribute__((always_inline)) -> f16x8 {
-    return *reinterpret_cast<const f16x8*>(kb + (32 * h2 + l31) * KSTR + (16 * s + 8 * half) * 2);
-  };
-
-  f32x16 oacc[2];
-#pragma unroll
-  for (int db = 0; db < 2; ++db)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
-  float m_run = 0.f, l_run = 0.f;   // (the first tile sets m_run to its row maximum, whatever its sign)
-
-  // S'(t) = S(t) - m_run in sc; masked for the ragged last tile; then the running maximum is raised if a row exceeds it
-  f32x16 sc[2], sn[2];
-  auto finish_scores = [&](f32x16 (&sx)[2], int t) __attribute__((always_inline)) {
-    if (t == ntiles - 1) {
-#pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = t * KT2 + 32 * h2 + 4 * half + (r & 3) + 8 * (r >> 2);
-          if (key >= p.J) sx[h2][r] = -1.0e30f;
-        }
-    }
-    float mx = sx[0][0];
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) mx = fmaxf(mx, sx[h2][r]);
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    if (t == 0 || __any(mx > 0.f)) {   // some row of the wave has a new maximum: shift its scores, rescale what it has accumulated
-      const float d = t == 0 ? mx : fmaxf(mx, 0.f);
-      const float alpha = __builtin_amdgcn_exp2f(-d);
-#pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) sx[h2][r] -= d;
-      l_run *= alpha;
-#pragma unroll
-      for (int db = 0; db < 2; ++db)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
-      m_run += d;
-    }
-  };
-
-  // ---- prologue: tiles 0 and 1 into the ring, S'(0)
-  tile_load(0);
-  tile_store(smem);
-  tile_load(1);
-  tile_store(smem + SLOT);
-  tile_load(2);
-  __syncthreads();
-#pragma unroll
-  for (int h2 = 0; h2 < 2; ++h2) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) sc[h2][r] = 0.f;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) sc[h2] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k_frag(smem, h2, s), qf[s], sc[h2], 0, 0, 0);
-  }
-  finish_scores(sc, 0);
-
-  int slot = 0;   // ring slot of tile t
-  for (int t = 0; t < ntiles; ++t) {
-    const char* kb_n = smem + (slot == 2 ? 0 : slot + 1) * SLOT;        // tile t+1 (resident since the previous barrier)
-    const char* vb = smem + slot * SLOT + KBYTES2;                      // V^T of tile t
-    // ---- part A: exponentials of tile t (VALU) with the S^T MFMAs of tile t+1 between them
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) sn[h2][r] = -m_run;
-    float psum = 0.f;
-    f16x8 pf[4];
-#pragma unroll
-    for (int g = 0; g < 8; ++g) {   // 8 groups: one MFMA + 4 exponentials each
-      const int h2m = g >> 2, sm = g & 3;
-      sn[h2m] = __builtin_amdgcn_mfma_f32_32x32x16_f16(k_frag(kb_n, h2m, sm), qf[sm], sn[h2m], 0, 0, 0);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const int e = 4 * g + j, h2 = e >> 4, r = e & 15;
-        const float ex = __builtin_amdgcn_exp2f(sc[h2][r]);
-        psum += ex;
-        pf[2 * h2 + (r >> 3)][r & 7] = (f16)ex;
-      }
-    }
-    l_run += psum;
-    // ---- part B: PV MFMAs of tile t (matrix pipe) with the maximum bookkeeping of tile t+1 (VALU) behind them
-#pragma unroll
-    for (int h2 = 0; h2 < 2; ++h2)
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int db = 0; db < 2; ++db) {
-          const f16x8 vf = *reinterpret_cast<const f16x8*>(vb + (32 * db + l31) * VSTR2 + (32 * h2 + 16 * s + 8 * half) * 2);
-          oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[2 * h2 + s], oacc[db], 0, 0, 0);
-        }
-    if (t + 1 < ntiles) {
-      finish_scores(sn, t + 1);
-#pragma unroll
-      for (int h2 = 0; h2 < 2; ++h2) sc[h2] = sn[h2];
-    }
-    // ---- ring: tile t+2 (in registers since the previous iteration) into the slot tile t-1 occupied; loads of tile t+3
-    const int slot_w = slot == 0 ? 2 : slot - 1;
-    tile_store(smem + slot_w * SLOT);
-    tile_load(t + 3);
-    __syncthreads();
-    slot = slot == 2 ? 0 : slot + 1;
-  }
-
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = 1.0f / l_tot;
-  if (row < p.rows) {
-    f16* o = reinterpret_cast<f16*>(p.o) + (size_t)b * p.o_bs + (size_t)hd * p.o_hs + (size_t)row * p.o_rs;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        f16x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (f16)(oacc[db][4 * qd + e] * inv);
-        *reinterpret_cast<f16x4*>(o + 32 * db + 8 * qd + 4 * half) = v;
-      }
-  }
-}
-
 }  // namespace
 
 int launch_attention(const ImagenAttentionParams* p, hipStream_t s) {
   IMAGEN_CHECK(p->rows > 0 && p->J > 0 && p->B > 0 && p->heads > 0, "attention: empty problem");
   IMAGEN_CHECK(p->q_rs % 8 == 0 && p->k_rs % 8 == 0 && p->vt_ds % 8 == 0 && p->o_rs % 4 == 0,
                "attention: strides must keep 16B alignment");
-  static const int force = [] { const char* e = getenv("IMAGEN_ATTN_KERNEL"); return e ? atoi(e) : 0; }();   // A/B: 1 = 4-wave, 2.. = 8-wave variants
   IMAGEN_CHECK(p->head_dim == 0 || p->head_dim == 64 || p->head_dim == 32, "attention: head_dim %d (64 or 32)", p->head_dim);
-  if (p->head_dim != 32 && ((p->rows >= 256 && force != 1) || force >= 2)) {
+  if (p->head_dim != 32 && p->rows >= 256) {
     dim3 grid((p->rows + 255) / 256, p->heads, p->B);
     auto launch = [&](auto kern, int lds) {
       static bool attr_done[16] = {};   // (per kernel instantiation: one lambda instantiation per `kern` type; per device)
@@ -564,10 +376,7 @@ int launch_attention(const ImagenAttentionParams* p, hipStream_t s) {
       hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, *p);
     };
     constexpr int slot = KBYTES2 + VBYTES2;
-    if (force == 4) launch(attention_kernel_w8p, 3 * slot);
-    else if (force == 3) launch(attention_kernel_w8<2, 1>, 2 * slot);
-    else if (force == 2) launch(attention_kernel_w8<4, 1>, 2 * slot);
-    else if (p->J <= 2 * KT2) launch(attention_kernel_w8<4, 1>, 2 * slot);   // one or two tiles: nothing to gain from staging two at a time
+    if (p->J <= 2 * KT2) launch(attention_kernel_w8<4, 1>, 2 * slot);   // one or two tiles: nothing to gain from staging two at a time
     else launch(attention_kernel_w8<4, 2>, 4 * slot);
     return imagen_hip_status("attention");
   }

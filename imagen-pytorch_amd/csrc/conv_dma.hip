@@ -55,10 +55,7 @@ __device__ __forceinline__ void cd_dma16(const void* gsrc, unsigned lds_dst) {
 // PF: fragment prefetch distance in K steps (PF + 1 register sets).  With PF = 1 a wave that finds its ds_reads slower than one K step
 // (LDS latency under 20 reads + 5 KiB of DMA writes per K step and CU: 250-300 cycles against 128 cycles of MFMA work) stalls every
 // step: r02_pmc_sq_dma.json shows 46 % of the wave cycles in s_waitcnt at 37 % MFMA-pipe occupancy.
-// DBG (only instantiated with -DCD_PROBE, tools/build_probe_lib.sh): compile-time ablations for time attribution — 1: no weight DMA in the
-// loop, 2: no activation DMA in the loop, 4: no B-fragment reads in the loop, 8: no A-fragment reads, 16: no MFMAs, 32: no chunk
-// barrier, 64: no vmcnt waits.  Results are garbage; every variant is its own kernel, so the others' schedules are untouched.
-template <int MI, int NI, int WM, int WN, int TW, int RW, int PF, bool GEN, int DBG = 0>
+template <int MI, int NI, int WM, int WN, int TW, int RW, int PF, bool GEN>
 __global__ __launch_bounds__(256, (MI * NI <= 2 ? 3 : 2)) void conv_dma_kernel(const ImagenIgemmParams p) {
   static_assert(WM * WN == 4, "4 waves per workgroup");
   static_assert(PF >= 1 && PF <= 3, "fragment prefetch distance");
@@ -180,15 +177,14 @@ __global__ __launch_bounds__(256, (MI * NI <= 2 ? 3 : 2)) void conv_dma_kernel(c
 
   struct Frags { f16x8 a[NI], b[MI]; };
   Frags F[NS];   // (indexed by compile-time constants only)
-  bool first_read = true;   // (probe builds: the ablated reads still run once, so that the registers hold finite values)
   // fragment f of a K step: f < NI: A fragment f, else B fragment f - NI (all arguments compile-time)
   auto read_frag = [&](Frags& Fr, int f, int buf, int t, int slot, int ks) __attribute__((always_inline)) {
     const int dy = t / 3, dx = t - 3 * dy;
     if (f < NI) {
-      if (!(DBG & 8) || first_read) Fr.a[f] = *reinterpret_cast<const f16x8*>(smem + aL + (slot * SLOTW + f * 2048 + ks * 1024));
+      Fr.a[f] = *reinterpret_cast<const f16x8*>(smem + aL + (slot * SLOTW + f * 2048 + ks * 1024));
     } else {
       const int mi = f - NI;
-      if (!(DBG & 4) || first_read) Fr.b[mi] = *reinterpret_cast<const f16x8*>(smem + (ks ? bP[mi][dx] ^ 32 : bP[mi][dx]) + (buf * ABUF + dy * PITCH));
+      Fr.b[mi] = *reinterpret_cast<const f16x8*>(smem + (ks ? bP[mi][dx] ^ 32 : bP[mi][dx]) + (buf * ABUF + dy * PITCH));
     }
   };
   auto read_frags = [&](Frags& Fr, int buf, int t, int slot, int ks) __attribute__((always_inline)) {
@@ -228,11 +224,10 @@ __global__ __launch_bounds__(256, (MI * NI <= 2 ? 3 : 2)) void conv_dma_kernel(c
 #pragma unroll
   for (int j = 0; j < RW - 1; ++j) dma_weights(j);
   CD_VM0_BARRIER();
-  cd_static_for<NS>([&](auto kc) __attribute__((always_inline)) {   // (set PF is overwritten by the first loop step; read here for the probe builds)
+  cd_static_for<NS>([&](auto kc) __attribute__((always_inline)) {   // (set PF is overwritten by the first loop step)
     constexpr int k = decltype(kc)::value;
     read_frags(F[k % NS], 0, k / 2, (k / 2) % RW, k % 2);
   });
-  first_read = false;
 
   // one 32-channel chunk = 9 taps x 2 K steps; PAR = chunk parity (halo buffer, fragment-set phase, and the ring phase when 9 % RW != 0).
   //
@@ -259,21 +254,20 @@ __global__ __launch_bounds__(256, (MI * NI <= 2 ? 3 : 2)) void conv_dma_kernel(c
       static_assert(L - u >= 0, "stage not issued yet");
       constexpr bool new_stage = kk % 2 == 0;                      // first read of stage u: this wave's own weight DMA must have landed
       constexpr int M = MI * NI, R = NI + MI;
-      constexpr int DA = (ks == 0 && t == 0 && !(DBG & 2)) ? NJ : 0;
-      constexpr int DW = (ks == 0 && !(DBG & 1)) ? KD : 0;
+      constexpr int DA = (ks == 0 && t == 0) ? NJ : 0;
+      constexpr int DW = ks == 0 ? KD : 0;
       constexpr int NF = R + DA + DW, per = (NF + M - 1) / M;
       Frags& cur = F[(18 * PAR + k) % NS];
       Frags& nx = F[(18 * PAR + kk) % NS];
       cd_static_for<M>([&](auto gc) __attribute__((always_inline)) {
         constexpr int g = decltype(gc)::value;
         constexpr int ni = g / MI, mi = g % MI;
-        if constexpr (!(DBG & 16)) acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[ni], cur.b[mi], acc[ni][mi], 0, 0, 0);
-        else asm volatile("" :: "v"(cur.a[ni]), "v"(cur.b[mi]));   // (keep the reads alive)
+        acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[ni], cur.b[mi], acc[ni][mi], 0, 0, 0);
         __builtin_amdgcn_sched_barrier(0);
         if constexpr (g == 0) {
-          if constexpr (new_stage && !(DBG & (64 | 1 | 2))) CD_WAIT_VM(N);
+          if constexpr (new_stage) CD_WAIT_VM(N);
           // chunk boundary: every wave's part of the next halo tile has landed, everybody is done reading this one
-          if constexpr (kk == 18 && !(DBG & 32)) CD_LGKM0_BARRIER();
+          if constexpr (kk == 18) CD_LGKM0_BARRIER();
         }
         cd_static_for<per>([&](auto fc) __attribute__((always_inline)) {
           constexpr int f = g * per + decltype(fc)::value;
@@ -301,7 +295,7 @@ __global__ __launch_bounds__(256, (MI * NI <= 2 ? 3 : 2)) void conv_dma_kernel(c
   cl_epilogue<MI, NI, WM, WN, GEN>(p, tc, acc, pix_y, pix_x, ep_red, reinterpret_cast<float*>(smem), wm, wn, half, l31);
 }
 
-template <int MI, int NI, int WM, int WN, int TW, int RW, int PF, bool GEN, int DBG = 0>
+template <int MI, int NI, int WM, int WN, int TW, int RW, int PF, bool GEN>
 int cd_launch_gen(const ImagenIgemmParams& p, hipStream_t s) {
   constexpr int TP = 32 * MI * WM, TH = TP / TW, BN = 32 * NI * WN;
   constexpr int NJ = (((TH + 2) * (TW + 2) * 4 + 63) / 64 + 3) / 4;
@@ -322,7 +316,7 @@ int cd_launch_gen(const ImagenIgemmParams& p, hipStream_t s) {
                "conv_dma: ssq_out needs NHWC output and one workgroup covering all %d output channels (tile has %d)", p.Cout, BN);
   const size_t lds = (size_t)2 * NJ * 4096 + (size_t)4 * RW * (NI * 2048) + (size_t)(4 * 32 * MI) * sizeof(float) + 16;
   IMAGEN_CHECK(lds <= 160 * 1024, "conv_dma: LDS tile %zu bytes too large", lds);
-  auto kern = conv_dma_kernel<MI, NI, WM, WN, TW, RW, PF, GEN, DBG>;
+  auto kern = conv_dma_kernel<MI, NI, WM, WN, TW, RW, PF, GEN>;
   static bool attr_done[16] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -343,10 +337,6 @@ int cd_launch(const ImagenIgemmParams& p, hipStream_t s) {
   return plain ? cd_launch_gen<MI, NI, WM, WN, TW, RW, PF, false>(p, s) : cd_launch_gen<MI, NI, WM, WN, TW, RW, PF, true>(p, s);
 }
 
-#ifdef CD_PROBE
-template <int DBG>
-int cd_launch_probe(const ImagenIgemmParams& p, hipStream_t s) { return cd_launch_gen<4, 1, 1, 4, 16, 3, 1, false, DBG>(p, s); }
-#endif
 
 struct CdCfg { int MI, NI, WM, WN, TW, RW, PF; };
 constexpr CdCfg kCdCfgs[] = {
@@ -370,10 +360,6 @@ constexpr CdCfg kCdCfgs[] = {
     {2, 1, 1, 4, 8, 6, 3},    // 17:  64 px x 128 co, 3 K steps ahead
     {2, 1, 2, 2, 16, 6, 2},   // 18: 128 px x  64 co, 2 K steps ahead
     {4, 1, 2, 2, 16, 6, 2},   // 19: 256 px x  64 co, 2 K steps ahead
-#ifdef CD_PROBE   // ablation variants of cfg 0 (plain epilogue only), in the order of kProbeDbg below
-    {4, 1, 1, 4, 16, 3, 1}, {4, 1, 1, 4, 16, 3, 1}, {4, 1, 1, 4, 16, 3, 1}, {4, 1, 1, 4, 16, 3, 1}, {4, 1, 1, 4, 16, 3, 1}, {4, 1, 1, 4, 16, 3, 1},
-    {4, 1, 1, 4, 16, 3, 1}, {4, 1, 1, 4, 16, 3, 1}, {4, 1, 1, 4, 16, 3, 1}, {4, 1, 1, 4, 16, 3, 1},
-#endif
 };
 constexpr int kNumCdCfgs = sizeof(kCdCfgs) / sizeof(kCdCfgs[0]);
 
@@ -423,18 +409,6 @@ int launch_conv_dma(const ImagenIgemmParams* pp, int idx, hipStream_t s) {
     case 17: return cd_launch<2, 1, 1, 4, 8, 6, 3>(p, s);
     case 18: return cd_launch<2, 1, 2, 2, 16, 6, 2>(p, s);
     case 19: return cd_launch<4, 1, 2, 2, 16, 6, 2>(p, s);
-#ifdef CD_PROBE
-    case 20: return cd_launch_probe<1>(p, s);            // no weight DMA
-    case 21: return cd_launch_probe<2>(p, s);            // no activation DMA
-    case 22: return cd_launch_probe<3>(p, s);            // no DMA at all
-    case 23: return cd_launch_probe<4>(p, s);            // no B reads
-    case 24: return cd_launch_probe<8>(p, s);            // no A reads
-    case 25: return cd_launch_probe<12>(p, s);           // no fragment reads
-    case 26: return cd_launch_probe<3 | 12>(p, s);       // MFMA + loop only
-    case 27: return cd_launch_probe<16>(p, s);           // no MFMA
-    case 28: return cd_launch_probe<32>(p, s);           // no chunk barrier
-    case 29: return cd_launch_probe<64>(p, s);           // no vmcnt waits
-#endif
   }
   imagen_set_error("conv_dma: bad cfg index %d", idx);
   return -1;

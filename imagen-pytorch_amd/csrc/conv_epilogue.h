@@ -1,16 +1,10 @@
-// conv_epilogue.h — the epilogue shared by the LDS-staged conv kernels (conv_lds.hip, conv_dma.hip): accumulators D[cout][pixel]
+// conv_epilogue.h — the epilogue of the all-DMA conv kernel (conv_dma.hip): accumulators D[cout][pixel]
 // (lane = pixel; register quad q of a 32x32 fragment holds couts 8q + 4*half + {0..3}) -> bias / activation / gate*addend / residual
 // / pixel-shuffle / fp32-NCHW / output-side Block prologue (post_pa) / per-pixel sum of squares, as documented at ImagenIgemmParams.
 #pragma once
 #include "common.h"
 
 struct ClTile { int b, oy0, ox0, n0; };
-
-#ifdef CL_PROBE
-#define CL_DBG(bit) ((p.dbg & (bit)) != 0)
-#else
-#define CL_DBG(bit) false
-#endif
 
 // ep_par: LDS scratch of 5 * BN + 8 * 32 * MI floats, dead staging memory of the caller (all its LDS traffic retired: call behind a barrier).  The
 // per-channel epilogue operands (bias, post_pa, post_ps) are fetched ONCE per workgroup into it: a dependent global load per channel
@@ -138,7 +132,7 @@ __device__ __forceinline__ void cl_epilogue(const ImagenIgemmParams& p, const Cl
           for (int mi = 0; mi < MI; ++mi) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) o2[h][mi][e] = (f16)silu_f(acc[ni][mi][4 * q + e] * rsn[mi] * pav[e] + psv[e]);
-            if (!wide && co < p.Cout && op[mi] >= 0 && !CL_DBG(8)) *reinterpret_cast<f16x4*>(y + (size_t)op[mi] * p.ldy + co) = o2[h][mi];
+            if (!wide && co < p.Cout && op[mi] >= 0) *reinterpret_cast<f16x4*>(y + (size_t)op[mi] * p.ldy + co) = o2[h][mi];
           }
         }
         if (wide) {
@@ -146,7 +140,7 @@ __device__ __forceinline__ void cl_epilogue(const ImagenIgemmParams& p, const Cl
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi) {
             const imagen_u32x4 v = imagen_pair_quads(o2[0][mi], o2[1][mi]);
-            if (co16 < p.Cout && op[mi] >= 0 && !CL_DBG(8)) *reinterpret_cast<imagen_u32x4*>(y + (size_t)op[mi] * p.ldy + co16) = v;
+            if (co16 < p.Cout && op[mi] >= 0) *reinterpret_cast<imagen_u32x4*>(y + (size_t)op[mi] * p.ldy + co16) = v;
           }
         }
       }
@@ -184,7 +178,7 @@ __device__ __forceinline__ void cl_epilogue(const ImagenIgemmParams& p, const Cl
               acc[ni][mi][4 * q + e] = r;          // (the GlobalContext block below reads the stored values back from here)
               gca_k[mi] += r * ww[e];
             }
-            if (!wide && co < p.Cout && op[mi] >= 0 && !CL_DBG(8)) *reinterpret_cast<f16x4*>(y + (size_t)op[mi] * p.ldy + co) = o2[h][mi];
+            if (!wide && co < p.Cout && op[mi] >= 0) *reinterpret_cast<f16x4*>(y + (size_t)op[mi] * p.ldy + co) = o2[h][mi];
           }
         }
         if (wide) {
@@ -192,7 +186,7 @@ __device__ __forceinline__ void cl_epilogue(const ImagenIgemmParams& p, const Cl
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi) {
             const imagen_u32x4 v = imagen_pair_quads(o2[0][mi], o2[1][mi]);
-            if (co16 < p.Cout && op[mi] >= 0 && !CL_DBG(8)) *reinterpret_cast<imagen_u32x4*>(y + (size_t)op[mi] * p.ldy + co16) = v;
+            if (co16 < p.Cout && op[mi] >= 0) *reinterpret_cast<imagen_u32x4*>(y + (size_t)op[mi] * p.ldy + co16) = v;
           }
         }
       }
@@ -328,7 +322,7 @@ __device__ __forceinline__ void cl_epilogue(const ImagenIgemmParams& p, const Cl
             const int oy = tc.oy0 + pix_y[mi], ox = tc.ox0 + pix_x[mi];
             const int yy = 2 * oy + (sub >> 1), xx = 2 * ox + (sub & 1);
             *reinterpret_cast<f16x4*>(y + (size_t)b * p.bsy + ((size_t)yy * (2 * p.OW) + xx) * p.ldy + cc) = o;
-          } else if (!CL_DBG(8)) {
+          } else {
             *reinterpret_cast<f16x4*>(y + (size_t)b * p.bsy + (size_t)op[mi] * p.ldy + co) = o;
           }
         }

@@ -265,8 +265,8 @@ __global__ __launch_bounds__(64 * CS_NW, NCH == 1 ? 4 : 2) void conv_stream_kern
   int stores_behind = 0;
   // store instructions of the plain / post epilogue of conv_epilogue.h per wave (a lower bound is what the wait needs): one 16-byte piece
   // per pair of channel quads when Cout is a multiple of 8, else one 8-byte store per quad below Cout
-  const int quads = (GEN || CL_DBG(8)) ? 0 : ((p.Cout & 7) == 0 ? 1 + (p.Cout > 8 ? 1 : 0) : min((p.Cout + 7) >> 3, 4));
-  const bool lean_ok = !GEN && p.Cout == 32 && !CL_DBG(8);   // the lean epilogue writes all four channel quads
+  const int quads = GEN ? 0 : ((p.Cout & 7) == 0 ? 1 + (p.Cout > 8 ? 1 : 0) : min((p.Cout + 7) >> 3, 4));
+  const bool lean_ok = !GEN && p.Cout == 32;   // the lean epilogue writes all four channel quads
 
   while (true) {
     float sa_c[CS_NJ], sb_c[CS_NJ];
@@ -423,10 +423,8 @@ int cs_launch_gen(const ImagenIgemmParams& p, hipStream_t s) {
   const int total = p.B * tilesX * tilesY;
   int cus = 256;
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  static const int per_cu_env = [] { const char* e = getenv("IMAGEN_STREAM_WG_PER_CU"); return e ? atoi(e) : 0; }();   // probe knob
-  const int per_cu = per_cu_env > 0 ? per_cu_env : (NCH == 1 ? 2 : 1);
-  static const int grid_pct = [] { const char* e = getenv("IMAGEN_GRID_PCT"); const int v = e ? atoi(e) : 100; return v >= 10 && v <= 100 ? v : 100; }();   // probe knob, see igemm.hip
-  const int resident = std::max(1, std::max(1, cus) * per_cu * grid_pct / 100);
+  const int per_cu = NCH == 1 ? 2 : 1;
+  const int resident = std::max(1, std::max(1, cus) * per_cu);
   int gx = total;
   if (total > resident) {   // even rounds: every workgroup walks the same number of tiles (+-1)
     const int rounds = (total + resident - 1) / resident;

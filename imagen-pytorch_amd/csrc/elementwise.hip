@@ -141,7 +141,7 @@ __global__ __launch_bounds__(256) void ln_residual_kernel(const ImagenLnResidual
     for (int j = 0; j < 8; ++j) { const float d = (float)v[j] - mean; q += d * d; }
   }
   const float rstd = rsqrtf(group_sum(q, lpr) / (float)p.C + p.eps);
-  float ssq = 0.f;
+  float ssq = 0.f, so = 0.f;
   for (int g = li; g < groups; g += lpr) {
     const f16x8 v = *reinterpret_cast<const f16x8*>(y + g * 8);
     f16x8 rv;
@@ -155,12 +155,27 @@ __global__ __launch_bounds__(256) void ln_residual_kernel(const ImagenLnResidual
       o[j] = (f16)t;
       const float tr = (float)o[j];
       ssq += tr * tr;
+      so += tr;
     }
     *reinterpret_cast<f16x8*>(out + g * 8) = o;
   }
   if (p.ssq_out) {
     const float tot = group_sum(ssq, lpr);
     if (li == 0) p.ssq_out[r] = tot;
+  }
+  if (p.mu_out) {   // LayerNorm statistics of the stored row (two-pass: a lane re-reads the groups it has just written)
+    const float mo = group_sum(so, lpr) / (float)p.C;
+    float qo = 0.f;
+    for (int g = li; g < groups; g += lpr) {
+      const f16x8 v = *reinterpret_cast<const f16x8*>(out + g * 8);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = (float)v[j] - mo; qo += d * d; }
+    }
+    const float ro = rsqrtf(group_sum(qo, lpr) / (float)p.C + p.eps_out);
+    if (li == 0) {
+      p.mu_out[r] = mo;
+      p.rs_out[r] = ro;
+    }
   }
 }
 
@@ -443,24 +458,24 @@ __global__ __launch_bounds__(256) void gca_final_kernel(const ImagenGcaFinalPara
 // gate depends on — their slice of both weight matrices (<= 8 float4 each), the chunk statistics and their partial rows — before
 // the first wait, and all arithmetic runs out of registers and LDS.  Needs power-of-two C and hidden (launcher-checked).
 constexpr int kGcaFastThreads = 1024;
-constexpr int kGcaFastW = 8;    // prefetched float4 per thread and weight matrix (larger matrices: a second, loop-carried pass)
+constexpr int kGcaFastW = 8;    // prefetched float4 per thread and weight matrix (larger matrices: a second, loop-carried pass); the fused tail kernel takes 6
 constexpr int kGcaFastP = 8;    // prefetched partial-row elements per thread
 
 // out[o] = emit(o, sum_i wt[i][o] * in[i]); wt: [n_in][n_out] fp32, n_out a power of two in [4, 4096]; w: this thread's prefetched rows
-template <class Emit>
-__device__ __forceinline__ void gca_fast_matvec(const float4 (&w)[kGcaFastW], const float* wt, int n_in, int n_out, const float* in, float4* red,
+template <int W, class Emit>
+__device__ __forceinline__ void gca_fast_matvec(const float4 (&w)[W], const float* wt, int n_in, int n_out, const float* in, float4* red,
                                                 Emit emit) {
   const int t = threadIdx.x;
   const int nvec = n_out >> 2, rpp = kGcaFastThreads / nvec;
   const int cg = t & (nvec - 1), r = t / nvec;
   float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-  for (int k = 0; k < kGcaFastW; ++k) {
+  for (int k = 0; k < W; ++k) {
     const int row = r + k * rpp;
     const float x = row < n_in ? in[row] : 0.f;
     a.x += w[k].x * x; a.y += w[k].y * x; a.z += w[k].z * x; a.w += w[k].w * x;
   }
-  for (int row = r + kGcaFastW * rpp; row < n_in; row += rpp) {
+  for (int row = r + W * rpp; row < n_in; row += rpp) {
     const float4 q = *reinterpret_cast<const float4*>(wt + (size_t)row * n_out + cg * 4);
     const float x = in[row];
     a.x += q.x * x; a.y += q.y * x; a.z += q.z * x; a.w += q.w * x;
@@ -476,24 +491,28 @@ __device__ __forceinline__ void gca_fast_matvec(const float4 (&w)[kGcaFastW], co
   __syncthreads();
 }
 
-__device__ __forceinline__ void gca_fast_prefetch(float4 (&w)[kGcaFastW], const float* wt, int n_in, int n_out) {
+template <int W>
+__device__ __forceinline__ void gca_fast_prefetch(float4 (&w)[W], const float* wt, int n_in, int n_out) {
   const int t = threadIdx.x;
   const int nvec = n_out >> 2, rpp = kGcaFastThreads / nvec;
   const int cg = t & (nvec - 1), r = t / nvec;
 #pragma unroll
-  for (int k = 0; k < kGcaFastW; ++k) {
+  for (int k = 0; k < W; ++k) {
     const int row = r + k * rpp;
     w[k] = row < n_in ? *reinterpret_cast<const float4*>(wt + (size_t)row * n_out + cg * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
 }
 
-__global__ __launch_bounds__(kGcaFastThreads) void gca_final_fast_kernel(const ImagenGcaFinalParams p) {
+// The finalisation of image b by the kGcaFastThreads threads of one workgroup: gate -> gate_a[C] and (optional) gate_b[C] (either may
+// be LDS or global memory; visible to the workgroup after the function's final barrier).
+template <int W>
+__device__ __forceinline__ void gca_final_fast_body(const float* part_base, const float* w1t, const float* b1, const float* w2t, const float* b2,
+                                                    int b, int C, int hidden, int chunks, float* gate_a, float* gate_b) {
   __shared__ float4 s_red[kGcaFastThreads];
   __shared__ float s_ctx[1024], s_hid[1024], s_wgt[1024], s_b1[1024], s_b2[1024], s_sc[40];
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
-  const int b = blockIdx.x, C = p.C, hidden = p.hidden, chunks = p.chunks;
   const int stride = C + 2;
-  const float* part = p.part + (size_t)b * chunks * stride;
+  const float* part = part_base + (size_t)b * chunks * stride;
   // ---- every global load the gate depends on, before the first wait — in the order of use (vmcnt retires in issue order)
   float2 ms = make_float2(-3.0e38f, 0.f);
   if (t < chunks) ms = *reinterpret_cast<const float2*>(part + (size_t)t * stride);
@@ -504,10 +523,10 @@ __global__ __launch_bounds__(kGcaFastThreads) void gca_final_fast_kernel(const I
     const int i = sl + j * nsl;
     pv[j] = i < chunks ? part[(size_t)i * stride + 2 + c] : 0.f;
   }
-  const float bias1 = t < hidden ? p.b1[t] : 0.f, bias2 = t < C ? p.b2[t] : 0.f;
-  float4 w1[kGcaFastW], w2[kGcaFastW];
-  gca_fast_prefetch(w1, p.w1t, C, hidden);
-  gca_fast_prefetch(w2, p.w2t, hidden, C);
+  const float bias1 = t < hidden ? b1[t] : 0.f, bias2 = t < C ? b2[t] : 0.f;
+  float4 w1[W], w2[W];
+  gca_fast_prefetch<W>(w1, w1t, C, hidden);
+  gca_fast_prefetch<W>(w2, w2t, hidden, C);
   // ---- softmax merge weights of the chunks
   float m = ms.x;
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
@@ -546,9 +565,101 @@ __global__ __launch_bounds__(kGcaFastThreads) void gca_final_fast_kernel(const I
   }
   __syncthreads();
   // ---- squeeze MLP out of the prefetched registers
-  gca_fast_matvec(w1, p.w1t, C, hidden, s_ctx, s_red, [&](int o, float v) __attribute__((always_inline)) { s_hid[o] = silu_f(v + s_b1[o]); });
-  float* gate = p.gate + (size_t)b * C;
-  gca_fast_matvec(w2, p.w2t, hidden, C, s_hid, s_red, [&](int o, float v) __attribute__((always_inline)) { gate[o] = sigmoid_f(v + s_b2[o]); });
+  gca_fast_matvec<W>(w1, w1t, C, hidden, s_ctx, s_red, [&](int o, float v) __attribute__((always_inline)) { s_hid[o] = silu_f(v + s_b1[o]); });
+  gca_fast_matvec<W>(w2, w2t, hidden, C, s_hid, s_red, [&](int o, float v) __attribute__((always_inline)) {
+    const float g = sigmoid_f(v + s_b2[o]);
+    gate_a[o] = g;
+    if (gate_b) gate_b[o] = g;
+  });
+}
+
+__global__ __launch_bounds__(kGcaFastThreads) void gca_final_fast_kernel(const ImagenGcaFinalParams p) {
+  gca_final_fast_body<kGcaFastW>(p.part, p.w1t, p.b1, p.w2t, p.b2, blockIdx.x, p.C, p.hidden, p.chunks, p.gate + (size_t)blockIdx.x * p.C, nullptr);
+}
+
+// ------------------------------------------------------------------------------------------------ gca_tail
+// The tail of an identity ResnetBlock in one launch (ImagenGcaTailParams): workgroup (slab, b) finalises the GlobalContext gate of image b
+// in LDS, then streams its slab of rows: out = h * gate + res (+ per-row statistics, + the next Block's activated input).  One lane = 8
+// channels of a row; a row = C / 8 consecutive lanes (a power of two <= 64: the reductions are shuffles inside the wave).  The first
+// pass's loads are issued BEFORE the finalisation — its ~5 dependent round trips then overlap the first rows' HBM latency.
+__global__ __launch_bounds__(kGcaFastThreads) void gca_tail_kernel(const ImagenGcaTailParams p) {
+  __shared__ float s_gate[1024];
+  const int t = threadIdx.x, b = blockIdx.y;
+  const int C = p.C, lpr = C >> 3;                         // lanes per row
+  const int rpp = kGcaFastThreads / lpr;                   // rows per pass
+  const int per = (p.HW + (int)gridDim.x - 1) / (int)gridDim.x;
+  const int r_begin = blockIdx.x * per, r_end = min(r_begin + per, p.HW);
+  const int g = t & (lpr - 1), sub = t / lpr;
+  const f16* hb = reinterpret_cast<const f16*>(p.h) + (size_t)b * p.HW * p.ld_h + g * 8;
+  const f16* rb = reinterpret_cast<const f16*>(p.res) + (size_t)b * p.HW * p.ld_res + g * 8;
+  f16* ob = reinterpret_cast<f16*>(p.out) + (size_t)b * p.HW * p.ld_out + g * 8;
+  f16* ab = p.act_out ? reinterpret_cast<f16*>(p.act_out) + (size_t)b * p.HW * p.ld_act + g * 8 : nullptr;
+  int r = r_begin + sub;
+  f16x8 hv = {}, rv = {};
+  if (r < r_end) {
+    hv = *reinterpret_cast<const f16x8*>(hb + (size_t)r * p.ld_h);
+    rv = *reinterpret_cast<const f16x8*>(rb + (size_t)r * p.ld_res);
+  }
+  // ---- the gate of image b -> LDS
+  if (p.part) {
+    gca_final_fast_body<6>(p.part, p.w1t, p.b1, p.w2t, p.b2, b, C, p.hidden, p.chunks, s_gate, (p.gate && blockIdx.x == 0) ? p.gate + (size_t)b * C : nullptr);
+  } else {
+    if (t < C) s_gate[t] = p.gate_in ? p.gate_in[(size_t)b * C + t] : 1.0f;
+    __syncthreads();
+  }
+  float4 pa0 = make_float4(0.f, 0.f, 0.f, 0.f), pa1 = pa0;
+  if (p.act_pa) {   // (an L2 hit after the first workgroups; loaded behind the finalisation to keep its register budget)
+    pa0 = *reinterpret_cast<const float4*>(p.act_pa + g * 8);
+    pa1 = *reinterpret_cast<const float4*>(p.act_pa + g * 8 + 4);
+  }
+  const float4 g0 = *reinterpret_cast<const float4*>(s_gate + g * 8), g1 = *reinterpret_cast<const float4*>(s_gate + g * 8 + 4);
+  const float gt[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+  const float pa[8] = {pa0.x, pa0.y, pa0.z, pa0.w, pa1.x, pa1.y, pa1.z, pa1.w};
+  const float inv_c = 1.0f / (float)C;
+  while (r < r_end) {   // (rows are dealt to whole lane groups: the loop condition is uniform inside a group)
+    const int rn = r + rpp;
+    f16x8 hn = {}, rnx = {};
+    if (rn < r_end) {   // next pass in flight while this one is reduced and stored
+      hn = *reinterpret_cast<const f16x8*>(hb + (size_t)rn * p.ld_h);
+      rnx = *reinterpret_cast<const f16x8*>(rb + (size_t)rn * p.ld_res);
+    }
+    f16x8 o;
+    float vr[8], ssq = 0.f, sum = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      o[j] = (f16)((float)hv[j] * gt[j] + (float)rv[j]);
+      vr[j] = (float)o[j];   // statistics of the value a consumer will read back
+      ssq += vr[j] * vr[j];
+      sum += vr[j];
+    }
+    *reinterpret_cast<f16x8*>(ob + (size_t)r * p.ld_out) = o;
+    const size_t row = (size_t)b * p.HW + r;
+    if (p.ssq_out || ab) {
+      const float tot = group_sum(ssq, lpr);
+      if (p.ssq_out && g == 0) p.ssq_out[row] = tot;
+      if (ab) {
+        const float rs = __builtin_amdgcn_rsqf(fmaxf(tot, 1e-24f));
+        f16x8 a;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) a[j] = (f16)silu_f(vr[j] * rs * pa[j]);
+        *reinterpret_cast<f16x8*>(ab + (size_t)r * p.ld_act) = a;
+      }
+    }
+    if (p.mu_out) {
+      const float mean = group_sum(sum, lpr) * inv_c;
+      float q = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = vr[j] - mean; q += d * d; }
+      const float var = group_sum(q, lpr) * inv_c;
+      if (g == 0) {
+        p.mu_out[row] = mean;
+        p.rs_out[row] = rsqrtf(var + p.eps);
+      }
+    }
+    hv = hn;
+    rv = rnx;
+    r = rn;
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ embeddings / affine
@@ -771,14 +882,27 @@ int launch_gca_partial(const ImagenGcaPartialParams* p, hipStream_t s) {
 
 int launch_gca_final(const ImagenGcaFinalParams* p, hipStream_t s) {
   auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
-  static const bool slow = getenv("IMAGEN_GCA_FINAL_SLOW") != nullptr;   // A/B switch
-  if (!slow && pow2(p->C) && pow2(p->hidden) && p->C >= 4 && p->C <= 1024 && p->hidden >= 4 && p->hidden <= 1024 && p->chunks <= 1024) {
+  if (pow2(p->C) && pow2(p->hidden) && p->C >= 4 && p->C <= 1024 && p->hidden >= 4 && p->hidden <= 1024 && p->chunks <= 1024) {
     hipLaunchKernelGGL(gca_final_fast_kernel, dim3(p->B), dim3(kGcaFastThreads), 0, s, *p);
     return imagen_hip_status("gca_final");
   }
   const size_t sm = (size_t)(p->C + p->hidden + p->chunks + kGcaScratchFloats) * sizeof(float);
   hipLaunchKernelGGL(gca_final_kernel, dim3(p->B), dim3(256), sm, s, *p);
   return imagen_hip_status("gca_final");
+}
+
+int launch_gca_tail(const ImagenGcaTailParams* p, hipStream_t s) {
+  auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+  IMAGEN_CHECK(p->h && p->res && p->out && p->B > 0 && p->HW > 0, "gca_tail: null tensors / empty problem");
+  IMAGEN_CHECK(pow2(p->C) && p->C >= 8 && p->C <= 512, "gca_tail: C %d must be a power of two in [8, 512]", p->C);
+  IMAGEN_CHECK(!p->part || (p->w1t && p->b1 && p->w2t && p->b2 && pow2(p->hidden) && p->hidden >= 4 && p->hidden <= 1024 && p->chunks >= 1 && p->chunks <= 1024),
+               "gca_tail: GlobalContext finalisation needs the squeeze MLP, a power-of-two hidden width (%d) and 1..1024 chunks (%d)", p->hidden, p->chunks);
+  IMAGEN_CHECK(p->ld_h % 8 == 0 && p->ld_res % 8 == 0 && p->ld_out % 8 == 0 && (!p->act_out || (p->act_pa && p->ld_act % 8 == 0)),
+               "gca_tail: row strides must be multiples of 8 (act_out needs act_pa)");
+  IMAGEN_CHECK(!p->mu_out == !p->rs_out, "gca_tail: mu_out and rs_out come together");
+  IMAGEN_CHECK(p->slabs >= 1 && p->slabs <= 65535, "gca_tail: slabs %d", p->slabs);
+  hipLaunchKernelGGL(gca_tail_kernel, dim3(p->slabs, p->B), dim3(kGcaFastThreads), 0, s, *p);
+  return imagen_hip_status("gca_tail");
 }
 
 int launch_time_embed(const ImagenTimeEmbedParams* p, hipStream_t s) {

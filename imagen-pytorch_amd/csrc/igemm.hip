@@ -105,34 +105,13 @@ __device__ __forceinline__ void lds_barrier() {
 #endif
 }
 
-// -DIGEMM_TRACE (tools/igemm_probe.py --timeline builds and loads a separate library): with dbg bit 128, lane 0 of the first
-// consumer / producer wave of workgroup 0 stamps s_memtime into the buffer passed in `gate` (unused by the probed launches):
-// trace[role][event], 64 events per role.  Compiled out of the product library (the stamps cost registers in the hot loops).
-#ifdef IGEMM_TRACE
-#define TRACE_STAMP(role, n)                                                                                          \
-  do {                                                                                                                \
-    if ((p.dbg & 128) && blockIdx.x == 0 && (threadIdx.x & 255) == 0 && (n) < 64) {                                   \
-      reinterpret_cast<unsigned long long*>(const_cast<float*>(p.gate))[(role) * 64 + (n)] = __builtin_amdgcn_s_memtime(); \
-      ++(n);                                                                                                          \
-    }                                                                                                                 \
-  } while (0)
-#else
-#define TRACE_STAMP(role, n) do { (void)(n); } while (0)
-#endif
 
 // GEN: the generic epilogue (output activation, gate*addend / residual, pixel-shuffle and fp32-NCHW stores).  The launcher picks the
 // GEN = false instantiation for plain NHWC outputs (optionally with ssq_out or the post_pa output-side prologue): its epilogue is
 // one branch-free block — the generic one tests act_out / out_mode / addend / res per element and quad, ~100 scalar branches
 // per tile that were measured (s_memtime stamps) at 7k of a tile's 13k cycles on the 32-channel 256^2 layers.
-// (A/B builds: -DIGEMM_ONE_WG gives every instantiation the 256-VGPR budget of ONE workgroup per CU — no spills, room for the deep
-// weight rings -DIGEMM_LA1 / -DIGEMM_LA2 that only cost registers at the product's 128 — at half the waves per SIMD)
-#ifdef IGEMM_ONE_WG
-#define IGEMM_MIN_WAVES(MI, NI) 2
-#else
-#define IGEMM_MIN_WAVES(MI, NI) ((MI) * (NI) <= 2 ? 4 : 2)
-#endif
 template <int MI, int NI, int WM, int WN, int G, int KSC, bool GEN>
-__global__ __launch_bounds__(512, IGEMM_MIN_WAVES(MI, NI)) void igemm_kernel(const ImagenIgemmParams p) {
+__global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(const ImagenIgemmParams p) {
   static_assert(WM * WN == 4, "4 consumer waves per workgroup");
   constexpr int BN = 32 * NI * WN;
   constexpr int KC = Geo<G>::KC;
@@ -147,13 +126,6 @@ __global__ __launch_bounds__(512, IGEMM_MIN_WAVES(MI, NI)) void igemm_kernel(con
   const bool producer = tid >= 256;   // wave-uniform role
   const int rtid = tid & 255;         // thread index inside the role
   const unsigned warm = imagen_code_warm(((unsigned)p.dbg >> 16) << 8, tid, 512);   // (code size / 256 rides in the upper half of dbg)
-#ifdef IGEMM_PRIO
-  // A/B builds only (-DIGEMM_PRIO=1: consumers, =2: producers): a static issue priority for one role.  The two roles of a SIMD's waves
-  // share its VALU issue bandwidth by priority, then age (MI355X_MICROARCH.md, "Two waves per SIMD", item 4: one s_setprio for the
-  // losing half, no flips).  Compile-time on purpose: as a run-time switch (two scalar branches here) it changed the register
-  // allocation of the whole kernel at the 128-VGPR budget — spill instructions inside the tile loops 342 -> 474 (tools/scratch_report.py).
-  if (IGEMM_PRIO == 1 ? !producer : producer) __builtin_amdgcn_s_setprio(1);
-#endif
 
   // ---- the tile list of this workgroup
   const int tilesX = (p.OW + p.TW - 1) / p.TW;
@@ -363,28 +335,19 @@ __global__ __launch_bounds__(512, IGEMM_MIN_WAVES(MI, NI)) void igemm_kernel(con
     advance();
     lds_barrier();          // phase 0 is in buffer 0
     imagen_code_warm_sink(warm);
-    int tn = 0;   // trace events per phase: loop top | loads issued | set written | before the barrier
     for (int q = 0; q < n_phases; q += 2) {
       // consumers: phase q out of buf0
-      TRACE_STAMP(1, tn);
       load_set(A);          // phase q+2
-      TRACE_STAMP(1, tn);
       write_set(B, buf1);   // phase q+1
-      TRACE_STAMP(1, tn);
       load_affine(A);
       advance();
-      TRACE_STAMP(1, tn);
       phase_end();
       if (q + 1 >= n_phases) break;
       // consumers: phase q+1 out of buf1
-      TRACE_STAMP(1, tn);
       load_set(B);          // phase q+3
-      TRACE_STAMP(1, tn);
       write_set(A, buf0);   // phase q+2
-      TRACE_STAMP(1, tn);
       load_affine(B);
       advance();
-      TRACE_STAMP(1, tn);
       phase_end();
     }
     return;
@@ -427,13 +390,8 @@ __global__ __launch_bounds__(512, IGEMM_MIN_WAVES(MI, NI)) void igemm_kernel(con
   // wq[j] holds the fragments of K=16 step (gstep + j); w_ofs is the offset (in fragments) of step (gstep + kLookAhead)
   // look-ahead depth of the weight ring: a wave consumes one fragment per MI MFMAs, so the single-MFMA-per-step tilings (small
   // feature maps: few workgroups, each streaming its whole weight slice) need a deeper ring to cover the L2 round trip
-#ifndef IGEMM_LA1
-#define IGEMM_LA1 8    // ring depth of the 1- and 2-MFMA-per-step tilings (A/B builds in the model: 8/6 beat 12/10 and 16/12 by 1-2 %)
-#endif
-#ifndef IGEMM_LA2
-#define IGEMM_LA2 6
-#endif
-  constexpr int kWantAhead = (MI * NI == 1) ? IGEMM_LA1 : (MI * NI == 2 ? IGEMM_LA2 : 6);
+  // ring depths measured in the model (A/B builds of round 2/3: 8/6 beat 12/10 and 16/12 by 1-2 %, 8/8 ties)
+  constexpr int kWantAhead = (MI * NI == 1) ? 8 : 6;
   constexpr int kLookAhead = KSC == 0 ? 1 : (KSC >= kWantAhead ? kWantAhead : KSC);
   f16x8 wq[kLookAhead][NI];
   int w_ofs = 0;
@@ -517,7 +475,6 @@ __global__ __launch_bounds__(512, IGEMM_MIN_WAVES(MI, NI)) void igemm_kernel(con
   // The weight ring is dead during the arithmetic of the epilogue (its registers go to the packed outputs) and is re-primed
   // with the NEXT tile's first steps right before the stores: those loads are older than the stores, so the next tile's first
   // weight wait does not cover a store either.
-  int tn = 0;   // trace event counter (IGEMM_TRACE builds only)
   auto prime_weights = [&](int n0) __attribute__((always_inline)) {
     w_ofs = n0;
 #pragma unroll
@@ -529,12 +486,11 @@ __global__ __launch_bounds__(512, IGEMM_MIN_WAVES(MI, NI)) void igemm_kernel(con
   };
   auto epilogue = [&](const TileCoord& tc, int n0_next) __attribute__((always_inline)) {
     const int b = tc.b, n0 = tc.n0;
-#ifdef IGEMM_EPI_REMAT
-    // A/B build (tools/build_remat_lib.sh): rematerialise the per-lane constants of the epilogue here instead of keeping
-    // them live across the k loop.  At the 128-VGPR budget the compiler hoists them out of the tile loop and spills them; every reload
-    // in the epilogue is a scratch_load followed by s_waitcnt vmcnt(0), i.e. a full drain of the re-primed weight ring (19 per tile in
-    // <2,1,1,4,4,18,false>, 46 in its GEN twin — none with this block).  The empty asm makes the thread id opaque inside the tile
-    // loop, so nothing derived from it can be hoisted; the names shadow the outer ones for the rest of the epilogue.
+    // The per-lane constants of the epilogue are rematerialised HERE instead of being kept live across the k loop: at the 128-VGPR
+    // budget the compiler otherwise hoists them out of the tile loop and spills them, and every reload in the epilogue is a scratch_load
+    // followed by s_waitcnt vmcnt(0), i.e. a full drain of the re-primed weight ring (19 per tile in <2,1,1,4,4,18,false>, 46 in its
+    // GEN twin — none this way; profiles/r02_static_spills_igemm_*.txt, measured -1 % per step pair in round 3's call A).  The empty
+    // asm makes the thread id opaque inside the tile loop, so nothing derived from it can be hoisted; the names shadow the outer ones.
     int tid_e = threadIdx.x;
 #ifndef IMAGEN_EMUL
     asm volatile("" : "+v"(tid_e));
@@ -544,7 +500,7 @@ __global__ __launch_bounds__(512, IGEMM_MIN_WAVES(MI, NI)) void igemm_kernel(con
     const int wm = wave_e / WN, wn = wave_e % WN;
     int pix_y[MI], pix_x[MI];
     {
-      const int tw_sh = __builtin_ctz(p.TW);   // launcher-checked in this build: TW is a power of two (every host-side tile shape is)
+      const int tw_sh = __builtin_ctz(p.TW);   // launcher-checked: TW is a power of two (every host-side tile shape is)
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) {
         const int tp = (wm * MI + mi) * 32 + l31;
@@ -552,7 +508,6 @@ __global__ __launch_bounds__(512, IGEMM_MIN_WAVES(MI, NI)) void igemm_kernel(con
         pix_x[mi] = tp & (p.TW - 1);
       }
     }
-#endif
     if (p.post_pa) {
       // ---- output-side Block prologue: two passes over the accumulators (norm over all Cout of the pixel, then activate + store)
       float tot[MI];
@@ -679,9 +634,7 @@ __global__ __launch_bounds__(512, IGEMM_MIN_WAVES(MI, NI)) void igemm_kernel(con
             pv[ni][q][mi] = o;
           }
         }
-      TRACE_STAMP(0, tn);   // (trace: phase 1 of the epilogue done)
       prime_weights(n0_next);
-      TRACE_STAMP(0, tn);   // (trace: ring re-primed)
       f16* y = reinterpret_cast<f16*>(p.y) + (size_t)b * p.bsy;
       if ((p.Cout & 7) == 0) {   // 16-byte pieces (imagen_pair_quads: all lanes take part in the exchange)
 #pragma unroll
@@ -820,9 +773,7 @@ __global__ __launch_bounds__(512, IGEMM_MIN_WAVES(MI, NI)) void igemm_kernel(con
     // all stores together: vmcnt retires in issue order and counts stores, so a wait on a load issued AFTER a store also waits
     // for that store's acknowledgement (~1.5k cycles under load; a load -> use -> store loop per channel quad was measured at
     // 14k cycles per tile).  With every store behind the last load, no wait in the epilogue covers one.
-    TRACE_STAMP(0, tn);   // (trace: phase 1 of the epilogue done)
     prime_weights(n0_next);
-    TRACE_STAMP(0, tn);   // (trace: ring re-primed)
     if (wide) {
       f16* y = reinterpret_cast<f16*>(p.y) + (size_t)b * p.bsy;
 #pragma unroll
@@ -926,15 +877,11 @@ __global__ __launch_bounds__(512, IGEMM_MIN_WAVES(MI, NI)) void igemm_kernel(con
     const int t_next = t_cursor + t_step;
     const int n0_next = t_next < t_end ? decode(t_next).n0 : tc.n0;
     for (int chunk = 0; chunk < NC; ++chunk) {
-      TRACE_STAMP(0, tn);   // trace events per phase: compute start | compute done | barrier passed (+ per tile: epilogue done)
       if (!(p.dbg & 2)) compute(smem + cur * buf_bytes);
-      TRACE_STAMP(0, tn);
       lds_barrier();   // done with buf[cur]; the producers have filled buf[cur^1]
-      TRACE_STAMP(0, tn);
       cur ^= 1;
     }
     epilogue(tc, n0_next);
-    TRACE_STAMP(0, tn);
     if (t_next >= t_end) break;
     zero_acc();
     t_cursor = t_next;
@@ -1004,12 +951,7 @@ int launch_gen(const ImagenIgemmParams& p, hipStream_t s) {
     occ_blocks = nb;
     occ_lds = lds;
   }
-  static const int forced_per_cu = [] { const char* e = getenv("IMAGEN_IGEMM_WG_PER_CU"); return e ? atoi(e) : 0; }();   // probe knob
-  const int per_cu = forced_per_cu > 0 ? forced_per_cu : occ_blocks;
-  // probe knob for concurrent lanes: a persistent grid below 100 % of the resident slots leaves room for the other streams' small
-  // launches while this one runs (they otherwise wait for a whole-chip kernel to drain)
-  static const int grid_pct = [] { const char* e = getenv("IMAGEN_GRID_PCT"); const int v = e ? atoi(e) : 100; return v >= 10 && v <= 100 ? v : 100; }();
-  const int resident = std::max(8, num_cus() * per_cu * grid_pct / 100 / 8 * 8);
+  const int resident = std::max(8, num_cus() * occ_blocks / 8 * 8);
   int gx;
   if ((p.dbg & 32) || total <= resident) {
     gx = total;                                    // dbg 32: one tile per workgroup (no cross-tile pipelining)
@@ -1020,11 +962,10 @@ int launch_gen(const ImagenIgemmParams& p, hipStream_t s) {
   }
   // code size of this instantiation (for the kernel's instruction warm-up), looked up once by its mangled name
   static const unsigned code_q = [] {
-    static const bool off = getenv("IMAGEN_CODE_WARM") && atoi(getenv("IMAGEN_CODE_WARM")) == 0;   // A/B switch
     char name[160];
     snprintf(name, sizeof(name), "_ZN12_GLOBAL__N_112igemm_kernelILi%dELi%dELi%dELi%dELi%dELi%dELb%dEEEv17ImagenIgemmParams", MI, NI, WM, WN, G, KSC,
              GEN ? 1 : 0);
-    return off ? 0u : std::min(imagen_kernel_code_bytes(name) >> 8, 0xffffu);
+    return std::min(imagen_kernel_code_bytes(name) >> 8, 0xffffu);
   }();
   ImagenIgemmParams q = p;
   q.dbg = (int)(((unsigned)q.dbg & 0xffffu) | (code_q << 16));
@@ -1047,20 +988,14 @@ int launch_cfg(const ImagenIgemmParams& p, hipStream_t s) {
 
 }  // namespace
 
-// second kernel family (conv_lds.hip): tile cfg ids kNumCfgs .. kNumCfgs + imagen_conv_lds_num_configs() - 1
-int imagen_conv_lds_num_configs();
-int imagen_conv_lds_config_info(int idx, int* tile_pixels, int* tile_cout, int* kgroups);
-int imagen_conv_lds_stage_slots(int idx, int KH, int KW);
-long imagen_conv_lds_lds_bytes(int idx, int KH, int KW, int TH, int TW);
-int launch_conv_lds(const ImagenIgemmParams* p, int idx, hipStream_t s);
-// third kernel family (conv_dma.hip): tile cfg ids behind the second family's
+// kernel family 2 (conv_dma.hip): tile cfg ids kNumCfgs ..   (family 1, the LDS-staged kernel with an in-kernel prologue, was retired in round 3)
 int imagen_conv_dma_num_configs();
 int imagen_conv_dma_config_info(int idx, int* tile_pixels, int* tile_cout, int* kgroups);
 long imagen_conv_dma_lds_bytes(int idx, int KH, int KW, int TH, int TW);
 int imagen_conv_dma_ring(int idx);
 int launch_conv_dma(const ImagenIgemmParams* p, int idx, hipStream_t s);
-static inline int cfg_base_dma() { return kNumCfgs + imagen_conv_lds_num_configs(); }
-// fourth kernel family (conv_stream.hip): tile cfg ids behind the third family's
+static inline int cfg_base_dma() { return kNumCfgs; }
+// kernel family 3 (conv_stream.hip): tile cfg ids behind family 2's
 int imagen_conv_stream_num_configs();
 int imagen_conv_stream_config_info(int idx, int* tile_pixels, int* tile_cout, int* kgroups);
 long imagen_conv_stream_lds_bytes(int idx, int KH, int KW, int TH, int TW);
@@ -1073,13 +1008,10 @@ int launch_igemm(const ImagenIgemmParams* pp, hipStream_t s) {
   IMAGEN_CHECK(p.cfg >= 0 && p.cfg < cfg_end(), "igemm: bad cfg %d", p.cfg);
   IMAGEN_CHECK(p.x1 && p.w && p.y, "igemm: null x1/w/y");
   IMAGEN_CHECK(!p.addend || p.gate, "igemm: addend requires gate");
-#ifdef IGEMM_EPI_REMAT
-  IMAGEN_CHECK(p.cfg >= kNumCfgs || (p.TW > 0 && (p.TW & (p.TW - 1)) == 0), "igemm (IGEMM_EPI_REMAT build): tile width %d is not a power of two", p.TW);
-#endif
-  IMAGEN_CHECK(!p.gca_part || p.cfg >= kNumCfgs, "igemm: gca_part is implemented by kernel families 1 and 2 only (cfg %d)", p.cfg);
+  IMAGEN_CHECK(p.cfg >= kNumCfgs || (p.TW > 0 && (p.TW & (p.TW - 1)) == 0), "igemm: tile width %d is not a power of two", p.TW);
+  IMAGEN_CHECK(!p.gca_part || p.cfg >= kNumCfgs, "igemm: gca_part is implemented by kernel family 2 only (cfg %d)", p.cfg);
   if (p.cfg >= cfg_base_stream()) return launch_conv_stream(pp, p.cfg - cfg_base_stream(), s);
   if (p.cfg >= cfg_base_dma()) return launch_conv_dma(pp, p.cfg - cfg_base_dma(), s);
-  if (p.cfg >= kNumCfgs) return launch_conv_lds(pp, p.cfg - kNumCfgs, s);
   switch (p.cfg) {
     case 0: return launch_cfg<2, 1, 4, 1, 4>(p, s);
     case 1: return launch_cfg<4, 1, 1, 4, 4>(p, s);
@@ -1103,9 +1035,9 @@ int launch_igemm(const ImagenIgemmParams* pp, hipStream_t s) {
 
 extern "C" int imagen_igemm_num_configs(void) { return cfg_end(); }
 
-extern "C" int imagen_igemm_config_family(int cfg) {   // 0: wave-specialised persistent kernel (this file), 1: LDS-staged kernel (conv_lds.hip)
+extern "C" int imagen_igemm_config_family(int cfg) {   // 0: wave-specialised persistent kernel (this file), 2: all-DMA kernel (conv_dma.hip), 3: streaming kernel (conv_stream.hip)
   if (cfg < 0 || cfg >= imagen_igemm_num_configs()) return -1;
-  return cfg >= cfg_base_stream() ? 3 : cfg >= cfg_base_dma() ? 2 : cfg >= kNumCfgs ? 1 : 0;   // 3: streaming kernel (conv_stream.hip)
+  return cfg >= cfg_base_stream() ? 3 : cfg >= cfg_base_dma() ? 2 : 0;
 }
 
 extern "C" int imagen_igemm_config_ring(int cfg) {   // weight look-ahead ring depth in stages (family 2; 0 elsewhere)
@@ -1115,7 +1047,6 @@ extern "C" int imagen_igemm_config_ring(int cfg) {   // weight look-ahead ring d
 extern "C" int imagen_igemm_config_info(int cfg, int* tile_pixels, int* tile_cout, int* kgroups) {
   if (cfg >= cfg_base_stream()) return imagen_conv_stream_config_info(cfg - cfg_base_stream(), tile_pixels, tile_cout, kgroups);
   if (cfg >= cfg_base_dma()) return imagen_conv_dma_config_info(cfg - cfg_base_dma(), tile_pixels, tile_cout, kgroups);
-  if (cfg >= kNumCfgs) return imagen_conv_lds_config_info(cfg - kNumCfgs, tile_pixels, tile_cout, kgroups);
   if (cfg < 0 || cfg >= kNumCfgs) return -1;
   const TileCfg& c = kCfgs[cfg];
   if (tile_pixels) *tile_pixels = 32 * c.MI * c.WM;
@@ -1133,7 +1064,6 @@ static constexpr int ksc_of(int G, int ks) {   // the launch_cfg dispatch, as a 
 
 extern "C" int imagen_igemm_stage_slots(int cfg, int KH, int KW) {
   if (cfg >= cfg_base_dma()) return (KH == 3 && KW == 3) ? 1 << 20 : 0;   // (no register staging: the tile shape is fixed per cfg; families 2 and 3)
-  if (cfg >= kNumCfgs) return imagen_conv_lds_stage_slots(cfg - kNumCfgs, KH, KW);
   if (cfg < 0 || cfg >= kNumCfgs || KH < 1 || KW < 1) return -1;
   const TileCfg& c = kCfgs[cfg];
   return stage_slots(32 * c.MI * c.WM, c.G, ksc_of(c.G, (KH * KW * c.G + 1) / 2));
@@ -1143,7 +1073,6 @@ extern "C" int imagen_igemm_stage_slots(int cfg, int KH, int KW) {
 extern "C" long imagen_igemm_lds_bytes(int cfg, int KH, int KW, int stride, int TH, int TW) {
   if (cfg >= cfg_base_stream()) return stride == 1 ? imagen_conv_stream_lds_bytes(cfg - cfg_base_stream(), KH, KW, TH, TW) : -1;
   if (cfg >= cfg_base_dma()) return stride == 1 ? imagen_conv_dma_lds_bytes(cfg - cfg_base_dma(), KH, KW, TH, TW) : -1;
-  if (cfg >= kNumCfgs) return stride == 1 ? imagen_conv_lds_lds_bytes(cfg - kNumCfgs, KH, KW, TH, TW) : -1;
   if (cfg < 0 || KH < 1 || KW < 1 || TH < 1 || TW < 1) return -1;
   const TileCfg& c = kCfgs[cfg];
   if (TH * TW != 32 * c.MI * c.WM) return -1;

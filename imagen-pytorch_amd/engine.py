@@ -91,12 +91,12 @@ def _fingerprint(unet) -> tuple:
     return tuple(p._version for p in unet.parameters()) + tuple(p.data_ptr() for p in unet.parameters())
 
 
-POST_NORM = int(os.environ.get("IMAGEN_POST_NORM", "1"))   # A/B switch: block2's prologue applied by block1's epilogue
 # ACT_PREP + all-DMA conv for the Blocks with at least this many output channels (the MFMA-bound layers: the prologue pass costs one
 # read + one write of the input, the conv kernel drops its staging instruction stream); 0 = never
 ACT_PREP_MIN_COUT = int(os.environ.get("IMAGEN_ACT_PREP_MIN_COUT", "0"))   # (measured in the model: the extra pass costs more than it saves — off)
-FINAL_CONV_G4 = int(os.environ.get("IMAGEN_FINAL_CONV_G4", "1"))   # A/B switch: 32-channel k-chunks for final_conv over cat(x, lowres image)
-KV_BATCH = int(os.environ.get("IMAGEN_KV_BATCH", "1"))     # A/B switch: one launch for the context K/V rows of all attention sites
+TAIL_FUSED = int(os.environ.get("IMAGEN_TAIL_FUSED", "1"))   # A/B switch: GCA_FINAL + GATE_RESIDUAL of an identity ResnetBlock as one GCA_TAIL launch
+TAIL_ACT = int(os.environ.get("IMAGEN_TAIL_ACT", "1"))       # A/B switch: ... which also writes the next block1's activated input
+LN_STATS_FUSED = int(os.environ.get("IMAGEN_LN_STATS_FUSED", "1"))   # A/B switch: LayerNorm statistics from the producing launch (GCA_TAIL / LN_RESIDUAL) instead of a ROWSTAT pass
 
 
 class UnetEngine:
@@ -367,7 +367,7 @@ class UnetEngine:
             wp[:, x.C + u.channels: x.C + 2 * u.channels] = w[:, x.C:]
             # 32-channel k-chunks whenever the feature part allows it (the 8 image channels then occupy one group of a second,
             # otherwise zero chunk): the 8-channel-chunk path (G = 1) took 100 us for this layer at 256^2, twice a 32->32 conv
-            G = 4 if (x.C % 32 == 0 and FINAL_CONV_G4) else None
+            G = 4 if x.C % 32 == 0 else None
             return ops.pack_weight(wp, u.final_conv.bias.detach().float(), self.dev, G=G)
 
         ops.igemm(plan, x, self.W.get("final_conv", make), self.out, x2=extra, out_mode=OUT_NCHW_F32, label="final_conv")
@@ -435,9 +435,14 @@ class UnetEngine:
         h1.ssq = self.f32buf(R * H * Wd)
         # without a cross-attention in between, block1's epilogue applies block2's ChanRMSNorm -> (scale+1, shift) -> SiLU itself
         # (its consumer waves have the slack; block2's producers then stage h1 with no arithmetic at all)
-        post = dict(pa=pa2, ps=ps2, pstride=self.total_c) if (rb.cross_attn is None and POST_NORM) else None
+        post = dict(pa=pa2, ps=ps2, pstride=self.total_c) if rb.cross_attn is None else None
         prep = ops.CONV_DMA and ACT_PREP_MIN_COUT > 0 and Cout >= ACT_PREP_MIN_COUT and Cin % 32 == 0 and Cout % 32 == 0
-        if prep:   # MFMA-bound layer: the prologue as its own pass, then the all-DMA conv on the activated concat
+        # x comes out of a fused ResnetBlock tail (GCA_TAIL): that launch also writes silu(ChanRMSNorm(x) * gamma) — it has the pixel's
+        # channels and its sum of squares in registers — and block1 stages its input with no arithmetic (prologue-free kernel families)
+        xa = ops.request_act(x, pa1) if (skip is None and TAIL_ACT and w1.Cin_pad == Cin) else None
+        if xa is not None:
+            op = ops.igemm(plan, xa, w1, h1, ssq_out=h1.ssq, post=post, label=name + ".block1")
+        elif prep:   # MFMA-bound layer: the prologue as its own pass, then the all-DMA conv on the activated concat
             xa = self.new(R, H, Wd, Cin)
             ops.act_prep(plan, x, xa, x2=skip, ssq_a=sx, ssq_b=ss, ssq_wb=s * s, pa=pa1, pstride=0, act_in=ACT_SILU, label=name + ".block1.prep")
             op = ops.igemm(plan, xa, w1, h1, ssq_out=h1.ssq, post=post, label=name + ".block1")
@@ -472,18 +477,33 @@ class UnetEngine:
             else:
                 op2 = ops.igemm(plan, h1, W.conv(name + ".block2", rb.block2.project), h2, ssq_a=s1, pa=pa2, ps=ps2, pstride=self.total_c,
                                 act_in=ACT_SILU, gca=gca_ep, label=name + ".block2")
+        # identity block: GlobalContext finalisation + h2 * gate + x (+ statistics) as ONE launch (GCA_TAIL) where its shapes allow
+        fused_tail = (TAIL_FUSED and rb.res_conv is None and x.ld == x.C and x.bs == H * Wd * x.C
+                      and ops.gca_tail_ok(Cout, (hidden if rb.gca is not None else None)))
+        tail_part, tail_chunks, gate_ready = None, 0, False
         if rb.gca is not None:
             if op2.gca_part_t is not None:   # the partials came out of block2's epilogue: only the merge + squeeze MLP is left
-                ops.gca_final(plan, op2.gca_part_t, gca_args["w1t"], gca_args["b1"], gca_args["w2t"], gca_args["b2"], gate, B=R, C=Cout,
-                              chunks=op2.gca_chunks, label=name + ".gca")
+                if fused_tail and op2.gca_chunks <= 1024:
+                    tail_part, tail_chunks = op2.gca_part_t, op2.gca_chunks
+                else:
+                    ops.gca_final(plan, op2.gca_part_t, gca_args["w1t"], gca_args["b1"], gca_args["w2t"], gca_args["b2"], gate, B=R, C=Cout,
+                                  chunks=op2.gca_chunks, label=name + ".gca")
+                    gate_ready = True
             else:                            # stand-alone pass over h2 (+ in-kernel finalisation where one workgroup covers the image)
                 chunks = ops.gca_chunks(H * Wd, R, Cout)
                 part = self.f32buf(R, chunks, Cout + 2)
-                ops.gca(plan, h2, gca_args["wk"], gca_args["bk"], gca_args["w1t"], gca_args["b1"], gca_args["w2t"], gca_args["b2"], part, gate,
-                        chunks, label=name + ".gca")
+                gate_ready = ops.gca(plan, h2, gca_args["wk"], gca_args["bk"], gca_args["w1t"], gca_args["b1"], gca_args["w2t"], gca_args["b2"], part,
+                                     gate, chunks, label=name + ".gca", final=not fused_tail)
+                if not gate_ready:
+                    tail_part, tail_chunks = part, chunks
         out = self.new(R, H, Wd, Cout)
         out.ssq = self.f32buf(R * H * Wd)
-        if rb.res_conv is not None:
+        if fused_tail:
+            assert skip is None
+            ops.gca_tail(plan, h2, x, out, part=tail_part, chunks=tail_chunks, w1t=gca_args and gca_args["w1t"], b1=gca_args and gca_args["b1"],
+                         w2t=gca_args and gca_args["w2t"], b2=gca_args and gca_args["b2"], gate_in=gate if gate_ready else None,
+                         gate=gate if tail_part is not None else None, ssq_out=out.ssq, label=name + ".tail")
+        elif rb.res_conv is not None:
             wr = W.conv(name + ".res_conv", rb.res_conv, in_scale=in_scale)
             if gate is not None:
                 op = ops.igemm(plan, x, wr, out, x2=skip, addend=h2, gate=gate, ssq_out=out.ssq, label=name + ".res_conv")
@@ -541,20 +561,24 @@ class UnetEngine:
         cur = x
         for d, (attn, ff) in enumerate(tb.layers):
             nm = f"{name}.layers.{d}"
-            x1 = self._self_attn(plan, cur.tokens(), attn, nm, with_context)
-            ffo = self._feed_forward(plan, x1, ff, nm + ".ff")
+            # LayerNorm statistics of the attention input from the launch that produced it (a fused ResnetBlock tail), where there is one
+            x1, st = self._self_attn(plan, cur.tokens(), attn, nm, with_context, ln_stats=ops.request_ln_stats(cur) if LN_STATS_FUSED else None)
+            ffo = self._feed_forward(plan, x1, ff, nm + ".ff", ln_stats=st)
             cur = Act(ffo.t, R, x.H, x.W, C, C, N * C, ssq=ffo.ssq)
         return cur
 
-    def _self_attn(self, plan, tok: Act, attn, nm: str, with_context: bool) -> Act:
+    def _self_attn(self, plan, tok: Act, attn, nm: str, with_context: bool, ln_stats: Optional[tuple] = None):
         """attn(tok) + tok for the (R, 1, N, C) token view `tok` (ip.py:502-591, 1017): LayerNorm -> q | k | v in one GEMM ->
         K^/V^T rows behind the conditioning and null rows -> flash attention -> to_out -> LayerNorm + residual."""
         W, R = self.W, self.R
         N, C = tok.H * tok.W, tok.C
         heads, dh = attn.heads, attn.dim_head
         inner = heads * dh
-        mu, rs = self.f32buf(R * N), self.f32buf(R * N)
-        ops.rowstat(plan, tok, mode=1, rs=rs, mu=mu, eps=1e-5, label=nm + ".norm")
+        if ln_stats is not None:
+            mu, rs = ln_stats
+        else:
+            mu, rs = self.f32buf(R * N), self.f32buf(R * N)
+            ops.rowstat(plan, tok, mode=1, rs=rs, mu=mu, eps=1e-5, label=nm + ".norm")
         # q | k | v from ONE GEMM (to_q and to_kv are both bias-free on the same normalised input, ip.py:539)
         wqkv = W.raw(nm + ".qkv", torch.cat((attn.to_q.weight.detach().float(), attn.to_kv.weight.detach().float())), None)
         qkv = self.new(R, 1, N, inner + 2 * dh)
@@ -579,16 +603,21 @@ class UnetEngine:
         y = self.new(R, 1, N, C)
         ops.igemm(plan, o, W.conv(nm + ".to_out", attn.to_out[0]), y, label=nm + ".to_out")
         x1 = self.new(R, 1, N, C)
-        ops.ln_residual(plan, y, W.f32(nm + ".out_g", lambda: attn.to_out[1].g), x1, res=tok, eps=1e-5, label=nm + ".out_norm")
-        return x1
+        st = (self.f32buf(R * N), self.f32buf(R * N)) if LN_STATS_FUSED else None   # statistics of x1 for the FeedForward's first LayerNorm
+        ops.ln_residual(plan, y, W.f32(nm + ".out_g", lambda: attn.to_out[1].g), x1, res=tok, eps=1e-5, ln_stats_out=st, label=nm + ".out_norm")
+        return x1, st
 
-    def _feed_forward(self, plan, x: Act, ff: nn.Sequential, name: str) -> Act:
-        """ip.py:972-980 + residual (ip.py:1018): LN -> Linear -> GELU -> LN -> Linear, + x."""
+    def _feed_forward(self, plan, x: Act, ff: nn.Sequential, name: str, ln_stats: Optional[tuple] = None) -> Act:
+        """ip.py:972-980 + residual (ip.py:1018): LN -> Linear -> GELU -> LN -> Linear, + x.  ln_stats: (mean, rstd) of x's rows where its
+        producer emitted them."""
         W = self.W
         rows = x.rows
         hidden = ff[1].weight.shape[0]
-        mu, rs = self.f32buf(rows), self.f32buf(rows)
-        ops.rowstat(plan, x, mode=1, rs=rs, mu=mu, eps=1e-5, label=name + ".ln0")
+        if ln_stats is not None:
+            mu, rs = ln_stats
+        else:
+            mu, rs = self.f32buf(rows), self.f32buf(rows)
+            ops.rowstat(plan, x, mode=1, rs=rs, mu=mu, eps=1e-5, label=name + ".ln0")
         w1 = W.conv(name + ".w1", ff[1])
         hid = self.new(x.B, x.H, x.W, hidden)
         ops.igemm(plan, x, w1, hid, mu=mu, rs=rs, pa=W.f32(name + ".g0", lambda: _pad_vec(ff[0].g, w1.Cin_pad)), act_out=ACT_GELU,
@@ -685,7 +714,7 @@ class UnetEngine:
         R, W = self.R, self.W
         selfs, crosses, ws, wc = self._ctx_weights()
         n = rows_per_batch
-        jobs = [] if KV_BATCH else None   # one K^/V^T job per site, all run by a single launch after the two projections
+        jobs = []   # one K^/V^T job per site, all run by a single launch after the two projections
         if selfs:
             mu, rs = self.f32buf(R * n), self.f32buf(R * n)
             ops.rowstat(plan, c_rows, mode=1, rs=rs, mu=mu, eps=1e-5, label=f"ctx.{tag}.ln")

@@ -201,7 +201,7 @@ class UnetEngine3D(UnetEngine):
         self.taps['mid_block1'] = x
         if u.mid_attn is not None:                    # Residual(Attention) over all f*h*w tokens, no context, no feed-forward
             tok = self.clip(x, f).tokens()
-            y = self._self_attn(plan, tok, u.mid_attn.fn, "mid_attn.fn", with_context=False)
+            y, _ = self._self_attn(plan, tok, u.mid_attn.fn, "mid_attn.fn", with_context=False)
             x = Act(y.t, x.B, x.H, x.W, x.C, x.C, x.H * x.W * x.C)
         self.taps['mid_attn'] = x
         if not it:
@@ -477,7 +477,7 @@ class UnetEngine3D(UnetEngine):
         cur = x
         for d, (attn, ff) in enumerate(tb.layers):
             nm = f"{name}.layers.{d}"
-            y = self._self_attn(plan, self.clip(cur, f).tokens(), attn, nm + ".0", with_context=True)
+            y, _ = self._self_attn(plan, self.clip(cur, f).tokens(), attn, nm + ".0", with_context=True)
             cur = Act(y.t, x.B, x.H, x.W, x.C, x.C, x.H * x.W * x.C)
             cur = self._chan_feed_forward(plan, cur, ff, nm + ".1", f)
         return cur

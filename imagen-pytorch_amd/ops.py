@@ -26,7 +26,7 @@ _CFG_TABLE = None
 
 def cfg_table():
     """[(tile pixels, tile couts, G, family)] per tile cfg id; family 0 = wave-specialised persistent kernel (csrc/igemm.hip),
-    1 = LDS-staged kernel (csrc/conv_lds.hip: 1x1 / 3x3, stride 1)."""
+    2 = all-DMA kernel (csrc/conv_dma.hip: prologue-free 3x3, stride 1), 3 = streaming kernel (csrc/conv_stream.hip)."""
     global _CFG_TABLE
     if _CFG_TABLE is None:
         lib = load_library()
@@ -48,25 +48,6 @@ def current_stream_handle() -> int:
 
 
 # ------------------------------------------------------------------------------------------------ plan
-import os as _os0
-import re as _re0
-
-# IMAGEN_SKIP=<regex over "kind:label">: ops whose description matches are left out of every plan (IMAGEN_SKIP_NOOP=1: replaced by a
-# one-word fill, so the launch stays).  ONLY for tools/ablate_step.py: the wall-clock difference is the true in-graph cost of an op
-# class; results are garbage.  Unset in production.
-_SKIP_RE = _re0.compile(_os0.environ["IMAGEN_SKIP"]) if _os0.environ.get("IMAGEN_SKIP") else None
-_SKIP_NOOP = _os0.environ.get("IMAGEN_SKIP_NOOP") == "1"
-_KIND_NAME = {v: k.replace("IMAGEN_OP_", "").lower() for k, v in ENUMS.items() if k.startswith("IMAGEN_OP_") and k != "IMAGEN_OP_KIND_COUNT"}
-_SKIP_SCRATCH = {}
-
-
-def _skip_scratch(keep):
-    dev = next((k.device for k in keep if isinstance(k, torch.Tensor)), torch.device("cpu"))
-    if dev not in _SKIP_SCRATCH:
-        _SKIP_SCRATCH[dev] = torch.zeros(4, dtype=torch.int32, device=dev)
-    return _SKIP_SCRATCH[dev]
-
-
 
 class Plan:
     """Ordered list of kernel launches with their params structs (kept alive here)."""
@@ -79,15 +60,6 @@ class Plan:
 
     def add(self, struct, label: str = "", keep: Sequence = ()):
         kind = _abi.STRUCT_KIND[type(struct)]
-        if _SKIP_RE is not None and _SKIP_RE.search(f"{_KIND_NAME.get(kind, kind)}:{label}"):
-            # timing ablation (tools/ablate_step.py): the op is dropped, or replaced by a one-word fill so that the launch itself stays
-            self.keep.extend(k for k in keep if k is not None)
-            if _SKIP_NOOP:
-                m = STRUCTS["ImagenMemset32Params"]()
-                m.dst, m.value, m.count = _skip_scratch(keep).data_ptr(), 0, 1
-                self.ops.append((_abi.STRUCT_KIND[type(m)], m, "noop:" + label))
-                self._arr = None
-            return struct
         self.ops.append((kind, struct, label))
         self.keep.extend(k for k in keep if k is not None)
         self._arr = None
@@ -167,6 +139,7 @@ class Act:
     bs: int
     off: int = 0             # element offset into t
     ssq: Optional[torch.Tensor] = None   # fp32 [rows]: per-pixel sum of squares emitted by the producer (ChanRMSNorm statistics)
+    tail_op: Optional[object] = None     # the GCA_TAIL params that produce this tensor: a consumer may ask it for more outputs (request_act)
 
     @property
     def ptr(self) -> int:
@@ -225,7 +198,7 @@ REFERENCE_WEIGHTS: dict = {}   # packed.data_ptr() -> (w [Cout, Cin, KH, KW] fp3
 
 def choose_G(Cin: int, taps: int = 9) -> int:
     """8-channel groups per k-chunk.  1x1 convs / linears have no halo, so their chunks go 64-128 channels deep."""
-    if taps == 1 and DEEP_CHUNKS:
+    if taps == 1:
         if Cin % 128 == 0:
             return 16
         if Cin % 64 == 0:
@@ -268,12 +241,6 @@ def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], device, in_scale:
 
 import os as _os
 
-PICK_256x64 = int(_os.environ.get("IMAGEN_PICK_256x64", "1"))
-PICK_256x32 = int(_os.environ.get("IMAGEN_PICK_256x32", "1"))
-PICK_128 = int(_os.environ.get("IMAGEN_PICK_128", "0"))              # A/B switch: 128x128 tiles for the big C_out >= 128 layers (3-9 % faster in the isolated probe, 3 % slower in the model: off)
-DEEP_CHUNKS = int(_os.environ.get("IMAGEN_DEEP_CHUNKS", "1"))       # A/B switch: 64/128-channel k-chunks for 1x1 convs / linears
-GCA_SINGLE_LAUNCH = int(_os.environ.get("IMAGEN_GCA_SINGLE_LAUNCH", "0"))   # A/B switch: finalise GlobalContext in the partial kernel behind an agent-scope ticket (measured slower than a second launch: the release/acquire fences write back and invalidate the XCD L2)
-IGEMM_DBG = int(_os.environ.get("IMAGEN_IGEMM_DBG", "0"))          # kernel A/B switches (see ImagenIgemmParams.dbg); 0 in production
 MAX_LDS_BYTES = 160 * 1024
 
 
@@ -298,18 +265,12 @@ def launchable_shapes(cfg: int, OH: int, OW: int, KH: int, KW: int, stride: int)
     return sorted(out)
 
 
-CONV_LDS = int(_os.environ.get("IMAGEN_CONV_LDS", "0"))             # A/B switch: the LDS-staged kernel family (in-kernel prologue) for 3x3 convs
-# ... only for launches of at most this many tiles: the partials cost every TILE a fixed ~2 us of reductions and barriers, a stand-alone
+# GlobalContext partials from the producing conv's epilogue ... only for launches of at most this many tiles: the partials cost every TILE a fixed ~2 us of reductions and barriers, a stand-alone
 # pass over the tensor costs ~9 us per LAUNCH + its read (measured in the model: a loss on the 4096-tile 256^2 layers, a gain below)
-GCA_EPILOGUE_MAX_TILES = int(_os.environ.get("IMAGEN_GCA_EPILOGUE_MAX_TILES", "1024"))
-GCA_IN_EPILOGUE = int(_os.environ.get("IMAGEN_GCA_IN_EPILOGUE", "1"))   # A/B switch: GlobalContext partials from the producing conv's epilogue
+GCA_EPILOGUE_MAX_TILES = 1024
 CONV_DMA = int(_os.environ.get("IMAGEN_CONV_DMA", "1"))             # A/B switch: the all-DMA kernel family for prologue-free single-input 3x3 convs
-CONV_LDS_1X1 = int(_os.environ.get("IMAGEN_CONV_LDS_1X1", "0"))     # ... and for 1x1 convs / linears
 CONV_STREAM = int(_os.environ.get("IMAGEN_CONV_STREAM", "1"))       # A/B switch: the streaming kernel family (conv_stream.hip) for the 32-channel 3x3 convs
-STREAM_MIN_TILES = int(_os.environ.get("IMAGEN_STREAM_MIN_TILES", "512"))   # ... of launches with at least this many 16x16 tiles (persistent workgroups need a few tiles each)
-# ... two inputs WITH the prologue: on a par with the wave-specialised kernel (98-109 us against 99-112 at 256^2, tools/stream_probe.py: the in-place
-# transform of 2 x 18 x 18 x 32 values per tile is VALU-bound and one workgroup per CU cannot hide it); A/B switch
-STREAM_CONCAT_PRO = int(_os.environ.get("IMAGEN_STREAM_CONCAT_PRO", "1"))
+STREAM_MIN_TILES = 512   # ... of launches with at least this many 16x16 tiles (persistent workgroups need a few tiles each)
 
 
 def stream_cfg() -> Optional[int]:
@@ -367,10 +328,7 @@ def pick_cfg(G: int, Cout: int, OH: int, OW: int, B: int, KH: int = 1, KW: int =
              family: Optional[int] = None, raw: bool = False):
     """Choose (cfg, TH, TW).
 
-    Family 1 (LDS-staged kernel, conv_lds.hip) takes the stride-1 3x3 convs with 32-channel chunks (and, behind a switch, 1x1):
-      Cout % 128 == 0 : 128 px x 128 co when that gives >= 256 workgroups, else 64 px x 128 co
-      Cout == 64      : 256 px x 64 co with >= 1024 workgroups, 128 x 64 with >= 512, else 64 x 64
-      Cout == 32      : 256 px x 32 co with >= 1024 workgroups, else 128 x 32
+    Family 2 (all-DMA kernel, conv_dma.hip) takes the prologue-free single-input stride-1 3x3 convs with 32-channel chunks (`raw`).
     Family 0 (wave-specialised persistent kernel, igemm.hip) takes everything else, measured on MI355X (tools/igemm_probe.py
     --sweep): the 64-pixel-per-wave tilings (MI <= 2) win everywhere, and when a layer has fewer workgroups than the chip has CUs
     the narrower output-channel tile (twice the workgroups) wins.  Preference order of (tile pixels, tile couts):
@@ -386,9 +344,7 @@ def pick_cfg(G: int, Cout: int, OH: int, OW: int, B: int, KH: int = 1, KW: int =
         if got is not None:
             return got
     assert family != 2, "no all-DMA tile configuration for this layer"
-    want1 = stride == 1 and G in (4, 8) and ((KH == 3 and KW == 3 and G == 4 and CONV_LDS) or (KH == 1 and KW == 1 and CONV_LDS_1X1))
-    fams = [family] if family is not None else ([1, 0] if want1 else [0])
-    for fam in fams:
+    for fam in ([family] if family is not None else [0]):
         avail = {}
         for i, (tp, bn, g, f) in enumerate(tab):
             if g == G and f == fam and (tp, bn) not in avail:
@@ -399,26 +355,14 @@ def pick_cfg(G: int, Cout: int, OH: int, OW: int, B: int, KH: int = 1, KW: int =
         def wgs(key):
             return B * avail[key][1][0] * math.ceil(Cout / key[1]) if key in avail else 0
 
-        if fam == 1:
-            if Cout <= 32:
-                order = [(256, 32)] if wgs((256, 32)) >= 1024 else []
-                order += [(128, 32), (256, 32), (64, 64), (128, 64)]
-            elif Cout <= 64:
-                order = [(256, 64)] if wgs((256, 64)) >= 1024 else []
-                order += [(128, 64)] if wgs((128, 64)) >= 512 else []
-                order += [(64, 64), (128, 64), (256, 64)]
-            else:
-                order = [(128, 128)] if wgs((128, 128)) >= 256 else []
-                order += [(64, 128), (128, 128), (64, 64)]
-        elif Cout <= 32:
-            order = [(256, 32)] if wgs((256, 32)) >= 1024 and PICK_256x32 else []
+        if Cout <= 32:
+            order = [(256, 32)] if wgs((256, 32)) >= 1024 else []
             order += [(128, 32), (256, 32), (64, 64), (64, 128)]
         elif Cout <= 64:
-            order = [(256, 64)] if wgs((256, 64)) >= 1024 and KH * KW > 1 and PICK_256x64 else []
+            order = [(256, 64)] if wgs((256, 64)) >= 1024 and KH * KW > 1 else []
             order += [(64, 64), (64, 128), (128, 32), (256, 32)]
         else:
-            order = [(128, 128)] if wgs((128, 128)) >= 256 and PICK_128 else []          # big layers: 3-9 % over 64x128 (MI = 4: half the weight traffic)
-            order += [(64, 128)] if wgs((64, 128)) >= 192 or (full_cout and Cout <= 128) else []
+            order = [(64, 128)] if wgs((64, 128)) >= 192 or (full_cout and Cout <= 128) else []
             order += [(64, 64), (64, 128), (128, 32), (256, 32)]
         if fam == 0:
             order += [(128, 128), (256, 64)]
@@ -446,7 +390,7 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
     OW = (W + 2 * pad - KW) // stride + 1
     C2 = x2.C if x2 is not None else 0
     assert x1.C + C2 == pw.Cin, f"{label}: input channels {x1.C}+{C2} != weight Cin {pw.Cin}"
-    want_gca = gca is not None and GCA_IN_EPILOGUE and out_mode == OUT_NHWC and act_out == ACT_NONE and addend is None and res is None and post is None
+    want_gca = gca is not None and out_mode == OUT_NHWC and act_out == ACT_NONE and addend is None and res is None and post is None
     if cfg is None and CONV_STREAM and KH == 3 and KW == 3 and stride == 1 and pad == 1 and pw.G == 4:
         # the streaming family: C_out <= 32 from one or two 32-channel inputs, raw or with the ssq-statistics Block prologue
         no_pro = mu is None and rs is None and pa is None and ps is None and ssq_a is None and act_in == ACT_NONE
@@ -454,7 +398,7 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
         tiles16 = x1.B * math.ceil(OH / 16) * math.ceil(OW / 16)
         gca_here = want_gca and tiles16 <= GCA_EPILOGUE_MAX_TILES     # (the other families emit the GlobalContext partials of such layers)
         if (pw.Cout <= 32 and x1.C == 32 and C2 in (0, 32) and pw.Cin_pad == x1.C + C2 and x1.ld % 8 == 0 and (x2 is None or x2.ld % 8 == 0)
-                and (no_pro or (ssq_pro and (C2 == 0 or STREAM_CONCAT_PRO))) and not gca_here and tiles16 >= STREAM_MIN_TILES
+                and (no_pro or ssq_pro) and not gca_here and tiles16 >= STREAM_MIN_TILES
                 and stream_cfg() is not None):
             cfg = (stream_cfg(), 16, 16)
     if cfg is None:
@@ -499,7 +443,6 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
         p.y, p.ldy, p.bsy = y.ptr, y.ld, y.bs
         keep.append(y.t)
     p.TH, p.TW, p.cfg = th, tw, cid
-    p.dbg = IGEMM_DBG
     if ssq_a is not None:
         p.ssq_a, p.ssq_b, p.ssq_wb = ssq_a.data_ptr(), ptr(ssq_b), ssq_wb
         keep += [ssq_a, ssq_b]
@@ -517,11 +460,11 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
         p.ssq_out = ssq_out.data_ptr()
         keep.append(ssq_out)
         emitted = True
-    # gca: dict(wk=fp32 [Cout], bk=float): GlobalContext partials of the output from the epilogue (kernel families 1 / 2, one tile over
+    # gca: dict(wk=fp32 [Cout], bk=float): GlobalContext partials of the output from the epilogue (kernel family 2, one tile over
     # all Cout); `p.gca_part_t` ([B, chunks, Cout + 2], chunks = tiles per image = `p.gca_chunks`) then feeds GCA_FINAL directly
     p.gca_part_t, p.gca_chunks = None, 0
     chunks = math.ceil(OH / th) * math.ceil(OW / tw)
-    if want_gca and cfg_table()[cid][3] in (1, 2) and pw.Cout <= cfg_table()[cid][1] and x1.B * chunks <= GCA_EPILOGUE_MAX_TILES:   # (not family 3)
+    if want_gca and cfg_table()[cid][3] == 2 and pw.Cout <= cfg_table()[cid][1] and x1.B * chunks <= GCA_EPILOGUE_MAX_TILES:   # (not family 3)
         part = torch.empty(x1.B, chunks, pw.Cout + 2, dtype=torch.float32, device=x1.t.device)
         p.gca_wk, p.gca_part, p.gca_bk = gca["wk"].data_ptr(), part.data_ptr(), gca["bk"]
         keep += [gca["wk"], part]
@@ -642,9 +585,12 @@ def gca_final(plan: Plan, part: torch.Tensor, w1t, b1, w2t, b2, gate: torch.Tens
     return f
 
 
-def gca(plan: Plan, h: Act, wk, bk: float, w1t, b1, w2t, b2, part: torch.Tensor, gate: torch.Tensor, chunks: int, label: str = ""):
+def gca(plan: Plan, h: Act, wk, bk: float, w1t, b1, w2t, b2, part: torch.Tensor, gate: torch.Tensor, chunks: int, label: str = "",
+        final: bool = True) -> bool:
     """GlobalContext gate of h.  w1t: [C, hidden] (net.0.weight transposed), w2t: [hidden, C] (net.2.weight transposed), fp32.
-    One launch when the in-kernel finalisation applies (power-of-two C/8, scratch fits), else GCA_PARTIAL + GCA_FINAL."""
+    One launch when the in-kernel finalisation applies (power-of-two C/8, scratch fits), else GCA_PARTIAL + GCA_FINAL.
+    final=False: the caller finalises (GCA_TAIL merges `part` itself) — only the partial pass is emitted, unless one workgroup covers the
+    image and finalises in place.  Returns True when `gate` has been written by the ops emitted here."""
     C = h.C
     hidden = w1t.shape[1]
     assert tuple(w1t.shape) == (C, w2t.shape[0]) and w2t.shape[1] == C
@@ -652,7 +598,7 @@ def gca(plan: Plan, h: Act, wk, bk: float, w1t, b1, w2t, b2, part: torch.Tensor,
     p.h, p.wk, p.part = h.ptr, wk.data_ptr(), part.data_ptr()
     p.B, p.HW, p.C, p.ld, p.chunks, p.bk = h.B, h.H * h.W, C, h.ld, chunks, bk
     groups = C // 8
-    single = ((GCA_SINGLE_LAUNCH or chunks == 1) and (groups & (groups - 1)) == 0 and groups <= 64
+    single = (chunks == 1 and (groups & (groups - 1)) == 0 and groups <= 64
               and C + hidden + chunks + GCA_SCRATCH <= 2048)
     keep = [h.t, wk, part]
     if single:
@@ -664,16 +610,83 @@ def gca(plan: Plan, h: Act, wk, bk: float, w1t, b1, w2t, b2, part: torch.Tensor,
             keep.append(counter)
     plan.add(p, (label or "gca") + (".fused" if single else ".partial"), keep)
     if single:
-        return
+        return True
+    if not final:
+        return False
     f = STRUCTS["ImagenGcaFinalParams"]()
     f.part, f.w1t, f.b1, f.w2t, f.b2, f.gate = part.data_ptr(), w1t.data_ptr(), b1.data_ptr(), w2t.data_ptr(), b2.data_ptr(), gate.data_ptr()
     f.B, f.C, f.hidden, f.chunks = h.B, C, hidden, chunks
     plan.add(f, (label or "gca") + ".final", [part, w1t, b1, w2t, b2, gate])
+    return True
+
+
+def _pow2(v: int) -> bool:
+    return v > 0 and (v & (v - 1)) == 0
+
+
+def gca_tail_ok(C: int, hidden: Optional[int], chunks: int = 1) -> bool:
+    """Shapes the fused tail kernel takes (launcher checks): power-of-two C in [8, 512], power-of-two squeeze width, <= 1024 chunks."""
+    return _pow2(C) and 8 <= C <= 512 and (hidden is None or (_pow2(hidden) and 4 <= hidden <= 1024 and 1 <= chunks <= 1024))
+
+
+def gca_tail(plan: Plan, h: Act, res: Act, out: Act, *, part: Optional[torch.Tensor] = None, chunks: int = 0, w1t=None, b1=None, w2t=None, b2=None,
+             gate_in: Optional[torch.Tensor] = None, gate: Optional[torch.Tensor] = None, ssq_out: Optional[torch.Tensor] = None, label: str = ""):
+    """Identity-ResnetBlock tail in one launch (ImagenGcaTailParams): GlobalContext finalisation from `part` (or a ready `gate_in`, or no
+    gate) + out = h * gate + res (+ ssq_out).  The returned params are kept on `out.tail_op`: request_act() / request_ln_stats() let the
+    consumer of `out` add the activated tensor / LayerNorm statistics to this launch."""
+    for a in (h, res, out):
+        assert a.ld * a.H * a.W == a.bs and (a.B, a.H * a.W, a.C) == (h.B, h.H * h.W, h.C), "gca_tail: dense, equally shaped tensors"
+    p = STRUCTS["ImagenGcaTailParams"]()
+    p.h, p.res, p.out = h.ptr, res.ptr, out.ptr
+    p.B, p.HW, p.C = h.B, h.H * h.W, h.C
+    p.ld_h, p.ld_res, p.ld_out = h.ld, res.ld, out.ld
+    keep = [h.t, res.t, out.t, part, w1t, b1, w2t, b2, gate_in, gate, ssq_out]
+    if part is not None:
+        p.part, p.chunks, p.hidden = part.data_ptr(), chunks, w1t.shape[1]
+        p.w1t, p.b1, p.w2t, p.b2 = w1t.data_ptr(), b1.data_ptr(), w2t.data_ptr(), b2.data_ptr()
+        assert tuple(w1t.shape) == (h.C, w2t.shape[0]) and w2t.shape[1] == h.C
+    p.gate_in, p.gate, p.ssq_out = ptr(gate_in), ptr(gate), ptr(ssq_out)
+    p.eps = 1e-5
+    # slabs per image: ~32 KiB of output per workgroup, about 512 workgroups over the batch at most (every workgroup re-derives the gate)
+    p.slabs = max(1, min(math.ceil(p.HW * p.C * 2 / 32768), max(1, 512 // max(h.B, 1))))
+    plan.add(p, label or "gca_tail", keep)
+    out.tail_op = (p, plan)
+    return p
+
+
+def request_act(x: Act, pa: torch.Tensor) -> Optional[Act]:
+    """Ask the GCA_TAIL launch that produces `x` to also write silu(ChanRMSNorm(x) * pa) — the next Block's activated input
+    (ip.py:683-690) — and return that tensor; None if x has no such producer or it already serves another consumer."""
+    if x.tail_op is None:
+        return None
+    p, plan = x.tail_op
+    if p.act_out or x.ld != x.C or x.C % 8:
+        return None
+    xa = Act(torch.empty_like(x.t), x.B, x.H, x.W, x.C, x.C, x.bs)
+    p.act_out, p.act_pa, p.ld_act = xa.ptr, pa.data_ptr(), xa.ld
+    plan.keep += [xa.t, pa]
+    return xa
+
+
+def request_ln_stats(x: Act, eps: float = 1e-5):
+    """Ask the GCA_TAIL launch that produces `x` for the LayerNorm statistics (mean, rstd) of its rows; None if unavailable."""
+    if x.tail_op is None:
+        return None
+    p, plan = x.tail_op
+    if p.mu_out and abs(p.eps - eps) > 1e-12:
+        return None
+    if not p.mu_out:
+        mu = torch.empty(x.rows, dtype=torch.float32, device=x.t.device)
+        rs = torch.empty(x.rows, dtype=torch.float32, device=x.t.device)
+        p.mu_out, p.rs_out, p.eps = mu.data_ptr(), rs.data_ptr(), eps
+        plan.keep += [mu, rs]
+        p._ln = (mu, rs)
+    return p._ln
 
 
 GCA_SCRATCH = 1024   # csrc/gca_device.h kGcaScratchFloats
-GCA_ONE_WG_ELEMS = int(_os.environ.get("IMAGEN_GCA_ONE_WG_ELEMS", "65536"))   # A/B knobs of gca_chunks()
-GCA_TARGET_WGS = int(_os.environ.get("IMAGEN_GCA_TARGET_WGS", "1024"))
+GCA_ONE_WG_ELEMS = 65536
+GCA_TARGET_WGS = 1024
 
 
 def gca_chunks(HW: int, B: int = 16, C: int = 0) -> int:
@@ -701,7 +714,8 @@ def gate_residual(plan: Plan, h: Act, gate: Optional[torch.Tensor], res: Act, ou
 
 
 def ln_residual(plan: Plan, y: Act, g: torch.Tensor, out: Act, *, beta=None, res: Optional[Act] = None, eps: float = 1e-5,
-                ssq_out: Optional[torch.Tensor] = None, label: str = ""):
+                ssq_out: Optional[torch.Tensor] = None, ln_stats_out: Optional[tuple] = None, eps_out: float = 1e-5, label: str = ""):
+    """ln_stats_out = (mu, rs) fp32 [rows]: also emit the LayerNorm statistics of the stored output rows (for a LayerNorm -> GEMM that follows)."""
     p = STRUCTS["ImagenLnResidualParams"]()
     p.y, p.g, p.beta, p.res, p.out = y.ptr, g.data_ptr(), ptr(beta), (res.ptr if res is not None else None), out.ptr
     p.rows, p.C, p.ld_y, p.ld_res, p.ld_out, p.eps = y.rows, y.C, y.ld, (res.ld if res is not None else 0), out.ld, eps
@@ -709,7 +723,11 @@ def ln_residual(plan: Plan, y: Act, g: torch.Tensor, out: Act, *, beta=None, res
     p.bs_y, p.bs_res, p.bs_out = y.bs, (res.bs if res is not None else 0), out.bs
     assert out.H * out.W == y.H * y.W and out.B == y.B
     p.ssq_out = ptr(ssq_out)
-    plan.add(p, label or "ln_residual", [y.t, g, beta, res.t if res is not None else None, out.t, ssq_out])
+    keep_stats = []
+    if ln_stats_out is not None:
+        p.mu_out, p.rs_out, p.eps_out = ln_stats_out[0].data_ptr(), ln_stats_out[1].data_ptr(), eps_out
+        keep_stats = list(ln_stats_out)
+    plan.add(p, label or "ln_residual", [y.t, g, beta, res.t if res is not None else None, out.t, ssq_out] + keep_stats)
     return p
 
 

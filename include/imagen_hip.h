@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define IMAGEN_ABI_VERSION 4 /* 3: head_dim in the attention / QNORM / KV_PREP params; 4: DDPM_UPDATE x0_thr */
+#define IMAGEN_ABI_VERSION 5 /* 3: head_dim in the attention / QNORM / KV_PREP params; 4: DDPM_UPDATE x0_thr; 5: GCA_TAIL */
 
 typedef void* imagen_stream_t; /* hipStream_t */
 
@@ -62,7 +62,8 @@ enum ImagenOpKind {
   IMAGEN_OP_TEMPORAL_PEG = 24,  /* Imagen-Video: depthwise causal conv over 3 frames + residual                        */
   IMAGEN_OP_TEMPORAL_ATTENTION = 25, /* Imagen-Video: per-pixel causal attention over the frames, with a bias table    */
   IMAGEN_OP_ACT_PREP = 26,     /* the IGEMM prologue as its own pass: norm -> affine -> SiLU of a (two-tensor) input, written as fp16 */
-  IMAGEN_OP_KIND_COUNT = 27
+  IMAGEN_OP_GCA_TAIL = 27,     /* ResnetBlock tail in ONE launch: GlobalContext finalisation + h*gate + res (+ statistics, + the next Block's activated input) */
+  IMAGEN_OP_KIND_COUNT = 28
 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -247,14 +248,38 @@ typedef struct ImagenGateResidualParams {
   int32_t raw_ssq; /* 1: rs_out receives the raw per-pixel sum of squares instead of 1/max(||out||, 1e-12) */
 } ImagenGateResidualParams;
 
+/* GCA_TAIL — the tail of an identity ResnetBlock (ip.py:753-757) as ONE launch instead of GCA_FINAL + GATE_RESIDUAL:
+ *   gate[b, :] = sigmoid(W2 silu(W1 ctx[b] + b1) + b2),  ctx[b] = the softmax-pooled mean merged from part[b][chunks][C + 2]  (GCA_FINAL's contract;
+ *                part == NULL: gate = gate_in[b, :] if gate_in != NULL, else 1)
+ *   out[b, p, c] = fp16(h[b, p, c] * gate[b, c] + res[b, p, c])
+ * Every workgroup (slab, b) recomputes the gate of its image in LDS (the partial rows and the squeeze MLP are a few KB out of L2) and then
+ * streams its slab of pixel rows; the first loads of the slab are issued before the gate arithmetic, so the dependent round trips of the
+ * finalisation overlap them.  Optional per-row outputs, all from the STORED fp16 values (what a consumer reads back):
+ *   ssq_out[r]  = sum_c out^2                                   (raw sum of squares: ChanRMSNorm statistics of the next Block)
+ *   mu_out[r], rs_out[r] = mean_c out, rsqrt(var_c out + eps)   (LayerNorm statistics of a following attention block)
+ *   act_out[r, c] = fp16(silu(out * rsqrt(max(ssq, 1e-24)) * act_pa[c]))   — the NEXT Block's block1 input already through its
+ *                 ChanRMSNorm -> SiLU (ip.py:683-690; block1 has no scale / shift), so that conv stages its input with no arithmetic.
+ * C: a power of two in [8, 512]; hidden: a power of two (launcher-checked); rows are dense per image (row r of image b at (b*HW + r)*ld). */
+typedef struct ImagenGcaTailParams {
+  const void* h; const void* res; void* out;
+  const float* part; const float* w1t; const float* b1; const float* w2t; const float* b2;
+  const float* gate_in; float* gate;     /* gate: optional copy of the computed gate [B][C] (written by slab 0 of every image) */
+  float* ssq_out; float* mu_out; float* rs_out;
+  void* act_out; const float* act_pa;    /* act_pa: fp32 [C] = gamma * sqrt(C) of the next Block's ChanRMSNorm */
+  int32_t B, HW, C, hidden, chunks, slabs;
+  int32_t ld_h, ld_res, ld_out, ld_act;
+  float eps;
+} ImagenGcaTailParams;
+
 /* LN_RESIDUAL — to_out LayerNorm + residual ip.py:529-532,1017 / nn.LayerNorm ip.py:1252:
  *   out = (y - mean)*rsqrt(var+eps)*g (+ beta) (+ res) */
 typedef struct ImagenLnResidualParams {
   const void* y; const float* g; const float* beta; const void* res; void* out;
   float* ssq_out; /* optional raw per-row sum of squares of the stored output (feeds a following ChanRMSNorm) */
+  float* mu_out; float* rs_out; /* optional LayerNorm statistics of the stored output rows: mean, rsqrt(var + eps_out) (feed a following LayerNorm -> GEMM) */
   int32_t rows, C, ld_y, ld_res, ld_out;
   int32_t rows_per_batch, bs_y, bs_res, bs_out; /* row r = (b, rr): address b*bs + rr*ld (rows_per_batch = rows if flat) */
-  float eps;
+  float eps, eps_out;
 } ImagenLnResidualParams;
 
 /* TIME_EMBED — LearnedSinusoidalPosEmb + Linear + SiLU ip.py:654-669, 1213-1217:

@@ -208,6 +208,40 @@ class Interpreter:
             ssq = (out.float() ** 2).sum(-1)
             m.view(p.rs_out, f32)[:p.rows].copy_(ssq if p.raw_ssq else 1.0 / ssq.sqrt().clamp(min=1e-12))
 
+    def gca_tail(self, p):
+        """GCA_TAIL: GlobalContext finalisation (GCA_FINAL's contract) + out = h * gate + res + optional per-row outputs."""
+        m = self.mem
+        B, HW, C = p.B, p.HW, p.C
+        h = m.strided(p.h, f16, (B, HW, C), (HW * p.ld_h, p.ld_h, 1)).float()
+        res = m.strided(p.res, f16, (B, HW, C), (HW * p.ld_res, p.ld_res, 1)).float()
+        if p.part:
+            if p.part in self.gca_ctx:
+                ctx = self.gca_ctx.pop(p.part)
+            else:
+                rows = m.view(p.part, f32)[:B * p.chunks * (C + 2)].reshape(B, p.chunks, C + 2)
+                w = torch.exp(rows[:, :, 0] - rows[:, :, 0].max(dim=1, keepdim=True).values)
+                ctx = torch.einsum("bk,bkc->bc", w, rows[:, :, 2:]) / (w * rows[:, :, 1]).sum(1, keepdim=True)
+            gate = self._gca_gate(ctx, p.w1t, p.b1, p.w2t, p.b2, C, p.hidden)
+            if p.gate:
+                m.view(p.gate, f32)[:B * C].copy_(gate.reshape(-1))
+        elif p.gate_in:
+            gate = m.view(p.gate_in, f32)[:B * C].reshape(B, C)
+        else:
+            gate = torch.ones(B, C)
+        out = (h * gate.reshape(B, 1, C) + res).half()
+        m.strided(p.out, f16, (B, HW, C), (HW * p.ld_out, p.ld_out, 1)).copy_(out)
+        of = out.float()
+        ssq = (of ** 2).sum(-1)
+        if p.ssq_out:
+            m.view(p.ssq_out, f32)[:B * HW].copy_(ssq.reshape(-1))
+        if p.mu_out:
+            m.view(p.mu_out, f32)[:B * HW].copy_(of.mean(-1).reshape(-1))
+            m.view(p.rs_out, f32)[:B * HW].copy_(torch.rsqrt(of.var(-1, unbiased=False) + p.eps).reshape(-1))
+        if p.act_out:
+            pa = m.view(p.act_pa, f32)[:C]
+            a = F.silu(of * (1.0 / ssq.sqrt().clamp(min=1e-12)).unsqueeze(-1) * pa)
+            m.strided(p.act_out, f16, (B, HW, C), (HW * p.ld_act, p.ld_act, 1)).copy_(a.half())
+
     def ln_residual(self, p):
         m = self.mem
         y = self._rows(p.y, p.rows, p.rows_per_batch, p.C, p.ld_y, p.bs_y).float()
@@ -220,6 +254,10 @@ class Interpreter:
         self._rows(p.out, p.rows, p.rows_per_batch, p.C, p.ld_out, p.bs_out).copy_(out)
         if p.ssq_out:
             m.view(p.ssq_out, f32)[:p.rows].copy_((out.float() ** 2).sum(-1).reshape(-1))
+        if p.mu_out:
+            of = out.float().reshape(p.rows, p.C)
+            m.view(p.mu_out, f32)[:p.rows].copy_(of.mean(-1))
+            m.view(p.rs_out, f32)[:p.rows].copy_(torch.rsqrt(of.var(-1, unbiased=False) + p.eps_out))
 
     def time_embed(self, p):
         m = self.mem
@@ -466,6 +504,7 @@ Interpreter.DISPATCH = {
     K["IMAGEN_OP_IGEMM"]: Interpreter.igemm, K["IMAGEN_OP_ROWSTAT"]: Interpreter.rowstat, K["IMAGEN_OP_ATTENTION"]: Interpreter.attention,
     K["IMAGEN_OP_KV_PREP"]: Interpreter.kv_prep, K["IMAGEN_OP_KV_PREP_MULTI"]: Interpreter.kv_prep_multi, K["IMAGEN_OP_QNORM"]: Interpreter.qnorm,
     K["IMAGEN_OP_GCA_PARTIAL"]: Interpreter.gca_partial, K["IMAGEN_OP_GCA_FINAL"]: Interpreter.gca_final,
+    K["IMAGEN_OP_GCA_TAIL"]: Interpreter.gca_tail,
     K["IMAGEN_OP_GATE_RESIDUAL"]: Interpreter.gate_residual, K["IMAGEN_OP_LN_RESIDUAL"]: Interpreter.ln_residual,
     K["IMAGEN_OP_TIME_EMBED"]: Interpreter.time_embed, K["IMAGEN_OP_SCALE_SHIFT"]: Interpreter.scale_shift,
     K["IMAGEN_OP_PACK_IMAGE"]: Interpreter.pack_image, K["IMAGEN_OP_ROWS_COPY"]: Interpreter.rows_copy, K["IMAGEN_OP_MEMSET32"]: Interpreter.memset32,

@@ -145,48 +145,3 @@ def test_config_classes(fixture):
     assert type(el) is ElucidatedImagen and el.hparams[0].num_sample_steps == 3
     uk = dict(params["unets"][0])
     assert type(UnetConfig(**uk).create()) is Unet and type(Unet3DConfig(**uk).create()) is Unet3D and type(NullUnetConfig(is_null=True).create()) is NullUnet
-
-
-def test_split_args_and_kwargs_matches_the_reference_rules():
-    """tr.py:163-186: tensors and lists are chunked along the batch, everything else is repeated, the chunk fraction is reported."""
-    from imagen_pytorch_amd.trainer import split_args_and_kwargs
-
-    te = torch.arange(10.).reshape(5, 2)
-    texts = ["a", "b", "c", "d", "e"]
-    chunks = list(split_args_and_kwargs(texts, text_embeds=te, cond_scale=3., text_masks=None, split_size=2))
-    assert [round(f, 3) for f, _ in chunks] == [0.4, 0.4, 0.2]
-    assert [a[0] for _, (a, _) in chunks] == [["a", "b"], ["c", "d"], ["e"]]
-    assert torch.equal(torch.cat([k["text_embeds"] for _, (_, k) in chunks]), te)
-    assert all(k["cond_scale"] == 3. and k["text_masks"] is None for _, (_, k) in chunks)
-
-
-def test_cli_sample_command(monkeypatch, tmp_path, fixture, ckpt_path):
-    """`imagen sample` (cli.py:27-64): loads the checkpoint (EMA by default), moves the model to the GPU, samples the prompt with
-    return_pil_images and writes ./<slug>.png — argument plumbing checked with the sampler stubbed out (no GPU here)."""
-    from click.testing import CliRunner
-    from PIL import Image
-
-    from imagen_pytorch_amd import checkpoint, cli
-
-    calls = {}
-
-    class Stub:
-        def to(self, device):
-            calls["device"] = str(device)
-            return self
-
-        def sample(self, texts, cond_scale=None, return_pil_images=False):
-            calls.update(texts=texts, cond_scale=cond_scale, pil=return_pil_images)
-            return [Image.new("RGB", (4, 4), (255, 0, 0))]
-
-    def fake_load(path, load_ema_if_available=False, trust_checkpoint=False, **kw):
-        calls.update(path=path, ema=load_ema_if_available)
-        return Stub()
-
-    monkeypatch.setattr(checkpoint, "load_imagen_from_checkpoint", fake_load)
-    monkeypatch.chdir(tmp_path)
-    res = CliRunner().invoke(cli.imagen, ["sample", "--model", str(ckpt_path), "--cond_scale", "3", "a red square, tiny"])
-    assert res.exit_code == 0, res.output
-    assert calls == dict(path=str(ckpt_path), ema=True, device="cuda", texts=["a red square, tiny"], cond_scale=3, pil=True)
-    assert (tmp_path / "a_red_square_tiny.png").exists() and "image saved to" in res.output
-    assert cli.simple_slugify("a-b, c|d ") == "a_b_c--d"

@@ -113,8 +113,6 @@ def test_tile_selection_respects_kernel_limits():
             assert it * G <= 256 * ops.load_library().imagen_igemm_stage_slots(cfg, K, K)
             lds = ops.load_library().imagen_igemm_lds_bytes(cfg, K, K, stride, th, tw)
             assert 0 < lds <= ops.MAX_LDS_BYTES
-            if family == 1:   # LDS-staged family: stride 1, 1x1 / 3x3 only, tile widths with conflict-free row pitches
-                assert stride == 1 and K in (1, 3) and (tw in (8, 16) or tw % 32 == 0)
 
 
 @pytest.mark.parametrize("name", ["unet_tiny_base.pt", "unet_tiny_sr.pt"])

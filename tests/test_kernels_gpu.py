@@ -375,6 +375,57 @@ def test_global_context(ops, dev, B, HW, C):
     assert nerr(gate, ref) < 1e-4
 
 
+@pytest.mark.parametrize("B,HW,C,mode", [(2, 64 * 64, 32, "part"), (2, 16 * 16, 128, "part"), (1, 8 * 8, 256, "gate_in"), (3, 20 * 20, 64, "part"),
+                                         (2, 32 * 32, 64, "none"), (2, 12 * 12, 512, "part")])
+def test_gca_tail(ops, dev, B, HW, C, mode):
+    """GCA_TAIL: GlobalContext finalisation (ip.py:965-970) + h * gate + res (ip.py:755-757) in one launch, with every optional output —
+    per-row sum of squares, LayerNorm statistics, the next Block's activated input silu(ChanRMSNorm(out) * gamma) (ip.py:683-690) — vs
+    fp32 torch; the gate from GCA_PARTIAL rows merged in the kernel, from a ready gate, or absent."""
+    torch.manual_seed(18)
+    S = int(math.isqrt(HW))
+    h, x = h16(torch.randn(B, C, S, S)), h16(torch.randn(B, C, S, S))
+    hidden = max(4, C // 2)
+    wk, bk = torch.randn(1, C, 1, 1) / math.sqrt(C), torch.randn(1) * 0.1
+    w1, b1 = torch.randn(hidden, C, 1, 1) / math.sqrt(C), torch.randn(hidden) * 0.1
+    w2, b2 = torch.randn(C, hidden, 1, 1) / math.sqrt(hidden), torch.randn(C) * 0.1
+    ctx = F.conv2d(h, wk, bk).reshape(B, 1, HW)
+    pooled = torch.einsum("bin,bcn->bci", ctx.softmax(-1), h.reshape(B, C, HW)).unsqueeze(-1)
+    gate_ref = torch.sigmoid(F.conv2d(F.silu(F.conv2d(pooled, w1, b1)), w2, b2)).reshape(B, C)
+    if mode == "none":
+        gate_ref = torch.ones(B, C)
+    gam = torch.rand(C) + 0.5
+    ha, xa = ops.act_from_nchw(h.to(dev)), ops.act_from_nchw(x.to(dev))
+    out = ops.new_act(B, S, S, C, dev)
+    w1t, w2t = w1.reshape(hidden, C).t().contiguous().to(dev), w2.reshape(C, hidden).t().contiguous().to(dev)
+    gate = torch.zeros(B, C, device=dev)
+    ssq = torch.zeros(B * HW, device=dev)
+    plan = ops.Plan()
+    kw = {}
+    if mode == "part":
+        chunks = max(2, ops.gca_chunks(HW, B, C))       # several chunks: the merge is the kernel's job
+        part = torch.empty(B, chunks, C + 2, device=dev)
+        done = ops.gca(plan, ha, wk.reshape(C).to(dev), float(bk), w1t, b1.to(dev), w2t, b2.to(dev), part, gate, chunks, final=False)
+        assert not done
+        kw = dict(part=part, chunks=chunks, w1t=w1t, b1=b1.to(dev), w2t=w2t, b2=b2.to(dev), gate=gate)
+    elif mode == "gate_in":
+        kw = dict(gate_in=gate_ref.to(dev))
+    ops.gca_tail(plan, ha, xa, out, ssq_out=ssq, label="tail", **kw)
+    act = ops.request_act(out, (gam * math.sqrt(C)).to(dev))
+    mu, rs = ops.request_ln_stats(out)
+    assert act is not None and ops.request_act(out, gam.to(dev)) is None      # one consumer per producer
+    _run(plan)
+    ref = (h * gate_ref.reshape(B, C, 1, 1) + x)
+    got = ops.act_to_nchw(out)
+    assert nerr(got, ref) < TOL
+    if mode == "part":
+        assert nerr(gate, gate_ref) < 1e-4
+    rows = out.t.float().reshape(B * HW, C).cpu()                      # statistics are those of the STORED fp16 values
+    assert nerr(ssq, (rows ** 2).sum(-1)) < 1e-5
+    assert nerr(mu, rows.mean(-1)) < 1e-4 and nerr(rs, torch.rsqrt(rows.var(-1, unbiased=False) + 1e-5)) < 1e-4
+    act_ref = F.silu(F.normalize(rows, dim=-1) * gam * math.sqrt(C))
+    assert nerr(act.t.reshape(B * HW, C), act_ref) < TOL
+
+
 def test_time_embed_scale_shift_pack_copy(ops, dev):
     torch.manual_seed(9)
     B, half, out = 4, 8, 256

@@ -358,42 +358,6 @@ def test_cond_images_sampling(cpu_backend):
         imagen.sample(text_embeds=te, cond_scale=3., use_tqdm=False, noise_fn=noise_fn, device="cpu")     # unet expects one (ip.py:1555)
 
 
-def test_trainer_facade_sampling(cpu_backend, tmp_path):
-    """ImagenTrainer (sampling half, tr.py:743-809, 947-961, 188-209): load() keeps both weight sets of the reference's checkpoint,
-    sample() uses the EMA unets unless use_non_ema, max_batch_size chunks the batch with the reference's splitting rules."""
-    from imagen_pytorch_amd import ImagenTrainer, load_imagen_from_checkpoint
-
-    g = torch.load(os.path.join(GOLDEN, "checkpoint_tiny.pt"), weights_only=False)
-    path = tmp_path / "ckpt.pt"
-    torch.save(g["checkpoint"], str(path))
-    trainer = ImagenTrainer(imagen=load_imagen_from_checkpoint(path, load_weights=False).eval(), device="cpu")
-    loaded = trainer.load(path)
-    assert loaded["version"] == g["checkpoint"]["version"] and trainer._ema_sds is not None
-    common = dict(text_embeds=g["text_embeds"], cond_scale=g["cond_scale"], use_tqdm=False)
-    for which, kw in (("ema", {}), ("model", dict(use_non_ema=True)), ("ema", {})):     # and back again: the selection is re-activated
-        exp = g["expected"][which]
-        out = trainer.sample(noise_fn=lambda tag, shape: exp["noise"][tag], **common, **kw)
-        assert nerr(out, exp["output"]) < 2e-2, which
-    # chunked sampling: the same images as one call (per-sample noise handed out chunk by chunk)
-    exp = g["expected"]["ema"]
-    whole = trainer.sample(noise_fn=lambda tag, shape: exp["noise"][tag], **common)
-    state = {"lo": 0}
-    inner = trainer.imagen.sample
-
-    def counting_sample(*a, **k):          # the chunk a call works on = how many samples the calls before it returned
-        out = inner(*a, **k)
-        state["lo"] += out.shape[0]
-        return out
-
-    trainer.imagen.sample = counting_sample
-    chunk_noise = lambda tag, shape: exp["noise"][tag][state["lo"]:state["lo"] + shape[0]]
-    B = g["text_embeds"].shape[0]
-    chunked = trainer.sample(noise_fn=chunk_noise, max_batch_size=max(1, B - 1), **common)
-    assert chunked.shape == whole.shape and torch.allclose(chunked, whole, atol=1e-6)
-    with pytest.raises(NotImplementedError):
-        trainer(torch.zeros(1, 3, 16, 16), unet_number=1)
-
-
 @pytest.mark.parametrize("tag", ["plain", "cond_pre", "inpaint"])
 def test_video_step_level_api(cpu_backend, monkeypatch, tag):
     """The reference's step-level methods on a video stage (ip.py:2042-2289 with 5-D shapes): the base Unet3D stage of the tiny video

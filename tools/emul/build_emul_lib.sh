@@ -1,7 +1,7 @@
 #!/bin/bash
-# Builds the CPU functional emulation of the kernel library (every csrc/*.hip except conv_lds.hip): imagen-pytorch_amd/libimagen_emul.so, and with "remat" as the first argument
-# libimagen_emul_remat.so (-DIGEMM_EPI_REMAT); `NAME -Dflags...` builds libimagen_emul_NAME.so with those flags.  Host clang (the ROCm toolchain's), no GPU code; skipped when the library is newer than
-# its sources.  See tools/emul/README.md.
+# Builds the CPU functional emulation of the kernel library (every csrc/*.hip): imagen-pytorch_amd/libimagen_emul.so;
+# `NAME -Dflags...` builds libimagen_emul_NAME.so with those flags (an A/B variant of a kernel edit).  Host clang (the ROCm toolchain's),
+# no GPU code; skipped when the library is newer than its sources.  See tools/emul/README.md.
 set -e
 ROOT=$(cd "$(dirname "$0")/../.." && pwd)
 P=$ROOT/imagen-pytorch_amd
@@ -9,8 +9,7 @@ CL=/opt/rocm/lib/llvm/bin/clang++
 OUT=$P/build/emul
 mkdir -p $OUT
 TAG=""; DEFS=""
-if [ "${1:-}" = "remat" ]; then TAG="_remat"; DEFS="-DIGEMM_EPI_REMAT";
-elif [ -n "${1:-}" ]; then TAG="_$1"; shift; DEFS="$*"; fi       # any other name: the remaining arguments are the -D flags of that variant
+if [ -n "${1:-}" ]; then TAG="_$1"; shift; DEFS="$*"; fi       # any other name: the remaining arguments are the -D flags of that variant
 LIB=$P/libimagen_emul$TAG.so
 TUS="igemm conv_dma conv_stream elementwise sampler temporal attention capi codesize"
 SRCS="$(for t in $TUS; do echo $P/csrc/$t.hip; done) $P/csrc/conv_epilogue.h $P/csrc/gca_device.h $P/csrc/common.h $ROOT/include/imagen_hip.h $ROOT/tools/emul/emul_runtime.cpp $ROOT/tools/emul/hip/hip_runtime.h $ROOT/tools/emul/build_emul_lib.sh"

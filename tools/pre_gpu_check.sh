@@ -5,7 +5,7 @@
 #      command line), bit-compared with the product build;
 #   3. the spill placement did not get worse than the last version that met hardware (profiles/r02_static_spills_igemm_default.txt);
 #   4. the host logic is green.
-#     bash tools/pre_gpu_check.sh [variant-name -Dflag ...]        e.g.  bash tools/pre_gpu_check.sh onewg -DIGEMM_ONE_WG -DIGEMM_LA1=12 -DIGEMM_LA2=10
+#     bash tools/pre_gpu_check.sh [variant-name -Dflag ...]        e.g.  bash tools/pre_gpu_check.sh deepring -DMY_AB_FLAG=1
 set -e
 ROOT=$(cd "$(dirname "$0")/.." && pwd)
 cd "$ROOT"
