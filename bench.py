@@ -130,6 +130,46 @@ def pmc_traffic_leg(log, budget_s: float = 300.0):
     return out or None
 
 
+def calibration_leg(device):
+    """Self-anchoring numbers measured in THIS process: the GPU's current shader / memory clocks (rocm-smi, best effort), a fixed 1 GiB
+    device copy (GB/s of read + written bytes) and a fixed dense fp16 MFMA loop on every CU (TFLOP/s) — imagen_probe_copy /
+    imagen_probe_mfma of the kernel library, HIP-event timed.  Boxes of the pool differ by up to +-20 % on the sampling workload; these
+    two figures let one round's line be normalised against another's."""
+    import ctypes
+    import shutil
+    import subprocess
+    from imagen_pytorch_amd import _abi, ops
+
+    lib = _abi.load_library()
+    out = {}
+    n = 1 << 30
+    src = torch.empty(n, dtype=torch.uint8, device=device).fill_(1)
+    dst = torch.empty(n, dtype=torch.uint8, device=device)
+    sink = torch.zeros(4, dtype=torch.float32, device=device)
+    torch.cuda.synchronize()
+    h = ops.current_stream_handle()
+    v = ctypes.c_float()
+    _abi.check(lib.imagen_probe_copy(dst.data_ptr(), src.data_ptr(), n, 5, h, ctypes.byref(v)), "probe_copy")
+    out["copy_1GiB_GBs"] = round(v.value, 1)
+    _abi.check(lib.imagen_probe_mfma(20000, 3, sink.data_ptr(), h, ctypes.byref(v)), "probe_mfma")
+    out["mfma_f16_loop_TFLOPs"] = round(v.value, 1)
+    out["mfma_f16_loop_frac_of_peak"] = round(v.value / MFMA_PEAK_TFLOPS, 4)
+    del src, dst
+    smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    try:
+        r = subprocess.run([smi, "--showclocks", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=20)
+        card = next(iter(json.loads(r.stdout.decode()).values()))
+        for k, val in card.items():
+            kl = k.lower()
+            if "sclk" in kl and "level" in kl:
+                out["sclk"] = val
+            elif "mclk" in kl and "level" in kl:
+                out["mclk"] = val
+    except Exception as e:  # noqa: BLE001 — best effort
+        out["clocks_error"] = f"{type(e).__name__}: {e}"
+    return out
+
+
 def roofline_leg(imagen, batch: int, device, pmc=None):
     """Event-time every igemm launch of one denoiser step of both stages (eager, same stream), grouped by tile configuration.
     Two roofs are reported: the tile configuration with the largest total time among the MFMA-bound launches (algorithmic
@@ -411,6 +451,7 @@ def main():
                                                       "batch k, one stream + hipGraph per stage); every batch runs the full cascade, pipeline fill "
                                                       "and drain are inside the timed region",
                                           "lanes": f"{args.lanes} whole cascades side by side (one stream each)"}[args.mode],
+                       "images_in_flight": B * (args.lanes if args.mode == "lanes" else (2 if args.mode == "pipeline" else 1)),
                        "denoiser_evals_per_image": 2 * 2 * args.timesteps},
             "path_tflops_reference_count": round(value * FLOPS_PER_IMAGE_REFERENCE * (args.timesteps / 1000) / 1e12, 1),
             "path_frac_of_mfma_peak": round(value * FLOPS_PER_IMAGE_REFERENCE * (args.timesteps / 1000) / 1e12 / (MFMA_PEAK_TFLOPS * world), 4),
@@ -429,8 +470,18 @@ def main():
             torch.cuda.synchronize()
             dt = time.perf_counter() - t1
             rec["sequential"] = {"ms_per_step": round(dt * 1e3, 2), "value": round(B / dt, 4), "unit": "images/s",
-                                 "note": "one sample() call at a time (no overlap between batches), measured once after the timed region"}
+                                 "ms_per_ddpm_step_pair": round(dt * 1e3 / args.timesteps, 4),
+                                 "path_frac_of_mfma_peak": round(B / dt * FLOPS_PER_IMAGE_REFERENCE * (args.timesteps / 1000) / 1e12 / MFMA_PEAK_TFLOPS, 4),
+                                 "note": "one sample() call at a time (no overlap between batches; round-over-round comparisons use THIS "
+                                         "figure), measured once after the timed region"}
             log("sequential pass done")
+        if world == 1:
+            try:
+                rec["calibration"] = calibration_leg(device)
+                log("calibration probes done")
+            except Exception as e:  # noqa: BLE001
+                rec["calibration"] = None
+                rec["calibration_error"] = f"{type(e).__name__}: {e}"
         # the extra legs must never cost the headline line: a failure is reported in the record instead
         if world == 1 and not args.no_roofline:
             try:

@@ -414,35 +414,9 @@ __global__ __launch_bounds__(256) void gca_partial_online_kernel(const ImagenGca
     }
   }
   if (p.w1t == nullptr) return;   // partials only: a GCA_FINAL launch follows
-  if (p.chunks == 1) {
-    __syncthreads();
-    gca_mlp(s_fin, s_fin + p.C, s_fin + p.C + p.hidden, p.C, p.hidden, p.w1t, p.b1, p.w2t, p.b2, p.gate + (size_t)b * p.C);
-    return;
-  }
-  // last workgroup of this image finalises (agent-scope release / acquire ticket; placement-independent)
-#ifdef IMAGEN_EMUL   // (tools/emul: host compile, no GPU assembler — loads complete in program order there)
-#define EW_WAIT_VM0() ((void)0)
-#else
-#define EW_WAIT_VM0() asm volatile("s_waitcnt vmcnt(0)" ::: "memory")
-#endif
-  __shared__ int s_last;
-  EW_WAIT_VM0();
+  // one chunk per image (launcher-checked): the whole image was this workgroup's, the squeeze MLP runs here
   __syncthreads();
-  if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    EW_WAIT_VM0();
-    const int old = __hip_atomic_fetch_add(p.counter + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    const int last = (old == p.chunks - 1) ? 1 : 0;
-    if (last) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-    s_last = last;
-  }
-  __syncthreads();
-  if (s_last) {
-    // scratch: the three LDS arrays above are contiguous enough only by luck — use s_acc (2048 floats) explicitly
-    gca_finalize(p.part + (size_t)b * p.chunks * (p.C + 2), p.chunks, p.C, p.hidden, p.w1t, p.b1, p.w2t, p.b2, p.gate + (size_t)b * p.C,
-                 s_acc);
-    if (threadIdx.x == 0) __hip_atomic_store(p.counter + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  }
+  gca_mlp(s_fin, s_fin + p.C, s_fin + p.C + p.hidden, p.C, p.hidden, p.w1t, p.b1, p.w2t, p.b2, p.gate + (size_t)b * p.C);
 }
 
 // One workgroup per image: merge the chunk partials and run the squeeze MLP (gca_device.h, shared with the fused igemm epilogue).
@@ -867,7 +841,7 @@ int launch_gca_partial(const ImagenGcaPartialParams* p, hipStream_t s) {
   if (p->w1t) {
     IMAGEN_CHECK((groups & (groups - 1)) == 0 && groups <= 64, "gca: in-kernel finalisation needs a power-of-two C/8 (C = %d)", p->C);
     IMAGEN_CHECK(p->b1 && p->w2t && p->b2 && p->gate && p->hidden > 0, "gca: incomplete finalisation parameters");
-    IMAGEN_CHECK(p->chunks == 1 || p->counter, "gca: in-kernel finalisation over %d chunks needs the ticket counter", p->chunks);
+    IMAGEN_CHECK(p->chunks == 1, "gca: in-kernel finalisation needs one chunk per image (got %d)", p->chunks);
     IMAGEN_CHECK(p->C + p->hidden + p->chunks + kGcaScratchFloats <= 2048, "gca: finalisation scratch too large (C %d hidden %d chunks %d)", p->C,
                  p->hidden, p->chunks);
   }

@@ -951,7 +951,10 @@ int launch_gen(const ImagenIgemmParams& p, hipStream_t s) {
     occ_blocks = nb;
     occ_lds = lds;
   }
-  const int resident = std::max(8, num_cus() * occ_blocks / 8 * 8);
+  // experiment knob (round 3): fewer resident workgroups per CU than fit leave registers / LDS for other streams' kernels (lanes)
+  static const int per_cu_cap = [] { const char* e = getenv("IMAGEN_PERSIST_WG_PER_CU"); return e ? atoi(e) : 0; }();
+  const int per_cu = per_cu_cap > 0 ? std::min(per_cu_cap, occ_blocks) : occ_blocks;
+  const int resident = std::max(8, num_cus() * per_cu / 8 * 8);
   int gx;
   if ((p.dbg & 32) || total <= resident) {
     gx = total;                                    // dbg 32: one tile per workgroup (no cross-tile pipelining)

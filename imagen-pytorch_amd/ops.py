@@ -604,10 +604,6 @@ def gca(plan: Plan, h: Act, wk, bk: float, w1t, b1, w2t, b2, part: torch.Tensor,
     if single:
         p.w1t, p.b1, p.w2t, p.b2, p.gate, p.hidden = w1t.data_ptr(), b1.data_ptr(), w2t.data_ptr(), b2.data_ptr(), gate.data_ptr(), hidden
         keep += [w1t, b1, w2t, b2, gate]
-        if chunks > 1:
-            counter = torch.zeros(h.B, dtype=torch.int32, device=h.t.device)   # self-resetting ticket
-            p.counter = counter.data_ptr()
-            keep.append(counter)
     plan.add(p, (label or "gca") + (".fused" if single else ".partial"), keep)
     if single:
         return True
@@ -647,8 +643,10 @@ def gca_tail(plan: Plan, h: Act, res: Act, out: Act, *, part: Optional[torch.Ten
         assert tuple(w1t.shape) == (h.C, w2t.shape[0]) and w2t.shape[1] == h.C
     p.gate_in, p.gate, p.ssq_out = ptr(gate_in), ptr(gate), ptr(ssq_out)
     p.eps = 1e-5
-    # slabs per image: ~32 KiB of output per workgroup, about 512 workgroups over the batch at most (every workgroup re-derives the gate)
-    p.slabs = max(1, min(math.ceil(p.HW * p.C * 2 / 32768), max(1, 512 // max(h.B, 1))))
+    # slabs per image: >= 32 KiB of output per workgroup, and at most ONE workgroup per CU over the batch — the kernel holds one
+    # 1024-thread workgroup per CU, so a second round would pay the ~5 us gate derivation again with nothing resident to hide it
+    # (measured, round 3 call B: 512 workgroups cost +10 us per launch at 256^2)
+    p.slabs = max(1, min(math.ceil(p.HW * p.C * 2 / 32768), max(1, 256 // max(h.B, 1))))
     plan.add(p, label or "gca_tail", keep)
     out.tail_op = (p, plan)
     return p

@@ -230,9 +230,9 @@ typedef struct ImagenQnormParams {
  *   final: ctx = softmax-pooled mean; gate = sigmoid(W2 silu(W1 ctx + b1) + b2)   -> gate[b][C] */
 typedef struct ImagenGcaPartialParams {
   const void* h; const float* wk; float* part;
-  /* optional in-kernel finalisation (replaces the GCA_FINAL launch): counter[B] is a zero-initialised, self-resetting ticket;
-   * the last workgroup of an image to finish merges the chunks and writes gate[b][C] (same protocol as the fused IGEMM epilogue) */
-  int32_t* counter; const float* w1t; const float* b1; const float* w2t; const float* b2; float* gate;
+  /* optional in-kernel finalisation (replaces the GCA_FINAL launch) when ONE chunk covers the image (small feature maps): the
+   * workgroup of image b pools into LDS, runs the squeeze MLP and writes gate[b][C] */
+  const float* w1t; const float* b1; const float* w2t; const float* b2; float* gate;
   int32_t B, HW, C, ld, chunks, hidden; float bk;
 } ImagenGcaPartialParams;
 typedef struct ImagenGcaFinalParams {
@@ -435,6 +435,12 @@ int imagen_event_create(void** ev);
 int imagen_event_record(void* ev, imagen_stream_t stream);
 int imagen_event_elapsed_ms(void* ev_start, void* ev_stop, float* ms);
 int imagen_event_destroy(void* ev);
+
+/* Calibration probes (bench.py `calibration`; not on the sampling path): a device copy of `bytes` (multiple of 16) repeated `reps`
+ * times -> GB/s of read + written bytes; a dense v_mfma_f32_32x32x16_f16 loop on every CU -> TFLOP/s.  Both time themselves with HIP
+ * events on `stream` and synchronise it. */
+int imagen_probe_copy(void* dst, const void* src, size_t bytes, int reps, imagen_stream_t stream, float* gbs_out);
+int imagen_probe_mfma(int iters, int reps, float* sink, imagen_stream_t stream, float* tflops_out);
 
 #ifdef __cplusplus
 }

@@ -94,14 +94,12 @@ def test_tail_kernels_emit_raw_ssq():
     assert nerr(ssq2, (o2 ** 2).sum(1).reshape(-1)) < 1e-5
 
 
-@pytest.mark.parametrize("single", [0, 1, 2])   # 2: the small-map path (one chunk per image, finalised by its own workgroup)
+@pytest.mark.parametrize("single", [0, 2])   # 2: the small-map path (one chunk per image, finalised by its own workgroup)
 @pytest.mark.parametrize("B,S,C", [(2, 64, 32), (2, 32, 64), (3, 16, 128), (1, 24, 64), (2, 8, 512)])
 def test_global_context_of_conv_output(B, S, C, single, monkeypatch):
     """GlobalContext (ip.py:945-970) of a conv output vs fp32 torch, as chunk partials + a finalisation kernel (default) and as
-    ONE launch (last-workgroup finalisation behind an agent-scope ticket); run twice: the ticket counter must reset itself."""
+    ONE launch (one chunk per image, finalised by its own workgroup); run twice."""
     from imagen_pytorch_amd import ops
-
-    monkeypatch.setattr(ops, "GCA_SINGLE_LAUNCH", int(single == 1))
 
     dev = gpu_device()
     torch.manual_seed(3)
@@ -124,7 +122,7 @@ def test_global_context_of_conv_output(B, S, C, single, monkeypatch):
     part = torch.empty(B, chunks, C + 2, device=dev)
     ops.gca(plan, y, wk.reshape(C).to(dev), float(bk), w1.reshape(hidden, C).t().contiguous().to(dev), b1.to(dev),
             w2.reshape(C, hidden).t().contiguous().to(dev), b2.to(dev), part, gate, chunks)
-    one_launch = (single == 1 or chunks == 1) and not (C // 8) & (C // 8 - 1)   # power-of-two C/8: the in-kernel finalisation exists
+    one_launch = chunks == 1 and not (C // 8) & (C // 8 - 1)   # power-of-two C/8: the in-kernel finalisation exists
     assert len(plan) == (2 if one_launch else 3)
     for _ in range(2):
         gate.zero_()
