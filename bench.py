@@ -48,6 +48,7 @@ README_U2 = dict(dim=32, cond_dim=512, dim_mults=(1, 2, 4, 8), num_resnet_blocks
                  layer_cross_attns=(False, False, False, True))
 FLOPS_PER_IMAGE_REFERENCE = 287.3e12   # 2000 * (12.71 + 130.94) GF, as the reference executes the path
 MFMA_PEAK_TFLOPS = 2500.0              # dense fp16/bf16, MI355X_MICROARCH.md
+LANES_DEFAULT = 6
 
 
 def build_imagen(timesteps: int, device):
@@ -159,12 +160,11 @@ def calibration_leg(device):
     try:
         r = subprocess.run([smi, "--showclocks", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=20)
         card = next(iter(json.loads(r.stdout.decode()).values()))
-        for k, val in card.items():
+        for k, val in card.items():     # e.g. "sclk clock speed:": "(2400Mhz)", "sclk clock level:": "1"
             kl = k.lower()
-            if "sclk" in kl and "level" in kl:
-                out["sclk"] = val
-            elif "mclk" in kl and "level" in kl:
-                out["mclk"] = val
+            for name in ("sclk", "mclk"):
+                if kl.startswith(name) and "speed" in kl:
+                    out[name] = str(val).strip("()")
     except Exception as e:  # noqa: BLE001 — best effort
         out["clocks_error"] = f"{type(e).__name__}: {e}"
     return out
@@ -331,8 +331,8 @@ def main():
                     help="how successive batches are scheduled on the GPU: one sample() after the other | cascade stages overlapped across "
                          "batches (Imagen.sample_pipelined) | --lanes whole cascades side by side (one thread + stream each)")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("IMAGEN_BENCH_LANES", "0")),
-                    help="concurrent cascades in --mode lanes; 0 = 3..5, whichever wastes the fewest lane-slots in the last round of --steps "
-                         "(throughput is flat from 3 lanes up — DESIGN.md, lanes paragraph — so only the tail matters)")
+                    help="concurrent cascades in --mode lanes; 0 = min(6, --steps): throughput still rises from 3 to 6 lanes (round 3, call C: "
+                         "8.90 / 8.00 / 7.50 ms per DDPM step pair at 3 / 4 / 6 lanes on one box); batches are handed out dynamically")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic / mfma_busy_frac = null)")
@@ -343,7 +343,7 @@ def main():
         return
 
     if args.lanes <= 0:
-        args.lanes = min(range(3, 6), key=lambda l: (-args.steps % l, l)) if args.steps >= 3 else max(args.steps, 1)
+        args.lanes = max(1, min(LANES_DEFAULT, args.steps))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

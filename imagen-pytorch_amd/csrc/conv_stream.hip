@@ -423,8 +423,7 @@ int cs_launch_gen(const ImagenIgemmParams& p, hipStream_t s) {
   const int total = p.B * tilesX * tilesY;
   int cus = 256;
   (void)hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev);
-  static const int per_cu_cap = [] { const char* e = getenv("IMAGEN_PERSIST_WG_PER_CU"); return e ? atoi(e) : 0; }();   // experiment knob, see igemm.hip
-  const int per_cu = per_cu_cap > 0 ? std::min(per_cu_cap, NCH == 1 ? 2 : 1) : (NCH == 1 ? 2 : 1);
+  const int per_cu = NCH == 1 ? 2 : 1;
   const int resident = std::max(1, std::max(1, cus) * per_cu);
   int gx = total;
   if (total > resident) {   // even rounds: every workgroup walks the same number of tiles (+-1)

@@ -951,10 +951,9 @@ int launch_gen(const ImagenIgemmParams& p, hipStream_t s) {
     occ_blocks = nb;
     occ_lds = lds;
   }
-  // experiment knob (round 3): fewer resident workgroups per CU than fit leave registers / LDS for other streams' kernels (lanes)
-  static const int per_cu_cap = [] { const char* e = getenv("IMAGEN_PERSIST_WG_PER_CU"); return e ? atoi(e) : 0; }();
-  const int per_cu = per_cu_cap > 0 ? std::min(per_cu_cap, occ_blocks) : occ_blocks;
-  const int resident = std::max(8, num_cus() * per_cu / 8 * 8);
+  // (persistent grids capped at ONE workgroup per CU, to leave registers / LDS for the other lanes' kernels, were measured in round 3's
+  // call C: sequential +7 %, lanes throughput unchanged — not kept)
+  const int resident = std::max(8, num_cus() * occ_blocks / 8 * 8);
   int gx;
   if ((p.dbg & 32) || total <= resident) {
     gx = total;                                    // dbg 32: one tile per workgroup (no cross-tile pipelining)
