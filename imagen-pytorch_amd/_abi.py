@@ -197,4 +197,4 @@ def check(rc: int, what: str = "") -> None:
 
 
 class OpRef(ctypes.Structure):
-    _fields_ = [("kind", ctypes.c_int32), ("flags", ctypes.c_int32), ("params", ctypes.c_void_p)]
+    _fields_ = [("kind", ctypes.c_int32), ("reserved", ctypes.c_int32), ("params", ctypes.c_void_p)]

@@ -2,38 +2,10 @@
 // execution, hipGraph capture helpers, HIP-event timing, error reporting.
 #include <cstdarg>
 #include <cstdio>
-#include <unordered_map>
-#include <vector>
 #include "common.h"
 
 namespace {
 thread_local char g_err[512] = "";
-
-#ifndef IMAGEN_EMUL
-// Side stream of a launch stream (IMAGEN_OPREF_SIDE): created lazily, one per (thread, launch stream) — a lane of the sampler is a
-// thread with its own stream — with a pool of timing-less events for the fork / join edges (one event per edge of a plan run: under
-// stream capture every record is a node of its own).
-struct SideCtx {
-  hipStream_t side = nullptr;
-  std::vector<hipEvent_t> events;
-  size_t used = 0;
-  hipEvent_t next_event() {
-    if (used == events.size()) {
-      hipEvent_t e = nullptr;
-      if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) return nullptr;
-      events.push_back(e);
-    }
-    return events[used++];
-  }
-};
-thread_local std::unordered_map<hipStream_t, SideCtx> g_side;
-
-SideCtx* side_ctx(hipStream_t main) {
-  SideCtx& c = g_side[main];
-  if (!c.side && hipStreamCreateWithFlags(&c.side, hipStreamNonBlocking) != hipSuccess) return nullptr;
-  return &c;
-}
-#endif
 }
 
 void imagen_set_error(const char* fmt, ...) {
@@ -115,39 +87,8 @@ extern "C" int imagen_launch(int kind, const void* params, imagen_stream_t strea
 }
 
 extern "C" int imagen_plan_run(const ImagenOpRef* ops, int n, imagen_stream_t stream) {
-  hipStream_t main = reinterpret_cast<hipStream_t>(stream);
-#ifndef IMAGEN_EMUL
-  SideCtx* sc = nullptr;
-  bool side_open = false;   // the side stream holds work the launch stream has not waited for yet
-  auto join = [&]() -> int {
-    hipEvent_t e = sc->next_event();
-    if (!e || hipEventRecord(e, sc->side) != hipSuccess || hipStreamWaitEvent(main, e, 0) != hipSuccess) {
-      imagen_set_error("plan: joining the side stream failed: %s", hipGetErrorString(hipGetLastError()));
-      return -1;
-    }
-    side_open = false;
-    return 0;
-  };
-#endif
   for (int i = 0; i < n; ++i) {
-    hipStream_t s = main;
-#ifndef IMAGEN_EMUL   // (the CPU emulation runs every op in plan order on the one stream)
-    if ((ops[i].flags & IMAGEN_OPREF_JOIN) && side_open && join() != 0) return -1;
-    if (ops[i].flags & IMAGEN_OPREF_SIDE) {
-      if (!sc) {
-        sc = side_ctx(main);
-        if (sc) sc->used = 0;
-      }
-      hipEvent_t e = sc ? sc->next_event() : nullptr;
-      if (!e || hipEventRecord(e, main) != hipSuccess || hipStreamWaitEvent(sc->side, e, 0) != hipSuccess) {
-        imagen_set_error("plan op %d: forking to the side stream failed: %s", i, hipGetErrorString(hipGetLastError()));
-        return -1;
-      }
-      s = sc->side;
-      side_open = true;
-    }
-#endif
-    const int rc = imagen_launch(ops[i].kind, ops[i].params, reinterpret_cast<imagen_stream_t>(s));
+    const int rc = imagen_launch(ops[i].kind, ops[i].params, stream);
     if (rc != 0) {
       char msg[400];
       snprintf(msg, sizeof(msg), "%s", g_err);
@@ -155,9 +96,6 @@ extern "C" int imagen_plan_run(const ImagenOpRef* ops, int n, imagen_stream_t st
       return rc;
     }
   }
-#ifndef IMAGEN_EMUL
-  if (side_open && join() != 0) return -1;   // nothing of a plan outlives the call on another stream (and a capture ends joined)
-#endif
   return 0;
 }
 

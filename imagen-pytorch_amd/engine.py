@@ -96,7 +96,6 @@ def _fingerprint(unet) -> tuple:
 ACT_PREP_MIN_COUT = int(os.environ.get("IMAGEN_ACT_PREP_MIN_COUT", "0"))   # (measured in the model: the extra pass costs more than it saves — off)
 TAIL_FUSED = int(os.environ.get("IMAGEN_TAIL_FUSED", "1"))   # A/B switch: GCA_FINAL + GATE_RESIDUAL of an identity ResnetBlock as one GCA_TAIL launch
 TAIL_ACT = int(os.environ.get("IMAGEN_TAIL_ACT", "1"))       # A/B switch: ... which also writes the next block1's activated input
-SIDE_RES = int(os.environ.get("IMAGEN_SIDE_RES", "1"))       # A/B switch: res_conv as a plain GEMM on the side stream + a fused tail (instead of GCA_FINAL + res_conv with the gated addend)
 LN_STATS_FUSED = int(os.environ.get("IMAGEN_LN_STATS_FUSED", "1"))   # A/B switch: LayerNorm statistics from the producing launch (GCA_TAIL / LN_RESIDUAL) instead of a ROWSTAT pass
 
 
@@ -432,13 +431,6 @@ class UnetEngine:
         off = self._blk_off[self._blk_index[id(rb)]]
         pa2 = self.pa2[:, off:]
         ps2 = self.ps2[:, off:]
-        # res_conv (ip.py:732) does not depend on block1 / block2: as a plain GEMM on the SIDE stream (a parallel branch of the step's hipGraph)
-        # it overlaps them, and the block ends like an identity block — one GCA_TAIL launch: gate finalisation + h2 * gate + r
-        hidden_gca = rb.gca.net[0].weight.shape[0] if rb.gca is not None else None
-        side_r = None
-        if rb.res_conv is not None and SIDE_RES and TAIL_FUSED and ops.gca_tail_ok(Cout, hidden_gca):
-            side_r = self.new(R, H, Wd, Cout)
-            ops.mark_side(ops.igemm(plan, x, W.conv(name + ".res_conv", rb.res_conv, in_scale=in_scale), side_r, x2=skip, label=name + ".res_conv"))
         h1 = self.new(R, H, Wd, Cout)
         h1.ssq = self.f32buf(R * H * Wd)
         # without a cross-attention in between, block1's epilogue applies block2's ChanRMSNorm -> (scale+1, shift) -> SiLU itself
@@ -486,9 +478,8 @@ class UnetEngine:
                 op2 = ops.igemm(plan, h1, W.conv(name + ".block2", rb.block2.project), h2, ssq_a=s1, pa=pa2, ps=ps2, pstride=self.total_c,
                                 act_in=ACT_SILU, gca=gca_ep, label=name + ".block2")
         # identity block: GlobalContext finalisation + h2 * gate + x (+ statistics) as ONE launch (GCA_TAIL) where its shapes allow
-        res_in = side_r if side_r is not None else x     # what the tail adds to h2 * gate
-        fused_tail = side_r is not None or (TAIL_FUSED and rb.res_conv is None and x.ld == x.C and x.bs == H * Wd * x.C
-                                            and ops.gca_tail_ok(Cout, (hidden if rb.gca is not None else None)))
+        fused_tail = (TAIL_FUSED and rb.res_conv is None and x.ld == x.C and x.bs == H * Wd * x.C
+                      and ops.gca_tail_ok(Cout, (hidden if rb.gca is not None else None)))
         tail_part, tail_chunks, gate_ready = None, 0, False
         if rb.gca is not None:
             if op2.gca_part_t is not None:   # the partials came out of block2's epilogue: only the merge + squeeze MLP is left
@@ -508,12 +499,10 @@ class UnetEngine:
         out = self.new(R, H, Wd, Cout)
         out.ssq = self.f32buf(R * H * Wd)
         if fused_tail:
-            assert skip is None or side_r is not None
-            tp = ops.gca_tail(plan, h2, res_in, out, part=tail_part, chunks=tail_chunks, w1t=gca_args and gca_args["w1t"], b1=gca_args and gca_args["b1"],
+            assert skip is None
+            ops.gca_tail(plan, h2, x, out, part=tail_part, chunks=tail_chunks, w1t=gca_args and gca_args["w1t"], b1=gca_args and gca_args["b1"],
                          w2t=gca_args and gca_args["w2t"], b2=gca_args and gca_args["b2"], gate_in=gate if gate_ready else None,
                          gate=gate if tail_part is not None else None, ssq_out=out.ssq, label=name + ".tail")
-            if side_r is not None:
-                ops.mark_join(tp)
         elif rb.res_conv is not None:
             wr = W.conv(name + ".res_conv", rb.res_conv, in_scale=in_scale)
             if gate is not None:

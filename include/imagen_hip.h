@@ -395,13 +395,7 @@ typedef struct ImagenMeanRowsParams {
 
 typedef struct ImagenMemset32Params { void* dst; uint32_t value; int32_t count; } ImagenMemset32Params;
 
-/* One op of a plan.  `flags` (0 for a plain sequential op):
- *   IMAGEN_OPREF_SIDE — the op is independent of the ops between it and the next IMAGEN_OPREF_JOIN: imagen_plan_run launches it on a side
- *                       stream that first waits for everything enqueued before it (a fork: under stream capture a parallel branch of the
- *                       hipGraph), so it overlaps the main chain (the ResnetBlock's res_conv GEMM beside block1 -> block2, ip.py:732, 753-757);
- *   IMAGEN_OPREF_JOIN — before this op the launch stream waits for the side stream's work. */
-enum { IMAGEN_OPREF_SIDE = 1, IMAGEN_OPREF_JOIN = 2 };
-typedef struct ImagenOpRef { int32_t kind; int32_t flags; const void* params; } ImagenOpRef;
+typedef struct ImagenOpRef { int32_t kind; int32_t reserved; const void* params; } ImagenOpRef;
 
 /* ---- entry points ------------------------------------------------------------------------------ */
 int imagen_abi_version(void);
