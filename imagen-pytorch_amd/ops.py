@@ -269,7 +269,6 @@ def launchable_shapes(cfg: int, OH: int, OW: int, KH: int, KW: int, stride: int)
 # pass over the tensor costs ~9 us per LAUNCH + its read (measured in the model: a loss on the 4096-tile 256^2 layers, a gain below)
 GCA_EPILOGUE_MAX_TILES = 1024
 CONV_DMA = int(_os.environ.get("IMAGEN_CONV_DMA", "1"))             # A/B switch: the all-DMA kernel family for prologue-free single-input 3x3 convs
-DMA_PREFER_64 = int(_os.environ.get("IMAGEN_DMA_PREFER_64", "0"))   # experiment knob, see _pick_dma
 CONV_STREAM = int(_os.environ.get("IMAGEN_CONV_STREAM", "1"))       # A/B switch: the streaming kernel family (conv_stream.hip) for the 32-channel 3x3 convs
 STREAM_MIN_TILES = 512   # ... of launches with at least this many 16x16 tiles (persistent workgroups need a few tiles each)
 
@@ -296,12 +295,6 @@ def _pick_dma(Cout: int, OH: int, OW: int, B: int, full_cout: bool):
         k = next((k for k in cand if k[0] == tp and k[1] == bn), None)
         return B * cand[k][1][0] * math.ceil(Cout / bn) if k else 0
 
-    if DMA_PREFER_64:   # experiment (round 3): 64-pixel tiles — twice the workgroups per CU (TLP) at 1.5x the LDS bytes per MFMA
-        order = ([(64, 256, 6), (64, 256, 3)] if (full_cout and Cout > 128) else []) + [(64, 128, 3), (64, 128, 6), (64, 64, 6)]
-        for key in order:
-            if key in cand and (not full_cout or key[1] >= Cout):
-                i, (_, _, th, tw) = cand[key]
-                return i, th, tw
     if Cout > 128:   # (one tile over all 256 couts only where the epilogue needs them: post_pa / ssq_out — and the map is large enough)
         order = [(64, 256, 3), (64, 256, 6)] if full_cout and wgs(64, 256) >= 128 else []
         order += [(128, 128, 3), (128, 128, 6)] if wgs(128, 128) >= 256 else []
