@@ -184,7 +184,7 @@ constexpr int VBYTES2 = 64 * VSTR2;
 
 // MINW: waves per SIMD the register budget is capped for (4: two workgroups per CU; 2: one, no spills).  SUB: 64-key tiles per
 // workgroup barrier — a staging buffer holds SUB tiles, so with SUB = 2 the 8 waves meet half as often (counters of SUB = 1 on the
-// 1024-token site: 37 % of the wave cycles parked at s_waitcnt / s_barrier, tools/gpu_r2_y.sh).
+// 1024-token site: 37 % of the wave cycles parked at s_waitcnt / s_barrier, round-2 call gpu_r2_y.sh).
 template <int MINW, int SUB>
 __global__ __launch_bounds__(512, MINW) void attention_kernel_w8(const ImagenAttentionParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // 2 buffers x SUB tiles x (KBYTES2 + VBYTES2)

@@ -2,7 +2,7 @@
 //
 // Why: inside the denoiser step every launch runs a different kernel from its predecessor and the 20-70 KB of an igemm instantiation
 // were last executed a whole step (GBs of traffic) ago, so a launch starts with a chain of instruction-cache misses served from HBM
-// (tools/latency_probe.py --separate: +3 us per launch when the code is still in L2, several times that from HBM).  The kernels
+// (round-2 probe latency_probe.py --separate: +3 us per launch when the code is still in L2, several times that from HBM).  The kernels
 // therefore read their own code range as DATA once at start (one parallel round trip that fills the XCD's L2), which needs the
 // size of the function.  The HIP runtime has no query for it, so the symbol tables of the gfx950 code objects embedded in this shared
 // object (section .hip_fatbin: clang offload bundles, one per translation unit) are read once from the file on disk.

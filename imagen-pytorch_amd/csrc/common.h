@@ -33,11 +33,11 @@ static inline int imagen_hip_status(const char* what) {
 }
 
 // v_rcp_f32 (1 ulp) instead of the ~10-instruction IEEE division: the staging prologue of the C=32 layers is VALU-bound
-// (tools/igemm_probe.py ablations), and SiLU runs once per staged element.  exp2 with the log2(e) fold saves the v_mul of __expf.
+// (round-2 probe igemm_probe.py ablations), and SiLU runs once per staged element.  exp2 with the log2(e) fold saves the v_mul of __expf.
 __device__ __forceinline__ float silu_f(float v) { return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * v)); }
 // exact-erf GELU (nn.GELU default, ip.py:413) with erfc by Abramowitz & Stegun 7.1.26 (|error| <= 1.5e-7, far inside the fp16 output
 // rounding): libm's erff is ~60 instructions per element and was measured at 18k of the 27k cycles of a FeedForward GEMM's tile
-// (tools/insitu_trace.py, ff.lin1); this form is one v_rcp, one v_exp and seven multiply-adds
+// (round-2 probe insitu_trace.py, ff.lin1); this form is one v_rcp, one v_exp and seven multiply-adds
 __device__ __forceinline__ float gelu_f(float v) {
   const float x = fabsf(v) * 0.70710678118654752f;
   const float t = __builtin_amdgcn_rcpf(1.0f + 0.3275911f * x);
@@ -74,7 +74,7 @@ __device__ __forceinline__ void imagen_code_warm_sink(unsigned v) { asm volatile
 // its pixel (lanes l and l + 32 share the pixel), i.e. 8-byte pieces at 16-byte stride.  Quads q and q + 2 are exchanged between the
 // half-waves (v_permlane32_swap, one per dword): the lower half-wave then owns channels 8q .. 8q+7, the upper one 16+8q .. 16+8q+7 — one
 // 16-byte store per lane instead of two 8-byte ones (half the store instructions, twice the bytes per memory request; measured on
-// the streaming conv: 36.7 -> 32.0 us for 32->32 @256^2, tools/stream_probe.py).  Must be executed by ALL lanes of the wave.
+// the streaming conv: 36.7 -> 32.0 us for 32->32 @256^2, round-2 probe stream_probe.py).  Must be executed by ALL lanes of the wave.
 typedef unsigned imagen_u32x4 __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ imagen_u32x4 imagen_pair_quads(const f16x4& q_lo, const f16x4& q_hi) {
   const uint2 lo = __builtin_bit_cast(uint2, q_lo), hi = __builtin_bit_cast(uint2, q_hi);

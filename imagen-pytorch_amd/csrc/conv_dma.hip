@@ -232,7 +232,7 @@ __global__ __launch_bounds__(256, (MI * NI <= 2 ? 3 : 2)) void conv_dma_kernel(c
   // one 32-channel chunk = 9 taps x 2 K steps; PAR = chunk parity (halo buffer, fragment-set phase, and the ring phase when 9 % RW != 0).
   //
   // A wave is IN-ORDER: while an MFMA waits for the matrix pipe (32 cycles per 32x32x16) nothing behind it issues, so a step written
-  // as "all loads, then all MFMAs" overlaps its loads only with the LAST MFMA (tools/dma_probe.py: the MFMAs alone 17 us, everything
+  // as "all loads, then all MFMAs" overlaps its loads only with the LAST MFMA (round-2 probe dma_probe.py: the MFMAs alone 17 us, everything
   // else alone 12 us, together 25 us of a 31 us launch).  Each step is therefore issued as MFMA, a few fillers, MFMA, a few fillers
   // ...: the fragment reads of the step PF ahead first, then (first K step of a stage) the DMA pieces that refill the weight ring
   // and, at tap 0, the next chunk's halo tile — 2-3 single-issue instructions per 32-cycle MFMA slot, pinned with sched_barrier.

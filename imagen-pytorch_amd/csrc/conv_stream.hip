@@ -2,7 +2,7 @@
 // input) or 32 + 32 (the up path's concat of x and the skip connection), stride 1, pad 1, NHWC fp16 (Block, ip.py:671-691, at the
 // 256^2 / 128^2 levels of the README super-resolution unet and the 64^2 level of the base unet).
 //
-// Why it exists (profiles/r02_pmc_SQ_mfma_busy.json, tools/stream_probe.py): these layers move 134-201 MB per launch for 19-39 GFLOP —
+// Why it exists (profiles/r02_pmc_SQ_mfma_busy.json, round-2 probe stream_probe.py): these layers move 134-201 MB per launch for 19-39 GFLOP —
 // HBM-bound by a factor of five — yet ran at 0.11-0.35 of the HBM rate.  The wave-specialised kernel (igemm.hip) stages through
 // registers with four producer waves, six 16-byte items each per tile; the all-DMA kernel (conv_dma.hip) starts one workgroup per tile,
 // reloads the weights for every tile and has a single halo load in flight per workgroup.  Measured here (MI355X, batch 16, 256^2):
@@ -77,7 +77,7 @@ __device__ __forceinline__ void cs_wait_vm(int n) {   // s_waitcnt vmcnt(min(n, 
 
 // NCH: 32-channel inputs (1: x1 only; 2: x1 | x2).  PRO: Block prologue on the inputs.  GEN: generic epilogue (conv_epilogue.h).
 //
-// What bounds it (rocprofv3 SQ counters, tools/gpu_r2_y.sh; variants in the history of this file): every wave issues ~24 % of the time
+// What bounds it (rocprofv3 SQ counters, round-2 call gpu_r2_y.sh; variants in the history of this file): every wave issues ~24 % of the time
 // and a SIMD holds four of them — the SIMD's instruction issue is saturated.  Deeper prefetch (tile t+2 / t+3 staged in registers, or
 // the LDS buffer refilled right after the MFMA phase with hand-counted vmcnt waits) changed nothing; fewer instructions did.  Hence
 //   * the tile list is walked incrementally (no integer division per tile: (b, ty, tx) advance by the grid stride with two wrap checks);

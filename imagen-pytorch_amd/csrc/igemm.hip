@@ -679,7 +679,7 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
     };
     // ALL groups' operands are requested before the first one is used (4 + 2 MI registers per group): one memory round trip per
     // tile instead of one per channel quad — in the graph the res_conv launches (a 1x1 GEMM of 1-3 k-chunks behind this epilogue)
-    // cost 1.18 ms of a 10.5 ms step pair with the one-group-ahead form (tools/ablate_step.sh)
+    // cost 1.18 ms of a 10.5 ms step pair with the one-group-ahead form (round-2 probe ablate_step.sh)
     EpiOps E[4 * NI];
     // 16-byte pieces for the NHWC operands and outputs when the channel counts allow it (imagen_pair_quads: a lane's quads q and q + 2
     // against its half-wave partner's): half the memory instructions of the 8-byte form, each a full 16 bytes per lane
@@ -850,7 +850,7 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
   // Epilogue operands of the first tile (residual | gate * addend): touched NOW, one dword per pixel row of this wave's channel
   // fragment(s), so that the loads of the epilogue itself — dependent on nothing but issued after the last k step — find the lines
   // (and the page translations) in place: in the denoiser step those loads were measured at 7-12k cycles per tile
-  // (tools/insitu_trace.py: to_time_cond, ff.lin2, res_conv), most of a small GEMM's run time.
+  // (round-2 probe insitu_trace.py: to_time_cond, ff.lin2, res_conv), most of a small GEMM's run time.
   unsigned warm_ep = 0;
   if constexpr (GEN) {
     const f16* eop = addend ? addend + (size_t)tc.b * p.bs_add : (res ? res + (size_t)tc.b * p.bs_res : nullptr);

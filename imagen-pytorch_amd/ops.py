@@ -329,7 +329,7 @@ def pick_cfg(G: int, Cout: int, OH: int, OW: int, B: int, KH: int = 1, KW: int =
     """Choose (cfg, TH, TW).
 
     Family 2 (all-DMA kernel, conv_dma.hip) takes the prologue-free single-input stride-1 3x3 convs with 32-channel chunks (`raw`).
-    Family 0 (wave-specialised persistent kernel, igemm.hip) takes everything else, measured on MI355X (tools/igemm_probe.py
+    Family 0 (wave-specialised persistent kernel, igemm.hip) takes everything else, measured on MI355X (round-2 probe igemm_probe.py
     --sweep): the 64-pixel-per-wave tilings (MI <= 2) win everywhere, and when a layer has fewer workgroups than the chip has CUs
     the narrower output-channel tile (twice the workgroups) wins.  Preference order of (tile pixels, tile couts):
       Cout <= 32 : 256x32 when that still gives >= 1024 workgroups, else 128x32

@@ -1,5 +1,5 @@
 """MI355X tests of the Imagen-Video path (SURVEY.md §8(f) NEXT-2).  Default-on since round 2 (first GPU run: gpurun_out of
-tools/r02_calls/gpu_r2_a.sh — both temporal kernels, the Unet3D forward and the two video samplers passed as written; the one failure was
+round-2 call gpu_r2_a.sh — both temporal kernels, the Unet3D forward and the two video samplers passed as written; the one failure was
 this file's own view-pattern test reading its outputs before the plan had run).  IMAGEN_VIDEO_GPU_TESTS=0 switches the file off.
 
 The kernel tests compare the HIP ops with tests/plan_interp.py's restatement of their contract (include/imagen_hip.h); the model

@@ -1,6 +1,6 @@
 """In-GRAPH per-op timing of the denoiser steps: a rocprofv3 kernel trace of a short sampling run joined with the plan's op labels.
 
-Event-timed eager launches (tools/step_profile.py) carry the event records' own cost and run every kernel cold behind an idle queue;
+Event-timed eager launches (round-2 probe step_profile.py) carry the event records' own cost and run every kernel cold behind an idle queue;
 the hipGraph replays of the real run do not.  This tool takes the dispatch timestamps of the replays themselves:
 
     cd /tmp && export TMPDIR=/tmp
