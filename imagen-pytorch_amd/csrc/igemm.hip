@@ -985,6 +985,10 @@ int launch_cfg(const ImagenIgemmParams& p, hipStream_t s) {
   }
   if (G == 8 && ks == 4) return launch_ksc<MI, NI, WM, WN, G, (G == 8 ? 4 : 0)>(p, s);
   if (G == 16 && ks == 8) return launch_ksc<MI, NI, WM, WN, G, (G == 16 ? 8 : 0)>(p, s);
+  // the 15x15 CrossEmbed window over the 8-channel packed image (init_conv, ip.py:1051-1076): 113 K=16 steps in ONE chunk.  The generic
+  // loop looks a single step ahead for its weight fragment (an L2 round trip per step: 190 us at 256^2, 8x its MFMA time); unrolled, the
+  // ring runs 6-8 steps ahead like every other layer's
+  if (G == 1 && ks == 113) return launch_ksc<MI, NI, WM, WN, G, (G == 1 ? 113 : 0)>(p, s);
   return launch_ksc<MI, NI, WM, WN, G, 0>(p, s);
 }
 
@@ -1061,6 +1065,7 @@ static constexpr int ksc_of(int G, int ks) {   // the launch_cfg dispatch, as a 
   if (G == 4 && (ks == 18 || ks == 2 || ks == 8)) return ks;
   if (G == 8 && ks == 4) return ks;
   if (G == 16 && ks == 8) return ks;
+  if (G == 1 && ks == 113) return ks;
   return 0;
 }
 

@@ -279,7 +279,12 @@ class ElucidatedImagen(Imagen):
                 if R:
                     st['noise_renoise'].zero_()
             init_state()
-            st['plan'].run()                                 # warm-up outside capture (kernel attributes), then rewind
+            # warm-up outside capture (kernel attributes), then rewind.  Both plans run from table row 0: `plan` advances the device
+            # step counter by its two evaluations, and started from the last timestep's rows (skip_steps = T - 1) `last` would read past
+            # the 2T-row tables (the kernels do not clamp *step_ptr) and `plan` would feed the all-zero final row into CFG_X0
+            st['step_ptr'].zero_()
+            st['plan'].run()
+            st['step_ptr'].zero_()
             st['last'].run()
             torch.cuda.synchronize()
             st['graph'] = ops.Graph(st['plan'], stream)

@@ -193,6 +193,13 @@ class Imagen(nn.Module):
         self._mode_depth = 0
         self._call_counter = 0
 
+    def _next_seed(self) -> int:
+        """Derived Philox key of a call without `seed=`: distinct per call, also when lanes call concurrently (the counter is locked)."""
+        with self._mode_lock:
+            self._call_counter += 1
+            c = self._call_counter
+        return (int(torch.initial_seed()) * 1000003 + c) & ((1 << 62) - 1)
+
     # ---- device bookkeeping (API parity; weights stay resident as packed copies, nothing is shuffled over PCIe) ----
     @property
     def device(self):
@@ -270,8 +277,7 @@ class Imagen(nn.Module):
         for b in batches:
             kw = {**common, **b}
             if kw.get('seed') is None:                   # the seed must be the same for every stage of a batch (as in one sample() call)
-                self._call_counter += 1
-                kw['seed'] = (int(torch.initial_seed()) * 1000003 + self._call_counter) & ((1 << 62) - 1)
+                kw['seed'] = self._next_seed()
             kw.setdefault('use_tqdm', False)
             jobs.append(kw)
         if n_stages == 1 or len(jobs) == 0:
@@ -324,9 +330,12 @@ class Imagen(nn.Module):
         """`_build_stage` under the construction lock; a NEW stage's packing kernels (weights shared with the other lanes) have
         completed before the stage becomes visible."""
         with self._build_lock:
-            n = len(self._stages)
+            before = {k: id(v) for k, v in self._stages.items()}
             st = self._build_stage(*args, **kwargs)
-            if len(self._stages) != n and torch.cuda.is_available():
+            # a stage was constructed (new key, or a stale one rebuilt under its old key after a weight swap): its packing work runs on
+            # THIS lane's stream and the packed weights are shared, so it must be complete before another lane can see the stage
+            built = any(before.get(k) != id(v) for k, v in self._stages.items())
+            if built and torch.cuda.is_available():
                 torch.cuda.current_stream().synchronize()
             return st
 
@@ -743,8 +752,7 @@ class Imagen(nn.Module):
         level = lowres_sample_noise_level if lowres_sample_noise_level is not None else self.lowres_sample_noise_level
         cond_scale = _cast_tuple(cond_scale, num_unets)
         if seed is None:
-            self._call_counter += 1
-            seed = (int(torch.initial_seed()) * 1000003 + self._call_counter) & ((1 << 62) - 1)
+            seed = self._next_seed()
 
         img = None
         if start_at_unet_number > 1:
