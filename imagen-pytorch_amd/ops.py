@@ -373,6 +373,40 @@ def pick_cfg(G: int, Cout: int, OH: int, OW: int, B: int, KH: int = 1, KW: int =
     raise ValueError(f"no igemm tile configuration for G={G} Cout={Cout} {OH}x{OW} k{KH}x{KW} s{stride}")
 
 
+# Measured tile choices (tools/cfg_sweep.py: every candidate configuration of a layer class timed IN the sampling loop on MI355X, one class
+# at a time) that replace the rules of pick_cfg for the layer classes they name: {layer_key: [cfg, TH, TW]}, loaded from tuned_cfgs.json
+# beside this file when it exists.  A pick that is not launchable for the call at hand is ignored (the rules apply).
+CFG_OVERRIDE: dict = {}
+
+
+def layer_key(Cin: int, Cout: int, K: int, stride: int, OH: int, OW: int, B: int, pro: bool) -> str:
+    return f"{Cin}->{Cout} k{K} s{stride} @{OH}x{OW} B{B} {'pro' if pro else 'raw'}"
+
+
+def _load_tuned():
+    import json
+    path = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tuned_cfgs.json")
+    if _os.path.exists(path) and _os.environ.get("IMAGEN_TUNED_CFGS", "1") != "0":
+        try:
+            CFG_OVERRIDE.update({k: tuple(v) for k, v in json.load(open(path)).get("picks", {}).items()})
+        except (OSError, ValueError):
+            pass
+
+
+_load_tuned()
+
+
+def _override_ok(ov, G: int, OH: int, OW: int, KH: int, KW: int, stride: int, raw: bool) -> bool:
+    cid, th, tw = ov
+    tab = cfg_table()
+    if not (0 <= cid < len(tab)) or tab[cid][2] != G:
+        return False
+    fam = tab[cid][3]
+    if fam == 3 or (fam == 2 and not (raw and KH == 3 and KW == 3 and stride == 1 and G == 4)):
+        return False
+    return any((th, tw) == (a, b) for _, _, a, b in launchable_shapes(cid, OH, OW, KH, KW, stride))
+
+
 def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None, mu=None, rs=None, pa=None, ps=None,
           pstride: int = 0, act_in: int = ACT_NONE, act_out: int = ACT_NONE, addend: Optional[Act] = None, gate=None,
           res: Optional[Act] = None, out_mode: int = OUT_NHWC, stride: int = 1, pad: Optional[int] = None,
@@ -404,6 +438,12 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
     if cfg is None:
         raw = (x2 is None and mu is None and rs is None and pa is None and ps is None and ssq_a is None and act_in == ACT_NONE
                and x1.C % 32 == 0 and pw.Cin_pad == x1.C and x1.ld % 8 == 0)
+        if CFG_OVERRIDE:
+            no_pro_any = mu is None and rs is None and pa is None and ps is None and ssq_a is None and act_in == ACT_NONE
+            ov = CFG_OVERRIDE.get(layer_key(x1.C + C2, pw.Cout, KH, stride, OH, OW, x1.B, not no_pro_any))
+            if ov is not None and _override_ok(ov, pw.G, OH, OW, KH, KW, stride, raw):
+                cfg = tuple(ov)
+    if cfg is None:
         cfg = pick_cfg(pw.G, pw.Cout, OH, OW, x1.B, KH, KW, stride,
                        full_cout=(ssq_out is not None or post is not None or want_gca) and out_mode == OUT_NHWC, raw=raw)
     cid, th, tw = cfg
