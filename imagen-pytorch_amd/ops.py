@@ -377,6 +377,10 @@ def pick_cfg(G: int, Cout: int, OH: int, OW: int, B: int, KH: int = 1, KW: int =
 # at a time) that replace the rules of pick_cfg for the layer classes they name: {layer_key: [cfg, TH, TW]}, loaded from tuned_cfgs.json
 # beside this file when it exists.  A pick that is not launchable for the call at hand is ignored (the rules apply).
 CFG_OVERRIDE: dict = {}
+# timing ablations for tools/r03_calls/call_g.sh ONLY (results are garbage): ImagenIgemmParams.dbg bits (2 = no consumer compute, 8 = no
+# stores) / no prologue arithmetic.  Unset in production.
+_ABLATE_DBG = int(_os.environ.get("IMAGEN_ABLATE_IGEMM_DBG", "0"))
+_ABLATE_PROLOGUE = _os.environ.get("IMAGEN_ABLATE_PROLOGUE") == "1"
 
 
 def layer_key(Cin: int, Cout: int, K: int, stride: int, OH: int, OW: int, B: int, pro: bool) -> str:
@@ -416,6 +420,9 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
     ssq_out: emit the per-pixel sum of squares of the output — honoured only when the chosen tile covers all Cout
     (`p.ssq_emitted` tells the caller, who otherwise falls back to a ROWSTAT op)."""
     """Append one implicit-GEMM launch.  y: Act (NHWC / pixel-shuffle target) or fp32 NCHW tensor (OUT_NCHW_F32)."""
+    if _ABLATE_PROLOGUE and pw.KH == 3:
+        mu = rs = pa = ps = ssq_a = ssq_b = None
+        act_in = ACT_NONE
     KH, KW = pw.KH, pw.KW
     if pad is None:
         pad = (KH - 1) // 2 if stride == 1 else 0
@@ -483,6 +490,8 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
         p.y, p.ldy, p.bsy = y.ptr, y.ld, y.bs
         keep.append(y.t)
     p.TH, p.TW, p.cfg = th, tw, cid
+    if _ABLATE_DBG:
+        p.dbg = _ABLATE_DBG
     if ssq_a is not None:
         p.ssq_a, p.ssq_b, p.ssq_wb = ssq_a.data_ptr(), ptr(ssq_b), ssq_wb
         keep += [ssq_a, ssq_b]
