@@ -208,20 +208,10 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
       unsigned mask;
       int b, chunk;                         // phase identity (for the affine load that follows one phase later)
     };
-    // NS register sets: the loads of phase q+NS-1 are in flight while phase q+1 is transformed.  With two sets a load has ONE phase
-    // period to arrive (issued in iteration q-1, consumed in iteration q): the phase period of a workgroup cannot drop below the memory
-    // latency under load — round 3's ablation (call G) took ALL consumer work out of these kernels and the step lost only 17 % of the
-    // family's time: the producers' round trips, not the MFMAs, set the pace.  Three sets (where the set is small: <= 3 items per
-    // thread) give every load two periods.  The per-chunk affine then needs two register copies, requested one iteration AHEAD of the
-    // set that follows it in the queue: vmcnt retires in order, so waiting for an affine issued after a set would drain that set too.
-#ifdef IGEMM_FORCE_NS2
-    constexpr int NS = 2;
-#else
-    constexpr int NS = kMaxItems <= 3 ? 3 : 2;
-#endif
-    StageSet S[NS];                          // (static indices only)
-    struct Affine { float4 a0, a1, s0, s1; };
-    Affine aff[2];                           // affine of phase j in aff[j & 1]
+    // (Three sets — every load two phase periods in flight, the affine requested an iteration ahead in two register copies — were
+    // measured in round 3's call H: +1.4 % per step pair.  The phase period is not set by the load latency.)
+    StageSet A, B;
+    float4 st_a0, st_a1, st_s0, st_s1;      // affine of the phase about to be written (shared by both sets)
 
     // phase cursor: (tl, chunk) is the phase whose loads are issued next; past the end it stays on the last phase (harmless re-loads)
     TileCoord tl = decode(t_cursor);
@@ -241,6 +231,14 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
       S.mask = 0;
       S.b = tl.b;
       S.chunk = chunk;
+      if (p.dbg & 16) {         // (timing ablation: no loads)
+        static_for<kMaxItems>([&](auto ic) __attribute__((always_inline)) {
+          S.raw[decltype(ic)::value] = make_uint4(0, 0, 0, 0);
+          S.q1[decltype(ic)::value] = 1.0f;
+          S.q2[decltype(ic)::value] = 0.0f;
+        });
+        return;
+      }
       const int b = tl.b;
       const int iy0 = tl.oy0 * p.stride - p.pad, ix0 = tl.ox0 * p.stride - p.pad;
       const int cc = chunk * KC + my_cg * 8;
@@ -266,14 +264,14 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
         S.q2[it] = q2_base[sp * q2_on];
       });
     };
-    auto load_affine = [&](const StageSet& S, Affine& A) __attribute__((always_inline)) {
+    auto load_affine = [&](const StageSet& S) __attribute__((always_inline)) {
       const int o = S.b * p.pstride + S.chunk * KC + my_cg * 8;
       const float4* qa = reinterpret_cast<const float4*>(pa_base + o * pa_on);
       const float4* qs = reinterpret_cast<const float4*>(ps_base + o * ps_on);
-      A.a0 = qa[0];
-      A.a1 = qa[1];
-      A.s0 = qs[0];
-      A.s1 = qs[1];
+      st_a0 = qa[0];
+      st_a1 = qa[1];
+      st_s0 = qs[0];
+      st_s1 = qs[1];
     };
 
     // transform + LDS write of a staged set
@@ -284,7 +282,8 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
     char* lds_dummy = smem + 2 * buf_bytes + (4 * PXW + kBiasLds) * (int)sizeof(float);
     const bool use_rs = p.rs != nullptr, use_ssq = !use_rs && p.ssq_a != nullptr, use_ssqb = use_ssq && p.ssq_b != nullptr;
     const bool use_mu = p.mu != nullptr, use_silu = p.act_in == IMAGEN_ACT_SILU;
-    auto write_set = [&](const StageSet& S, char* buf, const Affine& A) __attribute__((always_inline)) {
+    auto write_set = [&](const StageSet& S, char* buf) __attribute__((always_inline)) {
+      if (p.dbg & 1) return;    // (timing ablation)
       if (raw_copy) {   // input already activated by its producer (post_pa epilogue) or a plain GEMM operand: zero-fill only
         static_for<kMaxItems>([&](auto ic) __attribute__((always_inline)) {
           constexpr int it = decltype(ic)::value;
@@ -295,8 +294,8 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
         });
         return;
       }
-      const float a[8] = {A.a0.x, A.a0.y, A.a0.z, A.a0.w, A.a1.x, A.a1.y, A.a1.z, A.a1.w};
-      const float s[8] = {A.s0.x, A.s0.y, A.s0.z, A.s0.w, A.s1.x, A.s1.y, A.s1.z, A.s1.w};
+      const float a[8] = {st_a0.x, st_a0.y, st_a0.z, st_a0.w, st_a1.x, st_a1.y, st_a1.z, st_a1.w};
+      const float s[8] = {st_s0.x, st_s0.y, st_s0.z, st_s0.w, st_s1.x, st_s1.y, st_s1.z, st_s1.w};
       static_for<kMaxItems>([&](auto ic) __attribute__((always_inline)) {
         constexpr int it = decltype(ic)::value;
         const int idx = rtid + it * 256;
@@ -338,58 +337,29 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
     };
     // (the cursor is advanced AFTER the transform: the scalar control flow of advance()/decode() between a set's loads and the
     // other set's first use makes the compiler's vmcnt bookkeeping fall back to a full drain)
-    if constexpr (NS == 2) {
-      load_set(S[0]);                    // phase 0
-      load_affine(S[0], aff[0]);
+    load_set(A);            // phase 0
+    load_affine(A);
+    advance();
+    load_set(B);            // phase 1
+    write_set(A, buf0);     // waits for A and the affine; B stays in flight
+    load_affine(B);
+    advance();
+    lds_barrier();          // phase 0 is in buffer 0
+    imagen_code_warm_sink(warm);
+    for (int q = 0; q < n_phases; q += 2) {
+      // consumers: phase q out of buf0
+      load_set(A);          // phase q+2
+      write_set(B, buf1);   // phase q+1
+      load_affine(A);
       advance();
-      load_set(S[1]);                    // phase 1
-      write_set(S[0], buf0, aff[0]);     // waits for set 0 and the affine; set 1 stays in flight
-      load_affine(S[1], aff[1]);
+      phase_end();
+      if (q + 1 >= n_phases) break;
+      // consumers: phase q+1 out of buf1
+      load_set(B);          // phase q+3
+      write_set(A, buf0);   // phase q+2
+      load_affine(B);
       advance();
-      lds_barrier();                     // phase 0 is in buffer 0
-      imagen_code_warm_sink(warm);
-      for (int q = 0; q < n_phases; q += 2) {
-        // consumers: phase q out of buf0
-        load_set(S[0]);                  // phase q+2
-        write_set(S[1], buf1, aff[1]);   // phase q+1
-        load_affine(S[0], aff[0]);
-        advance();
-        phase_end();
-        if (q + 1 >= n_phases) break;
-        // consumers: phase q+1 out of buf1
-        load_set(S[1]);                  // phase q+3
-        write_set(S[0], buf0, aff[0]);   // phase q+2
-        load_affine(S[1], aff[1]);
-        advance();
-        phase_end();
-      }
-    } else {
-      // phase j lives in set j % 3, its affine in aff[j & 1].  Iteration q (consumers on phase q): request the affine of phase q+2, then
-      // the set of phase q+3, then transform + write phase q+1 — whose set was requested two iterations ago and whose affine one
-      // iteration ago, AHEAD of set q+2 in the queue (so the wait for it leaves sets q+2 and q+3 in flight).
-      load_set(S[0]);                    // phase 0
-      load_affine(S[0], aff[0]);
-      advance();
-      load_set(S[1]);                    // phase 1
-      load_affine(S[1], aff[1]);
-      advance();
-      load_set(S[2]);                    // phase 2
-      write_set(S[0], buf0, aff[0]);
-      advance();
-      lds_barrier();                     // phase 0 is in buffer 0
-      imagen_code_warm_sink(warm);
-      for (int q0 = 0; q0 < n_phases; q0 += 6) {
-        static_for<6>([&](auto uc) __attribute__((always_inline)) {
-          constexpr int u = decltype(uc)::value;
-          if (q0 + u < n_phases) {       // (workgroup-uniform)
-            load_affine(S[(u + 2) % 3], aff[u & 1]);            // phase q+2 (its set is already under way: b / chunk are known)
-            load_set(S[u % 3]);                                  // phase q+3
-            write_set(S[(u + 1) % 3], (u & 1) ? buf0 : buf1, aff[(u + 1) & 1]);   // phase q+1
-            advance();
-            phase_end();
-          }
-        });
-      }
+      phase_end();
     }
     return;
   }
