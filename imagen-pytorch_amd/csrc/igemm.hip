@@ -25,6 +25,7 @@ struct TileCfg { int MI, NI, WM, WN, G; };
 // 16-byte staging items per producer thread and phase, by tile pixels / k-chunk depth / kernel footprint: the producers hold
 // TWO such register sets, so the count is kept as small as the instantiation's use allows (the host asks
 // imagen_igemm_stage_slots() and only picks tile shapes that fit)
+constexpr int kTouchSink = 256;  // LDS bytes behind the staging dummy that the producers' operand-touch loads land in (never read)
 constexpr int kBiasLds = 1024;   // output channels whose bias the consumers keep in LDS (larger layers load it per channel quad)
 
 constexpr int stage_slots(int TP, int G, int KSC) {
@@ -227,18 +228,43 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
       }
     };
 
+    // Epilogue operands (gate * addend | residual, GEN kernels): the consumers fetch them in the epilogue of a tile — one DEPENDENT round
+    // trip per tile, and round 3's ablation (call J) found it to be most of a res_conv launch: with no producer work, no MFMAs and no
+    // stores a [64->32 k1 @256^2] launch still took 47 of its 75 us.  The consumers cannot prefetch (their loads retire in order with
+    // the weight ring), the producers can: with the first chunk of a tile they touch every 128-byte line of that tile's operand rows —
+    // a direct-to-LDS load into a sink nobody reads, no VGPR, nothing ever waits for it — so the consumers' loads find them in L2.
+    char* lds_dummy = smem + 2 * buf_bytes + (4 * PXW + kBiasLds) * (int)sizeof(float);   // 16 bytes for out-of-tile staging slots, then the touch sink
+    const f16* eop_base = nullptr;
+    int eop_ld = 0, eop_bs = 0;
+    if constexpr (GEN) {
+      eop_base = p.addend ? reinterpret_cast<const f16*>(p.addend) : reinterpret_cast<const f16*>(p.res);
+      eop_ld = p.addend ? p.ld_add : p.ld_res;
+      eop_bs = p.addend ? p.bs_add : p.bs_res;
+    }
+    const int tw_shift = __builtin_ctz(p.TW);
+    auto touch_operands = [&]() __attribute__((always_inline)) {
+#if !defined(IMAGEN_EMUL) && !defined(IGEMM_NO_TOUCH)   // (a cache warm-up: nothing to emulate; IGEMM_NO_TOUCH: the A/B build of call K)
+      if constexpr (GEN) {
+        if (eop_base != nullptr && chunk == 0 && p.out_mode == IMAGEN_OUT_NHWC) {   // (workgroup-uniform)
+          constexpr int TPX = 32 * MI * WM;
+          const int lines = (min(BN, p.Cout - tl.n0) * 2 + 127) >> 7;          // 128-byte lines per pixel row of this cout tile
+          const unsigned sink = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)(lds_dummy + 16));
+          for (int i = rtid; i < TPX * lines; i += 256) {
+            const int tp = i % TPX, ln = i / TPX;
+            const int oy = tl.oy0 + (tp >> tw_shift), ox = tl.ox0 + (tp & (p.TW - 1));
+            if (oy < p.OH && ox < p.OW) {
+              const f16* a = eop_base + (size_t)tl.b * eop_bs + (size_t)(oy * p.OW + ox) * eop_ld + tl.n0 + ln * 64;
+              asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(a), "s"(sink) : "memory");
+            }
+          }
+        }
+      }
+#endif
+    };
     auto load_set = [&](StageSet& S) __attribute__((always_inline)) {
       S.mask = 0;
       S.b = tl.b;
       S.chunk = chunk;
-      if (p.dbg & 16) {         // (timing ablation: no loads)
-        static_for<kMaxItems>([&](auto ic) __attribute__((always_inline)) {
-          S.raw[decltype(ic)::value] = make_uint4(0, 0, 0, 0);
-          S.q1[decltype(ic)::value] = 1.0f;
-          S.q2[decltype(ic)::value] = 0.0f;
-        });
-        return;
-      }
       const int b = tl.b;
       const int iy0 = tl.oy0 * p.stride - p.pad, ix0 = tl.ox0 * p.stride - p.pad;
       const int cc = chunk * KC + my_cg * 8;
@@ -263,6 +289,9 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
         S.q1[it] = q1_base[sp * q1_on];
         S.q2[it] = q2_base[sp * q2_on];
       });
+      // (right BEHIND the set's loads: the compiler does not count the asm loads, so its next vmcnt(N) also retires them — as old as
+      // the set it is waiting for, they have arrived with it; issued ahead of a set they would stall that wait by a whole round trip)
+      touch_operands();
     };
     auto load_affine = [&](const StageSet& S) __attribute__((always_inline)) {
       const int o = S.b * p.pstride + S.chunk * KC + my_cg * 8;
@@ -279,11 +308,9 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
     // ~10 cycles per instruction), so the items of a set must be interleaved by the scheduler, which stops at every branch.
     // Mode choices (rs | ssq | none, mu, activation) are uniform selects; out-of-image items are zeroed by a select; slots beyond
     // the tile write to a 16-byte dummy behind the epilogue scratch.
-    char* lds_dummy = smem + 2 * buf_bytes + (4 * PXW + kBiasLds) * (int)sizeof(float);
     const bool use_rs = p.rs != nullptr, use_ssq = !use_rs && p.ssq_a != nullptr, use_ssqb = use_ssq && p.ssq_b != nullptr;
     const bool use_mu = p.mu != nullptr, use_silu = p.act_in == IMAGEN_ACT_SILU;
     auto write_set = [&](const StageSet& S, char* buf) __attribute__((always_inline)) {
-      if (p.dbg & 1) return;    // (timing ablation)
       if (raw_copy) {   // input already activated by its producer (post_pa epilogue) or a plain GEMM operand: zero-fill only
         static_for<kMaxItems>([&](auto ic) __attribute__((always_inline)) {
           constexpr int it = decltype(ic)::value;
@@ -940,7 +967,7 @@ int launch_gen(const ImagenIgemmParams& p, hipStream_t s) {
   IMAGEN_CHECK(!(p.addend && p.res), "igemm: addend and residual are mutually exclusive");
   IMAGEN_CHECK(!p.ssq_out || (p.out_mode == IMAGEN_OUT_NHWC && p.Cout <= BN),
                "igemm: ssq_out needs NHWC output and one workgroup covering all %d output channels (tile has %d)", p.Cout, BN);
-  const size_t lds = (size_t)2 * IT * Geo<G>::PS + (size_t)(4 * 32 * MI + kBiasLds) * sizeof(float) + 16;   // staging double buffer + epilogue scratch + bias + dummy
+  const size_t lds = (size_t)2 * IT * Geo<G>::PS + (size_t)(4 * 32 * MI + kBiasLds) * sizeof(float) + 16 + kTouchSink;   // staging double buffer + epilogue scratch + bias + dummy + touch sink
   IMAGEN_CHECK(lds <= 160 * 1024, "igemm: LDS tile %zu bytes too large", lds);
   auto kern = igemm_kernel<MI, NI, WM, WN, G, KSC, GEN>;
   static bool attr_done[16] = {};   // the attribute is per DEVICE (a process may sample on several GPUs)
@@ -1097,7 +1124,7 @@ extern "C" long imagen_igemm_lds_bytes(int cfg, int KH, int KW, int stride, int 
   const int IT = ((TH - 1) * stride + KH) * ((TW - 1) * stride + KW);
   if (IT * c.G > imagen_igemm_stage_slots(cfg, KH, KW) * 256) return -1;
   const long PS = c.G == 1 ? 16 : c.G * 16 + 16;
-  const long lds = 2 * IT * PS + (long)(4 * 32 * c.MI + kBiasLds) * (long)sizeof(float) + 16;
+  const long lds = 2 * IT * PS + (long)(4 * 32 * c.MI + kBiasLds) * (long)sizeof(float) + 16 + kTouchSink;
   return lds <= 160 * 1024 ? lds : -1;
 }
 
