@@ -25,7 +25,6 @@ struct TileCfg { int MI, NI, WM, WN, G; };
 // 16-byte staging items per producer thread and phase, by tile pixels / k-chunk depth / kernel footprint: the producers hold
 // TWO such register sets, so the count is kept as small as the instantiation's use allows (the host asks
 // imagen_igemm_stage_slots() and only picks tile shapes that fit)
-constexpr int kTouchSink = 256;  // LDS bytes behind the staging dummy that the producers' operand-touch loads land in (never read)
 constexpr int kBiasLds = 1024;   // output channels whose bias the consumers keep in LDS (larger layers load it per channel quad)
 
 constexpr int stage_slots(int TP, int G, int KSC) {
@@ -228,39 +227,11 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
       }
     };
 
-    // Epilogue operands (gate * addend | residual, GEN kernels): the consumers fetch them in the epilogue of a tile — one DEPENDENT round
-    // trip per tile, and round 3's ablation (call J) found it to be most of a res_conv launch: with no producer work, no MFMAs and no
-    // stores a [64->32 k1 @256^2] launch still took 47 of its 75 us.  The consumers cannot prefetch (their loads retire in order with
-    // the weight ring), the producers can: with the first chunk of a tile they touch every 128-byte line of that tile's operand rows —
-    // a direct-to-LDS load into a sink nobody reads, no VGPR, nothing ever waits for it — so the consumers' loads find them in L2.
-    char* lds_dummy = smem + 2 * buf_bytes + (4 * PXW + kBiasLds) * (int)sizeof(float);   // 16 bytes for out-of-tile staging slots, then the touch sink
-    const f16* eop_base = nullptr;
-    int eop_ld = 0, eop_bs = 0;
-    if constexpr (GEN) {
-      eop_base = p.addend ? reinterpret_cast<const f16*>(p.addend) : reinterpret_cast<const f16*>(p.res);
-      eop_ld = p.addend ? p.ld_add : p.ld_res;
-      eop_bs = p.addend ? p.bs_add : p.bs_res;
-    }
-    const int tw_shift = __builtin_ctz(p.TW);
-    auto touch_operands = [&]() __attribute__((always_inline)) {
-#if !defined(IMAGEN_EMUL) && !defined(IGEMM_NO_TOUCH)   // (a cache warm-up: nothing to emulate; IGEMM_NO_TOUCH: the A/B build of call K)
-      if constexpr (GEN) {
-        if (eop_base != nullptr && chunk == 0 && p.out_mode == IMAGEN_OUT_NHWC) {   // (workgroup-uniform)
-          constexpr int TPX = 32 * MI * WM;
-          const int lines = (min(BN, p.Cout - tl.n0) * 2 + 127) >> 7;          // 128-byte lines per pixel row of this cout tile
-          const unsigned sink = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) char*)(lds_dummy + 16));
-          for (int i = rtid; i < TPX * lines; i += 256) {
-            const int tp = i % TPX, ln = i / TPX;
-            const int oy = tl.oy0 + (tp >> tw_shift), ox = tl.ox0 + (tp & (p.TW - 1));
-            if (oy < p.OH && ox < p.OW) {
-              const f16* a = eop_base + (size_t)tl.b * eop_bs + (size_t)(oy * p.OW + ox) * eop_ld + tl.n0 + ln * 64;
-              asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(a), "s"(sink) : "memory");
-            }
-          }
-        }
-      }
-#endif
-    };
+    // (Round 3, calls J / K: with no producer work, no MFMAs and no stores a res_conv launch keeps 60-67 % of its time — the per-tile
+    // skeleton of barriers + the generic epilogue.  Having the producers touch the next tile's gate * addend rows into L2 changed
+    // nothing (9.397 vs 9.377 ms per step pair): those operands are L2 hits already; what is left is the epilogue's own instruction
+    // stream and its one dependent round trip per tile.)
+    char* lds_dummy = smem + 2 * buf_bytes + (4 * PXW + kBiasLds) * (int)sizeof(float);
     auto load_set = [&](StageSet& S) __attribute__((always_inline)) {
       S.mask = 0;
       S.b = tl.b;
@@ -289,9 +260,6 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
         S.q1[it] = q1_base[sp * q1_on];
         S.q2[it] = q2_base[sp * q2_on];
       });
-      // (right BEHIND the set's loads: the compiler does not count the asm loads, so its next vmcnt(N) also retires them — as old as
-      // the set it is waiting for, they have arrived with it; issued ahead of a set they would stall that wait by a whole round trip)
-      touch_operands();
     };
     auto load_affine = [&](const StageSet& S) __attribute__((always_inline)) {
       const int o = S.b * p.pstride + S.chunk * KC + my_cg * 8;
@@ -725,6 +693,9 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
     const int eld = addend ? p.ld_add : p.ld_res;
     const bool wide = p.out_mode == IMAGEN_OUT_NHWC && ((p.Cout | p.ldy | eld) & 7) == 0 && (p.bsy & 7) == 0 &&
                       (((size_t)p.y | (size_t)eop) & 15) == 0 && !(p.dbg & 256);
+    // pixel-shuffle outputs in 16-byte pieces too: 8 consecutive packed couts (s1, s2, c) share their sub-pixel when Cout / 4 is a multiple of 8
+    const bool wide_ps = p.out_mode == IMAGEN_OUT_PIXEL_SHUFFLE && (p.Cout & 31) == 0 && (p.ldy & 7) == 0 && (p.bsy & 7) == 0 &&
+                         ((size_t)p.y & 15) == 0 && !(p.dbg & 256);
     if (wide && eop) {
       imagen_u32x4 raw[NI][2][MI];
 #pragma unroll
@@ -823,6 +794,23 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
           for (int mi = 0; mi < MI; ++mi) {
             const imagen_u32x4 v = imagen_pair_quads(outv[ni][qp][mi], outv[ni][qp + 2][mi]);
             if (cx < p.Cout && op[mi] >= 0 && !(p.dbg & 8)) *reinterpret_cast<imagen_u32x4*>(y + (size_t)op[mi] * p.ldy + cx) = v;
+          }
+        }
+    } else if (wide_ps) {
+      f16* y = reinterpret_cast<f16*>(p.y) + (size_t)b * p.bsy;
+      const int Cq = p.Cout >> 2;
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int qp = 0; qp < 2; ++qp) {
+          const int cx = n0 + (wn * NI + ni) * 32 + 8 * qp + 16 * half;     // 8 consecutive packed couts of one sub-pixel
+          const int sub = cx / Cq, c = cx - sub * Cq;
+#pragma unroll
+          for (int mi = 0; mi < MI; ++mi) {
+            const imagen_u32x4 v = imagen_pair_quads(outv[ni][qp][mi], outv[ni][qp + 2][mi]);
+            const int oy = tc.oy0 + pix_y[mi], ox = tc.ox0 + pix_x[mi];
+            const int yy = 2 * oy + (sub >> 1), xx = 2 * ox + (sub & 1);
+            if (cx < p.Cout && op[mi] >= 0) *reinterpret_cast<imagen_u32x4*>(y + ((size_t)yy * (2 * p.OW) + xx) * p.ldy + c) = v;
           }
         }
     } else if (p.out_mode != IMAGEN_OUT_NCHW_F32) {
@@ -967,7 +955,7 @@ int launch_gen(const ImagenIgemmParams& p, hipStream_t s) {
   IMAGEN_CHECK(!(p.addend && p.res), "igemm: addend and residual are mutually exclusive");
   IMAGEN_CHECK(!p.ssq_out || (p.out_mode == IMAGEN_OUT_NHWC && p.Cout <= BN),
                "igemm: ssq_out needs NHWC output and one workgroup covering all %d output channels (tile has %d)", p.Cout, BN);
-  const size_t lds = (size_t)2 * IT * Geo<G>::PS + (size_t)(4 * 32 * MI + kBiasLds) * sizeof(float) + 16 + kTouchSink;   // staging double buffer + epilogue scratch + bias + dummy + touch sink
+  const size_t lds = (size_t)2 * IT * Geo<G>::PS + (size_t)(4 * 32 * MI + kBiasLds) * sizeof(float) + 16;   // staging double buffer + epilogue scratch + bias + dummy
   IMAGEN_CHECK(lds <= 160 * 1024, "igemm: LDS tile %zu bytes too large", lds);
   auto kern = igemm_kernel<MI, NI, WM, WN, G, KSC, GEN>;
   static bool attr_done[16] = {};   // the attribute is per DEVICE (a process may sample on several GPUs)
@@ -1045,7 +1033,13 @@ int imagen_conv_stream_config_info(int idx, int* tile_pixels, int* tile_cout, in
 long imagen_conv_stream_lds_bytes(int idx, int KH, int KW, int TH, int TW);
 int launch_conv_stream(const ImagenIgemmParams* p, int idx, hipStream_t s);
 static inline int cfg_base_stream() { return cfg_base_dma() + imagen_conv_dma_num_configs(); }
-static inline int cfg_end() { return cfg_base_stream() + imagen_conv_stream_num_configs(); }
+// kernel family 4 (conv_pw.hip): the streaming pointwise convolution, tile cfg ids behind family 3's
+int imagen_conv_pw_num_configs();
+int imagen_conv_pw_config_info(int idx, int* tile_pixels, int* tile_cout, int* kchunks);
+long imagen_conv_pw_lds_bytes(int idx, int KH, int KW, int TH, int TW);
+int launch_conv_pw(const ImagenIgemmParams* p, int idx, hipStream_t s);
+static inline int cfg_base_pw() { return cfg_base_stream() + imagen_conv_stream_num_configs(); }
+static inline int cfg_end() { return cfg_base_pw() + imagen_conv_pw_num_configs(); }
 
 int launch_igemm(const ImagenIgemmParams* pp, hipStream_t s) {
   const ImagenIgemmParams& p = *pp;
@@ -1054,6 +1048,7 @@ int launch_igemm(const ImagenIgemmParams* pp, hipStream_t s) {
   IMAGEN_CHECK(!p.addend || p.gate, "igemm: addend requires gate");
   IMAGEN_CHECK(p.cfg >= kNumCfgs || (p.TW > 0 && (p.TW & (p.TW - 1)) == 0), "igemm: tile width %d is not a power of two", p.TW);
   IMAGEN_CHECK(!p.gca_part || p.cfg >= kNumCfgs, "igemm: gca_part is implemented by kernel family 2 only (cfg %d)", p.cfg);
+  if (p.cfg >= cfg_base_pw()) return launch_conv_pw(pp, p.cfg - cfg_base_pw(), s);
   if (p.cfg >= cfg_base_stream()) return launch_conv_stream(pp, p.cfg - cfg_base_stream(), s);
   if (p.cfg >= cfg_base_dma()) return launch_conv_dma(pp, p.cfg - cfg_base_dma(), s);
   switch (p.cfg) {
@@ -1081,7 +1076,7 @@ extern "C" int imagen_igemm_num_configs(void) { return cfg_end(); }
 
 extern "C" int imagen_igemm_config_family(int cfg) {   // 0: wave-specialised persistent kernel (this file), 2: all-DMA kernel (conv_dma.hip), 3: streaming kernel (conv_stream.hip)
   if (cfg < 0 || cfg >= imagen_igemm_num_configs()) return -1;
-  return cfg >= cfg_base_stream() ? 3 : cfg >= cfg_base_dma() ? 2 : 0;
+  return cfg >= cfg_base_pw() ? 4 : cfg >= cfg_base_stream() ? 3 : cfg >= cfg_base_dma() ? 2 : 0;   // 4: streaming pointwise kernel (conv_pw.hip)
 }
 
 extern "C" int imagen_igemm_config_ring(int cfg) {   // weight look-ahead ring depth in stages (family 2; 0 elsewhere)
@@ -1089,6 +1084,7 @@ extern "C" int imagen_igemm_config_ring(int cfg) {   // weight look-ahead ring d
 }
 
 extern "C" int imagen_igemm_config_info(int cfg, int* tile_pixels, int* tile_cout, int* kgroups) {
+  if (cfg >= cfg_base_pw()) return imagen_conv_pw_config_info(cfg - cfg_base_pw(), tile_pixels, tile_cout, kgroups);   // (family 4: kgroups = 32-channel input chunks)
   if (cfg >= cfg_base_stream()) return imagen_conv_stream_config_info(cfg - cfg_base_stream(), tile_pixels, tile_cout, kgroups);
   if (cfg >= cfg_base_dma()) return imagen_conv_dma_config_info(cfg - cfg_base_dma(), tile_pixels, tile_cout, kgroups);
   if (cfg < 0 || cfg >= kNumCfgs) return -1;
@@ -1108,6 +1104,7 @@ static constexpr int ksc_of(int G, int ks) {   // the launch_cfg dispatch, as a 
 }
 
 extern "C" int imagen_igemm_stage_slots(int cfg, int KH, int KW) {
+  if (cfg >= cfg_base_pw()) return (KH == 1 && KW == 1) ? 1 << 20 : 0;
   if (cfg >= cfg_base_dma()) return (KH == 3 && KW == 3) ? 1 << 20 : 0;   // (no register staging: the tile shape is fixed per cfg; families 2 and 3)
   if (cfg < 0 || cfg >= kNumCfgs || KH < 1 || KW < 1) return -1;
   const TileCfg& c = kCfgs[cfg];
@@ -1116,6 +1113,7 @@ extern "C" int imagen_igemm_stage_slots(int cfg, int KH, int KW) {
 
 // dynamic LDS bytes of a launch of `cfg` with a KH x KW kernel (at `stride`) and a TH x TW output tile; -1: the combination is not launchable
 extern "C" long imagen_igemm_lds_bytes(int cfg, int KH, int KW, int stride, int TH, int TW) {
+  if (cfg >= cfg_base_pw()) return stride == 1 ? imagen_conv_pw_lds_bytes(cfg - cfg_base_pw(), KH, KW, TH, TW) : -1;
   if (cfg >= cfg_base_stream()) return stride == 1 ? imagen_conv_stream_lds_bytes(cfg - cfg_base_stream(), KH, KW, TH, TW) : -1;
   if (cfg >= cfg_base_dma()) return stride == 1 ? imagen_conv_dma_lds_bytes(cfg - cfg_base_dma(), KH, KW, TH, TW) : -1;
   if (cfg < 0 || KH < 1 || KW < 1 || TH < 1 || TW < 1) return -1;
@@ -1124,7 +1122,7 @@ extern "C" long imagen_igemm_lds_bytes(int cfg, int KH, int KW, int stride, int 
   const int IT = ((TH - 1) * stride + KH) * ((TW - 1) * stride + KW);
   if (IT * c.G > imagen_igemm_stage_slots(cfg, KH, KW) * 256) return -1;
   const long PS = c.G == 1 ? 16 : c.G * 16 + 16;
-  const long lds = 2 * IT * PS + (long)(4 * 32 * c.MI + kBiasLds) * (long)sizeof(float) + 16 + kTouchSink;
+  const long lds = 2 * IT * PS + (long)(4 * 32 * c.MI + kBiasLds) * (long)sizeof(float) + 16;
   return lds <= 160 * 1024 ? lds : -1;
 }
 

@@ -273,6 +273,19 @@ CONV_STREAM = int(_os.environ.get("IMAGEN_CONV_STREAM", "1"))       # A/B switch
 STREAM_MIN_TILES = 512   # ... of launches with at least this many 16x16 tiles (persistent workgroups need a few tiles each)
 
 
+CONV_PW = int(_os.environ.get("IMAGEN_CONV_PW", "1"))               # A/B switch: the streaming pointwise family (conv_pw.hip) for the large res_conv launches
+PW_MIN_TILES = 1024    # ... of at least this many 256-pixel tiles (the big maps; below, the launch is latency-bound either way)
+
+
+def pw_cfg(kchunks: int, Cout: int) -> Optional[int]:
+    """Tile cfg id of the streaming pointwise family (family 4) built for `kchunks` 32-channel input chunks that covers Cout, else None."""
+    best = None
+    for i, (tp, bn, kch, fam) in enumerate(cfg_table()):
+        if fam == 4 and kch == kchunks and bn >= Cout and (best is None or bn < cfg_table()[best][1]):
+            best = i
+    return best
+
+
 def stream_cfg() -> Optional[int]:
     """Tile cfg id of the streaming family (family 3), None if the library has none."""
     return next((i for i, c in enumerate(cfg_table()) if c[3] == 3), None)
@@ -377,10 +390,6 @@ def pick_cfg(G: int, Cout: int, OH: int, OW: int, B: int, KH: int = 1, KW: int =
 # at a time) that replace the rules of pick_cfg for the layer classes they name: {layer_key: [cfg, TH, TW]}, loaded from tuned_cfgs.json
 # beside this file when it exists.  A pick that is not launchable for the call at hand is ignored (the rules apply).
 CFG_OVERRIDE: dict = {}
-# timing ablations for tools/r03_calls/call_g.sh ONLY (results are garbage): ImagenIgemmParams.dbg bits (2 = no consumer compute, 8 = no
-# stores) / no prologue arithmetic.  Unset in production.
-_ABLATE_DBG = int(_os.environ.get("IMAGEN_ABLATE_IGEMM_DBG", "0"))
-_ABLATE_PROLOGUE = _os.environ.get("IMAGEN_ABLATE_PROLOGUE") == "1"
 
 
 def layer_key(Cin: int, Cout: int, K: int, stride: int, OH: int, OW: int, B: int, pro: bool) -> str:
@@ -420,9 +429,6 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
     ssq_out: emit the per-pixel sum of squares of the output — honoured only when the chosen tile covers all Cout
     (`p.ssq_emitted` tells the caller, who otherwise falls back to a ROWSTAT op)."""
     """Append one implicit-GEMM launch.  y: Act (NHWC / pixel-shuffle target) or fp32 NCHW tensor (OUT_NCHW_F32)."""
-    if _ABLATE_PROLOGUE and pw.KH == 3:
-        mu = rs = pa = ps = ssq_a = ssq_b = None
-        act_in = ACT_NONE
     KH, KW = pw.KH, pw.KW
     if pad is None:
         pad = (KH - 1) // 2 if stride == 1 else 0
@@ -442,6 +448,18 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
                 and (no_pro or ssq_pro) and not gca_here and tiles16 >= STREAM_MIN_TILES
                 and stream_cfg() is not None):
             cfg = (stream_cfg(), 16, 16)
+    if cfg is None and CONV_PW and KH == 1 and KW == 1 and stride == 1 and pad == 0 and out_mode == OUT_NHWC:
+        # the streaming pointwise family: the res_conv GEMMs of the large maps (raw inputs in 32-channel chunks, <= 64 output channels,
+        # bias + gate * addend | residual epilogue)
+        no_pro = mu is None and rs is None and pa is None and ps is None and ssq_a is None and act_in == ACT_NONE
+        tiles = x1.B * math.ceil(OH * OW / 256)
+        if (no_pro and act_out == ACT_NONE and post is None and gca is None and x1.C % 32 == 0 and C2 % 32 == 0 and pw.Cin_pad == x1.C + C2
+                and pw.Cout % 8 == 0 and x1.ld % 8 == 0 and (x2 is None or x2.ld % 8 == 0) and tiles >= PW_MIN_TILES
+                and (addend is None or (addend.ld % 8 == 0 and addend.bs % 8 == 0)) and (res is None or (res.ld % 8 == 0 and res.bs % 8 == 0))
+                and isinstance(y, Act) and y.ld % 8 == 0 and y.bs % 8 == 0):
+            pc = pw_cfg((x1.C + C2) // 32, pw.Cout)
+            if pc is not None:
+                cfg = (pc, 256 // min(OW, 256), min(OW, 256))
     if cfg is None:
         raw = (x2 is None and mu is None and rs is None and pa is None and ps is None and ssq_a is None and act_in == ACT_NONE
                and x1.C % 32 == 0 and pw.Cin_pad == x1.C and x1.ld % 8 == 0)
@@ -490,8 +508,6 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
         p.y, p.ldy, p.bsy = y.ptr, y.ld, y.bs
         keep.append(y.t)
     p.TH, p.TW, p.cfg = th, tw, cid
-    if _ABLATE_DBG:
-        p.dbg = _ABLATE_DBG
     if ssq_a is not None:
         p.ssq_a, p.ssq_b, p.ssq_wb = ssq_a.data_ptr(), ptr(ssq_b), ssq_wb
         keep += [ssq_a, ssq_b]

@@ -141,6 +141,29 @@ def test_conv_stream_family(ops, dev):
     assert r["err"] < TOL and r["err_ssq"] < 2e-3, ("many tiles, raw", r)
 
 
+def test_conv_pw_family(ops, dev):
+    """The streaming pointwise family (csrc/conv_pw.hip): 1x1 convs over one or two raw 32-channel-chunk inputs with the res_conv epilogues
+    (bias + gate * addend | residual | plain) and the per-pixel sum of squares — every instantiation, ragged pixel counts (partial last
+    tile), several tiles per persistent workgroup, Cout below the tile width; and the planner's own pick for a benchmark-sized launch."""
+    tab = ops.cfg_table()
+    cfgs = [i for i, c in enumerate(tab) if c[3] == 4]
+    if not cfgs:
+        pytest.skip("the library holds no streaming pointwise family")
+    for cfg in cfgs:
+        tp, bn, kch, _ = tab[cfg]
+        for (C1, C2) in {(32 * (kch - 1), 32), (32 * kch, 0)}:
+            if C1 == 0:
+                continue
+            for ep, Cout, H, W in (("addend", bn, 40, 52), ("res", bn - 8, 16, 16), ("plain", bn, 9, 31)):
+                G = 8 if (C1 + C2) % 64 == 0 else 4
+                r = run_case(ops, dev, B=3, H=H, W=W, C1=C1, C2=C2, Cout=Cout, K=1, G=G, cfg=(cfg, 256 // min(W, 256), min(W, 256)) if W in (16, 128, 256) else (cfg, 1, 256),
+                             prologue="none", act_in="none", epilogue=ep, ssq_out=True)
+                assert r["err"] < TOL and r["err_ssq"] < 2e-3, (cfg, C1, C2, ep, r)
+    # the planner picks the family for the large res_conv launches by itself
+    r = run_case(ops, dev, B=16, H=128, W=128, C1=64, C2=32, Cout=64, K=1, prologue="none", act_in="none", epilogue="addend", ssq_out=True)
+    assert tab[r["cfg"][0]][3] == 4 and r["err"] < TOL and r["err_ssq"] < 2e-3, r
+
+
 def test_act_prep(ops, dev):
     """ACT_PREP: the Block prologue as its own pass (ssq statistics over a two-tensor concat, per-channel gain, SiLU; and the
     LayerNorm form with a per-(batch, channel) affine) vs fp32 torch."""

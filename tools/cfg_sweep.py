@@ -94,11 +94,11 @@ def main():
         rec = dict(stage=stage, baseline_ms=base, baseline_again_ms=base2, classes=[])
         order = sorted(cls.items(), key=lambda kv: -kv[1]["est_us"])[: args.top]
         for key, c in order:
-            if c["fam"] == 3:
-                continue      # the streaming family is chosen by its own rule
+            if c["fam"] in (3, 4):
+                continue      # the streaming families are chosen by their own rules
             cands = []
             for i, (tp, bn, g, fam) in enumerate(tab):
-                if g != c["G"] or fam == 3 or i == c["cfg"][0]:
+                if g != c["G"] or fam in (3, 4) or i == c["cfg"][0]:
                     continue
                 if fam == 2 and not (c["raw"] and c["K"] == 3 and c["stride"] == 1 and g == 4):
                     continue
