@@ -78,7 +78,7 @@ def test_every_bench_igemm_launch_matches_the_reference():
     report, worst = [], 0.0
     for d, label, count in bench_descriptors():
         kw = {k: v for k, v in d.items() if k not in ("has_pa", "ssq_b", "G")}
-        kw["G"] = tab[d["cfg"][0]][2]
+        kw["G"] = tab[d["cfg"][0]][2] if tab[d["cfg"][0]][3] != 4 else ops.choose_G(d["C1"] + d["C2"], d["K"] * d["K"])   # (family 4 lists input chunks there)
         if d["prologue"] == "none" and d["has_pa"]:
             kw["prologue"] = "rs"          # affine without statistics: exercised as a unit per-pixel scale
         if d["prologue"] == "ssq" and not d["C2"]:
