@@ -20,22 +20,28 @@
 
 namespace {
 
-constexpr int PW_NW = 8;                 // waves per workgroup: wave w owns the pixels [32 w, 32 w + 32) of the tile
-constexpr int PW_TP = 32 * PW_NW;        // 256 pixels per tile (consecutive in the image's row-major pixel order)
-constexpr int PW_CH = PW_TP * 64;        // LDS bytes of one 32-channel chunk of a tile
+constexpr int PW_NW = 8;                 // waves per workgroup
+// WN: waves that split the output channels of a pixel block (1: every wave owns 32 pixels x all couts; 2: 32 pixels x half the couts —
+// twice the couts per workgroup at half the pixels per tile, for the 128-channel res_conv of the 64^2 level).  A tile is 32 * 8 / WN
+// consecutive pixels of the image's row-major order.
 
 __device__ __forceinline__ int pw_swz(int px) { return (px >> 2) & 3; }
 
-template <int NI, int KCH>
+template <int NI, int KCH, int WN>
 __global__ __launch_bounds__(64 * PW_NW, 2) void conv_pw_kernel(const ImagenIgemmParams p) {
+  constexpr int PW_TP = 32 * PW_NW / WN;   // pixels per tile
+  constexpr int PW_CH = PW_TP * 64;        // LDS bytes of one 32-channel chunk of a tile
+  constexpr int NJ = PW_TP * 4 / 512;      // 16-byte staging slots per thread and chunk
+  constexpr int BN = 32 * NI * WN;         // output channels per workgroup
   extern __shared__ __attribute__((aligned(16))) char smem[];
   char* const acts = smem;                                                       // [2 tiles][KCH][PW_CH]
-  float* const par = reinterpret_cast<float*>(smem + 2 * KCH * PW_CH);           // [bias 32 NI | gate 32 NI]
-  constexpr int BN = 32 * NI;
+  float* const par = reinterpret_cast<float*>(smem + 2 * KCH * PW_CH);           // [bias BN | gate BN | ssq partials PW_TP (WN = 2)]
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
+  const int wpx = wave / WN, wn = wave % WN;      // pixel block / cout group of this wave
+  const int co0 = wn * 32 * NI;                   // first output channel of this wave
   const int HW = p.OH * p.OW;
   const int tiles_img = (HW + PW_TP - 1) / PW_TP;
   const int total = p.B * tiles_img;
@@ -45,19 +51,19 @@ __global__ __launch_bounds__(64 * PW_NW, 2) void conv_pw_kernel(const ImagenIgem
   // ---- weights: A fragment of K step s (input channels 16 s .. 16 s + 15) and cout block ni, straight from the packed buffer
   f16x8 areg[2 * KCH][NI];
   {
-    const f16x8* wl = reinterpret_cast<const f16x8*>(p.w) + (size_t)half * p.Cout_pad + l31;
+    const f16x8* wl = reinterpret_cast<const f16x8*>(p.w) + (size_t)half * p.Cout_pad + co0 + l31;
 #pragma unroll
     for (int s = 0; s < 2 * KCH; ++s)
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) areg[s][ni] = wl[(size_t)(2 * s) * p.Cout_pad + ni * 32];
   }
 
-  // ---- staging: thread -> slots S = tid + 512 j (j = 0, 1) of every chunk: halo-free, so slot = (pixel S >> 2, position S & 3) and the
+  // ---- staging: thread -> slots S = tid + 512 j (j < NJ) of every chunk: halo-free, so slot = (pixel S >> 2, position S & 3) and the
   //      thread fetches channel group (S & 3) ^ swz(pixel) of that pixel's chunk
   const int n1 = p.C1 >> 5;                       // chunks that come from x1
-  int s_px[2], s_goff[2];                         // pixel inside the tile, channel offset of the group inside the chunk (elements)
+  int s_px[NJ], s_goff[NJ];                       // pixel inside the tile, channel offset of the group inside the chunk (elements)
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
+  for (int j = 0; j < NJ; ++j) {
     const int S = tid + 512 * j;
     s_px[j] = S >> 2;
     s_goff[j] = ((S & 3) ^ pw_swz(S >> 2)) * 8;
@@ -69,8 +75,8 @@ __global__ __launch_bounds__(64 * PW_NW, 2) void conv_pw_kernel(const ImagenIgem
   const int ebs = p.addend ? p.bs_add : p.bs_res;
 
   struct Next {
-    uint4 x[KCH][2];              // the tile's input rows, as staged
-    imagen_u32x4 op[NI][2];       // this lane's epilogue operand pieces: couts ni * 32 + 8 qp + 16 half .. + 7 of its pixel
+    uint4 x[KCH][NJ];             // the tile's input rows, as staged
+    imagen_u32x4 op[NI][2];       // this lane's epilogue operand pieces: couts co0 + ni * 32 + 8 qp + 16 half .. + 7 of its pixel
   };
   auto request = [&](Next& N, int b, int pix0) __attribute__((always_inline)) {
 #pragma unroll
@@ -79,7 +85,7 @@ __global__ __launch_bounds__(64 * PW_NW, 2) void conv_pw_kernel(const ImagenIgem
       const f16* base = from1 ? x1 + (size_t)b * p.bs1 + c * 32 : x2 + (size_t)b * p.bs2 + (c - n1) * 32;
       const int ld = from1 ? p.ld1 : p.ld2;
 #pragma unroll
-      for (int j = 0; j < 2; ++j) {
+      for (int j = 0; j < NJ; ++j) {
         const int px = pix0 + s_px[j];
         const bool ok = px < HW;
         const uint4 v = *reinterpret_cast<const uint4*>(base + (size_t)(ok ? px : 0) * ld + s_goff[j]);
@@ -87,13 +93,13 @@ __global__ __launch_bounds__(64 * PW_NW, 2) void conv_pw_kernel(const ImagenIgem
       }
     }
     if (eop) {
-      const int px = pix0 + wave * 32 + l31;
+      const int px = pix0 + wpx * 32 + l31;
       const f16* row = eop + (size_t)b * ebs + (size_t)(px < HW ? px : 0) * eld;
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni)
 #pragma unroll
         for (int qp = 0; qp < 2; ++qp) {
-          const int cx = ni * 32 + 8 * qp + 16 * half;
+          const int cx = co0 + ni * 32 + 8 * qp + 16 * half;
           N.op[ni][qp] = *reinterpret_cast<const imagen_u32x4*>(row + (cx < p.Cout ? cx : 0));
         }
     }
@@ -102,10 +108,10 @@ __global__ __launch_bounds__(64 * PW_NW, 2) void conv_pw_kernel(const ImagenIgem
 #pragma unroll
     for (int c = 0; c < KCH; ++c)
 #pragma unroll
-      for (int j = 0; j < 2; ++j) *reinterpret_cast<uint4*>(acts + (buf * KCH + c) * PW_CH + (tid + 512 * j) * 16) = N.x[c][j];
+      for (int j = 0; j < NJ; ++j) *reinterpret_cast<uint4*>(acts + (buf * KCH + c) * PW_CH + (tid + 512 * j) * 16) = N.x[c][j];
   };
 
-  const int px_l = wave * 32 + l31;                                   // this lane's pixel inside the tile (MFMA N dimension)
+  const int px_l = wpx * 32 + l31;                                    // this lane's pixel inside the tile (MFMA N dimension)
   const int b_off0 = px_l * 64 + ((half ^ pw_swz(px_l)) << 4);        // B fragment of K step 0 of a chunk; K step 1: channel groups 2 + half
   const int b_off1 = px_l * 64 + (((2 + half) ^ pw_swz(px_l)) << 4);
 
@@ -170,7 +176,7 @@ __global__ __launch_bounds__(64 * PW_NW, 2) void conv_pw_kernel(const ImagenIgem
 #pragma unroll
           for (int h = 0; h < 2; ++h) {
             const int q = qp + 2 * h;
-            const int cl = ni * 32 + 8 * q + 4 * half;
+            const int cl = co0 + ni * 32 + 8 * q + 4 * half;
             const float4 bq = *reinterpret_cast<const float4*>(par + cl);
             const float4 gq = *reinterpret_cast<const float4*>(par + BN + cl);
             const float bb[4] = {bq.x, bq.y, bq.z, bq.w}, gg[4] = {gq.x, gq.y, gq.z, gq.w};
@@ -184,12 +190,19 @@ __global__ __launch_bounds__(64 * PW_NW, 2) void conv_pw_kernel(const ImagenIgem
             }
           }
           const imagen_u32x4 v16 = imagen_pair_quads(o[0], o[1]);
-          const int cx = ni * 32 + 8 * qp + 16 * half;
+          const int cx = co0 + ni * 32 + 8 * qp + 16 * half;
           if (px_ok && cx < p.Cout) *reinterpret_cast<imagen_u32x4*>(yrow + cx) = v16;
         }
       if (p.ssq_out) {
         ssq += __shfl_xor(ssq, 32);
-        if (half == 0 && px_ok) p.ssq_out[(size_t)b * HW + px] = ssq;
+        if constexpr (WN == 1) {
+          if (half == 0 && px_ok) p.ssq_out[(size_t)b * HW + px] = ssq;
+        } else {   // the two waves of a pixel block each hold half the channels: one hop through LDS (workgroup-uniform branch)
+          float* red = par + 2 * BN;
+          if (wn == 1 && half == 0) red[px_l] = ssq;
+          __syncthreads();
+          if (wn == 0 && half == 0 && px_ok) p.ssq_out[(size_t)b * HW + px] = ssq + red[px_l];
+        }
       }
     }
 
@@ -206,10 +219,11 @@ __global__ __launch_bounds__(64 * PW_NW, 2) void conv_pw_kernel(const ImagenIgem
   }
 }
 
-template <int NI, int KCH>
+template <int NI, int KCH, int WN>
 int pw_launch(const ImagenIgemmParams& p, hipStream_t s) {
-  const size_t lds = (size_t)2 * KCH * PW_CH + (size_t)2 * 32 * NI * sizeof(float);
-  auto kern = conv_pw_kernel<NI, KCH>;
+  constexpr int PW_TP = 32 * PW_NW / WN, PW_CH = PW_TP * 64;
+  const size_t lds = (size_t)2 * KCH * PW_CH + (size_t)(2 * 32 * NI * WN + PW_TP) * sizeof(float);
+  auto kern = conv_pw_kernel<NI, KCH, WN>;
   static bool attr_done[16] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);
@@ -233,12 +247,14 @@ int pw_launch(const ImagenIgemmParams& p, hipStream_t s) {
   return imagen_hip_status("conv_pw launch");
 }
 
-struct PwCfg { int NI, KCH; };
+struct PwCfg { int NI, KCH, WN; };
 constexpr PwCfg kPwCfgs[] = {
-    {1, 2},   // 0: 64 -> <= 32 channels
-    {2, 3},   // 1: 96 -> <= 64 channels
-    {2, 2},   // 2: 64 -> <= 64 channels
-    {1, 3},   // 3: 96 -> <= 32 channels
+    {1, 2, 1},   // 0: 256 px,  64 -> <= 32 channels
+    {2, 3, 1},   // 1: 256 px,  96 -> <= 64 channels
+    {2, 2, 1},   // 2: 256 px,  64 -> <= 64 channels
+    {1, 3, 1},   // 3: 256 px,  96 -> <= 32 channels
+    {2, 6, 2},   // 4: 128 px, 192 -> <= 128 channels (two waves per pixel block, 64 couts each: 24 A fragments per wave)
+    {2, 4, 2},   // 5: 128 px, 128 -> <= 128 channels
 };
 constexpr int kNumPwCfgs = sizeof(kPwCfgs) / sizeof(kPwCfgs[0]);
 
@@ -250,15 +266,18 @@ int imagen_conv_pw_num_configs() { return kNumPwCfgs; }
 // packed weight layout of a 1x1 layer is the same for every G >= 2: consecutive 8-channel group rows)
 int imagen_conv_pw_config_info(int idx, int* tile_pixels, int* tile_cout, int* kchunks) {
   if (idx < 0 || idx >= kNumPwCfgs) return -1;
-  if (tile_pixels) *tile_pixels = PW_TP;
-  if (tile_cout) *tile_cout = 32 * kPwCfgs[idx].NI;
+  if (tile_pixels) *tile_pixels = 32 * PW_NW / kPwCfgs[idx].WN;
+  if (tile_cout) *tile_cout = 32 * kPwCfgs[idx].NI * kPwCfgs[idx].WN;
   if (kchunks) *kchunks = kPwCfgs[idx].KCH;
   return 0;
 }
 
 long imagen_conv_pw_lds_bytes(int idx, int KH, int KW, int TH, int TW) {
-  if (idx < 0 || idx >= kNumPwCfgs || KH != 1 || KW != 1 || TH * TW != PW_TP) return -1;
-  return 2L * kPwCfgs[idx].KCH * PW_CH + 2L * 32 * kPwCfgs[idx].NI * (long)sizeof(float);
+  if (idx < 0 || idx >= kNumPwCfgs || KH != 1 || KW != 1) return -1;
+  const PwCfg c = kPwCfgs[idx];
+  const int tp = 32 * PW_NW / c.WN;
+  if (TH * TW != tp) return -1;
+  return 2L * c.KCH * tp * 64 + (2L * 32 * c.NI * c.WN + tp) * (long)sizeof(float);
 }
 
 int launch_conv_pw(const ImagenIgemmParams* pp, int idx, hipStream_t s) {
@@ -271,18 +290,20 @@ int launch_conv_pw(const ImagenIgemmParams* pp, int idx, hipStream_t s) {
   IMAGEN_CHECK(p.out_mode == IMAGEN_OUT_NHWC, "conv_pw: NHWC output only");
   IMAGEN_CHECK(p.C1 % 32 == 0 && p.C2 % 32 == 0 && (p.C1 + p.C2) == 32 * c.KCH && p.Cin_pad == p.C1 + p.C2 && (p.C2 == 0 || p.x2),
                "conv_pw: cfg %d takes %d input channels in 32-channel chunks (got %d + %d)", idx, 32 * c.KCH, p.C1, p.C2);
-  IMAGEN_CHECK(p.Cout <= 32 * c.NI && p.Cout % 8 == 0 && p.Cout_pad >= 32 * c.NI, "conv_pw: cfg %d covers %d output channels (Cout %d, padded %d)", idx,
-               32 * c.NI, p.Cout, p.Cout_pad);
+  IMAGEN_CHECK(p.Cout <= 32 * c.NI * c.WN && p.Cout % 8 == 0 && p.Cout_pad >= 32 * c.NI * c.WN, "conv_pw: cfg %d covers %d output channels (Cout %d, padded %d)",
+               idx, 32 * c.NI * c.WN, p.Cout, p.Cout_pad);
   IMAGEN_CHECK(p.ld1 % 8 == 0 && (p.C2 == 0 || p.ld2 % 8 == 0) && p.ldy % 8 == 0 && p.bsy % 8 == 0 && ((size_t)p.y & 15) == 0,
                "conv_pw: strides must keep 16-byte alignment");
   IMAGEN_CHECK(!(p.addend && p.res), "conv_pw: addend and residual are mutually exclusive");
   IMAGEN_CHECK(!p.addend || (p.gate && p.ld_add % 8 == 0 && p.bs_add % 8 == 0 && ((size_t)p.addend & 15) == 0), "conv_pw: addend needs gate and 16-byte aligned rows");
   IMAGEN_CHECK(!p.res || (p.ld_res % 8 == 0 && p.bs_res % 8 == 0 && ((size_t)p.res & 15) == 0), "conv_pw: residual rows must be 16-byte aligned");
   switch (idx) {
-    case 0: return pw_launch<1, 2>(p, s);
-    case 1: return pw_launch<2, 3>(p, s);
-    case 2: return pw_launch<2, 2>(p, s);
-    case 3: return pw_launch<1, 3>(p, s);
+    case 0: return pw_launch<1, 2, 1>(p, s);
+    case 1: return pw_launch<2, 3, 1>(p, s);
+    case 2: return pw_launch<2, 2, 1>(p, s);
+    case 3: return pw_launch<1, 3, 1>(p, s);
+    case 4: return pw_launch<2, 6, 2>(p, s);
+    case 5: return pw_launch<2, 4, 2>(p, s);
   }
   return -1;
 }

@@ -274,7 +274,7 @@ STREAM_MIN_TILES = 512   # ... of launches with at least this many 16x16 tiles (
 
 
 CONV_PW = int(_os.environ.get("IMAGEN_CONV_PW", "1"))               # A/B switch: the streaming pointwise family (conv_pw.hip) for the large res_conv launches
-PW_MIN_TILES = 1024    # ... of at least this many 256-pixel tiles (the big maps; below, the launch is latency-bound either way)
+PW_MIN_TILES = 512     # ... of at least this many tiles, i.e. two per CU (the big maps; below, the launch is latency-bound either way)
 
 
 def pw_cfg(kchunks: int, Cout: int) -> Optional[int]:
@@ -452,14 +452,14 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
         # the streaming pointwise family: the res_conv GEMMs of the large maps (raw inputs in 32-channel chunks, <= 64 output channels,
         # bias + gate * addend | residual epilogue)
         no_pro = mu is None and rs is None and pa is None and ps is None and ssq_a is None and act_in == ACT_NONE
-        tiles = x1.B * math.ceil(OH * OW / 256)
         if (no_pro and act_out == ACT_NONE and post is None and gca is None and x1.C % 32 == 0 and C2 % 32 == 0 and pw.Cin_pad == x1.C + C2
-                and pw.Cout % 8 == 0 and x1.ld % 8 == 0 and (x2 is None or x2.ld % 8 == 0) and tiles >= PW_MIN_TILES
+                and pw.Cout % 8 == 0 and x1.ld % 8 == 0 and (x2 is None or x2.ld % 8 == 0)
                 and (addend is None or (addend.ld % 8 == 0 and addend.bs % 8 == 0)) and (res is None or (res.ld % 8 == 0 and res.bs % 8 == 0))
                 and isinstance(y, Act) and y.ld % 8 == 0 and y.bs % 8 == 0):
             pc = pw_cfg((x1.C + C2) // 32, pw.Cout)
-            if pc is not None:
-                cfg = (pc, 256 // min(OW, 256), min(OW, 256))
+            if pc is not None and x1.B * math.ceil(OH * OW / cfg_table()[pc][0]) >= PW_MIN_TILES:
+                tp = cfg_table()[pc][0]
+                cfg = (pc, tp // min(OW, tp), min(OW, tp))
     if cfg is None:
         raw = (x2 is None and mu is None and rs is None and pa is None and ps is None and ssq_a is None and act_in == ACT_NONE
                and x1.C % 32 == 0 and pw.Cin_pad == x1.C and x1.ld % 8 == 0)

@@ -156,12 +156,14 @@ def test_conv_pw_family(ops, dev):
                 continue
             for ep, Cout, H, W in (("addend", bn, 40, 52), ("res", bn - 8, 16, 16), ("plain", bn, 9, 31)):
                 G = 8 if (C1 + C2) % 64 == 0 else 4
-                r = run_case(ops, dev, B=3, H=H, W=W, C1=C1, C2=C2, Cout=Cout, K=1, G=G, cfg=(cfg, 256 // min(W, 256), min(W, 256)) if W in (16, 128, 256) else (cfg, 1, 256),
-                             prologue="none", act_in="none", epilogue=ep, ssq_out=True)
+                r = run_case(ops, dev, B=3, H=H, W=W, C1=C1, C2=C2, Cout=Cout, K=1, G=G, cfg=(cfg, 1, tp), prologue="none", act_in="none", epilogue=ep,
+                             ssq_out=True)
                 assert r["err"] < TOL and r["err_ssq"] < 2e-3, (cfg, C1, C2, ep, r)
     # the planner picks the family for the large res_conv launches by itself
     r = run_case(ops, dev, B=16, H=128, W=128, C1=64, C2=32, Cout=64, K=1, prologue="none", act_in="none", epilogue="addend", ssq_out=True)
     assert tab[r["cfg"][0]][3] == 4 and r["err"] < TOL and r["err_ssq"] < 2e-3, r
+    r = run_case(ops, dev, B=16, H=64, W=64, C1=128, C2=64, Cout=128, K=1, prologue="none", act_in="none", epilogue="addend", ssq_out=True)   # two waves per pixel block
+    assert tab[r["cfg"][0]][3] == 4 and tab[r["cfg"][0]][0] == 128 and r["err"] < TOL and r["err_ssq"] < 2e-3, r
 
 
 def test_act_prep(ops, dev):
