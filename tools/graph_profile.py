@@ -30,6 +30,17 @@ def run(args):
     from imagen_pytorch_amd import _abi, ops
 
     dev = torch.device("cuda", 0)
+    if args.dup_igemm:
+        # timing experiment (results garbage where an op accumulates): every conv / GEMM launch is issued twice back to back, so the
+        # trace holds each one cold (operands last touched by other kernels) and warm (weights and input tile just read by itself)
+        add0 = ops.Plan.add
+
+        def add_twice(self, struct, label="", keep=()):
+            r = add0(self, struct, label, keep)
+            if _abi.STRUCT_KIND[type(struct)] == _abi.ENUMS["IMAGEN_OP_IGEMM"]:
+                self.ops.append((_abi.STRUCT_KIND[type(struct)], struct, (label or "igemm") + ".again"))
+            return r
+        ops.Plan.add = add_twice
     imagen = bench.build_imagen(1000, dev)
     te = torch.randn(args.batch, 256, 768, device=dev)
     imagen.sample(text_embeds=te, cond_scale=3.0, use_tqdm=False, seed=1, max_steps=args.steps)
@@ -223,6 +234,7 @@ def main():
     r.add_argument("--steps", type=int, default=12)
     r.add_argument("--batch", type=int, default=8)
     r.add_argument("--plan-out", default="/tmp/plan.json")
+    r.add_argument("--dup-igemm", action="store_true", help="issue every conv / GEMM launch twice (cold vs warm timing experiment)")
     a = sub.add_parser("analyze")
     a.add_argument("trace")
     a.add_argument("plan")
