@@ -266,7 +266,7 @@ def _tap3d(act, rows):
     return t.reshape(rows, f, *t.shape[1:]).permute(0, 2, 1, 3, 4)
 
 
-C5_TOL = 2e-3
+C5_TOL = 1.5e-3   # measured on MI355X (calls A and M): cond 9.9e-4, null 9.5e-4, CFG-3 combination 2.7e-3
 
 
 def test_unet3d_forward_vs_oracle_c5():
