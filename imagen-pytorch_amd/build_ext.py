@@ -17,7 +17,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["igemm.hip", "conv_dma.hip", "conv_stream.hip", "conv_pw.hip", "elementwise.hip", "attention.hip", "sampler.hip", "temporal.hip", "codesize.hip", "probe.hip", "capi.hip"]
+SOURCES = ["igemm.hip", "conv_dma.hip", "conv_stream.hip", "conv_pw.hip", "conv_big.hip", "elementwise.hip", "attention.hip", "sampler.hip", "temporal.hip", "codesize.hip", "probe.hip", "capi.hip"]
 LIB = os.path.join(HERE, "libimagen_hip.so")
 STAMP = os.path.join(HERE, ".libimagen_hip.stamp")
 
@@ -77,6 +77,33 @@ def build(force: bool = False, verbose: bool = True) -> str:
     if verbose:
         print(f"built {LIB}")
     return LIB
+
+
+def build_variant(tag: str, defs, sources=None) -> str:
+    """A/B library libimagen_hip_<tag>.so: the product sources with extra -D flags (bench-only builds, e.g. conv_big's timing ablations)."""
+    hipcc = shutil.which("hipcc") or "/opt/rocm/bin/hipcc"
+    build_dir = os.path.join(HERE, "build", tag)
+    os.makedirs(build_dir, exist_ok=True)
+    common = [hipcc, "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-I" + os.path.join(ROOT, "include"), "-I" + CSRC] + list(defs)
+    procs, objs = [], []
+    for src in SOURCES:
+        obj = os.path.join(build_dir, src.replace(".hip", ".o"))
+        objs.append(obj)
+        procs.append((src, subprocess.Popen(common + ["-c", os.path.join(CSRC, src), "-o", obj], stdout=subprocess.PIPE, stderr=subprocess.STDOUT)))
+    for src, pr in procs:
+        out, _ = pr.communicate()
+        if pr.returncode != 0:
+            raise RuntimeError(f"hipcc failed on {src}:\n{out.decode()}")
+    lib = os.path.join(HERE, f"libimagen_hip_{tag}.so")
+    link = [hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", lib] + objs
+    tl = _torch_lib_dir()
+    if tl and os.path.exists(os.path.join(tl, "libamdhip64.so")):
+        link += ["-L" + tl, "-Wl,-rpath," + tl]
+    link += ["-Wl,-rpath,/opt/rocm/lib"]
+    res = subprocess.run(link, stdout=subprocess.PIPE, stderr=subprocess.STDOUT)
+    if res.returncode != 0:
+        raise RuntimeError("link failed:\n" + res.stdout.decode())
+    return lib
 
 
 if __name__ == "__main__":

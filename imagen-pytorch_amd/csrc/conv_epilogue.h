@@ -6,7 +6,7 @@
 
 struct ClTile { int b, oy0, ox0, n0; };
 
-// ep_par: LDS scratch of 5 * BN + 8 * 32 * MI floats, dead staging memory of the caller (all its LDS traffic retired: call behind a barrier).  The
+// ep_par: LDS scratch of 4 * BN + WM * WN * 32 * MI + 8 + WM * (BN + 4) floats, ep_red: WM * WN * 32 * MI floats, dead staging memory of the caller (all its LDS traffic retired: call behind a barrier).  The
 // per-channel epilogue operands (bias, post_pa, post_ps) are fetched ONCE per workgroup into it: a dependent global load per channel
 // quad costs ~1-2 us each under load (igemm.hip measured 14k cycles for four such rounds), one cooperative fetch + barrier ~1 us.
 // sum (or max) over the 32 lanes of each half-wave on the VALU: inclusive scan inside the 16-lane rows by DPP row shifts, then row
@@ -42,11 +42,32 @@ __device__ __forceinline__ void cl_epilogue_params(const ImagenIgemmParams& p, i
 
 // PRELOADED: ep_par already holds the operands of tc.b (persistent kernels refresh it when the batch row changes): the epilogue then
 // contains NO global load — a load here is younger than the caller's in-flight prefetch, and waiting for it drains that whole queue
-template <int MI, int NI, int WM, int WN, bool GEN, bool PRELOADED = false>
+// STG: the 16-byte output pieces of the plain / post_pa paths go to an LDS image of the tile first ([tile pixel][BN couts] fp16, pitch
+// 2 BN + 16 bytes: a lane = pixel writes conflict-free), and the workgroup then stores it in memory order — 16 consecutive lanes write one
+// pixel's 2 BN contiguous bytes.  Direct stores are one 16-byte piece per lane at pixel stride: every store instruction touches 64 cache
+// lines with a 16-byte partial write, and the L2 takes one write per channel and clock whatever its size (conv_big timing ablation, round
+// 3 call Q: the epilogue cost 6 of 37 us).  stg: TP * (2 BN + 16) bytes of dead LDS that overlap neither ep_par nor ep_red.
+template <int TP, int BN, int NTHREADS>
+__device__ __forceinline__ void cl_copy_out(const ImagenIgemmParams& p, const ClTile& tc, const char* stg) {
+  constexpr int PPR = BN / 8, PITCH = 2 * BN + 16;
+  __syncthreads();
+  f16* y = reinterpret_cast<f16*>(p.y) + (size_t)tc.b * p.bsy;
+  for (int j = threadIdx.x; j < TP * PPR; j += NTHREADS) {
+    const int pix = j / PPR, pc = j - pix * PPR;
+    const int py = pix / p.TW, px = pix - py * p.TW;
+    const int oy = tc.oy0 + py, ox = tc.ox0 + px, co = tc.n0 + pc * 8;
+    if (oy < p.OH && ox < p.OW && co < p.Cout)
+      *reinterpret_cast<imagen_u32x4*>(y + (size_t)(oy * p.OW + ox) * p.ldy + co) = *reinterpret_cast<const imagen_u32x4*>(stg + pix * PITCH + pc * 16);
+  }
+}
+
+template <int MI, int NI, int WM, int WN, bool GEN, bool PRELOADED = false, bool STG = false>
 __device__ __forceinline__ void cl_epilogue(const ImagenIgemmParams& p, const ClTile& tc, f32x16 (&acc)[NI][MI], const int (&pix_y)[MI],
-                                            const int (&pix_x)[MI], float* ep_red, float* ep_par, int wm, int wn, int half, int l31) {
+                                            const int (&pix_x)[MI], float* ep_red, float* ep_par, int wm, int wn, int half, int l31,
+                                            char* stg = nullptr) {
   constexpr int PXW = 32 * MI;
   constexpr int BN = 32 * NI * WN;
+  constexpr int STG_PITCH = 2 * BN + 16;
   if constexpr (!PRELOADED) {
     const int i = threadIdx.x;
     if (i < BN) {
@@ -140,10 +161,14 @@ __device__ __forceinline__ void cl_epilogue(const ImagenIgemmParams& p, const Cl
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi) {
             const imagen_u32x4 v = imagen_pair_quads(o2[0][mi], o2[1][mi]);
-            if (co16 < p.Cout && op[mi] >= 0) *reinterpret_cast<imagen_u32x4*>(y + (size_t)op[mi] * p.ldy + co16) = v;
+            if constexpr (STG) *reinterpret_cast<imagen_u32x4*>(stg + ((wm * MI + mi) * 32 + l31) * STG_PITCH + (co16 - n0) * 2) = v;
+            else if (co16 < p.Cout && op[mi] >= 0) *reinterpret_cast<imagen_u32x4*>(y + (size_t)op[mi] * p.ldy + co16) = v;
           }
         }
       }
+    if constexpr (STG) {
+      if (wide) cl_copy_out<32 * MI * WM, BN, 64 * WM * WN>(p, tc, stg);
+    }
     return;
   }
 
@@ -186,18 +211,22 @@ __device__ __forceinline__ void cl_epilogue(const ImagenIgemmParams& p, const Cl
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi) {
             const imagen_u32x4 v = imagen_pair_quads(o2[0][mi], o2[1][mi]);
-            if (co16 < p.Cout && op[mi] >= 0) *reinterpret_cast<imagen_u32x4*>(y + (size_t)op[mi] * p.ldy + co16) = v;
+            if constexpr (STG) *reinterpret_cast<imagen_u32x4*>(stg + ((wm * MI + mi) * 32 + l31) * STG_PITCH + (co16 - n0) * 2) = v;
+            else if (co16 < p.Cout && op[mi] >= 0) *reinterpret_cast<imagen_u32x4*>(y + (size_t)op[mi] * p.ldy + co16) = v;
           }
         }
       }
+    if constexpr (STG) {
+      if (wide) cl_copy_out<32 * MI * WM, BN, 64 * WM * WN>(p, tc, stg);
+    }
     if (p.gca_part) {
       // ---- GlobalContext partials of this tile (ip.py:965-968; launcher: one tile covers all Cout): logit[px] = h[px, :].wk + bk,
       // (max, sum exp, sum exp * h[px, c]) over the tile's pixels -> part[b][tile][C + 2], merged over the tiles by GCA_FINAL.
       // h = the fp16 values just stored (kept in the accumulator registers by the store loop above).  Replaces the GCA_PARTIAL
       // launch and its re-read of the whole tensor.  Reductions over the 32 pixel lanes of a half-wave run on the VALU (DPP row
       // shifts + row broadcast: 5 instructions per value, result in lanes 31 / 63), not through the LDS crossbar.
-      float* gk = ep_par + 4 * BN;            // [4 waves][PXW] logit partials
-      float* gm = gk + 4 * PXW;               // [4] wave maxima
+      float* gk = ep_par + 4 * BN;            // [WM * WN waves][PXW] logit partials
+      float* gm = gk + WM * WN * PXW;         // [8] wave-row maxima
       float* gs = gm + 8;                     // [WM][BN + 4] weighted channel sums (+ sum exp at [BN])
 #pragma unroll
       for (int mi = 0; mi < MI; ++mi) gca_k[mi] += __shfl_xor(gca_k[mi], 32);

@@ -93,6 +93,7 @@ def _fingerprint(unet) -> tuple:
 
 # ACT_PREP + all-DMA conv for the Blocks with at least this many output channels (the MFMA-bound layers: the prologue pass costs one
 # read + one write of the input, the conv kernel drops its staging instruction stream); 0 = never
+BIG_PREP = int(os.environ.get("IMAGEN_BIG_PREP", "1"))   # A/B switch: ACT_PREP + conv_big for the Blocks conv_big applies to (else they keep the fused prologue)
 ACT_PREP_MIN_COUT = int(os.environ.get("IMAGEN_ACT_PREP_MIN_COUT", "0"))   # (measured in the model: the extra pass costs more than it saves — off)
 TAIL_FUSED = int(os.environ.get("IMAGEN_TAIL_FUSED", "1"))   # A/B switch: GCA_FINAL + GATE_RESIDUAL of an identity ResnetBlock as one GCA_TAIL launch
 TAIL_ACT = int(os.environ.get("IMAGEN_TAIL_ACT", "1"))       # A/B switch: ... which also writes the next block1's activated input
@@ -437,6 +438,9 @@ class UnetEngine:
         # (its consumer waves have the slack; block2's producers then stage h1 with no arithmetic at all)
         post = dict(pa=pa2, ps=ps2, pstride=self.total_c) if rb.cross_attn is None else None
         prep = ops.CONV_DMA and ACT_PREP_MIN_COUT > 0 and Cout >= ACT_PREP_MIN_COUT and Cin % 32 == 0 and Cout % 32 == 0
+        # the big-tile all-DMA family (conv_big.hip) wants activated inputs: where it applies, the Block prologue runs once per element as
+        # its own pass (ACT_PREP) instead of once per staging workgroup inside the wave-specialised kernel
+        prep = prep or (BIG_PREP and Cin % 32 == 0 and ops.big_cfg(Cout, H, Wd, R) is not None)
         # x comes out of a fused ResnetBlock tail (GCA_TAIL): that launch also writes silu(ChanRMSNorm(x) * gamma) — it has the pixel's
         # channels and its sum of squares in registers — and block1 stages its input with no arithmetic (prologue-free kernel families)
         xa = ops.request_act(x, pa1) if (skip is None and TAIL_ACT and w1.Cin_pad == Cin) else None

@@ -277,6 +277,27 @@ CONV_PW = int(_os.environ.get("IMAGEN_CONV_PW", "1"))               # A/B switch
 PW_MIN_TILES = 512     # ... of at least this many tiles, i.e. two per CU (the big maps; below, the launch is latency-bound either way)
 
 
+CONV_BIG = int(_os.environ.get("IMAGEN_CONV_BIG", "1"))               # A/B switch: the big-tile all-DMA family (conv_big.hip) for the C >= 128 3x3 convs
+BIG_MIN_WGS = 192      # ... of launches that give it at least this many workgroups (one per CU: below, the smaller tiles of family 2 fill the chip better)
+BIG_PICKS = tuple(int(v) for v in _os.environ.get("IMAGEN_BIG_PICKS", "0,1").split(","))   # family-5 configuration of the 256- / 128-pixel tile
+
+
+def big_cfg(Cout: int, OH: int, OW: int, B: int) -> Optional[tuple]:
+    """(cfg, th, tw) of the big-tile all-DMA family (family 5) for a prologue-free 3x3 stride-1 conv with 32-channel chunks, None where it
+    does not apply: 128-cout tiles only; the 256-pixel tile where that still gives one workgroup per CU, else the 128-pixel tile with the
+    K split, else nothing."""
+    if not CONV_BIG or Cout % 128 != 0:
+        return None
+    fam5 = [i for i, c in enumerate(cfg_table()) if c[3] == 5]
+    if len(fam5) <= max(BIG_PICKS):
+        return None
+    for i in (fam5[BIG_PICKS[0]], fam5[BIG_PICKS[1]]):
+        sh = launchable_shapes(i, OH, OW, 3, 3, 1)
+        if sh and B * sh[0][0] * (Cout // 128) >= BIG_MIN_WGS:
+            return i, sh[0][2], sh[0][3]
+    return None
+
+
 def pw_cfg(kchunks: int, Cout: int) -> Optional[int]:
     """Tile cfg id of the streaming pointwise family (family 4) built for `kchunks` 32-channel input chunks that covers Cout, else None."""
     best = None
@@ -352,6 +373,11 @@ def pick_cfg(G: int, Cout: int, OH: int, OW: int, B: int, KH: int = 1, KW: int =
     tiles narrower than Cout are then only used when nothing wider exists.  Among the tile shapes of the chosen
     configuration: least padded pixels, then the fewest staged halo pixels."""
     tab = cfg_table()
+    if raw and stride == 1 and KH == 3 and KW == 3 and G == 4 and family in (None, 5):
+        got = big_cfg(Cout, OH, OW, B)
+        if got is not None:
+            return got
+    assert family != 5, "no big-tile configuration for this layer"
     if raw and CONV_DMA and stride == 1 and KH == 3 and KW == 3 and G == 4 and family in (None, 2):
         got = _pick_dma(Cout, OH, OW, B, full_cout)
         if got is not None:
@@ -415,7 +441,7 @@ def _override_ok(ov, G: int, OH: int, OW: int, KH: int, KW: int, stride: int, ra
     if not (0 <= cid < len(tab)) or tab[cid][2] != G:
         return False
     fam = tab[cid][3]
-    if fam == 3 or (fam == 2 and not (raw and KH == 3 and KW == 3 and stride == 1 and G == 4)):
+    if fam == 3 or (fam in (2, 5) and not (raw and KH == 3 and KW == 3 and stride == 1 and G == 4)):
         return False
     return any((th, tw) == (a, b) for _, _, a, b in launchable_shapes(cid, OH, OW, KH, KW, stride))
 
@@ -529,7 +555,7 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
     # all Cout); `p.gca_part_t` ([B, chunks, Cout + 2], chunks = tiles per image = `p.gca_chunks`) then feeds GCA_FINAL directly
     p.gca_part_t, p.gca_chunks = None, 0
     chunks = math.ceil(OH / th) * math.ceil(OW / tw)
-    if want_gca and cfg_table()[cid][3] == 2 and pw.Cout <= cfg_table()[cid][1] and x1.B * chunks <= GCA_EPILOGUE_MAX_TILES:   # (not family 3)
+    if want_gca and cfg_table()[cid][3] in (2, 5) and pw.Cout <= cfg_table()[cid][1] and x1.B * chunks <= GCA_EPILOGUE_MAX_TILES:   # (not family 3)
         part = torch.empty(x1.B, chunks, pw.Cout + 2, dtype=torch.float32, device=x1.t.device)
         p.gca_wk, p.gca_part, p.gca_bk = gca["wk"].data_ptr(), part.data_ptr(), gca["bk"]
         keep += [gca["wk"], part]

@@ -50,7 +50,7 @@ def _shapes(ops, cfg, K, stride, H, W):
 def test_conv3x3_block_every_cfg_and_tile_shape(ops, dev, cfg):
     """Block conv (prologue rs * pa + ps -> SiLU, concat input, bias), plain NHWC output with ssq_out where one tile covers Cout."""
     tp, bn, G, fam = ops.cfg_table()[cfg]
-    if G not in (1, 4) or fam in (2, 3):
+    if G not in (1, 4) or fam in (2, 3, 5):
         pytest.skip("3x3 convs with a prologue use 8- or 32-channel chunks of families 0 / 1")
     C1, C2 = (64, 32) if G == 4 else (16, 8)
     H, W = (40, 36) if tp >= 128 else (20, 24)
@@ -71,7 +71,7 @@ def test_conv3x3_raw_post_and_ssq_prologue_every_cfg(ops, dev, cfg):
     """The two fused forms of a ResnetBlock: conv1 with ssq statistics (ssq_a + wb * ssq_b over the concat) and the output-side
     Block prologue (post_pa); conv2 staging an already activated input with no arithmetic (prologue none)."""
     tp, bn, G, fam = ops.cfg_table()[cfg]
-    if G != 4 or fam in (2, 3):
+    if G != 4 or fam in (2, 3, 5):
         pytest.skip("32-channel chunks of families 0 / 1 only")
     H, W = (32, 48) if tp >= 128 else (16, 24)
     shapes = _shapes(ops, cfg, 3, 1, H, W)
@@ -108,6 +108,32 @@ def test_conv_dma_every_cfg(ops, dev, cfg):
     if bn <= 128:
         r = run_case(ops, dev, B=2, H=H, W=W, C1=32, Cout=3, epilogue="nchw", **raw)
         assert r["err"] < TOL, (cfg, "nchw", r)
+
+
+@pytest.mark.parametrize("cfg", range(NUM_CFGS))
+def test_conv_big_every_cfg(ops, dev, cfg):
+    """The big-tile all-DMA family (csrc/conv_big.hip): prologue-free single-input 3x3 convs to 128-cout tiles, 64 x 64 per wave, shared
+    weight ring stages of one tap row, one barrier per tap row (and the K split over two wave groups on the 128-pixel tiles); ragged
+    images (partial tiles, zero padding from the zero page), 1-6 channel chunks (every ring / halo-buffer phase, the stream's repeated last
+    stage), one and two output-channel tile columns, every epilogue incl. the GlobalContext partials."""
+    tp, bn, G, fam = ops.cfg_table()[cfg]
+    if fam != 5:
+        pytest.skip("family 5 only")
+    H, W = 40, 36
+    (th, tw), = _shapes(ops, cfg, 3, 1, H, W)
+    raw = dict(prologue="none", act_in="none", K=3, G=4, cfg=(cfg, th, tw))
+    for Cin in (32, 64, 96, 128, 192):
+        r = run_case(ops, dev, B=2, H=H, W=W, C1=Cin, Cout=bn, ssq_out=True, gca=True, **raw)
+        assert r["err"] < TOL and r["err_ssq"] < 2e-3 and r["err_gca"] < 2e-3, (cfg, Cin, r)
+    r = run_case(ops, dev, B=2, H=H - 5, W=W - 3, C1=64, Cout=bn - 8, gca=True, **raw)   # ragged tiles, couts that do not fill the tile
+    assert r["err"] < TOL and r["err_gca"] < 2e-3, (cfg, "gca ragged", r)
+    r = run_case(ops, dev, B=3, H=H - 3, W=W + 5, C1=128, Cout=2 * bn, **raw)
+    assert r["err"] < TOL, (cfg, "cout tiles", r)
+    for ep in ("post", "addend", "res"):
+        r = run_case(ops, dev, B=2, H=H, W=W, C1=64, Cout=bn, epilogue=ep, **raw)
+        assert r["err"] < TOL, (cfg, ep, r)
+    r = run_case(ops, dev, B=2, H=H, W=W, C1=32, Cout=3, epilogue="nchw", **raw)
+    assert r["err"] < TOL, (cfg, "nchw", r)
 
 
 def test_conv_stream_family(ops, dev):

@@ -18,7 +18,7 @@
 namespace emul {
 namespace {
 constexpr size_t kStack = 1 << 20;
-struct Dma { const void* src; char* dst; };
+struct Dma { const void* src; char* dst; int bytes; };
 struct Fiber {
   ucontext_t ctx;
   char* stack = nullptr;
@@ -156,12 +156,16 @@ int readlane(int v, int lane) {
 }
 void dma16(const void* gsrc, unsigned lds_dst, char* lds) {
   Fiber& f = fibers[cur];
-  f.dma.push_back(Dma{gsrc, lds + lds_dst + 16 * (f.tid.x & 63)});
+  f.dma.push_back(Dma{gsrc, lds + lds_dst + 16 * (f.tid.x & 63), 16});
+}
+void dma4(const void* gsrc, unsigned lds_dst, char* lds) {   // global_load_lds_dword: lane l -> LDS bytes [dst + 4 l, + 4)
+  Fiber& f = fibers[cur];
+  f.dma.push_back(Dma{gsrc, lds + lds_dst + 4 * (f.tid.x & 63), 4});
 }
 void wait_vm(int n) {
   Fiber& f = fibers[cur];
   while ((int)f.dma.size() > n) {
-    memcpy(f.dma.front().dst, f.dma.front().src, 16);
+    memcpy(f.dma.front().dst, f.dma.front().src, f.dma.front().bytes);
     f.dma.pop_front();
   }
 }

@@ -78,6 +78,7 @@ int readlane(int v, int lane);
 // when a covering s_waitcnt vmcnt(n) of ITS wave-lane retires it — in issue order, the n youngest may stay in flight.  A kernel that
 // reads LDS before the covering wait sees the poison (or the previous tile), exactly as it would see stale bytes on the GPU.
 void dma16(const void* gsrc, unsigned lds_dst, char* lds);
+void dma4(const void* gsrc, unsigned lds_dst, char* lds);
 void wait_vm(int n);
 void s_waitcnt(int imm);                        // gfx9 encoding: vmcnt = imm[3:0] | imm[15:14] << 4; the other counters need no emulation
 void launch(dim3 grid, dim3 block, size_t lds_bytes, void (*body)(void*), void* arg, char* lds, size_t lds_cap);

@@ -45,6 +45,14 @@ CASES = {
     "dma_64x128_gca": dict(B=2, H=16, W=16, C1=64, Cout=128, K=3, G=4, cfg="dma:64x128", prologue="none", act_in="none", gca=True),
     "dma_128x128_post": dict(B=1, H=16, W=32, C1=128, Cout=128, K=3, G=4, cfg="dma:128x128", prologue="none", act_in="none", epilogue="post"),
     "dma_256x32_ssq": dict(B=1, H=20, W=36, C1=32, Cout=32, K=3, G=4, cfg="dma:256x32", prologue="none", act_in="none", ssq_out=True),
+    # the big-tile all-DMA family (conv_big.hip): cfg = "big:<n>" = the n-th configuration of family 5 (0: 256 px, 1: 128 px with the K split,
+    # 2: ... three halo buffers, 3: 256 px with a 3-stage ring); several tiles per image and partial tiles, 4 / 6 / 3 chunks, 256 couts = two tile columns
+    "big0_gca": dict(B=2, H=32, W=16, C1=128, Cout=128, K=3, G=4, cfg="big:0", prologue="none", act_in="none", gca=True),
+    "big0_post_ragged": dict(B=1, H=20, W=36, C1=96, Cout=128, K=3, G=4, cfg="big:0", prologue="none", act_in="none", epilogue="post"),
+    "big1_ssq": dict(B=2, H=16, W=16, C1=128, Cout=128, K=3, G=4, cfg="big:1", prologue="none", act_in="none", ssq_out=True),
+    "big1_256co_addend": dict(B=1, H=12, W=20, C1=192, Cout=256, K=3, G=4, cfg="big:1", prologue="none", act_in="none", epilogue="addend"),
+    "big2_gca": dict(B=1, H=16, W=32, C1=128, Cout=128, K=3, G=4, cfg="big:2", prologue="none", act_in="none", gca=True),
+    "big3_res": dict(B=1, H=16, W=16, C1=160, Cout=128, K=3, G=4, cfg="big:3", prologue="none", act_in="none", epilogue="res"),
     "stream_raw": dict(B=2, H=40, W=36, C1=32, Cout=32, K=3, G=4, cfg="stream", prologue="none", act_in="none", ssq_out=True),
     "stream_pro_concat_post": dict(B=2, H=40, W=36, C1=32, C2=32, Cout=32, K=3, G=4, cfg="stream", prologue="ssq", affine=False, epilogue="post"),
     "stream_pro_affine_ragged": dict(B=3, H=27, W=45, C1=32, Cout=24, K=3, G=4, cfg="stream", prologue="ssq", affine=True),
@@ -57,6 +65,10 @@ def resolve_cfg(ops, spec, kw):
         return spec
     if spec == "stream":
         return (ops.stream_cfg(), 16, 16)
+    if spec.startswith("big:"):
+        i = [j for j, c in enumerate(ops.cfg_table()) if c[3] == 5][int(spec.split(":")[1])]
+        sh = ops.launchable_shapes(i, kw["H"], kw["W"], 3, 3, 1)
+        return (i, sh[0][2], sh[0][3])
     tp, bn = map(int, spec.split(":")[1].split("x"))
     for i, (t, b, g, fam) in enumerate(ops.cfg_table()):
         if fam == 2 and (t, b) == (tp, bn):
