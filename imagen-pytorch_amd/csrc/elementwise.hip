@@ -789,6 +789,50 @@ __global__ __launch_bounds__(256) void act_prep_kernel(const ImagenActPrepParams
   }
 }
 
+// self_stat form: L lanes per pixel (L = 16 / 32 / 64 >= 8-channel groups of the pixel), one 16-byte group per lane; the sum of squares of
+// x1's channels is reduced over the pixel's lanes (butterfly inside the wave), so the input is read once and nothing precedes the launch
+template <int L>
+__global__ __launch_bounds__(256) void act_prep_stat_kernel(const ImagenActPrepParams p) {
+  const int gpp = (p.C1 + p.C2) >> 3;
+  const int g = threadIdx.x % L;
+  const int r = blockIdx.x * (256 / L) + threadIdx.x / L;
+  const bool live = r < p.rows && g < gpp;
+  const int rc = min(r, p.rows - 1), gc = min(g, gpp - 1);
+  const int b = rc / p.rows_per_batch, rr = rc - b * p.rows_per_batch;
+  const int c0 = gc * 8;
+  const f16* x1 = reinterpret_cast<const f16*>(p.x1);
+  const f16* x2 = reinterpret_cast<const f16*>(p.x2);
+  const f16* src = c0 < p.C1 ? x1 + (size_t)b * p.bs1 + (size_t)rr * p.ld1 + c0 : x2 + (size_t)b * p.bs2 + (size_t)rr * p.ld2 + (c0 - p.C1);
+  const f16x8 in = *reinterpret_cast<const f16x8*>(src);
+  const float qb = p.ssq_b ? p.ssq_b[rc] : 0.0f;
+  const float* pa = p.pa ? p.pa + (size_t)b * p.pstride + c0 : nullptr;
+  const float* ps = p.ps ? p.ps + (size_t)b * p.pstride + c0 : nullptr;
+  const float4 a0 = pa ? *reinterpret_cast<const float4*>(pa) : make_float4(1.f, 1.f, 1.f, 1.f);
+  const float4 a1 = pa ? *reinterpret_cast<const float4*>(pa + 4) : make_float4(1.f, 1.f, 1.f, 1.f);
+  const float4 s0 = ps ? *reinterpret_cast<const float4*>(ps) : make_float4(0.f, 0.f, 0.f, 0.f);
+  const float4 s1 = ps ? *reinterpret_cast<const float4*>(ps + 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+  float own = 0.0f;
+  if (live && c0 < p.C1) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) own += (float)in[j] * (float)in[j];
+  }
+#pragma unroll
+  for (int o = L / 2; o >= 1; o >>= 1) own += __shfl_xor(own, o);
+  if (!live) return;
+  const float sc = __builtin_amdgcn_rsqf(fmaxf(own + p.ssq_wb * qb, 1e-24f));
+  const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+  const float sh[8] = {s0.x, s0.y, s0.z, s0.w, s1.x, s1.y, s1.z, s1.w};
+  f16x8 out;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    float v = (float)in[j] * sc * a[j] + sh[j];
+    if (p.act_in == IMAGEN_ACT_SILU) v = silu_f(v);
+    else if (p.act_in == IMAGEN_ACT_GELU) v = gelu_f(v);
+    out[j] = (f16)v;
+  }
+  *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(p.y) + (size_t)b * p.bsy + (size_t)rr * p.ldy + c0) = out;
+}
+
 }  // namespace
 
 int launch_rowstat(const ImagenRowstatParams* p, hipStream_t s) {
@@ -930,6 +974,15 @@ int launch_act_prep(const ImagenActPrepParams* p, hipStream_t s) {
                "act_prep: channel counts / strides must be multiples of 8 (C1=%d C2=%d ld1=%d ld2=%d ldy=%d)", p->C1, p->C2, p->ld1, p->ld2, p->ldy);
   const long total = (long)p->rows * ((p->C1 + p->C2) >> 3);
   const int blocks = (int)std::min<long>((total + 1023) / 1024, 256L * 8);   // 4 items per thread and pass
+  if (p->self_stat) {
+    IMAGEN_CHECK(!p->rs && !p->mu && !p->ssq_a, "act_prep: self_stat excludes rs / mu / ssq_a");
+    const int gpp = (p->C1 + p->C2) / 8;
+    IMAGEN_CHECK(gpp <= 64, "act_prep: self_stat handles at most 512 channels per pixel (got %d)", 8 * gpp);
+    if (gpp <= 16) hipLaunchKernelGGL(act_prep_stat_kernel<16>, dim3((p->rows + 15) / 16), dim3(256), 0, s, *p);
+    else if (gpp <= 32) hipLaunchKernelGGL(act_prep_stat_kernel<32>, dim3((p->rows + 7) / 8), dim3(256), 0, s, *p);
+    else hipLaunchKernelGGL(act_prep_stat_kernel<64>, dim3((p->rows + 3) / 4), dim3(256), 0, s, *p);
+    return imagen_hip_status("act_prep (self_stat)");
+  }
   hipLaunchKernelGGL(act_prep_kernel, dim3(blocks), dim3(256), 0, s, *p);
   return imagen_hip_status("act_prep");
 }

@@ -424,7 +424,7 @@ class UnetEngine:
             in_scale[C1:] = s
         # block1: ChanRMSNorm over the (scaled) concat -> SiLU -> conv3x3.  The norm statistics come from the per-pixel sums of
         # squares the producers of x / skip emitted in their epilogues (a ROWSTAT pass only where a producer could not).
-        sx = self._ssq_of(plan, x, name + ".block1.stat_x")
+        stat_x = lambda: self._ssq_of(plan, x, name + ".block1.stat_x")
         ss = self._ssq_of(plan, skip, name + ".block1.stat_skip") if skip is not None else None
         w1 = W.conv(name + ".block1", rb.block1.project)
         pa1 = W.f32(name + ".block1.pa", lambda: _pad_vec(rb.block1.norm.gamma.detach().float().flatten().cpu() * math.sqrt(Cin)
@@ -439,19 +439,24 @@ class UnetEngine:
         post = dict(pa=pa2, ps=ps2, pstride=self.total_c) if rb.cross_attn is None else None
         prep = ops.CONV_DMA and ACT_PREP_MIN_COUT > 0 and Cout >= ACT_PREP_MIN_COUT and Cin % 32 == 0 and Cout % 32 == 0
         # the big-tile all-DMA family (conv_big.hip) wants activated inputs: where it applies, the Block prologue runs once per element as
-        # its own pass (ACT_PREP) instead of once per staging workgroup inside the wave-specialised kernel
-        prep = prep or (BIG_PREP and Cin % 32 == 0 and ops.big_cfg(Cout, H, Wd, R) is not None)
+        # its own pass (ACT_PREP, which also reduces x's statistics itself where no producer emitted them) instead of once per staging
+        # workgroup inside the wave-specialised kernel
+        big = BIG_PREP and ops.big_cfg(Cout, H, Wd, R) is not None
+        big1 = big and Cin % 32 == 0 and Cin <= 512 and w1.Cin_pad == Cin
         # x comes out of a fused ResnetBlock tail (GCA_TAIL): that launch also writes silu(ChanRMSNorm(x) * gamma) — it has the pixel's
         # channels and its sum of squares in registers — and block1 stages its input with no arithmetic (prologue-free kernel families)
         xa = ops.request_act(x, pa1) if (skip is None and TAIL_ACT and w1.Cin_pad == Cin) else None
         if xa is not None:
             op = ops.igemm(plan, xa, w1, h1, ssq_out=h1.ssq, post=post, label=name + ".block1")
-        elif prep:   # MFMA-bound layer: the prologue as its own pass, then the all-DMA conv on the activated concat
+        elif prep or big1:   # MFMA-bound layer: the prologue as its own pass, then an all-DMA conv on the activated concat
             xa = self.new(R, H, Wd, Cin)
-            ops.act_prep(plan, x, xa, x2=skip, ssq_a=sx, ssq_b=ss, ssq_wb=s * s, pa=pa1, pstride=0, act_in=ACT_SILU, label=name + ".block1.prep")
+            if big1 and x.ssq is None:
+                ops.act_prep(plan, x, xa, x2=skip, ssq_b=ss, ssq_wb=s * s, pa=pa1, pstride=0, act_in=ACT_SILU, self_stat=True, label=name + ".block1.prep")
+            else:
+                ops.act_prep(plan, x, xa, x2=skip, ssq_a=stat_x(), ssq_b=ss, ssq_wb=s * s, pa=pa1, pstride=0, act_in=ACT_SILU, label=name + ".block1.prep")
             op = ops.igemm(plan, xa, w1, h1, ssq_out=h1.ssq, post=post, label=name + ".block1")
         else:
-            op = ops.igemm(plan, x, w1, h1, x2=skip, ssq_a=sx, ssq_b=ss, ssq_wb=s * s, pa=pa1, pstride=0, act_in=ACT_SILU, ssq_out=h1.ssq,
+            op = ops.igemm(plan, x, w1, h1, x2=skip, ssq_a=stat_x(), ssq_b=ss, ssq_wb=s * s, pa=pa1, pstride=0, act_in=ACT_SILU, ssq_out=h1.ssq,
                            post=post, label=name + ".block1")
         if not op.ssq_emitted:
             h1.ssq = None
@@ -473,8 +478,16 @@ class UnetEngine:
         if op.post_applied:     # h1 already holds silu(norm(h1) * (scale + 1) + shift)
             op2 = ops.igemm(plan, h1, W.conv(name + ".block2", rb.block2.project), h2, gca=gca_ep, label=name + ".block2")
         else:                   # block2: ChanRMSNorm -> (scale+1, shift) from the time MLP -> SiLU -> conv3x3
-            s1 = self._ssq_of(plan, h1, name + ".block2.stat")
-            if prep:
+            if big and Cout % 32 == 0 and Cout <= 512 and h1.ssq is None:
+                ha = self.new(R, H, Wd, Cout)
+                ops.act_prep(plan, h1, ha, pa=pa2, ps=ps2, pstride=self.total_c, act_in=ACT_SILU, self_stat=True, label=name + ".block2.prep")
+                op2 = ops.igemm(plan, ha, W.conv(name + ".block2", rb.block2.project), h2, gca=gca_ep, label=name + ".block2")
+                s1 = None
+            else:
+                s1 = self._ssq_of(plan, h1, name + ".block2.stat")
+            if s1 is None:
+                pass
+            elif prep or big:
                 ha = self.new(R, H, Wd, Cout)
                 ops.act_prep(plan, h1, ha, ssq_a=s1, pa=pa2, ps=ps2, pstride=self.total_c, act_in=ACT_SILU, label=name + ".block2.prep")
                 op2 = ops.igemm(plan, ha, W.conv(name + ".block2", rb.block2.project), h2, gca=gca_ep, label=name + ".block2")

@@ -569,8 +569,9 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
 # ------------------------------------------------------------------------------------------------ small ops
 
 def act_prep(plan: Plan, x1: Act, y: Act, *, x2: Optional[Act] = None, mu=None, rs=None, pa=None, ps=None, pstride: int = 0,
-             act_in: int = ACT_NONE, ssq_a=None, ssq_b=None, ssq_wb: float = 1.0, label: str = ""):
-    """The IGEMM prologue as its own pass: y = fp16(act_in((concat(x1, x2) - mu) * rs * pa + ps)) (ImagenActPrepParams)."""
+             act_in: int = ACT_NONE, ssq_a=None, ssq_b=None, ssq_wb: float = 1.0, self_stat: bool = False, label: str = ""):
+    """The IGEMM prologue as its own pass: y = fp16(act_in((concat(x1, x2) - mu) * rs * pa + ps)) (ImagenActPrepParams).  self_stat: the launch
+    computes the sum of squares of x1's channels itself (rs = 1 / sqrt(that + ssq_wb * ssq_b))."""
     p = STRUCTS["ImagenActPrepParams"]()
     C2 = x2.C if x2 is not None else 0
     assert y.C == x1.C + C2 and (y.B, y.H * y.W) == (x1.B, x1.H * x1.W)
@@ -583,6 +584,9 @@ def act_prep(plan: Plan, x1: Act, y: Act, *, x2: Optional[Act] = None, mu=None, 
     p.y, p.ldy, p.bsy = y.ptr, y.ld, y.bs
     p.rows, p.rows_per_batch = x1.rows, x1.H * x1.W
     p.pstride, p.act_in = pstride, act_in
+    if self_stat:
+        assert mu is None and rs is None and ssq_a is None and (x1.C + C2) <= 512
+        p.self_stat = 1
     plan.add(p, label or "act_prep", [x1.t, x2.t if x2 is not None else None, mu, rs, pa, ps, ssq_a, ssq_b, y.t])
     return p
 

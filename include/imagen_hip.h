@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define IMAGEN_ABI_VERSION 5 /* 3: head_dim in the attention / QNORM / KV_PREP params; 4: DDPM_UPDATE x0_thr; 5: GCA_TAIL */
+#define IMAGEN_ABI_VERSION 6 /* 3: head_dim in the attention / QNORM / KV_PREP params; 4: DDPM_UPDATE x0_thr; 5: GCA_TAIL; 6: ACT_PREP self_stat */
 
 typedef void* imagen_stream_t; /* hipStream_t */
 
@@ -135,7 +135,7 @@ typedef struct ImagenIgemmParams {
 
 /* ACT_PREP — the IGEMM prologue (Block: ChanRMSNorm -> scale/shift -> SiLU, ip.py:683-690) materialised once:
  *   y[p, c] = fp16( act_in( (concat(x1, x2)[p, c] - mu[p]) * rs[p] * pa[b, c] + ps[b, c] ) )      rs from ssq_a (+ ssq_wb * ssq_b) when rs == NULL
- * Used in front of the all-DMA conv kernel family (csrc/conv_dma.hip), which copies its input global -> LDS without touching it, for
+ * Used in front of the all-DMA conv kernel families (csrc/conv_dma.hip, conv_big.hip), which copy their input global -> LDS without touching it, for
  * the MFMA-bound layers (C >= 128): the activation is then computed once per element instead of once per staging workgroup
  * (halo overlap x output-channel tiles = 2.8x on the 384 -> 256 convs) and leaves the conv's instruction stream. */
 typedef struct ImagenActPrepParams {
@@ -145,6 +145,8 @@ typedef struct ImagenActPrepParams {
   int32_t C1, ld1, bs1, C2, ld2, bs2;
   int32_t ldy, bsy, pstride, act_in;
   float ssq_wb;
+  int32_t self_stat;   /* 1: the per-pixel sum of squares of x1's channels is computed by this launch (rs, mu, ssq_a NULL): rs = 1 / sqrt(sum_c x1^2
+                        * + ssq_wb * ssq_b) — no ROWSTAT pass in front of it where the producer of x1 could not emit its statistics */
 } ImagenActPrepParams;
 
 /* ROWSTAT — replaces the reductions inside ChanRMSNorm (ip.py:322-329) and LayerNorm (ip.py:331-349,

@@ -90,6 +90,11 @@ class Interpreter:
             a = a - m.view(p.mu, f32)[:p.rows].reshape(B, n, 1)
         if p.rs:
             a = a * m.view(p.rs, f32)[:p.rows].reshape(B, n, 1)
+        elif p.self_stat:
+            ssq = (x[..., :p.C1] ** 2).sum(-1).reshape(-1)
+            if p.ssq_b:
+                ssq = ssq + p.ssq_wb * m.view(p.ssq_b, f32)[:p.rows]
+            a = a * (1.0 / ssq.sqrt().clamp(min=1e-12)).reshape(B, n, 1)
         elif p.ssq_a:
             ssq = m.view(p.ssq_a, f32)[:p.rows].clone()
             if p.ssq_b:

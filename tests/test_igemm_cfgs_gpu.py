@@ -195,8 +195,6 @@ def test_conv_pw_family(ops, dev):
 def test_act_prep(ops, dev):
     """ACT_PREP: the Block prologue as its own pass (ssq statistics over a two-tensor concat, per-channel gain, SiLU; and the
     LayerNorm form with a per-(batch, channel) affine) vs fp32 torch."""
-    if EMULATED:
-        pytest.skip("not an IGEMM launch: not emulated")
     import torch.nn.functional as F
 
     torch.manual_seed(0)
@@ -224,6 +222,29 @@ def test_act_prep(ops, dev):
     plan.run()
     torch.cuda.synchronize()
     assert nerr_(ops.act_to_nchw(y), ref) < 5e-4
+    # self_stat: the launch reduces x1's sum of squares itself (16 / 32 / 64 lanes per pixel), the skip tensor's comes from its producer;
+    # per-channel gain, or per-(batch, channel) scale + shift
+    for (c1, c2, affine) in ((64, 32, False), (256, 0, True), (256, 128, False), (128, 0, False)):
+        x1 = torch.randn(B, c1, H, W).half().float()
+        x2 = (torch.randn(B, c2, H, W) * 0.7).half().float() if c2 else None
+        C = c1 + c2
+        q = (x1 * x1).sum(1, keepdim=True) + (wb * (x2 * x2).sum(1, keepdim=True) if c2 else 0.0)
+        pa = 1 + 0.2 * torch.randn(B if affine else 1, C)
+        ps = 0.2 * torch.randn(B, C) if affine else None
+        xin = x1 if x2 is None else torch.cat((x1, x2), 1)
+        ref = xin / q.sqrt() * pa.view(-1, C, 1, 1)
+        if ps is not None:
+            ref = ref + ps.view(B, C, 1, 1)
+        ref = F.silu(ref)
+        a1 = ops.act_from_nchw(x1.to(dev))
+        a2 = ops.act_from_nchw(x2.to(dev)) if c2 else None
+        y = ops.new_act(B, H, W, C, dev)
+        plan = ops.Plan()
+        ops.act_prep(plan, a1, y, x2=a2, ssq_b=(x2 * x2).sum(1).reshape(-1).to(dev) if c2 else None, ssq_wb=wb, pa=pa.contiguous().to(dev),
+                     ps=ps.to(dev) if ps is not None else None, pstride=C if affine else 0, act_in=ops.ACT_SILU, self_stat=True)
+        plan.run()
+        torch.cuda.synchronize()
+        assert nerr_(ops.act_to_nchw(y), ref) < 5e-4, (c1, c2, affine)
 
 
 def nerr_(a, b):
