@@ -478,21 +478,17 @@ class UnetEngine:
         if op.post_applied:     # h1 already holds silu(norm(h1) * (scale + 1) + shift)
             op2 = ops.igemm(plan, h1, W.conv(name + ".block2", rb.block2.project), h2, gca=gca_ep, label=name + ".block2")
         else:                   # block2: ChanRMSNorm -> (scale+1, shift) from the time MLP -> SiLU -> conv3x3
-            if big and Cout % 32 == 0 and Cout <= 512 and h1.ssq is None:
+            w2 = W.conv(name + ".block2", rb.block2.project)
+            if (prep or big) and Cout % 32 == 0 and Cout <= 512:   # the prologue as its own pass (it reduces h1's statistics itself where block1 could not emit them)
                 ha = self.new(R, H, Wd, Cout)
-                ops.act_prep(plan, h1, ha, pa=pa2, ps=ps2, pstride=self.total_c, act_in=ACT_SILU, self_stat=True, label=name + ".block2.prep")
-                op2 = ops.igemm(plan, ha, W.conv(name + ".block2", rb.block2.project), h2, gca=gca_ep, label=name + ".block2")
-                s1 = None
+                if h1.ssq is None and big:
+                    ops.act_prep(plan, h1, ha, pa=pa2, ps=ps2, pstride=self.total_c, act_in=ACT_SILU, self_stat=True, label=name + ".block2.prep")
+                else:
+                    ops.act_prep(plan, h1, ha, ssq_a=self._ssq_of(plan, h1, name + ".block2.stat"), pa=pa2, ps=ps2, pstride=self.total_c,
+                                 act_in=ACT_SILU, label=name + ".block2.prep")
+                op2 = ops.igemm(plan, ha, w2, h2, gca=gca_ep, label=name + ".block2")
             else:
-                s1 = self._ssq_of(plan, h1, name + ".block2.stat")
-            if s1 is None:
-                pass
-            elif prep or big:
-                ha = self.new(R, H, Wd, Cout)
-                ops.act_prep(plan, h1, ha, ssq_a=s1, pa=pa2, ps=ps2, pstride=self.total_c, act_in=ACT_SILU, label=name + ".block2.prep")
-                op2 = ops.igemm(plan, ha, W.conv(name + ".block2", rb.block2.project), h2, gca=gca_ep, label=name + ".block2")
-            else:
-                op2 = ops.igemm(plan, h1, W.conv(name + ".block2", rb.block2.project), h2, ssq_a=s1, pa=pa2, ps=ps2, pstride=self.total_c,
+                op2 = ops.igemm(plan, h1, w2, h2, ssq_a=self._ssq_of(plan, h1, name + ".block2.stat"), pa=pa2, ps=ps2, pstride=self.total_c,
                                 act_in=ACT_SILU, gca=gca_ep, label=name + ".block2")
         # identity block: GlobalContext finalisation + h2 * gate + x (+ statistics) as ONE launch (GCA_TAIL) where its shapes allow
         fused_tail = (TAIL_FUSED and rb.res_conv is None and x.ld == x.C and x.bs == H * Wd * x.C

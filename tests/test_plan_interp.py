@@ -313,6 +313,34 @@ def test_unet_plan_config_sweep(name, reference_weights):
     assert e_c < 1e-2 and e_n < 1e-2, (name, e_c, e_n)
 
 
+def test_unet_plan_with_big_tile_family(reference_weights, monkeypatch):
+    """The planner path of the big-tile all-DMA family (ops.big_cfg -> conv_big.hip; engine._resnet: ACT_PREP in front of it, with the
+    statistics reduced by the pass itself where no producer emitted them), which the benchmark-sized layers take on the GPU, forced onto
+    a small model (its workgroup threshold lowered): buffer wiring, folded gains and launch order vs the oracle."""
+    from imagen_pytorch_amd import ops
+
+    monkeypatch.setattr(ops, "BIG_MIN_WGS", 1)
+    seen = dict(prep=0, self_stat=0, big=0)
+    real_prep, real_igemm = ops.act_prep, ops.igemm
+
+    def prep(plan, *a, **k):
+        seen["prep"] += 1
+        seen["self_stat"] += bool(k.get("self_stat"))
+        return real_prep(plan, *a, **k)
+
+    def igemm(plan, *a, **k):
+        p = real_igemm(plan, *a, **k)
+        seen["big"] += ops.cfg_table()[p.cfg][3] == 5
+        return p
+
+    monkeypatch.setattr(ops, "act_prep", prep)
+    monkeypatch.setattr(ops, "igemm", igemm)
+    test_unet_plan_config_sweep("dim32_three_levels", reference_weights)
+    assert seen["big"] >= 4 and seen["prep"] >= 2, seen
+    test_unet_plan_config_sweep("dim64_three_levels", reference_weights)      # 256-channel blocks: block2's prologue pass reduces its own statistics
+    assert seen["self_stat"] >= 1, seen
+
+
 def _dry_engines(monkeypatch):
     """Make Imagen._stage build its engines on CPU memory without launching (test-side patch; the product has no such switch)."""
     import functools

@@ -20,6 +20,9 @@ SWEEP = {
                                       init_dim=16, ff_mult=4.),
     "dim32_three_levels": dict(dim=32, cond_dim=64, text_embed_dim=32, dim_mults=(1, 2, 4), attn_heads=4, max_text_len=16, attn_pool_num_latents=8,
                                num_resnet_blocks=(1, 2, 2), layer_attns=(False, True, True), layer_cross_attns=(False, True, True)),
+    # 256 channels at the coarsest level: the ResnetBlocks whose block2 cannot get its norm from block1's epilogue (two output-channel tiles)
+    "dim64_three_levels": dict(dim=64, cond_dim=64, text_embed_dim=32, dim_mults=(1, 2, 4), attn_heads=2, max_text_len=16, attn_pool_num_latents=8,
+                               num_resnet_blocks=(1, 1, 2), layer_attns=(False, False, True), layer_cross_attns=(False, True, True)),
     "dim24_lowres": dict(dim=24, cond_dim=40, text_embed_dim=32, dim_mults=(1, 2), attn_heads=2, max_text_len=16, attn_pool_num_latents=8,
                          num_resnet_blocks=2, layer_attns=(False, True), layer_cross_attns=(True, True), lowres_cond=True),
     "nearest_upsample_init_residual": dict(_T, dim_mults=(1, 2, 4), num_resnet_blocks=1, layer_attns=(False, False, True),
