@@ -105,7 +105,7 @@ typedef struct ImagenIgemmParams {
    * pixel (ChanRMSNorm -> scale/shift -> SiLU of the NEXT Block, ip.py:671-691, applied by the producer so that the consuming
    * conv stages its input with no arithmetic at all) */
   const float* post_pa; const float* post_ps;
-  /* optional GlobalContext partials of the OUTPUT (plain NHWC mode, Cout <= tile couts, kernel families 1 and 2): with
+  /* optional GlobalContext partials of the OUTPUT (plain NHWC mode, Cout <= tile couts, the all-DMA kernel families 2 and 5): with
    * logit[q] = y[q, :] . gca_wk + gca_bk (ip.py:965-966), every output tile writes (max logit, sum exp, sum exp * y[q, c]) over its
    * pixels to gca_part[b][tile][Cout + 2] (tile = ty * tilesX + tx): exactly the rows GCA_PARTIAL produces with chunks = tiles per
    * image, ready for GCA_FINAL — the separate pass over the tensor disappears. */
@@ -413,8 +413,11 @@ int imagen_igemm_config_info(int cfg, int* tile_pixels, int* tile_cout, int* kgr
  * halo_pixels * G <= slots * 256 */
 int imagen_igemm_stage_slots(int cfg, int KH, int KW);
 /* kernel family of a tile cfg: 0 = wave-specialised persistent kernel (weights streamed from L2 per wave; every kernel size and
- * stride), 1 = LDS-staged kernel (both MFMA operands through LDS, weights by direct-to-LDS loads; 1x1 and 3x3, stride 1),
- * 2 = all-DMA kernel (3x3 stride 1, one input tensor, NO prologue: both operands by direct-to-LDS loads; fixed tile shape per cfg). */
+ * stride), (1 = the LDS-staged kernel with an in-kernel prologue, retired in round 3,)
+ * 2 = all-DMA kernel (3x3 stride 1, one input tensor, NO prologue: both operands by direct-to-LDS loads; fixed tile shape per cfg),
+ * 3 = streaming kernel (3x3 stride 1 to <= 32 channels from one or two 32-channel inputs, persistent, in-LDS prologue),
+ * 4 = streaming pointwise kernel (1x1, raw inputs, weights in registers; `kgroups` of its config info = 32-channel input chunks),
+ * 5 = big-tile all-DMA kernel (as 2, 128-cout tiles of 256 / 128 pixels, 64 x 64 per wave, one workgroup per CU). */
 int imagen_igemm_config_family(int cfg);
 int imagen_igemm_config_ring(int cfg);   /* weight look-ahead ring depth in stages (family 2; 0 for the others) */
 /* dynamic LDS bytes of a launch of `cfg` with a KHxKW kernel at `stride` and a THxTW output tile; -1 = not launchable */
