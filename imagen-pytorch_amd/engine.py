@@ -94,10 +94,10 @@ def _fingerprint(unet) -> tuple:
 # ACT_PREP + all-DMA conv for the Blocks with at least this many output channels (the MFMA-bound layers: the prologue pass costs one
 # read + one write of the input, the conv kernel drops its staging instruction stream); 0 = never
 BIG_PREP = int(os.environ.get("IMAGEN_BIG_PREP", "1"))   # A/B switch: ACT_PREP + conv_big for the Blocks conv_big applies to (else they keep the fused prologue)
-ACT_PREP_MIN_COUT = int(os.environ.get("IMAGEN_ACT_PREP_MIN_COUT", "0"))   # (measured in the model: the extra pass costs more than it saves — off)
-TAIL_FUSED = int(os.environ.get("IMAGEN_TAIL_FUSED", "1"))   # A/B switch: GCA_FINAL + GATE_RESIDUAL of an identity ResnetBlock as one GCA_TAIL launch
-TAIL_ACT = int(os.environ.get("IMAGEN_TAIL_ACT", "1"))       # A/B switch: ... which also writes the next block1's activated input
-LN_STATS_FUSED = int(os.environ.get("IMAGEN_LN_STATS_FUSED", "1"))   # A/B switch: LayerNorm statistics from the producing launch (GCA_TAIL / LN_RESIDUAL) instead of a ROWSTAT pass
+ACT_PREP_MIN_COUT = 0   # (measured in the model: the extra pass costs more than it saves — off)
+TAIL_FUSED = 1   # (module constant; measured in call B, profiles/r03_b_tail_ab.jsonl) GCA_FINAL + GATE_RESIDUAL of an identity ResnetBlock as one GCA_TAIL launch
+TAIL_ACT = 1     # (module constant; call B) ... which also writes the next block1's activated input
+LN_STATS_FUSED = 1   # (module constant; call B) LayerNorm statistics from the producing launch (GCA_TAIL / LN_RESIDUAL) instead of a ROWSTAT pass
 
 
 class UnetEngine:

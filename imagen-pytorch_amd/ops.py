@@ -279,7 +279,7 @@ PW_MIN_TILES = 512     # ... of at least this many tiles, i.e. two per CU (the b
 
 CONV_BIG = int(_os.environ.get("IMAGEN_CONV_BIG", "1"))               # A/B switch: the big-tile all-DMA family (conv_big.hip) for the C >= 128 3x3 convs
 BIG_MIN_WGS = 192      # ... of launches that give it at least this many workgroups (one per CU: below, the smaller tiles of family 2 fill the chip better)
-BIG_PICKS = tuple(int(v) for v in _os.environ.get("IMAGEN_BIG_PICKS", "3,2").split(","))   # family-5 configuration of the 256- / 128-pixel tile (call R: the 3-stage weight ring and the third halo buffer are 2-3 % ahead)
+BIG_PICKS = (3, 2)   # family-5 configuration of the 256- / 128-pixel tile (call R: the 3-stage weight ring and the third halo buffer are 2-3 % ahead)
 
 
 def big_cfg(Cout: int, OH: int, OW: int, B: int) -> Optional[tuple]:

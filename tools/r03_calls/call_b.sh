@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical: the IMAGEN_TAIL_* / IMAGEN_LN_STATS_FUSED switches this call used were folded into module constants of engine.py after the measurement)
 # Round-3 GPU call B: the cleaned-up library (remat epilogue as the product build) + GCA_TAIL on hardware.
 #   (1) whole -m gpu suite, (2) step-time A/B of the planner switches on one box, (3) in-graph profile of the new default.
 set -u

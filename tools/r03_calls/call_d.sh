@@ -1,4 +1,5 @@
 #!/bin/bash
+# (historical: the IMAGEN_TAIL_* / IMAGEN_LN_STATS_FUSED switches this call used were folded into module constants of engine.py after the measurement)
 # Round-3 GPU call D: lanes beyond 6; 64-pixel tiles for the all-DMA conv family (more workgroups per CU); calibration beside each.
 set -u
 cd "$(dirname "$0")/../.."
