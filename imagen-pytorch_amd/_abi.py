@@ -107,6 +107,7 @@ OP_STRUCT = {
     ENUMS["IMAGEN_OP_TEMPORAL_ATTENTION"]: STRUCTS["ImagenTemporalAttentionParams"],
     ENUMS["IMAGEN_OP_ACT_PREP"]: STRUCTS["ImagenActPrepParams"],
     ENUMS["IMAGEN_OP_GCA_TAIL"]: STRUCTS["ImagenGcaTailParams"],
+    ENUMS["IMAGEN_OP_STEP_SLICE"]: STRUCTS["ImagenStepSliceParams"],
 }
 STRUCT_KIND = {v: k for k, v in OP_STRUCT.items()}
 

@@ -833,7 +833,32 @@ __global__ __launch_bounds__(256) void act_prep_stat_kernel(const ImagenActPrepP
   *reinterpret_cast<f16x8*>(reinterpret_cast<f16*>(p.y) + (size_t)b * p.bsy + (size_t)rr * p.ldy + c0) = out;
 }
 
+// ------------------------------------------------------------------------------------------------ step_slice
+__global__ __launch_bounds__(256) void step_slice_kernel(const ImagenStepSliceParams p) {
+  const size_t step = (size_t)*p.step_ptr;
+  const int w0 = p.words0, w1 = w0 + p.words1, w2 = w1 + p.words2, tot = w2 + p.words3;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < tot; i += gridDim.x * 256) {
+    const uint4* s;
+    uint4* d;
+    int j, w;
+    if (i < w0) { s = reinterpret_cast<const uint4*>(p.src0); d = reinterpret_cast<uint4*>(p.dst0); j = i; w = p.words0; }
+    else if (i < w1) { s = reinterpret_cast<const uint4*>(p.src1); d = reinterpret_cast<uint4*>(p.dst1); j = i - w0; w = p.words1; }
+    else if (i < w2) { s = reinterpret_cast<const uint4*>(p.src2); d = reinterpret_cast<uint4*>(p.dst2); j = i - w1; w = p.words2; }
+    else { s = reinterpret_cast<const uint4*>(p.src3); d = reinterpret_cast<uint4*>(p.dst3); j = i - w2; w = p.words3; }
+    d[j] = s[step * (size_t)w + j];
+  }
+}
+
 }  // namespace
+
+int launch_step_slice(const ImagenStepSliceParams* p, hipStream_t s) {
+  IMAGEN_CHECK(p->step_ptr && p->words0 > 0 && p->src0 && p->dst0, "step_slice: null step_ptr / first segment");
+  IMAGEN_CHECK((!p->words1 || (p->src1 && p->dst1)) && (!p->words2 || (p->src2 && p->dst2)) && (!p->words3 || (p->src3 && p->dst3)),
+               "step_slice: a segment with words but no pointers");
+  const long tot = (long)p->words0 + p->words1 + p->words2 + p->words3;
+  hipLaunchKernelGGL(step_slice_kernel, dim3((unsigned)std::min<long>((tot + 255) / 256, 2048L)), dim3(256), 0, s, *p);
+  return imagen_hip_status("step_slice");
+}
 
 int launch_rowstat(const ImagenRowstatParams* p, hipStream_t s) {
   IMAGEN_CHECK(p->C1 % 8 == 0 && p->C2 % 8 == 0 && p->ld1 % 8 == 0, "rowstat: channels/stride must be multiples of 8");

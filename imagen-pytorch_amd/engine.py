@@ -126,6 +126,7 @@ class UnetEngine:
         self.taps: Dict[str, Act] = {}     # named intermediates (persistent buffers) for per-stage parity checks
         self._static_plans: Dict[int, tuple] = {}   # n_tok -> (plan, te16, mask_u8)
         self._cond_ready = False
+        self._tt_plan = None        # sampler mode: the batched all-steps pass of the timestep-only conditioning (enable_time_table)
         self._alloc_io()
         self.step_plan = self._build_step_plan()
 
@@ -304,7 +305,7 @@ class UnetEngine:
 
         # ---- now that every attention site is known: the per-step conditioning K/V ops, spliced in before the traversal
         dyn = Plan("kv-dynamic")
-        self._emit_context_kv(dyn, self.c_time, rows_per_batch=self.ntt, k_row0_self=0, k_row0_cross=1, tag="dyn")
+        self._dyn_proj = self._emit_context_kv(dyn, self.c_time, rows_per_batch=self.ntt, k_row0_self=0, k_row0_cross=1, tag="dyn")
         plan.ops[self._kv_dynamic_anchor:self._kv_dynamic_anchor] = dyn.ops
         plan.keep.extend(dyn.keep)
         plan._arr = None
@@ -728,11 +729,13 @@ class UnetEngine:
         selfs, crosses, ws, wc = self._ctx_weights()
         n = rows_per_batch
         jobs = []   # one K^/V^T job per site, all run by a single launch after the two projections
+        proj = {}   # the projections' output buffers (the per-step table of the sampler refills them: enable_time_table)
         if selfs:
             mu, rs = self.f32buf(R * n), self.f32buf(R * n)
             ops.rowstat(plan, c_rows, mode=1, rs=rs, mu=mu, eps=1e-5, label=f"ctx.{tag}.ln")
             st = self.new(1, 1, R * n, ws.Cout)
             ops.igemm(plan, c_rows, ws, st, mu=mu, rs=rs, label=f"ctx.{tag}.self")
+            proj["self"] = st
             col = 0   # to_context of site i yields (k | v) = 2 * dim_head columns
             for s in selfs:
                 d_ = s["dh"]
@@ -744,6 +747,7 @@ class UnetEngine:
         if crosses:
             st = self.new(1, 1, R * n, wc.Cout)
             ops.igemm(plan, c_rows, wc, st, label=f"ctx.{tag}.cross")
+            proj["cross"] = st
             col = 0  # sites differ in head count / head dim (the mid blocks are always 8 x 64, ip.py:1380-1382): cumulative column offsets
             for s in crosses:
                 d_ = s["dh"]
@@ -755,6 +759,7 @@ class UnetEngine:
             assert col == wc.Cout
         if jobs:
             ops.kv_prep_multi(plan, jobs, self.dev, label=f"kv_ctx.{tag}")
+        return proj
 
     def _emit_null_kv(self, plan):
         """learned null key/value (ip.py:545-547 self: after the context; ip.py:805-808 cross: first)."""
@@ -941,7 +946,80 @@ class UnetEngine:
             mask_u8.copy_(m)
         if not self.dry:
             plan.run()
+            if self._tt_plan is not None:
+                self._tt_plan.run()
         self._cond_ready = True
+
+    # the launches of the step plan that depend on the timestep and the conditioning only (not on x_t), by label
+    _TIME_CHAIN = ("time_embed", "to_time_cond", "to_time_tokens", "norm_cond(time)", "time_mlps", "scale_shift", "ctx.dyn.ln", "ctx.dyn.self",
+                   "ctx.dyn.cross")
+
+    def enable_time_table(self, coef: torch.Tensor, step_ptr: torch.Tensor) -> Optional[Plan]:
+        """Sampler mode: evaluate the timestep-only part of the denoiser — time embedding -> time conditioning / time tokens -> every
+        ResnetBlock's scale / shift, the time tokens' K / V projections of every attention site (nine launches of ~8 us each at the head of
+        every step, 1 workgroup each) — for ALL rows of the sampler's coefficient table in one batched pass per request (`_tt_plan`, run by
+        set_conditioning), and return the step plan in which one STEP_SLICE launch copies the current step's rows instead.  The batched
+        pass is the same kernels on `rows * steps` rows; the results are what the per-step launches compute."""
+        R, W, u = self.R, self.W, self.unet
+        NR = coef.shape[0]
+        if self._tt_plan is not None:
+            return self.step_plan_tt
+        rows_all = NR * R
+        tt = Plan("unet-time-table")
+        times_all = coef[:, 6].to(self.dev).float().repeat_interleave(R).contiguous()       # the log-SNR every step's time_embed reads
+        tc_all = self.new(1, 1, rows_all, self.Tc)
+        ops.rows_copy(tt, self.t_const.t, tc_all.t, B=NR, rows=R, C=self.Tc, src_bs=0, src_rs=self.Tc, dst_bs=R * self.Tc, dst_rs=self.Tc,
+                      label="tt.t_const")
+        hid = self.new(1, 1, rows_all, self.Tc)
+        ops.time_embed(tt, times=times_all, coef=None, step_ptr=None, freqs=W.f32("time.freqs", lambda: u.to_time_hiddens[0].weights),
+                       w=W.f32("time.w", lambda: u.to_time_hiddens[1].weight), bias=W.f32("time.b", lambda: u.to_time_hiddens[1].bias), hid=hid,
+                       label="tt.time_embed")
+        t_all = self.new(1, 1, rows_all, self.Tc)
+        ops.igemm(tt, hid, W.conv("time.cond", u.to_time_cond[0]), t_all, res=tc_all, label="tt.to_time_cond")
+        tok_raw = self.new(1, 1, rows_all, self.ntt * self.cond_dim)
+        ops.igemm(tt, hid, W.conv("time.tokens", u.to_time_tokens[0]), tok_raw, label="tt.to_time_tokens")
+        n_tok_rows = rows_all * self.ntt
+        c_time = self.new(1, 1, n_tok_rows, self.cond_dim)
+        tok_rows = Act(tok_raw.t, 1, 1, n_tok_rows, self.cond_dim, self.cond_dim, n_tok_rows * self.cond_dim)
+        ops.ln_residual(tt, tok_rows, W.f32("norm_cond.w", lambda: u.norm_cond.weight), c_time, beta=W.f32("norm_cond.b", lambda: u.norm_cond.bias),
+                        eps=1e-5, label="tt.norm_cond(time)")
+        tw, tb, gam, isc, ish, _, total_c = W.get("timemlp.tables", lambda: self._time_mlp_tables(self._all_resnet_blocks()))
+        ss = self.new(1, 1, rows_all, tw.shape[0])
+        ops.igemm(tt, t_all, W.raw("timemlp.w", tw, tb), ss, act_in=ACT_SILU, label="tt.time_mlps")
+        tab_pa, tab_ps = self.f32buf(rows_all, total_c), self.f32buf(rows_all, total_c)
+        ops.scale_shift(tt, ss, W.f32("timemlp.gam", lambda: gam), W.get("timemlp.isc", lambda: isc.to(self.dev)),
+                        W.get("timemlp.ish", lambda: ish.to(self.dev)), tab_pa, tab_ps, label="tt.scale_shift")
+        segments = [(tab_pa, self.pa2), (tab_ps, self.ps2)]
+        selfs, crosses, ws, wc = self._ctx_weights()
+        if selfs:
+            mu, rs = self.f32buf(n_tok_rows), self.f32buf(n_tok_rows)
+            ops.rowstat(tt, c_time, mode=1, rs=rs, mu=mu, eps=1e-5, label="tt.ctx.ln")
+            tab_self = self.new(1, 1, n_tok_rows, ws.Cout)
+            ops.igemm(tt, c_time, ws, tab_self, mu=mu, rs=rs, label="tt.ctx.self")
+            segments.append((tab_self.t, self._dyn_proj["self"].t))
+        if crosses:
+            tab_cross = self.new(1, 1, n_tok_rows, wc.Cout)
+            ops.igemm(tt, c_time, wc, tab_cross, label="tt.ctx.cross")
+            segments.append((tab_cross.t, self._dyn_proj["cross"].t))
+        # the step plan with the chain replaced by the copy of the current step's rows
+        one = Plan("slice")
+        ops.step_slice(one, segments, step_ptr, label="time_table_rows")
+        fast = Plan("unet-step-tt")
+        placed = False
+        for kind, st, label in self.step_plan.ops:
+            if label in self._TIME_CHAIN:
+                if not placed:
+                    fast.ops.append(one.ops[0])
+                    placed = True
+                continue
+            fast.ops.append((kind, st, label))
+        assert placed and len(fast.ops) == len(self.step_plan.ops) - sum(l in self._TIME_CHAIN for _, _, l in self.step_plan.ops) + 1
+        fast.keep = list(self.step_plan.keep) + list(one.keep) + [times_all]
+        self.step_plan_tt = fast
+        self._tt_plan = tt
+        if self._cond_ready and not self.dry:
+            tt.run()
+        return fast
 
     def bind_step_counter(self, coef: torch.Tensor, step_ptr: torch.Tensor):
         """Sampler mode: the time embedding reads log-SNR of the current step from the coef table (graph replay)."""

@@ -39,6 +39,7 @@ T5_DIMS = {  # d_model of the encoders the reference accepts by name (t5.py:47-5
 }
 DEFAULT_T5_NAME = 'google/t5-v1_1-base'
 
+TIME_TABLE = int(os.environ.get("IMAGEN_TIME_TABLE", "1"))   # A/B switch: the timestep-only conditioning of the image stages from a per-request table (engine.enable_time_table)
 _SAMPLING_DEVICE_TYPES = ('cuda',)   # where plans can be launched; tests/test_sample_cpu_replay.py widens it after replacing the launcher
 TAG_INIT, TAG_LOWRES = 0x7FFF0001, 0x7FFF0002  # RANDN counter tags (step noise uses the step index)
 
@@ -396,7 +397,12 @@ class Imagen(nn.Module):
             ops.lincomb(plan, known, eng.x_in, blend_coef, step_ptr, B=B, n_per_sample=n, t1=noise_blend, mask=mask, mask_else=eng.x_in,
                         stream_id=idx | 0x100, sample_offset=sample_offset, seed_ptr=seed_dev, label="inpaint.blend")
             extra = dict(known=known, mask=mask, noise_blend=noise_blend, noise_renoise=noise_renoise)
-        plan.extend(eng.step_plan)
+        # image stages without inpainting resampling: the timestep-only conditioning chain of the denoiser is evaluated for all steps at
+        # once per request (engine.enable_time_table), each step copies its rows
+        step_plan = eng.step_plan
+        if TIME_TABLE and not video and not R:
+            step_plan = eng.enable_time_table(coef, step_ptr) or step_plan
+        plan.extend(step_plan)
         ops.cfg_x0(plan, eng.x_in, eng.out, coef, step_ptr, x0, absx0, B=B, n_per_sample=n, cfg=cfg, cond_scale=float(cond_scale),
                    objective=self.pred_objectives[idx])
         dyn = bool(self.dynamic_thresholding[idx])

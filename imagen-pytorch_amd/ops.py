@@ -861,6 +861,24 @@ def scale_shift(plan: Plan, ss: Act, gamma_s, idx_scale, idx_shift, pa, ps, labe
     return p
 
 
+def step_slice(plan: Plan, segments, step_ptr: torch.Tensor, label: str = ""):
+    """segments: up to four (table, dst) tensor pairs; table = [steps, <dst's bytes>] (same dtype / element count per step as dst, a multiple
+    of 16 bytes): each launch copies row *step_ptr of every table into its dst (ImagenStepSliceParams)."""
+    assert 1 <= len(segments) <= 4
+    p = STRUCTS["ImagenStepSliceParams"]()
+    keep = [step_ptr]
+    for k, (tab, dst) in enumerate(segments):
+        nbytes = dst.numel() * dst.element_size()
+        assert nbytes % 16 == 0 and tab.dtype == dst.dtype and tab.is_contiguous() and dst.is_contiguous() and tab.numel() % dst.numel() == 0
+        setattr(p, f"src{k}", tab.data_ptr())
+        setattr(p, f"dst{k}", dst.data_ptr())
+        setattr(p, f"words{k}", nbytes // 16)
+        keep += [tab, dst]
+    p.step_ptr = step_ptr.data_ptr()
+    plan.add(p, label or "step_slice", keep)
+    return p
+
+
 def pack_image(plan: Plan, a: torch.Tensor, b: Optional[torch.Tensor], out: Act, brep: int, label: str = ""):
     p = STRUCTS["ImagenPackImageParams"]()
     B, Ca, H, W = a.shape

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define IMAGEN_ABI_VERSION 6 /* 3: head_dim in the attention / QNORM / KV_PREP params; 4: DDPM_UPDATE x0_thr; 5: GCA_TAIL; 6: ACT_PREP self_stat */
+#define IMAGEN_ABI_VERSION 6 /* 3: head_dim in the attention / QNORM / KV_PREP params; 4: DDPM_UPDATE x0_thr; 5: GCA_TAIL; 6: ACT_PREP self_stat, STEP_SLICE */
 
 typedef void* imagen_stream_t; /* hipStream_t */
 
@@ -63,7 +63,8 @@ enum ImagenOpKind {
   IMAGEN_OP_TEMPORAL_ATTENTION = 25, /* Imagen-Video: per-pixel causal attention over the frames, with a bias table    */
   IMAGEN_OP_ACT_PREP = 26,     /* the IGEMM prologue as its own pass: norm -> affine -> SiLU of a (two-tensor) input, written as fp16 */
   IMAGEN_OP_GCA_TAIL = 27,     /* ResnetBlock tail in ONE launch: GlobalContext finalisation + h*gate + res (+ statistics, + the next Block's activated input) */
-  IMAGEN_OP_KIND_COUNT = 28
+  IMAGEN_OP_STEP_SLICE = 28,   /* copy the current step's rows of up to four per-step tables (the timestep-only conditioning, computed for all steps at once) into the buffers the step's kernels read */
+  IMAGEN_OP_KIND_COUNT = 29
 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -375,6 +376,18 @@ typedef struct ImagenLincombParams {
   uint32_t seed_lo, seed_hi, stream_id;
   const float* mask; const float* mask_else;  /* optional fp32 [B, n_per_sample] 0/1 mask and the image kept where it is 0 */
 } ImagenLincombParams;
+
+/* STEP_SLICE — the part of the denoiser that depends on the timestep and the request's conditioning but NOT on x_t: time embedding ->
+ * time conditioning / time tokens (ip.py:1573-1578, 1588, 1660) -> every ResnetBlock's time-MLP scale / shift (ip.py:738-741) and the
+ * time tokens' key / value projections of every attention site (ip.py:527, 783).  The sampler evaluates it for ALL steps of a stage in
+ * one batched pass per request (tables [steps][words_k x 16 bytes], rows in the order of the sampler's coefficient table) and each
+ * step copies its row into the buffers the step's kernels read:   dst_k[0 .. 16 words_k) = src_k[*step_ptr * 16 words_k ..),  k < 4. */
+typedef struct ImagenStepSliceParams {
+  const void* src0; const void* src1; const void* src2; const void* src3;
+  void* dst0; void* dst1; void* dst2; void* dst3;
+  const int32_t* step_ptr;
+  int32_t words0, words1, words2, words3;   /* 16-byte words per step of each segment; 0 = segment unused */
+} ImagenStepSliceParams;
 
 /* ROWS_COPY — dst[b, r0 + r, :C] = src[b (or 0), r, :C]  (fp16). */
 typedef struct ImagenRowsCopyParams {

@@ -77,6 +77,18 @@ class Interpreter:
             fn(self, p)
             self.trace.append(label)
 
+    # ------------------------------------------------------------------------------------------------ STEP_SLICE
+    def step_slice(self, p):
+        m = self.mem
+        step = int(m.view(p.step_ptr, torch.int32)[0])
+        for k in range(4):
+            w = getattr(p, f"words{k}")
+            if not w:
+                continue
+            n = w * 16
+            src = m.view(getattr(p, f"src{k}") + step * n, torch.uint8)[:n]
+            m.view(getattr(p, f"dst{k}"), torch.uint8)[:n].copy_(src)
+
     # ------------------------------------------------------------------------------------------------ ACT_PREP
     def act_prep(self, p):
         m = self.mem
@@ -518,4 +530,5 @@ Interpreter.DISPATCH = {
     K["IMAGEN_OP_LINCOMB"]: Interpreter.lincomb, K["IMAGEN_OP_LOWRES_PREP"]: Interpreter.lowres_prep,
     K["IMAGEN_OP_TEMPORAL_PEG"]: Interpreter.temporal_peg, K["IMAGEN_OP_TEMPORAL_ATTENTION"]: Interpreter.temporal_attention,
     K["IMAGEN_OP_ACT_PREP"]: Interpreter.act_prep,
+    K["IMAGEN_OP_STEP_SLICE"]: Interpreter.step_slice,
 }

@@ -171,6 +171,27 @@ def test_sample_vs_reference_fixture():
         assert torch.equal(a, b), "hipGraph replay must be bit-identical to eager launches"
 
 
+def test_time_table_matches_per_step_chain(monkeypatch):
+    """The timestep-only conditioning of the image stages evaluated for all steps in one batched pass per request (engine.enable_time_table:
+    a STEP_SLICE copy per step) against the same launches at the head of every step (IMAGEN_TIME_TABLE=0): same kernels on more rows."""
+    from imagen_pytorch_amd import imagen as imagen_mod
+
+    dev = gpu_device()
+    g = _load("sample_tiny_cascade.pt")
+    outs = {}
+    for tt in (1, 0):
+        monkeypatch.setattr(imagen_mod, "TIME_TABLE", tt)
+        imagen = _tiny_cascade(g, dev, g["timesteps"])
+        outs[tt] = imagen.sample(text_embeds=g["text_embeds"].to(dev), cond_scale=g["cond_scale"], use_tqdm=False, return_all_unet_outputs=True,
+                                 noise_fn=lambda tag, shape: g["noise"][tag].to(dev))
+        st = next(iter(imagen._stages.values()))
+        assert any(l == "time_table_rows" for _, _, l in st['plan'].ops) == bool(tt)
+    errs = [nerr(a, b) for a, b in zip(outs[1], outs[0])]
+    from conftest import record_parity
+    record_parity("time_table_vs_per_step_chain", max_err=max(errs), bit_identical=all(torch.equal(a, b) for a, b in zip(outs[1], outs[0])))
+    assert max(errs) < 1e-3, errs     # (a chaotic sampler amplifies any last-bit difference of a GEMM's tile configuration; typically bit-identical)
+
+
 def test_reference_step_level_api(monkeypatch):
     """The reference's per-step methods (Imagen.p_sample_loop / p_sample / p_mean_variance, ip.py:2042-2289) on the GPU: the cascade
     strung together from single steps, fed the reference's recorded draws, against the reference's images and the graph path."""

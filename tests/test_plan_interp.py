@@ -350,6 +350,14 @@ def _dry_engines(monkeypatch):
     monkeypatch.setattr(engine, "UnetEngine", functools.partial(engine.UnetEngine, dry=True))
 
 
+def test_sampler_stage_plan_without_time_table(reference_weights, monkeypatch):
+    """The per-step conditioning chain inside the sampling plan (IMAGEN_TIME_TABLE=0; also what inpainting and the step-level API run)."""
+    from imagen_pytorch_amd import imagen as _im
+
+    monkeypatch.setattr(_im, "TIME_TABLE", 0)
+    test_sampler_stage_plan_on_cpu("plain", reference_weights, monkeypatch)
+
+
 def _stage0_loop(imagen, st, it, g, noise, *, resample_times=0, known=None, mask=None, init=None, skip=0):
     """The driver loop of Imagen.p_sample_loop for one stage (ip.py:2167-2289), with the per-step plan run by the interpreter."""
     eng, T = st['eng'], st['T']
@@ -409,6 +417,12 @@ def test_sampler_stage_plan_on_cpu(run, reference_weights, monkeypatch):
     for buf in (eng.x_in, eng.times, eng.lowres_times, eng.out, eng.keep_u8, eng.src_idx, eng.arange_idx, eng.t_const.t):
         it.mem.register(buf)
     it.run(eng._static_plans[te.shape[1]][0])
+    if eng._tt_plan is not None:               # the timestep-only conditioning of all steps in one batched pass (engine.enable_time_table)
+        assert run != "inpaint" and any(l == "time_table_rows" for _, _, l in st['plan'].ops)
+        it.run(eng._tt_plan)
+    else:
+        from imagen_pytorch_amd import imagen as _im
+        assert run == "inpaint" or not _im.TIME_TABLE   # (the inpainting plan's counter runs over inner iterations: it keeps the per-step chain)
     kw = {}
     if run == "init_skip":
         kw = dict(init=r["init_images"] * 2 - 1, skip=r["skip_steps"])
