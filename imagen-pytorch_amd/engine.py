@@ -93,6 +93,8 @@ def _fingerprint(unet) -> tuple:
 
 # ACT_PREP + all-DMA conv for the Blocks with at least this many output channels (the MFMA-bound layers: the prologue pass costs one
 # read + one write of the input, the conv kernel drops its staging instruction stream); 0 = never
+INIT_CONV_SHARED_MIN_PIXELS = 1 << 17   # ... of stages with at least this many distinct pixels (below, the two copies cost what the half launch saves)
+INIT_CONV_SHARED = int(os.environ.get("IMAGEN_INIT_CONV_SHARED", "1"))   # A/B switch: under CFG the init conv of the large stage runs on the B distinct images only
 BIG_PREP = int(os.environ.get("IMAGEN_BIG_PREP", "1"))   # A/B switch: ACT_PREP + conv_big for the Blocks conv_big applies to (else they keep the fused prologue)
 ACT_PREP_MIN_COUT = 0   # (measured in the model: the extra pass costs more than it saves — off)
 TAIL_FUSED = 1   # (module constant; measured in call B, profiles/r03_b_tail_ab.jsonl) GCA_FINAL + GATE_RESIDUAL of an identity ResnetBlock as one GCA_TAIL launch
@@ -349,7 +351,24 @@ class UnetEngine:
             return ops.pack_weight(spread(conv.weight.detach().float()), conv.bias.detach().float(), self.dev, G=1)
 
         out.ssq = self.f32buf(out.rows)
-        op = ops.igemm(plan, self.img, self.W.get("init_conv", make), out, x2=self.cimg, ssq_out=out.ssq, label="init_conv")
+        R, B = self.R, self.src_batch
+        px = out.H * out.W
+        # classifier-free guidance runs rows [B, 2B) on the SAME image: nothing conditions the init conv (ip.py:1562), so it is computed
+        # for the first B rows and copied — on the 256^2 stage half of a 150 us launch against two copies of 17 + 5 us
+        shared = (INIT_CONV_SHARED and R == 2 * B and B * px >= INIT_CONV_SHARED_MIN_PIXELS and out.ld == out.C and out.bs == px * out.C and px % 4 == 0)
+        if shared:
+            half = lambda a: Act(a.t, B, a.H, a.W, a.C, a.ld, a.bs, a.off)
+            op = ops.igemm(plan, half(self.img), self.W.get("init_conv", make), half(out), x2=half(self.cimg) if self.cimg is not None else None,
+                           ssq_out=out.ssq, label="init_conv")
+            ops.rows_copy(plan, out.t, out.t, B=1, rows=B * px, C=out.C, src_bs=0, src_rs=out.C, dst_bs=0, dst_rs=out.C, src_off=out.off,
+                          dst_off=out.off + B * px * out.C, label="init_conv.cfg_rows")
+            if op.ssq_emitted:   # the statistics too: fp32 [rows] seen as rows of 4 floats (8 halves)
+                ssq16 = out.ssq.view(torch.float16)
+                ops.rows_copy(plan, ssq16, ssq16, B=1, rows=B * px // 4, C=8, src_bs=0, src_rs=8, dst_bs=0, dst_rs=8, src_off=0, dst_off=2 * B * px,
+                              label="init_conv.cfg_rows.ssq")
+                plan.keep.append(out.ssq)
+        else:
+            op = ops.igemm(plan, self.img, self.W.get("init_conv", make), out, x2=self.cimg, ssq_out=out.ssq, label="init_conv")
         if not op.ssq_emitted:
             out.ssq = None
 

@@ -59,6 +59,20 @@ def test_unet_plan_on_cpu_matches_reference_fixture(name, cfg_rows, reference_we
     assert len(it.trace) == len(eng.step_plan) + len(eng._static_plans[g["text_embeds"].shape[1]][0])
 
 
+@pytest.mark.parametrize("name", ["unet_tiny_base.pt", "unet_tiny_sr.pt"])
+def test_unet_plan_init_conv_shared_between_cfg_rows(name, reference_weights, monkeypatch):
+    """Under classifier-free guidance the init conv runs on the B distinct images and its output (+ statistics) is copied to the null rows
+    (engine._init_conv; on the GPU only the large stages take that path): forced onto the tiny fixtures."""
+    from imagen_pytorch_amd import engine, ops
+
+    monkeypatch.setattr(engine, "INIT_CONV_SHARED_MIN_PIXELS", 1)
+    seen = []
+    real = ops.rows_copy
+    monkeypatch.setattr(ops, "rows_copy", lambda plan, *a, **k: (seen.append(k.get("label")), real(plan, *a, **k))[1])
+    test_unet_plan_on_cpu_matches_reference_fixture(name, True, reference_weights)
+    assert "init_conv.cfg_rows" in seen, seen
+
+
 @pytest.mark.parametrize("tag", ["base", "sr"])
 @pytest.mark.parametrize("mode", ["cond", "cfg", "ignore_time"])
 def test_unet3d_plan_on_cpu_matches_reference_fixture(tag, mode, reference_weights):
