@@ -301,8 +301,8 @@ __global__ __launch_bounds__(512, 1) void conv_big_kernel(const ImagenIgemmParam
   //
   // vmcnt budget of the wait in phase s = (chunk, dy) for stage s + 1 (issued in phase s + 2 - WR): younger are the pieces of the
   // phases s + 3 - WR .. s - 1 — KD weight pieces each, and NJ halo pieces ahead of them in the phases with dy = 0.  The halo of
-  // chunk c + 1 (first read behind the barrier of phase (c, 2)) is older than stage 3 c + 3: issued in phase (c + 2 - HR, 0), ahead of
-  // that phase's weight pieces, and 3 (HR - 2) >= ... holds for every (WR, HR) instantiated below (static_assert).
+  // chunk c + 1 (first read behind the barrier of phase (c, 2), whose wait is for stage 3 c + 3) needs no count of its own: it is issued
+  // in phase 3 (c + 2 - HR), ahead of that phase's weight pieces, stage 3 c + 3 in phase 3 c + 4 - WR — not earlier iff WR <= 3 HR - 2.
   static_assert(3 * (HR - 1) + 1 >= WR, "the next chunk's halo must be issued no later than the stage that follows it");
   for (int c = 0; c < NC; ++c) {
     cb_static_for<3>([&](auto dyc) __attribute__((always_inline)) {
