@@ -355,6 +355,57 @@ def test_unet_plan_with_big_tile_family(reference_weights, monkeypatch):
     assert seen["self_stat"] >= 1, seen
 
 
+@pytest.mark.parametrize("name", ["unconditional", "memory_efficient_lowres", "four_time_tokens_init_dim", "no_attn_pool", "head_dim_32",
+                                  "three_levels_no_gca", "self_cond"])
+def test_time_table_plan_equals_per_step_chain(name, reference_weights):
+    """engine.enable_time_table over constructor-flag combinations: the batched all-steps pass + one STEP_SLICE copy per step gives the step
+    plan exactly what the per-step conditioning chain computes (same op contracts on more rows), for several rows of a coefficient table."""
+    from imagen_pytorch_amd import Unet
+    from imagen_pytorch_amd.engine import UnetEngine
+    from plan_interp import Interpreter
+    from unet_config_sweep import SWEEP, cond_images_for, self_cond_for
+
+    kw = SWEEP[name]
+    torch.manual_seed(1)
+    u = Unet(**kw).eval()
+    torch.nn.init.normal_(u.final_conv.weight, std=0.05)
+    B, S = 2, 16
+    torch.manual_seed(5)
+    x = torch.randn(B, 3, S, S)
+    with_text = kw.get("cond_on_text", True)
+    te = torch.randn(B, 7, kw["text_embed_dim"]) if with_text else None
+    lowres = dict(lowres_cond_img=torch.randn(B, 3, S, S), lowres_noise_times=torch.tensor([0.9, 0.9])) if kw.get("lowres_cond") else {}
+    eng = UnetEngine(u, 2 * B, B, S, "cpu", with_text=with_text, dry=True)
+    keep = torch.ones(2 * B, dtype=torch.bool)
+    keep[B:] = False
+    eng.set_conditioning(text_embeds=te, text_mask=None, keep=keep, lowres_noise_times=lowres.get("lowres_noise_times"))
+    it = Interpreter()
+    for buf in (eng.x_in, eng.lowres_in, eng.times, eng.lowres_times, eng.out, eng.keep_u8, eng.src_idx, eng.arange_idx, eng.t_const.t, eng.self_cond_in):
+        if buf is not None:
+            it.mem.register(buf)
+    it.run(eng._static_plans[te.shape[1] if with_text else 0][0])
+    if eng.self_cond_in is not None:
+        eng.set_self_cond(self_cond_for(kw, B))
+    coef = torch.zeros(5, 8)
+    coef[:, 6] = torch.tensor([2.5, 0.7, -0.4, -1.9, -3.3])          # the log-SNR column the time embedding reads
+    step_ptr = torch.zeros(1, dtype=torch.int32)
+    fast = eng.enable_time_table(coef, step_ptr)
+    assert fast is not None and len(fast) == len(eng.step_plan) - sum(l in eng._TIME_CHAIN for _, _, l in eng.step_plan.ops) + 1
+    it.mem.register(step_ptr)
+    it.run(eng._tt_plan)
+    eng.x_in.copy_(x)
+    if eng.lowres:
+        eng.lowres_in.copy_(lowres["lowres_cond_img"])
+    for row in (0, 3, 4):
+        step_ptr.fill_(row)
+        it.run(fast)
+        got = eng.out.clone()
+        eng.out.zero_()
+        eng.times.fill_(float(coef[row, 6]))
+        it.run(eng.step_plan)
+        assert torch.equal(got, eng.out), (name, row, nerr(got, eng.out))
+
+
 def _dry_engines(monkeypatch):
     """Make Imagen._stage build its engines on CPU memory without launching (test-side patch; the product has no such switch)."""
     import functools
