@@ -355,6 +355,16 @@ def test_unet_plan_with_big_tile_family(reference_weights, monkeypatch):
     assert seen["self_stat"] >= 1, seen
 
 
+@pytest.mark.parametrize("name", ["cond_images_3", "self_cond_lowres_cond_images_5", "plain_init_conv_no_mid_attn", "memory_efficient_lowres"])
+def test_init_conv_shared_between_cfg_rows_config_sweep(name, reference_weights, monkeypatch):
+    """The init conv on the B distinct images (+ row copies) with a second input tensor (conditioning image / self-conditioning), a plain
+    7x7 init conv and the memory-efficient layout, vs the oracle (threshold lowered: on the GPU only the large stages take the path)."""
+    from imagen_pytorch_amd import engine
+
+    monkeypatch.setattr(engine, "INIT_CONV_SHARED_MIN_PIXELS", 1)
+    test_unet_plan_config_sweep(name, reference_weights)
+
+
 @pytest.mark.parametrize("name", ["unconditional", "memory_efficient_lowres", "four_time_tokens_init_dim", "no_attn_pool", "head_dim_32",
                                   "three_levels_no_gca", "self_cond"])
 def test_time_table_plan_equals_per_step_chain(name, reference_weights):
