@@ -179,6 +179,12 @@ class ElucidatedImagen(Imagen):
         step_ptr = torch.zeros(1, dtype=torch.int32, device=dev)
         seed_dev = torch.zeros(2, dtype=torch.int32, device=dev)
         eng.bind_step_counter(coef, step_ptr)
+        # image stages without inpainting resampling: the timestep-only conditioning chain of both denoiser evaluations of a step comes out
+        # of the per-request table (engine.enable_time_table; the table has this sampler's 2T evaluation rows)
+        from . import imagen as _imagen
+        step_plan = eng.step_plan
+        if _imagen.TIME_TABLE and not R and hasattr(eng, "enable_time_table"):
+            step_plan = eng.enable_time_table(coef, step_ptr) or step_plan
         mk = lambda: torch.empty_like(eng.x_in)
         x, xhat, xnext, x0a, x0b, absx0, final = mk(), mk(), mk(), mk(), mk(), mk(), mk()
         qa, qb = torch.empty(B, device=dev), torch.empty(B, device=dev)
@@ -202,7 +208,7 @@ class ElucidatedImagen(Imagen):
             if R:
                 ops.lincomb(plan, extra['known'], x, w_one, zero_ptr, mask=extra['mask'], mask_else=x, label="edm.inpaint.blend", **kw)
             ops.lincomb(plan, x, xhat, w_hat, step_ptr, t1=noise, out2=eng.x_in, label="edm.x_hat", **kw)
-            plan.extend(eng.step_plan)
+            plan.extend(step_plan)
             ops.cfg_x0(plan, xhat, eng.out, coef, step_ptr, x0a, absx0, B=B, n_per_sample=n, cfg=cfg, cond_scale=float(cond_scale),
                        objective="noise", label="edm.precond")
             if dyn:
@@ -212,7 +218,7 @@ class ElucidatedImagen(Imagen):
         first_eval(full)
         ops.lincomb(full, xhat, xnext, w_euler, step_ptr, t1=x0a, q1=qa if dyn else None, out2=eng.x_in, thr_mode=thr, advance=True,
                     label="edm.euler", **kw)
-        full.extend(eng.step_plan)
+        full.extend(step_plan)
         ops.cfg_x0(full, xnext, eng.out, coef, step_ptr, x0b, absx0, B=B, n_per_sample=n, cfg=cfg, cond_scale=float(cond_scale),
                    objective="noise", label="edm.precond2")
         if dyn:

@@ -49,6 +49,11 @@ def _w2d(mod):
 
 
 class UnetEngine3D(UnetEngine):
+
+    def enable_time_table(self, coef, step_ptr):
+        """(The per-request time table of the image engine is not built for the video plan: its step keeps the per-step chain.)"""
+        return None
+
     def __init__(self, unet, rows: int, src_batch: int, frames: int, size: int, device, with_text: bool = True, ignore_time: bool = False,
                  dry: bool = False, pre_frames: int = 0, post_frames: int = 0):
         self.Fx, self.Fpre, self.Fpost = frames, pre_frames, post_frames   # frames of the sampler state / of the two prompts

@@ -590,6 +590,8 @@ def test_elucidated_stage_plan_on_cpu(reference_weights, monkeypatch):
     for buf in (eng.x_in, eng.times, eng.lowres_times, eng.out, eng.keep_u8, eng.src_idx, eng.arange_idx, eng.t_const.t, x, st['final']):
         it.mem.register(buf)
     it.run(eng._static_plans[te.shape[1]][0])
+    assert eng._tt_plan is not None and sum(l == "time_table_rows" for _, _, l in st['plan'].ops) == 2   # both evaluations of a Heun step
+    it.run(eng._tt_plan)                       # the timestep-only conditioning of all 2T evaluations in one batched pass
     x.copy_(g["noise"][("init", 0)] * float(st['w_init'][0, 0]))        # images = init_sigma * randn (el.py:440-442)
     st['step_ptr'].zero_()
     for i in range(T):
