@@ -106,11 +106,6 @@ __global__ __launch_bounds__(512, 1) void conv_big_kernel(const ImagenIgemmParam
   static_assert(EPP0 >= PIPE && EPP0 >= STG0 + TP * (2 * BN + 16), "LDS layout");
   constexpr int PXW = 32 * MI;
 
-#ifdef CB_ABLATE   // bench-only library (tools/conv_bench.py --ablate): timing ablations selected by the otherwise unused p.pstride; results are garbage
-  const unsigned abl = (unsigned)p.pstride;
-#else
-  constexpr unsigned abl = 0;
-#endif
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -240,7 +235,7 @@ __global__ __launch_bounds__(512, 1) void conv_big_kernel(const ImagenIgemmParam
   // ================================================================================================ pipeline
   // Instruction warm-up (common.h) and L2 warm-up of the weights (conv_dma.hip: the workgroups of an XCD — blockIdx % 8 by observation; only
   // speed depends on it — each touch their share of the packed weights once, one dword per 128-byte line, into a sink nobody reads)
-  const unsigned warm = imagen_code_warm(((unsigned)p.dbg >> 16) << 8, tid, 512);
+  const unsigned warm = imagen_code_warm((unsigned)p.launcher_word << 8, tid, 512);
   {
     const size_t wbytes = (size_t)(NC * 36) * wrow;
     const unsigned nloc = (gridDim.x + 7) >> 3, lw = blockIdx.x >> 3;
@@ -329,19 +324,19 @@ __global__ __launch_bounds__(512, 1) void conv_big_kernel(const ImagenIgemmParam
         cb_static_for<4>([&](auto gc) __attribute__((always_inline)) {
           constexpr int g = decltype(gc)::value;
           constexpr int ni = g / MI, mi = g % MI;
-          if (!(abl & 8)) acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[ni], cur.b[mi], acc[ni][mi], 0, 0, 0);
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(cur.a[ni], cur.b[mi], acc[ni][mi], 0, 0, 0);
           __builtin_amdgcn_sched_barrier(0);
           if constexpr (k == SYNC_K && g == 0) {
-            if (!(abl & 2)) {
+            {
               CB_WAIT_VM(N_WAIT);   // this wave's pieces of the next stage (and of the next chunk's halo tile) have landed
               CB_BARRIER();         // ... everybody's have; nobody reads the previous stage (or, dy = 0, the previous chunk's halo) any more
             }
           }
-          if (!(abl & 4)) read_frag(nx, g, dy2, dx2, ks2, cross ? wnext : wcur, (cross && dy == 2) ? hnext : hcur);
+          read_frag(nx, g, dy2, dx2, ks2, cross ? wnext : wcur, (cross && dy == 2) ? hnext : hcur);
           // refill: piece slots are (SYNC_K, g = 1..3) and (SYNC_K + 1, g = 0..3)
           constexpr int slot = k == SYNC_K ? g - 1 : (k == SYNC_K + 1 ? 3 + g : -1);
           if constexpr (slot >= 0 && slot < NPIECE) {
-            if (!(abl & 1)) {
+            {
               if constexpr (dy == 0 && slot < NJ) dma_act_piece(slot);
               else dma_weight_piece(slot - (dy == 0 ? NJ : 0));
             }
@@ -379,7 +374,6 @@ __global__ __launch_bounds__(512, 1) void conv_big_kernel(const ImagenIgemmParam
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[ni][mi][r] += red[((wq * 4 + ni * MI + mi) * 16 + r) * 64 + lane];
   }
-  if (abl & 16) return;
   imagen_code_warm_sink(warm);
   float* const ep_par = reinterpret_cast<float*>(smem + EPP0);
   float* const ep_red = ep_par + (4 * BN + NQ * PXW + 8 + WM * (BN + 4));
@@ -434,7 +428,7 @@ int cb_launch_gen(const ImagenIgemmParams& p, hipStream_t s) {
     return std::min(imagen_kernel_code_bytes(name) >> 8, 0xffffu);
   }();
   ImagenIgemmParams q = p;
-  q.dbg = (int)(((unsigned)q.dbg & 0xffffu) | (code_q << 16));
+  q.launcher_word = (int)code_q;
   hipLaunchKernelGGL(kern, dim3(total), dim3(512), lds, s, q);
   return imagen_hip_status("conv_big launch");
 }

@@ -125,7 +125,7 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
   const int tid = threadIdx.x;
   const bool producer = tid >= 256;   // wave-uniform role
   const int rtid = tid & 255;         // thread index inside the role
-  const unsigned warm = imagen_code_warm(((unsigned)p.dbg >> 16) << 8, tid, 512);   // (code size / 256 rides in the upper half of dbg)
+  const unsigned warm = imagen_code_warm((unsigned)p.launcher_word << 8, tid, 512);   // (code size / 256, set by the launcher)
 
   // ---- the tile list of this workgroup
   const int tilesX = (p.OW + p.TW - 1) / p.TW;
@@ -133,7 +133,7 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
   const int tilesN = (p.Cout + BN - 1) / BN;
   const int total_tiles = p.B * tilesY * tilesX * tilesN;
   int t_cursor, t_end, t_step;
-  if ((gridDim.x & 7) == 0 && !(p.dbg & 64)) {
+  if ((gridDim.x & 7) == 0) {
     const int xcd = blockIdx.x & 7, lw = blockIdx.x >> 3;
     const int per_xcd = (total_tiles + 7) >> 3;
     t_cursor = xcd * per_xcd + lw;
@@ -593,7 +593,7 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
               const imagen_u32x4 v = imagen_pair_quads(pout[ni][q][mi], pout[ni][q + 2][mi]);
-              if (co < p.Cout && opx[mi] >= 0 && !(p.dbg & 8)) *reinterpret_cast<imagen_u32x4*>(y + (size_t)b * p.bsy + (size_t)opx[mi] * p.ldy + co) = v;
+              if (co < p.Cout && opx[mi] >= 0) *reinterpret_cast<imagen_u32x4*>(y + (size_t)b * p.bsy + (size_t)opx[mi] * p.ldy + co) = v;
             }
           }
         return;
@@ -606,7 +606,7 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
           if (co >= p.Cout) continue;
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi)
-            if (opx[mi] >= 0 && !(p.dbg & 8)) *reinterpret_cast<f16x4*>(y + (size_t)b * p.bsy + (size_t)opx[mi] * p.ldy + co) = pout[ni][q][mi];
+            if (opx[mi] >= 0) *reinterpret_cast<f16x4*>(y + (size_t)b * p.bsy + (size_t)opx[mi] * p.ldy + co) = pout[ni][q][mi];
         }
       return;
     }
@@ -651,7 +651,7 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi) {
               const imagen_u32x4 v = imagen_pair_quads(pv[ni][q][mi], pv[ni][q + 2][mi]);
-              if (co < p.Cout && op[mi] >= 0 && !(p.dbg & 8)) *reinterpret_cast<imagen_u32x4*>(y + (size_t)op[mi] * p.ldy + co) = v;
+              if (co < p.Cout && op[mi] >= 0) *reinterpret_cast<imagen_u32x4*>(y + (size_t)op[mi] * p.ldy + co) = v;
             }
           }
       } else {
@@ -662,7 +662,7 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
             const int co = n0 + (wn * NI + ni) * 32 + 8 * q + 4 * half;
 #pragma unroll
             for (int mi = 0; mi < MI; ++mi)
-              if (co < p.Cout && op[mi] >= 0 && !(p.dbg & 8)) *reinterpret_cast<f16x4*>(y + (size_t)op[mi] * p.ldy + co) = pv[ni][q][mi];
+              if (co < p.Cout && op[mi] >= 0) *reinterpret_cast<f16x4*>(y + (size_t)op[mi] * p.ldy + co) = pv[ni][q][mi];
           }
       }
     } else {
@@ -692,10 +692,10 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
     const f16* eop = addend ? addend + (size_t)b * p.bs_add : (res ? res + (size_t)b * p.bs_res : nullptr);
     const int eld = addend ? p.ld_add : p.ld_res;
     const bool wide = p.out_mode == IMAGEN_OUT_NHWC && ((p.Cout | p.ldy | eld) & 7) == 0 && (p.bsy & 7) == 0 &&
-                      (((size_t)p.y | (size_t)eop) & 15) == 0 && !(p.dbg & 256);
+                      (((size_t)p.y | (size_t)eop) & 15) == 0;
     // pixel-shuffle outputs in 16-byte pieces too: 8 consecutive packed couts (s1, s2, c) share their sub-pixel when Cout / 4 is a multiple of 8
     const bool wide_ps = p.out_mode == IMAGEN_OUT_PIXEL_SHUFFLE && (p.Cout & 31) == 0 && (p.ldy & 7) == 0 && (p.bsy & 7) == 0 &&
-                         ((size_t)p.y & 15) == 0 && !(p.dbg & 256);
+                         ((size_t)p.y & 15) == 0;
     if (wide && eop) {
       imagen_u32x4 raw[NI][2][MI];
 #pragma unroll
@@ -793,7 +793,7 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
 #pragma unroll
           for (int mi = 0; mi < MI; ++mi) {
             const imagen_u32x4 v = imagen_pair_quads(outv[ni][qp][mi], outv[ni][qp + 2][mi]);
-            if (cx < p.Cout && op[mi] >= 0 && !(p.dbg & 8)) *reinterpret_cast<imagen_u32x4*>(y + (size_t)op[mi] * p.ldy + cx) = v;
+            if (cx < p.Cout && op[mi] >= 0) *reinterpret_cast<imagen_u32x4*>(y + (size_t)op[mi] * p.ldy + cx) = v;
           }
         }
     } else if (wide_ps) {
@@ -832,7 +832,7 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
               const int yy = 2 * oy + (sub >> 1), xx = 2 * ox + (sub & 1);
               *reinterpret_cast<f16x4*>(y + (size_t)b * p.bsy + ((size_t)yy * (2 * p.OW) + xx) * p.ldy + c) = outv[ni][q][mi];
             } else {
-              if (!(p.dbg & 8)) *reinterpret_cast<f16x4*>(y + (size_t)b * p.bsy + (size_t)op[mi] * p.ldy + co) = outv[ni][q][mi];   // dbg 8: ablate the stores
+              *reinterpret_cast<f16x4*>(y + (size_t)b * p.bsy + (size_t)op[mi] * p.ldy + co) = outv[ni][q][mi];
             }
           }
         }
@@ -903,7 +903,7 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
     const int t_next = t_cursor + t_step;
     const int n0_next = t_next < t_end ? decode(t_next).n0 : tc.n0;
     for (int chunk = 0; chunk < NC; ++chunk) {
-      if (!(p.dbg & 2)) compute(smem + cur * buf_bytes);
+      compute(smem + cur * buf_bytes);
       lds_barrier();   // done with buf[cur]; the producers have filled buf[cur^1]
       cur ^= 1;
     }
@@ -981,8 +981,8 @@ int launch_gen(const ImagenIgemmParams& p, hipStream_t s) {
   // call C: sequential +7 %, lanes throughput unchanged — not kept)
   const int resident = std::max(8, num_cus() * occ_blocks / 8 * 8);
   int gx;
-  if ((p.dbg & 32) || total <= resident) {
-    gx = total;                                    // dbg 32: one tile per workgroup (no cross-tile pipelining)
+  if (total <= resident) {
+    gx = total;
   } else {
     const int rounds = (total + resident - 1) / resident;
     gx = (total + rounds - 1) / rounds;
@@ -996,7 +996,7 @@ int launch_gen(const ImagenIgemmParams& p, hipStream_t s) {
     return std::min(imagen_kernel_code_bytes(name) >> 8, 0xffffu);
   }();
   ImagenIgemmParams q = p;
-  q.dbg = (int)(((unsigned)q.dbg & 0xffffu) | (code_q << 16));
+  q.launcher_word = (int)code_q;
   hipLaunchKernelGGL(kern, dim3(gx), dim3(512), lds, s, q);
   return imagen_hip_status("igemm launch");
 }

@@ -59,7 +59,13 @@ class Weights:
             self.cache[key] = make()
         return self.cache[key]
 
-    def conv(self, key, mod: nn.Module, in_scale=None, G=None, cin_pad_to=None, out_perm=None):
+    def conv(self, key, mod: nn.Module, in_scale=None, G=None, cin_pad_to=None, out_perm=None, split=False):
+        """split: the split-precision form of the weight (ops.pack_weight) where the layer's input channels allow it."""
+        if split and mod.weight.shape[1] % 8 == 0 and cin_pad_to is None:
+            key = key + "|split"
+        else:
+            split = False
+
         def make():
             w, b = mod.weight.detach().float(), (mod.bias.detach().float() if mod.bias is not None else None)
             if w.ndim == 2:
@@ -74,11 +80,12 @@ class Weights:
             if in_scale is not None:
                 sc = torch.ones(w.shape[1])
                 sc[: in_scale.numel()] = in_scale
-            return ops.pack_weight(w, b, self.dev, in_scale=sc, G=G)
+            return ops.pack_weight(w, b, self.dev, in_scale=sc, G=G, split=split)
         return self.get(key, make)
 
-    def raw(self, key, w, b, G=None):
-        return self.get(key, lambda: ops.pack_weight(w, b, self.dev, G=G))
+    def raw(self, key, w, b, G=None, split=False):
+        split = bool(split and w.shape[1] % 8 == 0)
+        return self.get(key + ("|split" if split else ""), lambda: ops.pack_weight(w, b, self.dev, G=G, split=split))
 
     def f32(self, key, t_fn):
         return self.get(key, lambda: _f32(t_fn(), self.dev))
@@ -100,6 +107,22 @@ ACT_PREP_MIN_COUT = 0   # (measured in the model: the extra pass costs more than
 TAIL_FUSED = 1   # (module constant; measured in call B, profiles/r03_b_tail_ab.jsonl) GCA_FINAL + GATE_RESIDUAL of an identity ResnetBlock as one GCA_TAIL launch
 TAIL_ACT = 1     # (module constant; call B) ... which also writes the next block1's activated input
 LN_STATS_FUSED = 1   # (module constant; call B) LayerNorm statistics from the producing launch (GCA_TAIL / LN_RESIDUAL) instead of a ROWSTAT pass
+
+
+# Split-precision weights (ops.pack_weight(split=True): the fp32 weight as two fp16 MFMA operands, the input read twice) where the doubled K
+# costs nothing that matters — measured with tools/parity_budget.py (the plan interpreter against the oracle; README unet1 null branch):
+#  * SPLIT_STATIC: everything that runs once per request (text projection, Perceiver resampler, text hiddens, the K / V projections of the
+#    conditioning tokens) and the timestep-only chain (time embedding -> time conditioning / tokens -> the ResnetBlocks' scale / shift; one
+#    batched pass per request in sampler mode, R-row GEMMs otherwise).  The null branch's conditioning is input-independent, so the rounding
+#    error of these weights is the SAME vector in every null row: a bias, not noise — 1.11e-3 -> 0.99e-3 on the null rows of README unet1.
+#  * SPLIT_SMALL: block1 of the 32-channel ResnetBlocks and the final conv of stages whose launches are latency-bound (<= SPLIT_SMALL_FLOPS
+#    executed FLOPs): the layers next to the output, whose weight rounding reaches it unattenuated (0.99e-3 -> 0.94e-3).
+SPLIT_STATIC = int(os.environ.get("IMAGEN_SPLIT_STATIC", "1"))
+SPLIT_SMALL = int(os.environ.get("IMAGEN_SPLIT_SMALL", "1"))
+SPLIT_SMALL_MAX_K = int(os.environ.get("IMAGEN_SPLIT_MAX_K", "320"))        # taps * input channels of the unsplit weight
+SPLIT_1X1 = int(os.environ.get("IMAGEN_SPLIT_1X1", "0"))
+SPLIT_BLOCK2 = int(os.environ.get("IMAGEN_SPLIT_BLOCK2", "0"))
+SPLIT_SMALL_FLOPS = 3.0e9      # 2 * pixels * Cout * (2 K) of the split launch
 
 
 class UnetEngine:
@@ -138,6 +161,10 @@ class UnetEngine:
 
     def new(self, B, H, W, C, zero=False) -> Act:
         return ops.new_act(B, H, W, C, self.dev, zero=zero)
+
+    def _split_small(self, Cin: int, taps: int, Cout: int, pixels: int) -> bool:
+        """A split-precision weight for this launch (SPLIT_SMALL above)?"""
+        return bool(SPLIT_SMALL and Cin % 8 == 0 and taps * Cin <= SPLIT_SMALL_MAX_K and 4.0 * pixels * Cout * taps * Cin <= SPLIT_SMALL_FLOPS)
 
     def f32buf(self, *shape, zero=False):
         return (torch.zeros if zero else torch.empty)(*shape, dtype=torch.float32, device=self.dev)
@@ -224,10 +251,10 @@ class UnetEngine:
             freqs=W.f32("time.freqs", lambda: u.to_time_hiddens[0].weights), w=W.f32("time.w", lambda: u.to_time_hiddens[1].weight),
             bias=W.f32("time.b", lambda: u.to_time_hiddens[1].bias), hid=self.hid, label="time_embed")
         self.t = self.new(1, 1, R, self.Tc)
-        ops.igemm(plan, self.hid, W.conv("time.cond", u.to_time_cond[0]), self.t, res=self.t_const, label="to_time_cond")
+        ops.igemm(plan, self.hid, W.conv("time.cond", u.to_time_cond[0], split=SPLIT_STATIC), self.t, res=self.t_const, label="to_time_cond")
         # time tokens -> norm_cond (ip.py:1577, 1660)
         tok_raw = self.new(1, 1, R, self.ntt * self.cond_dim)
-        ops.igemm(plan, self.hid, W.conv("time.tokens", u.to_time_tokens[0]), tok_raw, label="to_time_tokens")
+        ops.igemm(plan, self.hid, W.conv("time.tokens", u.to_time_tokens[0], split=SPLIT_STATIC), tok_raw, label="to_time_tokens")
         self.c_time = self.new(1, 1, R * self.ntt, self.cond_dim)
         tok_rows = Act(tok_raw.t, 1, 1, R * self.ntt, self.cond_dim, self.cond_dim, R * self.ntt * self.cond_dim)
         ops.ln_residual(plan, tok_rows, W.f32("norm_cond.w", lambda: u.norm_cond.weight), self.c_time,
@@ -239,7 +266,7 @@ class UnetEngine:
         tw, tb, gam, isc, ish, self._blk_off, total_c = W.get("timemlp.tables", lambda: self._time_mlp_tables(blocks))
         self.total_c = total_c
         ss = self.new(1, 1, R, tw.shape[0])
-        ops.igemm(plan, self.t, W.raw("timemlp.w", tw, tb), ss, act_in=ACT_SILU, label="time_mlps")
+        ops.igemm(plan, self.t, W.raw("timemlp.w", tw, tb, split=SPLIT_STATIC), ss, act_in=ACT_SILU, label="time_mlps")
         self.pa2 = self.f32buf(R, total_c)
         self.ps2 = self.f32buf(R, total_c)
         ops.scale_shift(plan, ss, W.f32("timemlp.gam", lambda: gam), W.get("timemlp.isc", lambda: isc.to(self.dev)),
@@ -376,12 +403,14 @@ class UnetEngine:
         """final_conv over cat(x, lowres_cond_img) (ip.py:1722-1725) -> fp32 NCHW."""
         u = self.unet
         extra = self.img if self.lowres else None  # channels [C, 2C) of the packed image are the low-res image
+        kh = u.final_conv.weight.shape[-1]
+        split = extra is None and self._split_small(x.C, kh * kh, u.final_conv.weight.shape[0], x.rows)
 
         def make():
             w = u.final_conv.weight.detach().float()
             co, ci, kh, kw = w.shape
             if extra is None:
-                return ops.pack_weight(w, u.final_conv.bias.detach().float(), self.dev)
+                return ops.pack_weight(w, u.final_conv.bias.detach().float(), self.dev, split=split)
             wp = torch.zeros(co, x.C + 8, kh, kw)
             wp[:, : x.C] = w[:, : x.C]
             # packed image channel layout: [x (C) | lowres (C) | zero pad]; the reference concatenates lowres after the features
@@ -391,7 +420,7 @@ class UnetEngine:
             G = 4 if x.C % 32 == 0 else None
             return ops.pack_weight(wp, u.final_conv.bias.detach().float(), self.dev, G=G)
 
-        ops.igemm(plan, x, self.W.get("final_conv", make), self.out, x2=extra, out_mode=OUT_NCHW_F32, label="final_conv")
+        ops.igemm(plan, x, self.W.get("final_conv|split" if split else "final_conv", make), self.out, x2=extra, out_mode=OUT_NCHW_F32, label="final_conv")
 
     def _combine_upsample_fmaps(self, plan, x: Act, fmaps: List[Act]) -> Act:
         """UpsampleCombiner (ip.py:1078-1110, 1712): cat(x, Block_i(nearest-resize(fmap_i))) over the up levels.  Kernels of the image
@@ -446,7 +475,7 @@ class UnetEngine:
         # squares the producers of x / skip emitted in their epilogues (a ROWSTAT pass only where a producer could not).
         stat_x = lambda: self._ssq_of(plan, x, name + ".block1.stat_x")
         ss = self._ssq_of(plan, skip, name + ".block1.stat_skip") if skip is not None else None
-        w1 = W.conv(name + ".block1", rb.block1.project)
+        w1 = W.conv(name + ".block1", rb.block1.project, split=skip is None and self._split_small(Cin, 9, Cout, R * H * Wd))
         pa1 = W.f32(name + ".block1.pa", lambda: _pad_vec(rb.block1.norm.gamma.detach().float().flatten().cpu() * math.sqrt(Cin)
                                                          * (in_scale if in_scale is not None else 1.0), w1.Cin_pad))
         off = self._blk_off[self._blk_index[id(rb)]]
@@ -462,10 +491,10 @@ class UnetEngine:
         # its own pass (ACT_PREP, which also reduces x's statistics itself where no producer emitted them) instead of once per staging
         # workgroup inside the wave-specialised kernel
         big = BIG_PREP and ops.big_cfg(Cout, H, Wd, R) is not None
-        big1 = big and Cin % 32 == 0 and Cin <= 512 and w1.Cin_pad == Cin
+        big1 = big and Cin % 32 == 0 and Cin <= 512 and w1.Cin_pad == Cin and not w1.split
         # x comes out of a fused ResnetBlock tail (GCA_TAIL): that launch also writes silu(ChanRMSNorm(x) * gamma) — it has the pixel's
         # channels and its sum of squares in registers — and block1 stages its input with no arithmetic (prologue-free kernel families)
-        xa = ops.request_act(x, pa1) if (skip is None and TAIL_ACT and w1.Cin_pad == Cin) else None
+        xa = ops.request_act(x, pa1) if (skip is None and TAIL_ACT and w1.Cin_pad == w1.Cin) else None
         if xa is not None:
             op = ops.igemm(plan, xa, w1, h1, ssq_out=h1.ssq, post=post, label=name + ".block1")
         elif prep or big1:   # MFMA-bound layer: the prologue as its own pass, then an all-DMA conv on the activated concat
@@ -496,7 +525,8 @@ class UnetEngine:
                             b2=W.f32(name + ".gca.b2", lambda: g.net[2].bias), gate=gate)
         gca_ep = dict(wk=gca_args["wk"], bk=gca_args["bk"]) if rb.gca is not None else None   # GlobalContext partials from block2's epilogue
         if op.post_applied:     # h1 already holds silu(norm(h1) * (scale + 1) + shift)
-            op2 = ops.igemm(plan, h1, W.conv(name + ".block2", rb.block2.project), h2, gca=gca_ep, label=name + ".block2")
+            op2 = ops.igemm(plan, h1, W.conv(name + ".block2", rb.block2.project, split=SPLIT_BLOCK2 and self._split_small(Cout, 9, Cout, R * H * Wd)), h2,
+                            gca=gca_ep, label=name + ".block2")
         else:                   # block2: ChanRMSNorm -> (scale+1, shift) from the time MLP -> SiLU -> conv3x3
             w2 = W.conv(name + ".block2", rb.block2.project)
             if (prep or big) and Cout % 32 == 0 and Cout <= 512:   # the prologue as its own pass (it reduces h1's statistics itself where block1 could not emit them)
@@ -566,7 +596,7 @@ class UnetEngine:
         mu, rs = self.f32buf(R * N), self.f32buf(R * N)
         ops.rowstat(plan, tok, mode=1, rs=rs, mu=mu, eps=1e-5, label=name + ".norm")
         q = self.new(R, 1, N, inner)
-        wq = W.conv(name + ".to_q", ca.to_q)
+        wq = W.conv(name + ".to_q", ca.to_q, split=SPLIT_1X1 and self._split_small(C, 1, inner, R * N))
         ops.igemm(plan, tok, wq, q, mu=mu, rs=rs, pa=W.f32(name + ".norm.g", lambda: _pad_vec(ca.norm.g, wq.Cin_pad)), label=name + ".to_q")
         J = self.NT + 1
         Jp = ops._round_up(J, 32)
@@ -580,7 +610,7 @@ class UnetEngine:
                       k_strides=site["k_strides"], vt_strides=site["vt_strides"], o_strides=(N * inner, dh, inner),
                       q_scale=W.f32(name + ".q_scale", lambda: ca.q_scale), q_mult=SIM_SCALE * LOG2E, label=name + ".attn", head_dim=dh)
         y = self.new(R, 1, N, C)
-        ops.igemm(plan, o, W.conv(name + ".to_out", ca.to_out[0]), y, label=name + ".to_out")
+        ops.igemm(plan, o, W.conv(name + ".to_out", ca.to_out[0], split=SPLIT_1X1 and self._split_small(inner, 1, C, R * N)), y, label=name + ".to_out")
         out = self.new(R, h.H, h.W, C)
         out.ssq = self.f32buf(R * N)
         ops.ln_residual(plan, y, W.f32(name + ".out_g", lambda: ca.to_out[1].g), out.tokens(), res=tok, eps=1e-5, ssq_out=out.ssq,
@@ -596,7 +626,7 @@ class UnetEngine:
             nm = f"{name}.layers.{d}"
             # LayerNorm statistics of the attention input from the launch that produced it (a fused ResnetBlock tail), where there is one
             x1, st = self._self_attn(plan, cur.tokens(), attn, nm, with_context, ln_stats=ops.request_ln_stats(cur) if LN_STATS_FUSED else None)
-            ffo = self._feed_forward(plan, x1, ff, nm + ".ff", ln_stats=st)
+            ffo = self._feed_forward(plan, x1, ff, nm + ".ff", ln_stats=st, split=SPLIT_1X1 and self._split_small(2 * C, 1, C, R * N))
             cur = Act(ffo.t, R, x.H, x.W, C, C, N * C, ssq=ffo.ssq)
         return cur
 
@@ -613,7 +643,8 @@ class UnetEngine:
             mu, rs = self.f32buf(R * N), self.f32buf(R * N)
             ops.rowstat(plan, tok, mode=1, rs=rs, mu=mu, eps=1e-5, label=nm + ".norm")
         # q | k | v from ONE GEMM (to_q and to_kv are both bias-free on the same normalised input, ip.py:539)
-        wqkv = W.raw(nm + ".qkv", torch.cat((attn.to_q.weight.detach().float(), attn.to_kv.weight.detach().float())), None)
+        wqkv = W.raw(nm + ".qkv", torch.cat((attn.to_q.weight.detach().float(), attn.to_kv.weight.detach().float())), None,
+                      split=SPLIT_1X1 and self._split_small(C, 1, inner + 2 * dh, R * N))
         qkv = self.new(R, 1, N, inner + 2 * dh)
         ops.igemm(plan, tok, wqkv, qkv, mu=mu, rs=rs, pa=W.f32(nm + ".norm.g", lambda: _pad_vec(attn.norm.g, wqkv.Cin_pad)),
                   label=nm + ".qkv")
@@ -634,13 +665,13 @@ class UnetEngine:
                       vt_strides=vt_strides, o_strides=(N * inner, dh, inner), q_scale=W.f32(nm + ".q_scale", lambda: attn.q_scale),
                       q_mult=SIM_SCALE * LOG2E, label=nm + ".attn", head_dim=dh)
         y = self.new(R, 1, N, C)
-        ops.igemm(plan, o, W.conv(nm + ".to_out", attn.to_out[0]), y, label=nm + ".to_out")
+        ops.igemm(plan, o, W.conv(nm + ".to_out", attn.to_out[0], split=SPLIT_1X1 and self._split_small(inner, 1, C, R * N)), y, label=nm + ".to_out")
         x1 = self.new(R, 1, N, C)
         st = (self.f32buf(R * N), self.f32buf(R * N)) if LN_STATS_FUSED else None   # statistics of x1 for the FeedForward's first LayerNorm
         ops.ln_residual(plan, y, W.f32(nm + ".out_g", lambda: attn.to_out[1].g), x1, res=tok, eps=1e-5, ln_stats_out=st, label=nm + ".out_norm")
         return x1, st
 
-    def _feed_forward(self, plan, x: Act, ff: nn.Sequential, name: str, ln_stats: Optional[tuple] = None) -> Act:
+    def _feed_forward(self, plan, x: Act, ff: nn.Sequential, name: str, ln_stats: Optional[tuple] = None, split: bool = False) -> Act:
         """ip.py:972-980 + residual (ip.py:1018): LN -> Linear -> GELU -> LN -> Linear, + x.  ln_stats: (mean, rstd) of x's rows where its
         producer emitted them."""
         W = self.W
@@ -651,13 +682,13 @@ class UnetEngine:
         else:
             mu, rs = self.f32buf(rows), self.f32buf(rows)
             ops.rowstat(plan, x, mode=1, rs=rs, mu=mu, eps=1e-5, label=name + ".ln0")
-        w1 = W.conv(name + ".w1", ff[1])
+        w1 = W.conv(name + ".w1", ff[1], split=split)
         hid = self.new(x.B, x.H, x.W, hidden)
         ops.igemm(plan, x, w1, hid, mu=mu, rs=rs, pa=W.f32(name + ".g0", lambda: _pad_vec(ff[0].g, w1.Cin_pad)), act_out=ACT_GELU,
                   label=name + ".lin1")
         mu2, rs2 = self.f32buf(rows), self.f32buf(rows)
         ops.rowstat(plan, hid, mode=1, rs=rs2, mu=mu2, eps=1e-5, label=name + ".ln1")
-        w2 = W.conv(name + ".w2", ff[4])
+        w2 = W.conv(name + ".w2", ff[4], split=split)
         out = self.new(x.B, x.H, x.W, x.C)
         out.ssq = self.f32buf(rows)
         op = ops.igemm(plan, hid, w2, out, mu=mu2, rs=rs2, pa=W.f32(name + ".g1", lambda: _pad_vec(ff[3].g, w2.Cin_pad)), res=x,
@@ -733,10 +764,10 @@ class UnetEngine:
                 w = lin.weight.detach().float()
                 ws.append(w * ln.weight.detach().float()[None, :])
                 bs.append(lin.bias.detach().float() + w @ ln.bias.detach().float())
-            return ops.pack_weight(torch.cat(ws), torch.cat(bs), self.dev)
+            return ops.pack_weight(torch.cat(ws), torch.cat(bs), self.dev, split=bool(SPLIT_STATIC))
 
         def make_cross():
-            return ops.pack_weight(torch.cat([s["mod"].to_kv.weight.detach().float() for s in crosses]), None, self.dev)
+            return ops.pack_weight(torch.cat([s["mod"].to_kv.weight.detach().float() for s in crosses]), None, self.dev, split=bool(SPLIT_STATIC))
 
         ws = self.W.get("ctx.self", make_self) if selfs else None
         wc = self.W.get("ctx.cross", make_cross) if crosses else None
@@ -808,10 +839,10 @@ class UnetEngine:
                            w=W.f32("ltime.w", lambda: u.to_lowres_time_hiddens[1].weight),
                            bias=W.f32("ltime.b", lambda: u.to_lowres_time_hiddens[1].bias), hid=hid_l, label="lowres_time_embed")
             t_l = self.new(1, 1, R, Tc)
-            ops.igemm(plan, hid_l, W.conv("ltime.cond", u.to_lowres_time_cond[0]), t_l, label="to_lowres_time_cond")
+            ops.igemm(plan, hid_l, W.conv("ltime.cond", u.to_lowres_time_cond[0], split=SPLIT_STATIC), t_l, label="to_lowres_time_cond")
             t_parts.append(t_l)
             tok_l = self.new(1, 1, R, self.ntt * cd)
-            ops.igemm(plan, hid_l, W.conv("ltime.tokens", u.to_lowres_time_tokens[0]), tok_l, label="to_lowres_time_tokens")
+            ops.igemm(plan, hid_l, W.conv("ltime.tokens", u.to_lowres_time_tokens[0], split=SPLIT_STATIC), tok_l, label="to_lowres_time_tokens")
             static_tokens.append(Act(tok_l.t, R, 1, self.ntt, cd, cd, self.ntt * cd))
         # ---- text conditioning (ip.py:1595-1652)
         if self.has_text:
@@ -822,7 +853,7 @@ class UnetEngine:
             tok = self.new(src_batch, 1, L, cd, zero=True)          # rows >= n_tok stay zero (F.pad, ip.py:1617)
             te = Act(te16, src_batch, 1, n_tok, ted, ted, n_tok * ted)
             tok_head = Act(tok.t, src_batch, 1, n_tok, cd, cd, L * cd)
-            ops.igemm(plan, te, W.conv("text_to_cond", u.text_to_cond), tok_head, label="text_to_cond")
+            ops.igemm(plan, te, W.conv("text_to_cond", u.text_to_cond, split=SPLIT_STATIC), tok_head, label="text_to_cond")
             xt = self.new(R, 1, L, cd)
             ops.select_rows(plan, tok.t, W.f16("null_text_embed", lambda: u.null_text_embed[0]), mask_u8, self.src_idx, self.keep_u8, xt.t,
                             R=R, L=L, C=cd, label="text_keep_select")
@@ -833,12 +864,12 @@ class UnetEngine:
             nc = u.to_text_non_attn_cond
             mu, rs = self.f32buf(R), self.f32buf(R)
             ops.rowstat(plan, pooled, mode=1, rs=rs, mu=mu, eps=1e-5, label="text_hidden.ln")
-            w1 = W.conv("text_hidden.w1", nc[1])
+            w1 = W.conv("text_hidden.w1", nc[1], split=SPLIT_STATIC)
             h1 = self.new(1, 1, R, Tc)
             ops.igemm(plan, pooled, w1, h1, mu=mu, rs=rs, pa=W.f32("text_hidden.lnw", lambda: _pad_vec(nc[0].weight, w1.Cin_pad)),
                       ps=W.f32("text_hidden.lnb", lambda: _pad_vec(nc[0].bias, w1.Cin_pad)), act_out=ACT_SILU, label="text_hidden.lin1")
             h2 = self.new(1, 1, R, Tc)
-            ops.igemm(plan, h1, W.conv("text_hidden.w2", nc[3]), h2, label="text_hidden.lin2")
+            ops.igemm(plan, h1, W.conv("text_hidden.w2", nc[3], split=SPLIT_STATIC), h2, label="text_hidden.lin2")
             th = self.new(1, 1, R, Tc)
             ops.select_rows(plan, h2.t, W.f16("null_text_hidden", lambda: u.null_text_hidden), None, self.arange_idx, self.keep_u8, th.t,
                             R=R, L=1, C=Tc, label="text_hidden_select")
@@ -887,7 +918,7 @@ class UnetEngine:
             seq = pr.to_latents_from_mean_pooled_seq
             mu, rs = self.f32buf(R), self.f32buf(R)
             ops.rowstat(plan, pooled, mode=1, rs=rs, mu=mu, eps=1e-5, label="attn_pool.mp.ln")
-            wm = W.conv("attn_pool.mp", seq[1])
+            wm = W.conv("attn_pool.mp", seq[1], split=SPLIT_STATIC)
             dst = Act(lat.t, R, 1, 1, nm * cd, NL * cd, NL * cd)  # (R, nm*cd) written as the first nm rows of each row's latents
             src = Act(pooled.t, R, 1, 1, cd, cd, cd)
             ops.igemm(plan, src, wm, dst, mu=mu, rs=rs, pa=W.f32("attn_pool.mp.g", lambda: _pad_vec(seq[0].g, wm.Cin_pad)), label="attn_pool.mp.lin")
@@ -900,7 +931,7 @@ class UnetEngine:
             heads, dh = pa.heads, pa.dim_head
             inner = heads * dh
             kv = self.new(R, 1, Jk, 2 * inner)
-            wkv = W.conv(nm_ + ".to_kv", pa.to_kv)
+            wkv = W.conv(nm_ + ".to_kv", pa.to_kv, split=SPLIT_STATIC)
             # k/v of the normalised sequence ...
             mu, rs = self.f32buf(R * L), self.f32buf(R * L)
             ops.rowstat(plan, xpos, mode=1, rs=rs, mu=mu, eps=1e-5, label=nm_ + ".norm")
@@ -915,7 +946,7 @@ class UnetEngine:
             ops.igemm(plan, lat, wkv, Act(kv.t, R, 1, NL, 2 * inner, 2 * inner, Jk * 2 * inner, off=L * 2 * inner), mu=mul, rs=rsl, pa=lnw, ps=lnb,
                       label=nm_ + ".kv_lat")
             q = self.new(R, 1, NL, inner)
-            ops.igemm(plan, lat, W.conv(nm_ + ".to_q", pa.to_q), q, mu=mul, rs=rsl, pa=lnw, ps=lnb, label=nm_ + ".to_q")
+            ops.igemm(plan, lat, W.conv(nm_ + ".to_q", pa.to_q, split=SPLIT_STATIC), q, mu=mul, rs=rsl, pa=lnw, ps=lnb, label=nm_ + ".to_q")
             khat = torch.zeros(R, heads, Jp, dh, dtype=torch.float16, device=self.dev)
             vt = torch.zeros(R, heads, dh, Jp, dtype=torch.float16, device=self.dev)
             ks, vs = (heads * Jp * dh, Jp * dh, dh), (heads * dh * Jp, dh * Jp, Jp)
@@ -927,11 +958,11 @@ class UnetEngine:
                           vt_strides=vs, o_strides=(NL * inner, dh, inner), q_scale=W.f32(nm_ + ".q_scale", lambda pa=pa: pa.q_scale),
                           q_mult=SIM_SCALE * LOG2E, label=nm_ + ".attn", head_dim=dh)
             y = self.new(R, 1, NL, cd)
-            ops.igemm(plan, o, W.conv(nm_ + ".to_out", pa.to_out[0]), y, label=nm_ + ".to_out")
+            ops.igemm(plan, o, W.conv(nm_ + ".to_out", pa.to_out[0], split=SPLIT_STATIC), y, label=nm_ + ".to_out")
             lat2 = self.new(R, 1, NL, cd)
             ops.ln_residual(plan, y, W.f32(nm_ + ".out.w", lambda pa=pa: pa.to_out[1].weight), lat2,
                             beta=W.f32(nm_ + ".out.b", lambda pa=pa: pa.to_out[1].bias), res=lat, eps=1e-5, label=nm_ + ".out_norm")
-            lat = self._feed_forward(plan, lat2, ff, nm_ + ".ff")
+            lat = self._feed_forward(plan, lat2, ff, nm_ + ".ff", split=SPLIT_STATIC)
         return lat
 
     # ------------------------------------------------------------------------------------------ run-time API
@@ -994,9 +1025,9 @@ class UnetEngine:
                        w=W.f32("time.w", lambda: u.to_time_hiddens[1].weight), bias=W.f32("time.b", lambda: u.to_time_hiddens[1].bias), hid=hid,
                        label="tt.time_embed")
         t_all = self.new(1, 1, rows_all, self.Tc)
-        ops.igemm(tt, hid, W.conv("time.cond", u.to_time_cond[0]), t_all, res=tc_all, label="tt.to_time_cond")
+        ops.igemm(tt, hid, W.conv("time.cond", u.to_time_cond[0], split=SPLIT_STATIC), t_all, res=tc_all, label="tt.to_time_cond")
         tok_raw = self.new(1, 1, rows_all, self.ntt * self.cond_dim)
-        ops.igemm(tt, hid, W.conv("time.tokens", u.to_time_tokens[0]), tok_raw, label="tt.to_time_tokens")
+        ops.igemm(tt, hid, W.conv("time.tokens", u.to_time_tokens[0], split=SPLIT_STATIC), tok_raw, label="tt.to_time_tokens")
         n_tok_rows = rows_all * self.ntt
         c_time = self.new(1, 1, n_tok_rows, self.cond_dim)
         tok_rows = Act(tok_raw.t, 1, 1, n_tok_rows, self.cond_dim, self.cond_dim, n_tok_rows * self.cond_dim)
@@ -1004,7 +1035,7 @@ class UnetEngine:
                         eps=1e-5, label="tt.norm_cond(time)")
         tw, tb, gam, isc, ish, _, total_c = W.get("timemlp.tables", lambda: self._time_mlp_tables(self._all_resnet_blocks()))
         ss = self.new(1, 1, rows_all, tw.shape[0])
-        ops.igemm(tt, t_all, W.raw("timemlp.w", tw, tb), ss, act_in=ACT_SILU, label="tt.time_mlps")
+        ops.igemm(tt, t_all, W.raw("timemlp.w", tw, tb, split=SPLIT_STATIC), ss, act_in=ACT_SILU, label="tt.time_mlps")
         tab_pa, tab_ps = self.f32buf(rows_all, total_c), self.f32buf(rows_all, total_c)
         ops.scale_shift(tt, ss, W.f32("timemlp.gam", lambda: gam), W.get("timemlp.isc", lambda: isc.to(self.dev)),
                         W.get("timemlp.ish", lambda: ish.to(self.dev)), tab_pa, tab_ps, label="tt.scale_shift")

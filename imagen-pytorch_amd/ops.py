@@ -188,6 +188,8 @@ class PackedWeight:
     G: int
     Cin_pad: int
     Cout_pad: int
+    split: bool = False       # split-precision weight (pack_weight(split=True)): Cin counts the input channels TWICE — the launch reads the same
+                              # tensor as x1 and x2 against [fp16(W) | fp16(W - fp16(W))], i.e. the fp32 weight to ~2^-22 through two fp16 MFMA operands
 
 
 # Host-logic tests (tests/plan_interp.py) execute plans on the CPU from the documented op contracts; the packed MFMA-fragment
@@ -209,13 +211,23 @@ def choose_G(Cin: int, taps: int = 9) -> int:
 
 
 def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], device, in_scale: Optional[torch.Tensor] = None,
-                G: Optional[int] = None) -> PackedWeight:
-    """w: fp32 [Cout, Cin, KH, KW] or [Cout, Cin] (Linear).  Packs on the host through the C packer, uploads once."""
+                G: Optional[int] = None, split: bool = False) -> PackedWeight:
+    """w: fp32 [Cout, Cin, KH, KW] or [Cout, Cin] (Linear).  Packs on the host through the C packer, uploads once.
+    split: pack [hi | lo] along the input channels with hi = fp16(w), lo = fp16(w - hi) (Cin doubles; Cin % 8 == 0): igemm() then feeds the
+    input tensor twice (x2 = x1), and the product is that of the fp32 weight to ~2^-22 instead of 2^-11 — for the launches whose time does
+    not depend on their K (the once-per-request conditioning, the latency-bound small maps)."""
     lib = load_library()
     w = w.detach().float().cpu()
     if w.ndim == 2:
         w = w[:, :, None, None]
     w = w.contiguous()
+    if split:
+        assert w.shape[1] % 8 == 0, "split-precision weights need Cin % 8 == 0 (the second copy starts at an 8-channel group)"
+        if in_scale is not None:
+            w = w * in_scale.detach().float().cpu()[None, : w.shape[1], None, None]
+            in_scale = None
+        hi = w.half().float()
+        w = torch.cat((hi, (w - hi).half().float()), dim=1).contiguous()
     Cout, Cin, KH, KW = w.shape
     G = G or choose_G(Cin, KH * KW)
     KC = 8 * G
@@ -234,7 +246,7 @@ def pack_weight(w: torch.Tensor, bias: Optional[torch.Tensor], device, in_scale:
     packed = out.to(device)
     if KEEP_REFERENCE_WEIGHTS:
         REFERENCE_WEIGHTS[packed.data_ptr()] = ((w if sc is None else w * sc[None, :, None, None]).half().float(), bias)
-    return PackedWeight(packed, b, Cin, Cout, KH, KW, G, Cin_pad, Cout_pad)
+    return PackedWeight(packed, b, Cin, Cout, KH, KW, G, Cin_pad, Cout_pad, split)
 
 
 # ------------------------------------------------------------------------------------------------ igemm
@@ -412,38 +424,20 @@ def pick_cfg(G: int, Cout: int, OH: int, OW: int, B: int, KH: int = 1, KW: int =
     raise ValueError(f"no igemm tile configuration for G={G} Cout={Cout} {OH}x{OW} k{KH}x{KW} s{stride}")
 
 
-# Measured tile choices (tools/cfg_sweep.py: every candidate configuration of a layer class timed IN the sampling loop on MI355X, one class
-# at a time) that replace the rules of pick_cfg for the layer classes they name: {layer_key: [cfg, TH, TW]}, loaded from tuned_cfgs.json
-# beside this file when it exists.  A pick that is not launchable for the call at hand is ignored (the rules apply).
-CFG_OVERRIDE: dict = {}
+_TWICE: dict = {}   # (data_ptr of a per-channel fp32 vector, C, n) -> (the vector, [v[:C] | v[:C] | 0 ..] of length n): the affine of a split-precision launch
 
 
-def layer_key(Cin: int, Cout: int, K: int, stride: int, OH: int, OW: int, B: int, pro: bool) -> str:
-    return f"{Cin}->{Cout} k{K} s{stride} @{OH}x{OW} B{B} {'pro' if pro else 'raw'}"
-
-
-def _load_tuned():
-    import json
-    path = _os.path.join(_os.path.dirname(_os.path.abspath(__file__)), "tuned_cfgs.json")
-    if _os.path.exists(path) and _os.environ.get("IMAGEN_TUNED_CFGS", "1") != "0":
-        try:
-            CFG_OVERRIDE.update({k: tuple(v) for k, v in json.load(open(path)).get("picks", {}).items()})
-        except (OSError, ValueError):
-            pass
-
-
-_load_tuned()
-
-
-def _override_ok(ov, G: int, OH: int, OW: int, KH: int, KW: int, stride: int, raw: bool) -> bool:
-    cid, th, tw = ov
-    tab = cfg_table()
-    if not (0 <= cid < len(tab)) or tab[cid][2] != G:
-        return False
-    fam = tab[cid][3]
-    if fam == 3 or (fam in (2, 5) and not (raw and KH == 3 and KW == 3 and stride == 1 and G == 4)):
-        return False
-    return any((th, tw) == (a, b) for _, _, a, b in launchable_shapes(cid, OH, OW, KH, KW, stride))
+def _twice(v: Optional[torch.Tensor], C: int, n: int) -> Optional[torch.Tensor]:
+    if v is None:
+        return None
+    key = (v.data_ptr(), C, n)
+    hit = _TWICE.get(key)
+    if hit is None or hit[0] is not v:
+        out = torch.zeros(n, dtype=torch.float32, device=v.device)
+        out[:C] = v.reshape(-1)[:C]
+        out[C:2 * C] = v.reshape(-1)[:C]
+        hit = _TWICE[key] = (v, out)
+    return hit[1]
 
 
 def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None, mu=None, rs=None, pa=None, ps=None,
@@ -458,6 +452,10 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
     KH, KW = pw.KH, pw.KW
     if pad is None:
         pad = (KH - 1) // 2 if stride == 1 else 0
+    if pw.split:   # split-precision weight: the input is read twice, against the hi and the lo half of the weight
+        assert x2 is None and ssq_b is None and pstride == 0, f"{label}: a split-precision weight takes one input tensor and batch-shared affines"
+        x2 = x1
+        pa, ps = _twice(pa, x1.C, pw.Cin_pad), _twice(ps, x1.C, pw.Cin_pad)
     H, W = x1.H, x1.W
     OH = (H + 2 * pad - KH) // stride + 1
     OW = (W + 2 * pad - KW) // stride + 1
@@ -489,11 +487,6 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
     if cfg is None:
         raw = (x2 is None and mu is None and rs is None and pa is None and ps is None and ssq_a is None and act_in == ACT_NONE
                and x1.C % 32 == 0 and pw.Cin_pad == x1.C and x1.ld % 8 == 0)
-        if CFG_OVERRIDE:
-            no_pro_any = mu is None and rs is None and pa is None and ps is None and ssq_a is None and act_in == ACT_NONE
-            ov = CFG_OVERRIDE.get(layer_key(x1.C + C2, pw.Cout, KH, stride, OH, OW, x1.B, not no_pro_any))
-            if ov is not None and _override_ok(ov, pw.G, OH, OW, KH, KW, stride, raw):
-                cfg = tuple(ov)
     if cfg is None:
         cfg = pick_cfg(pw.G, pw.Cout, OH, OW, x1.B, KH, KW, stride,
                        full_cout=(ssq_out is not None or post is not None or want_gca) and out_mode == OUT_NHWC, raw=raw)

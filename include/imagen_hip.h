@@ -127,9 +127,7 @@ typedef struct ImagenIgemmParams {
   int32_t out_mode;
   int32_t TH, TW;      /* output tile (TH*TW must equal the tile's pixel count) */
   int32_t cfg;         /* tile configuration id, see imagen_igemm_config_info */
-  int32_t dbg;         /* ablation switches for round-2 probe igemm_probe.py (0 in production): 1 = skip restaging after chunk 0, 2 = skip MFMAs,
-                        * 8 = skip stores, 16 = skip activation loads, 32 = one tile per workgroup (no persistence), 64 = no XCD tile ranges,
-                        * 256 = 8-byte epilogue operand loads / stores */
+  int32_t launcher_word; /* pass 0: private to the launcher (it stores the kernel's code size here for the in-kernel instruction warm-up) */
   float ssq_wb;        /* weight of ssq_b (skip_connect_scale^2 for the concatenated skip tensor) */
   float gca_bk;        /* bias of the GlobalContext logit (to_k.bias) */
 } ImagenIgemmParams;

@@ -413,7 +413,9 @@ def test_time_table_plan_equals_per_step_chain(name, reference_weights):
         eng.out.zero_()
         eng.times.fill_(float(coef[row, 6]))
         it.run(eng.step_plan)
-        assert torch.equal(got, eng.out), (name, row, nerr(got, eng.out))
+        # bit-identical on the GPU (a GEMM's k-loop order does not depend on its row count: tests/test_model_gpu.py); torch's CPU kernels
+        # behind the interpreter choose their blocking by problem size, so fp32 sums may differ in the last bits here
+        assert nerr(got, eng.out) < 1e-3, (name, row, nerr(got, eng.out))   # (one flipped fp16 rounding upstream reaches the output at ~3e-4)
 
 
 def _dry_engines(monkeypatch):

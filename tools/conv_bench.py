@@ -47,9 +47,6 @@ def main():
     ap.add_argument("--shapes", nargs="*", default=DEFAULT_SHAPES)
     ap.add_argument("--cands", nargs="*", default=None)
     ap.add_argument("--gca", action="store_true", help="GlobalContext partials from the epilogue (Cout <= 128 shapes)")
-    ap.add_argument("--ablate", nargs="*", type=int, default=None,
-                    help="timing ablation bit masks for the conv_big candidates (needs the -DCB_ABLATE library: IMAGEN_LIB_PATH=...libimagen_hip_ablate.so); "
-                         "1: no refill copies, 2: no wait + barrier, 4: no fragment reads, 8: no MFMAs, 16: no epilogue")
     ap.add_argument("--out", default=None)
     args = ap.parse_args()
     dev = torch.device("cuda:0")
@@ -64,16 +61,13 @@ def main():
         ys = [ops.new_act(B, H, H, Cout, dev) for _ in range(4)]
         wk = torch.randn(Cout, generator=g).to(dev) * 0.3
         first = None
-        cands = [(spec, 0) for spec in (args.cands or DEFAULT_CANDS[H])]
-        if args.ablate:
-            cands = [(spec, a) for spec, _ in cands for a in ([0] + args.ablate if spec.startswith("big") else [0])]
-        for spec, abl in cands:
+        for spec in (args.cands or DEFAULT_CANDS[H]):
             try:
                 cfg = resolve(spec, Cout, H, B)
                 plan = ops.Plan("bench")
                 for i in range(4):
                     kw = dict(gca=dict(wk=wk, bk=0.1)) if (args.gca and Cout <= 128) else {}
-                    ops.igemm(plan, xs[i], pw, ys[i], cfg=cfg, label=spec, pstride=abl, **kw)
+                    ops.igemm(plan, xs[i], pw, ys[i], cfg=cfg, label=spec, **kw)
                 plan.run()
                 torch.cuda.synchronize()
             except Exception as e:   # noqa: BLE001
@@ -94,7 +88,7 @@ def main():
             torch.cuda.synchronize()
             us = e0.elapsed_time(e1) * 1e3 / (4 * args.iters)
             fl = 2.0 * B * H * H * Cout * 9 * Cin
-            lines.append(dict(shape=shp, cand=spec, ablate=abl, cfg=list(cfg), fam=ops.cfg_table()[cfg[0]][3], us=round(us, 2), tflops=round(fl / us / 1e6, 1),
+            lines.append(dict(shape=shp, cand=spec, cfg=list(cfg), fam=ops.cfg_table()[cfg[0]][3], us=round(us, 2), tflops=round(fl / us / 1e6, 1),
                               dist_to_first=float(f"{err:.3e}"), gca=bool(args.gca and Cout <= 128)))
             print(json.dumps(lines[-1]), flush=True)
     if args.out:
