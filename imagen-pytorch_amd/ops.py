@@ -26,7 +26,8 @@ _CFG_TABLE = None
 
 def cfg_table():
     """[(tile pixels, tile couts, G, family)] per tile cfg id; family 0 = wave-specialised persistent kernel (csrc/igemm.hip),
-    2 = all-DMA kernel (csrc/conv_dma.hip: prologue-free 3x3, stride 1), 3 = streaming kernel (csrc/conv_stream.hip)."""
+    2 = all-DMA kernel (csrc/conv_dma.hip: prologue-free 3x3, stride 1), 3 = streaming kernel (csrc/conv_stream.hip), 4 = streaming pointwise
+    kernel (conv_pw.hip), 5 = big-tile all-DMA kernel (conv_big.hip), 6 = streaming kernel with the prologue on register-staged rows (conv_pro.hip)."""
     global _CFG_TABLE
     if _CFG_TABLE is None:
         lib = load_library()
@@ -285,6 +286,10 @@ CONV_STREAM = int(_os.environ.get("IMAGEN_CONV_STREAM", "1"))       # A/B switch
 STREAM_MIN_TILES = 512   # ... of launches with at least this many 16x16 tiles (persistent workgroups need a few tiles each)
 
 
+CONV_PRO = int(_os.environ.get("IMAGEN_CONV_PRO", "1"))             # A/B switch: conv_pro.hip for the 32-channel 3x3 convs that need the Block prologue (2: the raw ones too)
+PRO_MIN_TILES = 1024     # ... of launches with at least this many 8x16 tiles (two per resident workgroup)
+
+
 CONV_PW = int(_os.environ.get("IMAGEN_CONV_PW", "1"))               # A/B switch: the streaming pointwise family (conv_pw.hip) for the large res_conv launches
 PW_MIN_TILES = 512     # ... of at least this many tiles, i.e. two per CU (the big maps; below, the launch is latency-bound either way)
 
@@ -317,6 +322,11 @@ def pw_cfg(kchunks: int, Cout: int) -> Optional[int]:
         if fam == 4 and kch == kchunks and bn >= Cout and (best is None or bn < cfg_table()[best][1]):
             best = i
     return best
+
+
+def pro_cfg() -> Optional[int]:
+    """Tile cfg id of the streaming family with the prologue on register-staged rows (family 6), None if the library has none."""
+    return next((i for i, c in enumerate(cfg_table()) if c[3] == 6), None)
 
 
 def stream_cfg() -> Optional[int]:
@@ -462,6 +472,18 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
     C2 = x2.C if x2 is not None else 0
     assert x1.C + C2 == pw.Cin, f"{label}: input channels {x1.C}+{C2} != weight Cin {pw.Cin}"
     want_gca = gca is not None and out_mode == OUT_NHWC and act_out == ACT_NONE and addend is None and res is None and post is None
+    if cfg is None and CONV_PRO and KH == 3 and KW == 3 and stride == 1 and pad == 1 and pw.G == 4 and pro_cfg() is not None:
+        # family 6: exactly 32 output channels from one or two 32-channel inputs, the ssq-statistics SiLU prologue on register-staged rows
+        # (CONV_PRO = 2: raw inputs too), plain / post / ssq_out epilogue
+        no_pro = mu is None and rs is None and pa is None and ps is None and ssq_a is None and act_in == ACT_NONE
+        ssq_pro = mu is None and rs is None and pa is not None and ssq_a is not None and act_in == ACT_SILU and (x2 is None or ssq_b is not None)
+        tiles = x1.B * math.ceil(OH / 8) * math.ceil(OW / 16)
+        gca_here = want_gca and x1.B * math.ceil(OH / 16) * math.ceil(OW / 16) <= GCA_EPILOGUE_MAX_TILES
+        if (pw.Cout == 32 and x1.C == 32 and C2 in (0, 32) and pw.Cin_pad == x1.C + C2 and x1.ld % 8 == 0 and x1.bs % 8 == 0
+                and (x2 is None or (x2.ld % 8 == 0 and x2.bs % 8 == 0)) and (ssq_pro or (no_pro and CONV_PRO >= 2)) and not gca_here
+                and tiles >= PRO_MIN_TILES and out_mode == OUT_NHWC and addend is None and res is None and act_out == ACT_NONE
+                and isinstance(y, Act) and y.ld % 8 == 0 and y.bs % 8 == 0 and not pw.split):
+            cfg = (pro_cfg(), 8, 16)
     if cfg is None and CONV_STREAM and KH == 3 and KW == 3 and stride == 1 and pad == 1 and pw.G == 4:
         # the streaming family: C_out <= 32 from one or two 32-channel inputs, raw or with the ssq-statistics Block prologue
         no_pro = mu is None and rs is None and pa is None and ps is None and ssq_a is None and act_in == ACT_NONE

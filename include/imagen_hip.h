@@ -428,7 +428,9 @@ int imagen_igemm_stage_slots(int cfg, int KH, int KW);
  * 2 = all-DMA kernel (3x3 stride 1, one input tensor, NO prologue: both operands by direct-to-LDS loads; fixed tile shape per cfg),
  * 3 = streaming kernel (3x3 stride 1 to <= 32 channels from one or two 32-channel inputs, persistent, in-LDS prologue),
  * 4 = streaming pointwise kernel (1x1, raw inputs, weights in registers; `kgroups` of its config info = 32-channel input chunks),
- * 5 = big-tile all-DMA kernel (as 2, 128-cout tiles of 256 / 128 pixels, 64 x 64 per wave, one workgroup per CU). */
+ * 5 = big-tile all-DMA kernel (as 2, 128-cout tiles of 256 / 128 pixels, 64 x 64 per wave, one workgroup per CU),
+ * 6 = streaming kernel with the Block prologue on register-staged rows (3x3 stride 1 to exactly 32 channels from one or two 32-channel
+ *     inputs, raw or with the ssq-statistics prologue, plain / post_pa / ssq_out epilogue; weights in registers, 8 x 16 tiles). */
 int imagen_igemm_config_family(int cfg);
 int imagen_igemm_config_ring(int cfg);   /* weight look-ahead ring depth in stages (family 2; 0 for the others) */
 /* dynamic LDS bytes of a launch of `cfg` with a KHxKW kernel at `stride` and a THxTW output tile; -1 = not launchable */

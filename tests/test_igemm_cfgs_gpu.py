@@ -50,7 +50,7 @@ def _shapes(ops, cfg, K, stride, H, W):
 def test_conv3x3_block_every_cfg_and_tile_shape(ops, dev, cfg):
     """Block conv (prologue rs * pa + ps -> SiLU, concat input, bias), plain NHWC output with ssq_out where one tile covers Cout."""
     tp, bn, G, fam = ops.cfg_table()[cfg]
-    if G not in (1, 4) or fam in (2, 3, 5):
+    if G not in (1, 4) or fam in (2, 3, 5, 6):
         pytest.skip("3x3 convs with a prologue use 8- or 32-channel chunks of families 0 / 1")
     C1, C2 = (64, 32) if G == 4 else (16, 8)
     H, W = (40, 36) if tp >= 128 else (20, 24)
@@ -71,7 +71,7 @@ def test_conv3x3_raw_post_and_ssq_prologue_every_cfg(ops, dev, cfg):
     """The two fused forms of a ResnetBlock: conv1 with ssq statistics (ssq_a + wb * ssq_b over the concat) and the output-side
     Block prologue (post_pa); conv2 staging an already activated input with no arithmetic (prologue none)."""
     tp, bn, G, fam = ops.cfg_table()[cfg]
-    if G != 4 or fam in (2, 3, 5):
+    if G != 4 or fam in (2, 3, 5, 6):
         pytest.skip("32-channel chunks of families 0 / 1 only")
     H, W = (32, 48) if tp >= 128 else (16, 24)
     shapes = _shapes(ops, cfg, 3, 1, H, W)
@@ -165,6 +165,35 @@ def test_conv_stream_family(ops, dev):
     assert r["err"] < TOL, ("many tiles, two inputs", r)
     r = run_case(ops, dev, B=2, H=272, W=272, C1=32, C2=0, **base, **raw, ssq_out=True)
     assert r["err"] < TOL and r["err_ssq"] < 2e-3, ("many tiles, raw", r)
+
+
+def test_conv_pro_family(ops, dev):
+    """The streaming family with the Block prologue on register-staged rows (csrc/conv_pro.hip): 3x3 convs to exactly 32 channels from one
+    or two 32-channel inputs — the ssq-statistics SiLU prologue (shared gain, per-(batch, channel) affine with shifts) and raw inputs, the
+    plain / ssq_out / post epilogues, ragged images (partial 8 x 16 tiles, zero padding of the ACTIVATED tensor), images of a single tile
+    (the per-image parameter sets alternate every tile), and maps with several tiles per persistent workgroup (contiguous tile ranges, the
+    register-staged rows two tiles ahead, the double-buffered tile image)."""
+    pid = ops.pro_cfg()
+    assert pid is not None
+    cfg = (pid, 8, 16)
+    base = dict(K=3, G=4, cfg=cfg, Cout=32, C1=32)
+    raw = dict(prologue="none", act_in="none")
+    for C2 in (0, 32):
+        for kw in (dict(prologue="ssq", affine=False, ssq_out=True), dict(prologue="ssq", affine=True, ssq_out=True), dict(prologue="ssq", affine=False, epilogue="post"),
+                   dict(prologue="ssq", affine=True, epilogue="post"), dict(raw, ssq_out=True), dict(raw, epilogue="post"), dict(prologue="ssq", affine=False)):
+            r = run_case(ops, dev, B=2, H=40, W=36, C2=C2, **base, **kw)
+            assert r["err"] < TOL and r.get("err_ssq", 0.0) < 2e-3, (C2, kw, r)
+        r = run_case(ops, dev, B=3, H=27, W=45, C2=C2, **base, prologue="ssq", affine=True, ssq_out=True)   # ragged right / bottom edges
+        assert r["err"] < TOL and r["err_ssq"] < 2e-3, (C2, "ragged", r)
+        r = run_case(ops, dev, B=9, H=8, W=16, C2=C2, **base, prologue="ssq", affine=True, epilogue="post")   # one tile per image
+        assert r["err"] < TOL, (C2, "single-tile images", r)
+    if not EMULATED:   # 2 x 34 x 17 = 1156 tiles (one input: 768 resident workgroups) / 2 x 45 x 12 = 1080 tiles (two inputs: 512)
+        r = run_case(ops, dev, B=2, H=272, W=272, C2=0, **base, prologue="ssq", affine=True, ssq_out=True)
+        assert r["err"] < TOL and r["err_ssq"] < 2e-3, ("many tiles", r)
+        r = run_case(ops, dev, B=2, H=360, W=190, C2=32, **base, prologue="ssq", affine=False, epilogue="post")
+        assert r["err"] < TOL, ("many tiles, two inputs", r)
+        r = run_case(ops, dev, B=16, H=64, W=64, C2=32, **base, **raw, ssq_out=True)
+        assert r["err"] < TOL and r["err_ssq"] < 2e-3, ("many tiles, raw, two inputs", r)
 
 
 def test_conv_pw_family(ops, dev):

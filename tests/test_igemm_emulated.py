@@ -36,7 +36,7 @@ def _run(lib, out):
 @pytest.mark.skipif(not os.path.exists(CLANG), reason="host clang of the ROCm toolchain not present")
 def test_emulated_igemm_matches_contract(tmp_path):
     product = _run(_lib(""), tmp_path / "product.pt")
-    assert len(product) >= 23
+    assert len(product) >= 35 and sum(n.startswith('pro_') for n in product) >= 6
     for name, r in product.items():
         assert r["err"] < TOL, (name, r["err"])
         if "err_ssq" in r:
@@ -61,7 +61,7 @@ def test_emulated_whole_library_runs_gpu_tests():
     """The emulation covers the whole library (capi.hip with recorded graph capture, attention, elementwise, sampler): a slice of the
     `-m gpu` tests — sampler kernels, hipGraph capture / replay, the quantile, the combine_upsample_fmaps forwards — runs on it in a child pytest (IMAGEN_EMUL_TESTS=1, tests/conftest.py)."""
     env = dict(os.environ, IMAGEN_LIB_PATH=_lib(""), IMAGEN_EMUL_TESTS="1")
-    sel = "graph_capture_replay or ddpm_step_vs_formula or lincomb_masked or quantile_exact or time_embed_scale_shift or upsample_combiner or test_act_prep"
+    sel = "test_conv_pro_family or graph_capture_replay or ddpm_step_vs_formula or lincomb_masked or quantile_exact or time_embed_scale_shift or upsample_combiner or test_act_prep"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_kernels_gpu.py"), os.path.join(ROOT, "tests", "test_model_gpu.py"),
                         os.path.join(ROOT, "tests", "test_igemm_cfgs_gpu.py"),
                         "-q", "-m", "gpu", "-k", sel, "-p", "no:cacheprovider"], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)

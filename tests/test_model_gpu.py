@@ -3,11 +3,12 @@
   (b) the CPU oracle (oracle/) on README-sized unets with identical weights and inputs.
 
 Tolerances (normwise relative error ||y - y_ref|| / ||y_ref||, fp16 storage / fp32 accumulate):
-  * whole Unet forward (README-sized unets, incl. the benchmark's unet2 at 256^2 with enough rows that the planner picks the
-    benchmark's tile configurations):  <= UNET_TOL = 1.2e-3 (north_star: 1e-3; measured figures are printed in the terminal summary —
-    conftest.record_parity — and committed as profiles/r03_parity.json).  The reference's own fp16-autocast forward sits 2.5e-3 from its fp32 forward
-    (SURVEY.md §8c calibration); per-kernel parity on identical inputs is held to 1e-3 in test_kernels_gpu.py /
-    test_bench_shapes_gpu.py.
+  * whole Unet forward (README-sized unets, incl. the benchmark's unet2 at 256^2 on the benchmark's OWN plan: batch 8 under CFG = 16
+    rows, the tile configurations asserted equal to bench.py's):  <= UNET_TOL = 1.0e-3, north_star's figure (measured values are printed
+    in the terminal summary — conftest.record_parity — and committed under profiles/).  Of that, 0.5-0.7e-3 is paid by ANY implementation
+    that holds its parameters and inputs in fp16 (the calibration figure printed beside every case); the reference's own fp16-autocast
+    forward sits 2.5e-3 from its fp32 forward.  Per-kernel parity on identical inputs is held to 1e-3 in
+    test_kernels_gpu.py / test_bench_shapes_gpu.py.
   * sampler epilogue on identical inputs: 1e-5 (fp32 math), quantile exact.
 """
 import os
@@ -20,7 +21,7 @@ from conftest import gpu_device
 pytestmark = pytest.mark.gpu
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden")
-UNET_TOL = 1.2e-3
+UNET_TOL = 1.0e-3
 
 
 def nerr(a, b):
@@ -89,9 +90,10 @@ def _record(name, **vals):
     record_parity("unet_forward_vs_oracle[" + name + "]", **vals)
 
 
-@pytest.mark.parametrize("kw,S,B", [(README_U1, 64, 2), (README_U2, 64, 2), (README_U2, 256, 4), (MEMEFF, 32, 2), (C2_BASE, 32, 2), (C2_BASE, 64, 2), (HD32, 64, 2)],
+@pytest.mark.parametrize("kw,S,B", [(README_U1, 64, 2), (README_U2, 64, 2), (README_U2, 256, 4), (MEMEFF, 32, 2), (C2_BASE, 32, 2), (C2_BASE, 64, 2), (HD32, 64, 2),
+                                    (README_U1, 64, 8), (README_U2, 256, 8)],
                          ids=["readme-unet1@64", "readme-unet2@64", "readme-unet2@256-bench-tiles", "memory-efficient@32", "c2-dim128@32",
-                              "c2-dim128@64", "readme-unet1-heads16x32@64"])
+                              "c2-dim128@64", "readme-unet1-heads16x32@64", "readme-unet1@64-rows16", "readme-unet2@256-rows16"])
 def test_unet_forward_vs_oracle(kw, S, B, request):
     """README-sized unets (32-channel-chunk MFMA paths, 1024-token attention) vs the fp32 CPU oracle, stage by stage."""
     from imagen_pytorch_amd import Unet
@@ -103,7 +105,7 @@ def test_unet_forward_vs_oracle(kw, S, B, request):
     torch.nn.init.normal_(u.final_conv.weight, std=0.05)
     torch.nn.init.normal_(u.final_conv.bias, std=0.05)
     sd = {k: v.clone() for k, v in u.state_dict().items()}
-    x, t = torch.randn(B, 3, S, S), torch.tensor([0.3, -1.2, 0.9, 2.0][:B])
+    x, t = torch.randn(B, 3, S, S), torch.tensor([0.3, -1.2, 0.9, 2.0, 1.4, -2.2, 0.1, -0.6][:B])
     te = torch.randn(B, 24, kw.get("text_embed_dim", 768))
     mask = torch.ones(B, 24, dtype=torch.bool)
     mask[1, 18:] = False
@@ -137,6 +139,24 @@ def test_unet_forward_vs_oracle(kw, S, B, request):
     from imagen_pytorch_amd import _abi
     K_IGEMM = _abi.ENUMS["IMAGEN_OP_IGEMM"]
     cfgs = sorted({p.cfg for eng_ in u._engines.values() for kind, p, _ in eng_.step_plan.ops if kind == K_IGEMM})
+    if request.node.callspec.id.endswith("-rows16"):
+        # the benchmark's own plan: the CFG batch above ran the 2B = 16-row engine bench.py samples with — the (tile configuration, tile shape,
+        # layer) triples of ITS launches are those of the stage bench.py builds (same planner, same rows, same size; asserted, not assumed)
+        import bench
+        eng16 = next(e_ for e_ in u._engines.values() if e_.R == 2 * B)
+        mine = sorted((l, p.cfg, p.TH, p.TW) for kind, p, l in eng16.step_plan.ops if kind == K_IGEMM)
+        imagen_b = bench.build_imagen(1000, dev)
+        ub = imagen_b.unets[0 if S == 64 else 1]
+        from imagen_pytorch_amd.engine import UnetEngine
+        engb = UnetEngine(ub, 16, 8, S, dev)
+        theirs = sorted((l, p.cfg, p.TH, p.TW) for kind, p, l in engb.step_plan.ops if kind == K_IGEMM)
+        assert mine == theirs, "this test's 16-row plan must be bench.py's plan"
+        cfgs = sorted({c for _, c, _, _ in mine})
+        del imagen_b, engb
+        # ... and its two halves (rows [0, B) conditional, [B, 2B) null) against the oracle's two forwards, each at the whole-Unet bar
+        both = u._run(x.to(dev), t.to(dev), text_embeds=te.to(dev), text_mask=mask.to(dev), cfg=True, **exd)
+        e, e_null = nerr(both[:B], ref), nerr(both[B:], ref_null)
+        print(f"16-row plan: cond {e:.2e} null {e_null:.2e}")
     _record(request.node.callspec.id, cond=e, null=e_null, cfg3=e_cfg, taps=rep, rows=B, size=S, igemm_cfgs=cfgs, tol=UNET_TOL,
             **({"fp16_params_and_inputs_only_null": calib} if calib is not None else {}))
     assert e < UNET_TOL and e_null < UNET_TOL, (e, e_null, rep)

@@ -56,6 +56,14 @@ CASES = {
     "stream_raw": dict(B=2, H=40, W=36, C1=32, Cout=32, K=3, G=4, cfg="stream", prologue="none", act_in="none", ssq_out=True),
     "stream_pro_concat_post": dict(B=2, H=40, W=36, C1=32, C2=32, Cout=32, K=3, G=4, cfg="stream", prologue="ssq", affine=False, epilogue="post"),
     "stream_pro_affine_ragged": dict(B=3, H=27, W=45, C1=32, Cout=24, K=3, G=4, cfg="stream", prologue="ssq", affine=True),
+    # the streaming family with the prologue on register-staged rows (conv_pro.hip): persistent contiguous tile ranges over several images,
+    # ragged right / bottom edges, one and two inputs, shared and per-row affines (+ shifts), the three epilogues
+    "pro_concat_post": dict(B=3, H=40, W=36, C1=32, C2=32, Cout=32, K=3, G=4, cfg="pro", prologue="ssq", affine=False, epilogue="post"),
+    "pro_concat_ssq": dict(B=2, H=24, W=48, C1=32, C2=32, Cout=32, K=3, G=4, cfg="pro", prologue="ssq", affine=False, ssq_out=True),
+    "pro_single_affine_ragged": dict(B=3, H=27, W=45, C1=32, Cout=32, K=3, G=4, cfg="pro", prologue="ssq", affine=True, ssq_out=True),
+    "pro_single_post_tiny_images": dict(B=9, H=8, W=16, C1=32, Cout=32, K=3, G=4, cfg="pro", prologue="ssq", affine=True, epilogue="post"),
+    "pro_raw": dict(B=2, H=40, W=36, C1=32, Cout=32, K=3, G=4, cfg="pro", prologue="none", act_in="none", ssq_out=True),
+    "pro_raw_concat": dict(B=1, H=16, W=64, C1=32, C2=32, Cout=32, K=3, G=4, cfg="pro", prologue="none", act_in="none"),
 }
 
 
@@ -65,6 +73,8 @@ def resolve_cfg(ops, spec, kw):
         return spec
     if spec == "stream":
         return (ops.stream_cfg(), 16, 16)
+    if spec == "pro":
+        return (ops.pro_cfg(), 8, 16)
     if spec.startswith("big:"):
         i = [j for j, c in enumerate(ops.cfg_table()) if c[3] == 5][int(spec.split(":")[1])]
         sh = ops.launchable_shapes(i, kw["H"], kw["W"], 3, 3, 1)
