@@ -198,11 +198,11 @@ def roofline_leg(imagen, batch: int, device, pmc=None):
                 lib.imagen_event_create(ctypes.byref(e0))
                 lib.imagen_event_create(ctypes.byref(e1))
                 lib.imagen_event_record(e0, h)
-                _abi.check(lib.imagen_launch(kind, ctypes.addressof(struct), h))
+                _abi.check(lib.imagen_launch(kind, ctypes.addressof(struct), ctypes.sizeof(struct), h))
                 lib.imagen_event_record(e1, h)
                 evs.append((struct.cfg, igemm_flops(struct), igemm_bytes(struct), (stage_no, label), e0, e1))
             else:
-                _abi.check(lib.imagen_launch(kind, ctypes.addressof(struct), h))
+                _abi.check(lib.imagen_launch(kind, ctypes.addressof(struct), ctypes.sizeof(struct), h))
         torch.cuda.synchronize()
         for cfg, fl, by, ident, e0, e1 in evs:
             ms = ctypes.c_float()

@@ -146,7 +146,7 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.imagen_last_error.restype = ctypes.c_char_p
     lib.imagen_sizeof.restype = ctypes.c_size_t
     lib.imagen_sizeof.argtypes = [ctypes.c_int]
-    lib.imagen_launch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    lib.imagen_launch.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_void_p]
     lib.imagen_plan_run.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
     lib.imagen_igemm_config_info.argtypes = [ctypes.c_int] + [ctypes.POINTER(ctypes.c_int)] * 3
     lib.imagen_igemm_stage_slots.argtypes = [ctypes.c_int] * 3
@@ -198,4 +198,4 @@ def check(rc: int, what: str = "") -> None:
 
 
 class OpRef(ctypes.Structure):
-    _fields_ = [("kind", ctypes.c_int32), ("reserved", ctypes.c_int32), ("params", ctypes.c_void_p)]
+    _fields_ = [("kind", ctypes.c_int32), ("params_bytes", ctypes.c_int32), ("params", ctypes.c_void_p)]

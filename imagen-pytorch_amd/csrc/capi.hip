@@ -52,9 +52,14 @@ extern "C" size_t imagen_sizeof(int kind) {
   }
 }
 
-extern "C" int imagen_launch(int kind, const void* params, imagen_stream_t stream) {
+extern "C" int imagen_launch(int kind, const void* params, size_t params_bytes, imagen_stream_t stream) {
   hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   if (!params) { imagen_set_error("imagen_launch: null params (kind %d)", kind); return -1; }
+  if (imagen_sizeof(kind) != 0 && params_bytes != imagen_sizeof(kind)) {
+    imagen_set_error("imagen_launch: op kind %d takes a %zu-byte params struct, the caller passed %zu bytes (a binding built against another include/imagen_hip.h?)",
+                     kind, imagen_sizeof(kind), params_bytes);
+    return -1;
+  }
   switch (kind) {
     case IMAGEN_OP_IGEMM: return launch_igemm(static_cast<const ImagenIgemmParams*>(params), s);
     case IMAGEN_OP_ROWSTAT: return launch_rowstat(static_cast<const ImagenRowstatParams*>(params), s);
@@ -90,7 +95,7 @@ extern "C" int imagen_launch(int kind, const void* params, imagen_stream_t strea
 
 extern "C" int imagen_plan_run(const ImagenOpRef* ops, int n, imagen_stream_t stream) {
   for (int i = 0; i < n; ++i) {
-    const int rc = imagen_launch(ops[i].kind, ops[i].params, stream);
+    const int rc = imagen_launch(ops[i].kind, ops[i].params, (size_t)ops[i].params_bytes, stream);
     if (rc != 0) {
       char msg[400];
       snprintf(msg, sizeof(msg), "%s", g_err);

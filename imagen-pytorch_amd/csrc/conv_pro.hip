@@ -100,26 +100,34 @@ __global__ __launch_bounds__(CP_NT, NCH == 1 ? 3 : 2) void conv_pro_kernel(const
   // raw rows (and statistics) of one tile, as requested
   struct Raw {
     uint4 x[NCH][CP_NJ];
-    float q[CP_NJ];        // PRO: ssq_a + ssq_wb * ssq_b of the slot's pixel
+    float qa[CP_NJ], qb[CP_NJ];   // PRO: the sums of squares of the slot's pixel in the two inputs, AS LOADED (combined where they are used: any
+                                  // arithmetic on them at the request site makes the compiler wait for the loads at the loop's back edge)
     unsigned ok;           // bit j: the slot's pixel lies inside the image
   };
-  auto request = [&](Raw& R, const Tile& c) __attribute__((always_inline)) {
-    R.ok = 0;
-#pragma unroll
-    for (int j = 0; j < CP_NJ; ++j) {
-      const int gy = c.oy0 - 1 + (s_yx[j] >> 8), gx = c.ox0 - 1 + ((s_yx[j] >> 2) & 63), kg8 = (s_yx[j] & 3) * 8;
-      const bool ok = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
-      const int gp = ok ? gy * p.W + gx : 0;
-      R.x[0][j] = *reinterpret_cast<const uint4*>(x1 + (size_t)c.b * p.bs1 + (size_t)gp * p.ld1 + kg8);
-      if constexpr (NCH == 2) R.x[1][j] = *reinterpret_cast<const uint4*>(x2 + (size_t)c.b * p.bs2 + (size_t)gp * p.ld2 + kg8);
+  // request input `ch` of slot j of tile c; with the slot's LAST input also its statistics and its in-image bit (both are read by every
+  // unit of the slot, so they may only change once the slot's last unit is through)
+  auto request_unit = [&](Raw& R, const Tile& c, int j, int ch) __attribute__((always_inline)) {
+    const int gy = c.oy0 - 1 + (s_yx[j] >> 8), gx = c.ox0 - 1 + ((s_yx[j] >> 2) & 63), kg8 = (s_yx[j] & 3) * 8;
+    const bool ok = gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+    const int gp = ok ? gy * p.W + gx : 0;
+    if (ch == 0) R.x[0][j] = *reinterpret_cast<const uint4*>(x1 + (size_t)c.b * p.bs1 + (size_t)gp * p.ld1 + kg8);
+    if constexpr (NCH == 2) {
+      if (ch == 1) R.x[1][j] = *reinterpret_cast<const uint4*>(x2 + (size_t)c.b * p.bs2 + (size_t)gp * p.ld2 + kg8);
+    }
+    if (ch == NCH - 1) {
       if constexpr (PRO) {
         const size_t sp = (size_t)c.b * HWin + gp;
-        float q = p.ssq_a[sp];
-        if (has_b) q += p.ssq_wb * p.ssq_b[sp];
-        R.q[j] = q;
+        R.qa[j] = p.ssq_a[sp];
+        if constexpr (has_b) R.qb[j] = p.ssq_b[sp];
       }
-      if (ok) R.ok |= 1u << j;
+      R.ok = (R.ok & ~(1u << j)) | ((ok ? 1u : 0u) << j);
     }
+  };
+  auto request = [&](Raw& R, const Tile& c) __attribute__((always_inline)) {
+#pragma unroll
+    for (int j = 0; j < CP_NJ; ++j)
+#pragma unroll
+      for (int ch = 0; ch < NCH; ++ch) request_unit(R, c, j, ch);
   };
 
   // per-image operands -> parameter set b & 1 (two consecutive images can be live: tile t in b, tile t + 1 in b + 1)
@@ -154,7 +162,11 @@ __global__ __launch_bounds__(CP_NT, NCH == 1 ? 3 : 2) void conv_pro_kernel(const
     const int j = u / NCH, ch = u - j * NCH;
     if (part == 0) {
       U.rs = 1.0f;
-      if constexpr (PRO) U.rs = __builtin_amdgcn_rsqf(fmaxf(R.q[j], 1e-24f));
+      if constexpr (PRO) {
+        float q = R.qa[j];
+        if constexpr (has_b) q += p.ssq_wb * R.qb[j];
+        U.rs = __builtin_amdgcn_rsqf(fmaxf(q, 1e-24f));
+      }
     } else if (part <= 4) {
       const int e = 2 * (part - 1);
       const unsigned w = e == 0 ? R.x[ch][j].x : e == 2 ? R.x[ch][j].y : e == 4 ? R.x[ch][j].z : R.x[ch][j].w;
@@ -189,6 +201,7 @@ __global__ __launch_bounds__(CP_NT, NCH == 1 ? 3 : 2) void conv_pro_kernel(const
 
   Tile cur = tile_at(t_begin);
   Raw R;
+  R.ok = 0;
   refresh(cur.b);
   request(R, cur);
   {
@@ -207,8 +220,8 @@ __global__ __launch_bounds__(CP_NT, NCH == 1 ? 3 : 2) void conv_pro_kernel(const
   int buf = 0;
 
   for (int t = t_begin; t < t_end; ++t) {
-    if (more) refresh(nxt.b);   // (uniform; a barrier of its own only when the image changes)
-    __syncthreads();            // tile t's image is complete; nobody reads the other buffer (tile t - 1) any more
+    __syncthreads();            // tile t's image is complete; nobody reads the other buffer (tile t - 1) or the previous epilogue's operands any more
+    if (more) refresh(nxt.b);   // (uniform; a second barrier only when tile t + 1 opens a new image)
     const char* ab = acts + buf * NCH * CP_ABUF;
     const float* ep = par + (cur.b & 1) * PSET + 128;
 
@@ -230,6 +243,11 @@ __global__ __launch_bounds__(CP_NT, NCH == 1 ? 3 : 2) void conv_pro_kernel(const
       const int dy = tap / 3, dx = tap - 3 * dy;
       return *reinterpret_cast<const f16x8*>(ab + ch * CP_ABUF + bA[2 * dx + ks] + dy * CP_PITCH);
     };
+    // ... and as soon as a unit of tile t + 1 has left its registers (part 5), the same unit of tile t + 2 is requested into them: every
+    // load has a whole tile period (K loop, epilogue, barrier) to land, with no second register set.  Past the end of the range the last
+    // tile is requested again (never consumed): no branch.
+    const bool more2 = t + 2 < t_end;
+    const Tile nn = tile_at(min(t + 2, t_end - 1));
     f16x8 bfr[2];
     bfr[0] = bfrag(0);
     Unit U;
@@ -238,15 +256,8 @@ __global__ __launch_bounds__(CP_NT, NCH == 1 ? 3 : 2) void conv_pro_kernel(const
       if (s + 1 < STEPS) bfr[(s + 1) & 1] = bfrag(s + 1);
       acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(areg[s / 18][s % 18], bfr[s & 1], acc, 0, 0, 0);
       transform_part(R, U, s / 6, s % 6, buf ^ 1, nxt.b);
+      if (s % 6 == 5) request_unit(R, nn, (s / 6) / NCH, (s / 6) % NCH);
       __builtin_amdgcn_sched_barrier(0);
-    }
-
-    // the rows of tile t + 2: in flight across this tile's epilogue and the next tile's K loop
-    Tile nn = nxt;
-    const bool more2 = t + 2 < t_end;
-    if (more2) {
-      nn = tile_at(t + 2);
-      request(R, nn);
     }
 
     // ---- epilogue of tile t: register quad q holds couts 8q + 4*half + {0..3} of the lane's pixel

@@ -117,6 +117,7 @@ LN_STATS_FUSED = 1   # (module constant; call B) LayerNorm statistics from the p
 #    error of these weights is the SAME vector in every null row: a bias, not noise — 1.11e-3 -> 0.99e-3 on the null rows of README unet1.
 #  * SPLIT_SMALL: block1 of the 32-channel ResnetBlocks and the final conv of stages whose launches are latency-bound (<= SPLIT_SMALL_FLOPS
 #    executed FLOPs): the layers next to the output, whose weight rounding reaches it unattenuated (0.99e-3 -> 0.94e-3).
+TIME_TABLE_MAX_BYTES = int(float(os.environ.get("IMAGEN_TIME_TABLE_MAX_GB", "4")) * (1 << 30))   # per stage and lane (enable_time_table)
 SPLIT_STATIC = int(os.environ.get("IMAGEN_SPLIT_STATIC", "1"))
 SPLIT_SMALL = int(os.environ.get("IMAGEN_SPLIT_SMALL", "1"))
 SPLIT_SMALL_MAX_K = int(os.environ.get("IMAGEN_SPLIT_MAX_K", "320"))        # taps * input channels of the unsplit weight
@@ -245,6 +246,7 @@ class UnetEngine:
             self._self_cond_op = ops.pack_image(plan, self.self_cond_in, self.cond_in, self.cimg, brep=R // self.src_batch, label="pack_self_cond")
 
         # ---- time conditioning (ip.py:1573-1578)
+        chain_begin = len(plan.ops)
         self.hid = self.new(1, 1, R, self.Tc)
         self._time_embed_op = ops.time_embed(
             plan, times=self.times, coef=None, step_ptr=None,
@@ -274,6 +276,7 @@ class UnetEngine:
 
         # ---- conditioning K/V rows that depend on the timestep (filled after the traversal registers the sites)
         self._kv_dynamic_anchor = len(plan.ops)
+        self._time_chain_ops = [st for _, st, label in plan.ops[chain_begin:] if label in self._TIME_CHAIN]
 
         # ---- U-net traversal
         x = self.new(R, S, S, self.lc["init_dim"])
@@ -336,6 +339,7 @@ class UnetEngine:
         dyn = Plan("kv-dynamic")
         self._dyn_proj = self._emit_context_kv(dyn, self.c_time, rows_per_batch=self.ntt, k_row0_self=0, k_row0_cross=1, tag="dyn")
         plan.ops[self._kv_dynamic_anchor:self._kv_dynamic_anchor] = dyn.ops
+        self._time_chain_ops += [st for _, st, label in dyn.ops if label in self._TIME_CHAIN]
         plan.keep.extend(dyn.keep)
         plan._arr = None
         return plan
@@ -625,12 +629,13 @@ class UnetEngine:
         for d, (attn, ff) in enumerate(tb.layers):
             nm = f"{name}.layers.{d}"
             # LayerNorm statistics of the attention input from the launch that produced it (a fused ResnetBlock tail), where there is one
-            x1, st = self._self_attn(plan, cur.tokens(), attn, nm, with_context, ln_stats=ops.request_ln_stats(cur) if LN_STATS_FUSED else None)
+            x1, st = self._self_attn(plan, cur.tokens(), attn, nm, with_context, ln_stats=ops.request_ln_stats(cur) if LN_STATS_FUSED else None,
+                                     want_stats=True)
             ffo = self._feed_forward(plan, x1, ff, nm + ".ff", ln_stats=st, split=SPLIT_1X1 and self._split_small(2 * C, 1, C, R * N))
             cur = Act(ffo.t, R, x.H, x.W, C, C, N * C, ssq=ffo.ssq)
         return cur
 
-    def _self_attn(self, plan, tok: Act, attn, nm: str, with_context: bool, ln_stats: Optional[tuple] = None):
+    def _self_attn(self, plan, tok: Act, attn, nm: str, with_context: bool, ln_stats: Optional[tuple] = None, want_stats: bool = False):
         """attn(tok) + tok for the (R, 1, N, C) token view `tok` (ip.py:502-591, 1017): LayerNorm -> q | k | v in one GEMM ->
         K^/V^T rows behind the conditioning and null rows -> flash attention -> to_out -> LayerNorm + residual."""
         W, R = self.W, self.R
@@ -667,7 +672,7 @@ class UnetEngine:
         y = self.new(R, 1, N, C)
         ops.igemm(plan, o, W.conv(nm + ".to_out", attn.to_out[0], split=SPLIT_1X1 and self._split_small(inner, 1, C, R * N)), y, label=nm + ".to_out")
         x1 = self.new(R, 1, N, C)
-        st = (self.f32buf(R * N), self.f32buf(R * N)) if LN_STATS_FUSED else None   # statistics of x1 for the FeedForward's first LayerNorm
+        st = (self.f32buf(R * N), self.f32buf(R * N)) if (LN_STATS_FUSED and want_stats) else None   # statistics of x1 for a FeedForward's first LayerNorm (a second pass over the row: only where one follows)
         ops.ln_residual(plan, y, W.f32(nm + ".out_g", lambda: attn.to_out[1].g), x1, res=tok, eps=1e-5, ln_stats_out=st, label=nm + ".out_norm")
         return x1, st
 
@@ -1000,7 +1005,8 @@ class UnetEngine:
                 self._tt_plan.run()
         self._cond_ready = True
 
-    # the launches of the step plan that depend on the timestep and the conditioning only (not on x_t), by label
+    # labels of the launches of the step plan that depend on the timestep and the conditioning only (not on x_t); the planner records the
+    # params structs themselves while it emits them (self._time_chain_ops): the fast plan drops exactly those, whatever a later op is called
     _TIME_CHAIN = ("time_embed", "to_time_cond", "to_time_tokens", "norm_cond(time)", "time_mlps", "scale_shift", "ctx.dyn.ln", "ctx.dyn.self",
                    "ctx.dyn.cross")
 
@@ -1015,6 +1021,15 @@ class UnetEngine:
         if self._tt_plan is not None:
             return self.step_plan_tt
         rows_all = NR * R
+        # footprint of the tables and of the batched pass's intermediates, per stage and lane (fp32 scale / shift rows, fp16 hiddens, time
+        # tokens and K / V projections): 1.1 GB for the README super-resolution unet at batch 8, 1000 steps.  Above the cap (large batches,
+        # long schedules, small-memory parts) the per-step chain stays: same results, nine small launches per step.
+        selfs_, crosses_, ws_, wc_ = self._ctx_weights()
+        proj_c = (ws_.Cout if selfs_ else 0) + (wc_.Cout if crosses_ else 0)
+        tt_bytes = rows_all * (2 * 4 * self.total_c + 2 * (3 * self.Tc + 2 * self.total_c) + self.ntt * (2 * 2 * self.cond_dim + 2 * proj_c + 8))
+        self.time_table_bytes = tt_bytes
+        if tt_bytes > TIME_TABLE_MAX_BYTES:
+            return None
         tt = Plan("unet-time-table")
         times_all = coef[:, 6].to(self.dev).float().repeat_interleave(R).contiguous()       # the log-SNR every step's time_embed reads
         tc_all = self.new(1, 1, rows_all, self.Tc)
@@ -1056,14 +1071,17 @@ class UnetEngine:
         ops.step_slice(one, segments, step_ptr, label="time_table_rows")
         fast = Plan("unet-step-tt")
         placed = False
+        chain = {id(st) for st in self._time_chain_ops}
+        assert NR == coef.shape[0] and len(chain) == sum(l in self._TIME_CHAIN for _, _, l in self.step_plan.ops), \
+            "the recorded timestep chain and the labelled one differ"
         for kind, st, label in self.step_plan.ops:
-            if label in self._TIME_CHAIN:
+            if id(st) in chain:
                 if not placed:
                     fast.ops.append(one.ops[0])
                     placed = True
                 continue
             fast.ops.append((kind, st, label))
-        assert placed and len(fast.ops) == len(self.step_plan.ops) - sum(l in self._TIME_CHAIN for _, _, l in self.step_plan.ops) + 1
+        assert placed and len(fast.ops) == len(self.step_plan.ops) - len(chain) + 1
         fast.keep = list(self.step_plan.keep) + list(one.keep) + [times_all]
         self.step_plan_tt = fast
         self._tt_plan = tt

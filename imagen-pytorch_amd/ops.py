@@ -79,6 +79,7 @@ class Plan:
             arr = (OpRef * len(self.ops))()
             for i, (kind, st, _) in enumerate(self.ops):
                 arr[i].kind = kind
+                arr[i].params_bytes = ctypes.sizeof(st)
                 arr[i].params = ctypes.addressof(st)
             self._arr = arr
         return self._arr
@@ -95,7 +96,7 @@ class Plan:
         lib = load_library()
         s = current_stream_handle() if stream is None else stream
         for kind, st, label in self.ops:
-            check(lib.imagen_launch(kind, ctypes.addressof(st), s), f"op {label or kind}")
+            check(lib.imagen_launch(kind, ctypes.addressof(st), ctypes.sizeof(st), s), f"op {label or kind}")
             if sync_each:
                 torch.cuda.synchronize()
 

@@ -31,7 +31,8 @@
 extern "C" {
 #endif
 
-#define IMAGEN_ABI_VERSION 6 /* 3: head_dim in the attention / QNORM / KV_PREP params; 4: DDPM_UPDATE x0_thr; 5: GCA_TAIL; 6: ACT_PREP self_stat, STEP_SLICE */
+#define IMAGEN_ABI_VERSION 7 /* 3: head_dim in the attention / QNORM / KV_PREP params; 4: DDPM_UPDATE x0_thr; 5: GCA_TAIL; 6: ACT_PREP self_stat, STEP_SLICE;
+                               * 7: every launch carries sizeof(its params struct) (a stale mirror of a struct fails loudly), ImagenIgemmParams.dbg -> launcher_word, kernel family 6 */
 
 typedef void* imagen_stream_t; /* hipStream_t */
 
@@ -408,13 +409,16 @@ typedef struct ImagenMeanRowsParams {
 
 typedef struct ImagenMemset32Params { void* dst; uint32_t value; int32_t count; } ImagenMemset32Params;
 
-typedef struct ImagenOpRef { int32_t kind; int32_t reserved; const void* params; } ImagenOpRef;
+/* one entry of a plan: params_bytes = the caller's sizeof(params struct of `kind`) — checked against imagen_sizeof(kind) on every run, so a binding
+ * built against another version of this header is refused instead of being read past its end */
+typedef struct ImagenOpRef { int32_t kind; int32_t params_bytes; const void* params; } ImagenOpRef;
 
 /* ---- entry points ------------------------------------------------------------------------------ */
 int imagen_abi_version(void);
 const char* imagen_last_error(void);
 size_t imagen_sizeof(int kind);                       /* sizeof the params struct of an op kind */
-int imagen_launch(int kind, const void* params, imagen_stream_t stream);
+/* launch one op: params_bytes must equal imagen_sizeof(kind) (the caller's sizeof of its mirror of the struct), else -1 and nothing is launched */
+int imagen_launch(int kind, const void* params, size_t params_bytes, imagen_stream_t stream);
 int imagen_plan_run(const ImagenOpRef* ops, int n, imagen_stream_t stream);
 
 /* igemm tile selection + packing.  cfg ids are stable; *_tile_* describe a cfg. */

@@ -23,6 +23,7 @@ def test_library_loads_and_exports_every_declared_symbol(lib):
     assert declared, "no entry points parsed from include/imagen_hip.h"
     for sym in declared:
         assert hasattr(lib, sym), f"libimagen_hip.so does not export {sym} declared in include/imagen_hip.h"
+    assert declared == set(_abi.EXPORTED_SYMBOLS), "the binding's symbol list (and INTEGRATION.md's) must be exactly the header's entry points"
     assert lib.imagen_abi_version() == _abi.ENUMS["IMAGEN_ABI_VERSION"]
 
 
@@ -38,12 +39,26 @@ def test_launch_rejects_bad_arguments_without_a_gpu(lib):
     """Argument validation happens on the host before any launch: error code + message, no crash."""
     from imagen_pytorch_amd import _abi
 
-    assert lib.imagen_launch(9999, ctypes.c_void_p(1), None) != 0
+    assert lib.imagen_launch(9999, ctypes.c_void_p(1), 0, None) != 0
     assert b"unknown op kind" in lib.imagen_last_error()
     p = _abi.STRUCTS["ImagenIgemmParams"]()
     p.cfg = 0
-    assert lib.imagen_launch(_abi.ENUMS["IMAGEN_OP_IGEMM"], ctypes.addressof(p), None) != 0
+    assert lib.imagen_launch(_abi.ENUMS["IMAGEN_OP_IGEMM"], ctypes.addressof(p), ctypes.sizeof(p), None) != 0
     assert b"null" in lib.imagen_last_error()
+
+
+def test_stale_struct_mirror_is_refused(lib):
+    """ABI 7: every launch carries the caller's sizeof(params struct); a binding built against another version of the header (one field
+    short here) is refused before anything is read, by imagen_launch and by imagen_plan_run alike."""
+    from imagen_pytorch_amd import _abi
+
+    K = _abi.ENUMS["IMAGEN_OP_IGEMM"]
+    p = _abi.STRUCTS["ImagenIgemmParams"]()
+    assert lib.imagen_launch(K, ctypes.addressof(p), ctypes.sizeof(p) - 8, None) != 0
+    assert b"params struct" in lib.imagen_last_error()
+    ref = _abi.OpRef(kind=K, params_bytes=ctypes.sizeof(p) - 8, params=ctypes.addressof(p))
+    assert lib.imagen_plan_run(ctypes.addressof(ref), 1, None) != 0
+    assert b"params struct" in lib.imagen_last_error()
 
 
 def test_missing_library_fails_loudly(tmp_path):
