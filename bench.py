@@ -217,7 +217,7 @@ def roofline_leg(imagen, batch: int, device, pmc=None):
             lib.imagen_event_destroy(e0)
             lib.imagen_event_destroy(e1)
     tab = ops.cfg_table()
-    fam_name = {0: "igemm_kernel", 2: "conv_dma_kernel", 3: "conv_stream_kernel", 4: "conv_pw_kernel", 5: "conv_big_kernel"}
+    fam_name = {0: "igemm_kernel", 2: "conv_dma_kernel", 3: "conv_stream_kernel", 4: "conv_pw_kernel", 5: "conv_big_kernel", 6: "conv_pro_kernel"}
 
     def describe(bound):
         cands = {k: v for k, v in groups.items() if k[0] == bound}
@@ -320,6 +320,72 @@ def cpu_baseline_leg(imagen, batch: int):
                       f"(u1 {per_step[0]:.2f} s, u2 {per_step[1]:.2f} s), linearly extrapolated to {T} steps/stage"}
 
 
+# BASELINE.json configs beside the headline (C3), informational legs printing the same JSON shape (`--config c2 | c4 | c5`): algorithmic
+# FLOPs per unit and the per-unit ceilings are SURVEY.md §8d's
+OTHER_CONFIGS = {
+    "c2": dict(flops_per_unit=186.1e12, ceiling=(12.47, 14.0), unit="images/s",
+               workload="C2: base Unet dim 128 (README unet1 kwargs x4 channels), 64^2, 1000 DDPM steps, CFG 3.0, batch 8 (BASELINE says bf16; this path "
+                        "computes in fp16 with fp32 accumulation: same MFMA rate, 8x finer mantissa)"),
+    "c4": dict(flops_per_unit=18.1e12, ceiling=(79.4, 140.8), unit="images/s",
+               workload="C4 (one GPU's shard): ElucidatedImagen, README unet1 + unet2, 64 -> 256, 32 Karras steps (63 denoiser evaluations per stage), "
+                        "CFG 3.0, 4 images per GPU (= 32 over 8 GPUs)"),
+    "c5": dict(flops_per_unit=163.0e12, ceiling=(15.3, 15.3), unit="clips/s",
+               workload="C5: Imagen-Video Unet3D(dim 64, dim_mults (1, 2, 4, 8)), one 16 x 64 x 64 clip, 250 DDPM steps, CFG 3.0"),
+}
+
+
+def other_config_leg(name: str, steps: int, reps: int):
+    """One of BASELINE.json's other configs on one GPU: `steps` sampling steps timed (graph replays, after a 2-step warm-up that packs the
+    weights and captures the graphs), linearly extrapolated to the config's full schedule where `steps` is smaller (said in the record).
+    Prints the bench JSON shape with the SURVEY ceiling and the fraction of the dense MFMA peak beside it."""
+    from imagen_pytorch_amd import ElucidatedImagen, Imagen, Unet, Unet3D
+
+    dev = torch.device("cuda", 0)
+    torch.cuda.set_device(dev)
+    torch.manual_seed(0)
+    meta = OTHER_CONFIGS[name]
+    kw = dict(cond_scale=3.0, use_tqdm=False)
+    if name == "c2":
+        model = Imagen((Unet(**dict(README_U1, dim=128)),), image_sizes=(64,), timesteps=1000, cond_drop_prob=0.1)
+        B, T, per = 8, 1000, "image"
+    elif name == "c4":
+        model = ElucidatedImagen((Unet(**README_U1), Unet(**README_U2)), image_sizes=(64, 256), num_sample_steps=32, cond_drop_prob=0.1)
+        B, T, per, steps = 4, 32, "image", 32
+    else:
+        model = Imagen((Unet3D(dim=64, dim_mults=(1, 2, 4, 8)),), image_sizes=(64,), timesteps=250, cond_drop_prob=0.1)
+        B, T, per = 1, 250, "clip"
+        kw["video_frames"] = 16
+    for u in model.unets:
+        torch.nn.init.normal_(u.final_conv.weight, std=0.05)
+        torch.nn.init.normal_(u.final_conv.bias, std=0.05)
+    model = model.to(dev).eval()
+    te = torch.randn(B, 256, 768, generator=torch.Generator().manual_seed(1234)).to(dev)
+    steps = min(steps, T)
+    run_kw = dict(kw) if name == "c4" else dict(kw, max_steps=steps)
+    model.sample(text_embeds=te, seed=1, **(kw if name == "c4" else dict(kw, max_steps=2)))
+    torch.cuda.synchronize()
+    best = 1e30
+    for r in range(reps):
+        t0 = time.perf_counter()
+        out = model.sample(text_embeds=te, seed=2 + r, **run_kw)
+        torch.cuda.synchronize()
+        best = min(best, time.perf_counter() - t0)
+    assert torch.isfinite(out).all()
+    full = best * (T / steps)          # seconds per batch at the config's full schedule
+    value = B / full
+    launches = {f"stage{k[0]}": len(st["plan"].ops) for k, st in getattr(model, "_stages", {}).items()}
+    rec = {"metric": f"{meta['unit']} ({name.upper()}, BASELINE.json configs)", "value": round(value, 4), "unit": meta["unit"], "n_gpus": 1, "steps": reps, "warmup": 1,
+           "ms_per_step": round(full * 1e3, 2), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f16", "data": "synthetic",
+           "config": {"workload": meta["workload"], "global_batch": B, "timed_sampling_steps": steps, "schedule_steps": T,
+                      "extrapolated": steps < T, "launches_per_step": launches},
+           "ms_per_sampling_step": round(best / steps * 1e3, 4),
+           "ceiling_per_unit": {"value": list(meta["ceiling"]), "unit": meta["unit"], "source": "SURVEY.md §8d: max(MFMA, HBM) per unit at 8 | 6.29 TB/s .. 100 % MFMA"},
+           "path_tflops_reference_count": round(value * meta["flops_per_unit"] / 1e12, 1),
+           "path_frac_of_mfma_peak": round(value * meta["flops_per_unit"] / 1e12 / MFMA_PEAK_TFLOPS, 4),
+           "note": f"one request at a time (batch {B}), best of {reps}; per {per}: {meta['flops_per_unit'] / 1e12:.1f} TFLOP by the reference's own count"}
+    print(json.dumps(rec), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -337,7 +403,13 @@ def main():
     ap.add_argument("--no-roofline", action="store_true")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic / mfma_busy_frac = null)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="time the CPU baseline leg only (no GPU needed) and print its JSON")
+    ap.add_argument("--config", choices=("c3", "c2", "c4", "c5"), default="c3",
+                    help="c3 (default): the headline metric; c2 / c4 / c5: BASELINE.json's other configs as informational one-GPU legs (same JSON shape)")
+    ap.add_argument("--config-steps", type=int, default=50, help="sampling steps timed by the c2 / c5 legs (extrapolated to the full schedule)")
     args = ap.parse_args()
+    if args.config != "c3":
+        other_config_leg(args.config, args.config_steps, max(1, args.steps))
+        return
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline_leg(None, args.batch)), flush=True)
         return

@@ -325,9 +325,10 @@ def pw_cfg(kchunks: int, Cout: int) -> Optional[int]:
     return best
 
 
-def pro_cfg() -> Optional[int]:
-    """Tile cfg id of the streaming family with the prologue on register-staged rows (family 6), None if the library has none."""
-    return next((i for i, c in enumerate(cfg_table()) if c[3] == 6), None)
+def pro_cfg(Cout: int = 32) -> Optional[int]:
+    """Tile cfg id of the streaming family with the prologue on register-staged rows (family 6) built for exactly `Cout` (32 | 64) output
+    channels, None if the library has none."""
+    return next((i for i, c in enumerate(cfg_table()) if c[3] == 6 and c[1] == Cout), None)
 
 
 def stream_cfg() -> Optional[int]:
@@ -473,18 +474,21 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
     C2 = x2.C if x2 is not None else 0
     assert x1.C + C2 == pw.Cin, f"{label}: input channels {x1.C}+{C2} != weight Cin {pw.Cin}"
     want_gca = gca is not None and out_mode == OUT_NHWC and act_out == ACT_NONE and addend is None and res is None and post is None
-    if cfg is None and CONV_PRO and KH == 3 and KW == 3 and stride == 1 and pad == 1 and pw.G == 4 and pro_cfg() is not None:
-        # family 6: exactly 32 output channels from one or two 32-channel inputs, the ssq-statistics SiLU prologue on register-staged rows
-        # (CONV_PRO = 2: raw inputs too), plain / post / ssq_out epilogue
+    if cfg is None and CONV_PRO and KH == 3 and KW == 3 and stride == 1 and pad == 1 and pw.G == 4 and pro_cfg(pw.Cout) is not None:
+        # family 6: exactly 32 output channels from 32 | 32 + 32 input channels, or 64 from two or three 32-channel chunks (64 | 64 + 32 | 32 + 32):
+        # the ssq-statistics SiLU prologue on register-staged rows (CONV_PRO = 2: raw inputs too), plain / post (/ ssq_out, 32 couts) epilogue
         no_pro = mu is None and rs is None and pa is None and ps is None and ssq_a is None and act_in == ACT_NONE
-        ssq_pro = mu is None and rs is None and pa is not None and ssq_a is not None and act_in == ACT_SILU and (x2 is None or ssq_b is not None)
+        ssq_pro = mu is None and rs is None and pa is not None and ssq_a is not None and act_in == ACT_SILU and ((x2 is None) == (ssq_b is None))
+        nch = (x1.C + C2) // 32
+        chunks_ok = x1.C % 32 == 0 and C2 % 32 == 0 and pw.Cin_pad == x1.C + C2 and ((pw.Cout == 32 and nch in (1, 2) and x1.C == 32)
+                                                                                      or (pw.Cout == 64 and nch in (2, 3)))
         tiles = x1.B * math.ceil(OH / 8) * math.ceil(OW / 16)
         gca_here = want_gca and x1.B * math.ceil(OH / 16) * math.ceil(OW / 16) <= GCA_EPILOGUE_MAX_TILES
-        if (pw.Cout == 32 and x1.C == 32 and C2 in (0, 32) and pw.Cin_pad == x1.C + C2 and x1.ld % 8 == 0 and x1.bs % 8 == 0
-                and (x2 is None or (x2.ld % 8 == 0 and x2.bs % 8 == 0)) and (ssq_pro or (no_pro and CONV_PRO >= 2)) and not gca_here
+        if (chunks_ok and x1.ld % 8 == 0 and x1.bs % 8 == 0 and (x2 is None or (x2.ld % 8 == 0 and x2.bs % 8 == 0))
+                and (ssq_pro or (no_pro and CONV_PRO >= 2)) and not gca_here and (pw.Cout == 32 or post is not None or ssq_out is None)
                 and tiles >= PRO_MIN_TILES and out_mode == OUT_NHWC and addend is None and res is None and act_out == ACT_NONE
                 and isinstance(y, Act) and y.ld % 8 == 0 and y.bs % 8 == 0 and not pw.split):
-            cfg = (pro_cfg(), 8, 16)
+            cfg = (pro_cfg(pw.Cout), 8, 16)
     if cfg is None and CONV_STREAM and KH == 3 and KW == 3 and stride == 1 and pad == 1 and pw.G == 4:
         # the streaming family: C_out <= 32 from one or two 32-channel inputs, raw or with the ssq-statistics Block prologue
         no_pro = mu is None and rs is None and pa is None and ps is None and ssq_a is None and act_in == ACT_NONE

@@ -173,8 +173,8 @@ def test_conv_pro_family(ops, dev):
     plain / ssq_out / post epilogues, ragged images (partial 8 x 16 tiles, zero padding of the ACTIVATED tensor), images of a single tile
     (the per-image parameter sets alternate every tile), and maps with several tiles per persistent workgroup (contiguous tile ranges, the
     register-staged rows two tiles ahead, the double-buffered tile image)."""
-    pid = ops.pro_cfg()
-    assert pid is not None
+    pid = ops.pro_cfg(32)
+    assert pid is not None and ops.pro_cfg(64) is not None
     cfg = (pid, 8, 16)
     base = dict(K=3, G=4, cfg=cfg, Cout=32, C1=32)
     raw = dict(prologue="none", act_in="none")
@@ -187,7 +187,19 @@ def test_conv_pro_family(ops, dev):
         assert r["err"] < TOL and r["err_ssq"] < 2e-3, (C2, "ragged", r)
         r = run_case(ops, dev, B=9, H=8, W=16, C2=C2, **base, prologue="ssq", affine=True, epilogue="post")   # one tile per image
         assert r["err"] < TOL, (C2, "single-tile images", r)
+    # 64 output channels: eight waves (two cout blocks per pixel block), the last chunks' weights from LDS, the output-side norm across the two
+    # cout waves of a pixel; 64 | 64 + 32 | 32 + 32 input channels; ranges of odd length compute their last tile twice
+    base64 = dict(K=3, G=4, cfg=(ops.pro_cfg(64), 8, 16), Cout=64)
+    for C1, C2 in ((64, 32), (32, 32), (64, 0)):
+        for kw in (dict(prologue="ssq", affine=False, epilogue="post"), dict(prologue="ssq", affine=True, epilogue="post"), dict(prologue="ssq", affine=True),
+                   dict(raw), dict(raw, epilogue="post")):
+            r = run_case(ops, dev, B=3, H=27, W=45, C1=C1, C2=C2, **base64, **kw)
+            assert r["err"] < TOL, ("64 couts", C1, C2, kw, r)
+    r = run_case(ops, dev, B=5, H=24, W=16, C1=32, C2=32, **base64, prologue="ssq", affine=True, epilogue="post")
+    assert r["err"] < TOL, ("64 couts, odd ranges", r)
     if not EMULATED:   # 2 x 34 x 17 = 1156 tiles (one input: 768 resident workgroups) / 2 x 45 x 12 = 1080 tiles (two inputs: 512)
+        r = run_case(ops, dev, B=16, H=128, W=128, C1=64, C2=32, **base64, prologue="ssq", affine=False, epilogue="post")
+        assert r["err"] < TOL, ("96 -> 64 at the benchmark's size", r)
         r = run_case(ops, dev, B=2, H=272, W=272, C2=0, **base, prologue="ssq", affine=True, ssq_out=True)
         assert r["err"] < TOL and r["err_ssq"] < 2e-3, ("many tiles", r)
         r = run_case(ops, dev, B=2, H=360, W=190, C2=32, **base, prologue="ssq", affine=False, epilogue="post")

@@ -2,7 +2,8 @@
 round-2 call gpu_r2_a.sh — both temporal kernels, the Unet3D forward and the two video samplers passed as written; the one failure was
 this file's own view-pattern test reading its outputs before the plan had run).  IMAGEN_VIDEO_GPU_TESTS=0 switches the file off.
 
-The kernel tests compare the HIP ops with tests/plan_interp.py's restatement of their contract (include/imagen_hip.h); the model
+The two temporal kernels are compared stand-alone with the ORACLE's functions (oracle/unet3d_oracle.py: temporal_peg, attention3d +
+dynamic_position_bias) and, as a second opinion, with tests/plan_interp.py's restatement of their contract (include/imagen_hip.h); the model
 test compares Unet3D.forward with the reference fixture (tests/golden/unet3d_tiny.pt), bar as for the image Unet.
 """
 import os
@@ -121,6 +122,94 @@ def test_temporal_attention_kernel(Fr, causal):
 
     hip, ref = _both(build)
     assert nerr(hip, ref) < 2e-3
+
+
+@pytest.mark.parametrize("causal", [True, False])
+def test_temporal_peg_kernel_vs_oracle(causal):
+    """TEMPORAL_PEG alone against the ORACLE's temporal_peg (oracle/unet3d_oracle.py, iv.py:1413-1414: F.pad + depthwise Conv3d (3, 1, 1) +
+    residual) — not against the contract interpreter, which is this repo's own restatement of the kernel."""
+    from imagen_pytorch_amd import ops
+    from oracle import unet3d_oracle as u3
+    from oracle.unet_oracle import _SD
+
+    dev = gpu_device()
+    g = torch.Generator().manual_seed(3)
+    R, Fr, S, C = 2, 6, 8, 40
+    x = torch.randn(R, C, Fr, S, S, generator=g).half().float()
+    sd = {"fn.1.weight": torch.randn(C, 1, 3, 1, 1, generator=g) * 0.5, "fn.1.bias": torch.randn(C, generator=g) * 0.2}
+    ref = u3.temporal_peg(_SD(sd), x, causal=causal)                                   # (R, C, F, S, S)
+    xa = ops.new_act(R * Fr, S, S, C, dev)
+    xa.t.copy_(x.permute(0, 2, 3, 4, 1).reshape(R * Fr, S, S, C).half())             # frame-major clips: (b, f) consecutive NHWC frames
+    out = ops.new_act(R * Fr, S, S, C, dev)
+    plan = ops.Plan()
+    ops.temporal_peg(plan, xa, sd["fn.1.weight"].reshape(C, 3).contiguous().to(dev), sd["fn.1.bias"].to(dev), out, B=R, F=Fr, causal=causal)
+    plan.run()
+    torch.cuda.synchronize()
+    got = out.t.float().cpu().reshape(R, Fr, S, S, C).permute(0, 4, 1, 2, 3)
+    assert nerr(got, ref) < 1e-3
+
+
+@pytest.mark.parametrize("Fr,causal", [(4, True), (16, True), (7, False)])
+def test_temporal_attention_kernel_vs_oracle(Fr, causal):
+    """TEMPORAL_ATTENTION alone against the ORACLE's attention3d (iv.py:499-570 along the frame axis, iv.py:257-270): the q | k | v rows are
+    the oracle-side projections of the normalised sequence (fp32 torch, rounded to the kernel's fp16 storage), the bias table is the oracle's
+    dynamic_position_bias + null_attn_bias; `to_out` is the identity so that the oracle's output is LayerNorm(kernel output) * g — the
+    kernel's own product is what is compared."""
+    import torch.nn.functional as F
+    from imagen_pytorch_amd import ops
+    from oracle import unet3d_oracle as u3
+    from oracle.unet_oracle import _SD, gain_layernorm
+
+    dev = gpu_device()
+    g = torch.Generator().manual_seed(4)
+    R, P, heads, dh = 2, 37, 3, 64
+    C = heads * dh
+    rn = lambda *s: torch.randn(*s, generator=g)
+    sd = {"norm.g": 1 + 0.1 * rn(C), "to_q.weight": rn(C, C) / C ** 0.5, "to_kv.weight": rn(2 * dh, C) / C ** 0.5, "null_kv": rn(2, dh),
+          "q_scale": torch.rand(dh, generator=g) + 0.5, "k_scale": torch.rand(dh, generator=g) + 0.5, "null_attn_bias": rn(heads),
+          "to_out.0.weight": torch.eye(C), "to_out.1.g": 1 + 0.1 * rn(C),
+          "rel_pos_bias.mlp.0.0.weight": rn(16, 1), "rel_pos_bias.mlp.0.0.bias": rn(16) * 0.1, "rel_pos_bias.mlp.0.1.g": torch.ones(16),
+          "rel_pos_bias.mlp.1.weight": rn(heads, 16) * 0.3, "rel_pos_bias.mlp.1.bias": rn(heads) * 0.1}
+    p = _SD(sd)
+    seq = rn(R * P, Fr, C)                                                             # one sequence of F frames per (clip, pixel)
+    xn = gain_layernorm(seq, sd["norm.g"])
+    q16, kv16 = F.linear(xn, sd["to_q.weight"]).half(), F.linear(xn, sd["to_kv.weight"]).half()
+    # attention3d's arithmetic from its l2norm on, restated piece by piece on the ROUNDED projections (checked against the function itself below)
+    q = q16.float().reshape(R * P, Fr, heads, dh).permute(0, 2, 1, 3)
+    k = torch.cat((sd["null_kv"][0].expand(R * P, 1, dh), kv16[..., :dh].float()), dim=1)
+    v = torch.cat((sd["null_kv"][1].expand(R * P, 1, dh), kv16[..., dh:].float()), dim=1)
+    qh = F.normalize(q, dim=-1, eps=1e-12) * sd["q_scale"]
+    kh = F.normalize(k, dim=-1, eps=1e-12) * sd["k_scale"]
+    sim = torch.einsum("bhid,bjd->bhij", qh, kh) * 8.0
+    bias = torch.cat((sd["null_attn_bias"].reshape(heads, 1, 1).expand(heads, Fr, 1), u3.dynamic_position_bias(p.sub("rel_pos_bias"), Fr)), dim=-1)
+    sim = sim + bias
+    if causal:
+        sim = sim.masked_fill(torch.ones(Fr, Fr + 1, dtype=torch.bool).triu(2), -torch.finfo(sim.dtype).max)
+    ref_o = torch.einsum("bhij,bjd->bhid", sim.softmax(dim=-1), v).permute(0, 2, 1, 3).reshape(R * P, Fr, C)
+    # cross-check of the restated pieces against the oracle's own function on unrounded projections (same arithmetic, fp32 end to end)
+    full = u3.attention3d(p, seq, None, causal)
+    qf = F.linear(xn, sd["to_q.weight"]).reshape(R * P, Fr, heads, dh).permute(0, 2, 1, 3)
+    kvf = F.linear(xn, sd["to_kv.weight"])
+    kf = torch.cat((sd["null_kv"][0].expand(R * P, 1, dh), kvf[..., :dh]), dim=1)
+    vf = torch.cat((sd["null_kv"][1].expand(R * P, 1, dh), kvf[..., dh:]), dim=1)
+    simf = torch.einsum("bhid,bjd->bhij", F.normalize(qf, dim=-1, eps=1e-12) * sd["q_scale"], F.normalize(kf, dim=-1, eps=1e-12) * sd["k_scale"]) * 8.0 + bias
+    if causal:
+        simf = simf.masked_fill(torch.ones(Fr, Fr + 1, dtype=torch.bool).triu(2), -torch.finfo(simf.dtype).max)
+    of = torch.einsum("bhij,bjd->bhid", simf.softmax(dim=-1), vf).permute(0, 2, 1, 3).reshape(R * P, Fr, C)
+    assert nerr(gain_layernorm(of, sd["to_out.1.g"]), full) < 1e-5, "the pieces above must BE the oracle's attention3d"
+    # ---- the kernel: rows (b, f, p) of q | k | v
+    rows = R * Fr * P
+    qkv = ops.new_act(1, 1, rows, C + 2 * dh, dev)
+    packed = torch.cat((q16, kv16), dim=-1).reshape(R, P, Fr, C + 2 * dh).permute(0, 2, 1, 3).reshape(rows, C + 2 * dh)
+    qkv.t.copy_(packed.reshape(qkv.t.shape))
+    o = ops.new_act(1, 1, rows, C, dev, zero=True)
+    plan = ops.Plan()
+    ops.temporal_attention(plan, qkv, sd["null_kv"].contiguous().to(dev), sd["q_scale"].to(dev), sd["k_scale"].to(dev), bias.contiguous().to(dev), o,
+                           B=R, F=Fr, P=P, heads=heads, causal=causal, scale=8.0)
+    plan.run()
+    torch.cuda.synchronize()
+    got = o.t.float().cpu().reshape(R, Fr, P, C).permute(0, 2, 1, 3).reshape(R * P, Fr, C)
+    assert nerr(got, ref_o) < 2e-3
 
 
 @pytest.mark.parametrize("tag", ["base", "sr"])

@@ -64,6 +64,11 @@ CASES = {
     "pro_single_post_tiny_images": dict(B=9, H=8, W=16, C1=32, Cout=32, K=3, G=4, cfg="pro", prologue="ssq", affine=True, epilogue="post"),
     "pro_raw": dict(B=2, H=40, W=36, C1=32, Cout=32, K=3, G=4, cfg="pro", prologue="none", act_in="none", ssq_out=True),
     "pro_raw_concat": dict(B=1, H=16, W=64, C1=32, C2=32, Cout=32, K=3, G=4, cfg="pro", prologue="none", act_in="none"),
+    # ... 64 output channels (eight waves: two cout blocks per pixel block; the last chunks' weights from LDS; the output-side norm crosses the two waves)
+    "pro64_concat3_post": dict(B=3, H=27, W=45, C1=64, C2=32, Cout=64, K=3, G=4, cfg="pro64", prologue="ssq", affine=False, epilogue="post"),
+    "pro64_concat2_post_odd_range": dict(B=5, H=24, W=16, C1=32, C2=32, Cout=64, K=3, G=4, cfg="pro64", prologue="ssq", affine=True, epilogue="post"),
+    "pro64_single_plain": dict(B=2, H=16, W=48, C1=64, Cout=64, K=3, G=4, cfg="pro64", prologue="ssq", affine=True),
+    "pro64_raw": dict(B=2, H=24, W=32, C1=64, Cout=64, K=3, G=4, cfg="pro64", prologue="none", act_in="none"),
 }
 
 
@@ -74,7 +79,9 @@ def resolve_cfg(ops, spec, kw):
     if spec == "stream":
         return (ops.stream_cfg(), 16, 16)
     if spec == "pro":
-        return (ops.pro_cfg(), 8, 16)
+        return (ops.pro_cfg(32), 8, 16)
+    if spec == "pro64":
+        return (ops.pro_cfg(64), 8, 16)
     if spec.startswith("big:"):
         i = [j for j, c in enumerate(ops.cfg_table()) if c[3] == 5][int(spec.split(":")[1])]
         sh = ops.launchable_shapes(i, kw["H"], kw["W"], 3, 3, 1)

@@ -19,8 +19,8 @@ import torch  # noqa: E402
 
 from imagen_pytorch_amd import ops  # noqa: E402
 
-# (H, C2): the up path's concat conv and the single-input conv of the 256^2 and 128^2 levels
-SHAPES = [(256, 32), (256, 0), (128, 0)]
+# (H, C1, C2, Cout): the up path's concat convs and the single-input convs of the 256^2 and 128^2 levels
+SHAPES = [(256, 32, 32, 32), (256, 32, 0, 32), (128, 64, 32, 64), (128, 64, 0, 64), (128, 32, 0, 32)]
 VARIANTS = {"pro+post": dict(pro=True, post=True), "pro+ssq": dict(pro=True, post=False), "raw+ssq": dict(pro=False, post=False)}
 
 
@@ -33,26 +33,32 @@ def main():
     dev = torch.device("cuda:0")
     B = args.rows
     g = torch.Generator().manual_seed(0)
-    cands = {"stream": (ops.stream_cfg(), 16, 16), "pro": (ops.pro_cfg(), 8, 16), "fam0": None}
     lines = []
-    for H, C2 in SHAPES:
-        Cin = 32 + C2
-        w = torch.randn(32, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
-        pw = ops.pack_weight(w, torch.randn(32, generator=g) * 0.1, dev, G=4)
+    for H, C1, C2, Co in SHAPES:
+        Cin = C1 + C2
+        cands = {"stream": (ops.stream_cfg(), 16, 16) if Co == 32 else "dma", "pro": (ops.pro_cfg(Co), 8, 16), "fam0": None}
+        w = torch.randn(Co, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
+        pw = ops.pack_weight(w, torch.randn(Co, generator=g) * 0.1, dev, G=4)
         sets = []
         for _ in range(4):
-            x1 = ops.act_from_nchw((torch.randn(B, 32, H, H, generator=g) * 0.7).to(dev))
-            x2 = ops.act_from_nchw((torch.randn(B, 32, H, H, generator=g) * 0.7).to(dev)) if C2 else None
+            x1 = ops.act_from_nchw((torch.randn(B, C1, H, H, generator=g) * 0.7).to(dev))
+            x2 = ops.act_from_nchw((torch.randn(B, C2, H, H, generator=g) * 0.7).to(dev)) if C2 else None
             sa = (x1.t.float() ** 2).sum(-1).reshape(-1).contiguous()
             sb = (x2.t.float() ** 2).sum(-1).reshape(-1).contiguous() if C2 else None
-            sets.append((x1, x2, sa, sb, ops.new_act(B, H, H, 32, dev), torch.empty(B * H * H, device=dev)))
+            sets.append((x1, x2, sa, sb, ops.new_act(B, H, H, Co, dev), torch.empty(B * H * H, device=dev)))
         pa = (1 + 0.2 * torch.randn(Cin, generator=g)).to(dev)
-        post = dict(pa=(1 + 0.2 * torch.randn(B, 32, generator=g)).to(dev), ps=(0.2 * torch.randn(B, 32, generator=g)).to(dev), pstride=32)
+        post = dict(pa=(1 + 0.2 * torch.randn(B, Co, generator=g)).to(dev), ps=(0.2 * torch.randn(B, Co, generator=g)).to(dev), pstride=Co)
         for vname, v in VARIANTS.items():
             first = None
+            if Co == 64 and not v["post"] and v["pro"]:
+                continue                      # (64 couts: the family emits no ssq_out; the benchmark's launches are pro + post and raw)
             for cname, cfg in cands.items():
                 if cname == "fam0" and not v["pro"]:
                     continue
+                if cfg == "dma":              # 64 couts: the all-DMA family takes the raw single-input launches only
+                    if v["pro"] or C2:
+                        continue
+                    cfg = ops.pick_cfg(4, Co, H, H, B, 3, 3, 1, full_cout=True, raw=True, family=2)
                 try:
                     plan = ops.Plan("bench")
                     for x1, x2, sa, sb, y, sq in sets:
@@ -61,17 +67,17 @@ def main():
                             kw.update(ssq_a=sa, ssq_b=sb, ssq_wb=0.5, pa=pa, pstride=0, act_in=ops.ACT_SILU)
                         if v["post"]:
                             kw.update(post=post)
-                        else:
+                        elif Co == 32:
                             kw.update(ssq_out=sq)
                         if cfg is None:
-                            kw.update(cfg=ops.pick_cfg(4, 32, H, H, B, 3, 3, 1, full_cout=True, family=0))
+                            kw.update(cfg=ops.pick_cfg(4, Co, H, H, B, 3, 3, 1, full_cout=True, family=0))
                         else:
                             kw.update(cfg=cfg)
                         ops.igemm(plan, x1, pw, y, label=cname, **kw)
                     plan.run()
                     torch.cuda.synchronize()
                 except Exception as e:   # noqa: BLE001
-                    lines.append(dict(H=H, C2=C2, variant=vname, cand=cname, error=str(e)[:200]))
+                    lines.append(dict(H=H, Cin=Cin, Cout=Co, variant=vname, cand=cname, error=str(e)[:200]))
                     print(json.dumps(lines[-1]), flush=True)
                     continue
                 out = sets[0][4].t.float().clone()
@@ -87,8 +93,8 @@ def main():
                 e1.record()
                 torch.cuda.synchronize()
                 us = e0.elapsed_time(e1) * 1e3 / (4 * args.iters)
-                nbytes = B * H * H * (Cin + 32) * 2
-                lines.append(dict(H=H, Cin=Cin, variant=vname, cand=cname, us=round(us, 2), gbs=round(nbytes / us / 1e3, 1), dist_to_first=float(f"{err:.3e}")))
+                nbytes = B * H * H * (Cin + Co) * 2
+                lines.append(dict(H=H, Cin=Cin, Cout=Co, variant=vname, cand=cname, us=round(us, 2), gbs=round(nbytes / us / 1e3, 1), dist_to_first=float(f"{err:.3e}")))
                 print(json.dumps(lines[-1]), flush=True)
     if args.out:
         with open(args.out, "a") as f:
