@@ -3,6 +3,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "imagen_hip.h"
+#include "lds_dma.h"
 
 typedef _Float16 f16;
 typedef f16 f16x2 __attribute__((ext_vector_type(2)));
@@ -64,11 +65,7 @@ __device__ __forceinline__ unsigned imagen_code_warm(unsigned code_bytes, int ti
   }
   return v;
 }
-#ifdef IMAGEN_EMUL
-__device__ __forceinline__ void imagen_code_warm_sink(unsigned v) { (void)v; }
-#else
-__device__ __forceinline__ void imagen_code_warm_sink(unsigned v) { asm volatile("" ::"v"(v)); }
-#endif
+__device__ __forceinline__ void imagen_code_warm_sink(unsigned v) { IMAGEN_SINK(v); }
 
 // 16-byte output pieces from the MFMA accumulator layout.  A lane of a 32x32 fragment holds channel quads 8q + 4*half + {0..3} of
 // its pixel (lanes l and l + 32 share the pixel), i.e. 8-byte pieces at 16-byte stride.  Quads q and q + 2 are exchanged between the

@@ -38,30 +38,12 @@ __device__ __forceinline__ void cb_static_for(F&& f) {
   cb_static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 
-// one 1-KiB direct-to-LDS copy: lane l writes LDS bytes [dst + 16 l, +16) from its own global address
-#ifdef IMAGEN_EMUL   // CPU functional emulation (tools/emul): the copy is queued and lands at the covering vmcnt wait, in issue order
-#define CB_DMA16(gsrc, lds_dst) emul::dma16(gsrc, lds_dst, smem)
-#define CB_DMA4(gsrc, lds_dst) emul::dma4(gsrc, lds_dst, smem)
-#define CB_LDS_BASE(ptr) 0u
-#define CB_BARRIER() __syncthreads()
-#else
-__device__ __forceinline__ void cb_dma16(const void* gsrc, unsigned lds_dst) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory");
-}
-__device__ __forceinline__ void cb_dma4(const void* gsrc, unsigned lds_dst) {   // lane l writes LDS bytes [dst + 4 l, +4)
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory");
-}
-#define CB_DMA16(gsrc, lds_dst) cb_dma16(gsrc, lds_dst)
-#define CB_DMA4(gsrc, lds_dst) cb_dma4(gsrc, lds_dst)
-#define CB_LDS_BASE(ptr) ((unsigned)(size_t)(__attribute__((address_space(3))) char*)(ptr))
-#define CB_BARRIER() asm volatile("s_barrier" ::: "memory")
-#endif
-// s_waitcnt vmcnt(n) only (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14]) + a compiler-level fence
-#define CB_WAIT_VM(n)                                                                         \
-  do {                                                                                        \
-    __builtin_amdgcn_s_waitcnt(((n) & 15) | (7 << 4) | (15 << 8) | ((((n) >> 4) & 3) << 14)); \
-    asm volatile("" ::: "memory");                                                            \
-  } while (0)
+// direct-to-LDS copies (1 KiB / 256 B per wave instruction), LDS base, barrier and counted vmcnt wait: lds_dma.h
+#define CB_DMA16 IMAGEN_DMA16
+#define CB_DMA4 IMAGEN_DMA4
+#define CB_LDS_BASE IMAGEN_LDS_BASE
+#define CB_BARRIER IMAGEN_BARRIER
+#define CB_WAIT_VM IMAGEN_WAIT_VM
 
 constexpr int cb_halo_pieces(int TH, int TW) { return (((TH + 2) * (TW + 2) * 4 + 63) / 64 + 7) / 8; }   // DMA instructions per wave and halo tile
 constexpr int cb_scratch_floats(int WM, int WN) { return 4 * 64 * WN + WM * WN * 64 + 8 + WM * (64 * WN + 4) + WM * WN * 64; }   // ep_par + ep_red
@@ -243,12 +225,7 @@ __global__ __launch_bounds__(512, 1) void conv_big_kernel(const ImagenIgemmParam
     const char* base = reinterpret_cast<const char*>(p.w) + (size_t)lw * per;
     const size_t lim = (size_t)lw * per < wbytes ? min(per, wbytes - (size_t)lw * per) : 0;
     const unsigned sink = __builtin_amdgcn_readfirstlane(lds0 + (unsigned)(cb_lds_bytes(WM, WN, KS, TW, WR, HR) - 256));
-#ifndef IMAGEN_EMUL   // (a cache warm-up: nothing to emulate)
-    for (size_t off = (size_t)tid * 128; off < lim; off += 512 * 128)
-      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(base + off), "s"(sink) : "memory");
-#else
-    (void)base; (void)lim; (void)sink;
-#endif
+    for (size_t off = (size_t)tid * 128; off < lim; off += 512 * 128) IMAGEN_WARM_DMA4(base + off, sink);
   }
   // the per-channel epilogue operands (bias | post_pa | post_ps | gca_wk of this tile's 128 couts: ep_par[v * BN + i]) ride at the head of
   // the copy queue, one 64-float piece per wave: the epilogue then holds no global load (conv_epilogue.h PRELOADED)

@@ -31,20 +31,11 @@ __device__ __forceinline__ void cd_static_for(F&& f) {
   cd_static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 
-// one 1-KiB direct-to-LDS copy: lane l writes LDS bytes [dst + 16 l, +16) from its own global address
-#ifdef IMAGEN_EMUL   // CPU functional emulation (tools/emul): the copy is queued and lands at the covering vmcnt wait, in issue order
-__device__ __forceinline__ void cd_dma16(const void* gsrc, unsigned lds_dst) { emul::dma16(gsrc, lds_dst, smem); }
-#define CD_LDS_BASE(ptr) 0u
-#define CD_VM0_BARRIER() do { emul::wait_vm(0); __syncthreads(); } while (0)
-#define CD_LGKM0_BARRIER() __syncthreads()
-#else
-__device__ __forceinline__ void cd_dma16(const void* gsrc, unsigned lds_dst) {
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory");
-}
-#define CD_LDS_BASE(ptr) ((unsigned)(size_t)(__attribute__((address_space(3))) char*)(ptr))
-#define CD_VM0_BARRIER() asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory")
-#define CD_LGKM0_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
-#endif
+// direct-to-LDS copy (1 KiB per wave instruction), LDS base and the two barriers: lds_dma.h
+#define cd_dma16 IMAGEN_DMA16
+#define CD_LDS_BASE IMAGEN_LDS_BASE
+#define CD_VM0_BARRIER IMAGEN_VM0_BARRIER
+#define CD_LGKM0_BARRIER IMAGEN_LGKM0_BARRIER
 // s_waitcnt vmcnt(n) only (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14]) + a compiler-level fence
 #define CD_WAIT_VM(n)                                                                         \
   do {                                                                                        \
@@ -213,12 +204,7 @@ __global__ __launch_bounds__(256, (MI * NI <= 2 ? 3 : 2)) void conv_dma_kernel(c
     // (a direct-to-LDS load into the epilogue scratch, 4 bytes per lane: an asm load with a VGPR destination would land in a register
     // the compiler has long since reused)
     const unsigned sink = __builtin_amdgcn_readfirstlane(lds0 + 2 * ABUF + 4 * RW * SLOTW);   // 256 bytes, every wave the same (never read)
-#ifndef IMAGEN_EMUL   // (a cache warm-up: nothing to emulate)
-    for (size_t off = (size_t)tid * 128; off < lim; off += 256 * 128)
-      asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %0, off" ::"v"(base + off), "s"(sink) : "memory");
-#else
-    (void)base; (void)lim; (void)sink;
-#endif
+    for (size_t off = (size_t)tid * 128; off < lim; off += 256 * 128) IMAGEN_WARM_DMA4(base + off, sink);
   }
   dma_acts(0, false);
 #pragma unroll

@@ -37,43 +37,16 @@ constexpr int CS_EP_PAR = 5 * 32 + 8 * 32 * 2;   // floats (conv_epilogue.h: 5 *
 
 typedef unsigned cs_u32x4 __attribute__((ext_vector_type(4)));
 
-#ifdef IMAGEN_EMUL   // CPU functional emulation (tools/emul): the copy is queued and lands at the covering vmcnt wait, in issue order
-__device__ __forceinline__ void cs_dma16(const void* gsrc, unsigned lds_dst) { emul::dma16(gsrc, lds_dst, smem); }
-#define CS_LDS_BASE(ptr) 0u
-#else
-__device__ __forceinline__ void cs_dma16(const void* gsrc, unsigned lds_dst) {   // lane l -> LDS bytes [dst + 16 l, +16)
-  asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory");
-}
-#define CS_LDS_BASE(ptr) ((unsigned)(size_t)(__attribute__((address_space(3))) char*)(ptr))
-#endif
+// direct-to-LDS copy (lane l -> LDS bytes [dst + 16 l, +16)) and LDS base: lds_dma.h
+#define cs_dma16 IMAGEN_DMA16
+#define CS_LDS_BASE IMAGEN_LDS_BASE
 
 constexpr size_t cs_lds_bytes(int nch) {
   return (size_t)2 * nch * CS_ABUF + (size_t)nch * CS_WCH + (size_t)(CS_EP_RED + CS_EP_PAR) * sizeof(float) + (size_t)2 * 2 * 64 * sizeof(float) + 16;
 }
 
-__device__ __forceinline__ void cs_wait_vm(int n) {   // s_waitcnt vmcnt(min(n, 12)): fewer outstanding than allowed is always safe
-#ifdef IMAGEN_EMUL   // the allowance n counts this lane's output STORES behind the copies; the emulation queues copies only, so it drains them all
-  (void)n;
-  emul::wait_vm(0);
-  return;
-#else
-  switch (n < 12 ? n : 12) {
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;
-  }
-#endif
-}
+// s_waitcnt vmcnt(min(n, 12)) where n counts the lane's output stores behind its copies (lds_dma.h)
+#define cs_wait_vm IMAGEN_WAIT_VM_STORES
 
 // NCH: 32-channel inputs (1: x1 only; 2: x1 | x2).  PRO: Block prologue on the inputs.  GEN: generic epilogue (conv_epilogue.h).
 //

@@ -97,13 +97,7 @@ __device__ __attribute__((aligned(16))) float kZeros8[8] = {0.f, 0.f, 0.f, 0.f, 
 
 // LDS hand-over between the roles: LDS traffic of this wave retired, then the workgroup barrier.  Deliberately NOT
 // __syncthreads(): global loads stay in flight across it.
-__device__ __forceinline__ void lds_barrier() {
-#ifdef IMAGEN_EMUL   // CPU functional emulation (tools/emul): memory is coherent there, the barrier is the fiber rendezvous
-  __syncthreads();
-#else
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#endif
-}
+__device__ __forceinline__ void lds_barrier() { IMAGEN_LGKM0_BARRIER(); }
 
 
 // GEN: the generic epilogue (output activation, gate*addend / residual, pixel-shuffle and fp32-NCHW stores).  The launcher picks the
@@ -498,9 +492,7 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
     // GEN twin — none this way; profiles/r02_static_spills_igemm_*.txt, measured -1 % per step pair in round 3's call A).  The empty
     // asm makes the thread id opaque inside the tile loop, so nothing derived from it can be hoisted; the names shadow the outer ones.
     int tid_e = threadIdx.x;
-#ifndef IMAGEN_EMUL
-    asm volatile("" : "+v"(tid_e));
-#endif
+    IMAGEN_OPAQUE(tid_e);
     const int half = (tid_e >> 5) & 1, l31 = tid_e & 31;
     const int wave_e = __builtin_amdgcn_readfirstlane(tid_e >> 6);
     const int wm = wave_e / WN, wn = wave_e % WN;

@@ -29,12 +29,16 @@ def main():
     ap.add_argument("--iters", type=int, default=30)
     ap.add_argument("--rows", type=int, default=16)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--shapes", nargs="*", default=None, help="H:C1:C2:Cout, e.g. 256:32:32:32 (default: all of SHAPES)")
+    ap.add_argument("--variants", nargs="*", default=None, help="subset of pro+post pro+ssq raw+ssq")
+    ap.add_argument("--cands", nargs="*", default=None, help="subset of stream pro fam0")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     B = args.rows
     g = torch.Generator().manual_seed(0)
     lines = []
-    for H, C1, C2, Co in SHAPES:
+    shapes = [tuple(map(int, s.split(':'))) for s in args.shapes] if args.shapes else SHAPES
+    for H, C1, C2, Co in shapes:
         Cin = C1 + C2
         cands = {"stream": (ops.stream_cfg(), 16, 16) if Co == 32 else "dma", "pro": (ops.pro_cfg(Co), 8, 16), "fam0": None}
         w = torch.randn(Co, Cin, 3, 3, generator=g) / math.sqrt(9 * Cin)
@@ -50,10 +54,12 @@ def main():
         post = dict(pa=(1 + 0.2 * torch.randn(B, Co, generator=g)).to(dev), ps=(0.2 * torch.randn(B, Co, generator=g)).to(dev), pstride=Co)
         for vname, v in VARIANTS.items():
             first = None
+            if args.variants and vname not in args.variants:
+                continue
             if Co == 64 and not v["post"] and v["pro"]:
                 continue                      # (64 couts: the family emits no ssq_out; the benchmark's launches are pro + post and raw)
             for cname, cfg in cands.items():
-                if cname == "fam0" and not v["pro"]:
+                if (cname == "fam0" and not v["pro"]) or (args.cands and cname not in args.cands):
                     continue
                 if cfg == "dma":              # 64 couts: the all-DMA family takes the raw single-input launches only
                     if v["pro"] or C2:
