@@ -15,6 +15,8 @@
 // The key order of the PV contraction is chosen to match the S^T accumulator layout, so P never moves
 // between lanes.  K / V^T tiles are register-prefetched one tile ahead and double-buffered in LDS.
 #include <cstdlib>
+#include <type_traits>
+#include <utility>
 #include "common.h"
 
 namespace {
@@ -356,6 +358,207 @@ __global__ __launch_bounds__(512, MINW) void attention_kernel_w8(const ImagenAtt
   }
 }
 
+// ---- third tiling: bounded logits, no running maximum (ImagenAttentionParams.softmax_mode = 1).
+// q and k rows are l2-normalised and scaled by fixed parameter vectors, so every logit lies in [-B, B] with B known when the plan is built
+// (ops.attention: q_mult * max_d |q_scale_d k_scale_d|, in log2 units).  With B <= 14.5 the weights exp2(s - B + 15) of ALL keys fit the
+// NORMAL fp16 range at once (2^-14 .. 2^15), so the softmax needs no row maximum, no accumulator rescale and no cross-tile dependency:
+// p = v_exp_f32(s') with the constant shift riding in the MFMA's accumulator input, the row sum and one conversion per element are all that
+// is left on the VALU (the online kernel above: + max, subtract, the rescale test).  Without the serial m_run chain the three stages of a
+// 32-key half tile — S^T(i+1) = K.Q^T (4 MFMA), exp2 of S^T(i) (16 v_exp_f32 per lane), O^T += V^T.P(i-1) (4 MFMA) — are independent of
+// each other, and a wave interleaves them instruction by instruction: two matrix instructions per ~3 exponentials.  K / V^T tiles of 64
+// keys move through a ring of four LDS slots (tiles t-1, t, t+1 are read in tile step t while t+2 arrives), one workgroup barrier per tile.
+constexpr int BND_RING = 4;
+
+template <class F, int... I>
+__device__ __forceinline__ void att_static_for_impl(F&& f, std::integer_sequence<int, I...>) {
+  (f(std::integral_constant<int, I>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void att_static_for(F&& f) {
+  att_static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
+}
+
+template <bool QK, bool PV>
+__device__ __forceinline__ void att_bnd_step(f32x16& Sn, f32x16& Sc, f16x8 (&pc)[2], const f16x8 (&pp)[2], f32x16 (&oacc)[2], float& sum0, float& sum1,
+                                             const f16x8 (&qf)[4], const char* krow, const char* vrow, const f32x16& shv) {
+  // One scheduling region per half step.  The exponentials are pure VALU work the instruction selector is free to place anywhere after
+  // their inputs exist (it put them right behind the previous step's last MFMA): the empty asm makes S^T(i) opaque HERE, so they stay
+  // inside this region, and the sched_group_barrier pipeline below deals them between the matrix instructions.
+  __builtin_amdgcn_sched_barrier(0);
+  IMAGEN_OPAQUE(Sc);
+  f16x8 kf[4], vf[4];
+  if constexpr (QK) {
+#pragma unroll
+    for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const f16x8*>(krow + 32 * s);
+  }
+  if constexpr (PV) {
+#pragma unroll
+    for (int k = 0; k < 4; ++k) vf[k] = *reinterpret_cast<const f16x8*>(vrow + (k & 1) * 32 * VSTR2 + (k >> 1) * 32);
+  }
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float e = __builtin_amdgcn_exp2f(Sc[r]);
+    if (r & 1) sum1 += e; else sum0 += e;
+    pc[r >> 3][r & 7] = (f16)e;
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    if constexpr (QK) Sn = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[k], qf[k], k == 0 ? shv : Sn, 0, 0, 0);
+    if constexpr (PV) oacc[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[k], pp[k >> 1], oacc[k & 1], 0, 0, 0);
+  }
+  // pipeline: fragment reads, 4 exponentials under their latency, then per matrix instruction ~1/NM of the remaining VALU work
+  constexpr int NM = (QK ? 4 : 0) + (PV ? 4 : 0);
+  __builtin_amdgcn_sched_group_barrier(0x100, NM, 0);      // DS reads
+  __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);       // transcendentals
+  __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);       // other VALU (sums, conversions)
+  att_static_for<NM>([&](auto kc) __attribute__((always_inline)) {
+    constexpr int k = decltype(kc)::value;
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
+    __builtin_amdgcn_sched_group_barrier(0x400, NM == 8 ? (k < 6 ? 2 : 0) : 3, 0);
+    __builtin_amdgcn_sched_group_barrier(0x002, NM == 8 ? 3 : 6, 0);
+  });
+  __builtin_amdgcn_sched_barrier(0);
+}
+
+template <int MINW>
+__global__ __launch_bounds__(512, MINW) void attention_kernel_bnd(const ImagenAttentionParams p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];   // BND_RING slots of one 64-key tile (K rows | V^T rows)
+  constexpr int SLOT = KBYTES2 + VBYTES2;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int b = blockIdx.z, hd = blockIdx.y;
+  const int row = blockIdx.x * 256 + wave * 32 + l31;
+  const int row_c = row < p.rows ? row : p.rows - 1;
+
+  const f16* q = reinterpret_cast<const f16*>(p.q) + (size_t)b * p.q_bs + (size_t)hd * p.q_hs + (size_t)row_c * p.q_rs;
+  f16x8 qf[4];
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const f16x8*>(q + 16 * s + 8 * half);
+  if (p.q_scale) {   // fused QNORM (ip.py:559-560)
+    float ssq = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ssq += (float)qf[s][j] * (float)qf[s][j];
+    ssq += __shfl_xor(ssq, 32);
+    const float inv = p.q_mult / fmaxf(sqrtf(ssq), 1e-12f);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const float4 g0 = *reinterpret_cast<const float4*>(p.q_scale + 16 * s + 8 * half);
+      const float4 g1 = *reinterpret_cast<const float4*>(p.q_scale + 16 * s + 8 * half + 4);
+      const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+#pragma unroll
+      for (int j = 0; j < 8; ++j) qf[s][j] = (f16)((float)qf[s][j] * inv * g[j]);
+    }
+  }
+
+  const f16* kg = reinterpret_cast<const f16*>(p.k) + (size_t)b * p.k_bs + (size_t)hd * p.k_hs;
+  const f16* vg = reinterpret_cast<const f16*>(p.vt) + (size_t)b * p.vt_bs + (size_t)hd * p.vt_hs;
+  // staging roles, padding rules and the V^T key order inside a 16-key group: those of attention_kernel_w8
+  const int sk_key = tid >> 3, sk_dg = tid & 7;
+  const int sv_d = tid >> 3, sv_kg = tid & 7;
+  const int Jpad = (p.J + 31) & ~31;
+  const int ntiles = (p.J + KT2 - 1) / KT2;
+  uint4 ks, vs;
+  auto one_load = [&](int t) __attribute__((always_inline)) {
+    const int kt0 = t * KT2;
+    const int kk = kt0 + sk_key < Jpad ? kt0 + sk_key : kt0;
+    const int kv = kt0 + sv_kg * 8 < Jpad ? kt0 + sv_kg * 8 : kt0;
+    ks = *reinterpret_cast<const uint4*>(kg + (size_t)kk * p.k_rs + sk_dg * 8);
+    vs = *reinterpret_cast<const uint4*>(vg + (size_t)sv_d * p.vt_ds + kv);
+  };
+  auto one_store = [&](char* buf) __attribute__((always_inline)) {
+    *reinterpret_cast<uint4*>(buf + sk_key * KSTR + sk_dg * 16) = ks;
+    char* vrow = buf + KBYTES2 + sv_d * VSTR2 + (sv_kg >> 1) * 32 + (sv_kg & 1) * 8;
+    *reinterpret_cast<uint2*>(vrow) = make_uint2(vs.x, vs.y);
+    *reinterpret_cast<uint2*>(vrow + 16) = make_uint2(vs.z, vs.w);
+  };
+  auto slot = [&](int t) __attribute__((always_inline)) { return smem + (t & (BND_RING - 1)) * SLOT; };
+  // this lane's fragment rows inside a slot: K row (32 hh + l31), dims 8 half..; V^T row l31 (+ 32 db), keys 32 hh + 8 half..
+  const int koff = l31 * KSTR + 16 * half, voff = KBYTES2 + l31 * VSTR2 + 16 * half;
+  auto mask_last = [&](f32x16& S, int t, int hh) __attribute__((always_inline)) {   // ragged last tile: keys >= J weigh nothing
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int key = t * KT2 + 32 * hh + 4 * half + (r & 3) + 8 * (r >> 2);
+      if (key >= p.J) S[r] = -1.0e30f;
+    }
+  };
+
+  f32x16 oacc[2], S0, S1;
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
+  f16x8 pA[2], pB[2];
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) pA[s][j] = pB[s][j] = (f16)0.f;
+  float sum0 = 0.f, sum1 = 0.f;
+  const float shift = p.softmax_shift;
+
+  f32x16 shv;   // the constant shift as the first MFMA's accumulator input
+#pragma unroll
+  for (int r = 0; r < 16; ++r) shv[r] = shift;
+
+  one_load(0);
+  one_store(slot(0));
+  if (ntiles > 1) {
+    one_load(1);
+    one_store(slot(1));
+  }
+  __syncthreads();
+  // half steps: A(t) = S^T(t, 1) | exp2 S^T(t, 0) | O^T += V^T P(t - 1, 1);   B(t) = S^T(t + 1, 0) | exp2 S^T(t, 1) | O^T += V^T P(t, 0)
+  {   // S^T(0, 0), then A(0) without a predecessor
+    S0 = shv;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) S0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(slot(0) + koff + 32 * s), qf[s], S0, 0, 0, 0);
+    if (ntiles == 1) mask_last(S0, 0, 0);
+    att_bnd_step<true, false>(S1, S0, pA, pB, oacc, sum0, sum1, qf, slot(0) + koff + 32 * KSTR, slot(0), shv);
+    if (ntiles == 1) mask_last(S1, 0, 1);
+  }
+  // B(t), A(t + 1): slots t and t + 1 are read, tile t + 2 arrives.  The iteration that computes the LAST tile's S^T is a separate copy
+  // with the ragged-tile mask applied unconditionally: a branch around the mask lets the compiler hoist the exponentials into it
+  auto iter = [&](int t, auto last_c) __attribute__((always_inline)) {
+    constexpr bool LAST = decltype(last_c)::value;
+    if constexpr (!LAST) one_load(t + 2);
+    const char* st = slot(t);
+    const char* sn = slot(t + 1);
+    att_bnd_step<true, true>(S0, S1, pB, pA, oacc, sum0, sum1, qf, sn + koff, st + voff, shv);
+    if constexpr (LAST) mask_last(S0, t + 1, 0);
+    att_bnd_step<true, true>(S1, S0, pA, pB, oacc, sum0, sum1, qf, sn + koff + 32 * KSTR, st + voff + 64, shv);
+    if constexpr (LAST) mask_last(S1, t + 1, 1);
+    if constexpr (!LAST) one_store(slot(t + 2));
+    __syncthreads();
+  };
+  for (int t = 0; t + 2 < ntiles; ++t) iter(t, std::false_type{});
+  if (ntiles > 1) iter(ntiles - 2, std::true_type{});
+  {   // B(last) without a successor, then O^T += V^T P(last, 1)
+    const char* st = slot(ntiles - 1);
+    att_bnd_step<false, true>(S0, S1, pB, pA, oacc, sum0, sum1, qf, st, st + voff, shv);
+    const char* vrow = st + voff + 64;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+      oacc[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(vrow + (k & 1) * 32 * VSTR2 + (k >> 1) * 32), pB[k >> 1], oacc[k & 1], 0, 0, 0);
+  }
+
+  float l_run = sum0 + sum1;
+  const float l_tot = l_run + __shfl_xor(l_run, 32);
+  const float inv = 1.0f / l_tot;
+  if (row < p.rows) {
+    f16* o = reinterpret_cast<f16*>(p.o) + (size_t)b * p.o_bs + (size_t)hd * p.o_hs + (size_t)row * p.o_rs;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int qd = 0; qd < 4; ++qd) {
+        f16x4 v;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (f16)(oacc[db][4 * qd + e] * inv);
+        *reinterpret_cast<f16x4*>(o + 32 * db + 8 * qd + 4 * half) = v;
+      }
+  }
+}
+
 }  // namespace
 
 int launch_attention(const ImagenAttentionParams* p, hipStream_t s) {
@@ -363,6 +566,7 @@ int launch_attention(const ImagenAttentionParams* p, hipStream_t s) {
   IMAGEN_CHECK(p->q_rs % 8 == 0 && p->k_rs % 8 == 0 && p->vt_ds % 8 == 0 && p->o_rs % 4 == 0,
                "attention: strides must keep 16B alignment");
   IMAGEN_CHECK(p->head_dim == 0 || p->head_dim == 64 || p->head_dim == 32, "attention: head_dim %d (64 or 32)", p->head_dim);
+  IMAGEN_CHECK(p->softmax_mode == 0 || p->softmax_mode == 1, "attention: softmax_mode %d", p->softmax_mode);
   if (p->head_dim != 32 && p->rows >= 256) {
     dim3 grid((p->rows + 255) / 256, p->heads, p->B);
     auto launch = [&](auto kern, int lds) {
@@ -376,6 +580,11 @@ int launch_attention(const ImagenAttentionParams* p, hipStream_t s) {
       hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, *p);
     };
     constexpr int slot = KBYTES2 + VBYTES2;
+    if (p->softmax_mode == 1) {
+      IMAGEN_CHECK(p->softmax_shift >= 0.5f && p->softmax_shift <= 15.0f, "attention: softmax_shift %g outside [0.5, 15] (logit bound above 14.5: use softmax_mode 0)", (double)p->softmax_shift);
+      launch(attention_kernel_bnd<2>, BND_RING * slot);
+      return imagen_hip_status("attention");
+    }
     if (p->J <= 2 * KT2) launch(attention_kernel_w8<4, 1>, 2 * slot);   // one or two tiles: nothing to gain from staging two at a time
     else launch(attention_kernel_w8<4, 2>, 4 * slot);
     return imagen_hip_status("attention");

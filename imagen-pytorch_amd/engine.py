@@ -612,7 +612,8 @@ class UnetEngine:
         o = self.new(R, 1, N, inner)
         ops.attention(plan, q.t, khat, vt, o.t, B=R, heads=heads, rows=N, J=J, q_strides=(N * inner, dh, inner),
                       k_strides=site["k_strides"], vt_strides=site["vt_strides"], o_strides=(N * inner, dh, inner),
-                      q_scale=W.f32(name + ".q_scale", lambda: ca.q_scale), q_mult=SIM_SCALE * LOG2E, label=name + ".attn", head_dim=dh)
+                      q_scale=W.f32(name + ".q_scale", lambda: ca.q_scale), q_mult=SIM_SCALE * LOG2E, label=name + ".attn", head_dim=dh,
+                      logit_bound=ops.attention_logit_bound(ca.q_scale, ca.k_scale, SIM_SCALE * LOG2E))
         y = self.new(R, 1, N, C)
         ops.igemm(plan, o, W.conv(name + ".to_out", ca.to_out[0], split=SPLIT_1X1 and self._split_small(inner, 1, C, R * N)), y, label=name + ".to_out")
         out = self.new(R, h.H, h.W, C)
@@ -668,7 +669,8 @@ class UnetEngine:
         o = self.new(R, 1, N, inner)
         ops.attention(plan, qkv.t, khat, vt, o.t, B=R, heads=heads, rows=N, J=J, q_strides=(N * ld, dh, ld), k_strides=k_strides,
                       vt_strides=vt_strides, o_strides=(N * inner, dh, inner), q_scale=W.f32(nm + ".q_scale", lambda: attn.q_scale),
-                      q_mult=SIM_SCALE * LOG2E, label=nm + ".attn", head_dim=dh)
+                      q_mult=SIM_SCALE * LOG2E, label=nm + ".attn", head_dim=dh,
+                      logit_bound=ops.attention_logit_bound(attn.q_scale, attn.k_scale, SIM_SCALE * LOG2E))
         y = self.new(R, 1, N, C)
         ops.igemm(plan, o, W.conv(nm + ".to_out", attn.to_out[0], split=SPLIT_1X1 and self._split_small(inner, 1, C, R * N)), y, label=nm + ".to_out")
         x1 = self.new(R, 1, N, C)
@@ -961,7 +963,8 @@ class UnetEngine:
             o = self.new(R, 1, NL, inner)
             ops.attention(plan, q.t, khat, vt, o.t, B=R, heads=heads, rows=NL, J=Jk, q_strides=(NL * inner, dh, inner), k_strides=ks,
                           vt_strides=vs, o_strides=(NL * inner, dh, inner), q_scale=W.f32(nm_ + ".q_scale", lambda pa=pa: pa.q_scale),
-                          q_mult=SIM_SCALE * LOG2E, label=nm_ + ".attn", head_dim=dh)
+                          q_mult=SIM_SCALE * LOG2E, label=nm_ + ".attn", head_dim=dh,
+                          logit_bound=ops.attention_logit_bound(pa.q_scale, pa.k_scale, SIM_SCALE * LOG2E))
             y = self.new(R, 1, NL, cd)
             ops.igemm(plan, o, W.conv(nm_ + ".to_out", pa.to_out[0], split=SPLIT_STATIC), y, label=nm_ + ".to_out")
             lat2 = self.new(R, 1, NL, cd)

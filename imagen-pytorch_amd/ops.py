@@ -624,13 +624,28 @@ def rowstat(plan: Plan, x1: Act, *, mode: int, rs: torch.Tensor, mu: Optional[to
     return p
 
 
+ATTN_BOUNDED = int(_os.environ.get("IMAGEN_ATTN_BOUNDED", "1"))   # 0: always the online softmax (A/B)
+ATTN_BOUND_MAX = 14.5    # log2 units: exp2(s - B + 15) of every key stays inside fp16's normal range (2^-14 .. 2^15) while 2 B <= 29
+
+
+def attention_logit_bound(q_scale: torch.Tensor, k_scale: torch.Tensor, q_mult: float) -> float:
+    """|sum_d q^_d qs_d k^_d ks_d| * q_mult <= q_mult * max_d |qs_d ks_d| for unit vectors q^, k^ (Cauchy-Schwarz); + 1 % and 0.05 for the
+    fp16 rounding of the normalised rows.  The parameters are fixed when a plan is built, so the bound is a plan constant."""
+    m = float((q_scale.detach().float().cpu() * k_scale.detach().float().cpu()).abs().max())
+    return q_mult * m * 1.01 + 0.05
+
+
 def attention(plan: Plan, q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, o: torch.Tensor, *, B, heads, rows, J,
               q_strides, k_strides, vt_strides, o_strides, q_scale: Optional[torch.Tensor] = None, q_mult: float = 0.0, label: str = "",
-              head_dim: int = 64):
-    """q_scale / q_mult: fuse QNORM into the q load (q rows raw); None: q was normalised by a QNORM op.  head_dim: 64 or 32."""
+              head_dim: int = 64, logit_bound: Optional[float] = None):
+    """q_scale / q_mult: fuse QNORM into the q load (q rows raw); None: q was normalised by a QNORM op.  head_dim: 64 or 32.
+    logit_bound: an upper bound of |q . k| in the kernel's log2 units (`attention_logit_bound`); bounds up to ATTN_BOUND_MAX select the
+    bounded-logit softmax (no running maximum; softmax_mode 1 of include/imagen_hip.h), larger ones or None the online softmax."""
     assert head_dim in (32, 64), f"attention head dim {head_dim}: the kernels are built for 64 and 32"
     p = STRUCTS["ImagenAttentionParams"]()
     p.head_dim = head_dim
+    if ATTN_BOUNDED and logit_bound is not None and logit_bound <= ATTN_BOUND_MAX:
+        p.softmax_mode, p.softmax_shift = 1, 15.0 - max(float(logit_bound), 0.0)
     p.q, p.k, p.vt, p.o = q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr()
     p.q_scale, p.q_mult = ptr(q_scale), q_mult
     p.B, p.heads, p.rows, p.J = B, heads, rows, J

@@ -244,17 +244,28 @@ def test_igemm_res_conv_gate_addend(ops, dev):
 
 @pytest.mark.parametrize("D", [64, 32])
 @pytest.mark.parametrize("fused_qnorm", [False, True])
+@pytest.mark.parametrize("bounded", [False, True, "extreme"])
 @pytest.mark.parametrize("B,heads,rows,J,shared", [(2, 1, 8 * 1024, 1065, True), (2, 8, 256, 41, False), (1, 8, 36, 292, False),
                                                    (2, 1, 8 * 64, 103, True), (2, 8, 256, 80, False), (1, 1, 8 * 64, 20, True),
-                                                   (1, 2, 300, 129, False)])
-def test_attention(ops, dev, B, heads, rows, J, shared, fused_qnorm, D):
+                                                   (1, 2, 300, 129, False), (1, 1, 8 * 64, 64, True), (1, 1, 8 * 64, 65, True),
+                                                   (1, 1, 8 * 64, 128, True), (1, 2, 256, 193, False)])
+def test_attention(ops, dev, B, heads, rows, J, shared, fused_qnorm, D, bounded):
     """Cosine-sim attention (ip.py:559-590 / 812-833): QNORM (as its own op, or fused into the q load) + KV_PREP + ATTENTION vs
-    softmax(8 * q^ k^T) v in fp32."""
+    softmax(8 * q^ k^T) v in fp32.  bounded: the plan passes the logit bound of the scale vectors (ops.attention_logit_bound) and the
+    64-dim / >= 256-row launches take the bounded-logit softmax; "extreme": unit scales, every query parallel to its first key and
+    antiparallel to its second — logits at + and - the bound, the two ends of the fp16 range the bounded kernel relies on."""
+    if bounded and (D != 64 or rows < 256):
+        pytest.skip("the bounded-logit softmax is a tiling of the 64-dim / >= 256-row launches")
     torch.manual_seed(6)
     q = h16(torch.randn(B, rows, heads, D))
     k = h16(torch.randn(B, J, heads, D))
     v = h16(torch.randn(B, J, heads, D))
-    qs, ks = 1 + 0.2 * torch.randn(D), 1 + 0.2 * torch.randn(D)
+    sd = 0.04 if bounded else 0.2   # (bounded: scales near the init value 1, the bound stays under ATTN_BOUND_MAX; 0.2: it does not)
+    qs, ks = 1 + sd * torch.randn(D), 1 + sd * torch.randn(D)
+    if bounded == "extreme":
+        qs, ks = torch.ones(D), torch.ones(D)
+        q = h16(k[:, :1].expand(B, rows, heads, D) * (1 + torch.rand(B, rows, 1, 1)))
+        k[:, 1] = -k[:, 0]
     qn = F.normalize(q, dim=-1) * qs
     kn = F.normalize(k, dim=-1) * ks
     sim = torch.einsum("bihd,bjhd->bhij", qn, kn) * 8
@@ -267,14 +278,18 @@ def test_attention(ops, dev, B, heads, rows, J, shared, fused_qnorm, D):
     kd, vd = k.half().to(dev).contiguous(), v.half().to(dev).contiguous()
     plan = ops.Plan()
     qkw = dict(q_scale=qs.to(dev), q_mult=8 * ops.LOG2E) if fused_qnorm else {}
+    if bounded:
+        qkw["logit_bound"] = ops.attention_logit_bound(qs, ks, 8 * ops.LOG2E)
+        assert qkw["logit_bound"] <= ops.ATTN_BOUND_MAX
     if not fused_qnorm:
         ops.qnorm(plan, qd, qs.to(dev), rows=B * rows, heads=heads, ld=heads * D, mult=8 * ops.LOG2E, head_dim=D)
     ops.kv_prep(plan, kd, vd, ks.to(dev), khat, vt, B=B, heads=heads, rows=J, r0=0,
                 src_strides=(J * heads * D, heads * D, D), k_strides=(heads * Jp * D, Jp * D, D),
                 vt_strides=(heads * D * Jp, D * Jp, Jp), head_dim=D)
-    ops.attention(plan, qd, khat, vt, o, B=B, heads=heads, rows=rows, J=J, head_dim=D,
-                  q_strides=(rows * heads * D, D, heads * D), k_strides=(heads * Jp * D, Jp * D, D),
-                  vt_strides=(heads * D * Jp, D * Jp, Jp), o_strides=(rows * heads * D, D, heads * D), **qkw)
+    pa = ops.attention(plan, qd, khat, vt, o, B=B, heads=heads, rows=rows, J=J, head_dim=D,
+                       q_strides=(rows * heads * D, D, heads * D), k_strides=(heads * Jp * D, Jp * D, D),
+                       vt_strides=(heads * D * Jp, D * Jp, Jp), o_strides=(rows * heads * D, D, heads * D), **qkw)
+    assert pa.softmax_mode == int(bool(bounded))
     _run(plan)
     e = nerr(o, ref)
     assert e < 2e-3, f"attention normwise error {e:.2e}"
