@@ -33,7 +33,7 @@ constexpr int CS_NJ = (CS_NDMA + CS_NW - 1) / CS_NW;   // <= 3 DMA pieces per wa
 constexpr int CS_ABUF = CS_NJ * CS_NW * 1024;    // 24 KiB per (tile, input) buffer (pieces 21-23 are never written)
 constexpr int CS_WCH = 18 * 1024;                // packed weights of one 32-channel chunk: 18 K steps x 1 KiB
 constexpr int CS_EP_RED = CS_NW * 32;             // floats
-constexpr int CS_EP_PAR = 5 * 32 + 8 * 32 * 2;   // floats (conv_epilogue.h: 5 * BN + 8 * 32 * MI, MI = 1 here: ample)
+constexpr int CS_EP_PAR = 5 * 32 + 8 * 32 * 2 + 64;   // floats (conv_epilogue.h: 4 * BN + WM * WN * 32 * MI + 8 + WM * (BN + 4) with the GlobalContext partials = 680 here)
 
 typedef unsigned cs_u32x4 __attribute__((ext_vector_type(4)));
 
@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64 * CS_NW, NCH == 1 ? 4 : 2) void conv_stream_kern
   // store instructions of the plain / post epilogue of conv_epilogue.h per wave (a lower bound is what the wait needs): one 16-byte piece
   // per pair of channel quads when Cout is a multiple of 8, else one 8-byte store per quad below Cout
   const int quads = GEN ? 0 : ((p.Cout & 7) == 0 ? 1 + (p.Cout > 8 ? 1 : 0) : min((p.Cout + 7) >> 3, 4));
-  const bool lean_ok = !GEN && p.Cout == 32;   // the lean epilogue writes all four channel quads
+  const bool lean_ok = !GEN && p.Cout == 32 && !p.gca_part;   // the lean epilogue writes all four channel quads (GlobalContext partials: conv_epilogue.h)
 
   while (true) {
     float sa_c[CS_NJ], sb_c[CS_NJ];
@@ -443,7 +443,8 @@ int launch_conv_stream(const ImagenIgemmParams* pp, int idx, hipStream_t s) {
   IMAGEN_CHECK(!p.post_pa || (p.post_ps && p.out_mode == IMAGEN_OUT_NHWC && !p.addend && !p.res && !p.ssq_out && p.act_out == IMAGEN_ACT_NONE && p.Cout % 4 == 0),
                "conv_stream: post_pa needs post_ps and a plain NHWC output");
   IMAGEN_CHECK(!(p.addend && p.res), "conv_stream: addend and residual are mutually exclusive");
-  IMAGEN_CHECK(!p.gca_part, "conv_stream: GlobalContext partials are emitted by the other families only");
+  IMAGEN_CHECK(!p.gca_part || (p.gca_wk && !p.post_pa && p.out_mode == IMAGEN_OUT_NHWC && !p.addend && !p.res && p.act_out == IMAGEN_ACT_NONE),
+               "conv_stream: gca_part needs gca_wk and a plain NHWC output");
   IMAGEN_CHECK(!p.ssq_out || p.out_mode == IMAGEN_OUT_NHWC, "conv_stream: ssq_out needs NHWC output");
   const bool plain = p.act_out == IMAGEN_ACT_NONE && p.out_mode == IMAGEN_OUT_NHWC && !p.addend && !p.res;
   const int key = (p.C2 ? 4 : 0) | (pro ? 2 : 0) | (plain ? 0 : 1);

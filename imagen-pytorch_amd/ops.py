@@ -284,6 +284,7 @@ def launchable_shapes(cfg: int, OH: int, OW: int, KH: int, KW: int, stride: int)
 GCA_EPILOGUE_MAX_TILES = 1024
 CONV_DMA = int(_os.environ.get("IMAGEN_CONV_DMA", "1"))             # A/B switch: the all-DMA kernel family for prologue-free single-input 3x3 convs
 CONV_STREAM = int(_os.environ.get("IMAGEN_CONV_STREAM", "1"))       # A/B switch: the streaming kernel family (conv_stream.hip) for the 32-channel 3x3 convs
+STREAM_GCA = int(_os.environ.get("IMAGEN_STREAM_GCA", "1"))         # A/B switch: the streaming family emits the GlobalContext partials of its output too (0: a GCA_PARTIAL pass / family 2)
 STREAM_MIN_TILES = 512   # ... of launches with at least this many 16x16 tiles (persistent workgroups need a few tiles each)
 
 
@@ -494,7 +495,7 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
         no_pro = mu is None and rs is None and pa is None and ps is None and ssq_a is None and act_in == ACT_NONE
         ssq_pro = mu is None and rs is None and pa is not None and ssq_a is not None and act_in in (ACT_NONE, ACT_SILU)
         tiles16 = x1.B * math.ceil(OH / 16) * math.ceil(OW / 16)
-        gca_here = want_gca and tiles16 <= GCA_EPILOGUE_MAX_TILES     # (the other families emit the GlobalContext partials of such layers)
+        gca_here = want_gca and tiles16 <= GCA_EPILOGUE_MAX_TILES and not STREAM_GCA   # (STREAM_GCA = 0: the other families emit the GlobalContext partials of such layers)
         if (pw.Cout <= 32 and x1.C == 32 and C2 in (0, 32) and pw.Cin_pad == x1.C + C2 and x1.ld % 8 == 0 and (x2 is None or x2.ld % 8 == 0)
                 and (no_pro or ssq_pro) and not gca_here and tiles16 >= STREAM_MIN_TILES
                 and stream_cfg() is not None):
@@ -575,7 +576,9 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
     # all Cout); `p.gca_part_t` ([B, chunks, Cout + 2], chunks = tiles per image = `p.gca_chunks`) then feeds GCA_FINAL directly
     p.gca_part_t, p.gca_chunks = None, 0
     chunks = math.ceil(OH / th) * math.ceil(OW / tw)
-    if want_gca and cfg_table()[cid][3] in (2, 5) and pw.Cout <= cfg_table()[cid][1] and x1.B * chunks <= GCA_EPILOGUE_MAX_TILES:   # (not family 3)
+    fam = cfg_table()[cid][3]
+    if want_gca and pw.Cout <= cfg_table()[cid][1] and ((fam in (2, 5) and x1.B * chunks <= GCA_EPILOGUE_MAX_TILES)
+                                                        or (fam == 3 and STREAM_GCA and chunks <= 1024)):   # (GCA_FINAL / GCA_TAIL merge up to 1024 chunks per image)
         part = torch.empty(x1.B, chunks, pw.Cout + 2, dtype=torch.float32, device=x1.t.device)
         p.gca_wk, p.gca_part, p.gca_bk = gca["wk"].data_ptr(), part.data_ptr(), gca["bk"]
         keep += [gca["wk"], part]
