@@ -360,13 +360,15 @@ __global__ __launch_bounds__(512, MINW) void attention_kernel_w8(const ImagenAtt
 
 // ---- third tiling: bounded logits, no running maximum (ImagenAttentionParams.softmax_mode = 1).
 // q and k rows are l2-normalised and scaled by fixed parameter vectors, so every logit lies in [-B, B] with B known when the plan is built
-// (ops.attention: q_mult * max_d |q_scale_d k_scale_d|, in log2 units).  With B <= 14.5 the weights exp2(s - B + 15) of ALL keys fit the
-// NORMAL fp16 range at once (2^-14 .. 2^15), so the softmax needs no row maximum, no accumulator rescale and no cross-tile dependency:
-// p = v_exp_f32(s') with the constant shift riding in the MFMA's accumulator input, the row sum and one conversion per element are all that
-// is left on the VALU (the online kernel above: + max, subtract, the rescale test).  Without the serial m_run chain the three stages of a
-// 32-key half tile — S^T(i+1) = K.Q^T (4 MFMA), exp2 of S^T(i) (16 v_exp_f32 per lane), O^T += V^T.P(i-1) (4 MFMA) — are independent of
-// each other, and a wave interleaves them instruction by instruction: two matrix instructions per ~3 exponentials.  K / V^T tiles of 64
-// keys move through a ring of four LDS slots (tiles t-1, t, t+1 are read in tile step t while t+2 arrives), one workgroup barrier per tile.
+// (ops.attention: q_mult * max_d |q_scale_d k_scale_d|, in log2 units).  With B <= 14 the weights exp2(s) of ALL keys fit the NORMAL fp16
+// range at once (2^-14 .. 2^14), so the softmax needs no row maximum, no subtraction, no accumulator rescale and no cross-tile dependency:
+// p = v_exp_f32(s) straight from the MFMA result, the row sum and one conversion per element are all that is left on the VALU (the online
+// kernel above: + max, subtract, the rescale test).  Without the serial m_run chain the three stages of a 32-key half tile —
+// S^T(i+1) = K.Q^T (4 MFMA), exp2 of S^T(i) (16 v_exp_f32 per lane), O^T += V^T.P(i-1) (4 MFMA) — are independent of each other, and a
+// wave interleaves them instruction by instruction.  The K / V^T fragments of half step i+1 are read from LDS during half step i (after a
+// workgroup barrier all eight waves would otherwise ask the LDS for their 8 KB at once and wait for it together: 512 cycles of LDS time
+// per round, measured as a third of the kernel in round-4 call E).  Tiles of 64 keys move through a ring of four LDS slots, three tiles
+// ahead of the half step that multiplies them; one workgroup barrier per tile.
 constexpr int BND_RING = 4;
 
 template <class F, int... I>
@@ -378,44 +380,45 @@ __device__ __forceinline__ void att_static_for(F&& f) {
   att_static_for_impl(static_cast<F&&>(f), std::make_integer_sequence<int, N>{});
 }
 
+struct AttFrag { f16x8 k[4], v[4]; };   // one half step's operands: K rows (4 K=16 steps) and V^T rows (2 key steps x 2 dim blocks)
+
+__device__ __forceinline__ void att_frag_load(AttFrag& f, const char* krow, const char* vrow) {
+#pragma unroll
+  for (int s = 0; s < 4; ++s) f.k[s] = *reinterpret_cast<const f16x8*>(krow + 32 * s);
+#pragma unroll
+  for (int k = 0; k < 4; ++k) f.v[k] = *reinterpret_cast<const f16x8*>(vrow + (k & 1) * 32 * VSTR2 + (k >> 1) * 32);
+}
+
+// One half step: Sn = K.Q^T out of fc.k (QK), pc = exp2(Sc) (+ row sums), oacc += V^T.pp out of fc.v (PV); fn <- the next half step's fragments
 template <bool QK, bool PV>
 __device__ __forceinline__ void att_bnd_step(f32x16& Sn, f32x16& Sc, f16x8 (&pc)[2], const f16x8 (&pp)[2], f32x16 (&oacc)[2], float& sum0, float& sum1,
-                                             const f16x8 (&qf)[4], const char* krow, const char* vrow, const f32x16& shv) {
+                                             const f16x8 (&qf)[4], const AttFrag& fc, AttFrag& fn, const char* krow_next, const char* vrow_next) {
   // One scheduling region per half step.  The exponentials are pure VALU work the instruction selector is free to place anywhere after
   // their inputs exist (it put them right behind the previous step's last MFMA): the empty asm makes S^T(i) opaque HERE, so they stay
   // inside this region, and the sched_group_barrier pipeline below deals them between the matrix instructions.
   __builtin_amdgcn_sched_barrier(0);
   IMAGEN_OPAQUE(Sc);
-  f16x8 kf[4], vf[4];
-  if constexpr (QK) {
-#pragma unroll
-    for (int s = 0; s < 4; ++s) kf[s] = *reinterpret_cast<const f16x8*>(krow + 32 * s);
-  }
-  if constexpr (PV) {
-#pragma unroll
-    for (int k = 0; k < 4; ++k) vf[k] = *reinterpret_cast<const f16x8*>(vrow + (k & 1) * 32 * VSTR2 + (k >> 1) * 32);
-  }
+  att_frag_load(fn, krow_next, vrow_next);
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const float e = __builtin_amdgcn_exp2f(Sc[r]);
     if (r & 1) sum1 += e; else sum0 += e;
     pc[r >> 3][r & 7] = (f16)e;
   }
+  f32x16 zero;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) zero[r] = 0.f;
 #pragma unroll
   for (int k = 0; k < 4; ++k) {
-    if constexpr (QK) Sn = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf[k], qf[k], k == 0 ? shv : Sn, 0, 0, 0);
-    if constexpr (PV) oacc[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf[k], pp[k >> 1], oacc[k & 1], 0, 0, 0);
+    if constexpr (QK) Sn = __builtin_amdgcn_mfma_f32_32x32x16_f16(fc.k[k], qf[k], k == 0 ? zero : Sn, 0, 0, 0);
+    if constexpr (PV) oacc[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fc.v[k], pp[k >> 1], oacc[k & 1], 0, 0, 0);
   }
-  // pipeline: fragment reads, 4 exponentials under their latency, then per matrix instruction ~1/NM of the remaining VALU work
   constexpr int NM = (QK ? 4 : 0) + (PV ? 4 : 0);
-  __builtin_amdgcn_sched_group_barrier(0x100, NM, 0);      // DS reads
-  __builtin_amdgcn_sched_group_barrier(0x400, 4, 0);       // transcendentals
-  __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);       // other VALU (sums, conversions)
   att_static_for<NM>([&](auto kc) __attribute__((always_inline)) {
-    constexpr int k = decltype(kc)::value;
-    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);     // MFMA
-    __builtin_amdgcn_sched_group_barrier(0x400, NM == 8 ? (k < 6 ? 2 : 0) : 3, 0);
-    __builtin_amdgcn_sched_group_barrier(0x002, NM == 8 ? 3 : 6, 0);
+    __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 // MFMA
+    __builtin_amdgcn_sched_group_barrier(0x100, 8 / NM, 0);           // the next half step's fragment reads
+    __builtin_amdgcn_sched_group_barrier(0x400, 16 / NM, 0);          // transcendentals
+    __builtin_amdgcn_sched_group_barrier(0x002, NM == 8 ? 3 : 6, 0);  // other VALU (sums, conversions)
   });
   __builtin_amdgcn_sched_barrier(0);
 }
@@ -460,8 +463,8 @@ __global__ __launch_bounds__(512, MINW) void attention_kernel_bnd(const ImagenAt
   const int Jpad = (p.J + 31) & ~31;
   const int ntiles = (p.J + KT2 - 1) / KT2;
   uint4 ks, vs;
-  auto one_load = [&](int t) __attribute__((always_inline)) {
-    const int kt0 = t * KT2;
+  auto one_load = [&](int t) __attribute__((always_inline)) {   // (tiles past the end re-read the last one: stored to a dead slot, never multiplied)
+    const int kt0 = (t < ntiles ? t : ntiles - 1) * KT2;
     const int kk = kt0 + sk_key < Jpad ? kt0 + sk_key : kt0;
     const int kv = kt0 + sv_kg * 8 < Jpad ? kt0 + sv_kg * 8 : kt0;
     ks = *reinterpret_cast<const uint4*>(kg + (size_t)kk * p.k_rs + sk_dg * 8);
@@ -476,6 +479,8 @@ __global__ __launch_bounds__(512, MINW) void attention_kernel_bnd(const ImagenAt
   auto slot = [&](int t) __attribute__((always_inline)) { return smem + (t & (BND_RING - 1)) * SLOT; };
   // this lane's fragment rows inside a slot: K row (32 hh + l31), dims 8 half..; V^T row l31 (+ 32 db), keys 32 hh + 8 half..
   const int koff = l31 * KSTR + 16 * half, voff = KBYTES2 + l31 * VSTR2 + 16 * half;
+  auto krow = [&](int t, int hh) __attribute__((always_inline)) { return slot(t) + koff + hh * 32 * KSTR; };
+  auto vrow = [&](int t, int hh) __attribute__((always_inline)) { return slot(t) + voff + hh * 64; };
   auto mask_last = [&](f32x16& S, int t, int hh) __attribute__((always_inline)) {   // ragged last tile: keys >= J weigh nothing
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -495,51 +500,45 @@ __global__ __launch_bounds__(512, MINW) void attention_kernel_bnd(const ImagenAt
 #pragma unroll
     for (int j = 0; j < 8; ++j) pA[s][j] = pB[s][j] = (f16)0.f;
   float sum0 = 0.f, sum1 = 0.f;
-  const float shift = p.softmax_shift;
+  AttFrag fA, fB;
 
-  f32x16 shv;   // the constant shift as the first MFMA's accumulator input
-#pragma unroll
-  for (int r = 0; r < 16; ++r) shv[r] = shift;
-
-  one_load(0);
-  one_store(slot(0));
-  if (ntiles > 1) {
-    one_load(1);
-    one_store(slot(1));
+  for (int t = 0; t < 3 && t < ntiles; ++t) {
+    one_load(t);
+    one_store(slot(t));
   }
   __syncthreads();
   // half steps: A(t) = S^T(t, 1) | exp2 S^T(t, 0) | O^T += V^T P(t - 1, 1);   B(t) = S^T(t + 1, 0) | exp2 S^T(t, 1) | O^T += V^T P(t, 0)
+  // fragment sets: A steps multiply fA and read fB for the B step behind them, B steps the other way round
   {   // S^T(0, 0), then A(0) without a predecessor
-    S0 = shv;
 #pragma unroll
-    for (int s = 0; s < 4; ++s) S0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(slot(0) + koff + 32 * s), qf[s], S0, 0, 0, 0);
+    for (int r = 0; r < 16; ++r) S0[r] = 0.f;
+    att_frag_load(fA, krow(0, 0), vrow(0, 0));
+#pragma unroll
+    for (int s = 0; s < 4; ++s) S0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(fA.k[s], qf[s], S0, 0, 0, 0);
     if (ntiles == 1) mask_last(S0, 0, 0);
-    att_bnd_step<true, false>(S1, S0, pA, pB, oacc, sum0, sum1, qf, slot(0) + koff + 32 * KSTR, slot(0), shv);
+    att_frag_load(fA, krow(0, 1), vrow(0, 0));
+    att_bnd_step<true, false>(S1, S0, pA, pB, oacc, sum0, sum1, qf, fA, fB, krow(ntiles > 1 ? 1 : 0, 0), vrow(0, 0));
     if (ntiles == 1) mask_last(S1, 0, 1);
   }
-  // B(t), A(t + 1): slots t and t + 1 are read, tile t + 2 arrives.  The iteration that computes the LAST tile's S^T is a separate copy
-  // with the ragged-tile mask applied unconditionally: a branch around the mask lets the compiler hoist the exponentials into it
+  // B(t), A(t + 1): slots t and t + 1 are multiplied, slots t + 1 and t + 2 read for the steps behind, tile t + 3 arrives.  The iteration
+  // that computes the LAST tile's S^T is a separate copy with the ragged-tile mask applied unconditionally: a branch around the mask lets
+  // the compiler hoist the exponentials into it
   auto iter = [&](int t, auto last_c) __attribute__((always_inline)) {
     constexpr bool LAST = decltype(last_c)::value;
-    if constexpr (!LAST) one_load(t + 2);
-    const char* st = slot(t);
-    const char* sn = slot(t + 1);
-    att_bnd_step<true, true>(S0, S1, pB, pA, oacc, sum0, sum1, qf, sn + koff, st + voff, shv);
+    if constexpr (!LAST) one_load(t + 3);
+    att_bnd_step<true, true>(S0, S1, pB, pA, oacc, sum0, sum1, qf, fB, fA, krow(t + 1, 1), vrow(t, 1));
     if constexpr (LAST) mask_last(S0, t + 1, 0);
-    att_bnd_step<true, true>(S1, S0, pA, pB, oacc, sum0, sum1, qf, sn + koff + 32 * KSTR, st + voff + 64, shv);
+    att_bnd_step<true, true>(S1, S0, pA, pB, oacc, sum0, sum1, qf, fA, fB, krow(LAST ? t + 1 : t + 2, 0), vrow(t + 1, 0));
     if constexpr (LAST) mask_last(S1, t + 1, 1);
-    if constexpr (!LAST) one_store(slot(t + 2));
+    if constexpr (!LAST) one_store(slot(t + 3));
     __syncthreads();
   };
   for (int t = 0; t + 2 < ntiles; ++t) iter(t, std::false_type{});
   if (ntiles > 1) iter(ntiles - 2, std::true_type{});
   {   // B(last) without a successor, then O^T += V^T P(last, 1)
-    const char* st = slot(ntiles - 1);
-    att_bnd_step<false, true>(S0, S1, pB, pA, oacc, sum0, sum1, qf, st, st + voff, shv);
-    const char* vrow = st + voff + 64;
+    att_bnd_step<false, true>(S0, S1, pB, pA, oacc, sum0, sum1, qf, fB, fA, krow(ntiles - 1, 1), vrow(ntiles - 1, 1));
 #pragma unroll
-    for (int k = 0; k < 4; ++k)
-      oacc[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(vrow + (k & 1) * 32 * VSTR2 + (k >> 1) * 32), pB[k >> 1], oacc[k & 1], 0, 0, 0);
+    for (int k = 0; k < 4; ++k) oacc[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(fA.v[k], pB[k >> 1], oacc[k & 1], 0, 0, 0);
   }
 
   float l_run = sum0 + sum1;
@@ -581,7 +580,7 @@ int launch_attention(const ImagenAttentionParams* p, hipStream_t s) {
     };
     constexpr int slot = KBYTES2 + VBYTES2;
     if (p->softmax_mode == 1) {
-      IMAGEN_CHECK(p->softmax_shift >= 0.5f && p->softmax_shift <= 15.0f, "attention: softmax_shift %g outside [0.5, 15] (logit bound above 14.5: use softmax_mode 0)", (double)p->softmax_shift);
+      IMAGEN_CHECK(p->logit_bound > 0.0f && p->logit_bound <= 14.0f, "attention: softmax_mode 1 needs a logit bound in (0, 14] log2 units (got %g): use softmax_mode 0", (double)p->logit_bound);
       launch(attention_kernel_bnd<2>, BND_RING * slot);
       return imagen_hip_status("attention");
     }

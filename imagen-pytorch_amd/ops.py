@@ -628,7 +628,7 @@ def rowstat(plan: Plan, x1: Act, *, mode: int, rs: torch.Tensor, mu: Optional[to
 
 
 ATTN_BOUNDED = int(_os.environ.get("IMAGEN_ATTN_BOUNDED", "1"))   # 0: always the online softmax (A/B)
-ATTN_BOUND_MAX = 14.5    # log2 units: exp2(s - B + 15) of every key stays inside fp16's normal range (2^-14 .. 2^15) while 2 B <= 29
+ATTN_BOUND_MAX = 14.0    # log2 units: exp2(s) of every key stays inside fp16's normal range (2^-14 .. 2^14) while |s| <= 14
 
 
 def attention_logit_bound(q_scale: torch.Tensor, k_scale: torch.Tensor, q_mult: float) -> float:
@@ -648,7 +648,7 @@ def attention(plan: Plan, q: torch.Tensor, k: torch.Tensor, vt: torch.Tensor, o:
     p = STRUCTS["ImagenAttentionParams"]()
     p.head_dim = head_dim
     if ATTN_BOUNDED and logit_bound is not None and logit_bound <= ATTN_BOUND_MAX:
-        p.softmax_mode, p.softmax_shift = 1, 15.0 - max(float(logit_bound), 0.0)
+        p.softmax_mode, p.logit_bound = 1, float(logit_bound)
     p.q, p.k, p.vt, p.o = q.data_ptr(), k.data_ptr(), vt.data_ptr(), o.data_ptr()
     p.q_scale, p.q_mult = ptr(q_scale), q_mult
     p.B, p.heads, p.rows, p.J = B, heads, rows, J

@@ -177,11 +177,11 @@ typedef struct ImagenAttentionParams {
   /* optional fused QNORM: q rows arrive raw and are l2-normalised * q_scale[head_dim] * q_mult while they are loaded */
   const float* q_scale; float q_mult;
   int32_t head_dim;
-  /* softmax_mode 0: online softmax (running row maximum).  1: the CALLER guarantees |logit| <= B for every (query, key) pair — q and k
-   * rows are unit vectors times fixed parameter vectors, so B = q_mult * max_d |q_scale_d k_scale_d| is known when the plan is built — and
-   * passes softmax_shift = 15 - B (log2 units, B <= 14.5): the weights exp2(logit + softmax_shift) of all keys then lie in fp16's normal
-   * range together and no maximum is tracked.  Same result up to rounding; honoured by the 64-dim / >= 256-row tiling, ignored elsewhere. */
-  int32_t softmax_mode; float softmax_shift;
+  /* softmax_mode 0: online softmax (running row maximum).  1: the CALLER guarantees |logit| <= logit_bound (log2 units, <= 14) for every
+   * (query, key) pair — q and k rows are unit vectors times fixed parameter vectors, so q_mult * max_d |q_scale_d k_scale_d| is known when
+   * the plan is built: the weights exp2(logit) of all keys then lie in fp16's normal range together and no maximum is tracked.  Same result
+   * up to rounding; honoured by the 64-dim / >= 256-row tiling, ignored elsewhere. */
+  int32_t softmax_mode; float logit_bound;
 } ImagenAttentionParams;
 
 /* KV_PREP — k/v rows -> attention operand buffers (null_kv, context kv, self kv; ip.py:545-561, 805-814).
