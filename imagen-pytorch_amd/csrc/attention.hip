@@ -462,15 +462,17 @@ __global__ __launch_bounds__(512, MINW) void attention_kernel_bnd(const ImagenAt
   const int sv_d = tid >> 3, sv_kg = tid & 7;
   const int Jpad = (p.J + 31) & ~31;
   const int ntiles = (p.J + KT2 - 1) / KT2;
-  uint4 ks, vs;
-  auto one_load = [&](int t) __attribute__((always_inline)) {   // (tiles past the end re-read the last one: stored to a dead slot, never multiplied)
+  // two register sets: a tile is requested TWO tile steps before it is written to its slot (one step is ~700 cycles of work, an L2 round
+  // trip under load 1-2k: with one set every tile step ended waiting for its own request — round-4 call F: 3.7k cycles per tile step)
+  uint4 ks0, vs0, ks1, vs1;
+  auto one_load = [&](int t, uint4& ks, uint4& vs) __attribute__((always_inline)) {   // (tiles past the end re-read the last one: stored to a dead slot, never multiplied)
     const int kt0 = (t < ntiles ? t : ntiles - 1) * KT2;
     const int kk = kt0 + sk_key < Jpad ? kt0 + sk_key : kt0;
     const int kv = kt0 + sv_kg * 8 < Jpad ? kt0 + sv_kg * 8 : kt0;
     ks = *reinterpret_cast<const uint4*>(kg + (size_t)kk * p.k_rs + sk_dg * 8);
     vs = *reinterpret_cast<const uint4*>(vg + (size_t)sv_d * p.vt_ds + kv);
   };
-  auto one_store = [&](char* buf) __attribute__((always_inline)) {
+  auto one_store = [&](char* buf, const uint4& ks, const uint4& vs) __attribute__((always_inline)) {
     *reinterpret_cast<uint4*>(buf + sk_key * KSTR + sk_dg * 16) = ks;
     char* vrow = buf + KBYTES2 + sv_d * VSTR2 + (sv_kg >> 1) * 32 + (sv_kg & 1) * 8;
     *reinterpret_cast<uint2*>(vrow) = make_uint2(vs.x, vs.y);
@@ -503,9 +505,10 @@ __global__ __launch_bounds__(512, MINW) void attention_kernel_bnd(const ImagenAt
   AttFrag fA, fB;
 
   for (int t = 0; t < 3 && t < ntiles; ++t) {
-    one_load(t);
-    one_store(slot(t));
+    one_load(t, ks0, vs0);
+    one_store(slot(t), ks0, vs0);
   }
+  one_load(3, ks1, vs1);   // (in flight: written to its slot at the end of tile step 0)
   __syncthreads();
   // half steps: A(t) = S^T(t, 1) | exp2 S^T(t, 0) | O^T += V^T P(t - 1, 1);   B(t) = S^T(t + 1, 0) | exp2 S^T(t, 1) | O^T += V^T P(t, 0)
   // fragment sets: A steps multiply fA and read fB for the B step behind them, B steps the other way round
@@ -523,18 +526,26 @@ __global__ __launch_bounds__(512, MINW) void attention_kernel_bnd(const ImagenAt
   // B(t), A(t + 1): slots t and t + 1 are multiplied, slots t + 1 and t + 2 read for the steps behind, tile t + 3 arrives.  The iteration
   // that computes the LAST tile's S^T is a separate copy with the ragged-tile mask applied unconditionally: a branch around the mask lets
   // the compiler hoist the exponentials into it
-  auto iter = [&](int t, auto last_c) __attribute__((always_inline)) {
+  auto iter = [&](int t, auto last_c, auto par_c) __attribute__((always_inline)) {
     constexpr bool LAST = decltype(last_c)::value;
-    if constexpr (!LAST) one_load(t + 3);
+    constexpr int PAR = decltype(par_c)::value;     // = t & 1: tile t + 4 is requested into set PAR, tile t + 3 written from set PAR ^ 1
+    if constexpr (!LAST) {
+      if constexpr (PAR == 0) one_load(t + 4, ks0, vs0); else one_load(t + 4, ks1, vs1);
+    }
     att_bnd_step<true, true>(S0, S1, pB, pA, oacc, sum0, sum1, qf, fB, fA, krow(t + 1, 1), vrow(t, 1));
     if constexpr (LAST) mask_last(S0, t + 1, 0);
     att_bnd_step<true, true>(S1, S0, pA, pB, oacc, sum0, sum1, qf, fA, fB, krow(LAST ? t + 1 : t + 2, 0), vrow(t + 1, 0));
     if constexpr (LAST) mask_last(S1, t + 1, 1);
-    if constexpr (!LAST) one_store(slot(t + 3));
+    if constexpr (!LAST) {
+      if constexpr (PAR == 0) one_store(slot(t + 3), ks1, vs1); else one_store(slot(t + 3), ks0, vs0);
+    }
     __syncthreads();
   };
-  for (int t = 0; t + 2 < ntiles; ++t) iter(t, std::false_type{});
-  if (ntiles > 1) iter(ntiles - 2, std::true_type{});
+  for (int t = 0; t + 2 < ntiles; t += 2) {
+    iter(t, std::false_type{}, std::integral_constant<int, 0>{});
+    if (t + 3 < ntiles) iter(t + 1, std::false_type{}, std::integral_constant<int, 1>{});
+  }
+  if (ntiles > 1) iter(ntiles - 2, std::true_type{}, std::integral_constant<int, 0>{});
   {   // B(last) without a successor, then O^T += V^T P(last, 1)
     att_bnd_step<false, true>(S0, S1, pB, pA, oacc, sum0, sum1, qf, fB, fA, krow(ntiles - 1, 1), vrow(ntiles - 1, 1));
 #pragma unroll

@@ -284,7 +284,7 @@ def launchable_shapes(cfg: int, OH: int, OW: int, KH: int, KW: int, stride: int)
 GCA_EPILOGUE_MAX_TILES = 1024
 CONV_DMA = int(_os.environ.get("IMAGEN_CONV_DMA", "1"))             # A/B switch: the all-DMA kernel family for prologue-free single-input 3x3 convs
 CONV_STREAM = int(_os.environ.get("IMAGEN_CONV_STREAM", "1"))       # A/B switch: the streaming kernel family (conv_stream.hip) for the 32-channel 3x3 convs
-STREAM_GCA = int(_os.environ.get("IMAGEN_STREAM_GCA", "1"))         # A/B switch: the streaming family emits the GlobalContext partials of its output too (0: a GCA_PARTIAL pass / family 2)
+STREAM_GCA = int(_os.environ.get("IMAGEN_STREAM_GCA", "0"))         # A/B switch: the streaming family emits the GlobalContext partials of its output too (0: a GCA_PARTIAL pass / family 2)
 STREAM_MIN_TILES = 512   # ... of launches with at least this many 16x16 tiles (persistent workgroups need a few tiles each)
 
 
