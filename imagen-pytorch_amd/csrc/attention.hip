@@ -423,14 +423,19 @@ __device__ __forceinline__ void att_bnd_step(f32x16& Sn, f32x16& Sc, f16x8 (&pc)
   __builtin_amdgcn_sched_barrier(0);
 }
 
-template <int MINW>
-__global__ __launch_bounds__(512, MINW) void attention_kernel_bnd(const ImagenAttentionParams p) {
+// NW waves (32 query rows each) per workgroup.  NW = 4: two workgroups share a CU (2 x 72 KB of LDS, one wave per SIMD each) — their
+// barriers are independent and one's prologue / epilogue (a third of a workgroup's life on the 1024-token site: round-4 call I, loop
+// removed: 18 of 60 us) runs behind the other's tile steps; each thread then stages two 16-byte items of K and of V^T per tile.
+template <int NW>
+__global__ __launch_bounds__(64 * NW, 2) void attention_kernel_bnd(const ImagenAttentionParams p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];   // BND_RING slots of one 64-key tile (K rows | V^T rows)
   constexpr int SLOT = KBYTES2 + VBYTES2;
+  constexpr int NT = 64 * NW, IT = 512 / NT;   // staging items (16 bytes of K + 16 bytes of V^T each) per thread and tile
+  static_assert(IT * NT == 512 && IT <= 2, "512 items per tile, one or two per thread");
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int b = blockIdx.z, hd = blockIdx.y;
-  const int row = blockIdx.x * 256 + wave * 32 + l31;
+  const int row = blockIdx.x * (32 * NW) + wave * 32 + l31;
   const int row_c = row < p.rows ? row : p.rows - 1;
 
   const f16* q = reinterpret_cast<const f16*>(p.q) + (size_t)b * p.q_bs + (size_t)hd * p.q_hs + (size_t)row_c * p.q_rs;
@@ -457,26 +462,36 @@ __global__ __launch_bounds__(512, MINW) void attention_kernel_bnd(const ImagenAt
 
   const f16* kg = reinterpret_cast<const f16*>(p.k) + (size_t)b * p.k_bs + (size_t)hd * p.k_hs;
   const f16* vg = reinterpret_cast<const f16*>(p.vt) + (size_t)b * p.vt_bs + (size_t)hd * p.vt_hs;
-  // staging roles, padding rules and the V^T key order inside a 16-key group: those of attention_kernel_w8
-  const int sk_key = tid >> 3, sk_dg = tid & 7;
-  const int sv_d = tid >> 3, sv_kg = tid & 7;
+  // staging roles (item i = tid + j NT: K key i >> 3, dims 8 (i & 7)..; V^T dim i >> 3, keys 8 (i & 7)..), padding rules and the V^T key
+  // order inside a 16-key group: those of attention_kernel_w8
   const int Jpad = (p.J + 31) & ~31;
   const int ntiles = (p.J + KT2 - 1) / KT2;
   // two register sets: a tile is requested TWO tile steps before it is written to its slot (one step is ~700 cycles of work, an L2 round
-  // trip under load 1-2k: with one set every tile step ended waiting for its own request — round-4 call F: 3.7k cycles per tile step)
-  uint4 ks0, vs0, ks1, vs1;
-  auto one_load = [&](int t, uint4& ks, uint4& vs) __attribute__((always_inline)) {   // (tiles past the end re-read the last one: stored to a dead slot, never multiplied)
-    const int kt0 = (t < ntiles ? t : ntiles - 1) * KT2;
-    const int kk = kt0 + sk_key < Jpad ? kt0 + sk_key : kt0;
-    const int kv = kt0 + sv_kg * 8 < Jpad ? kt0 + sv_kg * 8 : kt0;
-    ks = *reinterpret_cast<const uint4*>(kg + (size_t)kk * p.k_rs + sk_dg * 8);
-    vs = *reinterpret_cast<const uint4*>(vg + (size_t)sv_d * p.vt_ds + kv);
+  // trip under load 1-2k: with one set every tile step ended waiting for its own request)
+  struct Stage { uint4 k0, v0, k1, v1; };   // (named members, not arrays: indexed through the lambdas below an array lands in scratch)
+  Stage st0, st1;
+  auto load_item = [&](int kt0, int i, uint4& kd, uint4& vd) __attribute__((always_inline)) {
+    const int key = i >> 3, g8 = i & 7;
+    const int kk = kt0 + key < Jpad ? kt0 + key : kt0;
+    const int kv = kt0 + g8 * 8 < Jpad ? kt0 + g8 * 8 : kt0;
+    kd = *reinterpret_cast<const uint4*>(kg + (size_t)kk * p.k_rs + g8 * 8);
+    vd = *reinterpret_cast<const uint4*>(vg + (size_t)key * p.vt_ds + kv);
   };
-  auto one_store = [&](char* buf, const uint4& ks, const uint4& vs) __attribute__((always_inline)) {
-    *reinterpret_cast<uint4*>(buf + sk_key * KSTR + sk_dg * 16) = ks;
-    char* vrow = buf + KBYTES2 + sv_d * VSTR2 + (sv_kg >> 1) * 32 + (sv_kg & 1) * 8;
-    *reinterpret_cast<uint2*>(vrow) = make_uint2(vs.x, vs.y);
-    *reinterpret_cast<uint2*>(vrow + 16) = make_uint2(vs.z, vs.w);
+  auto store_item = [&](char* buf, int i, const uint4& kd, const uint4& vd) __attribute__((always_inline)) {
+    const int key = i >> 3, g8 = i & 7;
+    *reinterpret_cast<uint4*>(buf + key * KSTR + g8 * 16) = kd;
+    char* vrow = buf + KBYTES2 + key * VSTR2 + (g8 >> 1) * 32 + (g8 & 1) * 8;
+    *reinterpret_cast<uint2*>(vrow) = make_uint2(vd.x, vd.y);
+    *reinterpret_cast<uint2*>(vrow + 16) = make_uint2(vd.z, vd.w);
+  };
+  auto one_load = [&](int t, Stage& st) __attribute__((always_inline)) {   // (tiles past the end re-read the last one: stored to a dead slot, never multiplied)
+    const int kt0 = (t < ntiles ? t : ntiles - 1) * KT2;
+    load_item(kt0, tid, st.k0, st.v0);
+    if constexpr (IT > 1) load_item(kt0, tid + NT, st.k1, st.v1);
+  };
+  auto one_store = [&](char* buf, const Stage& st) __attribute__((always_inline)) {
+    store_item(buf, tid, st.k0, st.v0);
+    if constexpr (IT > 1) store_item(buf, tid + NT, st.k1, st.v1);
   };
   auto slot = [&](int t) __attribute__((always_inline)) { return smem + (t & (BND_RING - 1)) * SLOT; };
   // this lane's fragment rows inside a slot: K row (32 hh + l31), dims 8 half..; V^T row l31 (+ 32 db), keys 32 hh + 8 half..
@@ -504,11 +519,16 @@ __global__ __launch_bounds__(512, MINW) void attention_kernel_bnd(const ImagenAt
   float sum0 = 0.f, sum1 = 0.f;
   AttFrag fA, fB;
 
-  for (int t = 0; t < 3 && t < ntiles; ++t) {
-    one_load(t, ks0, vs0);
-    one_store(slot(t), ks0, vs0);
+  {   // tiles 0-2 -> their slots (all three requested before the first is written: one round trip, not three), tile 3 left in flight
+    Stage st2;
+    one_load(0, st0);
+    one_load(1, st1);
+    one_load(2, st2);
+    one_store(slot(0), st0);
+    one_store(slot(1), st1);
+    one_store(slot(2), st2);
+    one_load(3, st1);   // (written to its slot at the end of tile step 0)
   }
-  one_load(3, ks1, vs1);   // (in flight: written to its slot at the end of tile step 0)
   __syncthreads();
   // half steps: A(t) = S^T(t, 1) | exp2 S^T(t, 0) | O^T += V^T P(t - 1, 1);   B(t) = S^T(t + 1, 0) | exp2 S^T(t, 1) | O^T += V^T P(t, 0)
   // fragment sets: A steps multiply fA and read fB for the B step behind them, B steps the other way round
@@ -530,14 +550,14 @@ __global__ __launch_bounds__(512, MINW) void attention_kernel_bnd(const ImagenAt
     constexpr bool LAST = decltype(last_c)::value;
     constexpr int PAR = decltype(par_c)::value;     // = t & 1: tile t + 4 is requested into set PAR, tile t + 3 written from set PAR ^ 1
     if constexpr (!LAST) {
-      if constexpr (PAR == 0) one_load(t + 4, ks0, vs0); else one_load(t + 4, ks1, vs1);
+      if constexpr (PAR == 0) one_load(t + 4, st0); else one_load(t + 4, st1);
     }
     att_bnd_step<true, true>(S0, S1, pB, pA, oacc, sum0, sum1, qf, fB, fA, krow(t + 1, 1), vrow(t, 1));
     if constexpr (LAST) mask_last(S0, t + 1, 0);
     att_bnd_step<true, true>(S1, S0, pA, pB, oacc, sum0, sum1, qf, fA, fB, krow(LAST ? t + 1 : t + 2, 0), vrow(t + 1, 0));
     if constexpr (LAST) mask_last(S1, t + 1, 1);
     if constexpr (!LAST) {
-      if constexpr (PAR == 0) one_store(slot(t + 3), ks1, vs1); else one_store(slot(t + 3), ks0, vs0);
+      if constexpr (PAR == 0) one_store(slot(t + 3), st1); else one_store(slot(t + 3), st0);
     }
     __syncthreads();
   };
@@ -579,7 +599,7 @@ int launch_attention(const ImagenAttentionParams* p, hipStream_t s) {
   IMAGEN_CHECK(p->softmax_mode == 0 || p->softmax_mode == 1, "attention: softmax_mode %d", p->softmax_mode);
   if (p->head_dim != 32 && p->rows >= 256) {
     dim3 grid((p->rows + 255) / 256, p->heads, p->B);
-    auto launch = [&](auto kern, int lds) {
+    auto launch = [&](auto kern, int lds, int threads = 512) {
       static bool attr_done[16] = {};   // (per kernel instantiation: one lambda instantiation per `kern` type; per device)
       int dev = 0;
       (void)hipGetDevice(&dev);
@@ -587,12 +607,13 @@ int launch_attention(const ImagenAttentionParams* p, hipStream_t s) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
         if (dev >= 0 && dev < 16) attr_done[dev] = true;
       }
-      hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, *p);
+      hipLaunchKernelGGL(kern, grid, dim3(threads), lds, s, *p);
     };
     constexpr int slot = KBYTES2 + VBYTES2;
     if (p->softmax_mode == 1) {
       IMAGEN_CHECK(p->logit_bound > 0.0f && p->logit_bound <= 14.0f, "attention: softmax_mode 1 needs a logit bound in (0, 14] log2 units (got %g): use softmax_mode 0", (double)p->logit_bound);
-      launch(attention_kernel_bnd<2>, BND_RING * slot);
+      grid = dim3((p->rows + 127) / 128, p->heads, p->B);
+      launch(attention_kernel_bnd<4>, BND_RING * slot, 256);
       return imagen_hip_status("attention");
     }
     if (p->J <= 2 * KT2) launch(attention_kernel_w8<4, 1>, 2 * slot);   // one or two tiles: nothing to gain from staging two at a time
