@@ -589,201 +589,6 @@ __global__ __launch_bounds__(64 * NW, 2) void attention_kernel_bnd(const ImagenA
   }
 }
 
-
-// ---- fourth tiling: the bounded-logit softmax as a PING-PONG of the two waves that share a SIMD (ImagenAttentionParams.softmax_mode = 1,
-// >= 256 query rows).  What call I's ablations and the issue-rate probe (profiles/r04_h_pipe_probe.json, r04_i_attention_ablations.txt) say
-// about the interleaved kernel above: nothing overlaps — MFMA 23 us + VALU 13 + fragment reads 9 + barrier 5 + prologue/epilogue 13-18 add
-// up to its 58-60 us.  A wave issues in order, an MFMA on the accumulator of the one before it is only cheap when it follows it DIRECTLY
-// (anything in between costs a ~43-cycle cliff, MI355X_MICROARCH.md), and a 32-cycle MFMA gap hides at most ~5 issue slots while a half
-// step needs ~60.  So this kernel does not interleave inside a wave at all.  A half step (32 keys) is two segments,
-//     V: p = exp2(S^T) (16 v_exp_f32 per lane), row sums, fp16 conversion, the LDS reads of the M segment's fragments, tile staging
-//     M: eight bare MFMAs — S^T of the next half step (four on one accumulator, back to back) and O^T += V^T.p (two accumulators)
-// separated by workgroup barriers, and waves 4-7 run one segment behind waves 0-3: while one wave of a SIMD owns the matrix pipe with an
-// uninterrupted MFMA stream, its partner owns the VALU and the LDS.  Both segments are ~260-290 cycles, so the pipe is offered work nearly
-// all the time; every wave passes the same 2 N + 2 barriers (N half steps).  Tiles move through the four-slot ring as above.
-template <int DUMMY>
-__global__ __launch_bounds__(512, 2) void attention_kernel_pp(const ImagenAttentionParams p) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // BND_RING slots of one 64-key tile (K rows | V^T rows)
-  constexpr int SLOT = KBYTES2 + VBYTES2;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int half = lane >> 5, l31 = lane & 31;
-  const int b = blockIdx.z, hd = blockIdx.y;
-  const int row = blockIdx.x * 256 + wave * 32 + l31;
-  const int row_c = row < p.rows ? row : p.rows - 1;
-  const bool late = wave >= 4;   // (wave-uniform) this wave runs one segment behind waves 0-3
-
-  const f16* q = reinterpret_cast<const f16*>(p.q) + (size_t)b * p.q_bs + (size_t)hd * p.q_hs + (size_t)row_c * p.q_rs;
-  f16x8 qf[4];
-#pragma unroll
-  for (int s = 0; s < 4; ++s) qf[s] = *reinterpret_cast<const f16x8*>(q + 16 * s + 8 * half);
-  if (p.q_scale) {   // fused QNORM (ip.py:559-560)
-    float ssq = 0.f;
-#pragma unroll
-    for (int s = 0; s < 4; ++s)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) ssq += (float)qf[s][j] * (float)qf[s][j];
-    ssq += __shfl_xor(ssq, 32);
-    const float inv = p.q_mult / fmaxf(sqrtf(ssq), 1e-12f);
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const float4 g0 = *reinterpret_cast<const float4*>(p.q_scale + 16 * s + 8 * half);
-      const float4 g1 = *reinterpret_cast<const float4*>(p.q_scale + 16 * s + 8 * half + 4);
-      const float g[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
-#pragma unroll
-      for (int j = 0; j < 8; ++j) qf[s][j] = (f16)((float)qf[s][j] * inv * g[j]);
-    }
-  }
-
-  const f16* kg = reinterpret_cast<const f16*>(p.k) + (size_t)b * p.k_bs + (size_t)hd * p.k_hs;
-  const f16* vg = reinterpret_cast<const f16*>(p.vt) + (size_t)b * p.vt_bs + (size_t)hd * p.vt_hs;
-  const int Jpad = (p.J + 31) & ~31;
-  const int ntiles = (p.J + KT2 - 1) / KT2;
-  const int N = 2 * ntiles;   // half steps
-  // staging (one 16-byte item of K and of V^T per thread and tile; roles, padding and V^T key order of attention_kernel_w8); two register
-  // sets: tile t + 4 is requested in half step 2 t, tile t + 3 written to its slot in half step 2 t + 1
-  const int sk_key = tid >> 3, sk_g8 = tid & 7;
-  uint4 ka, va, kb2, vb2;
-  auto one_load = [&](int t, uint4& kd, uint4& vd) __attribute__((always_inline)) {
-    const int kt0 = (t < ntiles ? t : ntiles - 1) * KT2;
-    const int kk = kt0 + sk_key < Jpad ? kt0 + sk_key : kt0;
-    const int kv = kt0 + sk_g8 * 8 < Jpad ? kt0 + sk_g8 * 8 : kt0;
-    kd = *reinterpret_cast<const uint4*>(kg + (size_t)kk * p.k_rs + sk_g8 * 8);
-    vd = *reinterpret_cast<const uint4*>(vg + (size_t)sk_key * p.vt_ds + kv);
-  };
-  auto one_store = [&](char* buf, const uint4& kd, const uint4& vd) __attribute__((always_inline)) {
-    *reinterpret_cast<uint4*>(buf + sk_key * KSTR + sk_g8 * 16) = kd;
-    char* vrow = buf + KBYTES2 + sk_key * VSTR2 + (sk_g8 >> 1) * 32 + (sk_g8 & 1) * 8;
-    *reinterpret_cast<uint2*>(vrow) = make_uint2(vd.x, vd.y);
-    *reinterpret_cast<uint2*>(vrow + 16) = make_uint2(vd.z, vd.w);
-  };
-  auto slot = [&](int t) __attribute__((always_inline)) { return smem + (t & (BND_RING - 1)) * SLOT; };
-  const int koff = l31 * KSTR + 16 * half, voff = KBYTES2 + l31 * VSTR2 + 16 * half;
-  auto krow = [&](int i) __attribute__((always_inline)) { return slot(i >> 1) + koff + (i & 1) * 32 * KSTR; };   // half step i = (tile i >> 1, half i & 1)
-  auto vrow = [&](int i) __attribute__((always_inline)) { return slot(i >> 1) + voff + (i & 1) * 64; };
-
-  f32x16 oacc[2], S;
-#pragma unroll
-  for (int db = 0; db < 2; ++db)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
-  float sum0 = 0.f, sum1 = 0.f, sum2 = 0.f, sum3 = 0.f;
-  f16x8 P[2];
-  AttFrag F;
-
-  {   // tiles 0-2 -> their slots (one round trip), tile 3 left in flight
-    uint4 kc, vc;
-    one_load(0, ka, va);
-    one_load(1, kb2, vb2);
-    one_load(2, kc, vc);
-    one_store(slot(0), ka, va);
-    one_store(slot(1), kb2, vb2);
-    one_store(slot(2), kc, vc);
-    one_load(3, kb2, vb2);
-  }
-  __syncthreads();
-  {   // S^T of half step 0 (every wave; the ping-pong starts behind it)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) S[r] = 0.f;
-#pragma unroll
-    for (int s = 0; s < 4; ++s) S = __builtin_amdgcn_mfma_f32_32x32x16_f16(*reinterpret_cast<const f16x8*>(krow(0) + 32 * s), qf[s], S, 0, 0, 0);
-  }
-  if (late) IMAGEN_LGKM0_BARRIER();   // waves 4-7: one segment behind
-
-  // (the half of a tile and the staging register set are compile-time: selected at run time the two sets are merged through v_cndmask
-  // right behind the load, i.e. every request is waited for on the spot)
-  auto hstep = [&](int i, auto odd_c, auto set_c) __attribute__((always_inline)) {
-    constexpr bool ODD = decltype(odd_c)::value;      // i & 1
-    constexpr int SET = decltype(set_c)::value;       // (i >> 1) & 1
-    // ---------------------------------------------------------------- V segment of half step i
-    if (i >= N - 2) {   // (wave-uniform) ragged last tile: keys >= J weigh nothing
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = i * 32 + 4 * half + (r & 3) + 8 * (r >> 2);
-        if (key >= p.J) S[r] = -1.0e30f;
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    IMAGEN_OPAQUE(S);
-    att_frag_load(F, krow(i + 1 < N ? i + 1 : i), vrow(i));   // the M segment's operands (past the end: a valid address, never multiplied)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float e = __builtin_amdgcn_exp2f(S[r]);
-      if ((r & 3) == 0) sum0 += e; else if ((r & 3) == 1) sum1 += e; else if ((r & 3) == 2) sum2 += e; else sum3 += e;
-      P[r >> 3][r & 7] = (f16)e;
-    }
-    if constexpr (!ODD) {   // tile t = i / 2: request tile t + 4
-      if constexpr (SET == 0) one_load((i >> 1) + 4, ka, va); else one_load((i >> 1) + 4, kb2, vb2);
-    } else {                // write tile t + 3 (requested one tile step ago) over tile t - 1, which every wave has left by now
-      if constexpr (SET == 0) one_store(slot((i >> 1) + 3), kb2, vb2); else one_store(slot((i >> 1) + 3), ka, va);
-    }
-    // (the exponentials, MFMAs and conversions are pure operations the instruction selector places wherever their operands allow — it
-    // moved the exponentials behind the barrier, between the MFMAs; the empty asm statements pin each segment's results to its side)
-    IMAGEN_OPAQUE(P[0]);
-    IMAGEN_OPAQUE(P[1]);
-    IMAGEN_OPAQUE(sum0);
-    IMAGEN_OPAQUE(sum1);
-    IMAGEN_OPAQUE(sum2);
-    IMAGEN_OPAQUE(sum3);
-    __builtin_amdgcn_sched_barrier(0);
-    IMAGEN_LGKM0_BARRIER();
-    // ---------------------------------------------------------------- M segment of half step i: eight bare MFMAs
-#pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      IMAGEN_OPAQUE(F.k[s]);
-      IMAGEN_OPAQUE(F.v[s]);
-    }
-    if (i + 1 < N) {
-      f32x16 zero;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) zero[r] = 0.f;
-#pragma unroll
-      for (int s = 0; s < 4; ++s) S = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.k[s], qf[s], s == 0 ? zero : S, 0, 0, 0);
-    }
-#pragma unroll
-    for (int k = 0; k < 4; ++k) oacc[k & 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(F.v[k], P[k >> 1], oacc[k & 1], 0, 0, 0);
-    IMAGEN_OPAQUE(S);
-    IMAGEN_OPAQUE(oacc[0]);
-    IMAGEN_OPAQUE(oacc[1]);
-    __builtin_amdgcn_sched_barrier(0);
-    IMAGEN_LGKM0_BARRIER();
-  };
-  {
-    using T = std::true_type;
-    using Fl = std::false_type;
-    using Z = std::integral_constant<int, 0>;
-    using O = std::integral_constant<int, 1>;
-    int i = 0;
-    for (; i + 4 <= N; i += 4) {
-      hstep(i, Fl{}, Z{});
-      hstep(i + 1, T{}, Z{});
-      hstep(i + 2, Fl{}, O{});
-      hstep(i + 3, T{}, O{});
-    }
-    if (i < N) {   // (N is even)
-      hstep(i, Fl{}, Z{});
-      hstep(i + 1, T{}, Z{});
-    }
-  }
-  if (!late) IMAGEN_LGKM0_BARRIER();   // waves 0-3: the barrier waves 4-7 passed before their first segment
-
-  float l_run = (sum0 + sum1) + (sum2 + sum3);
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
-  const float inv = 1.0f / l_tot;
-  if (row < p.rows) {
-    f16* o = reinterpret_cast<f16*>(p.o) + (size_t)b * p.o_bs + (size_t)hd * p.o_hs + (size_t)row * p.o_rs;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int qd = 0; qd < 4; ++qd) {
-        f16x4 v;
-#pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = (f16)(oacc[db][4 * qd + e] * inv);
-        *reinterpret_cast<f16x4*>(o + 32 * db + 8 * qd + 4 * half) = v;
-      }
-  }
-}
-
 }  // namespace
 
 int launch_attention(const ImagenAttentionParams* p, hipStream_t s) {
@@ -807,12 +612,8 @@ int launch_attention(const ImagenAttentionParams* p, hipStream_t s) {
     constexpr int slot = KBYTES2 + VBYTES2;
     if (p->softmax_mode == 1) {
       IMAGEN_CHECK(p->logit_bound > 0.0f && p->logit_bound <= 14.0f, "attention: softmax_mode 1 needs a logit bound in (0, 14] log2 units (got %g): use softmax_mode 0", (double)p->logit_bound);
-      if (p->J > 2 * KT2) {   // several tiles: the ping-pong of the two waves of a SIMD
-        launch(attention_kernel_pp<0>, BND_RING * slot);
-      } else {               // one or two tiles (the cross-attention sites): the interleaved kernel, two 4-wave workgroups per CU
-        grid = dim3((p->rows + 127) / 128, p->heads, p->B);
-        launch(attention_kernel_bnd<4>, BND_RING * slot, 256);
-      }
+      grid = dim3((p->rows + 127) / 128, p->heads, p->B);
+      launch(attention_kernel_bnd<4>, BND_RING * slot, 256);
       return imagen_hip_status("attention");
     }
     if (p->J <= 2 * KT2) launch(attention_kernel_w8<4, 1>, 2 * slot);   // one or two tiles: nothing to gain from staging two at a time
