@@ -18,7 +18,7 @@ reported under "sequential").  Every batch runs the full cascade at batch 8; not
 
 Extra legs (rank 0, N = 1 only):
   roofline     — HIP-event timing, on the launch stream, of every implicit-GEMM launch of one denoiser step of each stage, grouped
-                 by tile configuration and by bound (algorithmic FLOP/byte vs the 312 FLOP/B ridge).  "roofline" is the dominant
+                 by kernel symbol (tile configuration, taps, epilogue / prologue instantiation) and by bound (algorithmic FLOP/byte vs the 312 FLOP/B ridge).  "roofline" is the dominant
                  group overall, "roofline_other_bound" the dominant group under the other roof: achieved = algorithmic FLOPs
                  (2*MACs) or bytes (inputs + output + weights + epilogue operand) / time, vs 2.5 PFLOP/s dense fp16 MFMA or 8 TB/s
                  HBM (/opt/skills/guides/MI355X_MICROARCH.md).  `traffic` (HBM bytes per launch) and `mfma_busy_frac` come from
@@ -171,15 +171,17 @@ def calibration_leg(device):
 
 
 def roofline_leg(imagen, batch: int, device, pmc=None):
-    """Event-time every igemm launch of one denoiser step of both stages (eager, same stream), grouped by tile configuration.
-    Two roofs are reported: the tile configuration with the largest total time among the MFMA-bound launches (algorithmic
-    FLOP/byte above the ridge) and the one among the HBM-bound launches."""
+    """Event-time every igemm launch of one denoiser step of both stages (eager, same stream), grouped by kernel symbol — the template
+    instantiation a launch takes, i.e. the rows of `rocprofv3 --stats` (round 3 grouped by tile configuration, which merges the plain- and
+    generic-epilogue instantiations of one configuration into a group no rocprof row corresponds to).  Two roofs are reported: the symbol
+    with the largest total time among the MFMA-bound launches (algorithmic FLOP/byte above the ridge) and the one among the HBM-bound."""
     import ctypes
     from imagen_pytorch_amd import _abi, ops
 
     lib = _abi.load_library()
     K_IGEMM = _abi.ENUMS["IMAGEN_OP_IGEMM"]
     groups = {}
+    tab_fam = [c[3] for c in ops.cfg_table()]
     stream = torch.cuda.current_stream()
     h = stream.cuda_stream
     seen = set()
@@ -200,7 +202,12 @@ def roofline_leg(imagen, batch: int, device, pmc=None):
                 lib.imagen_event_record(e0, h)
                 _abi.check(lib.imagen_launch(kind, ctypes.addressof(struct), ctypes.sizeof(struct), h))
                 lib.imagen_event_record(e1, h)
-                evs.append((struct.cfg, igemm_flops(struct), igemm_bytes(struct), (stage_no, label), e0, e1))
+                # the kernel SYMBOL a launch takes (what `rocprofv3 --stats` lists, profiles/rNN_kernel_stats.csv): tile configuration +
+                # taps (the unrolled k-loop instantiation) + generic / plain epilogue + (family 6) the prologue instantiation
+                fam = tab_fam[struct.cfg]
+                gen = fam in (0, 2, 3, 5) and bool(struct.act_out or struct.out_mode or struct.addend or struct.res)
+                sym = (struct.cfg, struct.KH * struct.KW, gen, fam in (3, 6) and bool(struct.ssq_a))
+                evs.append((sym, igemm_flops(struct), igemm_bytes(struct), (stage_no, label), e0, e1))
             else:
                 _abi.check(lib.imagen_launch(kind, ctypes.addressof(struct), ctypes.sizeof(struct), h))
         torch.cuda.synchronize()
@@ -223,7 +230,8 @@ def roofline_leg(imagen, batch: int, device, pmc=None):
         cands = {k: v for k, v in groups.items() if k[0] == bound}
         if not cands:
             return None
-        (_, cfg), g = max(cands.items(), key=lambda kv: kv[1]["sec"])
+        (_, sym), g = max(cands.items(), key=lambda kv: kv[1]["sec"])
+        cfg, taps, gen, pro = sym
         traffic = mfma_util = None
         if pmc:
             rows = [pmc[i] for i in g["ids"] if i in pmc]
@@ -240,22 +248,24 @@ def roofline_leg(imagen, batch: int, device, pmc=None):
         return {"bound": bound, "achieved": round(ach, 1), "peak": peak, "unit": unit, "frac": round(ach / peak, 4), "traffic": traffic,
                 "traffic_source": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes run by this bench.py invocation" if traffic is not None else None,
                 "mfma_busy_frac": mfma_util,
-                "kernel": f"{fam_name.get(tab[cfg][3], 'igemm family ' + str(tab[cfg][3]))} cfg {cfg} ({tab[cfg][0]} px x {tab[cfg][1]} cout tile, G={tab[cfg][2]})",
+                "kernel": f"{fam_name.get(tab[cfg][3], 'igemm family ' + str(tab[cfg][3]))} cfg {cfg} ({tab[cfg][0]} px x {tab[cfg][1]} cout tile, G={tab[cfg][2]}), "
+                          f"{taps}-tap instantiation, {'generic' if gen else 'plain'} epilogue{', with the Block prologue' if pro else ''}",
                 "launches_per_denoiser_step_pair": g["n"], "avg_launch_us": round(g["sec"] / g["n"] * 1e6, 2),
                 "avg_launch_gflop": round(g["fl"] / g["n"] / 1e9, 3), "avg_launch_algorithmic_bytes": round(g["by"] / g["n"]),
                 "timing": "HIP events around each eager launch of one denoiser step per stage (cold caches, as inside the sampling loop)"}
 
     mf, hb = describe("mfma"), describe("hbm")
     tsum = lambda b: sum(v["sec"] for k, v in groups.items() if k[0] == b)
-    # "roofline" = the single (bound, tile configuration) group with the largest total time; the other bound's dominant group beside it
+    # "roofline" = the single (bound, kernel symbol) group with the largest total time; the other bound's dominant group beside it
     top_bound = max(groups.items(), key=lambda kv: kv[1]["sec"])[0][0]
     main, other = (mf, hb) if top_bound == "mfma" else (hb, mf)
     main = dict(main)
     main["share_of_igemm_time"] = {"mfma_bound_launches": round(tsum("mfma") / (tsum("mfma") + tsum("hbm")), 3),
                                    "hbm_bound_launches": round(tsum("hbm") / (tsum("mfma") + tsum("hbm")), 3)}
-    main["per_cfg"] = {f"{b}:{c}": {"launches": v["n"], "tflops": round(v["fl"] / max(v["sec"], 1e-12) / 1e12, 1),
-                                    "gbytes_per_s": round(v["by"] / max(v["sec"], 1e-12) / 1e9, 1), "ms_total": round(v["sec"] * 1e3, 3)}
-                       for (b, c), v in sorted(groups.items())}
+    main["per_kernel"] = {f"{b}:cfg{c[0]}:k{c[1]}{':gen' if c[2] else ''}{':pro' if c[3] else ''}":
+                          {"launches": v["n"], "tflops": round(v["fl"] / max(v["sec"], 1e-12) / 1e12, 1),
+                           "gbytes_per_s": round(v["by"] / max(v["sec"], 1e-12) / 1e9, 1), "ms_total": round(v["sec"] * 1e3, 3)}
+                          for (b, c), v in sorted(groups.items())}
     return main, other
 
 
