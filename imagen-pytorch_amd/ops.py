@@ -296,6 +296,9 @@ CONV_PW = int(_os.environ.get("IMAGEN_CONV_PW", "1"))               # A/B switch
 PW_MIN_TILES = 512     # ... of at least this many tiles, i.e. two per CU (the big maps; below, the launch is latency-bound either way)
 
 
+CONV_GEMM = int(_os.environ.get("IMAGEN_CONV_GEMM", "1"))             # A/B switch: the tiled pointwise GEMM (conv_gemm.hip) for the deep 1x1 layers
+GEMM_MIN_K = 128         # ... with at least this many input channels (below: family 4 / the wave-specialised kernel)
+GEMM_MIN_TILES = 128     # ... and at least this many 128-row x 128-cout workgroup tiles
 CONV_BIG = int(_os.environ.get("IMAGEN_CONV_BIG", "1"))               # A/B switch: the big-tile all-DMA family (conv_big.hip) for the C >= 128 3x3 convs
 BIG_MIN_WGS = 192      # ... of launches that give it at least this many workgroups (one per CU: below, the smaller tiles of family 2 fill the chip better)
 BIG_PICKS = (3, 2)   # family-5 configuration of the 256- / 128-pixel tile (call R: the 3-stage weight ring and the third halo buffer are 2-3 % ahead)
@@ -324,6 +327,11 @@ def pw_cfg(kchunks: int, Cout: int) -> Optional[int]:
         if fam == 4 and kch == kchunks and bn >= Cout and (best is None or bn < cfg_table()[best][1]):
             best = i
     return best
+
+
+def gemm_cfg() -> Optional[int]:
+    """Tile cfg id of the tiled pointwise GEMM (family 7), None if the library has none."""
+    return next((i for i, c in enumerate(cfg_table()) if c[3] == 7), None)
 
 
 def pro_cfg(Cout: int = 32) -> Optional[int]:
@@ -512,6 +520,17 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
             if pc is not None and x1.B * math.ceil(OH * OW / cfg_table()[pc][0]) >= PW_MIN_TILES:
                 tp = cfg_table()[pc][0]
                 cfg = (pc, tp // min(OW, tp), min(OW, tp))
+    if cfg is None and CONV_GEMM and KH == 1 and KW == 1 and stride == 1 and pad == 0 and gemm_cfg() is not None:
+        # family 7, the tiled pointwise GEMM: the token / small-map 1x1 layers too deep for family 4's register-resident weights — raw rows
+        # or the LayerNorm prologue (mu / rs statistics, per-channel affine), every epilogue; 128-row x 128-cout workgroup tiles
+        ln_pro = ssq_a is None and ssq_b is None and act_in == ACT_NONE and (mu is None or rs is not None)
+        tiles = x1.B * math.ceil(OH * OW / 128) * math.ceil(pw.Cout / 128)
+        full = ssq_out is not None or post is not None or want_gca
+        if (ln_pro and x1.C % 32 == 0 and C2 % 32 == 0 and pw.Cin_pad == x1.C + C2 and x1.C + C2 >= GEMM_MIN_K and tiles >= GEMM_MIN_TILES
+                and x1.ld % 8 == 0 and x1.bs % 8 == 0 and (x2 is None or (x2.ld % 8 == 0 and x2.bs % 8 == 0)) and (not full or pw.Cout <= 128)
+                and (out_mode == OUT_NCHW_F32 or pw.Cout % 4 == 0)):
+            tw = 128 if OW >= 128 else 1 << (OW.bit_length() - 1)   # (the largest power of two inside the row, 128 pixels per tile)
+            cfg = (gemm_cfg(), 128 // tw, tw)
     if cfg is None:
         raw = (x2 is None and mu is None and rs is None and pa is None and ps is None and ssq_a is None and act_in == ACT_NONE
                and x1.C % 32 == 0 and pw.Cin_pad == x1.C and x1.ld % 8 == 0)
@@ -577,7 +596,7 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
     p.gca_part_t, p.gca_chunks = None, 0
     chunks = math.ceil(OH / th) * math.ceil(OW / tw)
     fam = cfg_table()[cid][3]
-    if want_gca and pw.Cout <= cfg_table()[cid][1] and ((fam in (2, 5) and x1.B * chunks <= GCA_EPILOGUE_MAX_TILES)
+    if want_gca and pw.Cout <= cfg_table()[cid][1] and ((fam in (2, 5, 7) and x1.B * chunks <= GCA_EPILOGUE_MAX_TILES)
                                                         or (fam == 3 and STREAM_GCA and chunks <= 1024)):   # (GCA_FINAL / GCA_TAIL merge up to 1024 chunks per image)
         part = torch.empty(x1.B, chunks, pw.Cout + 2, dtype=torch.float32, device=x1.t.device)
         p.gca_wk, p.gca_part, p.gca_bk = gca["wk"].data_ptr(), part.data_ptr(), gca["bk"]

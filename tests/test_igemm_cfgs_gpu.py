@@ -238,6 +238,40 @@ def test_conv_pw_family(ops, dev):
     assert tab[r["cfg"][0]][3] == 4 and tab[r["cfg"][0]][0] == 128 and r["err"] < TOL and r["err_ssq"] < 2e-3, r
 
 
+def test_conv_gemm_family(ops, dev):
+    """The tiled pointwise GEMM (csrc/conv_gemm.hip): 1x1 layers in 32-channel chunks — raw rows, the LayerNorm prologue (mu + rs statistics,
+    per-(batch, channel) or shared affine) and a bare per-row scale; one or two inputs; every epilogue (plain + ssq_out, GELU, gate * addend,
+    residual, pixel shuffle, fp32 NCHW, post_pa, GlobalContext partials); several cout slabs, couts below the slab, ragged rows (partial
+    tiles in both tile directions), an odd and an even number of chunks; and the planner's own pick for the benchmark's token GEMMs."""
+    tab = ops.cfg_table()
+    gid = ops.gemm_cfg()
+    if gid is None:
+        pytest.skip("the library holds no tiled pointwise GEMM family")
+    raw = dict(prologue="none", act_in="none")
+    ln = dict(prologue="ln", act_in="none")
+    cases = [
+        dict(raw, B=2, H=1, W=300, C1=256, Cout=256, cfg=(gid, 1, 128), ssq_out=False),                         # tokens, two slabs, ragged rows
+        dict(ln, B=2, H=1, W=256, C1=128, Cout=640, cfg=(gid, 1, 128), affine=True),                           # qkv: LN prologue, five slabs
+        dict(ln, B=2, H=1, W=130, C1=256, Cout=512, cfg=(gid, 1, 128), affine=False, act_out="gelu"),          # FeedForward lin1: shared gain, GELU
+        dict(raw, B=2, H=1, W=256, C1=512, Cout=256, cfg=(gid, 1, 128), epilogue="res"),                       # to_out / lin2 + residual
+        dict(raw, B=2, H=20, W=32, C1=256, C2=128, Cout=256, cfg=(gid, 4, 32), epilogue="addend"),             # res_conv of the 32^2 level
+        dict(raw, B=2, H=9, W=20, C1=96, C2=32, Cout=120, cfg=(gid, 8, 16), ssq_out=True),                      # ragged both ways, couts below the slab, ssq_out
+        dict(raw, B=2, H=16, W=64, C1=128, Cout=256, cfg=(gid, 2, 64), epilogue="shuffle"),                    # pixel-shuffle upsample GEMM
+        dict(raw, B=2, H=12, W=32, C1=160, Cout=3, cfg=(gid, 4, 32), epilogue="nchw"),                         # fp32 NCHW, odd chunk count
+        dict(dict(prologue="rs", act_in="none"), B=2, H=1, W=200, C1=128, Cout=128, cfg=(gid, 1, 128), epilogue="post"),   # per-row scale only; post_pa
+        dict(raw, B=2, H=16, W=16, C1=128, Cout=128, cfg=(gid, 8, 16), gca=True, ssq_out=True),                 # GlobalContext partials
+    ]
+    for kw in cases:
+        r = run_case(ops, dev, K=1, **kw)
+        assert r["err"] < TOL and r.get("err_ssq", 0.0) < 2e-3 and r.get("err_gca", 0.0) < 2e-3, (kw, r)
+    if not EMULATED:
+        # the planner picks the family for the benchmark's token GEMMs and the 32^2 res_conv by itself
+        r = run_case(ops, dev, B=16, H=1, W=1024, C1=256, Cout=640, K=1, **ln)
+        assert tab[r["cfg"][0]][3] == 7 and r["err"] < TOL, r
+        r = run_case(ops, dev, B=16, H=32, W=32, C1=256, C2=128, Cout=256, K=1, epilogue="addend", **raw)
+        assert tab[r["cfg"][0]][3] == 7 and r["err"] < TOL, r
+
+
 def test_act_prep(ops, dev):
     """ACT_PREP: the Block prologue as its own pass (ssq statistics over a two-tensor concat, per-channel gain, SiLU; and the
     LayerNorm form with a per-(batch, channel) affine) vs fp32 torch."""
