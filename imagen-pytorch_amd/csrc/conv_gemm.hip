@@ -7,7 +7,7 @@
 // 30 MB) takes 30 us.  DESIGN 9.1 measured why: that kernel's skeleton (persistent roles, a barrier hand-over per 64-pixel phase, a generic
 // epilogue with dependent round trips) costs more than the work.  conv_pw.hip fixed the same problem for K <= 192 by keeping the whole
 // weight matrix in registers; these layers do not fit.  This kernel is the plain tiled GEMM instead:
-//   * one workgroup of 4 waves per (128 rows x 128 output channels) tile, two workgroups per CU (32 KB of LDS, ~200 VGPRs each), no persistence —
+//   * one workgroup of 4 waves per (128 rows x 128 output channels) tile, three workgroups per CU (32 KB of LDS, 160 VGPRs each), no persistence —
 //     128-640 workgroups per launch, the slabs of a row tile next to each other on one XCD (the rows are re-read from that XCD's L2);
 //   * wave = 64 rows x 64 couts (2 x 2 fragments of v_mfma_f32_32x32x16_f16: 1 KB of ds_read_b128 per MFMA);
 //   * K loop over 32-channel chunks, both operands register-staged TWO chunks ahead (two register sets, chunk c + 2 requested while chunk c
@@ -43,7 +43,7 @@ constexpr size_t cg_lds_bytes(int K, bool aff) {
 
 // PRO: the LayerNorm prologue on the rows.  GEN: generic epilogue (conv_epilogue.h).
 template <bool PRO, bool GEN>
-__global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ImagenIgemmParams p) {
+__global__ __launch_bounds__(256, 3) void conv_gemm_kernel(const ImagenIgemmParams p) {
   constexpr int MI = 2, NI = 2, WM = 2, WN = 2;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* const aff = reinterpret_cast<float*>(smem + 2 * CG_SLOT);   // [pa K | ps K] of this tile's batch row (PRO)
@@ -119,7 +119,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ImagenIgemmPara
     R.w1 = *reinterpret_cast<const uint4*>(w_src[1] + (size_t)cc * w_chunk);
   };
   auto transform = [&](uint4 raw, int j, int c) __attribute__((always_inline)) -> uint4 {
-    if (!a_ok[j]) return make_uint4(0, 0, 0, 0);
+    if (!a_ok[j] || c >= NC) return make_uint4(0, 0, 0, 0);   // (outside the image / past the last chunk: zero rows)
     if constexpr (!PRO) {
       return raw;
     } else {
@@ -181,6 +181,7 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ImagenIgemmPara
   // other slot, barrier
   auto step = [&](int i, Regs& Rload, const Regs& Rwrite) __attribute__((always_inline)) {
     request(Rload, i + 2);
+    __builtin_amdgcn_sched_barrier(0);   // (the requests stay HERE: the scheduler otherwise sinks them behind the LDS writes below — one step of latency cover instead of two)
     const char* sb = smem + (i & 1) * CG_SLOT;
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
@@ -194,13 +195,20 @@ __global__ __launch_bounds__(256, 2) void conv_gemm_kernel(const ImagenIgemmPara
 #pragma unroll
         for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ni], bf[mi], acc[ni][mi], 0, 0, 0);
     }
+    __builtin_amdgcn_sched_barrier(0);
     stage(Rwrite, i + 1, (i + 1) & 1);
-    __syncthreads();
+    IMAGEN_LGKM0_BARRIER();   // (LDS traffic retired + workgroup barrier; the requests stay in flight)
   };
-  for (int i = 0; i < NC; i += 2) {
+  // (two steps per trip with the sets swapped by NAME: a conditional second step lets the compiler roll the pair into one body that rotates
+  // the sets through v_mov / v_cndmask — of registers with loads in flight, i.e. vmcnt(0) at the top of every step)
+  // An odd chunk count runs one step more on zero rows (stage() writes zeros past the end): a separate tail step and a loop that may
+  // run zero times each cost a copy of the 64 accumulator registers at the merge in front of the generic epilogue — 130 dwords of scratch.
+  int i = 0;
+  do {
     step(i, R0, R1);
-    if (i + 1 < NC) step(i + 1, R1, R0);
-  }
+    step(i + 1, R1, R0);
+    i += 2;
+  } while (i < NC);
 
   // ---- epilogue (its scratch aliases the ring: every wave is behind the last step's barrier, the stray write of that step included)
   float* ep_par = reinterpret_cast<float*>(smem);

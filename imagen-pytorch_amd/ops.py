@@ -525,10 +525,9 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
         # or the LayerNorm prologue (mu / rs statistics, per-channel affine), every epilogue; 128-row x 128-cout workgroup tiles
         ln_pro = ssq_a is None and ssq_b is None and act_in == ACT_NONE and (mu is None or rs is not None)
         tiles = x1.B * math.ceil(OH * OW / 128) * math.ceil(pw.Cout / 128)
-        full = ssq_out is not None or post is not None or want_gca
         if (ln_pro and x1.C % 32 == 0 and C2 % 32 == 0 and pw.Cin_pad == x1.C + C2 and x1.C + C2 >= GEMM_MIN_K and tiles >= GEMM_MIN_TILES
-                and x1.ld % 8 == 0 and x1.bs % 8 == 0 and (x2 is None or (x2.ld % 8 == 0 and x2.bs % 8 == 0)) and (not full or pw.Cout <= 128)
-                and (out_mode == OUT_NCHW_F32 or pw.Cout % 4 == 0)):
+                and x1.ld % 8 == 0 and x1.bs % 8 == 0 and (x2 is None or (x2.ld % 8 == 0 and x2.bs % 8 == 0))
+                and (out_mode == OUT_NCHW_F32 or pw.Cout % 4 == 0)):   # (ssq_out / post / gca wider than the 128-cout tile: not emitted, as in family 0)
             tw = 128 if OW >= 128 else 1 << (OW.bit_length() - 1)   # (the largest power of two inside the row, 128 pixels per tile)
             cfg = (gemm_cfg(), 128 // tw, tw)
     if cfg is None:

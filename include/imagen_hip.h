@@ -32,7 +32,7 @@ extern "C" {
 #endif
 
 #define IMAGEN_ABI_VERSION 7 /* 3: head_dim in the attention / QNORM / KV_PREP params; 4: DDPM_UPDATE x0_thr; 5: GCA_TAIL; 6: ACT_PREP self_stat, STEP_SLICE;
-                               * 7: every launch carries sizeof(its params struct) (a stale mirror of a struct fails loudly), ImagenIgemmParams.dbg -> launcher_word, kernel family 6 */
+                               * 7: every launch carries sizeof(its params struct) (a stale mirror of a struct fails loudly), ImagenIgemmParams.dbg -> launcher_word, kernel families 6 and 7, ImagenAttentionParams.softmax_mode */
 
 typedef void* imagen_stream_t; /* hipStream_t */
 
@@ -439,7 +439,9 @@ int imagen_igemm_stage_slots(int cfg, int KH, int KW);
  * 4 = streaming pointwise kernel (1x1, raw inputs, weights in registers; `kgroups` of its config info = 32-channel input chunks),
  * 5 = big-tile all-DMA kernel (as 2, 128-cout tiles of 256 / 128 pixels, 64 x 64 per wave, one workgroup per CU),
  * 6 = streaming kernel with the Block prologue on register-staged rows (3x3 stride 1 to exactly 32 channels from one or two 32-channel
- *     inputs, raw or with the ssq-statistics prologue, plain / post_pa / ssq_out epilogue; weights in registers, 8 x 16 tiles). */
+ *     inputs, raw or with the ssq-statistics prologue, plain / post_pa / ssq_out epilogue; weights in registers, 8 x 16 tiles),
+ * 7 = tiled pointwise GEMM (1x1 stride 1, inputs in 32-channel chunks, raw or with the (x - mu) * rs * pa + ps prologue, every epilogue;
+ *     128-pixel x 128-cout workgroup tiles, K loop with both operands register-staged two chunks ahead). */
 int imagen_igemm_config_family(int cfg);
 int imagen_igemm_config_ring(int cfg);   /* weight look-ahead ring depth in stages (family 2; 0 for the others) */
 /* dynamic LDS bytes of a launch of `cfg` with a KHxKW kernel at `stride` and a THxTW output tile; -1 = not launchable */
