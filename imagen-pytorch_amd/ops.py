@@ -299,6 +299,7 @@ PW_MIN_TILES = 512     # ... of at least this many tiles, i.e. two per CU (the b
 CONV_GEMM = int(_os.environ.get("IMAGEN_CONV_GEMM", "1"))             # A/B switch: the tiled pointwise GEMM (conv_gemm.hip) for the deep 1x1 layers
 GEMM_MIN_K = 128         # ... with at least this many input channels (below: family 4 / the wave-specialised kernel)
 GEMM_MIN_TILES = 128     # ... and at least this many 128-row x 128-cout workgroup tiles
+GEMM_MIN_COUT = 256      # ... that fill at least two output-channel slabs
 CONV_BIG = int(_os.environ.get("IMAGEN_CONV_BIG", "1"))               # A/B switch: the big-tile all-DMA family (conv_big.hip) for the C >= 128 3x3 convs
 BIG_MIN_WGS = 192      # ... of launches that give it at least this many workgroups (one per CU: below, the smaller tiles of family 2 fill the chip better)
 BIG_PICKS = (3, 2)   # family-5 configuration of the 256- / 128-pixel tile (call R: the 3-stage weight ring and the third halo buffer are 2-3 % ahead)
@@ -525,7 +526,12 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
         # or the LayerNorm prologue (mu / rs statistics, per-channel affine), every epilogue; 128-row x 128-cout workgroup tiles
         ln_pro = ssq_a is None and ssq_b is None and act_in == ACT_NONE and (mu is None or rs is not None)
         tiles = x1.B * math.ceil(OH * OW / 128) * math.ceil(pw.Cout / 128)
-        if (ln_pro and x1.C % 32 == 0 and C2 % 32 == 0 and pw.Cin_pad == x1.C + C2 and x1.C + C2 >= GEMM_MIN_K and tiles >= GEMM_MIN_TILES
+        # (measured, call O: it wins where the epilogue is the plain store and the slabs are full — qkv 29.6 -> 18.6 us, to_q 23.6 -> 16.0 —
+        # and loses with the generic epilogue, whose operand round trips a one-tile workgroup cannot hide: res_conv 17.0 -> 22.4;
+        # IMAGEN_CONV_GEMM=2 routes those too)
+        plain_ep = act_out == ACT_NONE and out_mode == OUT_NHWC and addend is None and res is None
+        if ((CONV_GEMM >= 2 or (plain_ep and pw.Cout >= GEMM_MIN_COUT))
+                and ln_pro and x1.C % 32 == 0 and C2 % 32 == 0 and pw.Cin_pad == x1.C + C2 and x1.C + C2 >= GEMM_MIN_K and tiles >= GEMM_MIN_TILES
                 and x1.ld % 8 == 0 and x1.bs % 8 == 0 and (x2 is None or (x2.ld % 8 == 0 and x2.bs % 8 == 0))
                 and (out_mode == OUT_NCHW_F32 or pw.Cout % 4 == 0)):   # (ssq_out / post / gca wider than the 128-cout tile: not emitted, as in family 0)
             tw = 128 if OW >= 128 else 1 << (OW.bit_length() - 1)   # (the largest power of two inside the row, 128 pixels per tile)
