@@ -50,7 +50,7 @@ def _shapes(ops, cfg, K, stride, H, W):
 def test_conv3x3_block_every_cfg_and_tile_shape(ops, dev, cfg):
     """Block conv (prologue rs * pa + ps -> SiLU, concat input, bias), plain NHWC output with ssq_out where one tile covers Cout."""
     tp, bn, G, fam = ops.cfg_table()[cfg]
-    if G not in (1, 4) or fam in (2, 3, 5, 6):
+    if G not in (1, 4) or fam in (2, 3, 5, 6, 7):
         pytest.skip("3x3 convs with a prologue use 8- or 32-channel chunks of families 0 / 1")
     C1, C2 = (64, 32) if G == 4 else (16, 8)
     H, W = (40, 36) if tp >= 128 else (20, 24)
@@ -71,7 +71,7 @@ def test_conv3x3_raw_post_and_ssq_prologue_every_cfg(ops, dev, cfg):
     """The two fused forms of a ResnetBlock: conv1 with ssq statistics (ssq_a + wb * ssq_b over the concat) and the output-side
     Block prologue (post_pa); conv2 staging an already activated input with no arithmetic (prologue none)."""
     tp, bn, G, fam = ops.cfg_table()[cfg]
-    if G != 4 or fam in (2, 3, 5, 6):
+    if G != 4 or fam in (2, 3, 5, 6, 7):
         pytest.skip("32-channel chunks of families 0 / 1 only")
     H, W = (32, 48) if tp >= 128 else (16, 24)
     shapes = _shapes(ops, cfg, 3, 1, H, W)
@@ -341,6 +341,8 @@ def test_1x1_every_cfg_and_epilogue(ops, dev, cfg):
     tp, bn, G, fam = ops.cfg_table()[cfg]
     if fam == 4:
         pytest.skip("the streaming pointwise family has its own test (test_conv_pw_family)")
+    if fam == 7:
+        pytest.skip("the tiled pointwise GEMM has its own test (test_conv_gemm_family)")
     Cin = {1: 24, 4: 96, 8: 192, 16: 256}[G]
     H, W = (24, 40) if tp >= 128 else (12, 20)
     shapes = _shapes(ops, cfg, 1, 1, H, W)
