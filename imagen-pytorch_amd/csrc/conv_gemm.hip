@@ -7,13 +7,12 @@
 // 30 MB) takes 30 us.  DESIGN 9.1 measured why: that kernel's skeleton (persistent roles, a barrier hand-over per 64-pixel phase, a generic
 // epilogue with dependent round trips) costs more than the work.  conv_pw.hip fixed the same problem for K <= 192 by keeping the whole
 // weight matrix in registers; these layers do not fit.  This kernel is the plain tiled GEMM instead:
-//   * one workgroup of 4 waves per (128 rows x 128 output channels) tile, three workgroups per CU (16 KB of LDS, <= 168 VGPRs each), no persistence —
+//   * one workgroup of 4 waves per (128 rows x 128 output channels) tile, three workgroups per CU (32 KB of LDS, 160 VGPRs each), no persistence —
 //     128-640 workgroups per launch, the slabs of a row tile next to each other on one XCD (the rows are re-read from that XCD's L2);
 //   * wave = 64 rows x 64 couts (2 x 2 fragments of v_mfma_f32_32x32x16_f16: 1 KB of ds_read_b128 per MFMA);
-//   * K loop over 32-channel chunks, both operands requested TWO chunks ahead (two register sets each): the rows are register-staged into a
-//     two-slot LDS ring in conv_pw.hip's swizzled order (conflict-free B-fragment reads, one barrier per chunk), the weights go straight
-//     from L2 into each wave's A-fragment registers (the packed layout is the fragment order) — half the LDS traffic of a version that
-//     staged both (that one was bound by it: ~770 cycles of LDS time per chunk step and CU against 256 of MFMA time);
+//   * K loop over 32-channel chunks, both operands register-staged TWO chunks ahead (two register sets, chunk c + 2 requested while chunk c
+//     is multiplied and chunk c + 1 written) into a two-slot LDS ring, one barrier per chunk; rows land in conv_pw.hip's swizzled order,
+//     weights as contiguous [8-channel group][128 couts][8] images — both fragment reads conflict-free;
 //   * the LayerNorm prologue (x - mu[row]) * rs[row] * pa[c] + ps[c] (each factor optional) is applied in registers between the global
 //     load and the LDS write: once per element, 16 elements per thread and chunk;
 //   * every epilogue of the contract through conv_epilogue.h (bias, GELU / SiLU, gate * addend, residual, pixel shuffle, fp32 NCHW,
@@ -30,7 +29,8 @@ namespace {
 
 constexpr int CG_TP = 128, CG_BN = 128;          // rows (pixels) and output channels per workgroup tile
 constexpr int CG_ABYTES = CG_TP * 64;            // one 32-channel chunk of the tile's rows
-constexpr int CG_SLOT = CG_ABYTES;               // 8 KB (the weights do not pass through LDS)
+constexpr int CG_WBYTES = 4 * CG_BN * 16;        // one 32-channel chunk of the slab's weights: [4 groups][128 couts][8 halves]
+constexpr int CG_SLOT = CG_ABYTES + CG_WBYTES;   // 16 KB
 constexpr int CG_EP_PAR = 4 * CG_BN + 2 * 2 * 64 + 8 + 2 * (CG_BN + 4);   // floats (conv_epilogue.h, MI = NI = WM = WN = 2)
 constexpr int CG_EP_RED = 2 * 2 * 64;                                      // floats
 
@@ -100,26 +100,23 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_kernel(const ImagenIgemmPara
       if (p.rs) a_rs[j] = p.rs[row];
     }
   }
-  // weights: the packed buffer IS the A-fragment order ([8-channel group][Cout_pad][8 halves]) — each wave requests the fragments of its own
-  // 64 couts straight into registers, two chunks ahead like the rows (conv_pw.hip keeps the whole matrix there; here one chunk at a time)
-  const f16x8* const wl = reinterpret_cast<const f16x8*>(p.w) + (size_t)half * p.Cout_pad + tc.n0 + wn * 64 + l31;
-  struct WFrag { f16x8 k0n0, k0n1, k1n0, k1n1; };   // (K step, cout block) of one chunk
-  auto request_w = [&](WFrag& W, int c) __attribute__((always_inline)) {
-    const int cc = c < NC ? c : NC - 1;
-    const f16x8* wc = wl + (size_t)(4 * cc) * p.Cout_pad;
-    W.k0n0 = wc[0];
-    W.k0n1 = wc[32];
-    W.k1n0 = wc[(size_t)2 * p.Cout_pad];
-    W.k1n1 = wc[(size_t)2 * p.Cout_pad + 32];
-  };
+  const char* w_src[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int S = tid + 256 * j;
+    w_src[j] = reinterpret_cast<const char*>(p.w) + ((size_t)(S >> 7) * p.Cout_pad + tc.n0 + (S & 127)) * 16;
+  }
+  const size_t w_chunk = (size_t)4 * p.Cout_pad * 16;   // bytes between the same group of consecutive chunks
 
-  struct Regs { uint4 a0, a1; };
+  struct Regs { uint4 a0, a1, w0, w1; };
   auto request = [&](Regs& R, int c) __attribute__((always_inline)) {   // (chunks past the end re-read the last one: written to a slot nobody multiplies)
     const int cc = c < NC ? c : NC - 1;
     const bool from1 = cc < n1;                                          // (workgroup-uniform)
     const int coff = (from1 ? cc : cc - n1) * 32;
     R.a0 = *reinterpret_cast<const uint4*>((from1 ? a_row1[0] : a_row2[0]) + coff);
     R.a1 = *reinterpret_cast<const uint4*>((from1 ? a_row1[1] : a_row2[1]) + coff);
+    R.w0 = *reinterpret_cast<const uint4*>(w_src[0] + (size_t)cc * w_chunk);
+    R.w1 = *reinterpret_cast<const uint4*>(w_src[1] + (size_t)cc * w_chunk);
   };
   auto transform = [&](uint4 raw, int j, int c) __attribute__((always_inline)) -> uint4 {
     if (!a_ok[j] || c >= NC) return make_uint4(0, 0, 0, 0);   // (outside the image / past the last chunk: zero rows)
@@ -143,6 +140,8 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_kernel(const ImagenIgemmPara
     char* sb = smem + slot * CG_SLOT;
     *reinterpret_cast<uint4*>(sb + tid * 16) = transform(R.a0, 0, c);
     *reinterpret_cast<uint4*>(sb + (tid + 256) * 16) = transform(R.a1, 1, c);
+    *reinterpret_cast<uint4*>(sb + CG_ABYTES + tid * 16) = R.w0;
+    *reinterpret_cast<uint4*>(sb + CG_ABYTES + (tid + 256) * 16) = R.w1;
   };
 
   // ---- MFMA side: lane = row (B operand) / cout (A operand)
@@ -155,6 +154,7 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_kernel(const ImagenIgemmPara
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) b_off[mi][ks] = tp * 64 + (((2 * ks + half) ^ cg_swz(tp)) << 4);
   }
+  const int a_off = CG_ABYTES + (half * CG_BN + wn * 64 + l31) * 16;   // + ks * 2 * CG_BN * 16 + ni * 512
 
   f32x16 acc[NI][MI];
 #pragma unroll
@@ -165,11 +165,8 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_kernel(const ImagenIgemmPara
       for (int r = 0; r < 16; ++r) acc[ni][mi][r] = 0.0f;
 
   Regs R0, R1;
-  WFrag W0, W1;
   request(R0, 0);
-  request_w(W0, 0);
   request(R1, 1);
-  request_w(W1, 1);
   if constexpr (PRO) {   // the per-channel affine of this batch row -> LDS (absent factors: neutral constants)
     for (int i = tid; i < p.Cin_pad; i += 256) {
       aff[i] = p.pa ? p.pa[(size_t)tc.b * p.pstride + i] : 1.0f;
@@ -180,38 +177,36 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_kernel(const ImagenIgemmPara
   stage(R0, 0, 0);
   __syncthreads();
 
-  // chunk step i: request the rows of chunk i + 2 into the set chunk i came from, multiply slot i & 1 by this chunk's weight fragments, request
-  // the weights of chunk i + 2 into the registers just multiplied, write chunk i + 1 (requested a step ago) to the other slot, barrier
-  auto step = [&](int i, Regs& Rload, const Regs& Rwrite, WFrag& W) __attribute__((always_inline)) {
+  // chunk step i: request chunk i + 2 into the set chunk i came from, multiply slot i & 1, write chunk i + 1 (requested a step ago) to the
+  // other slot, barrier
+  auto step = [&](int i, Regs& Rload, const Regs& Rwrite) __attribute__((always_inline)) {
     request(Rload, i + 2);
     __builtin_amdgcn_sched_barrier(0);   // (the requests stay HERE: the scheduler otherwise sinks them behind the LDS writes below — one step of latency cover instead of two)
     const char* sb = smem + (i & 1) * CG_SLOT;
-    f16x8 bf[2][MI];
 #pragma unroll
-    for (int ks = 0; ks < 2; ++ks)
+    for (int ks = 0; ks < 2; ++ks) {
+      f16x8 af[NI], bf[MI];
 #pragma unroll
-      for (int mi = 0; mi < MI; ++mi) bf[ks][mi] = *reinterpret_cast<const f16x8*>(sb + b_off[mi][ks]);
+      for (int ni = 0; ni < NI; ++ni) af[ni] = *reinterpret_cast<const f16x8*>(sb + a_off + ks * 2 * CG_BN * 16 + ni * 512);
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      acc[0][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W.k0n0, bf[0][mi], acc[0][mi], 0, 0, 0);
-      acc[1][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W.k0n1, bf[0][mi], acc[1][mi], 0, 0, 0);
-    }
+      for (int mi = 0; mi < MI; ++mi) bf[mi] = *reinterpret_cast<const f16x8*>(sb + b_off[mi][ks]);
 #pragma unroll
-    for (int mi = 0; mi < MI; ++mi) {
-      acc[0][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W.k1n0, bf[1][mi], acc[0][mi], 0, 0, 0);
-      acc[1][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(W.k1n1, bf[1][mi], acc[1][mi], 0, 0, 0);
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(af[ni], bf[mi], acc[ni][mi], 0, 0, 0);
     }
     __builtin_amdgcn_sched_barrier(0);
-    request_w(W, i + 2);
     stage(Rwrite, i + 1, (i + 1) & 1);
     IMAGEN_LGKM0_BARRIER();   // (LDS traffic retired + workgroup barrier; the requests stay in flight)
   };
+  // (two steps per trip with the sets swapped by NAME: a conditional second step lets the compiler roll the pair into one body that rotates
+  // the sets through v_mov / v_cndmask — of registers with loads in flight, i.e. vmcnt(0) at the top of every step)
   // An odd chunk count runs one step more on zero rows (stage() writes zeros past the end): a separate tail step and a loop that may
   // run zero times each cost a copy of the 64 accumulator registers at the merge in front of the generic epilogue — 130 dwords of scratch.
   int i = 0;
   do {
-    step(i, R0, R1, W0);
-    step(i + 1, R1, R0, W1);
+    step(i, R0, R1);
+    step(i + 1, R1, R0);
     i += 2;
   } while (i < NC);
 
