@@ -641,7 +641,9 @@ __global__ __launch_bounds__(256) void time_embed_kernel(const ImagenTimeEmbedPa
   const int i = blockIdx.x * 256 + threadIdx.x;
   if (i >= p.B * p.out_dim) return;
   const int b = i / p.out_dim, o = i - b * p.out_dim;
-  const float x = p.step_ptr ? p.coef[(size_t)(*p.step_ptr) * 8 + 6] : p.times[b];
+  int st = p.step_ptr ? *p.step_ptr : 0;
+  if (p.steps > 0) st = min(max(st, 0), p.steps - 1);
+  const float x = p.step_ptr ? p.coef[(size_t)st * 8 + 6] : p.times[b];
   const int nf = 2 * p.half_dim + 1;
   const float* w = p.w + (size_t)o * nf;
   float a = p.bias[o] + w[0] * x;
@@ -835,7 +837,9 @@ __global__ __launch_bounds__(256) void act_prep_stat_kernel(const ImagenActPrepP
 
 // ------------------------------------------------------------------------------------------------ step_slice
 __global__ __launch_bounds__(256) void step_slice_kernel(const ImagenStepSliceParams p) {
-  const size_t step = (size_t)*p.step_ptr;
+  int st = *p.step_ptr;
+  if (p.steps > 0) st = min(max(st, 0), p.steps - 1);
+  const size_t step = (size_t)st;
   const int w0 = p.words0, w1 = w0 + p.words1, w2 = w1 + p.words2, tot = w2 + p.words3;
   for (int i = blockIdx.x * 256 + threadIdx.x; i < tot; i += gridDim.x * 256) {
     const uint4* s;

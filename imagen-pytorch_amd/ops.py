@@ -911,6 +911,7 @@ def time_embed(plan: Plan, *, times, coef, step_ptr, freqs, w, bias, hid: Act, l
     p.times, p.coef, p.step_ptr = ptr(times), ptr(coef), ptr(step_ptr)
     p.freqs, p.w, p.bias, p.hid = freqs.data_ptr(), w.data_ptr(), bias.data_ptr(), hid.ptr
     p.B, p.half_dim, p.out_dim, p.ld_hid = hid.B * hid.H * hid.W, freqs.numel(), hid.C, hid.ld
+    p.steps = coef.shape[0] if (coef is not None and step_ptr is not None) else 0   # rows of coef: the kernel clamps *step_ptr to them
     plan.add(p, label or "time_embed", [times, coef, step_ptr, freqs, w, bias, hid.t])
     return p
 
@@ -937,6 +938,8 @@ def step_slice(plan: Plan, segments, step_ptr: torch.Tensor, label: str = ""):
         setattr(p, f"words{k}", nbytes // 16)
         keep += [tab, dst]
     p.step_ptr = step_ptr.data_ptr()
+    p.steps = segments[0][0].numel() // segments[0][1].numel()   # rows of the tables: the kernel clamps *step_ptr to them
+    assert all(tab.numel() // dst.numel() == p.steps for tab, dst in segments), "step_slice: tables of one launch hold the same number of steps"
     plan.add(p, label or "step_slice", keep)
     return p
 

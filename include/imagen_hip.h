@@ -296,6 +296,7 @@ typedef struct ImagenTimeEmbedParams {
   const float* times; const float* coef; const int32_t* step_ptr;
   const float* freqs; const float* w; const float* bias; void* hid;
   int32_t B, half_dim, out_dim, ld_hid;
+  int32_t steps;   /* rows of coef: *step_ptr is clamped to [0, steps - 1] (0: not clamped) */
 } ImagenTimeEmbedParams;
 
 /* SCALE_SHIFT — ResnetBlock time_mlp tail ip.py:738-741 folded with block2's ChanRMSNorm gain, for every
@@ -391,6 +392,8 @@ typedef struct ImagenStepSliceParams {
   void* dst0; void* dst1; void* dst2; void* dst3;
   const int32_t* step_ptr;
   int32_t words0, words1, words2, words3;   /* 16-byte words per step of each segment; 0 = segment unused */
+  int32_t steps;                            /* rows of the tables: *step_ptr is clamped to [0, steps - 1] (0: not clamped) — a replay past the
+                                             * last step (a warm-up launch, a counter left over from a longer schedule) reads the last row, not beyond */
 } ImagenStepSliceParams;
 
 /* ROWS_COPY — dst[b, r0 + r, :C] = src[b (or 0), r, :C]  (fp16). */

@@ -81,6 +81,8 @@ class Interpreter:
     def step_slice(self, p):
         m = self.mem
         step = int(m.view(p.step_ptr, torch.int32)[0])
+        if p.steps > 0:
+            step = min(max(step, 0), p.steps - 1)
         for k in range(4):
             w = getattr(p, f"words{k}")
             if not w:
@@ -281,6 +283,8 @@ class Interpreter:
         nf = 2 * p.half_dim + 1
         if p.step_ptr:
             step = int(m.view(p.step_ptr, i32)[0])
+            if p.steps > 0:
+                step = min(max(step, 0), p.steps - 1)
             x = m.view(p.coef, f32)[step * 8 + 6].expand(p.B)
         else:
             x = m.view(p.times, f32)[:p.B]

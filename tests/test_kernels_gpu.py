@@ -441,6 +441,32 @@ def test_gca_tail(ops, dev, B, HW, C, mode):
     assert nerr(act.t.reshape(B * HW, C), act_ref) < TOL
 
 
+def test_step_slice_and_time_embed_clamp_the_step(ops, dev):
+    """STEP_SLICE copies row *step_ptr of up to four per-step tables; TIME_EMBED reads coef[*step_ptr]: a counter outside [0, steps) — a warm-up
+    launch, a counter left over from a longer schedule — is clamped to the last / first row instead of read out of bounds."""
+    torch.manual_seed(13)
+    T = 5
+    tab_a, tab_b = torch.randn(T, 64).to(dev), torch.randn(T, 8, 16).half().to(dev)
+    dst_a, dst_b = torch.zeros(64, device=dev), torch.zeros(8, 16, dtype=torch.float16, device=dev)
+    step = torch.zeros(1, dtype=torch.int32, device=dev)
+    coef = torch.randn(T, 8).to(dev)
+    half, out = 4, 32
+    freqs, w, b = torch.randn(half).to(dev), (torch.randn(out, 2 * half + 1) / 4).to(dev), (torch.randn(out) * 0.1).to(dev)
+    hid = ops.new_act(2, 1, 1, out, dev)
+    plan = ops.Plan()
+    p = ops.step_slice(plan, [(tab_a, dst_a), (tab_b, dst_b)], step)
+    assert p.steps == T
+    ops.time_embed(plan, times=None, coef=coef, step_ptr=step, freqs=freqs, w=w, bias=b, hid=hid)
+    for s, row in ((0, 0), (3, 3), (T - 1, T - 1), (T + 7, T - 1), (-2, 0)):
+        step.fill_(s)
+        _run(plan)
+        assert torch.equal(dst_a.cpu(), tab_a[row].cpu()) and torch.equal(dst_b.cpu(), tab_b[row].cpu()), (s, row)
+        x = coef[row, 6].cpu()
+        f = x * freqs.cpu() * 2 * math.pi
+        ref = F.silu(torch.cat((x.view(1), f.sin(), f.cos())) @ w.cpu().t() + b.cpu())
+        assert nerr(hid.t.reshape(2, out)[0], ref) < 2e-3, (s, row)
+
+
 def test_time_embed_scale_shift_pack_copy(ops, dev):
     torch.manual_seed(9)
     B, half, out = 4, 8, 256
