@@ -551,6 +551,47 @@ __global__ __launch_bounds__(kGcaFastThreads) void gca_final_fast_kernel(const I
   gca_final_fast_body<kGcaFastW>(p.part, p.w1t, p.b1, p.w2t, p.b2, blockIdx.x, p.C, p.hidden, p.chunks, p.gate + (size_t)blockIdx.x * p.C, nullptr);
 }
 
+// The finalisation of a WIDE block (C * hidden >= 128 Ki elements: C2's 512- and 1024-channel levels, 1-4 MB of squeeze-MLP weights) as two
+// launches over many workgroups instead of one workgroup per image streaming the weights alone (39.7 us average, up to 115 us, 7.5 % of the C2
+// step: profiles/r04_c2_kernel_stats.csv).  Phase 1: workgroup (slice, b) merges the chunks of image b (redundantly: a few KB) and computes 32
+// hidden units over 8 channel slices; phase 2: workgroup (slice, b) computes 64 gate channels over 4 hidden slices.  Each reads 128 KB of weights.
+template <int PHASE>
+__global__ __launch_bounds__(256) void gca_final_split_kernel(const ImagenGcaFinalParams p) {
+  __shared__ float s_in[1024], s_wgt[1024], s_red[kGcaScratchFloats];
+  const int tid = threadIdx.x, b = blockIdx.y;
+  if constexpr (PHASE == 1) {
+    gca_merge(p.part + (size_t)b * p.chunks * (p.C + 2), p.chunks, p.C, s_in, s_wgt, s_red);   // s_in = ctx[C]
+    const int o = blockIdx.x * 32 + (tid & 31), sl = tid >> 5;                                 // 8 slices of the channels
+    float a = 0.f;
+    if (o < p.hidden) {
+      const float* w = p.w1t + o;
+#pragma unroll 8
+      for (int c = sl; c < p.C; c += 8) a += w[(size_t)c * p.hidden] * s_in[c];
+    }
+    s_red[tid] = a;
+    __syncthreads();
+    if (tid < 32 && o < p.hidden) {
+      float t = 0.f;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) t += s_red[q * 32 + tid];
+      p.hid[(size_t)b * p.hidden + o] = silu_f(t + p.b1[o]);
+    }
+  } else {
+    for (int i = tid; i < p.hidden; i += 256) s_in[i] = p.hid[(size_t)b * p.hidden + i];
+    __syncthreads();
+    const int c = blockIdx.x * 64 + (tid & 63), sl = tid >> 6;                                 // 4 slices of the hidden units
+    float a = 0.f;
+    if (c < p.C) {
+      const float* w = p.w2t + c;
+#pragma unroll 8
+      for (int o = sl; o < p.hidden; o += 4) a += w[(size_t)o * p.C] * s_in[o];
+    }
+    s_red[tid] = a;
+    __syncthreads();
+    if (tid < 64 && c < p.C) p.gate[(size_t)b * p.C + c] = sigmoid_f(s_red[tid] + s_red[64 + tid] + s_red[128 + tid] + s_red[192 + tid] + p.b2[c]);
+  }
+}
+
 // ------------------------------------------------------------------------------------------------ gca_tail
 // The tail of an identity ResnetBlock in one launch (ImagenGcaTailParams): workgroup (slab, b) finalises the GlobalContext gate of image b
 // in LDS, then streams its slab of rows: out = h * gate + res (+ per-row statistics, + the next Block's activated input).  One lane = 8
@@ -929,6 +970,13 @@ int launch_gca_partial(const ImagenGcaPartialParams* p, hipStream_t s) {
 
 int launch_gca_final(const ImagenGcaFinalParams* p, hipStream_t s) {
   auto pow2 = [](int v) { return v > 0 && (v & (v - 1)) == 0; };
+  IMAGEN_CHECK(p->phase >= 0 && p->phase <= 2, "gca_final: phase %d", p->phase);
+  if (p->phase != 0) {
+    IMAGEN_CHECK(p->hid && p->C <= 1024 && p->hidden <= 1024 && p->chunks <= 1024 && p->C % 2 == 0, "gca_final: the two-phase finalisation needs hid, C / hidden / chunks <= 1024 (got %d / %d / %d)", p->C, p->hidden, p->chunks);
+    if (p->phase == 1) hipLaunchKernelGGL(gca_final_split_kernel<1>, dim3((p->hidden + 31) / 32, p->B), dim3(256), 0, s, *p);
+    else hipLaunchKernelGGL(gca_final_split_kernel<2>, dim3((p->C + 63) / 64, p->B), dim3(256), 0, s, *p);
+    return imagen_hip_status("gca_final");
+  }
   if (pow2(p->C) && pow2(p->hidden) && p->C >= 4 && p->C <= 1024 && p->hidden >= 4 && p->hidden <= 1024 && p->chunks <= 1024) {
     hipLaunchKernelGGL(gca_final_fast_kernel, dim3(p->B), dim3(kGcaFastThreads), 0, s, *p);
     return imagen_hip_status("gca_final");

@@ -80,6 +80,31 @@ __device__ __forceinline__ void gca_mlp(const float* ctx, float* hid, float* s_r
 //   ctx[c] = sum_i part[i][2+c] * exp(m_i - M) / sum_i s_i * exp(m_i - M)
 //   gate   = sigmoid(W2 silu(W1 ctx + b1) + b2)        (w1t: [C][hidden], w2t: [hidden][C], 16-byte aligned, C % 8 == 0)
 // lds: scratch of at least C + hidden + chunks + kGcaScratchFloats floats.
+// the merge alone: ctx[C] (LDS) from the chunk rows; wgt: [chunks], s_red: kGcaScratchFloats (LDS).  All 256 threads; ctx is visible on return.
+__device__ __forceinline__ void gca_merge(const float* part, int chunks, int C, float* ctx, float* wgt, float* s_red) {
+  const int tid = threadIdx.x;
+  const int stride = C + 2;
+  const int lane = tid & 63, wave = tid >> 6;
+  float lm = -3.0e38f;
+  for (int i = tid; i < chunks; i += 256) lm = fmaxf(lm, part[(size_t)i * stride]);
+  for (int off = 32; off > 0; off >>= 1) lm = fmaxf(lm, __shfl_xor(lm, off));
+  if (lane == 0) s_red[wave] = lm;
+  __syncthreads();
+  const float M = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  float ls = 0.f;
+  for (int i = tid; i < chunks; i += 256) {
+    const float w = __expf(part[(size_t)i * stride] - M);
+    wgt[i] = w;
+    ls += part[(size_t)i * stride + 1] * w;
+  }
+  for (int off = 32; off > 0; off >>= 1) ls += __shfl_xor(ls, off);
+  if (lane == 0) s_red[4 + wave] = ls;
+  __syncthreads();   // also publishes wgt[]
+  const float inv_S = 1.0f / (s_red[4] + s_red[5] + s_red[6] + s_red[7]);
+  __syncthreads();   // s_red is reused by the matvec
+  gca_matvec<2>(C, chunks, part + 2, stride, wgt, s_red, [&](int o, float t) __attribute__((always_inline)) { ctx[o] = t * inv_S; });
+}
+
 __device__ __forceinline__ void gca_finalize(const float* part, int chunks, int C, int hidden, const float* w1t, const float* b1,
                                              const float* w2t, const float* b2, float* gate, float* lds) {
   float* ctx = lds;

@@ -549,8 +549,9 @@ class UnetEngine:
                       and ops.gca_tail_ok(Cout, (hidden if rb.gca is not None else None)))
         tail_part, tail_chunks, gate_ready = None, 0, False
         if rb.gca is not None:
+            wide = ops.GCA_FINAL_SPLIT and ops.gca_final_is_wide(Cout, hidden)   # (a fused tail would stream 1-4 MB of MLP weights in EVERY workgroup)
             if op2.gca_part_t is not None:   # the partials came out of block2's epilogue: only the merge + squeeze MLP is left
-                if fused_tail and op2.gca_chunks <= 1024:
+                if fused_tail and op2.gca_chunks <= 1024 and not wide:
                     tail_part, tail_chunks = op2.gca_part_t, op2.gca_chunks
                 else:
                     ops.gca_final(plan, op2.gca_part_t, gca_args["w1t"], gca_args["b1"], gca_args["w2t"], gca_args["b2"], gate, B=R, C=Cout,
@@ -560,7 +561,7 @@ class UnetEngine:
                 chunks = ops.gca_chunks(H * Wd, R, Cout)
                 part = self.f32buf(R, chunks, Cout + 2)
                 gate_ready = ops.gca(plan, h2, gca_args["wk"], gca_args["bk"], gca_args["w1t"], gca_args["b1"], gca_args["w2t"], gca_args["b2"], part,
-                                     gate, chunks, label=name + ".gca", final=not fused_tail)
+                                     gate, chunks, label=name + ".gca", final=(not fused_tail) or wide)
                 if not gate_ready:
                     tail_part, tail_chunks = part, chunks
         out = self.new(R, H, Wd, Cout)

@@ -735,11 +735,26 @@ def qnorm(plan: Plan, q: torch.Tensor, q_scale: torch.Tensor, *, rows, heads, ld
 
 def gca_final(plan: Plan, part: torch.Tensor, w1t, b1, w2t, b2, gate: torch.Tensor, *, B: int, C: int, chunks: int, label: str = ""):
     """GCA_FINAL alone: merge `chunks` partial rows per image (from GCA_PARTIAL or from a conv epilogue) and run the squeeze MLP."""
-    f = STRUCTS["ImagenGcaFinalParams"]()
-    f.part, f.w1t, f.b1, f.w2t, f.b2, f.gate = part.data_ptr(), w1t.data_ptr(), b1.data_ptr(), w2t.data_ptr(), b2.data_ptr(), gate.data_ptr()
-    f.B, f.C, f.hidden, f.chunks = B, C, w1t.shape[1], chunks
-    plan.add(f, (label or "gca") + ".final", [part, w1t, b1, w2t, b2, gate])
+    hidden = w1t.shape[1]
+    split = GCA_FINAL_SPLIT and gca_final_is_wide(C, hidden) and chunks <= 1024
+    hid = torch.empty(B, hidden, dtype=torch.float32, device=gate.device) if split else None
+    f = None
+    for phase in ((1, 2) if split else (0,)):
+        f = STRUCTS["ImagenGcaFinalParams"]()
+        f.part, f.w1t, f.b1, f.w2t, f.b2, f.gate = part.data_ptr(), w1t.data_ptr(), b1.data_ptr(), w2t.data_ptr(), b2.data_ptr(), gate.data_ptr()
+        f.B, f.C, f.hidden, f.chunks = B, C, hidden, chunks
+        f.hid, f.phase = ptr(hid), phase
+        plan.add(f, (label or "gca") + (".final" if phase == 0 else f".final{phase}"), [part, w1t, b1, w2t, b2, gate, hid])
     return f
+
+
+GCA_FINAL_SPLIT = int(_os.environ.get("IMAGEN_GCA_FINAL_SPLIT", "1"))   # A/B switch: the finalisation of wide blocks as two many-workgroup launches
+
+
+def gca_final_is_wide(C: int, hidden: int) -> bool:
+    """The squeeze MLP of a block this wide (>= 128 Ki weights per matrix: 1 MB and up) is streamed by many workgroups in two launches, not by
+    one workgroup per image (GCA_FINAL phase 1 / 2) — and not redundantly by every workgroup of a fused tail."""
+    return C * hidden >= 128 * 1024
 
 
 def gca(plan: Plan, h: Act, wk, bk: float, w1t, b1, w2t, b2, part: torch.Tensor, gate: torch.Tensor, chunks: int, label: str = "",
@@ -756,7 +771,8 @@ def gca(plan: Plan, h: Act, wk, bk: float, w1t, b1, w2t, b2, part: torch.Tensor,
     p.B, p.HW, p.C, p.ld, p.chunks, p.bk = h.B, h.H * h.W, C, h.ld, chunks, bk
     groups = C // 8
     single = (chunks == 1 and (groups & (groups - 1)) == 0 and groups <= 64
-              and C + hidden + chunks + GCA_SCRATCH <= 2048)
+              and C + hidden + chunks + GCA_SCRATCH <= 2048
+              and not (GCA_FINAL_SPLIT and gca_final_is_wide(C, hidden)))   # (a wide block's MLP: many workgroups, GCA_FINAL phases 1 / 2)
     keep = [h.t, wk, part]
     if single:
         p.w1t, p.b1, p.w2t, p.b2, p.gate, p.hidden = w1t.data_ptr(), b1.data_ptr(), w2t.data_ptr(), b2.data_ptr(), gate.data_ptr(), hidden
@@ -766,10 +782,7 @@ def gca(plan: Plan, h: Act, wk, bk: float, w1t, b1, w2t, b2, part: torch.Tensor,
         return True
     if not final:
         return False
-    f = STRUCTS["ImagenGcaFinalParams"]()
-    f.part, f.w1t, f.b1, f.w2t, f.b2, f.gate = part.data_ptr(), w1t.data_ptr(), b1.data_ptr(), w2t.data_ptr(), b2.data_ptr(), gate.data_ptr()
-    f.B, f.C, f.hidden, f.chunks = h.B, C, hidden, chunks
-    plan.add(f, (label or "gca") + ".final", [part, w1t, b1, w2t, b2, gate])
+    gca_final(plan, part, w1t, b1, w2t, b2, gate, B=h.B, C=C, chunks=chunks, label=label)
     return True
 
 

@@ -245,6 +245,11 @@ typedef struct ImagenGcaPartialParams {
 typedef struct ImagenGcaFinalParams {
   const float* part; const float* w1t; const float* b1; const float* w2t; const float* b2; float* gate;
   int32_t B, C, hidden, chunks; /* w1t: [C][hidden] (= net.0.weight transposed), w2t: [hidden][C] (= net.2.weight transposed) */
+  /* phase 0: the whole finalisation, one workgroup per image.  Wide blocks (C * hidden >= 128 Ki: 1-4 MB of squeeze-MLP weights that one
+   * workgroup would stream alone) run it as TWO launches over many workgroups: phase 1 merges the chunks and writes
+   * hid[b, :] = silu(W1 ctx + b1) (a workgroup per 32 hidden units and image), phase 2 writes gate[b, :] = sigmoid(W2 hid + b2)
+   * (a workgroup per 64 channels and image).  hid: fp32 [B][hidden] scratch, required for phases 1 and 2. */
+  float* hid; int32_t phase;
 } ImagenGcaFinalParams;
 
 /* GATE_RESIDUAL — ResnetBlock tail ip.py:755-757 with identity residual: out = h*gate[b,c] + res

@@ -394,6 +394,8 @@ class Interpreter:
             self.gca_ctx[p.part] = ctx
 
     def gca_final(self, p):
+        if p.phase == 1:     # two-phase finalisation of a wide block: the gate is complete after phase 2, computed there from the same inputs
+            return
         if p.part in self.gca_ctx:
             ctx = self.gca_ctx.pop(p.part)
         else:   # partial rows in memory (written by a conv epilogue): merge (max, sum exp, sum exp * h) over the chunks

@@ -366,9 +366,11 @@ def test_rowstat_gate_ln(ops, dev):
     assert nerr(out2.t.reshape(-1, C), ref) < TOL
 
 
-@pytest.mark.parametrize("B,HW,C", [(2, 64 * 64, 32), (2, 16 * 16, 128), (1, 8 * 8, 256), (2, 24 * 24, 96)])
+@pytest.mark.parametrize("B,HW,C", [(2, 64 * 64, 32), (2, 16 * 16, 128), (1, 8 * 8, 256), (2, 24 * 24, 96), (2, 8 * 8, 512), (3, 16 * 16, 1024),
+                                    (2, 8 * 8, 1024)])
 def test_global_context(ops, dev, B, HW, C):
-    """GlobalContext gate (ip.py:945-970)."""
+    """GlobalContext gate (ip.py:945-970).  The 512- and 1024-channel cases (C2's deep levels) take the two-phase finalisation (GCA_FINAL
+    phase 1 / 2: the squeeze MLP over many workgroups) — one chunk per image and several."""
     torch.manual_seed(8)
     S = int(math.isqrt(HW))
     x = h16(torch.randn(B, C, S, S))
@@ -386,6 +388,8 @@ def test_global_context(ops, dev, B, HW, C):
     plan = ops.Plan()
     ops.gca(plan, a, wk.reshape(C).to(dev), float(bk), w1.reshape(hidden, C).t().contiguous().to(dev), b1.to(dev),
             w2.reshape(C, hidden).t().contiguous().to(dev), b2.to(dev), part, gate, chunks)
+    if ops.gca_final_is_wide(C, hidden):
+        assert [l for _, _, l in plan.ops][-2:] == ["gca.final1", "gca.final2"], [l for _, _, l in plan.ops]
     _run(plan)
     assert nerr(gate, ref) < 1e-4
 
