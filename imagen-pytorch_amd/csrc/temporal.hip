@@ -1,6 +1,5 @@
 // temporal.hip — the two kernels the Imagen-Video denoiser (Unet3D) adds to the image path: the depthwise temporal PEG and the
-// per-pixel attention over the frame axis.  Both are small HBM-/latency-bound vector kernels (F <= 32 frames): no MFMA.
-// STATUS: compiled for gfx950 and specified by include/imagen_hip.h + tests/plan_interp.py; not yet run on a GPU.
+// per-pixel attention over the frame axis (a vector kernel for any F <= 32, and — round 4 — the MFMA kernel that takes every F <= 31).
 #include "common.h"
 
 namespace {
@@ -98,6 +97,181 @@ __global__ __launch_bounds__(256) void temporal_attention_kernel(const ImagenTem
   }
 }
 
+// ---- the same attention on the matrix pipe (F <= 31: the F + 1 keys fit one 32-key tile).  Round-4 kernel table of BASELINE C5
+// (profiles/r04_c5_kernel_stats.csv): the kernel above is 57 % of the C5 step — 757 us per launch for 235 MB of traffic, every one of the
+// heads x F x (F + 1) similarities of a pixel a six-step wave reduction.  Here a wave still owns one (clip, pixel), but its heads x F query
+// rows are MFMA rows: per block of 32 rows  S^T[key][row] = K^ . Q^T (v_mfma_f32_32x32x16_f16, the attention.hip layouts: lane = row, 16
+// keys per lane), bias + causal mask + softmax in registers (one cross-half shuffle), O^T += V^T . P.  K^ and Q^ enter the MFMA as
+// fp16 hi + lo pairs (three products per K step: hi.hi + lo.hi + hi.lo), so the logits keep the fp32 accuracy of the kernel above — they
+// reach 18 with the scale vectors the reference trains, where a bare fp16 operand would cost 5e-3 in the softmax weights; P is fp16 as in
+// attention.hip.  V^T (dims x 32 keys, fp16) and the bias table go through LDS; per pixel 64 MFMAs instead of ~1200 wave reductions.
+constexpr int kTaVtRow = 72;   // LDS bytes per V^T row (32 keys x 2 B + 8: conflict-free ds_read_b64, attention.hip's VSTR)
+
+__device__ __forceinline__ void ta_split(const float (&x)[8], f16x8& hi, f16x8& lo) {
+#pragma unroll
+  for (int j = 0; j < 8; ++j) {
+    hi[j] = (f16)x[j];
+    lo[j] = (f16)(x[j] - (float)hi[j]);
+  }
+}
+
+__global__ __launch_bounds__(256) void temporal_attention_mfma_kernel(const ImagenTemporalAttentionParams p) {
+  extern __shared__ float lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int F = p.F, J = F + 1;
+  // ---- the bias table of all heads -> LDS (shared by the four waves)
+  float* s_bias = lds;                                                   // [heads][F][J]
+  const int nb = p.heads * F * J;
+  for (int i = threadIdx.x; i < nb; i += 256) s_bias[i] = p.bias[i];
+  char* vt = reinterpret_cast<char*>(lds + ((nb + 3) & ~3)) + (size_t)wave * 64 * kTaVtRow;   // this wave's V^T: [64 dims][32 keys] fp16
+  __syncthreads();
+  const size_t item = (size_t)blockIdx.x * 4 + wave;       // (b, px)
+  if (item >= (size_t)p.B * p.P) return;                    // (behind the only workgroup barrier)
+  const int b = (int)(item / p.P), px = (int)(item - (size_t)b * p.P);
+  const f16* base = reinterpret_cast<const f16*>(p.qkv) + ((size_t)b * F * p.P + px) * p.ld;
+  const size_t fstride = (size_t)p.P * p.ld;
+  const int inner = p.heads * 64;
+
+  // ---- V^T: lane d gathers column d of the J value rows (null value first); keys J..31 are zero
+  {
+    f16* col = reinterpret_cast<f16*>(vt + lane * kTaVtRow);
+    col[0] = (f16)p.null_kv[64 + lane];
+    for (int j = 0; j < F; ++j) col[1 + j] = base[(size_t)j * fstride + inner + 64 + lane];
+    for (int j = J; j < 32; ++j) col[j] = (f16)0.f;
+  }
+  // ---- K^ fragments (A operand: lane = key l31, dims 16 s + 8 half ..): l2norm * k_scale, as fp16 hi + lo; key 0 = the null key
+  f16x8 kh[4], kl[4];
+  {
+    float kx[4][8];
+    float ssq = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int d0 = 16 * s + 8 * half;
+      if (l31 == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kx[s][j] = p.null_kv[d0 + j];
+      } else if (l31 < J) {
+        const f16x8 r = *reinterpret_cast<const f16x8*>(base + (size_t)(l31 - 1) * fstride + inner + d0);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kx[s][j] = (float)r[j];
+      } else {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) kx[s][j] = 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < 8; ++j) ssq += kx[s][j] * kx[s][j];
+    }
+    ssq += __shfl_xor(ssq, 32);
+    const float inv = 1.0f / fmaxf(sqrtf(ssq), 1e-12f);
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      const int d0 = 16 * s + 8 * half;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) kx[s][j] *= inv * p.k_scale[d0 + j];
+      ta_split(kx[s], kh[s], kl[s]);
+    }
+  }
+  float qsc[4][8];   // q_scale * scale of this lane's dims
+#pragma unroll
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) qsc[s][j] = p.q_scale[16 * s + 8 * half + j] * p.scale;
+
+  f16* obase = reinterpret_cast<f16*>(p.o) + ((size_t)b * F * p.P + px) * p.ld_o;
+  const size_t ostride = (size_t)p.P * p.ld_o;
+  const int rows = p.heads * F;
+  for (int r0 = 0; r0 < rows; r0 += 32) {
+    // ---- Q^ fragments of row r0 + l31 = (head, frame) (B operand: lane = row, the same dims)
+    const int r = r0 + l31;
+    const bool rok = r < rows;
+    const int h = rok ? r / F : 0, i = rok ? r - h * F : 0;
+    f16x8 qh[4], ql[4];
+    {
+      float qx[4][8];
+      float ssq = 0.f;
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const f16x8 v = *reinterpret_cast<const f16x8*>(base + (size_t)i * fstride + h * 64 + 16 * s + 8 * half);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          qx[s][j] = rok ? (float)v[j] : 0.f;
+          ssq += qx[s][j] * qx[s][j];
+        }
+      }
+      ssq += __shfl_xor(ssq, 32);
+      const float inv = 1.0f / fmaxf(sqrtf(ssq), 1e-12f);
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) qx[s][j] *= inv * qsc[s][j];
+        ta_split(qx[s], qh[s], ql[s]);
+      }
+    }
+    // ---- S^T[key][row]: register e of this lane = key (e & 3) + 8 (e >> 2) + 4 half of row l31
+    f32x16 sacc;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sacc[e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl[s], qh[s], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[s], ql[s], sacc, 0, 0, 0);
+      sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh[s], qh[s], sacc, 0, 0, 0);
+    }
+    // ---- bias, causal mask (keys 0 (null) .. last are visible), softmax over the 32 key slots (this lane's 16 + lane ^ 32's)
+    const int last = p.causal ? i + 1 : F;
+    const float* brow = s_bias + ((size_t)h * F + i) * J;
+    float mx = -3.0e38f;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const int key = (e & 3) + 8 * (e >> 2) + 4 * half;
+      const bool vis = key <= last && key < J;
+      sacc[e] = vis ? sacc[e] + brow[vis ? key : 0] : -3.0e38f;
+      mx = fmaxf(mx, sacc[e]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float den = 0.f;
+    f16x8 pf[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float w = sacc[e] > -1.0e38f ? __expf(sacc[e] - mx) : 0.f;
+      den += w;
+      pf[e >> 3][e & 7] = (f16)w;
+    }
+    den += __shfl_xor(den, 32);
+    // ---- O^T[d][row] += V^T . P   (k-step s covers the keys of accumulator registers 8 s .. 8 s + 7)
+    f32x16 oacc[2];
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[db][e] = 0.f;
+#pragma unroll
+    for (int s = 0; s < 2; ++s)
+#pragma unroll
+      for (int db = 0; db < 2; ++db) {
+        const char* vrow = vt + (32 * db + l31) * kTaVtRow + (16 * s + 4 * half) * 2;
+        const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
+        const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16);
+        uint4 packed = make_uint4(lo.x, lo.y, hi.x, hi.y);
+        const f16x8 vf = *reinterpret_cast<const f16x8*>(&packed);
+        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], oacc[db], 0, 0, 0);
+      }
+    if (rok) {
+      const float inv = 1.0f / den;
+      f16* o = obase + (size_t)i * ostride + h * 64;
+#pragma unroll
+      for (int db = 0; db < 2; ++db)
+#pragma unroll
+        for (int qd = 0; qd < 4; ++qd) {
+          f16x4 v;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) v[e] = (f16)(oacc[db][4 * qd + e] * inv);
+          *reinterpret_cast<f16x4*>(o + 32 * db + 8 * qd + 4 * half) = v;
+        }
+    }
+  }
+}
+
 }  // namespace
 
 int launch_temporal_peg(const ImagenTemporalPegParams* p, hipStream_t s) {
@@ -113,6 +287,13 @@ int launch_temporal_attention(const ImagenTemporalAttentionParams* p, hipStream_
   IMAGEN_CHECK(p->F > 0 && p->F <= kMaxFrames, "temporal_attention: 1 <= F <= 32");
   IMAGEN_CHECK(p->heads > 0 && p->B > 0 && p->P > 0, "temporal_attention: bad shape");
   const size_t items = (size_t)p->B * p->P;
+  if (p->F <= 31 && p->ld % 8 == 0 && p->ld_o % 4 == 0 && ((size_t)p->qkv & 15) == 0 && ((size_t)p->o & 7) == 0) {   // the MFMA kernel: F + 1 keys in one 32-key tile
+    const size_t nb = (size_t)p->heads * p->F * (p->F + 1);
+    const size_t lds = ((nb + 3) & ~(size_t)3) * sizeof(float) + (size_t)4 * 64 * kTaVtRow;
+    IMAGEN_CHECK(lds <= 64 * 1024, "temporal_attention: bias table of %d heads x %d frames does not fit LDS", p->heads, p->F);
+    hipLaunchKernelGGL(temporal_attention_mfma_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), lds, s, *p);
+    return imagen_hip_status("temporal_attention");
+  }
   const size_t lds_bytes = (size_t)4 * 2 * (kMaxFrames + 1) * kKvRow * sizeof(float);
   static bool attr_set[16] = {};   // per device
   int dev = 0;
