@@ -122,8 +122,9 @@ def test_global_context_of_conv_output(B, S, C, single, monkeypatch):
     part = torch.empty(B, chunks, C + 2, device=dev)
     ops.gca(plan, y, wk.reshape(C).to(dev), float(bk), w1.reshape(hidden, C).t().contiguous().to(dev), b1.to(dev),
             w2.reshape(C, hidden).t().contiguous().to(dev), b2.to(dev), part, gate, chunks)
-    one_launch = chunks == 1 and not (C // 8) & (C // 8 - 1)   # power-of-two C/8: the in-kernel finalisation exists
-    assert len(plan) == (2 if one_launch else 3)
+    wide = bool(ops.GCA_FINAL_SPLIT) and ops.gca_final_is_wide(C, hidden)   # a wide block's squeeze MLP: GCA_FINAL phases 1 / 2 over many workgroups
+    one_launch = chunks == 1 and not (C // 8) & (C // 8 - 1) and not wide   # power-of-two C/8: the in-kernel finalisation exists
+    assert len(plan) == (4 if wide else 2 if one_launch else 3)
     for _ in range(2):
         gate.zero_()
         plan.run()
