@@ -32,16 +32,17 @@ def _both(build):
     from plan_interp import Interpreter
 
     outs = []
-    for dev in ("cuda:0", "cpu"):
+    for leg, dev in (("kernels", gpu_device()), ("interpreter", torch.device("cpu"))):   # (IMAGEN_EMUL_TESTS=1: the kernels run on the CPU emulation)
         torch.manual_seed(0)
         plan = ops.Plan()
-        out = build(plan, torch.device(dev))
-        if dev == "cpu":
+        out = build(plan, dev)
+        if leg == "interpreter":
             it = Interpreter()
             it.run(plan)
         else:
             plan.run()
-            torch.cuda.synchronize()
+            if dev.type == "cuda":
+                torch.cuda.synchronize()
         if isinstance(out, (list, tuple)):
             out = torch.cat([t.flatten() for t in out])
         outs.append(out.float().cpu())
