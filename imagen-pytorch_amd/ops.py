@@ -754,7 +754,7 @@ GCA_FINAL_SPLIT = int(_os.environ.get("IMAGEN_GCA_FINAL_SPLIT", "1"))   # A/B sw
 def gca_final_is_wide(C: int, hidden: int) -> bool:
     """The squeeze MLP of a block this wide (>= 128 Ki weights per matrix: 1 MB and up) is streamed by many workgroups in two launches, not by
     one workgroup per image (GCA_FINAL phase 1 / 2) — and not redundantly by every workgroup of a fused tail."""
-    return C * hidden >= 128 * 1024
+    return C * hidden >= 128 * 1024 and C <= 1024 and hidden <= 1024 and C % 2 == 0   # (the two-phase kernels' LDS tables hold 1024 entries)
 
 
 def gca(plan: Plan, h: Act, wk, bk: float, w1t, b1, w2t, b2, part: torch.Tensor, gate: torch.Tensor, chunks: int, label: str = "",
