@@ -333,3 +333,25 @@ def test_text_encoder_hook_and_conditioning_handle():
     fresh = Imagen([Unet(**kw)], image_sizes=(16,), timesteps=2, text_embed_dim=32, text_encoder_name="google/t5-v1_1-small")
     with pytest.raises(RuntimeError, match="not available from local files"):
         fresh.encode_text(["hello"], return_attn_mask=True)
+
+
+def test_round4_planner_predicates():
+    """Host-side decisions added in round 4 (no GPU): the logit bound that selects the bounded-logit attention tiling, the width above which the
+    GlobalContext finalisation runs as two many-workgroup launches, the step count STEP_SLICE clamps to, and the family-7 routing rule."""
+    import math
+
+    from imagen_pytorch_amd import ops
+
+    # |q^ . k^| * q_mult <= q_mult * max |q_scale * k_scale| (+ 1 % and 0.05 for the fp16 rounding of the unit rows)
+    ones = torch.ones(64)
+    b = ops.attention_logit_bound(ones, ones, 8 * ops.LOG2E)
+    assert math.isclose(b, 8 * ops.LOG2E * 1.01 + 0.05) and b <= ops.ATTN_BOUND_MAX           # the reference's init: bounded tiling
+    assert ops.attention_logit_bound(1.5 * ones, ones, 8 * ops.LOG2E) > ops.ATTN_BOUND_MAX    # trained scales can leave it: online softmax
+    qs = torch.linspace(0.5, 1.2, 64)
+    assert math.isclose(ops.attention_logit_bound(qs, -qs, 2.0), 2.0 * 1.44 * 1.01 + 0.05, rel_tol=1e-6)   # the sign does not matter, the largest product does
+    # wide GlobalContext blocks (C2's 512- / 1024-channel levels) finalise in two phases; the README widths and anything the kernels cannot hold do not
+    assert ops.gca_final_is_wide(512, 256) and ops.gca_final_is_wide(1024, 512)
+    assert not ops.gca_final_is_wide(256, 128) and not ops.gca_final_is_wide(128, 64) and not ops.gca_final_is_wide(2048, 1024)
+    # family 7 exists in the library and is built for 128-pixel x 128-cout tiles of 32-channel chunks
+    gid = ops.gemm_cfg()
+    assert gid is not None and ops.cfg_table()[gid] == (128, 128, 4, 7)
