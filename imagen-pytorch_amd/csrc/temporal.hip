@@ -140,6 +140,11 @@ __global__ __launch_bounds__(256) void temporal_attention_mfma_kernel(const Imag
     for (int j = 0; j < F; ++j) col[1 + j] = base[(size_t)j * fstride + inner + 64 + lane];
     for (int j = J; j < 32; ++j) col[j] = (f16)0.f;
   }
+  // the tile is wave-private, but other LANES of the wave read what this lane stored: order the stores before the PV fragment reads
+  // (hardware issues a wave's LDS operations in order; the fence keeps the compiler — and the CPU emulation's fibers — to that order)
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
   // ---- K^ fragments (A operand: lane = key l31, dims 16 s + 8 half ..): l2norm * k_scale, as fp16 hi + lo; key 0 = the null key
   f16x8 kh[4], kl[4];
   {
@@ -231,12 +236,14 @@ __global__ __launch_bounds__(256) void temporal_attention_mfma_kernel(const Imag
     }
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     float den = 0.f;
-    f16x8 pf[2];
+    f16x8 pf[2], pl[2];   // the softmax weights as fp16 hi + lo pairs too (round 5): a bare fp16 P cost the C5 denoiser 6 % of its 1e-3 budget
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
       const float w = sacc[e] > -1.0e38f ? __expf(sacc[e] - mx) : 0.f;
       den += w;
-      pf[e >> 3][e & 7] = (f16)w;
+      const f16 wh = (f16)w;
+      pf[e >> 3][e & 7] = wh;
+      pl[e >> 3][e & 7] = (f16)(w - (float)wh);
     }
     den += __shfl_xor(den, 32);
     // ---- O^T[d][row] += V^T . P   (k-step s covers the keys of accumulator registers 8 s .. 8 s + 7)
@@ -254,6 +261,7 @@ __global__ __launch_bounds__(256) void temporal_attention_mfma_kernel(const Imag
         const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16);
         uint4 packed = make_uint4(lo.x, lo.y, hi.x, hi.y);
         const f16x8 vf = *reinterpret_cast<const f16x8*>(&packed);
+        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pl[s], oacc[db], 0, 0, 0);
         oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], oacc[db], 0, 0, 0);
       }
     if (rok) {
@@ -287,10 +295,11 @@ int launch_temporal_attention(const ImagenTemporalAttentionParams* p, hipStream_
   IMAGEN_CHECK(p->F > 0 && p->F <= kMaxFrames, "temporal_attention: 1 <= F <= 32");
   IMAGEN_CHECK(p->heads > 0 && p->B > 0 && p->P > 0, "temporal_attention: bad shape");
   const size_t items = (size_t)p->B * p->P;
-  if (p->F <= 31 && p->ld % 8 == 0 && p->ld_o % 4 == 0 && ((size_t)p->qkv & 15) == 0 && ((size_t)p->o & 7) == 0) {   // the MFMA kernel: F + 1 keys in one 32-key tile
-    const size_t nb = (size_t)p->heads * p->F * (p->F + 1);
-    const size_t lds = ((nb + 3) & ~(size_t)3) * sizeof(float) + (size_t)4 * 64 * kTaVtRow;
-    IMAGEN_CHECK(lds <= 64 * 1024, "temporal_attention: bias table of %d heads x %d frames does not fit LDS", p->heads, p->F);
+  const size_t nb = (size_t)p->heads * p->F * (p->F + 1);
+  const size_t lds = ((nb + 3) & ~(size_t)3) * sizeof(float) + (size_t)4 * 64 * kTaVtRow;
+  // the MFMA kernel: F + 1 keys in one 32-key tile, aligned rows, the bias table of all heads in 64 KB of LDS (12+ heads at F = 31 do not
+  // fit: those shapes keep the vector kernel below, as every shape did before round 4)
+  if (p->F <= 31 && p->ld % 8 == 0 && p->ld_o % 4 == 0 && ((size_t)p->qkv & 15) == 0 && ((size_t)p->o & 7) == 0 && lds <= 64 * 1024) {
     hipLaunchKernelGGL(temporal_attention_mfma_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), lds, s, *p);
     return imagen_hip_status("temporal_attention");
   }

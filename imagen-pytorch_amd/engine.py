@@ -122,7 +122,7 @@ SPLIT_STATIC = int(os.environ.get("IMAGEN_SPLIT_STATIC", "1"))
 SPLIT_SMALL = int(os.environ.get("IMAGEN_SPLIT_SMALL", "1"))
 SPLIT_SMALL_MAX_K = int(os.environ.get("IMAGEN_SPLIT_MAX_K", "320"))        # taps * input channels of the unsplit weight
 SPLIT_1X1 = int(os.environ.get("IMAGEN_SPLIT_1X1", "0"))
-SPLIT_BLOCK2 = int(os.environ.get("IMAGEN_SPLIT_BLOCK2", "0"))
+SPLIT_BLOCK2 = int(os.environ.get("IMAGEN_SPLIT_BLOCK2", "1"))   # round 5: on (measured -4 % whole-Unet error for +0.03 ms per step pair: the margin under 1e-3)
 SPLIT_SMALL_FLOPS = 3.0e9      # 2 * pixels * Cout * (2 K) of the split launch
 
 

@@ -57,6 +57,7 @@ class Plan:
         self.name = name
         self.ops: List[tuple] = []   # (kind, struct, label)
         self.keep: List[object] = []  # tensors referenced by raw pointer
+        self.twice: dict = {}         # doubled per-channel affines of this plan's split-precision launches (_twice)
         self._arr = None
 
     def add(self, struct, label: str = "", keep: Sequence = ()):
@@ -298,6 +299,8 @@ PW_MIN_TILES = 512     # ... of at least this many tiles, i.e. two per CU (the b
 
 CONV_GEMM = int(_os.environ.get("IMAGEN_CONV_GEMM", "1"))             # A/B switch: the tiled pointwise GEMM (conv_gemm.hip) for the deep 1x1 layers
 GEMM_MIN_K = 128         # ... with at least this many input channels (below: family 4 / the wave-specialised kernel)
+GEMM_MAX_K = 2048        # ... and at most this many (the launcher's limit, conv_gemm.hip: the prologue affine table in LDS; a split-precision
+                         # weight counts its input channels twice) — wider layers stay on the wave-specialised kernel
 GEMM_MIN_TILES = 128     # ... and at least this many 128-row x 128-cout workgroup tiles
 GEMM_MIN_COUT = 256      # ... that fill at least two output-channel slabs
 CONV_BIG = int(_os.environ.get("IMAGEN_CONV_BIG", "1"))               # A/B switch: the big-tile all-DMA family (conv_big.hip) for the C >= 128 3x3 convs
@@ -446,19 +449,18 @@ def pick_cfg(G: int, Cout: int, OH: int, OW: int, B: int, KH: int = 1, KW: int =
     raise ValueError(f"no igemm tile configuration for G={G} Cout={Cout} {OH}x{OW} k{KH}x{KW} s{stride}")
 
 
-_TWICE: dict = {}   # (data_ptr of a per-channel fp32 vector, C, n) -> (the vector, [v[:C] | v[:C] | 0 ..] of length n): the affine of a split-precision launch
-
-
-def _twice(v: Optional[torch.Tensor], C: int, n: int) -> Optional[torch.Tensor]:
+def _twice(plan: "Plan", v: Optional[torch.Tensor], C: int, n: int) -> Optional[torch.Tensor]:
+    """[v[:C] | v[:C] | 0 ..] of length n: the per-channel affine of a split-precision launch (the input is read twice).  The doubled copy
+    belongs to the PLAN that uses it (it dies with the plan; a snapshot of `v` at plan build, like every folded / packed parameter)."""
     if v is None:
         return None
     key = (v.data_ptr(), C, n)
-    hit = _TWICE.get(key)
+    hit = plan.twice.get(key)
     if hit is None or hit[0] is not v:
         out = torch.zeros(n, dtype=torch.float32, device=v.device)
         out[:C] = v.reshape(-1)[:C]
         out[C:2 * C] = v.reshape(-1)[:C]
-        hit = _TWICE[key] = (v, out)
+        hit = plan.twice[key] = (v, out)
     return hit[1]
 
 
@@ -477,7 +479,7 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
     if pw.split:   # split-precision weight: the input is read twice, against the hi and the lo half of the weight
         assert x2 is None and ssq_b is None and pstride == 0, f"{label}: a split-precision weight takes one input tensor and batch-shared affines"
         x2 = x1
-        pa, ps = _twice(pa, x1.C, pw.Cin_pad), _twice(ps, x1.C, pw.Cin_pad)
+        pa, ps = _twice(plan, pa, x1.C, pw.Cin_pad), _twice(plan, ps, x1.C, pw.Cin_pad)
     H, W = x1.H, x1.W
     OH = (H + 2 * pad - KH) // stride + 1
     OW = (W + 2 * pad - KW) // stride + 1
@@ -531,7 +533,7 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
         # IMAGEN_CONV_GEMM=2 routes those too)
         plain_ep = act_out == ACT_NONE and out_mode == OUT_NHWC and addend is None and res is None
         if ((CONV_GEMM >= 2 or (plain_ep and pw.Cout >= GEMM_MIN_COUT))
-                and ln_pro and x1.C % 32 == 0 and C2 % 32 == 0 and pw.Cin_pad == x1.C + C2 and x1.C + C2 >= GEMM_MIN_K and tiles >= GEMM_MIN_TILES
+                and ln_pro and x1.C % 32 == 0 and C2 % 32 == 0 and pw.Cin_pad == x1.C + C2 and GEMM_MIN_K <= x1.C + C2 <= GEMM_MAX_K and tiles >= GEMM_MIN_TILES
                 and x1.ld % 8 == 0 and x1.bs % 8 == 0 and (x2 is None or (x2.ld % 8 == 0 and x2.bs % 8 == 0))
                 and (out_mode == OUT_NCHW_F32 or pw.Cout % 4 == 0)):   # (ssq_out / post / gca wider than the 128-cout tile: not emitted, as in family 0)
             tw = 128 if OW >= 128 else 1 << (OW.bit_length() - 1)   # (the largest power of two inside the row, 128 pixels per tile)

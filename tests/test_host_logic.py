@@ -355,3 +355,30 @@ def test_round4_planner_predicates():
     # family 7 exists in the library and is built for 128-pixel x 128-cout tiles of 32-channel chunks
     gid = ops.gemm_cfg()
     assert gid is not None and ops.cfg_table()[gid] == (128, 128, 4, 7)
+
+
+def test_family7_respects_the_launcher_k_limit():
+    """a 1x1 layer whose (split-precision-doubled) input width exceeds conv_gemm.hip's Cin_pad <= 2048 must not be routed to
+    family 7 — before the fix a Cin = 4096 layer and a split Cin = 2048 layer got cfg 49 and failed at launch time with no fallback.  Dry plans on
+    CPU memory; `imagen_launch` is only asked whether it accepts the parameters (the CPU library refuses to run, which is a different error)."""
+    from imagen_pytorch_amd import ops
+
+    gid = ops.gemm_cfg()
+    rows, cout = 8192, 1024
+    for cin, split in ((4096, False), (2048, True), (2048, False), (1024, True)):
+        w = ops.pack_weight(torch.randn(cout, cin) * 0.01, None, "cpu", split=split)
+        x = ops.new_act(1, 1, rows, cin, "cpu")
+        y = ops.new_act(1, 1, rows, cout, "cpu")
+        plan = ops.Plan("k-limit")
+        p = ops.igemm(plan, x, w, y, label="wide")
+        fam = ops.cfg_table()[p.cfg][3]
+        if w.Cin_pad > ops.GEMM_MAX_K:
+            assert fam != 7, f"Cin_pad {w.Cin_pad} routed to family 7"
+        else:
+            assert p.cfg == gid, f"Cin_pad {w.Cin_pad} should still take family 7 (got cfg {p.cfg})"
+    # the doubled affine of a split launch belongs to the plan (ADVICE: no process-global cache)
+    pa = torch.ones(64)
+    w = ops.pack_weight(torch.randn(32, 64) * 0.1, None, "cpu", split=True)
+    plan = ops.Plan("twice")
+    ops.igemm(plan, ops.new_act(1, 1, 64, 64, "cpu"), w, ops.new_act(1, 1, 64, 32, "cpu"), pa=pa)
+    assert len(plan.twice) == 1 and not hasattr(ops, "_TWICE")

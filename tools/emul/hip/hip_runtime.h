@@ -178,6 +178,7 @@ hipError_t hipEventDestroy(hipEvent_t);
 #define __builtin_amdgcn_permlane32_swap(a, b, fi, bc) emul::permlane32_swap((a), (b))
 #define __builtin_amdgcn_readfirstlane(v) (v)
 #define __builtin_amdgcn_sched_barrier(m) ((void)0)
+#define __builtin_amdgcn_wave_barrier() do { int wb_ = 0; (void)emul::shfl_xor(wb_, 0); } while (0)   // a wave rendezvous: every lane's earlier stores precede every lane's later reads
 #define __builtin_amdgcn_sched_group_barrier(m, n, id) ((void)0)
 #define __builtin_amdgcn_s_setprio(n) ((void)0)
 #define __builtin_amdgcn_s_waitcnt(imm) emul::s_waitcnt(imm)
