@@ -108,6 +108,7 @@ OP_STRUCT = {
     ENUMS["IMAGEN_OP_ACT_PREP"]: STRUCTS["ImagenActPrepParams"],
     ENUMS["IMAGEN_OP_GCA_TAIL"]: STRUCTS["ImagenGcaTailParams"],
     ENUMS["IMAGEN_OP_STEP_SLICE"]: STRUCTS["ImagenStepSliceParams"],
+    ENUMS["IMAGEN_OP_ROWCHAIN"]: STRUCTS["ImagenRowchainParams"],
 }
 STRUCT_KIND = {v: k for k, v in OP_STRUCT.items()}
 
@@ -116,7 +117,7 @@ EXPORTED_SYMBOLS = [
     "imagen_igemm_num_configs", "imagen_igemm_config_info", "imagen_igemm_stage_slots", "imagen_igemm_config_family", "imagen_igemm_config_ring", "imagen_igemm_lds_bytes", "imagen_igemm_packed_elems", "imagen_pack_igemm_weights",
     "imagen_graph_begin", "imagen_graph_end", "imagen_graph_launch", "imagen_graph_destroy",
     "imagen_event_create", "imagen_event_record", "imagen_event_elapsed_ms", "imagen_event_destroy",
-    "imagen_probe_copy", "imagen_probe_mfma",
+    "imagen_probe_copy", "imagen_probe_mfma", "imagen_probe_latency", "imagen_probe_launch_chain",
 ]
 
 
@@ -167,6 +168,8 @@ def load_library(path: str = LIB_PATH) -> ctypes.CDLL:
     lib.imagen_event_destroy.argtypes = [ctypes.c_void_p]
     lib.imagen_probe_copy.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
     lib.imagen_probe_mfma.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+    lib.imagen_probe_latency.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
+    lib.imagen_probe_launch_chain.argtypes = [ctypes.c_int, ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.POINTER(ctypes.c_float)]
     if lib.imagen_abi_version() != ENUMS["IMAGEN_ABI_VERSION"]:
         raise ImagenHipError("libimagen_hip.so ABI version does not match include/imagen_hip.h")
     for kind, st in OP_STRUCT.items():

@@ -117,3 +117,4 @@ int launch_temporal_attention(const ImagenTemporalAttentionParams* p, hipStream_
 int launch_act_prep(const ImagenActPrepParams* p, hipStream_t s);
 int launch_gca_tail(const ImagenGcaTailParams* p, hipStream_t s);
 int launch_step_slice(const ImagenStepSliceParams* p, hipStream_t s);
+int launch_rowchain(const ImagenRowchainParams* p, hipStream_t s);

@@ -36,6 +36,20 @@ __global__ __launch_bounds__(256) void probe_mfma_kernel(float* sink, int iters)
   if (s == 12345.678f) sink[0] = s;   // (keeps the loop alive; never true)
 }
 
+// one lane follows a chain of 128-byte nodes (word 0 of node i = the next node): every load depends on the one before it, so the time per
+// hop is the load-to-use latency of whichever level of the hierarchy the working set lives in
+__global__ __launch_bounds__(64) void probe_chase_kernel(const unsigned* __restrict__ nodes, int hops, unsigned* out) {
+  if (threadIdx.x != 0) return;
+  unsigned i = 0;
+  for (int h = 0; h < hops; ++h) i = __builtin_nontemporal_load(nodes + (size_t)i * 32);
+  out[0] = i;   // (keeps the chain alive)
+}
+
+// three distinct trivial kernels for the dependent-launch chain (a denoiser step never runs the same kernel twice in a row)
+__global__ __launch_bounds__(64) void probe_tick_a(unsigned* c) { if (threadIdx.x == 0) c[0] += 1; }
+__global__ __launch_bounds__(64) void probe_tick_b(unsigned* c) { if (threadIdx.x == 0) c[0] += 2; }
+__global__ __launch_bounds__(64) void probe_tick_c(unsigned* c) { if (threadIdx.x == 0) c[0] += 3; }
+
 struct Timer {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   bool ok = false;
@@ -85,4 +99,62 @@ extern "C" int imagen_probe_mfma(int iters, int reps, float* sink, imagen_stream
   const double flops = (double)grid * 4 /*waves*/ * (double)iters * 4 /*MFMAs*/ * 32768.0 * reps;   // 32x32x16: 2 * 32 * 32 * 16
   *tflops_out = ms > 0.f ? (float)(flops / (ms * 1e-3) / 1e12) : 0.f;
   return imagen_hip_status("probe_mfma");
+}
+
+// Dependent-load latency: `nodes` = a device array of n 128-byte nodes whose first words form ONE cycle through all of them (built by the
+// caller: a random permutation), `hops` dependent loads by one lane, HIP-event timed -> ns per hop.  The working set (n * 128 bytes) picks
+// the level: <= 2 MiB the XCD's L2, ~64-128 MiB the Infinity Cache, >= 1 GiB HBM.  The sampling path's small launches are chains of such
+// round trips: this is the box-to-box difference the copy / MFMA probes do not see.
+extern "C" int imagen_probe_latency(const void* nodes, int hops, void* out_word, imagen_stream_t stream, float* ns_per_hop) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  IMAGEN_CHECK(nodes && out_word && ns_per_hop && hops >= 1, "probe_latency: bad arguments");
+  Timer t;
+  IMAGEN_CHECK(t.ok, "probe_latency: hipEventCreate failed");
+  hipLaunchKernelGGL(probe_chase_kernel, dim3(1), dim3(64), 0, s, static_cast<const unsigned*>(nodes), hops, static_cast<unsigned*>(out_word));   // warm (fills the caches the set fits)
+  (void)hipEventRecord(t.e0, s);
+  hipLaunchKernelGGL(probe_chase_kernel, dim3(1), dim3(64), 0, s, static_cast<const unsigned*>(nodes), hops, static_cast<unsigned*>(out_word));
+  (void)hipEventRecord(t.e1, s);
+  if (hipEventSynchronize(t.e1) != hipSuccess) return imagen_hip_status("probe_latency");
+  float ms = 0.f;
+  (void)hipEventElapsedTime(&ms, t.e0, t.e1);
+  *ns_per_hop = (float)((double)ms * 1e6 / hops);
+  return imagen_hip_status("probe_latency");
+}
+
+// Dependent-launch cost inside a hipGraph: `n` one-wave kernels (three distinct symbols in rotation, each a read-modify-write of the same
+// word, so every launch depends on the one before it) captured once and replayed `reps` times -> us per launch.  The floor under every
+// small launch of the captured denoiser step.
+extern "C" int imagen_probe_launch_chain(int n, int reps, void* counter_word, imagen_stream_t stream, float* us_per_launch) {
+  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
+  IMAGEN_CHECK(counter_word && us_per_launch && n >= 1 && reps >= 1, "probe_launch_chain: bad arguments");
+  unsigned* c = static_cast<unsigned*>(counter_word);
+  void* exec = nullptr;
+  for (int k = 0; k < 3; ++k) {   // outside the capture first (module load)
+    hipLaunchKernelGGL(probe_tick_a, dim3(1), dim3(64), 0, s, c);
+    hipLaunchKernelGGL(probe_tick_b, dim3(1), dim3(64), 0, s, c);
+    hipLaunchKernelGGL(probe_tick_c, dim3(1), dim3(64), 0, s, c);
+  }
+  if (imagen_graph_begin(stream) != 0) return -1;
+  for (int i = 0; i < n; ++i) {
+    if (i % 3 == 0) hipLaunchKernelGGL(probe_tick_a, dim3(1), dim3(64), 0, s, c);
+    else if (i % 3 == 1) hipLaunchKernelGGL(probe_tick_b, dim3(1), dim3(64), 0, s, c);
+    else hipLaunchKernelGGL(probe_tick_c, dim3(1), dim3(64), 0, s, c);
+  }
+  if (imagen_graph_end(stream, &exec) != 0) return -1;
+  Timer t;
+  int rc = t.ok ? 0 : -1;
+  if (rc == 0) rc = imagen_graph_launch(exec, stream);   // warm replay
+  if (rc == 0) {
+    (void)hipEventRecord(t.e0, s);
+    for (int r = 0; r < reps && rc == 0; ++r) rc = imagen_graph_launch(exec, stream);
+    (void)hipEventRecord(t.e1, s);
+    if (hipEventSynchronize(t.e1) != hipSuccess) rc = imagen_hip_status("probe_launch_chain");
+  }
+  if (rc == 0) {
+    float ms = 0.f;
+    (void)hipEventElapsedTime(&ms, t.e0, t.e1);
+    *us_per_launch = (float)((double)ms * 1e3 / ((double)n * reps));
+  }
+  (void)imagen_graph_destroy(exec);
+  return rc;
 }

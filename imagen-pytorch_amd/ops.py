@@ -901,6 +901,77 @@ def ln_residual(plan: Plan, y: Act, g: torch.Tensor, out: Act, *, beta=None, res
     return p
 
 
+ROWCHAIN = int(_os.environ.get("IMAGEN_ROWCHAIN", "1"))   # A/B switch: the token chains of the <= 32^2 levels as one ROWCHAIN launch each (0: the launch-per-op plan)
+CHAIN_TILE64_MIN_ROWS = 16384    # 64-row tiles (every weight fragment feeds two MFMAs) once that still gives one workgroup per CU
+
+
+def rowchain_ok(C: int, N: int, heads: int, dh: int, *weights, hidden: Optional[int] = None) -> bool:
+    """Shapes the ROWCHAIN launcher takes (csrc/rowchain.hip): 8 heads x 64, C (and the FeedForward width) a power of two in 32 .. 256 (512),
+    32-row tiles inside one image, plain (unsplit, bias-free) 1x1 weights in 32-channel chunks."""
+    if not ROWCHAIN or dh != 64 or heads * dh != 512 or not (_pow2(C) and 32 <= C <= 256) or N % 32 != 0:
+        return False
+    if hidden is not None and not (_pow2(hidden) and 32 <= hidden <= 512):
+        return False
+    return all(w is not None and not w.split and w.bias is None and w.KH == 1 and w.KW == 1 and w.Cin % 32 == 0 and w.Cin_pad == w.Cin for w in weights)
+
+
+def _rowchain(plan: Plan, mode: int, x: Act, out: Act, rows_per_batch: int, label: str, keep: list, **f):
+    p = STRUCTS["ImagenRowchainParams"]()
+    p.mode = mode
+    assert x.ld * x.H * x.W == x.bs and out.ld * out.H * out.W == out.bs, f"{label}: dense rows"
+    p.x, p.ld_x, p.out, p.ld_out = x.ptr, x.ld, out.ptr, out.ld
+    p.rows, p.rows_per_batch = x.rows, rows_per_batch
+    p.eps = 1e-5
+    p.tile64 = int(x.rows >= CHAIN_TILE64_MIN_ROWS and rows_per_batch % 64 == 0)
+    for k, v in f.items():
+        setattr(p, k, v)
+    plan.add(p, label, [x.t, out.t] + keep)
+    return p
+
+
+def rowchain_ff(plan: Plan, o: Act, res: Act, out: Act, w_out: PackedWeight, g_out, w1: PackedWeight, g_ln0, w2: PackedWeight, g_ln1, *,
+                rows_per_batch: int, ssq_out: Optional[torch.Tensor] = None, label: str = ""):
+    """Attention out-projection -> LayerNorm + residual -> FeedForward (+ residual) of a TransformerBlock in one launch (ROWCHAIN mode FF):
+    replaces to_out IGEMM, LN_RESIDUAL, lin1 IGEMM (+ GELU), ROWSTAT, lin2 IGEMM."""
+    C, inner, hidden = out.C, o.C, w1.Cout
+    assert (w_out.Cin, w_out.Cout, w1.Cin, w2.Cin, w2.Cout) == (inner, C, C, hidden, C) and res.C == C and res.ld * res.H * res.W == res.bs
+    return _rowchain(plan, ENUMS["IMAGEN_CHAIN_FF"], o, out, rows_per_batch, label or "rowchain.ff",
+                     [res.t, w_out.w, w1.w, w2.w, g_out, g_ln0, g_ln1, ssq_out],
+                     res=res.ptr, ld_res=res.ld, w0=w_out.w.data_ptr(), w1=w1.w.data_ptr(), w2=w2.w.data_ptr(), g0=g_out.data_ptr(),
+                     g1=g_ln0.data_ptr(), g2=g_ln1.data_ptr(), ssq_out=ptr(ssq_out), C=C, inner=inner, hidden=hidden, heads=inner // 64,
+                     w_cout_pad0=w_out.Cout_pad, w_cout_pad1=w1.Cout_pad, w_cout_pad2=w2.Cout_pad)
+
+
+def rowchain_xattn(plan: Plan, x: Act, out: Act, wq: PackedWeight, g_norm, w_out: PackedWeight, g_out, khat: torch.Tensor, vt: torch.Tensor, *,
+                   heads: int, J: int, k_strides, vt_strides, q_scale: torch.Tensor, q_mult: float, rows_per_batch: int, ln_stats: Optional[tuple] = None,
+                   ssq_out: Optional[torch.Tensor] = None, label: str = ""):
+    """A whole cross-attention of a ResnetBlock in one launch (ROWCHAIN mode XATTN): LayerNorm -> to_q -> cosine-sim attention over the site's
+    K^ / V^T operand buffers -> to_out -> LayerNorm + residual; replaces ROWSTAT, to_q IGEMM, ATTENTION, to_out IGEMM, LN_RESIDUAL."""
+    C, inner = x.C, heads * 64
+    assert (wq.Cin, wq.Cout, w_out.Cin, w_out.Cout, out.C) == (C, inner, inner, C, C)
+    mu, rs = ln_stats if ln_stats is not None else (None, None)
+    return _rowchain(plan, ENUMS["IMAGEN_CHAIN_XATTN"], x, out, rows_per_batch, label or "rowchain.xattn",
+                     [wq.w, w_out.w, g_norm, g_out, khat, vt, q_scale, mu, rs, ssq_out],
+                     w0=wq.w.data_ptr(), w1=w_out.w.data_ptr(), g0=g_norm.data_ptr(), g1=g_out.data_ptr(), mu=ptr(mu), rs=ptr(rs),
+                     khat=khat.data_ptr(), vt=vt.data_ptr(), q_scale=q_scale.data_ptr(), q_mult=q_mult, ssq_out=ptr(ssq_out), C=C, inner=inner,
+                     heads=heads, J=J, k_bs=k_strides[0], k_hs=k_strides[1], k_rs=k_strides[2], vt_bs=vt_strides[0], vt_hs=vt_strides[1],
+                     vt_ds=vt_strides[2], w_cout_pad0=wq.Cout_pad, w_cout_pad1=w_out.Cout_pad)
+
+
+def rowchain_qkv(plan: Plan, x: Act, qkv: Act, wqkv: PackedWeight, g_norm, khat: torch.Tensor, vt: torch.Tensor, k_scale: torch.Tensor, *,
+                 heads: int, r0: int, k_strides, vt_strides, rows_per_batch: int, ln_stats: Optional[tuple] = None, label: str = ""):
+    """The front of a self-attention in one launch (ROWCHAIN mode QKV): LayerNorm -> q | k | v projection -> q rows, K^ rows and V^T columns
+    behind the site's conditioning rows; replaces (ROWSTAT,) qkv IGEMM, KV_PREP."""
+    C, inner = x.C, heads * 64
+    assert (wqkv.Cin, wqkv.Cout) == (C, inner + 128) and qkv.C >= inner
+    mu, rs = ln_stats if ln_stats is not None else (None, None)
+    return _rowchain(plan, ENUMS["IMAGEN_CHAIN_QKV"], x, qkv, rows_per_batch, label or "rowchain.qkv",
+                     [wqkv.w, g_norm, khat, vt, k_scale, mu, rs],
+                     w0=wqkv.w.data_ptr(), g0=g_norm.data_ptr(), mu=ptr(mu), rs=ptr(rs), khat=khat.data_ptr(), vt=vt.data_ptr(),
+                     k_scale=k_scale.data_ptr(), C=C, inner=inner, heads=heads, r0=r0, k_bs=k_strides[0], k_hs=k_strides[1], k_rs=k_strides[2],
+                     vt_bs=vt_strides[0], vt_hs=vt_strides[1], vt_ds=vt_strides[2], w_cout_pad0=wqkv.Cout_pad)
+
+
 def select_rows(plan: Plan, a: torch.Tensor, nul: torch.Tensor, mask: Optional[torch.Tensor], src: torch.Tensor, keep: torch.Tensor,
                 dst: torch.Tensor, *, R, L, C, label: str = ""):
     """dst[r,l,:] = keep[r] & mask[src[r],l] ? a[src[r],l,:] : nul[l,:]   (mask/keep uint8, src int32)."""

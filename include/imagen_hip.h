@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define IMAGEN_ABI_VERSION 7 /* 3: head_dim in the attention / QNORM / KV_PREP params; 4: DDPM_UPDATE x0_thr; 5: GCA_TAIL; 6: ACT_PREP self_stat, STEP_SLICE;
+#define IMAGEN_ABI_VERSION 8 /* 8: ROWCHAIN, the latency probes;  3: head_dim in the attention / QNORM / KV_PREP params; 4: DDPM_UPDATE x0_thr; 5: GCA_TAIL; 6: ACT_PREP self_stat, STEP_SLICE;
                                * 7: every launch carries sizeof(its params struct) (a stale mirror of a struct fails loudly), ImagenIgemmParams.dbg -> launcher_word, kernel families 6 and 7, ImagenAttentionParams.softmax_mode */
 
 typedef void* imagen_stream_t; /* hipStream_t */
@@ -65,7 +65,8 @@ enum ImagenOpKind {
   IMAGEN_OP_ACT_PREP = 26,     /* the IGEMM prologue as its own pass: norm -> affine -> SiLU of a (two-tensor) input, written as fp16 */
   IMAGEN_OP_GCA_TAIL = 27,     /* ResnetBlock tail in ONE launch: GlobalContext finalisation + h*gate + res (+ statistics, + the next Block's activated input) */
   IMAGEN_OP_STEP_SLICE = 28,   /* copy the current step's rows of up to four per-step tables (the timestep-only conditioning, computed for all steps at once) into the buffers the step's kernels read */
-  IMAGEN_OP_KIND_COUNT = 29
+  IMAGEN_OP_ROWCHAIN = 29,     /* a chain of row-local token layers (attention out-projection + LayerNorm + FeedForward | a whole cross-attention | LayerNorm + q/k/v projection + K^/V^T rows) in ONE launch */
+  IMAGEN_OP_KIND_COUNT = 30
 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -422,6 +423,43 @@ typedef struct ImagenMeanRowsParams {
 
 typedef struct ImagenMemset32Params { void* dst; uint32_t value; int32_t count; } ImagenMemset32Params;
 
+/* ROWCHAIN — the small-map execution unit of the token path (round 5).  On maps of <= 32^2 pixels the transformer / cross-attention layers
+ * of the denoiser are chains of launches that each take ~10 us for a few MFLOP per row: latency, not work.  Every layer below maps a token
+ * row to a token row (the one exception, the keys / values of a cross-attention, are constants of the image), so a tile of 32 | 64 rows of ONE
+ * image flows through the whole chain inside one workgroup — GEMM stages on the matrix pipe (weights straight from L2 into A fragments,
+ * rows from LDS), the LayerNorms / residuals as row passes over the LDS tile between them — with the SAME rounding points as the launches
+ * it replaces (fp16 wherever those stored fp16).  Rows are dense: row r at base + r * ld; rows_per_batch % tile == 0.
+ *   mode 1, FF   (ip.py:529-532, 1017, 972-980, 1018; replaces to_out IGEMM -> LN_RESIDUAL -> lin1 IGEMM -> ROWSTAT -> lin2 IGEMM):
+ *        x1  = fp16(LN(fp16(o W_out^T)) * g0 + res)                                    o = x [rows][inner] (the attention output)
+ *        hid = fp16(gelu(fp16((x1 - mean x1) * rstd x1 * g1) W1^T))                                        [rows][hidden]
+ *        out = fp16(fp16((hid - mean hid) * rstd hid * g2) W2^T + x1) ;  ssq_out[r] = sum_c out^2
+ *   mode 2, XATTN (ip.py:759-834 inside a ResnetBlock, 745-751; replaces ROWSTAT -> to_q IGEMM -> ATTENTION -> to_out IGEMM -> LN_RESIDUAL):
+ *        q   = fp16(fp16((x - mean x) * rstd x * g0) Wq^T)           [rows][heads * 64];  (mu, rs): the caller's statistics or computed here
+ *        o_h = fp16(softmax_j(q^_h . K^[b, h, j]) @ V[b, h])          q^_h = fp16(q_h / max(|q_h|, 1e-12) * q_scale * q_mult), j < J (ATTENTION's contract)
+ *        out = fp16(LN(fp16(o W_out^T)) * g1 + x) ;  ssq_out
+ *   mode 3, QKV  (ip.py:521-561; replaces (ROWSTAT ->) qkv IGEMM -> KV_PREP of the self-attention rows):
+ *        y   = fp16(fp16((x - mean x) * rstd x * g0) [Wq | Wkv]^T)    [rows][heads * 64 + 128];  out[r, : heads * 64] = q
+ *        K^[b, r0 + n, :] = fp16(k / max(|k|, 1e-12) * k_scale),  V^T[b, :, r0 + n] = v      (KV_PREP's contract, one shared k / v head)
+ * Weights: imagen_pack_igemm_weights() buffers of 1x1 layers with Cin % 32 == 0 (w_cout_pad* = their Cout_pad), bias-free.
+ * Launcher limits: heads * 64 == 512, C % 32 == 0, 32 <= C <= 256, hidden % 32 == 0, hidden <= 512; tile = 64 rows when `tile64`. */
+enum { IMAGEN_CHAIN_FF = 1, IMAGEN_CHAIN_XATTN = 2, IMAGEN_CHAIN_QKV = 3 };
+typedef struct ImagenRowchainParams {
+  const void* x; const void* res; void* out;
+  const void* w0; const void* w1; const void* w2;      /* FF: W_out, W1, W2;  XATTN: Wq, W_out;  QKV: [Wq | Wkv] */
+  const float* g0; const float* g1; const float* g2;   /* FF: to_out LN gain, FeedForward LN gains;  XATTN: norm gain, to_out LN gain;  QKV: norm gain */
+  const float* mu; const float* rs;                     /* XATTN / QKV: optional LayerNorm statistics of the x rows from their producer (both or neither) */
+  void* khat; void* vt;                                 /* XATTN: the site's K^ / V^T operand buffers (read);  QKV: the buffers to fill */
+  const float* q_scale; const float* k_scale;
+  float* ssq_out;
+  int32_t mode, rows, rows_per_batch, C, inner, hidden, heads, J;
+  int32_t ld_x, ld_res, ld_out;
+  int32_t k_bs, k_hs, k_rs, vt_bs, vt_hs, vt_ds;        /* operand buffer strides (elements), as ImagenAttentionParams / ImagenKvPrepParams */
+  int32_t r0;                                           /* QKV: first key row of the tile rows' keys (behind the context and null rows) */
+  int32_t w_cout_pad0, w_cout_pad1, w_cout_pad2;
+  int32_t tile64;                                       /* 1: 64-row tiles (rows_per_batch % 64 == 0): every weight fragment feeds two MFMAs */
+  float eps, q_mult;
+} ImagenRowchainParams;
+
 /* one entry of a plan: params_bytes = the caller's sizeof(params struct of `kind`) — checked against imagen_sizeof(kind) on every run, so a binding
  * built against another version of this header is refused instead of being read past its end */
 typedef struct ImagenOpRef { int32_t kind; int32_t params_bytes; const void* params; } ImagenOpRef;
@@ -478,6 +516,13 @@ int imagen_event_destroy(void* ev);
  * events on `stream` and synchronise it. */
 int imagen_probe_copy(void* dst, const void* src, size_t bytes, int reps, imagen_stream_t stream, float* gbs_out);
 int imagen_probe_mfma(int iters, int reps, float* sink, imagen_stream_t stream, float* tflops_out);
+/* Latency-side probes (round 5: the sampling path is dependent-latency-bound, and boxes that agree on the two throughput probes above differ
+ * by 20 % on it).  imagen_probe_latency: one lane follows `hops` links of a chain of 128-byte nodes (word 0 of node i = index of the next node; the
+ * caller builds ONE random cycle over all nodes) -> ns per dependent load; the working set picks L2 / Infinity Cache / HBM.
+ * imagen_probe_launch_chain: `n` dependent one-wave launches (three kernel symbols in rotation) captured into a hipGraph, replayed `reps`
+ * times -> us per dependent launch inside a graph.  Both time themselves with HIP events on `stream` and synchronise it. */
+int imagen_probe_latency(const void* nodes, int hops, void* out_word, imagen_stream_t stream, float* ns_per_hop);
+int imagen_probe_launch_chain(int n, int reps, void* counter_word, imagen_stream_t stream, float* us_per_launch);
 
 #ifdef __cplusplus
 }
