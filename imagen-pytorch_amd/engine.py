@@ -598,11 +598,8 @@ class UnetEngine:
         heads, dh = ca.heads, ca.dim_head
         inner = heads * dh
         tok = h.tokens()
-        mu, rs = self.f32buf(R * N), self.f32buf(R * N)
-        ops.rowstat(plan, tok, mode=1, rs=rs, mu=mu, eps=1e-5, label=name + ".norm")
-        q = self.new(R, 1, N, inner)
         wq = W.conv(name + ".to_q", ca.to_q, split=SPLIT_1X1 and self._split_small(C, 1, inner, R * N))
-        ops.igemm(plan, tok, wq, q, mu=mu, rs=rs, pa=W.f32(name + ".norm.g", lambda: _pad_vec(ca.norm.g, wq.Cin_pad)), label=name + ".to_q")
+        wo = W.conv(name + ".to_out", ca.to_out[0], split=SPLIT_1X1 and self._split_small(inner, 1, C, R * N))
         J = self.NT + 1
         Jp = ops._round_up(J, 32)
         khat = torch.zeros(R, heads, Jp, dh, dtype=torch.float16, device=self.dev)
@@ -610,51 +607,73 @@ class UnetEngine:
         site = dict(kind="cross", name=name, mod=ca, khat=khat, vt=vt, heads=heads, Jp=Jp, dh=dh,
                     k_strides=(heads * Jp * dh, Jp * dh, dh), vt_strides=(heads * dh * Jp, dh * Jp, Jp))
         self.attn_sites.append(site)
+        out = self.new(R, h.H, h.W, C)
+        out.ssq = self.f32buf(R * N)
+        g_norm = W.f32(name + ".norm.g", lambda: _pad_vec(ca.norm.g, wq.Cin_pad))
+        g_out = W.f32(name + ".out_g", lambda: ca.to_out[1].g)
+        q_scale = W.f32(name + ".q_scale", lambda: ca.q_scale)
+        if ops.rowchain_ok(C, N, heads, dh, wq, wo) and h.ld == C:
+            # the whole cross-attention as ONE launch (ROWCHAIN mode XATTN): its rows only meet constants of their image
+            ops.rowchain_xattn(plan, tok, out.tokens(), wq, g_norm, wo, g_out, khat, vt, heads=heads, J=J, k_strides=site["k_strides"],
+                               vt_strides=site["vt_strides"], q_scale=q_scale, q_mult=SIM_SCALE * LOG2E, rows_per_batch=N, ssq_out=out.ssq,
+                               label=name + ".chain")
+            return out
+        mu, rs = self.f32buf(R * N), self.f32buf(R * N)
+        ops.rowstat(plan, tok, mode=1, rs=rs, mu=mu, eps=1e-5, label=name + ".norm")
+        q = self.new(R, 1, N, inner)
+        ops.igemm(plan, tok, wq, q, mu=mu, rs=rs, pa=g_norm, label=name + ".to_q")
         o = self.new(R, 1, N, inner)
         ops.attention(plan, q.t, khat, vt, o.t, B=R, heads=heads, rows=N, J=J, q_strides=(N * inner, dh, inner),
                       k_strides=site["k_strides"], vt_strides=site["vt_strides"], o_strides=(N * inner, dh, inner),
-                      q_scale=W.f32(name + ".q_scale", lambda: ca.q_scale), q_mult=SIM_SCALE * LOG2E, label=name + ".attn", head_dim=dh,
+                      q_scale=q_scale, q_mult=SIM_SCALE * LOG2E, label=name + ".attn", head_dim=dh,
                       logit_bound=ops.attention_logit_bound(ca.q_scale, ca.k_scale, SIM_SCALE * LOG2E))
         y = self.new(R, 1, N, C)
-        ops.igemm(plan, o, W.conv(name + ".to_out", ca.to_out[0], split=SPLIT_1X1 and self._split_small(inner, 1, C, R * N)), y, label=name + ".to_out")
-        out = self.new(R, h.H, h.W, C)
-        out.ssq = self.f32buf(R * N)
-        ops.ln_residual(plan, y, W.f32(name + ".out_g", lambda: ca.to_out[1].g), out.tokens(), res=tok, eps=1e-5, ssq_out=out.ssq,
-                        label=name + ".out_norm")
+        ops.igemm(plan, o, wo, y, label=name + ".to_out")
+        ops.ln_residual(plan, y, g_out, out.tokens(), res=tok, eps=1e-5, ssq_out=out.ssq, label=name + ".out_norm")
         return out
 
     # ---- TransformerBlock (ip.py:992-1022): depth x [multi-query self attention + FeedForward]
     def _transformer(self, plan, x: Act, tb: TransformerBlockP, name: str, with_context: bool) -> Act:
-        R = self.R
+        R, W = self.R, self.W
         N, C = x.H * x.W, x.C
         cur = x
         for d, (attn, ff) in enumerate(tb.layers):
             nm = f"{name}.layers.{d}"
             # LayerNorm statistics of the attention input from the launch that produced it (a fused ResnetBlock tail), where there is one
-            x1, st = self._self_attn(plan, cur.tokens(), attn, nm, with_context, ln_stats=ops.request_ln_stats(cur) if LN_STATS_FUSED else None,
-                                     want_stats=True)
-            ffo = self._feed_forward(plan, x1, ff, nm + ".ff", ln_stats=st, split=SPLIT_1X1 and self._split_small(2 * C, 1, C, R * N))
+            stats_in = ops.request_ln_stats(cur) if LN_STATS_FUSED else None
+            hidden = ff[1].weight.shape[0]
+            heads, dh = attn.heads, attn.dim_head
+            inner = heads * dh
+            w_out = W.conv(nm + ".to_out", attn.to_out[0], split=SPLIT_1X1 and self._split_small(inner, 1, C, R * N))
+            split_ff = SPLIT_1X1 and self._split_small(2 * C, 1, C, R * N)
+            w1, w2 = W.conv(nm + ".ff.w1", ff[1], split=split_ff), W.conv(nm + ".ff.w2", ff[4], split=split_ff)
+            if ops.rowchain_ok(C, N, heads, dh, w_out, w1, w2, hidden=hidden) and cur.ld == C:
+                # attention out-projection -> LayerNorm + residual -> FeedForward as ONE launch behind the attention (ROWCHAIN mode FF)
+                o = self._self_attn(plan, cur.tokens(), attn, nm, with_context, ln_stats=stats_in, stop_at_attention=True)
+                out = self.new(R, 1, N, C)
+                out.ssq = self.f32buf(R * N)
+                ops.rowchain_ff(plan, o, cur.tokens(), out, w_out, W.f32(nm + ".out_g", lambda: attn.to_out[1].g), w1,
+                                W.f32(nm + ".ff.g0", lambda: _pad_vec(ff[0].g, w1.Cin_pad)), w2,
+                                W.f32(nm + ".ff.g1", lambda: _pad_vec(ff[3].g, w2.Cin_pad)), rows_per_batch=N, ssq_out=out.ssq, label=nm + ".ff.chain")
+                cur = Act(out.t, R, x.H, x.W, C, C, N * C, ssq=out.ssq)
+                continue
+            x1, st = self._self_attn(plan, cur.tokens(), attn, nm, with_context, ln_stats=stats_in, want_stats=True)
+            ffo = self._feed_forward(plan, x1, ff, nm + ".ff", ln_stats=st, split=split_ff)
             cur = Act(ffo.t, R, x.H, x.W, C, C, N * C, ssq=ffo.ssq)
         return cur
 
-    def _self_attn(self, plan, tok: Act, attn, nm: str, with_context: bool, ln_stats: Optional[tuple] = None, want_stats: bool = False):
+    def _self_attn(self, plan, tok: Act, attn, nm: str, with_context: bool, ln_stats: Optional[tuple] = None, want_stats: bool = False,
+                   stop_at_attention: bool = False):
         """attn(tok) + tok for the (R, 1, N, C) token view `tok` (ip.py:502-591, 1017): LayerNorm -> q | k | v in one GEMM ->
         K^/V^T rows behind the conditioning and null rows -> flash attention -> to_out -> LayerNorm + residual."""
         W, R = self.W, self.R
         N, C = tok.H * tok.W, tok.C
         heads, dh = attn.heads, attn.dim_head
         inner = heads * dh
-        if ln_stats is not None:
-            mu, rs = ln_stats
-        else:
-            mu, rs = self.f32buf(R * N), self.f32buf(R * N)
-            ops.rowstat(plan, tok, mode=1, rs=rs, mu=mu, eps=1e-5, label=nm + ".norm")
         # q | k | v from ONE GEMM (to_q and to_kv are both bias-free on the same normalised input, ip.py:539)
         wqkv = W.raw(nm + ".qkv", torch.cat((attn.to_q.weight.detach().float(), attn.to_kv.weight.detach().float())), None,
                       split=SPLIT_1X1 and self._split_small(C, 1, inner + 2 * dh, R * N))
         qkv = self.new(R, 1, N, inner + 2 * dh)
-        ops.igemm(plan, tok, wqkv, qkv, mu=mu, rs=rs, pa=W.f32(nm + ".norm.g", lambda: _pad_vec(attn.norm.g, wqkv.Cin_pad)),
-                  label=nm + ".qkv")
         ld = inner + 2 * dh
         n_ctx = self.NT if (with_context and attn.to_context is not None) else 0
         J = n_ctx + 1 + N
@@ -664,14 +683,29 @@ class UnetEngine:
         k_strides, vt_strides = (Jp * dh, 0, dh), (dh * Jp, 0, Jp)
         site = dict(kind="self", name=nm, mod=attn, khat=khat, vt=vt, heads=1, Jp=Jp, n_ctx=n_ctx, dh=dh, k_strides=k_strides, vt_strides=vt_strides)
         self.attn_sites.append(site)
-        ops.kv_prep(plan, qkv.t, qkv.t, W.f32(nm + ".k_scale", lambda: attn.k_scale), khat, vt, B=R, heads=1, rows=N, r0=n_ctx + 1,
-                    src_strides=(N * ld, ld, 0), k_strides=k_strides, vt_strides=vt_strides, k_off=inner, v_off=inner + dh,
-                    label=nm + ".kv_self", head_dim=dh)
+        g_norm = W.f32(nm + ".norm.g", lambda: _pad_vec(attn.norm.g, wqkv.Cin_pad))
+        k_scale = W.f32(nm + ".k_scale", lambda: attn.k_scale)
+        if ops.rowchain_ok(C, N, heads, dh, wqkv) and tok.ld == C:
+            # LayerNorm -> q | k | v -> q rows, K^ rows, V^T columns as ONE launch (ROWCHAIN mode QKV); the statistics its producer emitted, if any
+            ops.rowchain_qkv(plan, tok, qkv, wqkv, g_norm, khat, vt, k_scale, heads=heads, r0=n_ctx + 1, k_strides=k_strides, vt_strides=vt_strides,
+                             rows_per_batch=N, ln_stats=ln_stats, label=nm + ".qkv.chain")
+        else:
+            if ln_stats is not None:
+                mu, rs = ln_stats
+            else:
+                mu, rs = self.f32buf(R * N), self.f32buf(R * N)
+                ops.rowstat(plan, tok, mode=1, rs=rs, mu=mu, eps=1e-5, label=nm + ".norm")
+            ops.igemm(plan, tok, wqkv, qkv, mu=mu, rs=rs, pa=g_norm, label=nm + ".qkv")
+            ops.kv_prep(plan, qkv.t, qkv.t, k_scale, khat, vt, B=R, heads=1, rows=N, r0=n_ctx + 1,
+                        src_strides=(N * ld, ld, 0), k_strides=k_strides, vt_strides=vt_strides, k_off=inner, v_off=inner + dh,
+                        label=nm + ".kv_self", head_dim=dh)
         o = self.new(R, 1, N, inner)
         ops.attention(plan, qkv.t, khat, vt, o.t, B=R, heads=heads, rows=N, J=J, q_strides=(N * ld, dh, ld), k_strides=k_strides,
                       vt_strides=vt_strides, o_strides=(N * inner, dh, inner), q_scale=W.f32(nm + ".q_scale", lambda: attn.q_scale),
                       q_mult=SIM_SCALE * LOG2E, label=nm + ".attn", head_dim=dh,
                       logit_bound=ops.attention_logit_bound(attn.q_scale, attn.k_scale, SIM_SCALE * LOG2E))
+        if stop_at_attention:       # (the caller runs the out-projection, the LayerNorm + residual and the FeedForward as one ROWCHAIN launch)
+            return o
         y = self.new(R, 1, N, C)
         ops.igemm(plan, o, W.conv(nm + ".to_out", attn.to_out[0], split=SPLIT_1X1 and self._split_small(inner, 1, C, R * N)), y, label=nm + ".to_out")
         x1 = self.new(R, 1, N, C)

@@ -375,6 +375,55 @@ class Interpreter:
         o = torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), v)
         m.strided(p.o, f16, (p.B, p.heads, p.rows, D), (p.o_bs, p.o_hs, p.o_rs, 1)).copy_(o.half())
 
+    # ------------------------------------------------------------------------------------------------ ROWCHAIN
+    def rowchain(self, p):
+        """include/imagen_hip.h, ImagenRowchainParams: the chain's layers in fp32 with fp16 roundings where the contract states them."""
+        m = self.mem
+        rows, C, inner = p.rows, p.C, p.inner
+        r16 = lambda t: t.half().float()
+
+        def ln(t, g, n):
+            return (t - t.mean(-1, keepdim=True)) * torch.rsqrt(t.var(-1, unbiased=False, keepdim=True) + p.eps) * m.view(g, f32)[:n]
+
+        def lin(t, w, cin, cout):
+            wref, bias = ops.REFERENCE_WEIGHTS[w]
+            assert bias is None and tuple(wref.shape[:2]) == (cout, cin), (wref.shape, cout, cin)
+            return t @ wref[:, :, 0, 0].t()
+
+        x = m.strided(p.x, f16, (rows, inner if p.mode == K["IMAGEN_CHAIN_FF"] else C), (p.ld_x, 1)).float()
+        B, n = rows // p.rows_per_batch, p.rows_per_batch
+        if p.mode == K["IMAGEN_CHAIN_FF"]:
+            res = m.strided(p.res, f16, (rows, C), (p.ld_res, 1)).float()
+            x1 = r16(ln(r16(lin(x, p.w0, inner, C)), p.g0, C) + res)
+            hid = r16(F.gelu(lin(r16(ln(x1, p.g1, C)), p.w1, C, p.hidden)))
+            out = (lin(r16(ln(hid, p.g2, p.hidden)), p.w2, p.hidden, C) + x1).half()
+        else:
+            if p.mu:
+                a = (x - m.view(p.mu, f32)[:rows, None]) * m.view(p.rs, f32)[:rows, None] * m.view(p.g0, f32)[:C]
+            else:
+                a = ln(x, p.g0, C)
+            a = r16(a)
+            if p.mode == K["IMAGEN_CHAIN_XATTN"]:
+                H = p.heads
+                q = r16(lin(a, p.w0, C, inner)).reshape(B, n, H, 64).permute(0, 2, 1, 3)
+                qh = r16(F.normalize(q, dim=-1, eps=1e-12) * m.view(p.q_scale, f32)[:64] * p.q_mult)
+                k = m.strided(p.khat, f16, (B, H, p.J, 64), (p.k_bs, p.k_hs, p.k_rs, 1)).float()
+                v = m.strided(p.vt, f16, (B, H, p.J, 64), (p.vt_bs, p.vt_hs, 1, p.vt_ds)).float()
+                sim = torch.einsum("bhid,bhjd->bhij", qh, k) * math.log(2.0)
+                o = r16(torch.einsum("bhij,bhjd->bhid", sim.softmax(-1), v)).permute(0, 2, 1, 3).reshape(rows, inner)
+                res = m.strided(p.res, f16, (rows, C), (p.ld_res, 1)).float() if p.res else x
+                out = (ln(r16(lin(o, p.w1, inner, C)), p.g1, C) + res).half()
+            else:
+                y = r16(lin(a, p.w0, C, inner + 128))
+                m.strided(p.out, f16, (rows, inner), (p.ld_out, 1)).copy_(y[:, :inner].half())
+                kk = (F.normalize(y[:, inner:inner + 64], dim=-1, eps=1e-12) * m.view(p.k_scale, f32)[:64]).half().reshape(B, n, 64)
+                m.strided(p.khat + 2 * p.r0 * p.k_rs, f16, (B, n, 64), (p.k_bs, p.k_rs, 1)).copy_(kk)
+                m.strided(p.vt + 2 * p.r0, f16, (B, n, 64), (p.vt_bs, 1, p.vt_ds)).copy_(y[:, inner + 64:].half().reshape(B, n, 64))
+                return
+        m.strided(p.out, f16, (rows, C), (p.ld_out, 1)).copy_(out)
+        if p.ssq_out:
+            m.view(p.ssq_out, f32)[:rows].copy_((out.float() ** 2).sum(-1))
+
     # ------------------------------------------------------------------------------------------------ GlobalContext
     def _gca_gate(self, ctx, w1t, b1, w2t, b2, C, hidden):
         m = self.mem
@@ -537,4 +586,5 @@ Interpreter.DISPATCH = {
     K["IMAGEN_OP_TEMPORAL_PEG"]: Interpreter.temporal_peg, K["IMAGEN_OP_TEMPORAL_ATTENTION"]: Interpreter.temporal_attention,
     K["IMAGEN_OP_ACT_PREP"]: Interpreter.act_prep,
     K["IMAGEN_OP_STEP_SLICE"]: Interpreter.step_slice,
+    K["IMAGEN_OP_ROWCHAIN"]: Interpreter.rowchain,
 }

@@ -310,7 +310,7 @@ def test_video_sample_options_vs_reference_fixture(tag):
 
 def test_unet3d_cond_images_vs_oracle():
     """Unet3D(cond_images_channels=5).forward_with_cond_scale on the GPU against the oracle (iv.py:1722-1731): the static second input of the
-    init conv on every frame (written after the round's GPU budget: gated until it has met hardware; CPU: tests/test_plan_interp.py)."""
+    init conv on every frame (green on MI355X since round 3's call A; CPU: tests/test_plan_interp.py)."""
     from imagen_pytorch_amd import Unet3D
     from oracle import unet3d_oracle as u3
 
