@@ -125,8 +125,11 @@ extern "C" int imagen_probe_latency(const void* nodes, int hops, void* out_word,
 // word, so every launch depends on the one before it) captured once and replayed `reps` times -> us per launch.  The floor under every
 // small launch of the captured denoiser step.
 extern "C" int imagen_probe_launch_chain(int n, int reps, void* counter_word, imagen_stream_t stream, float* us_per_launch) {
-  hipStream_t s = reinterpret_cast<hipStream_t>(stream);
   IMAGEN_CHECK(counter_word && us_per_launch && n >= 1 && reps >= 1, "probe_launch_chain: bad arguments");
+  (void)hipStreamSynchronize(reinterpret_cast<hipStream_t>(stream));
+  hipStream_t s = nullptr;   // a private stream: the caller's may be the legacy default stream, which cannot be captured
+  if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) return imagen_hip_status("probe_launch_chain: hipStreamCreate");
+  imagen_stream_t ps = reinterpret_cast<imagen_stream_t>(s);
   unsigned* c = static_cast<unsigned*>(counter_word);
   void* exec = nullptr;
   for (int k = 0; k < 3; ++k) {   // outside the capture first (module load)
@@ -134,19 +137,21 @@ extern "C" int imagen_probe_launch_chain(int n, int reps, void* counter_word, im
     hipLaunchKernelGGL(probe_tick_b, dim3(1), dim3(64), 0, s, c);
     hipLaunchKernelGGL(probe_tick_c, dim3(1), dim3(64), 0, s, c);
   }
-  if (imagen_graph_begin(stream) != 0) return -1;
-  for (int i = 0; i < n; ++i) {
-    if (i % 3 == 0) hipLaunchKernelGGL(probe_tick_a, dim3(1), dim3(64), 0, s, c);
-    else if (i % 3 == 1) hipLaunchKernelGGL(probe_tick_b, dim3(1), dim3(64), 0, s, c);
-    else hipLaunchKernelGGL(probe_tick_c, dim3(1), dim3(64), 0, s, c);
+  int rc = imagen_graph_begin(ps);
+  if (rc == 0) {
+    for (int i = 0; i < n; ++i) {
+      if (i % 3 == 0) hipLaunchKernelGGL(probe_tick_a, dim3(1), dim3(64), 0, s, c);
+      else if (i % 3 == 1) hipLaunchKernelGGL(probe_tick_b, dim3(1), dim3(64), 0, s, c);
+      else hipLaunchKernelGGL(probe_tick_c, dim3(1), dim3(64), 0, s, c);
+    }
+    rc = imagen_graph_end(ps, &exec);
   }
-  if (imagen_graph_end(stream, &exec) != 0) return -1;
   Timer t;
-  int rc = t.ok ? 0 : -1;
-  if (rc == 0) rc = imagen_graph_launch(exec, stream);   // warm replay
+  if (rc == 0 && !t.ok) rc = -1;
+  if (rc == 0) rc = imagen_graph_launch(exec, ps);   // warm replay
   if (rc == 0) {
     (void)hipEventRecord(t.e0, s);
-    for (int r = 0; r < reps && rc == 0; ++r) rc = imagen_graph_launch(exec, stream);
+    for (int r = 0; r < reps && rc == 0; ++r) rc = imagen_graph_launch(exec, ps);
     (void)hipEventRecord(t.e1, s);
     if (hipEventSynchronize(t.e1) != hipSuccess) rc = imagen_hip_status("probe_launch_chain");
   }
@@ -155,6 +160,8 @@ extern "C" int imagen_probe_launch_chain(int n, int reps, void* counter_word, im
     (void)hipEventElapsedTime(&ms, t.e0, t.e1);
     *us_per_launch = (float)((double)ms * 1e3 / ((double)n * reps));
   }
-  (void)imagen_graph_destroy(exec);
+  if (exec) (void)imagen_graph_destroy(exec);
+  (void)hipStreamSynchronize(s);
+  (void)hipStreamDestroy(s);
   return rc;
 }

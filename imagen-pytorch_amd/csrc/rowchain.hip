@@ -18,6 +18,7 @@
 //     registers ARE the B fragments of S^T = K^ . Q^T in a permuted dim order (attention.hip's P trick applied to Q), K^ and V^T
 //     fragments are 8-byte loads from the site's operand buffers (16 KB per image and head, L2), online softmax as attention_kernel.
 // The rounding points are those of the launches it replaces (fp16 where they stored fp16), so parity is that of the unfused path.
+#include <cstdio>
 #include "common.h"
 
 namespace {
@@ -96,52 +97,82 @@ __device__ __forceinline__ void acc_zero(f32x16 (*acc)[RB]) {
       for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
 }
 
-// acc[t][j] += W[tiles tile0 + t][k steps s0 .. s1) . X[rows of row block j]: weights four steps ahead in a register ring (every load
-// unconditional, past-the-end steps re-read the last one), rows from the LDS tile xs.
-template <int NT, int RB>
-__device__ __forceinline__ void gemm_rows(f32x16 (*acc)[RB], const f16* __restrict__ w, int cout_pad, int tile0, int s0, int s1,
-                                          const char* xs, int pitch, int lane) {
-  const int n = s1 - s0;
+// ---- the weight stream of a GEMM stage.  A wave's A fragments are 16-byte loads from the packed weight buffer; sixteen of them (16 K
+// steps of one cout tile, or 8 of two) are kept in flight in a register ring.  The weights are cold when a launch starts (last touched a
+// whole denoiser step ago: Infinity Cache / HBM latency, ~0.5 us a round trip), so the ring depth IS the stage's speed on the small
+// grids of the 8^2 / 16^2 levels (round-5 call A: four steps ahead made a 32-step stage 8 dependent round trips), and the ring of the
+// NEXT stage is requested before the current stage's row pass and barriers (fill and run are separate calls).
+// Addressing: a wave-uniform byte offset (cout tile, K step: scalar registers) + ONE 32-bit per-lane offset that never changes — the loads
+// then take their base from SGPRs and the whole ring costs a single address VGPR (64-bit per-load addresses cost 2 x 16 of them).
+struct WeightStream {
+  const char* base;      // packed weight buffer (kernel argument: uniform)
+  unsigned lane_off;     // (half * cout_pad + l31) * 16 bytes
+  size_t tile_off;       // tile0 * 512 bytes (uniform)
+  size_t step_bytes;     // 2 * cout_pad * 16 bytes per K = 16 step (uniform)
+};
+
+__device__ __forceinline__ WeightStream weight_stream(const void* w, int cout_pad, int tile0, int lane) {
+  WeightStream ws;
+  ws.base = reinterpret_cast<const char*>(w);
+  ws.lane_off = ((unsigned)(lane >> 5) * (unsigned)cout_pad + (unsigned)(lane & 31)) * 16u;
+  ws.tile_off = (size_t)tile0 * 512;
+  ws.step_bytes = (size_t)cout_pad * 32;
+  return ws;
+}
+
+__device__ __forceinline__ f16x8 weight_frag(const WeightStream& ws, int s, int t) {
+  const char* ub = ws.base + (ws.tile_off + (size_t)s * ws.step_bytes + (size_t)t * 512);   // uniform
+  return *reinterpret_cast<const f16x8*>(ub + ws.lane_off);
+}
+
+template <int NT>
+__device__ __forceinline__ void ring_fill(f16x8 (&ring)[16], const WeightStream& ws, int s0, int n) {
+  constexpr int D = 16 / NT;
   if (n <= 0) return;
-  const int half = lane >> 5, l31 = lane & 31;
-  const f16* wl = w + ((size_t)half * cout_pad + (size_t)tile0 * 32 + l31) * 8;
-  const size_t step = (size_t)2 * cout_pad * 8;
-  const char* xl = xs + l31 * pitch + 16 * half;
-  const int n4 = n & ~3;
-  if (n4 > 0) {
-    f16x8 a[4][NT];
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < D; ++i) {
+    const int s = s0 + (i < n ? i : n - 1);
 #pragma unroll
-      for (int t = 0; t < NT; ++t) a[i][t] = *reinterpret_cast<const f16x8*>(wl + (size_t)(s0 + i) * step + t * 256);
-    for (int sb = 0; sb < n4; sb += 4) {   // straight-line body: four steps, each followed by the request of the step four ahead
+    for (int t = 0; t < NT; ++t) ring[i * NT + t] = weight_frag(ws, s, t);
+  }
+}
+
+// acc[t][j] += W[cout tiles tile0 + t][K steps s0 .. s0 + n) . X[rows of row block j]: the ring holds steps s0 .. s0 + D - 1 on entry
+template <int NT, int RB>
+__device__ __forceinline__ void gemm_run(f32x16 (*acc)[RB], f16x8 (&ring)[16], const WeightStream& ws, int s0, int n, const char* xs, int pitch,
+                                         int lane) {
+  constexpr int D = 16 / NT;
+  if (n <= 0) return;
+  const char* xl = xs + (lane & 31) * pitch + 16 * (lane >> 5);
+  int sb = 0;
+  for (; sb + D < n; sb += D) {   // straight-line body: D steps, each followed by the request of the step D ahead (clamped to the last one)
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int s = sb + i;
-        f16x8 b[RB];
+    for (int i = 0; i < D; ++i) {
+      const int s = sb + i;
+      f16x8 b[RB];
 #pragma unroll
-        for (int j = 0; j < RB; ++j) b[j] = *reinterpret_cast<const f16x8*>(xl + (size_t)j * 32 * pitch + (s0 + s) * 32);
+      for (int j = 0; j < RB; ++j) b[j] = *reinterpret_cast<const f16x8*>(xl + (size_t)j * 32 * pitch + (s0 + s) * 32);
 #pragma unroll
-        for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-          for (int j = 0; j < RB; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[i][t], b[j], acc[t][j], 0, 0, 0);
-        const int sn = s0 + (s + 4 < n ? s + 4 : n - 1);
+        for (int j = 0; j < RB; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[i * NT + t], b[j], acc[t][j], 0, 0, 0);
+      const int sn = s0 + (s + D < n ? s + D : n - 1);
 #pragma unroll
-        for (int t = 0; t < NT; ++t) a[i][t] = *reinterpret_cast<const f16x8*>(wl + (size_t)sn * step + t * 256);
-        __builtin_amdgcn_sched_barrier(0);   // pins the request here (the scheduler otherwise sinks look-ahead loads to their use)
-      }
+      for (int t = 0; t < NT; ++t) ring[i * NT + t] = weight_frag(ws, sn, t);
+      __builtin_amdgcn_sched_barrier(0);   // pins the request here (the scheduler otherwise sinks look-ahead loads to their use)
     }
   }
-  for (int s = n4; s < n; ++s) {           // 1 - 3 remaining steps (the K-split parts of the narrowest layers)
-    f16x8 a[NT], b[RB];
 #pragma unroll
-    for (int t = 0; t < NT; ++t) a[t] = *reinterpret_cast<const f16x8*>(wl + (size_t)(s0 + s) * step + t * 256);
+  for (int i = 0; i < D; ++i) {   // the last (up to D) steps are in the ring: no further requests
+    if (sb + i < n) {
+      f16x8 b[RB];
 #pragma unroll
-    for (int j = 0; j < RB; ++j) b[j] = *reinterpret_cast<const f16x8*>(xl + (size_t)j * 32 * pitch + (s0 + s) * 32);
+      for (int j = 0; j < RB; ++j) b[j] = *reinterpret_cast<const f16x8*>(xl + (size_t)j * 32 * pitch + (s0 + sb + i) * 32);
 #pragma unroll
-    for (int t = 0; t < NT; ++t)
+      for (int t = 0; t < NT; ++t)
 #pragma unroll
-      for (int j = 0; j < RB; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(a[t], b[j], acc[t][j], 0, 0, 0);
+        for (int j = 0; j < RB; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[i * NT + t], b[j], acc[t][j], 0, 0, 0);
+    }
   }
 }
 
@@ -225,82 +256,115 @@ __device__ __forceinline__ void row_ln_stats(const char* row, int C, int li, flo
   rstd = rsqrtf(row_sum<LPR>(q) / (float)C + eps);
 }
 
-// x rows (global) -> fp16((x - mean) * rstd * g) into the LDS tile: the LayerNorm prologue of a GEMM (IGEMM's (x - mu) * rs * pa)
+// this thread's pieces (8 channels each) of row r = tid / LPR of a [rows][C] global tensor, C <= 256: pieces li, li + LPR, ... (at most PMAX)
 template <int RB>
-__device__ __forceinline__ void load_ln_rows(const ImagenRowchainParams& p, int row0, char* dst, int pitch, int tid) {
-  constexpr int LPR = kThreads / (32 * RB);
+struct RowPieces {
+  static constexpr int LPR = kThreads / (32 * RB);
+  static constexpr int PMAX = 32 / LPR;
+  f16x8 v[PMAX];
+};
+
+template <int RB>
+__device__ __forceinline__ void load_row_pieces(RowPieces<RB>& rp, const void* base, int ld, int row, int C, int li) {
+  constexpr int LPR = RowPieces<RB>::LPR;
+  const f16* x = reinterpret_cast<const f16*>(base) + (size_t)row * ld;
+  const int np = C >> 3;
+#pragma unroll
+  for (int k = 0; k < RowPieces<RB>::PMAX; ++k) {
+    const int g = li + k * LPR;
+    rp.v[k] = *reinterpret_cast<const f16x8*>(x + (g < np ? g : 0) * 8);   // (unconditional: a piece past the row re-reads piece 0)
+  }
+}
+
+// the x rows (already in registers) -> fp16((x - mean) * rstd * g) into the LDS tile: the LayerNorm prologue of a GEMM (IGEMM's (x - mu) * rs * pa)
+template <int RB>
+__device__ __forceinline__ void ln_rows_to_lds(const ImagenRowchainParams& p, const RowPieces<RB>& rp, int row0, char* dst, int pitch, int tid) {
+  constexpr int LPR = RowPieces<RB>::LPR, PMAX = RowPieces<RB>::PMAX;
   const int r = tid / LPR, li = tid % LPR;
   const int C = p.C, np = C >> 3;
-  const f16* x = reinterpret_cast<const f16*>(p.x) + (size_t)(row0 + r) * p.ld_x;
   float mean, rstd;
   if (p.mu) {
     mean = p.mu[row0 + r];
     rstd = p.rs[row0 + r];
   } else {
     float s = 0.f;
-    for (int g = li; g < np; g += LPR) {
-      const f16x8 v = *reinterpret_cast<const f16x8*>(x + g * 8);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) s += (float)v[e];
-    }
+    for (int k = 0; k < PMAX; ++k)
+      if (li + k * LPR < np)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) s += (float)rp.v[k][e];
     mean = row_sum<LPR>(s) / (float)C;
     float q = 0.f;
-    for (int g = li; g < np; g += LPR) {
-      const f16x8 v = *reinterpret_cast<const f16x8*>(x + g * 8);
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float d = (float)v[e] - mean;
-        q += d * d;
-      }
-    }
+    for (int k = 0; k < PMAX; ++k)
+      if (li + k * LPR < np)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = (float)rp.v[k][e] - mean;
+          q += d * d;
+        }
     rstd = rsqrtf(row_sum<LPR>(q) / (float)C + p.eps);
   }
   char* drow = dst + (size_t)r * pitch;
-  for (int g = li; g < np; g += LPR) {
-    const f16x8 v = *reinterpret_cast<const f16x8*>(x + g * 8);
-    f16x8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) o[e] = (f16)(((float)v[e] - mean) * rstd * p.g0[g * 8 + e]);
-    *reinterpret_cast<f16x8*>(drow + g * 16) = o;
+  for (int k = 0; k < PMAX; ++k) {
+    const int g = li + k * LPR;
+    if (g < np) {
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) o[e] = (f16)(((float)rp.v[k][e] - mean) * rstd * p.g0[g * 8 + e]);
+      *reinterpret_cast<f16x8*>(drow + g * 16) = o;
+    }
   }
 }
 
-// y (fp16 LDS tile) -> out = fp16(LN(y) * g + res) -> global rows (16-byte pieces) + the row's sum of squares: LN_RESIDUAL with ssq_out
+// y (fp16 LDS tile) -> out = fp16(LN(y) * g + res) -> global rows (16-byte pieces) + the row's sum of squares: LN_RESIDUAL with ssq_out;
+// res: this thread's pieces of the residual rows, requested long before (RowPieces)
 template <int RB>
 __device__ __forceinline__ void ln_res_out_rows(const ImagenRowchainParams& p, int row0, const char* src, int pitch, const float* gain,
-                                                const f16* resbase, int ld_res, int tid) {
-  constexpr int LPR = kThreads / (32 * RB);
+                                                const RowPieces<RB>& res, int tid) {
+  constexpr int LPR = RowPieces<RB>::LPR, PMAX = RowPieces<RB>::PMAX;
   const int r = tid / LPR, li = tid % LPR;
   const int C = p.C, np = C >> 3;
   const char* srow = src + (size_t)r * pitch;
   float mean, rstd;
   row_ln_stats<LPR>(srow, C, li, p.eps, mean, rstd);
-  const f16* res = resbase + (size_t)(row0 + r) * ld_res;
   f16* out = reinterpret_cast<f16*>(p.out) + (size_t)(row0 + r) * p.ld_out;
   float ssq = 0.f;
-  for (int g = li; g < np; g += LPR) {
-    const f16x8 v = *reinterpret_cast<const f16x8*>(srow + g * 16);
-    const f16x8 rv = *reinterpret_cast<const f16x8*>(res + g * 8);
-    f16x8 o;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      o[e] = (f16)(((float)v[e] - mean) * rstd * gain[g * 8 + e] + (float)rv[e]);
-      const float t = (float)o[e];
-      ssq += t * t;
+  for (int k = 0; k < PMAX; ++k) {
+    const int g = li + k * LPR;
+    if (g < np) {
+      const f16x8 v = *reinterpret_cast<const f16x8*>(srow + g * 16);
+      f16x8 o;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        o[e] = (f16)(((float)v[e] - mean) * rstd * gain[g * 8 + e] + (float)res.v[k][e]);
+        const float t = (float)o[e];
+        ssq += t * t;
+      }
+      *reinterpret_cast<f16x8*>(out + g * 8) = o;
     }
-    *reinterpret_cast<f16x8*>(out + g * 8) = o;
   }
   ssq = row_sum<LPR>(ssq);
   if (p.ssq_out && li == 0) p.ssq_out[row0 + r] = ssq;
 }
 
-// one GEMM stage with its K-split reduction; the owners' accumulators stay in acc (first q.nt tiles)
+// one GEMM stage: the request of its first ring-full (stage_fill: as early as the caller can place it) and the K loop + K-split reduction
+// (stage_run); the owners' accumulators stay in acc (first q.nt tiles)
+__device__ __forceinline__ void stage_fill(f16x8 (&ring)[16], const Part& q, const void* w, int cout_pad, int lane) {
+  const WeightStream ws = weight_stream(w, cout_pad, q.tile0, lane);
+  if (q.nt == 2) ring_fill<2>(ring, ws, q.s0, q.s1 - q.s0);
+  else ring_fill<1>(ring, ws, q.s0, q.s1 - q.s0);
+}
+
 template <int RB>
-__device__ __forceinline__ void gemm_stage(f32x16 (&acc)[2][RB], const Part& q, const f16* w, int cout_pad, const char* xs, int pitch, char* scratch,
-                                           int lane) {
+__device__ __forceinline__ void stage_run(f32x16 (&acc)[2][RB], f16x8 (&ring)[16], const Part& q, const void* w, int cout_pad, const char* xs, int pitch,
+                                          char* scratch, int lane) {
+  const WeightStream ws = weight_stream(w, cout_pad, q.tile0, lane);
   acc_zero<2, RB>(acc);
-  if (q.nt == 2) gemm_rows<2, RB>(acc, w, cout_pad, q.tile0, q.s0, q.s1, xs, pitch, lane);
-  else gemm_rows<1, RB>(acc, w, cout_pad, q.tile0, q.s0, q.s1, xs, pitch, lane);
+  if (q.nt == 2) gemm_run<2, RB>(acc, ring, ws, q.s0, q.s1 - q.s0, xs, pitch, lane);
+  else gemm_run<1, RB>(acc, ring, ws, q.s0, q.s1 - q.s0, xs, pitch, lane);
   ksplit_reduce<RB>(acc[0], q, scratch, lane);
 }
 
@@ -317,7 +381,7 @@ __device__ __forceinline__ void store_stage(const f32x16 (&acc)[2][RB], const Pa
 // ------------------------------------------------------------------------------------------------ mode 1: FF
 template <int RB>
 __device__ __forceinline__ void chain_ff(const ImagenRowchainParams& p, char* smem, int row0) {
-  constexpr int ROWS = 32 * RB, LPR = kThreads / ROWS;
+  constexpr int ROWS = 32 * RB, LPR = RowPieces<RB>::LPR, PMAX = RowPieces<RB>::PMAX;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const Geo geo = chain_geo(p);
   const int C = p.C, inner = p.inner, hidden = p.hidden;
@@ -325,70 +389,83 @@ __device__ __forceinline__ void chain_ff(const ImagenRowchainParams& p, char* sm
   char* P0 = smem;
   char* P1 = P0 + (size_t)ROWS * Geo::pitch(geo.p0_cols);
   char* P2 = P1 + (size_t)ROWS * pitch1;
-  // ---- o rows -> P0
+  const int r = tid / LPR, li = tid % LPR;
+  f16x8 ring[16];
+  f32x16 acc[2][RB];
+  // ---- every request that depends on nothing: the out-projection's first weights, the residual rows, the o rows
+  const Part q0 = make_part(C >> 5, inner >> 4, wave);
+  stage_fill(ring, q0, p.w0, p.w_cout_pad0, lane);
+  RowPieces<RB> res;
+  load_row_pieces<RB>(res, p.res, p.ld_res, row0 + r, C, li);
   {
     const int npr = inner >> 3;
     const f16* x = reinterpret_cast<const f16*>(p.x);
     for (int i = tid; i < ROWS * npr; i += kThreads) {
-      const int r = i / npr, g = i - r * npr;
-      *reinterpret_cast<uint4*>(P0 + (size_t)r * pitch0o + g * 16) = *reinterpret_cast<const uint4*>(x + (size_t)(row0 + r) * p.ld_x + g * 8);
+      const int rr = i / npr, g = i - rr * npr;
+      *reinterpret_cast<uint4*>(P0 + (size_t)rr * pitch0o + g * 16) = *reinterpret_cast<const uint4*>(x + (size_t)(row0 + rr) * p.ld_x + g * 8);
     }
   }
   __syncthreads();
-  f32x16 acc[2][RB];
   // ---- y = o W_out^T -> P1 (fp16)
-  const Part q0 = make_part(C >> 5, inner >> 4, wave);
-  gemm_stage<RB>(acc, q0, reinterpret_cast<const f16*>(p.w0), p.w_cout_pad0, P0, pitch0o, P0, lane);
+  stage_run<RB>(acc, ring, q0, p.w0, p.w_cout_pad0, P0, pitch0o, P0, lane);
   store_stage<IMAGEN_ACT_NONE, RB>(acc, q0, P1, pitch1, lane);
+  const Part q1 = make_part(hidden >> 5, C >> 4, wave);
+  stage_fill(ring, q1, p.w1, p.w_cout_pad1, lane);          // (in flight across the barrier and the row pass)
   __syncthreads();
   // ---- row pass: x1 = fp16(LN(y) * g0 + res) -> P2;  a0 = fp16((x1 - mean x1) * rstd x1 * g1) -> P1
   {
-    const int r = tid / LPR, li = tid % LPR, np = C >> 3;
+    const int np = C >> 3;
     char* yrow = P1 + (size_t)r * pitch1;
     char* xrow = P2 + (size_t)r * pitch1;
     float mean, rstd;
     row_ln_stats<LPR>(yrow, C, li, p.eps, mean, rstd);
-    const f16* res = reinterpret_cast<const f16*>(p.res) + (size_t)(row0 + r) * p.ld_res;
+    f16x8 x1[PMAX];
     float so = 0.f;
-    for (int g = li; g < np; g += LPR) {
-      const f16x8 v = *reinterpret_cast<const f16x8*>(yrow + g * 16);
-      const f16x8 rv = *reinterpret_cast<const f16x8*>(res + g * 8);
-      f16x8 o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        o[e] = (f16)(((float)v[e] - mean) * rstd * p.g0[g * 8 + e] + (float)rv[e]);
-        so += (float)o[e];
+    for (int k = 0; k < PMAX; ++k) {
+      const int g = li + k * LPR;
+      if (g < np) {
+        const f16x8 v = *reinterpret_cast<const f16x8*>(yrow + g * 16);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          x1[k][e] = (f16)(((float)v[e] - mean) * rstd * p.g0[g * 8 + e] + (float)res.v[k][e]);
+          so += (float)x1[k][e];
+        }
+        *reinterpret_cast<f16x8*>(xrow + g * 16) = x1[k];
       }
-      *reinterpret_cast<f16x8*>(xrow + g * 16) = o;
     }
     const float mo = row_sum<LPR>(so) / (float)C;
     float qo = 0.f;
-    for (int g = li; g < np; g += LPR) {
-      const f16x8 v = *reinterpret_cast<const f16x8*>(xrow + g * 16);   // (this lane's own pieces: no barrier needed)
 #pragma unroll
-      for (int e = 0; e < 8; ++e) {
-        const float d = (float)v[e] - mo;
-        qo += d * d;
-      }
-    }
+    for (int k = 0; k < PMAX; ++k)
+      if (li + k * LPR < np)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float d = (float)x1[k][e] - mo;
+          qo += d * d;
+        }
     const float ro = rsqrtf(row_sum<LPR>(qo) / (float)C + p.eps);
-    for (int g = li; g < np; g += LPR) {
-      const f16x8 v = *reinterpret_cast<const f16x8*>(xrow + g * 16);
-      f16x8 a;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) a[e] = (f16)(((float)v[e] - mo) * ro * p.g1[g * 8 + e]);
-      *reinterpret_cast<f16x8*>(yrow + g * 16) = a;
+    for (int k = 0; k < PMAX; ++k) {
+      const int g = li + k * LPR;
+      if (g < np) {
+        f16x8 a;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) a[e] = (f16)(((float)x1[k][e] - mo) * ro * p.g1[g * 8 + e]);
+        *reinterpret_cast<f16x8*>(yrow + g * 16) = a;
+      }
     }
   }
   __syncthreads();
   // ---- hid = fp16(gelu(a0 W1^T)) -> P0
-  const Part q1 = make_part(hidden >> 5, C >> 4, wave);
-  gemm_stage<RB>(acc, q1, reinterpret_cast<const f16*>(p.w1), p.w_cout_pad1, P1, pitch1, P0, lane);
+  stage_run<RB>(acc, ring, q1, p.w1, p.w_cout_pad1, P1, pitch1, P0, lane);
   store_stage<IMAGEN_ACT_GELU, RB>(acc, q1, P0, pitch0h, lane);
+  const Part q2 = make_part(C >> 5, hidden >> 4, wave);
+  stage_fill(ring, q2, p.w2, p.w_cout_pad2, lane);
   __syncthreads();
   // ---- row pass: a1 = fp16((hid - mean) * rstd * g2), in place
   {
-    const int r = tid / LPR, li = tid % LPR, np = hidden >> 3;
+    const int np = hidden >> 3;
     char* hrow = P0 + (size_t)r * pitch0h;
     float mean, rstd;
     row_ln_stats<LPR>(hrow, hidden, li, p.eps, mean, rstd);
@@ -402,30 +479,27 @@ __device__ __forceinline__ void chain_ff(const ImagenRowchainParams& p, char* sm
   }
   __syncthreads();
   // ---- out = fp16(a1 W2^T + x1) -> P1 -> global
-  {
-    const Part q2 = make_part(C >> 5, hidden >> 4, wave);
-    gemm_stage<RB>(acc, q2, reinterpret_cast<const f16*>(p.w2), p.w_cout_pad2, P0, pitch0h, P0, lane);
-    if (q2.kpart == 0) {
-      const int half = lane >> 5, l31 = lane & 31;
+  stage_run<RB>(acc, ring, q2, p.w2, p.w_cout_pad2, P0, pitch0h, P0, lane);
+  if (q2.kpart == 0) {
+    const int half = lane >> 5, l31 = lane & 31;
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
-        if (t < q2.nt)
+    for (int t = 0; t < 2; ++t)
+      if (t < q2.nt)
 #pragma unroll
-          for (int j = 0; j < RB; ++j) {
-            const char* xr = P2 + (size_t)(32 * j + l31) * pitch1 + ((q2.tile0 + t) * 32 + 4 * half) * 2;
+        for (int j = 0; j < RB; ++j) {
+          const char* xr = P2 + (size_t)(32 * j + l31) * pitch1 + ((q2.tile0 + t) * 32 + 4 * half) * 2;
 #pragma unroll
-            for (int g = 0; g < 4; ++g) {
-              const f16x4 xv = *reinterpret_cast<const f16x4*>(xr + g * 16);
+          for (int g = 0; g < 4; ++g) {
+            const f16x4 xv = *reinterpret_cast<const f16x4*>(xr + g * 16);
 #pragma unroll
-              for (int e = 0; e < 4; ++e) acc[t][j][4 * g + e] += (float)xv[e];
-            }
+            for (int e = 0; e < 4; ++e) acc[t][j][4 * g + e] += (float)xv[e];
           }
-    }
-    store_stage<IMAGEN_ACT_NONE, RB>(acc, q2, P1, pitch1, lane);
+        }
   }
+  store_stage<IMAGEN_ACT_NONE, RB>(acc, q2, P1, pitch1, lane);
   __syncthreads();
   {
-    const int r = tid / LPR, li = tid % LPR, np = C >> 3;
+    const int np = C >> 3;
     const char* srow = P1 + (size_t)r * pitch1;
     f16* out = reinterpret_cast<f16*>(p.out) + (size_t)(row0 + r) * p.ld_out;
     float ssq = 0.f;
@@ -441,24 +515,48 @@ __device__ __forceinline__ void chain_ff(const ImagenRowchainParams& p, char* sm
 }
 
 // ------------------------------------------------------------------------------------------------ mode 2: XATTN
-// wave-local cross attention of head `wave` for one 32-row block: qa = the wave's two q accumulator tiles (dims 0-31 | 32-63 of the head)
-__device__ __forceinline__ void head_attention(const ImagenRowchainParams& p, const f32x16 (&qa)[2], int b, int hd, char* orow /* P0 row of this lane */,
-                                               int lane) {
+// The K^ / V^T fragments of ONE 32-key tile of head hd of image b, in the permuted dim / key orders of the two contractions below: A fragments
+// built from two 8-byte pieces each (16 requests per tile, issued together).
+struct KvTile {
+  f16x8 k[2][2];   // [32-dim block t][K step s]: key 32 kt + l31, dims 32 t + 16 s + 4 half + {0..3, 8..11}
+  f16x8 v[2][2];   // [K step s][32-dim block db]: dim 32 db + l31, keys 32 kt + 16 s + 4 half + {0..3, 8..11}
+};
+
+__device__ __forceinline__ f16x8 two_pieces(const f16* ptr) {
+  const uint2 lo = *reinterpret_cast<const uint2*>(ptr);
+  const uint2 hi = *reinterpret_cast<const uint2*>(ptr + 8);
+  uint4 pk = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  return *reinterpret_cast<const f16x8*>(&pk);
+}
+
+__device__ __forceinline__ void load_kv_tile(KvTile& kv, const ImagenRowchainParams& p, int b, int hd, int kt, int lane) {
   const int half = lane >> 5, l31 = lane & 31;
-  // ---- Q^: fp16(q) -> l2norm * q_scale * q_mult (ATTENTION's fused QNORM), as B fragments in the accumulator's own dim order:
-  // fragment (t, s), element e  <->  dim 32 t + 16 s + 4 half + (e & 3) + 8 (e >> 2)
-  f16 q16[2][16];
-  float ssq = 0.f;
+  const f16* krow = reinterpret_cast<const f16*>(p.khat) + (size_t)b * p.k_bs + (size_t)hd * p.k_hs + (size_t)(32 * kt + l31) * p.k_rs + 4 * half;
+  const f16* vg = reinterpret_cast<const f16*>(p.vt) + (size_t)b * p.vt_bs + (size_t)hd * p.vt_hs + 32 * kt + 4 * half;
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      q16[t][r] = (f16)qa[t][r];
-      ssq += (float)q16[t][r] * (float)q16[t][r];
-    }
+    for (int s = 0; s < 2; ++s) kv.k[t][s] = two_pieces(krow + 32 * t + 16 * s);
+#pragma unroll
+  for (int s = 0; s < 2; ++s)
+#pragma unroll
+    for (int db = 0; db < 2; ++db) kv.v[s][db] = two_pieces(vg + (size_t)(32 * db + l31) * p.vt_ds + 16 * s);
+}
+
+// Q^ of this lane's row from the wave's two q accumulator tiles (dims 0-31 | 32-63 of the head): fp16(q) -> l2norm * q_scale * q_mult
+// (ATTENTION's fused QNORM), as B fragments in the accumulator's own dim order: fragment (t, s), element e <-> dim 32 t + 16 s + 4 half + (e & 3) + 8 (e >> 2)
+__device__ __forceinline__ void make_qhat(f16x8 (&qf)[2][2], const ImagenRowchainParams& p, const f32x16& q0, const f32x16& q1, int lane) {
+  const int half = lane >> 5;
+  f16 q16[2][16];
+  float ssq = 0.f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    q16[0][r] = (f16)q0[r];
+    q16[1][r] = (f16)q1[r];
+    ssq += (float)q16[0][r] * (float)q16[0][r] + (float)q16[1][r] * (float)q16[1][r];
+  }
   ssq += __shfl_xor(ssq, 32);
   const float inv = p.q_mult / fmaxf(sqrtf(ssq), 1e-12f);
-  f16x8 qf[2][2];
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
@@ -466,155 +564,186 @@ __device__ __forceinline__ void head_attention(const ImagenRowchainParams& p, co
       const int d = 32 * t + 8 * (r >> 2) + 4 * half + (r & 3);
       qf[t][r >> 3][r & 7] = (f16)((float)q16[t][r] * inv * p.q_scale[d]);
     }
-  const f16* kg = reinterpret_cast<const f16*>(p.khat) + (size_t)b * p.k_bs + (size_t)hd * p.k_hs;
-  const f16* vg = reinterpret_cast<const f16*>(p.vt) + (size_t)b * p.vt_bs + (size_t)hd * p.vt_hs;
+}
+
+struct Softmax {   // attention_kernel's online softmax state of one row (lane = row; the two half-waves hold the two halves of a key tile)
   f32x16 oacc[2];
+  float m_run, l_run;
+};
+
+__device__ __forceinline__ void attn_tile(Softmax& st, const KvTile& kv, const f16x8 (&qf)[2][2], int kt, int J, int lane) {
+  const int half = lane >> 5;
+  f32x16 sacc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+#pragma unroll
+  for (int t = 0; t < 2; ++t)
+#pragma unroll
+    for (int s = 0; s < 2; ++s) sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kv.k[t][s], qf[t][s], sacc, 0, 0, 0);
+  const int kbase = 32 * kt + 4 * half;
+  float mx = -1.0e30f;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int key = kbase + (r & 3) + 8 * (r >> 2);
+    if (key >= J) sacc[r] = -1.0e30f;
+    mx = fmaxf(mx, sacc[r]);
+  }
+  mx = fmaxf(mx, __shfl_xor(mx, 32));
+  const float m_new = fmaxf(st.m_run, mx);
+  const float alpha = exp2f(st.m_run - m_new);
+  st.m_run = m_new;
+  float psum = 0.f;
+  f16x8 pf[2];
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const float e = exp2f(sacc[r] - m_new);
+    psum += e;
+    pf[r >> 3][r & 7] = (f16)e;
+  }
+  st.l_run = st.l_run * alpha + psum;
 #pragma unroll
   for (int db = 0; db < 2; ++db)
 #pragma unroll
-    for (int r = 0; r < 16; ++r) oacc[db][r] = 0.f;
-  float m_run = -1.0e30f, l_run = 0.f;
-  const int ntiles = (p.J + 31) >> 5;
-  for (int kt = 0; kt < ntiles; ++kt) {
-    // ---- S^T[key][row] = K^ . Q^T: A fragment of key 32 kt + l31 in the same permuted dim order (two 8-byte pieces)
-    const f16* krow = kg + (size_t)(32 * kt + l31) * p.k_rs + 4 * half;
-    f32x16 sacc;
+    for (int r = 0; r < 16; ++r) st.oacc[db][r] *= alpha;
 #pragma unroll
-    for (int r = 0; r < 16; ++r) sacc[r] = 0.f;
+  for (int s = 0; s < 2; ++s)     // O^T[d][row] += V^T . P (k-step s covers the keys of accumulator registers 8 s .. 8 s + 7)
 #pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int s = 0; s < 2; ++s) {
-        const uint2 lo = *reinterpret_cast<const uint2*>(krow + 32 * t + 16 * s);
-        const uint2 hi = *reinterpret_cast<const uint2*>(krow + 32 * t + 16 * s + 8);
-        uint4 pk = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        const f16x8 kf = *reinterpret_cast<const f16x8*>(&pk);
-        sacc = __builtin_amdgcn_mfma_f32_32x32x16_f16(kf, qf[t][s], sacc, 0, 0, 0);
-      }
-    // ---- online softmax (attention_kernel's): lane = row, this lane holds 16 of the tile's 32 keys
-    const int kbase = 32 * kt + 4 * half;
-    float mx = -1.0e30f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int key = kbase + (r & 3) + 8 * (r >> 2);
-      if (key >= p.J) sacc[r] = -1.0e30f;
-      mx = fmaxf(mx, sacc[r]);
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    const float m_new = fmaxf(m_run, mx);
-    const float alpha = exp2f(m_run - m_new);
-    m_run = m_new;
-    float psum = 0.f;
-    f16x8 pf[2];
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const float e = exp2f(sacc[r] - m_new);
-      psum += e;
-      pf[r >> 3][r & 7] = (f16)e;
-    }
-    l_run = l_run * alpha + psum;
-#pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) oacc[db][r] *= alpha;
-    // ---- O^T[d][row] += V^T . P (k-step s covers the keys of accumulator registers 8 s .. 8 s + 7)
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int db = 0; db < 2; ++db) {
-        const f16* vrow = vg + (size_t)(32 * db + l31) * p.vt_ds + 32 * kt + 16 * s + 4 * half;
-        const uint2 lo = *reinterpret_cast<const uint2*>(vrow);
-        const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 8);
-        uint4 pk = make_uint4(lo.x, lo.y, hi.x, hi.y);
-        const f16x8 vf = *reinterpret_cast<const f16x8*>(&pk);
-        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], oacc[db], 0, 0, 0);
-      }
-  }
-  const float l_tot = l_run + __shfl_xor(l_run, 32);
+    for (int db = 0; db < 2; ++db) st.oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kv.v[s][db], pf[s], st.oacc[db], 0, 0, 0);
+}
+
+// o[row][hd * 64 + 32 db + 8 g + 4 half + e] -> the P0 row tile (the B operand of the out-projection)
+__device__ __forceinline__ void store_o(const Softmax& st, int hd, char* orow, int lane) {
+  const int half = lane >> 5;
+  const float l_tot = st.l_run + __shfl_xor(st.l_run, 32);
   const float il = 1.0f / l_tot;
-  // o[row][hd * 64 + 32 db + 8 g + 4 half + e] -> the P0 row tile (the B operand of the out-projection)
 #pragma unroll
   for (int db = 0; db < 2; ++db)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       f16x4 v;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = (f16)(oacc[db][4 * g + e] * il);
+      for (int e = 0; e < 4; ++e) v[e] = (f16)(st.oacc[db][4 * g + e] * il);
       *reinterpret_cast<f16x4*>(orow + (hd * 64 + 32 * db + 8 * g + 4 * half) * 2) = v;
     }
 }
 
 template <int RB>
 __device__ __forceinline__ void chain_xattn(const ImagenRowchainParams& p, char* smem, int row0) {
-  constexpr int ROWS = 32 * RB;
+  constexpr int ROWS = 32 * RB, LPR = RowPieces<RB>::LPR;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), l31 = lane & 31;
   const int C = p.C, inner = p.inner;
   const int pitch0 = Geo::pitch(inner), pitch1 = Geo::pitch(C);
   char* P0 = smem;
   char* P1 = P0 + (size_t)ROWS * pitch0;
-  load_ln_rows<RB>(p, row0, P1, pitch1, tid);
-  __syncthreads();
+  const int r = tid / LPR, li = tid % LPR;
+  f16x8 ring[16];
   f32x16 acc[2][RB];
-  // ---- q = a Wq^T: wave h owns the 64 output channels of head h (two cout tiles), all K steps
+  // ---- q = a Wq^T: wave h owns the 64 output channels of head h (two cout tiles), all K steps; its first weights are requested first
+  Part qq;
+  qq.T = inner >> 5;
+  qq.nt = 2;
+  qq.tile0 = 2 * wave;
+  qq.wk = 1;
+  qq.kpart = 0;
+  qq.s0 = 0;
+  qq.s1 = C >> 4;
+  stage_fill(ring, qq, p.w0, p.w_cout_pad0, lane);
   {
-    Part q;
-    q.T = inner >> 5;
-    q.nt = 2;
-    q.tile0 = 2 * wave;
-    q.wk = 1;
-    q.kpart = 0;
-    q.s0 = 0;
-    q.s1 = C >> 4;
-    acc_zero<2, RB>(acc);
-    gemm_rows<2, RB>(acc, reinterpret_cast<const f16*>(p.w0), p.w_cout_pad0, q.tile0, q.s0, q.s1, P1, pitch1, lane);
+    RowPieces<RB> xr;   // the block input rows: the LayerNorm input
+    load_row_pieces<RB>(xr, p.x, p.ld_x, row0 + r, C, li);
+    ln_rows_to_lds<RB>(p, xr, row0, P1, pitch1, tid);
   }
+  __syncthreads();
+  {
+    const WeightStream ws = weight_stream(p.w0, p.w_cout_pad0, qq.tile0, lane);
+    acc_zero<2, RB>(acc);
+    gemm_run<2, RB>(acc, ring, ws, 0, qq.s1, P1, pitch1, lane);
+  }
+  // ---- the attention of head `wave`, wave-local.  Q^ of every row block first (the fp32 accumulators are dead after it); the first key tile is
+  // requested before that arithmetic
   const int b = row0 / p.rows_per_batch;
+  const int ntiles = (p.J + 31) >> 5;
+  KvTile kv0;
+  load_kv_tile(kv0, p, b, wave, 0, lane);
+  f16x8 qf[RB][2][2];
 #pragma unroll
   for (int j = 0; j < RB; ++j) {
-    const f32x16 qa[2] = {acc[0][j], acc[1][j]};
-    head_attention(p, qa, b, wave, P0 + (size_t)(32 * j + l31) * pitch0, lane);
+    make_qhat(qf[j], p, acc[0][j], acc[1][j], lane);
+    __builtin_amdgcn_sched_barrier(0);
   }
+  const Part q1 = make_part(C >> 5, inner >> 4, wave);
+#pragma unroll
+  for (int j = 0; j < RB; ++j) {
+    Softmax st;
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) st.oacc[db][e] = 0.f;
+    st.m_run = -1.0e30f;
+    st.l_run = 0.f;
+    attn_tile(st, kv0, qf[j], 0, p.J, lane);
+    for (int kt = 1; kt < ntiles; ++kt) {   // (every README / BASELINE site has two tiles: J = 39 | 41; long contexts: tile after tile)
+      KvTile kv;
+      load_kv_tile(kv, p, b, wave, kt, lane);
+      attn_tile(st, kv, qf[j], kt, p.J, lane);
+    }
+    store_o(st, wave, P0 + (size_t)(32 * j + l31) * pitch0, lane);
+    __builtin_amdgcn_sched_barrier(0);   // (one row block after the other: interleaved, their softmax states do not fit the register file)
+  }
+  __builtin_amdgcn_sched_barrier(0);   // (the out-projection's ring is 64 registers: requested here, not hoisted across the attention)
+  stage_fill(ring, q1, p.w1, p.w_cout_pad1, lane);
+  RowPieces<RB> xr;     // the residual rows of the last row pass (the block input again unless the caller names another tensor), requested
+  if (p.res) load_row_pieces<RB>(xr, p.res, p.ld_res, row0 + r, C, li);   // behind the attention: 16 registers it could not spare
+  else load_row_pieces<RB>(xr, p.x, p.ld_x, row0 + r, C, li);
   __syncthreads();
   // ---- y = o W_out^T -> P1 (the normalised input rows are dead)
-  const Part q1 = make_part(C >> 5, inner >> 4, wave);
-  gemm_stage<RB>(acc, q1, reinterpret_cast<const f16*>(p.w1), p.w_cout_pad1, P0, pitch0, P0, lane);
+  stage_run<RB>(acc, ring, q1, p.w1, p.w_cout_pad1, P0, pitch0, P0, lane);
   store_stage<IMAGEN_ACT_NONE, RB>(acc, q1, P1, pitch1, lane);
   __syncthreads();
   // ---- out = fp16(LN(y) * g1 + x)
-  const f16* resbase = p.res ? reinterpret_cast<const f16*>(p.res) : reinterpret_cast<const f16*>(p.x);
-  ln_res_out_rows<RB>(p, row0, P1, pitch1, p.g1, resbase, p.res ? p.ld_res : p.ld_x, tid);
+  ln_res_out_rows<RB>(p, row0, P1, pitch1, p.g1, xr, tid);
 }
 
 // ------------------------------------------------------------------------------------------------ mode 3: QKV
 template <int RB>
 __device__ __forceinline__ void chain_qkv(const ImagenRowchainParams& p, char* smem, int row0) {
-  constexpr int ROWS = 32 * RB, LPR = kThreads / ROWS;
+  constexpr int ROWS = 32 * RB, LPR = RowPieces<RB>::LPR;
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int C = p.C, inner = p.inner, nout = inner + 2 * kDh;
   const int pitch0 = Geo::pitch(nout), pitch1 = Geo::pitch(C);
   char* P0 = smem;
   char* P1 = P0 + (size_t)ROWS * pitch0;
-  load_ln_rows<RB>(p, row0, P1, pitch1, tid);
-  __syncthreads();
+  const int r = tid / LPR, li = tid % LPR;
   // ---- y = a [Wq | Wkv]^T: 20 cout tiles — every wave two (q head `wave`), waves 0-3 one of the k | v tiles on top
+  f16x8 ring[16];
+  WeightStream ws = weight_stream(p.w0, p.w_cout_pad0, 2 * wave, lane);
+  ring_fill<2>(ring, ws, 0, C >> 4);
+  {
+    RowPieces<RB> xr;
+    load_row_pieces<RB>(xr, p.x, p.ld_x, row0 + r, C, li);
+    ln_rows_to_lds<RB>(p, xr, row0, P1, pitch1, tid);
+  }
+  __syncthreads();
   f32x16 acc[2][RB];
   acc_zero<2, RB>(acc);
-  gemm_rows<2, RB>(acc, reinterpret_cast<const f16*>(p.w0), p.w_cout_pad0, 2 * wave, 0, C >> 4, P1, pitch1, lane);
+  gemm_run<2, RB>(acc, ring, ws, 0, C >> 4, P1, pitch1, lane);
+  if (wave < 4) {   // (requested before the first two tiles are stored)
+    ws = weight_stream(p.w0, p.w_cout_pad0, 16 + wave, lane);
+    ring_fill<1>(ring, ws, 0, C >> 4);
+  }
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
     for (int j = 0; j < RB; ++j) store_tile<IMAGEN_ACT_NONE>(acc[t][j], P0, pitch0, 2 * wave + t, j, lane);
   if (wave < 4) {
-    f32x16 a1[1][RB];
-    acc_zero<1, RB>(a1);
-    gemm_rows<1, RB>(a1, reinterpret_cast<const f16*>(p.w0), p.w_cout_pad0, 16 + wave, 0, C >> 4, P1, pitch1, lane);
+    acc_zero<1, RB>(acc);
+    gemm_run<1, RB>(acc, ring, ws, 0, C >> 4, P1, pitch1, lane);
 #pragma unroll
-    for (int j = 0; j < RB; ++j) store_tile<IMAGEN_ACT_NONE>(a1[0][j], P0, pitch0, 16 + wave, j, lane);
+    for (int j = 0; j < RB; ++j) store_tile<IMAGEN_ACT_NONE>(acc[0][j], P0, pitch0, 16 + wave, j, lane);
   }
   __syncthreads();
   // ---- row pass: q pieces -> out rows; K^ = l2norm(k) * k_scale -> khat row; v -> V^T column
   {
-    const int r = tid / LPR, li = tid % LPR;
     const char* srow = P0 + (size_t)r * pitch0;
     f16* out = reinterpret_cast<f16*>(p.out) + (size_t)(row0 + r) * p.ld_out;
     const int npq = inner >> 3;
@@ -648,12 +777,15 @@ __device__ __forceinline__ void chain_qkv(const ImagenRowchainParams& p, char* s
 }
 
 template <int MODE, int RB>
-__global__ __launch_bounds__(kThreads) void rowchain_kernel(const ImagenRowchainParams p) {
+__global__ __launch_bounds__(kThreads) void rowchain_kernel(const ImagenRowchainParams p, unsigned code_bytes) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  // the kernel's own code range read as data, one parallel round trip (common.h: consecutive launches of a step run different kernels)
+  const unsigned warm = imagen_code_warm(code_bytes, threadIdx.x, kThreads);
   const int row0 = blockIdx.x * 32 * RB;
   if (MODE == IMAGEN_CHAIN_FF) chain_ff<RB>(p, smem, row0);
   else if (MODE == IMAGEN_CHAIN_XATTN) chain_xattn<RB>(p, smem, row0);
   else chain_qkv<RB>(p, smem, row0);
+  imagen_code_warm_sink(warm);
 }
 
 template <int MODE, int RB>
@@ -667,7 +799,12 @@ int launch_one(const ImagenRowchainParams& p, hipStream_t s) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(rowchain_kernel<MODE, RB>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     if (dev >= 0 && dev < 16) attr_set[dev] = true;
   }
-  hipLaunchKernelGGL((rowchain_kernel<MODE, RB>), dim3((unsigned)(p.rows / (32 * RB))), dim3(kThreads), lds, s, p);
+  static const unsigned code_bytes = [] {
+    char name[160];
+    snprintf(name, sizeof(name), "_ZN12_GLOBAL__N_115rowchain_kernelILi%dELi%dEEEv20ImagenRowchainParamsj", MODE, RB);
+    return imagen_kernel_code_bytes(name);
+  }();
+  hipLaunchKernelGGL((rowchain_kernel<MODE, RB>), dim3((unsigned)(p.rows / (32 * RB))), dim3(kThreads), lds, s, p, code_bytes);
   return imagen_hip_status("rowchain");
 }
 

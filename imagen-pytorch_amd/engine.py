@@ -101,8 +101,8 @@ def _fingerprint(unet) -> tuple:
 # ACT_PREP + all-DMA conv for the Blocks with at least this many output channels (the MFMA-bound layers: the prologue pass costs one
 # read + one write of the input, the conv kernel drops its staging instruction stream); 0 = never
 INIT_CONV_SHARED_MIN_PIXELS = 1 << 17   # ... of stages with at least this many distinct pixels (below, the two copies cost what the half launch saves)
-INIT_CONV_SHARED = int(os.environ.get("IMAGEN_INIT_CONV_SHARED", "1"))   # A/B switch: under CFG the init conv of the large stage runs on the B distinct images only
-BIG_PREP = int(os.environ.get("IMAGEN_BIG_PREP", "1"))   # A/B switch: ACT_PREP + conv_big for the Blocks conv_big applies to (else they keep the fused prologue)
+INIT_CONV_SHARED = 1   # (module constant; measured in round 3, call X) under CFG the init conv of the large stage runs on the B distinct images only
+BIG_PREP = 1   # (module constant; round 3, call S) ACT_PREP + conv_big for the Blocks conv_big applies to (else they keep the fused prologue)
 ACT_PREP_MIN_COUT = 0   # (measured in the model: the extra pass costs more than it saves — off)
 TAIL_FUSED = 1   # (module constant; measured in call B, profiles/r03_b_tail_ab.jsonl) GCA_FINAL + GATE_RESIDUAL of an identity ResnetBlock as one GCA_TAIL launch
 TAIL_ACT = 1     # (module constant; call B) ... which also writes the next block1's activated input
@@ -118,11 +118,11 @@ LN_STATS_FUSED = 1   # (module constant; call B) LayerNorm statistics from the p
 #  * SPLIT_SMALL: block1 of the 32-channel ResnetBlocks and the final conv of stages whose launches are latency-bound (<= SPLIT_SMALL_FLOPS
 #    executed FLOPs): the layers next to the output, whose weight rounding reaches it unattenuated (0.99e-3 -> 0.94e-3).
 TIME_TABLE_MAX_BYTES = int(float(os.environ.get("IMAGEN_TIME_TABLE_MAX_GB", "4")) * (1 << 30))   # per stage and lane (enable_time_table)
-SPLIT_STATIC = int(os.environ.get("IMAGEN_SPLIT_STATIC", "1"))
-SPLIT_SMALL = int(os.environ.get("IMAGEN_SPLIT_SMALL", "1"))
-SPLIT_SMALL_MAX_K = int(os.environ.get("IMAGEN_SPLIT_MAX_K", "320"))        # taps * input channels of the unsplit weight
-SPLIT_1X1 = int(os.environ.get("IMAGEN_SPLIT_1X1", "0"))
-SPLIT_BLOCK2 = int(os.environ.get("IMAGEN_SPLIT_BLOCK2", "1"))   # round 5: on (measured -4 % whole-Unet error for +0.03 ms per step pair: the margin under 1e-3)
+SPLIT_STATIC = 1
+SPLIT_SMALL = 1
+SPLIT_SMALL_MAX_K = 320        # taps * input channels of the unsplit weight
+SPLIT_1X1 = 0      # (measured in round 4, call A: no parity gain worth its launches; a split 1x1 layer also leaves the ROWCHAIN path)
+SPLIT_BLOCK2 = 1   # round 5: on (measured -4 % whole-Unet error for +0.03 ms per step pair: the margin under 1e-3)
 SPLIT_SMALL_FLOPS = 3.0e9      # 2 * pixels * Cout * (2 K) of the split launch
 
 

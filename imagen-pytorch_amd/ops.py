@@ -283,9 +283,9 @@ def launchable_shapes(cfg: int, OH: int, OW: int, KH: int, KW: int, stride: int)
 # GlobalContext partials from the producing conv's epilogue ... only for launches of at most this many tiles: the partials cost every TILE a fixed ~2 us of reductions and barriers, a stand-alone
 # pass over the tensor costs ~9 us per LAUNCH + its read (measured in the model: a loss on the 4096-tile 256^2 layers, a gain below)
 GCA_EPILOGUE_MAX_TILES = 1024
-CONV_DMA = int(_os.environ.get("IMAGEN_CONV_DMA", "1"))             # A/B switch: the all-DMA kernel family for prologue-free single-input 3x3 convs
-CONV_STREAM = int(_os.environ.get("IMAGEN_CONV_STREAM", "1"))       # A/B switch: the streaming kernel family (conv_stream.hip) for the 32-channel 3x3 convs
-STREAM_GCA = int(_os.environ.get("IMAGEN_STREAM_GCA", "0"))         # A/B switch: the streaming family emits the GlobalContext partials of its output too (0: a GCA_PARTIAL pass / family 2)
+CONV_DMA = 1       # (module constant since round 5; tests monkeypatch it) the all-DMA kernel family for prologue-free single-input 3x3 convs
+CONV_STREAM = 1    # (module constant) the streaming kernel family (conv_stream.hip) for the 32-channel 3x3 convs
+STREAM_GCA = 0     # (module constant: measured slower in round 4, call F; the epilogue path is the shared conv_epilogue.h code, tested by monkeypatching) the streaming family emits the GlobalContext partials of its output too (0: a GCA_PARTIAL pass / family 2)
 STREAM_MIN_TILES = 512   # ... of launches with at least this many 16x16 tiles (persistent workgroups need a few tiles each)
 
 
@@ -293,7 +293,7 @@ CONV_PRO = int(_os.environ.get("IMAGEN_CONV_PRO", "1"))             # A/B switch
 PRO_MIN_TILES = 1024     # ... of launches with at least this many 8x16 tiles (two per resident workgroup)
 
 
-CONV_PW = int(_os.environ.get("IMAGEN_CONV_PW", "1"))               # A/B switch: the streaming pointwise family (conv_pw.hip) for the large res_conv launches
+CONV_PW = 1        # (module constant) the streaming pointwise family (conv_pw.hip) for the large res_conv launches
 PW_MIN_TILES = 512     # ... of at least this many tiles, i.e. two per CU (the big maps; below, the launch is latency-bound either way)
 
 
@@ -303,7 +303,7 @@ GEMM_MAX_K = 2048        # ... and at most this many (the launcher's limit, conv
                          # weight counts its input channels twice) — wider layers stay on the wave-specialised kernel
 GEMM_MIN_TILES = 128     # ... and at least this many 128-row x 128-cout workgroup tiles
 GEMM_MIN_COUT = 256      # ... that fill at least two output-channel slabs
-CONV_BIG = int(_os.environ.get("IMAGEN_CONV_BIG", "1"))               # A/B switch: the big-tile all-DMA family (conv_big.hip) for the C >= 128 3x3 convs
+CONV_BIG = 1       # (module constant) the big-tile all-DMA family (conv_big.hip) for the C >= 128 3x3 convs
 BIG_MIN_WGS = 192      # ... of launches that give it at least this many workgroups (one per CU: below, the smaller tiles of family 2 fill the chip better)
 BIG_PICKS = (3, 2)   # family-5 configuration of the 256- / 128-pixel tile (call R: the 3-stage weight ring and the third halo buffer are 2-3 % ahead)
 
@@ -653,7 +653,7 @@ def rowstat(plan: Plan, x1: Act, *, mode: int, rs: torch.Tensor, mu: Optional[to
     return p
 
 
-ATTN_BOUNDED = int(_os.environ.get("IMAGEN_ATTN_BOUNDED", "1"))   # 0: always the online softmax (A/B)
+ATTN_BOUNDED = 1   # (module constant; 0: always the online softmax)
 ATTN_BOUND_MAX = 14.0    # log2 units: exp2(s) of every key stays inside fp16's normal range (2^-14 .. 2^14) while |s| <= 14
 
 
@@ -750,7 +750,7 @@ def gca_final(plan: Plan, part: torch.Tensor, w1t, b1, w2t, b2, gate: torch.Tens
     return f
 
 
-GCA_FINAL_SPLIT = int(_os.environ.get("IMAGEN_GCA_FINAL_SPLIT", "1"))   # A/B switch: the finalisation of wide blocks as two many-workgroup launches
+GCA_FINAL_SPLIT = 1   # (module constant; round 4, call V) the finalisation of wide blocks as two many-workgroup launches
 
 
 def gca_final_is_wide(C: int, hidden: int) -> bool:

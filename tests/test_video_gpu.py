@@ -357,7 +357,9 @@ def _tap3d(act, rows):
     return t.reshape(rows, f, *t.shape[1:]).permute(0, 2, 1, 3, 4)
 
 
-C5_TOL = 1.5e-3   # measured on MI355X (calls A and M): cond 9.9e-4, null 9.5e-4, CFG-3 combination 2.7e-3
+C5_TOL = 1.15e-3   # measured on MI355X in rounds 4 and 5: cond 1.05e-3, null 1.06e-3, CFG-3 combination 2.81e-3 (round 3: 9.9e-4 / 9.5e-4 / 2.7e-3).  ABOVE
+                   # north_star's 1e-3: the fp32-P temporal attention of round 5 did not move it; tools/parity_budget.py's ablations on the image
+                   # unet say even fp32 weights everywhere buy 8 % — what is left is fp16 storage of the activations
 
 
 def test_unet3d_forward_vs_oracle_c5():
@@ -395,4 +397,4 @@ def test_unet3d_forward_vs_oracle_c5():
     from conftest import record_parity
     record_parity("unet3d_forward_vs_oracle_c5", cond=e, null=e_null, cfg3=e_cfg, taps=rep, tol=C5_TOL)
     assert {"mid_peg", "mid_tattn"} <= set(rep)
-    assert e < C5_TOL and e_null < C5_TOL and e_cfg < 2 * C5_TOL, (e, e_null, e_cfg, rep)
+    assert e < C5_TOL and e_null < C5_TOL and e_cfg < 2.7 * C5_TOL, (e, e_null, e_cfg, rep)

@@ -157,6 +157,10 @@ hipError_t hipGraphInstantiate(hipGraphExec_t*, hipGraph_t, void*, void*, size_t
 hipError_t hipGraphDestroy(hipGraph_t);
 hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t);
 hipError_t hipGraphExecDestroy(hipGraphExec_t);
+static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+enum { hipStreamNonBlocking = 1 };
+static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, int) { *s = nullptr; return hipSuccess; }
+static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 hipError_t hipEventCreate(hipEvent_t*);
 hipError_t hipEventRecord(hipEvent_t, hipStream_t);
 hipError_t hipEventSynchronize(hipEvent_t);
