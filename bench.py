@@ -455,7 +455,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=8, help="images per GPU (BASELINE: 8)")
     ap.add_argument("--timesteps", type=int, default=1000, help="DDPM steps per stage (BASELINE: 1000); other values are NOT the headline metric")
-    ap.add_argument("--mode", choices=("sequential", "pipeline", "lanes", "staged"), default=os.environ.get("IMAGEN_BENCH_MODE", "lanes"),
+    ap.add_argument("--mode", choices=("sequential", "pipeline", "lanes"), default=os.environ.get("IMAGEN_BENCH_MODE", "lanes"),
                     help="how successive batches are scheduled on the GPU: one sample() after the other | cascade stages overlapped across "
                          "batches (Imagen.sample_pipelined) | --lanes whole cascades side by side (one thread + stream each)")
     ap.add_argument("--lanes", type=int, default=int(os.environ.get("IMAGEN_BENCH_LANES", "0")),
@@ -518,9 +518,7 @@ def main():
             for i in range(count):
                 out = one_pass(first + i)
             return out
-        if mode == "staged":
-            outs = staged_passes(first, count)
-        elif mode == "pipeline":
+        if mode == "pipeline":
             outs = imagen.sample_pipelined([dict(seed=1000 + first + i) for i in range(count)], text_embeds=text_embeds, cond_scale=3.0,
                                            sample_offset=rank * B)
         else:
@@ -550,72 +548,14 @@ def main():
             outs = [all_gather_images(o, B * world) for o in outs]
         return outs[-1]
 
-    def staged_passes(first, count):
-        """`--mode staged`: the lanes, but never more than half of them inside the 64^2 stage at once.  Every batch still runs the full cascade
-        (stage 1, then stage 2 on its own output; same seeds, bit-identical images to one sample() call); a lane takes a waiting stage-2 job
-        first, else starts the next batch's stage 1 if fewer than lanes // 2 lanes are in stage 1.  With every lane started at the same moment
-        (--mode lanes) the six cascades march through stage 1 together and then through stage 2 together; here the latency-bound 64^2 stage
-        of some batches always runs UNDER the throughput-bound 256^2 stage of others."""
-        import threading
-        cv = threading.Condition()
-        state = dict(next=0, s1=0, ready=[], left=count)
-        outs, errors = [None] * count, []
-        s1_max = max(1, args.lanes // 2)
-
-        def take():
-            with cv:
-                while True:
-                    if errors or state["left"] == 0:
-                        return None
-                    if state["ready"]:
-                        return ("s2",) + state["ready"].pop(0)
-                    if state["next"] < count and state["s1"] < s1_max:
-                        i = state["next"]
-                        state["next"] += 1
-                        state["s1"] += 1
-                        return ("s1", i, None)
-                    cv.wait()
-
-        def run(lane):
-            try:
-                with imagen.lane(lane), torch.cuda.device(device):
-                    while True:
-                        job = take()
-                        if job is None:
-                            return
-                        kind, i, low = job
-                        kw = dict(text_embeds=text_embeds, cond_scale=3.0, use_tqdm=False, seed=1000 + first + i, sample_offset=rank * B)
-                        if kind == "s1":
-                            low = imagen.sample(stop_at_unet_number=1, **kw)
-                            with cv:
-                                state["s1"] -= 1
-                                state["ready"].append((i, low))
-                                cv.notify_all()
-                        else:
-                            outs[i] = imagen.sample(start_at_unet_number=2, start_image_or_video=low, **kw)
-                            with cv:
-                                state["left"] -= 1
-                                cv.notify_all()
-            except BaseException as e:   # noqa: BLE001 — re-raised in the main thread
-                with cv:
-                    errors.append(e)
-                    cv.notify_all()
-
-        th = [threading.Thread(target=run, args=(1 + l,)) for l in range(args.lanes)]
-        [t.start() for t in th]
-        [t.join() for t in th]
-        if errors:
-            raise errors[0]
-        return outs
-
     def fence():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
 
     # every lane's stages / graphs are built by the warm-up (a lane only exists once a batch has run on it)
-    n_warm = max(args.warmup, min(args.lanes, args.steps)) if args.mode in ("lanes", "staged") else args.warmup
-    passes(0, n_warm, mode="lanes" if args.mode == "staged" else None)   # (staged: every lane builds BOTH of its stages in the warm-up)
+    n_warm = max(args.warmup, min(args.lanes, args.steps)) if args.mode == "lanes" else args.warmup
+    passes(0, n_warm)
     log(f"{n_warm} warmup passes done ({args.mode})")
     fence()
     t0 = time.perf_counter()
@@ -645,11 +585,8 @@ def main():
                                           "pipeline": "successive batches with the cascade stages overlapped (stage 1 of batch k+1 || stage 2 of "
                                                       "batch k, one stream + hipGraph per stage); every batch runs the full cascade, pipeline fill "
                                                       "and drain are inside the timed region",
-                                          "lanes": f"{args.lanes} whole cascades side by side (one stream each)",
-                                          "staged": f"{args.lanes} lanes (one stream each), at most {max(1, args.lanes // 2)} of them in the 64^2 stage at once: "
-                                                    "every batch runs the full cascade, the 64^2 stage of some batches under the 256^2 stage of others; "
-                                                    "fill and drain are inside the timed region"}[args.mode],
-                       "images_in_flight": B * (args.lanes if args.mode in ("lanes", "staged") else (2 if args.mode == "pipeline" else 1)),
+                                          "lanes": f"{args.lanes} whole cascades side by side (one stream each)"}[args.mode],
+                       "images_in_flight": B * (args.lanes if args.mode == "lanes" else (2 if args.mode == "pipeline" else 1)),
                        "denoiser_evals_per_image": 2 * 2 * args.timesteps},
             "path_tflops_reference_count": round(value * FLOPS_PER_IMAGE_REFERENCE * (args.timesteps / 1000) / 1e12, 1),
             "path_frac_of_mfma_peak": round(value * FLOPS_PER_IMAGE_REFERENCE * (args.timesteps / 1000) / 1e12 / (MFMA_PEAK_TFLOPS * world), 4),

@@ -40,9 +40,12 @@ __global__ __launch_bounds__(256) void probe_mfma_kernel(float* sink, int iters)
 // hop is the load-to-use latency of whichever level of the hierarchy the working set lives in
 __global__ __launch_bounds__(64) void probe_chase_kernel(const unsigned* __restrict__ nodes, int hops, unsigned* out) {
   if (threadIdx.x != 0) return;
-  unsigned i = 0;
-  for (int h = 0; h < hops; ++h) i = __builtin_nontemporal_load(nodes + (size_t)i * 32);
-  out[0] = i;   // (keeps the chain alive)
+  unsigned i = out[0];   // continue where the previous launch stopped: the timed launch walks nodes the warm-up launch has NOT touched
+  for (int h = 0; h < hops; ++h) {
+    IMAGEN_OPAQUE(i);    // (a vector register: the hop is a global_load like the kernels' own, not a scalar-cache load)
+    i = nodes[(size_t)i * 32];
+  }
+  out[0] = i;
 }
 
 // three distinct trivial kernels for the dependent-launch chain (a denoiser step never runs the same kernel twice in a row)
@@ -110,7 +113,8 @@ extern "C" int imagen_probe_latency(const void* nodes, int hops, void* out_word,
   IMAGEN_CHECK(nodes && out_word && ns_per_hop && hops >= 1, "probe_latency: bad arguments");
   Timer t;
   IMAGEN_CHECK(t.ok, "probe_latency: hipEventCreate failed");
-  hipLaunchKernelGGL(probe_chase_kernel, dim3(1), dim3(64), 0, s, static_cast<const unsigned*>(nodes), hops, static_cast<unsigned*>(out_word));   // warm (fills the caches the set fits)
+  (void)hipMemsetAsync(out_word, 0, sizeof(unsigned), s);
+  hipLaunchKernelGGL(probe_chase_kernel, dim3(1), dim3(64), 0, s, static_cast<const unsigned*>(nodes), hops, static_cast<unsigned*>(out_word));   // warm: code, TLB reach, and — where the set fits a cache — the set
   (void)hipEventRecord(t.e0, s);
   hipLaunchKernelGGL(probe_chase_kernel, dim3(1), dim3(64), 0, s, static_cast<const unsigned*>(nodes), hops, static_cast<unsigned*>(out_word));
   (void)hipEventRecord(t.e1, s);

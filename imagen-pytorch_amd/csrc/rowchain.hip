@@ -25,6 +25,13 @@ namespace {
 
 constexpr int kThreads = 512;
 constexpr int kDh = 64;
+#ifndef ROWCHAIN_RING
+#define ROWCHAIN_RING 16      // A fragments in flight per wave (tools/chain_bench.py builds variants with -DROWCHAIN_RING=4 | 8)
+#endif
+#ifndef ROWCHAIN_MINW
+#define ROWCHAIN_MINW 1       // minimum waves per SIMD the register allocation leaves room for (4: two 512-thread workgroups per CU)
+#endif
+constexpr int kRing = ROWCHAIN_RING;
 
 struct Geo {           // LDS geometry of a launch (launcher and kernel agree through this)
   int p0_cols, p1_cols, p2_cols;
@@ -41,8 +48,12 @@ __host__ __device__ inline Geo chain_geo(const ImagenRowchainParams& p) {
     g.p0_cols = p.inner;
     g.p1_cols = p.C;
     g.p2_cols = 0;
-  } else {
+  } else if (p.mode == IMAGEN_CHAIN_QKV) {
     g.p0_cols = p.inner + 2 * kDh;
+    g.p1_cols = p.C;
+    g.p2_cols = 0;
+  } else {   // RESPREP: the concatenated input rows | the output rows (+ gate and bias of the image behind them)
+    g.p0_cols = p.inner + p.C2;
     g.p1_cols = p.C;
     g.p2_cols = 0;
   }
@@ -52,6 +63,16 @@ __host__ __device__ inline Geo chain_geo(const ImagenRowchainParams& p) {
 __host__ __device__ inline size_t chain_lds_bytes(const ImagenRowchainParams& p, int rows) {
   const Geo g = chain_geo(p);
   size_t n = (size_t)rows * Geo::pitch(g.p0_cols) + (size_t)rows * Geo::pitch(g.p1_cols) + (g.p2_cols ? (size_t)rows * Geo::pitch(g.p2_cols) : 0);
+  if (p.mode == IMAGEN_CHAIN_RESPREP) {
+    n += (size_t)2 * p.C * sizeof(float);
+    const int T = p.C >> 5, ks = (p.inner + p.C2) >> 4;
+    if (T < 8) {   // the K-split partials of the narrow layers go through the row tiles (dead by then): room for (wk - 1) * T tiles of 4 KB per row block
+      int wk = 8 / T;
+      if (wk > ks) wk = ks;
+      const size_t need = (size_t)(wk - 1) * T * (rows / 32) * 4096;
+      if (need > n) n = need;
+    }
+  }
   return (n + 15) & ~(size_t)15;
 }
 
@@ -126,8 +147,8 @@ __device__ __forceinline__ f16x8 weight_frag(const WeightStream& ws, int s, int 
 }
 
 template <int NT>
-__device__ __forceinline__ void ring_fill(f16x8 (&ring)[16], const WeightStream& ws, int s0, int n) {
-  constexpr int D = 16 / NT;
+__device__ __forceinline__ void ring_fill(f16x8 (&ring)[kRing], const WeightStream& ws, int s0, int n) {
+  constexpr int D = kRing / NT;
   if (n <= 0) return;
 #pragma unroll
   for (int i = 0; i < D; ++i) {
@@ -139,9 +160,9 @@ __device__ __forceinline__ void ring_fill(f16x8 (&ring)[16], const WeightStream&
 
 // acc[t][j] += W[cout tiles tile0 + t][K steps s0 .. s0 + n) . X[rows of row block j]: the ring holds steps s0 .. s0 + D - 1 on entry
 template <int NT, int RB>
-__device__ __forceinline__ void gemm_run(f32x16 (*acc)[RB], f16x8 (&ring)[16], const WeightStream& ws, int s0, int n, const char* xs, int pitch,
+__device__ __forceinline__ void gemm_run(f32x16 (*acc)[RB], f16x8 (&ring)[kRing], const WeightStream& ws, int s0, int n, const char* xs, int pitch,
                                          int lane) {
-  constexpr int D = 16 / NT;
+  constexpr int D = kRing / NT;
   if (n <= 0) return;
   const char* xl = xs + (lane & 31) * pitch + 16 * (lane >> 5);
   int sb = 0;
@@ -352,14 +373,14 @@ __device__ __forceinline__ void ln_res_out_rows(const ImagenRowchainParams& p, i
 
 // one GEMM stage: the request of its first ring-full (stage_fill: as early as the caller can place it) and the K loop + K-split reduction
 // (stage_run); the owners' accumulators stay in acc (first q.nt tiles)
-__device__ __forceinline__ void stage_fill(f16x8 (&ring)[16], const Part& q, const void* w, int cout_pad, int lane) {
+__device__ __forceinline__ void stage_fill(f16x8 (&ring)[kRing], const Part& q, const void* w, int cout_pad, int lane) {
   const WeightStream ws = weight_stream(w, cout_pad, q.tile0, lane);
   if (q.nt == 2) ring_fill<2>(ring, ws, q.s0, q.s1 - q.s0);
   else ring_fill<1>(ring, ws, q.s0, q.s1 - q.s0);
 }
 
 template <int RB>
-__device__ __forceinline__ void stage_run(f32x16 (&acc)[2][RB], f16x8 (&ring)[16], const Part& q, const void* w, int cout_pad, const char* xs, int pitch,
+__device__ __forceinline__ void stage_run(f32x16 (&acc)[2][RB], f16x8 (&ring)[kRing], const Part& q, const void* w, int cout_pad, const char* xs, int pitch,
                                           char* scratch, int lane) {
   const WeightStream ws = weight_stream(w, cout_pad, q.tile0, lane);
   acc_zero<2, RB>(acc);
@@ -390,7 +411,7 @@ __device__ __forceinline__ void chain_ff(const ImagenRowchainParams& p, char* sm
   char* P1 = P0 + (size_t)ROWS * Geo::pitch(geo.p0_cols);
   char* P2 = P1 + (size_t)ROWS * pitch1;
   const int r = tid / LPR, li = tid % LPR;
-  f16x8 ring[16];
+  f16x8 ring[kRing];
   f32x16 acc[2][RB];
   // ---- every request that depends on nothing: the out-projection's first weights, the residual rows, the o rows
   const Part q0 = make_part(C >> 5, inner >> 4, wave);
@@ -636,7 +657,7 @@ __device__ __forceinline__ void chain_xattn(const ImagenRowchainParams& p, char*
   char* P0 = smem;
   char* P1 = P0 + (size_t)ROWS * pitch0;
   const int r = tid / LPR, li = tid % LPR;
-  f16x8 ring[16];
+  f16x8 ring[kRing];
   f32x16 acc[2][RB];
   // ---- q = a Wq^T: wave h owns the 64 output channels of head h (two cout tiles), all K steps; its first weights are requested first
   Part qq;
@@ -715,7 +736,7 @@ __device__ __forceinline__ void chain_qkv(const ImagenRowchainParams& p, char* s
   char* P1 = P0 + (size_t)ROWS * pitch0;
   const int r = tid / LPR, li = tid % LPR;
   // ---- y = a [Wq | Wkv]^T: 20 cout tiles — every wave two (q head `wave`), waves 0-3 one of the k | v tiles on top
-  f16x8 ring[16];
+  f16x8 ring[kRing];
   WeightStream ws = weight_stream(p.w0, p.w_cout_pad0, 2 * wave, lane);
   ring_fill<2>(ring, ws, 0, C >> 4);
   {
@@ -776,15 +797,137 @@ __device__ __forceinline__ void chain_qkv(const ImagenRowchainParams& p, char* s
   }
 }
 
+// ------------------------------------------------------------------------------------------------ mode 4: RESPREP
+template <int RB>
+__device__ __forceinline__ void chain_resprep(const ImagenRowchainParams& p, char* smem, int row0) {
+  constexpr int ROWS = 32 * RB, LPR = RowPieces<RB>::LPR, PMAX = RowPieces<RB>::PMAX;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int C = p.C, C1 = p.inner, K = C1 + p.C2;
+  const int pitch0 = Geo::pitch(K), pitch1 = Geo::pitch(C);
+  char* P0 = smem;
+  char* P1 = P0 + (size_t)ROWS * pitch0;
+  float* s_gate = reinterpret_cast<float*>(P1 + (size_t)ROWS * pitch1);
+  float* s_bias = s_gate + C;
+  const int r = tid / LPR, li = tid % LPR;
+  const int b = row0 / p.rows_per_batch;
+  f16x8 ring[kRing];
+  f32x16 acc[2][RB];
+  const Part q0 = make_part(C >> 5, K >> 4, wave);
+  stage_fill(ring, q0, p.w0, p.w_cout_pad0, lane);
+  // ---- the requests that depend on nothing: the next Block's second input rows and their statistics, the addend rows of this wave's tiles
+  RowPieces<RB> nx;
+  float nssq = 0.f;
+  if (p.prep_out) {
+    if (p.prep_x2) load_row_pieces<RB>(nx, p.prep_x2, p.ld_prep_x2, row0 + r, p.prep_C2, li);
+    if (p.prep_ssq_b) nssq = p.prep_ssq_b[row0 + r];
+  }
+  f16x4 add[2][RB][4];
+  const bool owner = q0.kpart == 0;
+  if (p.addend && owner) {
+    const int half = lane >> 5, l31 = lane & 31;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      if (t < q0.nt)
+#pragma unroll
+        for (int j = 0; j < RB; ++j) {
+          const f16* ar = reinterpret_cast<const f16*>(p.addend) + (size_t)(row0 + 32 * j + l31) * p.ld_add + (q0.tile0 + t) * 32 + 4 * half;
+#pragma unroll
+          for (int g = 0; g < 4; ++g) add[t][j][g] = *reinterpret_cast<const f16x4*>(ar + g * 8);
+        }
+  }
+  for (int c = tid; c < C; c += kThreads) {
+    s_gate[c] = p.gate ? p.gate[(size_t)b * p.gate_stride + c] : 1.f;   // (no gate: the plain residual add of a block without GlobalContext)
+    s_bias[c] = p.bias ? p.bias[c] : 0.f;
+  }
+  {   // concat(x, x2) rows -> P0
+    const int npr = K >> 3, np1 = C1 >> 3;
+    const f16* x1 = reinterpret_cast<const f16*>(p.x);
+    const f16* x2 = reinterpret_cast<const f16*>(p.x2);
+    for (int i = tid; i < ROWS * npr; i += kThreads) {
+      const int rr = i / npr, g = i - rr * npr;
+      const f16* src = g < np1 ? x1 + (size_t)(row0 + rr) * p.ld_x + g * 8 : x2 + (size_t)(row0 + rr) * p.ld_x2 + (g - np1) * 8;
+      *reinterpret_cast<uint4*>(P0 + (size_t)rr * pitch0 + g * 16) = *reinterpret_cast<const uint4*>(src);
+    }
+  }
+  __syncthreads();
+  // ---- out = fp16(in Wres^T + bias + addend * gate) -> P1
+  stage_run<RB>(acc, ring, q0, p.w0, p.w_cout_pad0, P0, pitch0, P0, lane);
+  if (owner) {
+    const int half = lane >> 5;
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+      if (t < q0.nt)
+#pragma unroll
+        for (int j = 0; j < RB; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              const int c = (q0.tile0 + t) * 32 + 8 * g + 4 * half + e;
+              float v = acc[t][j][4 * g + e] + s_bias[c];
+              if (p.addend) v += (float)add[t][j][g][e] * s_gate[c];
+              acc[t][j][4 * g + e] = v;
+            }
+  }
+  store_stage<IMAGEN_ACT_NONE, RB>(acc, q0, P1, pitch1, lane);
+  __syncthreads();
+  // ---- row pass: out rows -> global (+ their sum of squares), then the next Block's activated input silu(concat(out, prep_x2) * rs * pa)
+  {
+    const int np = C >> 3;
+    const char* srow = P1 + (size_t)r * pitch1;
+    f16* out = reinterpret_cast<f16*>(p.out) + (size_t)(row0 + r) * p.ld_out;
+    f16x8 ov[PMAX];
+    float ssq = 0.f;
+#pragma unroll
+    for (int k = 0; k < PMAX; ++k) {
+      const int g = li + k * LPR;
+      if (g < np) {
+        ov[k] = *reinterpret_cast<const f16x8*>(srow + g * 16);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) ssq += (float)ov[k][e] * (float)ov[k][e];
+        *reinterpret_cast<f16x8*>(out + g * 8) = ov[k];
+      }
+    }
+    ssq = row_sum<LPR>(ssq);
+    if (p.ssq_out && li == 0) p.ssq_out[row0 + r] = ssq;
+    if (p.prep_out) {
+      const float sc = __builtin_amdgcn_rsqf(fmaxf(ssq + p.prep_ssq_wb * nssq, 1e-24f));
+      f16* ya = reinterpret_cast<f16*>(p.prep_out) + (size_t)(row0 + r) * p.ld_prep;
+#pragma unroll
+      for (int k = 0; k < PMAX; ++k) {
+        const int g = li + k * LPR;
+        if (g < np) {
+          f16x8 a;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] = (f16)silu_f((float)ov[k][e] * sc * p.prep_pa[g * 8 + e]);
+          *reinterpret_cast<f16x8*>(ya + g * 8) = a;
+        }
+      }
+      const int np2 = p.prep_C2 >> 3;
+#pragma unroll
+      for (int k = 0; k < PMAX; ++k) {
+        const int g = li + k * LPR;
+        if (g < np2) {
+          f16x8 a;
+#pragma unroll
+          for (int e = 0; e < 8; ++e) a[e] = (f16)silu_f((float)nx.v[k][e] * sc * p.prep_pa[C + g * 8 + e]);
+          *reinterpret_cast<f16x8*>(ya + C + g * 8) = a;
+        }
+      }
+    }
+  }
+}
+
 template <int MODE, int RB>
-__global__ __launch_bounds__(kThreads) void rowchain_kernel(const ImagenRowchainParams p, unsigned code_bytes) {
+__global__ __launch_bounds__(kThreads, ROWCHAIN_MINW) void rowchain_kernel(const ImagenRowchainParams p, unsigned code_bytes) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // the kernel's own code range read as data, one parallel round trip (common.h: consecutive launches of a step run different kernels)
   const unsigned warm = imagen_code_warm(code_bytes, threadIdx.x, kThreads);
   const int row0 = blockIdx.x * 32 * RB;
   if (MODE == IMAGEN_CHAIN_FF) chain_ff<RB>(p, smem, row0);
   else if (MODE == IMAGEN_CHAIN_XATTN) chain_xattn<RB>(p, smem, row0);
-  else chain_qkv<RB>(p, smem, row0);
+  else if (MODE == IMAGEN_CHAIN_QKV) chain_qkv<RB>(p, smem, row0);
+  else chain_resprep<RB>(p, smem, row0);
   imagen_code_warm_sink(warm);
 }
 
@@ -812,12 +955,26 @@ int launch_one(const ImagenRowchainParams& p, hipStream_t s) {
 
 int launch_rowchain(const ImagenRowchainParams* pp, hipStream_t s) {
   const ImagenRowchainParams& p = *pp;
-  IMAGEN_CHECK(p.mode >= IMAGEN_CHAIN_FF && p.mode <= IMAGEN_CHAIN_QKV, "rowchain: mode %d", p.mode);
-  IMAGEN_CHECK(p.x && p.out && p.w0 && p.g0, "rowchain: null pointer");
+  IMAGEN_CHECK(p.mode >= IMAGEN_CHAIN_FF && p.mode <= IMAGEN_CHAIN_RESPREP, "rowchain: mode %d", p.mode);
+  IMAGEN_CHECK(p.x && p.out && p.w0 && (p.g0 || p.mode == IMAGEN_CHAIN_RESPREP), "rowchain: null pointer");
   const int tile = p.tile64 ? 64 : 32;
   IMAGEN_CHECK(p.rows > 0 && p.rows_per_batch > 0 && p.rows % p.rows_per_batch == 0 && p.rows_per_batch % tile == 0,
                "rowchain: %d rows, %d per image, %d-row tiles", p.rows, p.rows_per_batch, tile);
   IMAGEN_CHECK(p.C >= 32 && p.C <= 256 && (p.C & (p.C - 1)) == 0, "rowchain: C = %d (a power of two in 32 .. 256: 1, 2, 4 or 8 cout tiles)", p.C);
+  if (p.mode == IMAGEN_CHAIN_RESPREP) {
+    IMAGEN_CHECK(p.inner % 32 == 0 && p.inner > 0 && p.C2 % 32 == 0 && p.C2 >= 0 && p.inner + p.C2 <= 512 && (p.C2 == 0 || p.x2),
+                 "rowchain RESPREP: inputs in 32-channel chunks, C1 + C2 <= 512 (got %d + %d)", p.inner, p.C2);
+    IMAGEN_CHECK(p.ld_x % 8 == 0 && p.ld_out % 8 == 0 && (p.C2 == 0 || (p.ld_x2 % 8 == 0 && ((size_t)p.x2 & 15) == 0)) && ((size_t)p.x & 15) == 0 &&
+                     ((size_t)p.out & 15) == 0,
+                 "rowchain RESPREP: 16-byte aligned rows");
+    IMAGEN_CHECK((p.addend || !p.gate) && (!p.addend || (p.ld_add % 4 == 0 && ((size_t)p.addend & 7) == 0)),
+                 "rowchain RESPREP: a gate needs its addend (8-byte aligned rows)");
+    IMAGEN_CHECK(!p.prep_out || (p.prep_pa && p.ld_prep % 8 == 0 && ((size_t)p.prep_out & 15) == 0 && p.prep_C2 % 8 == 0 && p.prep_C2 <= 256 &&
+                                 (p.prep_C2 == 0 || (p.prep_x2 && p.ld_prep_x2 % 8 == 0 && ((size_t)p.prep_x2 & 15) == 0))),
+                 "rowchain RESPREP: the activated output needs its gain vector, 16-byte aligned rows, prep_C2 <= 256");
+    IMAGEN_CHECK(p.w_cout_pad0 >= p.C, "rowchain RESPREP: weight padding");
+    return p.tile64 ? launch_one<IMAGEN_CHAIN_RESPREP, 2>(p, s) : launch_one<IMAGEN_CHAIN_RESPREP, 1>(p, s);
+  }
   IMAGEN_CHECK(p.inner == 512 && p.heads * kDh == p.inner, "rowchain: heads x 64 == 512 (got %d heads, inner %d)", p.heads, p.inner);
   IMAGEN_CHECK(p.ld_x % 8 == 0 && p.ld_out % 8 == 0 && ((size_t)p.x & 15) == 0 && ((size_t)p.out & 15) == 0, "rowchain: 16-byte aligned rows");
   IMAGEN_CHECK((p.mu == nullptr) == (p.rs == nullptr), "rowchain: mu and rs come together");

@@ -499,8 +499,12 @@ class UnetEngine:
         # x comes out of a fused ResnetBlock tail (GCA_TAIL): that launch also writes silu(ChanRMSNorm(x) * gamma) — it has the pixel's
         # channels and its sum of squares in registers — and block1 stages its input with no arithmetic (prologue-free kernel families)
         xa = ops.request_act(x, pa1) if (skip is None and TAIL_ACT and w1.Cin_pad == w1.Cin) else None
+        # ... or out of the previous block's res_conv as a ROWCHAIN launch (RESPREP), which then writes the activated concat(x, skip) as well
+        xr = ops.request_prep(x, skip, skip.ssq if skip is not None else None, s * s, pa1) if (xa is None and (prep or big1)) else None
         if xa is not None:
             op = ops.igemm(plan, xa, w1, h1, ssq_out=h1.ssq, post=post, label=name + ".block1")
+        elif xr is not None:     # (no ACT_PREP pass)
+            op = ops.igemm(plan, Act(xr.t, R, H, Wd, Cin, Cin, H * Wd * Cin), w1, h1, ssq_out=h1.ssq, post=post, label=name + ".block1")
         elif prep or big1:   # MFMA-bound layer: the prologue as its own pass, then an all-DMA conv on the activated concat
             xa = self.new(R, H, Wd, Cin)
             if big1 and x.ssq is None:
@@ -573,7 +577,14 @@ class UnetEngine:
                          gate=gate if tail_part is not None else None, ssq_out=out.ssq, label=name + ".tail")
         elif rb.res_conv is not None:
             wr = W.conv(name + ".res_conv", rb.res_conv, in_scale=in_scale)
-            if gate is not None:
+            if big and ops.resprep_ok(x, skip, wr, H * Wd):
+                # on the levels whose Blocks take the big-tile all-DMA convs (their prologue is a pass of its own), the res_conv + gate tail is
+                # a ROWCHAIN launch that the NEXT block asks for its activated input too (request_prep): that block needs no ACT_PREP
+                op = ops.rowchain_resprep(plan, x.tokens(), skip.tokens() if skip is not None else None, h2.tokens(), gate, out.tokens(), wr,
+                                          rows_per_batch=H * Wd, ssq_out=out.ssq, label=name + ".res_conv.chain")
+                out.res_op = (op, plan)
+                op.ssq_emitted = True
+            elif gate is not None:
                 op = ops.igemm(plan, x, wr, out, x2=skip, addend=h2, gate=gate, ssq_out=out.ssq, label=name + ".res_conv")
             else:
                 op = ops.igemm(plan, x, wr, out, x2=skip, res=h2, ssq_out=out.ssq, label=name + ".res_conv")

@@ -143,6 +143,7 @@ class Act:
     off: int = 0             # element offset into t
     ssq: Optional[torch.Tensor] = None   # fp32 [rows]: per-pixel sum of squares emitted by the producer (ChanRMSNorm statistics)
     tail_op: Optional[object] = None     # the GCA_TAIL params that produce this tensor: a consumer may ask it for more outputs (request_act)
+    res_op: Optional[object] = None      # the ROWCHAIN RESPREP params that produce this tensor: a consumer may ask it for its activated input (request_prep)
 
     @property
     def ptr(self) -> int:
@@ -901,7 +902,8 @@ def ln_residual(plan: Plan, y: Act, g: torch.Tensor, out: Act, *, beta=None, res
     return p
 
 
-ROWCHAIN = int(_os.environ.get("IMAGEN_ROWCHAIN", "1"))   # A/B switch: the token chains of the <= 32^2 levels as one ROWCHAIN launch each (0: the launch-per-op plan)
+ROWCHAIN = int(_os.environ.get("IMAGEN_ROWCHAIN", "2"))   # A/B switch: 0 = the launch-per-op plan; 1 = the token chains of the <= 32^2 levels as one ROWCHAIN
+                                                           # launch each; 2 (default) = also the res_conv + gate tails of the big-tile levels (RESPREP)
 CHAIN_TILE64_MIN_ROWS = 16384    # 64-row tiles (every weight fragment feeds two MFMAs) once that still gives one workgroup per CU
 
 
@@ -970,6 +972,49 @@ def rowchain_qkv(plan: Plan, x: Act, qkv: Act, wqkv: PackedWeight, g_norm, khat:
                      w0=wqkv.w.data_ptr(), g0=g_norm.data_ptr(), mu=ptr(mu), rs=ptr(rs), khat=khat.data_ptr(), vt=vt.data_ptr(),
                      k_scale=k_scale.data_ptr(), C=C, inner=inner, heads=heads, r0=r0, k_bs=k_strides[0], k_hs=k_strides[1], k_rs=k_strides[2],
                      vt_bs=vt_strides[0], vt_hs=vt_strides[1], vt_ds=vt_strides[2], w_cout_pad0=wqkv.Cout_pad)
+
+
+def resprep_ok(x: Act, skip: Optional[Act], w: PackedWeight, N: int) -> bool:
+    """Shapes ROWCHAIN mode RESPREP takes: a 1x1 res_conv of 32-channel chunks (<= 512 input channels) to a power-of-two 128 | 256 output channels."""
+    C2 = skip.C if skip is not None else 0
+    return bool(ROWCHAIN >= 2 and w.KH == 1 and w.KW == 1 and not w.split and x.C % 32 == 0 and C2 % 32 == 0 and w.Cin_pad == x.C + C2 <= 512
+                and w.Cout in (128, 256) and N % 32 == 0 and x.ld * x.H * x.W == x.bs and (skip is None or skip.ld * skip.H * skip.W == skip.bs))
+
+
+def rowchain_resprep(plan: Plan, x: Act, skip: Optional[Act], addend: Act, gate: Optional[torch.Tensor], out: Act, w: PackedWeight, *, rows_per_batch: int,
+                     ssq_out: torch.Tensor, label: str = ""):
+    """The tail of a ResnetBlock with a res_conv — out = h * gate + res_conv(concat(x, skip)) (ip.py:741, 753-757) — as a ROWCHAIN launch (mode
+    RESPREP) that can also write the NEXT Block's activated input (request_prep): the consumer then needs no ACT_PREP pass."""
+    assert (addend.H * addend.W, addend.C) == (x.H * x.W, w.Cout) and addend.ld * addend.H * addend.W == addend.bs
+    f = dict(w0=w.w.data_ptr(), bias=ptr(w.bias), addend=addend.ptr, gate=ptr(gate), ld_add=addend.ld, gate_stride=w.Cout,
+             ssq_out=ssq_out.data_ptr(), C=w.Cout, inner=x.C, w_cout_pad0=w.Cout_pad)
+    keep = [w.w, w.bias, addend.t, gate, ssq_out]
+    if skip is not None:
+        f.update(x2=skip.ptr, C2=skip.C, ld_x2=skip.ld)
+        keep.append(skip.t)
+    p = _rowchain(plan, ENUMS["IMAGEN_CHAIN_RESPREP"], x, out, rows_per_batch, label or "rowchain.resprep", keep, **f)
+    out.res_op = (p, plan)
+    return p
+
+
+def request_prep(x: Act, skip: Optional[Act], ssq_skip: Optional[torch.Tensor], ssq_wb: float, pa: torch.Tensor) -> Optional[Act]:
+    """Ask the RESPREP launch that produces `x` to also write silu(ChanRMSNorm(concat(x, skip)) * pa) — the next Block's block1 input through its
+    prologue (ACT_PREP's contract) — and return that tensor; None if x has no such producer, it already serves another consumer, or the
+    statistics of `skip` are not in memory yet (they would have to be computed by a launch BEHIND the producer)."""
+    op = getattr(x, "res_op", None)
+    if op is None:
+        return None
+    p, plan = op
+    C2 = skip.C if skip is not None else 0
+    if p.prep_out or x.ld != x.C or (skip is not None and (ssq_skip is None or skip.C % 8 or skip.C > 256 or skip.ld * skip.H * skip.W != skip.bs)):
+        return None
+    xa = new_act(x.B, x.H, x.W, x.C + C2, x.t.device)
+    p.prep_out, p.ld_prep, p.prep_pa, p.prep_ssq_wb = xa.ptr, xa.ld, pa.data_ptr(), float(ssq_wb)
+    plan.keep += [xa.t, pa]
+    if skip is not None:
+        p.prep_x2, p.prep_C2, p.ld_prep_x2, p.prep_ssq_b = skip.ptr, skip.C, skip.ld, ssq_skip.data_ptr()
+        plan.keep += [skip.t, ssq_skip]
+    return xa
 
 
 def select_rows(plan: Plan, a: torch.Tensor, nul: torch.Tensor, mask: Optional[torch.Tensor], src: torch.Tensor, keep: torch.Tensor,

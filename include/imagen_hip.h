@@ -440,9 +440,14 @@ typedef struct ImagenMemset32Params { void* dst; uint32_t value; int32_t count; 
  *   mode 3, QKV  (ip.py:521-561; replaces (ROWSTAT ->) qkv IGEMM -> KV_PREP of the self-attention rows):
  *        y   = fp16(fp16((x - mean x) * rstd x * g0) [Wq | Wkv]^T)    [rows][heads * 64 + 128];  out[r, : heads * 64] = q
  *        K^[b, r0 + n, :] = fp16(k / max(|k|, 1e-12) * k_scale),  V^T[b, :, r0 + n] = v      (KV_PREP's contract, one shared k / v head)
- * Weights: imagen_pack_igemm_weights() buffers of 1x1 layers with Cin % 32 == 0 (w_cout_pad* = their Cout_pad), bias-free.
- * Launcher limits: heads * 64 == 512, C % 32 == 0, 32 <= C <= 256, hidden % 32 == 0, hidden <= 512; tile = 64 rows when `tile64`. */
-enum { IMAGEN_CHAIN_FF = 1, IMAGEN_CHAIN_XATTN = 2, IMAGEN_CHAIN_QKV = 3 };
+ *   mode 4, RESPREP (ip.py:741, 753-757 + the NEXT block's 683-690; replaces the up path's res_conv IGEMM -> the next Block's ACT_PREP):
+ *        out = fp16(concat(x, x2) Wres^T + bias + addend * gate[b, :]) ;   (gate NULL: + addend)  ssq_out[r] = sum_c out^2            the ResnetBlock's `h * gate + res_conv(x)`
+ *        prep_out[r, :] = fp16(silu(concat(out, prep_x2)[r, :] * rsqrt(max(ssq_out[r] + prep_ssq_wb * prep_ssq_b[r], 1e-24)) * prep_pa[:]))   (optional:
+ *        ACT_PREP's contract with pstride 0 — the next Block's ChanRMSNorm over ITS concatenated input -> SiLU, written by the producer of `out`)
+ * Weights: imagen_pack_igemm_weights() buffers of 1x1 layers with Cin % 32 == 0 (w_cout_pad* = their Cout_pad), bias-free but RESPREP's.
+ * Launcher limits: modes 1-3: heads * 64 == 512; C (the layer width / RESPREP's Cout) a power of two in 32 .. 256, hidden a power of two <= 512;
+ * RESPREP: C1 + C2 <= 512 in 32-channel chunks, prep_C2 % 8 == 0; tile = 64 rows when `tile64`. */
+enum { IMAGEN_CHAIN_FF = 1, IMAGEN_CHAIN_XATTN = 2, IMAGEN_CHAIN_QKV = 3, IMAGEN_CHAIN_RESPREP = 4 };
 typedef struct ImagenRowchainParams {
   const void* x; const void* res; void* out;
   const void* w0; const void* w1; const void* w2;      /* FF: W_out, W1, W2;  XATTN: Wq, W_out;  QKV: [Wq | Wkv] */
@@ -451,13 +456,18 @@ typedef struct ImagenRowchainParams {
   void* khat; void* vt;                                 /* XATTN: the site's K^ / V^T operand buffers (read);  QKV: the buffers to fill */
   const float* q_scale; const float* k_scale;
   float* ssq_out;
+  /* RESPREP: x2 = the second (skip) input of the GEMM, bias [C], addend rows [rows][C] with gate [B][C] (gate NULL: 1); prep_*: the next Block's
+   * second input rows, its per-row sum of squares, the per-channel gain [C + prep_C2] and the activated output rows [rows][C + prep_C2] */
+  const void* x2; const float* bias; const void* addend; const float* gate;
+  const void* prep_x2; const float* prep_ssq_b; const float* prep_pa; void* prep_out;
   int32_t mode, rows, rows_per_batch, C, inner, hidden, heads, J;
   int32_t ld_x, ld_res, ld_out;
   int32_t k_bs, k_hs, k_rs, vt_bs, vt_hs, vt_ds;        /* operand buffer strides (elements), as ImagenAttentionParams / ImagenKvPrepParams */
   int32_t r0;                                           /* QKV: first key row of the tile rows' keys (behind the context and null rows) */
   int32_t w_cout_pad0, w_cout_pad1, w_cout_pad2;
   int32_t tile64;                                       /* 1: 64-row tiles (rows_per_batch % 64 == 0): every weight fragment feeds two MFMAs */
-  float eps, q_mult;
+  int32_t C2, ld_x2, ld_add, gate_stride, prep_C2, ld_prep_x2, ld_prep;   /* RESPREP (inner = C1, the channels of x) */
+  float eps, q_mult, prep_ssq_wb;
 } ImagenRowchainParams;
 
 /* one entry of a plan: params_bytes = the caller's sizeof(params struct of `kind`) — checked against imagen_sizeof(kind) on every run, so a binding

@@ -390,8 +390,34 @@ class Interpreter:
             assert bias is None and tuple(wref.shape[:2]) == (cout, cin), (wref.shape, cout, cin)
             return t @ wref[:, :, 0, 0].t()
 
-        x = m.strided(p.x, f16, (rows, inner if p.mode == K["IMAGEN_CHAIN_FF"] else C), (p.ld_x, 1)).float()
         B, n = rows // p.rows_per_batch, p.rows_per_batch
+        if p.mode == K["IMAGEN_CHAIN_RESPREP"]:
+            xin = m.strided(p.x, f16, (rows, inner), (p.ld_x, 1)).float()
+            if p.C2:
+                xin = torch.cat((xin, m.strided(p.x2, f16, (rows, p.C2), (p.ld_x2, 1)).float()), dim=-1)
+            wref, bias = ops.REFERENCE_WEIGHTS[p.w0]
+            v = xin @ wref[:, :inner + p.C2, 0, 0].t()
+            if p.bias:
+                v = v + m.view(p.bias, f32)[:C]
+            if p.addend:
+                gate = m.strided(p.gate, f32, (B, C), (p.gate_stride, 1)).repeat_interleave(n, dim=0) if p.gate else 1.0
+                v = v + m.strided(p.addend, f16, (rows, C), (p.ld_add, 1)).float() * gate
+            out = v.half()
+            m.strided(p.out, f16, (rows, C), (p.ld_out, 1)).copy_(out)
+            ssq = (out.float() ** 2).sum(-1)
+            if p.ssq_out:
+                m.view(p.ssq_out, f32)[:rows].copy_(ssq)
+            if p.prep_out:
+                cat = out.float()
+                tot = ssq.clone()
+                if p.prep_C2:
+                    cat = torch.cat((cat, m.strided(p.prep_x2, f16, (rows, p.prep_C2), (p.ld_prep_x2, 1)).float()), dim=-1)
+                    if p.prep_ssq_b:
+                        tot = tot + p.prep_ssq_wb * m.view(p.prep_ssq_b, f32)[:rows]
+                a = F.silu(cat * torch.rsqrt(tot.clamp(min=1e-24))[:, None] * m.view(p.prep_pa, f32)[:C + p.prep_C2])
+                m.strided(p.prep_out, f16, (rows, C + p.prep_C2), (p.ld_prep, 1)).copy_(a.half())
+            return
+        x = m.strided(p.x, f16, (rows, inner if p.mode == K["IMAGEN_CHAIN_FF"] else C), (p.ld_x, 1)).float()
         if p.mode == K["IMAGEN_CHAIN_FF"]:
             res = m.strided(p.res, f16, (rows, C), (p.ld_res, 1)).float()
             x1 = r16(ln(r16(lin(x, p.w0, inner, C)), p.g0, C) + res)

@@ -334,8 +334,17 @@ def test_unet_plan_with_big_tile_family(reference_weights, monkeypatch):
     from imagen_pytorch_amd import ops
 
     monkeypatch.setattr(ops, "BIG_MIN_WGS", 1)
-    seen = dict(prep=0, self_stat=0, big=0)
-    real_prep, real_igemm = ops.act_prep, ops.igemm
+    seen = dict(prep=0, self_stat=0, big=0, resprep=0, asked=0)
+    real_prep, real_igemm, real_rp, real_req = ops.act_prep, ops.igemm, ops.rowchain_resprep, ops.request_prep
+
+    def resprep(plan, *a, **k):
+        seen["resprep"] += 1
+        return real_rp(plan, *a, **k)
+
+    def request(*a, **k):
+        xa = real_req(*a, **k)
+        seen["asked"] += xa is not None
+        return xa
 
     def prep(plan, *a, **k):
         seen["prep"] += 1
@@ -349,10 +358,15 @@ def test_unet_plan_with_big_tile_family(reference_weights, monkeypatch):
 
     monkeypatch.setattr(ops, "act_prep", prep)
     monkeypatch.setattr(ops, "igemm", igemm)
+    monkeypatch.setattr(ops, "rowchain_resprep", resprep)
+    monkeypatch.setattr(ops, "request_prep", request)
     test_unet_plan_config_sweep("dim32_three_levels", reference_weights)
     assert seen["big"] >= 4 and seen["prep"] >= 2, seen
     test_unet_plan_config_sweep("dim64_three_levels", reference_weights)      # 256-channel blocks: block2's prologue pass reduces its own statistics
     assert seen["self_stat"] >= 1, seen
+    # round 5: on these levels the res_conv + gate tail of an up block is a ROWCHAIN launch (RESPREP), and the block behind it takes its
+    # activated input from that launch instead of an ACT_PREP pass
+    assert seen["resprep"] >= 2 and seen["asked"] >= 1, seen
 
 
 @pytest.mark.parametrize("name", ["cond_images_3", "self_cond_lowres_cond_images_5", "plain_init_conv_no_mid_attn", "memory_efficient_lowres"])

@@ -228,3 +228,61 @@ def test_rowchain_qkv(B, N, C, n_ctx, tile64):
     record_parity(f"rowchain_qkv[{B}x{N}x{C}]", **errs)
     assert max(errs["q"], errs["k"], errs["v"]) < TOL and max(errs["q_pair"], errs["k_pair"], errs["v_pair"]) < 5e-4, errs
     assert not k1[:, :r0].any() and not v1[:, :, :r0].any(), "rows in front of r0 belong to the conditioning: untouched"
+
+
+RP_CASES = [(2, 64, 256, 128, 256, 128), (2, 256, 128, 64, 128, 64), (1, 64, 128, 0, 128, 0), (16, 1024, 256, 128, 256, 128), (16, 4096, 128, 64, 128, 64)]
+
+
+@pytest.mark.parametrize("B,N,C1,C2,C,C2n", RP_CASES)
+def test_rowchain_resprep(B, N, C1, C2, C, C2n, tile64):
+    """res_conv + gate * h tail of a ResnetBlock + the next Block's activated input in one launch vs the IGEMM -> ACT_PREP pair it replaces."""
+    from conftest import EMULATED
+    from imagen_pytorch_amd import ops
+    if EMULATED and B * N > 2048:
+        pytest.skip("the benchmark's row counts: hardware only")
+    if tile64 and N % 64:
+        pytest.skip("64-row tiles need N % 64 == 0")
+    dev = gpu_device()
+    torch.manual_seed(3)
+    x, skip = h16(torch.randn(B, N, C1)), (h16(torch.randn(B, N, C2) * 1.4) if C2 else None)
+    h2 = h16(torch.randn(B, N, C))
+    nskip = h16(torch.randn(B, N, C2n) * 0.8) if C2n else None
+    w = torch.randn(C, C1 + C2) / math.sqrt(C1 + C2)
+    bias = 0.1 * torch.randn(C)
+    gate = torch.sigmoid(torch.randn(B, C))
+    pa = (1 + 0.1 * torch.randn(C + C2n)) * math.sqrt(C + C2n)
+    wb = 0.5
+    cat = torch.cat((x, skip), -1) if C2 else x
+    ref = cat @ h16(w).t() + bias + h2 * gate[:, None, :]
+    pw = ops.pack_weight(w, bias, dev)
+    xa_, h2a = _act(x, dev, B, N), _act(h2, dev, B, N)
+    ska = _act(skip, dev, B, N) if C2 else None
+    nska = _act(nskip, dev, B, N) if C2n else None
+    gd, pad = gate.float().contiguous().to(dev), pa.float().to(dev)
+    nssq = (nskip.float() ** 2).sum(-1).reshape(-1).to(dev) if C2n else None
+    assert ops.resprep_ok(xa_, ska, pw, N)
+    # (a) IGEMM (+ gate * addend) -> ACT_PREP
+    plan = ops.Plan("unfused")
+    outa, ssq_a = ops.new_act(B, 1, N, C, dev), torch.empty(B * N, device=dev)
+    opa = ops.igemm(plan, xa_, pw, outa, x2=ska, addend=h2a, gate=gd, ssq_out=ssq_a)
+    ya = ops.new_act(B, 1, N, C + C2n, dev)
+    if opa.ssq_emitted:
+        ops.act_prep(plan, outa, ya, x2=nska, ssq_a=ssq_a, ssq_b=nssq, ssq_wb=wb, pa=pad, act_in=ops.ACT_SILU)
+    else:
+        ops.act_prep(plan, outa, ya, x2=nska, ssq_b=nssq, ssq_wb=wb, pa=pad, act_in=ops.ACT_SILU, self_stat=True)
+    plan.run()
+    # (b) one ROWCHAIN launch
+    chain = ops.Plan("chain")
+    outb, ssq_b = ops.new_act(B, 1, N, C, dev), torch.empty(B * N, device=dev)
+    ops.rowchain_resprep(chain, xa_, ska, h2a, gd, outb, pw, rows_per_batch=N, ssq_out=ssq_b)
+    yb = ops.request_prep(outb, nska, nssq, wb, pad)
+    assert yb is not None and ops.request_prep(outb, nska, nssq, wb, pad) is None      # one consumer per producer
+    chain.run()
+    _sync()
+    of = outb.t.reshape(B, N, C).float().cpu()
+    tot = (of ** 2).sum(-1) + (wb * (nskip ** 2).sum(-1) if C2n else 0.0)
+    ref_y = F.silu((torch.cat((of, nskip), -1) if C2n else of) * torch.rsqrt(tot)[..., None] * pa)
+    errs = dict(out=nerr(of, ref), out_pair=nerr(outb.t, outa.t), prep=nerr(yb.t.reshape(B, N, -1), ref_y), prep_pair=nerr(yb.t, ya.t))
+    record_parity(f"rowchain_resprep[{B}x{N} {C1}+{C2}->{C}|{C2n}]", **errs)
+    assert errs["out"] < TOL and errs["prep"] < TOL and errs["out_pair"] < 5e-4 and errs["prep_pair"] < 1e-3, errs
+    assert nerr(ssq_b, (of ** 2).sum(-1).reshape(-1)) < 1e-5

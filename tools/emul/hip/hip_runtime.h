@@ -158,6 +158,7 @@ hipError_t hipGraphDestroy(hipGraph_t);
 hipError_t hipGraphLaunch(hipGraphExec_t, hipStream_t);
 hipError_t hipGraphExecDestroy(hipGraphExec_t);
 static inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
+static inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { memset(p, v, n); return hipSuccess; }
 enum { hipStreamNonBlocking = 1 };
 static inline hipError_t hipStreamCreateWithFlags(hipStream_t* s, int) { *s = nullptr; return hipSuccess; }
 static inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
