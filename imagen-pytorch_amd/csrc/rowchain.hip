@@ -26,7 +26,9 @@ namespace {
 constexpr int kThreads = 512;
 constexpr int kDh = 64;
 #ifndef ROWCHAIN_RING
-#define ROWCHAIN_RING 16      // A fragments in flight per wave (tools/chain_bench.py builds variants with -DROWCHAIN_RING=4 | 8)
+#define ROWCHAIN_RING 8       // A fragments in flight per wave.  Call C (profiles/r05_c_chain_bench_variants.jsonl: every chain shape of the benchmark, 4 / 8 / 16
+                              // deep, one or two workgroups per CU, the round's first kernel beside them): 8 is best or within 1 us of the best on 17 of
+                              // 20 shapes; 16 costs the 16384-row launches 20-30 % (registers), 4 the small grids 5-15 % (tools/chain_bench.py builds the variants)
 #endif
 #ifndef ROWCHAIN_MINW
 #define ROWCHAIN_MINW 1       // minimum waves per SIMD the register allocation leaves room for (4: two 512-thread workgroups per CU)
@@ -118,11 +120,10 @@ __device__ __forceinline__ void acc_zero(f32x16 (*acc)[RB]) {
       for (int r = 0; r < 16; ++r) acc[t][j][r] = 0.f;
 }
 
-// ---- the weight stream of a GEMM stage.  A wave's A fragments are 16-byte loads from the packed weight buffer; sixteen of them (16 K
-// steps of one cout tile, or 8 of two) are kept in flight in a register ring.  The weights are cold when a launch starts (last touched a
-// whole denoiser step ago: Infinity Cache / HBM latency, ~0.5 us a round trip), so the ring depth IS the stage's speed on the small
-// grids of the 8^2 / 16^2 levels (round-5 call A: four steps ahead made a 32-step stage 8 dependent round trips), and the ring of the
-// NEXT stage is requested before the current stage's row pass and barriers (fill and run are separate calls).
+// ---- the weight stream of a GEMM stage.  A wave's A fragments are 16-byte loads from the packed weight buffer; kRing of them (8 K steps of
+// one cout tile, or 4 of two) are kept in flight in a register ring, and the ring of the NEXT stage is requested before the current stage's
+// row pass and barriers (fill and run are separate calls): the weights are cold when a launch starts (last touched a whole denoiser step
+// ago).  Measured (call C): the depth matters little — a chain is ~7 dependent phases of 1.5-3 us each, whatever feeds the matrix pipe.
 // Addressing: a wave-uniform byte offset (cout tile, K step: scalar registers) + ONE 32-bit per-lane offset that never changes — the loads
 // then take their base from SGPRs and the whole ring costs a single address VGPR (64-bit per-load addresses cost 2 x 16 of them).
 struct WeightStream {

@@ -974,9 +974,15 @@ def rowchain_qkv(plan: Plan, x: Act, qkv: Act, wqkv: PackedWeight, g_norm, khat:
                      vt_bs=vt_strides[0], vt_hs=vt_strides[1], vt_ds=vt_strides[2], w_cout_pad0=wqkv.Cout_pad)
 
 
+RESPREP_MAX_ROWS = 16384   # (call C: at 65536 rows — unet2's 64^2 level, 92 MB a launch — the one-tile-per-workgroup chain runs at 2 TB/s, 45 us against
+                           # 34 for the streaming res_conv + ACT_PREP pair; at 16384 rows it is 22 against 33)
+
+
 def resprep_ok(x: Act, skip: Optional[Act], w: PackedWeight, N: int) -> bool:
     """Shapes ROWCHAIN mode RESPREP takes: a 1x1 res_conv of 32-channel chunks (<= 512 input channels) to a power-of-two 128 | 256 output channels."""
     C2 = skip.C if skip is not None else 0
+    if x.rows > RESPREP_MAX_ROWS:
+        return False
     return bool(ROWCHAIN >= 2 and w.KH == 1 and w.KW == 1 and not w.split and x.C % 32 == 0 and C2 % 32 == 0 and w.Cin_pad == x.C + C2 <= 512
                 and w.Cout in (128, 256) and N % 32 == 0 and x.ld * x.H * x.W == x.bs and (skip is None or skip.ld * skip.H * skip.W == skip.bs))
 

@@ -69,3 +69,16 @@ def test_emulated_whole_library_runs_gpu_tests():
                         "-q", "-m", "gpu", "-k", sel, "-p", "no:cacheprovider"], env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=1500)
     out = r.stdout.decode()
     assert r.returncode == 0 and " passed" in out and "failed" not in out and "skipped" not in out.splitlines()[-1], out[-3000:]
+
+
+@pytest.mark.skipif(not os.path.exists(CLANG), reason="host clang of the ROCm toolchain not present")
+def test_emulated_rowchain_kernels():
+    """Round 5: csrc/rowchain.hip — the four chains, 32- and 64-row tiles, the K-split layers — on the emulation in a child pytest, against
+    the launch-per-op plans they replace and fp32 torch (tests/test_rowchain_gpu.py; the benchmark-sized cases are hardware-only)."""
+    env = dict(os.environ, IMAGEN_LIB_PATH=_lib(""), IMAGEN_EMUL_TESTS="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_rowchain_gpu.py"), "-q", "-m", "gpu", "-p", "no:cacheprovider"],
+                       env=env, cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=900)
+    out = r.stdout.decode()
+    assert r.returncode == 0 and "failed" not in out, out[-3000:]
+    passed = int(out.split(" passed")[0].split()[-1])
+    assert passed >= 24, out[-800:]

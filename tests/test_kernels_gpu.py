@@ -242,7 +242,7 @@ def test_igemm_res_conv_gate_addend(ops, dev):
 
 # ------------------------------------------------------------------------------------------------ attention
 
-ATTN_TOL_BOUNDED = 2e-3   # (set from the measured figures of the round's first GPU call)
+ATTN_TOL_BOUNDED = 1e-3   # (round 5, call A: 5.4e-4 at worst over the parametrisation, init-sized and sd = 0.2 scale draws alike)
 ATTN_ERR = [0.0, 0.0]   # worst measured error over the parametrisation: [init-sized scales (bounded tiling), sd = 0.2 scale draws]
 
 
@@ -296,13 +296,12 @@ def test_attention(ops, dev, B, heads, rows, J, shared, fused_qnorm, D, bounded)
     assert pa.softmax_mode == int(bool(bounded))
     _run(plan)
     e = nerr(o, ref)
-    # bounded / init-sized scale vectors (every README / BASELINE configuration): the per-op bar.  The sd = 0.2 draws put logits at 8 * 1.44 and
-    # beyond, where the fp16 rounding of the unit-norm operands alone moves the softmax weights by ~1e-3: those cases keep 2e-3
-    tol = ATTN_TOL_BOUNDED if bounded else 2e-3
+    # the per-op bar of every other kernel test (round 4 asserted 2e-3 here and nobody had looked at the measured figure: 5.4e-4)
+    tol = ATTN_TOL_BOUNDED
     ATTN_ERR[0] = max(ATTN_ERR[0], e) if bounded else ATTN_ERR[0]
     ATTN_ERR[1] = ATTN_ERR[1] if bounded else max(ATTN_ERR[1], e)
     from conftest import record_parity
-    record_parity("attention", worst_bounded_scales=ATTN_ERR[0], worst_wide_scales=ATTN_ERR[1], tol_bounded=ATTN_TOL_BOUNDED, tol_wide=2e-3)
+    record_parity("attention", worst_bounded_scales=ATTN_ERR[0], worst_wide_scales=ATTN_ERR[1], tol=ATTN_TOL_BOUNDED)
     assert e < tol, f"attention normwise error {e:.2e}"
 
 

@@ -260,7 +260,7 @@ def test_rowchain_resprep(B, N, C1, C2, C, C2n, tile64):
     nska = _act(nskip, dev, B, N) if C2n else None
     gd, pad = gate.float().contiguous().to(dev), pa.float().to(dev)
     nssq = (nskip.float() ** 2).sum(-1).reshape(-1).to(dev) if C2n else None
-    assert ops.resprep_ok(xa_, ska, pw, N)
+    assert ops.resprep_ok(xa_, ska, pw, N) == (B * N <= ops.RESPREP_MAX_ROWS)      # (the planner's row limit; the kernel takes every case)
     # (a) IGEMM (+ gate * addend) -> ACT_PREP
     plan = ops.Plan("unfused")
     outa, ssq_a = ops.new_act(B, 1, N, C, dev), torch.empty(B * N, device=dev)
