@@ -35,6 +35,18 @@ constexpr int kDh = 64;
 #endif
 constexpr int kRing = ROWCHAIN_RING;
 
+// -DROWCHAIN_TRACE (tools/chain_bench.py --trace, a throw-away variant library: never in the product build): thread 0 of every workgroup
+// stamps s_memtime at the phase boundaries into a buffer handed over by imagen_debug_rowchain_trace()
+#ifdef ROWCHAIN_TRACE
+__device__ unsigned long long* g_rowchain_trace = nullptr;
+#define RC_STAMP(i)                                                                                                  \
+  do {                                                                                                               \
+    if (threadIdx.x == 0 && g_rowchain_trace) g_rowchain_trace[(size_t)blockIdx.x * 16 + (i)] = __builtin_amdgcn_s_memtime(); \
+  } while (0)
+#else
+#define RC_STAMP(i) ((void)0)
+#endif
+
 struct Geo {           // LDS geometry of a launch (launcher and kernel agree through this)
   int p0_cols, p1_cols, p2_cols;
   __host__ __device__ static int pitch(int cols) { return (cols + 8) * 2; }
@@ -62,9 +74,21 @@ __host__ __device__ inline Geo chain_geo(const ImagenRowchainParams& p) {
   return g;
 }
 
-__host__ __device__ inline size_t chain_lds_bytes(const ImagenRowchainParams& p, int rows) {
+// behind the row tiles: the per-channel gain vectors of the chain (fp32: g0 | g1 | g2 | q_scale or k_scale) and, for the cross-attention, every
+// wave's private K^ / V^T staging of one 32-key tile of its head
+constexpr int kGainG1 = 256, kGainG2 = 512, kGainQs = 1024, kGainFloats = 1088;
+constexpr int kKPitch = 136, kVPitch = 72;                 // bytes per staged K^ row (64 dims) / V^T row (32 keys): conflict-free ds_read_b64
+constexpr int kKvWave = 32 * kKPitch + 64 * kVPitch;       // 8960 bytes per wave
+
+__host__ __device__ inline size_t chain_tiles_bytes(const ImagenRowchainParams& p, int rows) {
   const Geo g = chain_geo(p);
-  size_t n = (size_t)rows * Geo::pitch(g.p0_cols) + (size_t)rows * Geo::pitch(g.p1_cols) + (g.p2_cols ? (size_t)rows * Geo::pitch(g.p2_cols) : 0);
+  return (size_t)rows * Geo::pitch(g.p0_cols) + (size_t)rows * Geo::pitch(g.p1_cols) + (g.p2_cols ? (size_t)rows * Geo::pitch(g.p2_cols) : 0);
+}
+
+__host__ __device__ inline size_t chain_lds_bytes(const ImagenRowchainParams& p, int rows) {
+  size_t n = chain_tiles_bytes(p, rows);
+  if (p.mode != IMAGEN_CHAIN_RESPREP) n += kGainFloats * sizeof(float);
+  if (p.mode == IMAGEN_CHAIN_XATTN) n += (size_t)8 * kKvWave;
   if (p.mode == IMAGEN_CHAIN_RESPREP) {
     n += (size_t)2 * p.C * sizeof(float);
     const int T = p.C >> 5, ks = (p.inner + p.C2) >> 4;
@@ -278,6 +302,21 @@ __device__ __forceinline__ void row_ln_stats(const char* row, int C, int li, flo
   rstd = rsqrtf(row_sum<LPR>(q) / (float)C + eps);
 }
 
+// the chain's gain vectors -> LDS (visible behind the next workgroup barrier): the row passes then read them without a global round trip
+__device__ __forceinline__ float* stage_gains(const ImagenRowchainParams& p, char* smem, size_t tiles_bytes, int tid) {
+  float* sg = reinterpret_cast<float*>(smem + tiles_bytes);
+  const int C = p.C;
+  for (int i = tid; i < kGainFloats; i += kThreads) {
+    float v = 0.f;
+    if (i < kGainG1) v = i < C ? p.g0[i] : 0.f;
+    else if (i < kGainG2) v = (p.g1 && i - kGainG1 < C) ? p.g1[i - kGainG1] : 0.f;
+    else if (i < kGainQs) v = (p.g2 && i - kGainG2 < p.hidden) ? p.g2[i - kGainG2] : 0.f;
+    else v = p.q_scale ? p.q_scale[i - kGainQs] : (p.k_scale ? p.k_scale[i - kGainQs] : 0.f);
+    sg[i] = v;
+  }
+  return sg;
+}
+
 // this thread's pieces (8 channels each) of row r = tid / LPR of a [rows][C] global tensor, C <= 256: pieces li, li + LPR, ... (at most PMAX)
 template <int RB>
 struct RowPieces {
@@ -304,6 +343,13 @@ __device__ __forceinline__ void ln_rows_to_lds(const ImagenRowchainParams& p, co
   constexpr int LPR = RowPieces<RB>::LPR, PMAX = RowPieces<RB>::PMAX;
   const int r = tid / LPR, li = tid % LPR;
   const int C = p.C, np = C >> 3;
+  float4 ga[PMAX][2];     // the gain of this thread's pieces: requested with the rows, one round trip
+#pragma unroll
+  for (int k = 0; k < PMAX; ++k) {
+    const int g = li + k * LPR < np ? li + k * LPR : 0;
+    ga[k][0] = *reinterpret_cast<const float4*>(p.g0 + g * 8);
+    ga[k][1] = *reinterpret_cast<const float4*>(p.g0 + g * 8 + 4);
+  }
   float mean, rstd;
   if (p.mu) {
     mean = p.mu[row0 + r];
@@ -332,9 +378,10 @@ __device__ __forceinline__ void ln_rows_to_lds(const ImagenRowchainParams& p, co
   for (int k = 0; k < PMAX; ++k) {
     const int g = li + k * LPR;
     if (g < np) {
+      const float gv[8] = {ga[k][0].x, ga[k][0].y, ga[k][0].z, ga[k][0].w, ga[k][1].x, ga[k][1].y, ga[k][1].z, ga[k][1].w};
       f16x8 o;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) o[e] = (f16)(((float)rp.v[k][e] - mean) * rstd * p.g0[g * 8 + e]);
+      for (int e = 0; e < 8; ++e) o[e] = (f16)(((float)rp.v[k][e] - mean) * rstd * gv[e]);
       *reinterpret_cast<f16x8*>(drow + g * 16) = o;
     }
   }
@@ -415,25 +462,40 @@ __device__ __forceinline__ void chain_ff(const ImagenRowchainParams& p, char* sm
   f16x8 ring[kRing];
   f32x16 acc[2][RB];
   // ---- every request that depends on nothing: the out-projection's first weights, the residual rows, the o rows
+  RC_STAMP(0);
   const Part q0 = make_part(C >> 5, inner >> 4, wave);
   stage_fill(ring, q0, p.w0, p.w_cout_pad0, lane);
   RowPieces<RB> res;
   load_row_pieces<RB>(res, p.res, p.ld_res, row0 + r, C, li);
-  {
+  {   // the o rows: every piece of this thread requested before the first is stored (inner == 512: 4 RB pieces per thread)
+    constexpr int NP = 4 * RB;
     const int npr = inner >> 3;
     const f16* x = reinterpret_cast<const f16*>(p.x);
-    for (int i = tid; i < ROWS * npr; i += kThreads) {
-      const int rr = i / npr, g = i - rr * npr;
-      *reinterpret_cast<uint4*>(P0 + (size_t)rr * pitch0o + g * 16) = *reinterpret_cast<const uint4*>(x + (size_t)(row0 + rr) * p.ld_x + g * 8);
+    uint4 t[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const int i = tid + k * kThreads, rr = i / npr, g = i - rr * npr;
+      t[k] = *reinterpret_cast<const uint4*>(x + (size_t)(row0 + rr) * p.ld_x + g * 8);
+    }
+    const float* sg0 = stage_gains(p, smem, chain_tiles_bytes(p, ROWS), tid);
+    (void)sg0;
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const int i = tid + k * kThreads, rr = i / npr, g = i - rr * npr;
+      *reinterpret_cast<uint4*>(P0 + (size_t)rr * pitch0o + g * 16) = t[k];
     }
   }
+  const float* sg = reinterpret_cast<const float*>(smem + chain_tiles_bytes(p, ROWS));
   __syncthreads();
+  RC_STAMP(1);
   // ---- y = o W_out^T -> P1 (fp16)
   stage_run<RB>(acc, ring, q0, p.w0, p.w_cout_pad0, P0, pitch0o, P0, lane);
+  RC_STAMP(2);
   store_stage<IMAGEN_ACT_NONE, RB>(acc, q0, P1, pitch1, lane);
   const Part q1 = make_part(hidden >> 5, C >> 4, wave);
   stage_fill(ring, q1, p.w1, p.w_cout_pad1, lane);          // (in flight across the barrier and the row pass)
   __syncthreads();
+  RC_STAMP(3);
   // ---- row pass: x1 = fp16(LN(y) * g0 + res) -> P2;  a0 = fp16((x1 - mean x1) * rstd x1 * g1) -> P1
   {
     const int np = C >> 3;
@@ -450,7 +512,7 @@ __device__ __forceinline__ void chain_ff(const ImagenRowchainParams& p, char* sm
         const f16x8 v = *reinterpret_cast<const f16x8*>(yrow + g * 16);
 #pragma unroll
         for (int e = 0; e < 8; ++e) {
-          x1[k][e] = (f16)(((float)v[e] - mean) * rstd * p.g0[g * 8 + e] + (float)res.v[k][e]);
+          x1[k][e] = (f16)(((float)v[e] - mean) * rstd * sg[g * 8 + e] + (float)res.v[k][e]);
           so += (float)x1[k][e];
         }
         *reinterpret_cast<f16x8*>(xrow + g * 16) = x1[k];
@@ -473,18 +535,21 @@ __device__ __forceinline__ void chain_ff(const ImagenRowchainParams& p, char* sm
       if (g < np) {
         f16x8 a;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) a[e] = (f16)(((float)x1[k][e] - mo) * ro * p.g1[g * 8 + e]);
+        for (int e = 0; e < 8; ++e) a[e] = (f16)(((float)x1[k][e] - mo) * ro * sg[kGainG1 + g * 8 + e]);
         *reinterpret_cast<f16x8*>(yrow + g * 16) = a;
       }
     }
   }
   __syncthreads();
+  RC_STAMP(4);
   // ---- hid = fp16(gelu(a0 W1^T)) -> P0
   stage_run<RB>(acc, ring, q1, p.w1, p.w_cout_pad1, P1, pitch1, P0, lane);
+  RC_STAMP(5);
   store_stage<IMAGEN_ACT_GELU, RB>(acc, q1, P0, pitch0h, lane);
   const Part q2 = make_part(C >> 5, hidden >> 4, wave);
   stage_fill(ring, q2, p.w2, p.w_cout_pad2, lane);
   __syncthreads();
+  RC_STAMP(6);
   // ---- row pass: a1 = fp16((hid - mean) * rstd * g2), in place
   {
     const int np = hidden >> 3;
@@ -495,13 +560,15 @@ __device__ __forceinline__ void chain_ff(const ImagenRowchainParams& p, char* sm
       const f16x8 v = *reinterpret_cast<const f16x8*>(hrow + g * 16);
       f16x8 a;
 #pragma unroll
-      for (int e = 0; e < 8; ++e) a[e] = (f16)(((float)v[e] - mean) * rstd * p.g2[g * 8 + e]);
+      for (int e = 0; e < 8; ++e) a[e] = (f16)(((float)v[e] - mean) * rstd * sg[kGainG2 + g * 8 + e]);
       *reinterpret_cast<f16x8*>(hrow + g * 16) = a;
     }
   }
   __syncthreads();
+  RC_STAMP(7);
   // ---- out = fp16(a1 W2^T + x1) -> P1 -> global
   stage_run<RB>(acc, ring, q2, p.w2, p.w_cout_pad2, P0, pitch0h, P0, lane);
+  RC_STAMP(8);
   if (q2.kpart == 0) {
     const int half = lane >> 5, l31 = lane & 31;
 #pragma unroll
@@ -520,6 +587,7 @@ __device__ __forceinline__ void chain_ff(const ImagenRowchainParams& p, char* sm
   }
   store_stage<IMAGEN_ACT_NONE, RB>(acc, q2, P1, pitch1, lane);
   __syncthreads();
+  RC_STAMP(9);
   {
     const int np = C >> 3;
     const char* srow = P1 + (size_t)r * pitch1;
@@ -534,6 +602,7 @@ __device__ __forceinline__ void chain_ff(const ImagenRowchainParams& p, char* sm
     ssq = row_sum<LPR>(ssq);
     if (p.ssq_out && li == 0) p.ssq_out[row0 + r] = ssq;
   }
+  RC_STAMP(10);
 }
 
 // ------------------------------------------------------------------------------------------------ mode 2: XATTN
@@ -544,30 +613,60 @@ struct KvTile {
   f16x8 v[2][2];   // [K step s][32-dim block db]: dim 32 db + l31, keys 32 kt + 16 s + 4 half + {0..3, 8..11}
 };
 
-__device__ __forceinline__ f16x8 two_pieces(const f16* ptr) {
+// The tile travels global -> registers (16-byte pieces, consecutive lanes on consecutive addresses) -> the wave's private LDS staging -> fragments
+// (two ds_read_b64 each).  Round 5, call D (profiles/r05_d_rowchain_phase_timeline.json): with the fragments taken straight from global memory
+// — 8-byte pieces of 32 different rows per load instruction — the attention of a 32-row block took 17.6k cycles, a third of the launch: the
+// CU's address coalescer serves one cache line per cycle, and 8 waves x 32 instructions x 32 lines is 16k of them.
+struct KvRegs { uint4 k[4], v[4]; };
+
+__device__ __forceinline__ void kv_request(KvRegs& r, const ImagenRowchainParams& p, int b, int hd, int kt, int lane) {
+  const f16* kg = reinterpret_cast<const f16*>(p.khat) + (size_t)b * p.k_bs + (size_t)hd * p.k_hs + (size_t)(32 * kt) * p.k_rs;
+  const f16* vg = reinterpret_cast<const f16*>(p.vt) + (size_t)b * p.vt_bs + (size_t)hd * p.vt_hs + 32 * kt;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + 64 * i;
+    r.k[i] = *reinterpret_cast<const uint4*>(kg + (size_t)(c >> 3) * p.k_rs + (c & 7) * 8);      // key c / 8, dims 8 (c % 8) ..
+    r.v[i] = *reinterpret_cast<const uint4*>(vg + (size_t)(c >> 2) * p.vt_ds + (c & 3) * 8);     // dim c / 4, keys 8 (c % 4) ..
+  }
+}
+
+__device__ __forceinline__ void kv_stage(const KvRegs& r, char* kvs, int lane) {
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int c = lane + 64 * i;
+    uint2* kd = reinterpret_cast<uint2*>(kvs + (c >> 3) * kKPitch + (c & 7) * 16);
+    kd[0] = make_uint2(r.k[i].x, r.k[i].y);
+    kd[1] = make_uint2(r.k[i].z, r.k[i].w);
+    uint2* vd = reinterpret_cast<uint2*>(kvs + 32 * kKPitch + (c >> 2) * kVPitch + (c & 3) * 16);
+    vd[0] = make_uint2(r.v[i].x, r.v[i].y);
+    vd[1] = make_uint2(r.v[i].z, r.v[i].w);
+  }
+}
+
+__device__ __forceinline__ f16x8 two_pieces(const char* ptr) {
   const uint2 lo = *reinterpret_cast<const uint2*>(ptr);
-  const uint2 hi = *reinterpret_cast<const uint2*>(ptr + 8);
+  const uint2 hi = *reinterpret_cast<const uint2*>(ptr + 16);
   uint4 pk = make_uint4(lo.x, lo.y, hi.x, hi.y);
   return *reinterpret_cast<const f16x8*>(&pk);
 }
 
-__device__ __forceinline__ void load_kv_tile(KvTile& kv, const ImagenRowchainParams& p, int b, int hd, int kt, int lane) {
+__device__ __forceinline__ void kv_frags(KvTile& kv, const char* kvs, int lane) {
   const int half = lane >> 5, l31 = lane & 31;
-  const f16* krow = reinterpret_cast<const f16*>(p.khat) + (size_t)b * p.k_bs + (size_t)hd * p.k_hs + (size_t)(32 * kt + l31) * p.k_rs + 4 * half;
-  const f16* vg = reinterpret_cast<const f16*>(p.vt) + (size_t)b * p.vt_bs + (size_t)hd * p.vt_hs + 32 * kt + 4 * half;
+  const char* krow = kvs + l31 * kKPitch + 8 * half;
+  const char* vbase = kvs + 32 * kKPitch + 8 * half;
 #pragma unroll
   for (int t = 0; t < 2; ++t)
 #pragma unroll
-    for (int s = 0; s < 2; ++s) kv.k[t][s] = two_pieces(krow + 32 * t + 16 * s);
+    for (int s = 0; s < 2; ++s) kv.k[t][s] = two_pieces(krow + (32 * t + 16 * s) * 2);
 #pragma unroll
   for (int s = 0; s < 2; ++s)
 #pragma unroll
-    for (int db = 0; db < 2; ++db) kv.v[s][db] = two_pieces(vg + (size_t)(32 * db + l31) * p.vt_ds + 16 * s);
+    for (int db = 0; db < 2; ++db) kv.v[s][db] = two_pieces(vbase + (32 * db + l31) * kVPitch + 32 * s);
 }
 
 // Q^ of this lane's row from the wave's two q accumulator tiles (dims 0-31 | 32-63 of the head): fp16(q) -> l2norm * q_scale * q_mult
 // (ATTENTION's fused QNORM), as B fragments in the accumulator's own dim order: fragment (t, s), element e <-> dim 32 t + 16 s + 4 half + (e & 3) + 8 (e >> 2)
-__device__ __forceinline__ void make_qhat(f16x8 (&qf)[2][2], const ImagenRowchainParams& p, const f32x16& q0, const f32x16& q1, int lane) {
+__device__ __forceinline__ void make_qhat(f16x8 (&qf)[2][2], const ImagenRowchainParams& p, const float* s_qscale, const f32x16& q0, const f32x16& q1, int lane) {
   const int half = lane >> 5;
   f16 q16[2][16];
   float ssq = 0.f;
@@ -584,7 +683,7 @@ __device__ __forceinline__ void make_qhat(f16x8 (&qf)[2][2], const ImagenRowchai
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int d = 32 * t + 8 * (r >> 2) + 4 * half + (r & 3);
-      qf[t][r >> 3][r & 7] = (f16)((float)q16[t][r] * inv * p.q_scale[d]);
+      qf[t][r >> 3][r & 7] = (f16)((float)q16[t][r] * inv * s_qscale[d]);
     }
 }
 
@@ -669,31 +768,47 @@ __device__ __forceinline__ void chain_xattn(const ImagenRowchainParams& p, char*
   qq.kpart = 0;
   qq.s0 = 0;
   qq.s1 = C >> 4;
+  RC_STAMP(0);
   stage_fill(ring, qq, p.w0, p.w_cout_pad0, lane);
   {
     RowPieces<RB> xr;   // the block input rows: the LayerNorm input
     load_row_pieces<RB>(xr, p.x, p.ld_x, row0 + r, C, li);
     ln_rows_to_lds<RB>(p, xr, row0, P1, pitch1, tid);
   }
+  const float* sg = stage_gains(p, smem, chain_tiles_bytes(p, ROWS), tid);
+  RC_STAMP(1);
   __syncthreads();
+  RC_STAMP(2);
   {
     const WeightStream ws = weight_stream(p.w0, p.w_cout_pad0, qq.tile0, lane);
     acc_zero<2, RB>(acc);
     gemm_run<2, RB>(acc, ring, ws, 0, qq.s1, P1, pitch1, lane);
   }
-  // ---- the attention of head `wave`, wave-local.  Q^ of every row block first (the fp32 accumulators are dead after it); the first key tile is
+  RC_STAMP(3);
+  // ---- the attention of head `wave`, wave-local.  Q^ of every row block first (the fp32 accumulators are dead after it); the key tiles are
   // requested before that arithmetic
   const int b = row0 / p.rows_per_batch;
   const int ntiles = (p.J + 31) >> 5;
-  KvTile kv0;
-  load_kv_tile(kv0, p, b, wave, 0, lane);
+  char* kvs = smem + chain_tiles_bytes(p, ROWS) + kGainFloats * sizeof(float) + (size_t)wave * kKvWave;
+  KvRegs kr0, kr1;      // the first two key tiles (every README / BASELINE site: J = 39 | 41) in ONE round trip
+  kv_request(kr0, p, b, wave, 0, lane);
+  kv_request(kr1, p, b, wave, ntiles > 1 ? 1 : 0, lane);
   f16x8 qf[RB][2][2];
 #pragma unroll
   for (int j = 0; j < RB; ++j) {
-    make_qhat(qf[j], p, acc[0][j], acc[1][j], lane);
+    make_qhat(qf[j], p, sg + kGainQs, acc[0][j], acc[1][j], lane);
     __builtin_amdgcn_sched_barrier(0);
   }
   const Part q1 = make_part(C >> 5, inner >> 4, wave);
+  auto stage = [&](const KvRegs& r) __attribute__((always_inline)) {
+    // the staging is wave-private: the wave's earlier fragment reads precede these stores, the stores precede the reads behind them
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    kv_stage(r, kvs, lane);
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+  };
 #pragma unroll
   for (int j = 0; j < RB; ++j) {
     Softmax st;
@@ -703,10 +818,20 @@ __device__ __forceinline__ void chain_xattn(const ImagenRowchainParams& p, char*
       for (int e = 0; e < 16; ++e) st.oacc[db][e] = 0.f;
     st.m_run = -1.0e30f;
     st.l_run = 0.f;
-    attn_tile(st, kv0, qf[j], 0, p.J, lane);
-    for (int kt = 1; kt < ntiles; ++kt) {   // (every README / BASELINE site has two tiles: J = 39 | 41; long contexts: tile after tile)
-      KvTile kv;
-      load_kv_tile(kv, p, b, wave, kt, lane);
+    KvTile kv;
+    stage(kr0);
+    kv_frags(kv, kvs, lane);
+    attn_tile(st, kv, qf[j], 0, p.J, lane);
+    if (ntiles > 1) {
+      stage(kr1);
+      kv_frags(kv, kvs, lane);
+      attn_tile(st, kv, qf[j], 1, p.J, lane);
+    }
+    for (int kt = 2; kt < ntiles; ++kt) {   // (long contexts: tile after tile, through a third register set)
+      KvRegs kr;
+      kv_request(kr, p, b, wave, kt, lane);
+      stage(kr);
+      kv_frags(kv, kvs, lane);
       attn_tile(st, kv, qf[j], kt, p.J, lane);
     }
     store_o(st, wave, P0 + (size_t)(32 * j + l31) * pitch0, lane);
@@ -717,13 +842,18 @@ __device__ __forceinline__ void chain_xattn(const ImagenRowchainParams& p, char*
   RowPieces<RB> xr;     // the residual rows of the last row pass (the block input again unless the caller names another tensor), requested
   if (p.res) load_row_pieces<RB>(xr, p.res, p.ld_res, row0 + r, C, li);   // behind the attention: 16 registers it could not spare
   else load_row_pieces<RB>(xr, p.x, p.ld_x, row0 + r, C, li);
+  RC_STAMP(4);
   __syncthreads();
+  RC_STAMP(5);
   // ---- y = o W_out^T -> P1 (the normalised input rows are dead)
   stage_run<RB>(acc, ring, q1, p.w1, p.w_cout_pad1, P0, pitch0, P0, lane);
+  RC_STAMP(6);
   store_stage<IMAGEN_ACT_NONE, RB>(acc, q1, P1, pitch1, lane);
   __syncthreads();
+  RC_STAMP(7);
   // ---- out = fp16(LN(y) * g1 + x)
-  ln_res_out_rows<RB>(p, row0, P1, pitch1, p.g1, xr, tid);
+  ln_res_out_rows<RB>(p, row0, P1, pitch1, sg + kGainG1, xr, tid);
+  RC_STAMP(8);
 }
 
 // ------------------------------------------------------------------------------------------------ mode 3: QKV
@@ -840,14 +970,26 @@ __device__ __forceinline__ void chain_resprep(const ImagenRowchainParams& p, cha
     s_gate[c] = p.gate ? p.gate[(size_t)b * p.gate_stride + c] : 1.f;   // (no gate: the plain residual add of a block without GlobalContext)
     s_bias[c] = p.bias ? p.bias[c] : 0.f;
   }
-  {   // concat(x, x2) rows -> P0
-    const int npr = K >> 3, np1 = C1 >> 3;
+  {   // concat(x, x2) rows -> P0: every piece of this thread requested before the first is stored (K <= 512: at most 4 RB pieces per thread)
+    constexpr int NP = 4 * RB;
+    const int npr = K >> 3, np1 = C1 >> 3, total = ROWS * npr;
     const f16* x1 = reinterpret_cast<const f16*>(p.x);
     const f16* x2 = reinterpret_cast<const f16*>(p.x2);
-    for (int i = tid; i < ROWS * npr; i += kThreads) {
+    uint4 t[NP];
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const int i = tid + k * kThreads < total ? tid + k * kThreads : 0;
       const int rr = i / npr, g = i - rr * npr;
       const f16* src = g < np1 ? x1 + (size_t)(row0 + rr) * p.ld_x + g * 8 : x2 + (size_t)(row0 + rr) * p.ld_x2 + (g - np1) * 8;
-      *reinterpret_cast<uint4*>(P0 + (size_t)rr * pitch0 + g * 16) = *reinterpret_cast<const uint4*>(src);
+      t[k] = *reinterpret_cast<const uint4*>(src);
+    }
+#pragma unroll
+    for (int k = 0; k < NP; ++k) {
+      const int i = tid + k * kThreads;
+      if (i < total) {
+        const int rr = i / npr, g = i - rr * npr;
+        *reinterpret_cast<uint4*>(P0 + (size_t)rr * pitch0 + g * 16) = t[k];
+      }
     }
   }
   __syncthreads();
@@ -954,6 +1096,12 @@ int launch_one(const ImagenRowchainParams& p, hipStream_t s) {
 
 }  // namespace
 
+#ifdef ROWCHAIN_TRACE
+extern "C" int imagen_debug_rowchain_trace(void* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_rowchain_trace), &buf, sizeof(buf));
+}
+#endif
+
 int launch_rowchain(const ImagenRowchainParams* pp, hipStream_t s) {
   const ImagenRowchainParams& p = *pp;
   IMAGEN_CHECK(p.mode >= IMAGEN_CHAIN_FF && p.mode <= IMAGEN_CHAIN_RESPREP, "rowchain: mode %d", p.mode);
@@ -992,7 +1140,9 @@ int launch_rowchain(const ImagenRowchainParams* pp, hipStream_t s) {
                  "rowchain XATTN: 8-byte aligned operand rows");
     IMAGEN_CHECK(p.w_cout_pad0 >= p.inner && p.w_cout_pad1 >= p.C, "rowchain XATTN: weight padding");
     IMAGEN_CHECK(!p.res || (p.ld_res % 8 == 0 && ((size_t)p.res & 15) == 0), "rowchain XATTN: unaligned residual");
-    return p.tile64 ? launch_one<IMAGEN_CHAIN_XATTN, 2>(p, s) : launch_one<IMAGEN_CHAIN_XATTN, 1>(p, s);
+    // (always 32-row tiles: with 64 the two row blocks' softmax states and the K^ / V^T register sets spill, and call E measured no gain —
+    // 28.2 vs 26.8 us at 16384 rows of 32 channels; `tile64` is ignored here)
+    return launch_one<IMAGEN_CHAIN_XATTN, 1>(p, s);
   }
   IMAGEN_CHECK(p.khat && p.vt && p.k_scale, "rowchain QKV: null operand");
   IMAGEN_CHECK(p.k_rs % 8 == 0 && p.k_bs % 8 == 0 && ((size_t)p.khat & 15) == 0, "rowchain QKV: 16-byte aligned K^ rows");

@@ -465,7 +465,7 @@ typedef struct ImagenRowchainParams {
   int32_t k_bs, k_hs, k_rs, vt_bs, vt_hs, vt_ds;        /* operand buffer strides (elements), as ImagenAttentionParams / ImagenKvPrepParams */
   int32_t r0;                                           /* QKV: first key row of the tile rows' keys (behind the context and null rows) */
   int32_t w_cout_pad0, w_cout_pad1, w_cout_pad2;
-  int32_t tile64;                                       /* 1: 64-row tiles (rows_per_batch % 64 == 0): every weight fragment feeds two MFMAs */
+  int32_t tile64;                                       /* 1: 64-row tiles (rows_per_batch % 64 == 0): every weight fragment feeds two MFMAs (XATTN: always 32) */
   int32_t C2, ld_x2, ld_add, gate_stride, prep_C2, ld_prep_x2, ld_prep;   /* RESPREP (inner = C1, the channels of x) */
   float eps, q_mult, prep_ssq_wb;
 } ImagenRowchainParams;

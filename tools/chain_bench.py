@@ -91,6 +91,50 @@ def run(args):
     print(f"chain_bench: {len(order)} cases x {args.reps} launches done ({os.path.basename(_abi.LIB_PATH)})", flush=True)
 
 
+def trace(args):
+    """--trace (a -DROWCHAIN_TRACE variant library): per-phase s_memtime deltas of thread 0 of every workgroup, averaged over workgroups and launches."""
+    import ctypes
+
+    import torch
+    from imagen_pytorch_amd import _abi, ops
+
+    dev = torch.device("cuda:0")
+    torch.manual_seed(0)
+    lib = _abi.load_library()
+    assert hasattr(lib, "imagen_debug_rowchain_trace"), "not a -DROWCHAIN_TRACE library"
+    lib.imagen_debug_rowchain_trace.argtypes = [ctypes.c_void_p]
+    buf = torch.zeros(8192, 16, dtype=torch.int64, device=dev)
+    assert lib.imagen_debug_rowchain_trace(buf.data_ptr()) == 0
+    n = 256 << 20
+    src, dst = torch.empty(n, dtype=torch.uint8, device=dev).fill_(1), torch.empty(n, dtype=torch.uint8, device=dev)
+    v = ctypes.c_float()
+    out = {}
+    for mode, N, C in CASES:
+        if mode not in ("ff", "xattn"):
+            continue
+        for tile64 in (0, 1):
+            if (N % 64 and tile64) or (tile64 != (16 * N >= 16384)):
+                continue
+            plan = build_case(ops, torch, dev, mode, N, C, tile64)
+            plan.run()
+            torch.cuda.synchronize()
+            wgs = 16 * N // (64 if tile64 else 32)
+            acc = None
+            for _ in range(args.reps):
+                _abi.check(lib.imagen_probe_copy(dst.data_ptr(), src.data_ptr(), n, 1, ops.current_stream_handle(), ctypes.byref(v)), "flush")
+                buf.zero_()
+                plan.run()
+                torch.cuda.synchronize()
+                t = buf[:wgs].cpu().double()
+                nst = int((t[0] > 0).sum())
+                d = torch.cat(((t[:, 1:nst] - t[:, :nst - 1]).mean(0), torch.tensor([t[:, nst - 1].max() - t[:, 0].min(), (t[:, nst - 1] - t[:, 0]).mean()])))
+                acc = d if acc is None else acc + d
+            acc = (acc / args.reps).tolist()
+            out[f"{mode}:N{N}:C{C}:t{64 if tile64 else 32}"] = dict(phase_cycles=[round(x) for x in acc[:-2]], first_to_last_cycles=round(acc[-2]),
+                                                                    per_wg_cycles=round(acc[-1]), wgs=wgs)
+    print(json.dumps(dict(tag=args.tag, trace=out)))
+
+
 def parse(trace_dir, list_path):
     meta = json.load(open(list_path))
     f = next(iter(sorted(glob.glob(os.path.join(trace_dir, "**", "*kernel_trace.csv"), recursive=True))))
@@ -111,9 +155,12 @@ def main():
     ap.add_argument("--reps", type=int, default=12)
     ap.add_argument("--list", default="/tmp/chain_cases.json")
     ap.add_argument("--parse", nargs=2, metavar=("TRACE_DIR", "LIST"))
+    ap.add_argument("--trace", action="store_true", help="phase timeline of the ff / xattn chains (needs a -DROWCHAIN_TRACE library)")
     args = ap.parse_args()
     if args.parse:
         parse(*args.parse)
+    elif args.trace:
+        trace(args)
     else:
         run(args)
 

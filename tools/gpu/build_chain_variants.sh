@@ -13,7 +13,8 @@ build() {   # tag source flags...
   echo "built $P/libimagen_hip_$tag.so"
 }
 git show 785fb26:imagen-pytorch_amd/csrc/rowchain.hip > /tmp/rowchain_v1.hip      # round 5's first version (call A): 4-step ring, loads at use
-build rc1 /tmp/rowchain_v1.hip
-build r8 $P/csrc/rowchain.hip -DROWCHAIN_RING=8
-build r4w4 $P/csrc/rowchain.hip -DROWCHAIN_RING=4 -DROWCHAIN_MINW=4
-build r8w4 $P/csrc/rowchain.hip -DROWCHAIN_RING=8 -DROWCHAIN_MINW=4
+#build rc1 /tmp/rowchain_v1.hip
+#build r8 $P/csrc/rowchain.hip -DROWCHAIN_RING=8
+#build r4w4 $P/csrc/rowchain.hip -DROWCHAIN_RING=4 -DROWCHAIN_MINW=4
+#build r8w4 $P/csrc/rowchain.hip -DROWCHAIN_RING=8 -DROWCHAIN_MINW=4
+build trace $P/csrc/rowchain.hip -DROWCHAIN_TRACE
