@@ -89,8 +89,9 @@ def find_period(names, lo, hi, reps, start):
         for per in range(lo, hi + 1):
             if off + per * reps > len(names):
                 break
-            if names[off:off + per * (reps - 1)] == names[off + per:off + per * reps]:
-                return off, per
+            if names[off:off + per * (reps - 1)] == names[off + per:off + per * reps] and len(set(names[off:off + per])) > 4:
+                return off, per      # (more than a handful of distinct kernels: a long run of ONE kernel — the upload copies of the weight
+                                     # packing, ~1000 __amd_rocclr_copyBuffer dispatches since round 5 — is periodic with every period)
     return -1, 0
 
 
