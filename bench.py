@@ -175,15 +175,30 @@ def calibration_leg(device):
     out["dependent_load_ns"] = lat
     _abi.check(lib.imagen_probe_launch_chain(300, 20, word.data_ptr(), h, ctypes.byref(v)), "probe_launch_chain")
     out["graph_dependent_launch_us"] = round(v.value, 3)
+    out.update(smi_sample(("sclk", "mclk")))
+    return out
+
+
+def smi_sample(clocks=("sclk", "mclk", "fclk", "socclk"), extra=False):
+    """Best-effort reading of rocm-smi: the named clocks ("sclk clock speed:": "(2400Mhz)" -> {"sclk": "2400Mhz"}) and, with `extra`, every power /
+    temperature field verbatim.  Idle readings say little (every box of the pool reports the same levels); `sequential.rocm_smi_under_load` is the
+    same reading taken two seconds into a sampling pass."""
+    import shutil
+    import subprocess
+
     smi = shutil.which("rocm-smi") or "/opt/rocm/bin/rocm-smi"
+    out = {}
     try:
-        r = subprocess.run([smi, "--showclocks", "--json"], stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=20)
+        cmd = [smi, "--showclocks", "--json"] + (["--showpower", "--showtemp"] if extra else [])
+        r = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.DEVNULL, timeout=20)
         card = next(iter(json.loads(r.stdout.decode()).values()))
-        for k, val in card.items():     # e.g. "sclk clock speed:": "(2400Mhz)", "sclk clock level:": "1"
+        for k, val in card.items():
             kl = k.lower()
-            for name in ("sclk", "mclk"):
+            for name in clocks:
                 if kl.startswith(name) and "speed" in kl:
                     out[name] = str(val).strip("()")
+            if extra and ("power" in kl or "temperature" in kl):
+                out[k.strip(": ")] = str(val)
     except Exception as e:  # noqa: BLE001 — best effort
         out["clocks_error"] = f"{type(e).__name__}: {e}"
     return out
@@ -599,20 +614,29 @@ def main():
             rec["config"]["probe_knobs"] = knobs
         if world == 1 and args.mode != "sequential":
             # the same cascade as ONE request at a time (latency view): three sequential passes outside the timed region, the median reported
-            dts = []
+            import threading
+            dts, under_load = [], {}
             for k in range(3):
+                # clocks / power under load: one rocm-smi reading two seconds into the FIRST pass (the pass that also re-warms the default lane)
+                timer = threading.Timer(2.0, lambda: under_load.update(smi_sample(extra=True))) if k == 0 else None
+                if timer:
+                    timer.daemon = True
+                    timer.start()
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 one_pass(n_warm + args.steps + k)
                 torch.cuda.synchronize()
                 dts.append(time.perf_counter() - t1)
+                if timer:
+                    timer.join(timeout=30)
             dt = sorted(dts)[1]
             rec["sequential"] = {"ms_per_step": round(dt * 1e3, 2), "value": round(B / dt, 4), "unit": "images/s",
                                  "ms_per_ddpm_step_pair": round(dt * 1e3 / args.timesteps, 4),
                                  "passes_ms": [round(x * 1e3, 1) for x in dts],
                                  "path_frac_of_mfma_peak": round(B / dt * FLOPS_PER_IMAGE_REFERENCE * (args.timesteps / 1000) / 1e12 / MFMA_PEAK_TFLOPS, 4),
                                  "note": "one sample() call at a time (no overlap between batches; round-over-round comparisons use THIS "
-                                         "figure): the median of three passes after the timed region"}
+                                         "figure): the median of three passes after the timed region",
+                                 "rocm_smi_under_load": dict(under_load)}
             try:
                 rec["sequential"]["in_graph_step_ms"] = stage_replay_leg(imagen)
             except Exception as e:  # noqa: BLE001
