@@ -17,7 +17,7 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.dirname(HERE)
 CSRC = os.path.join(HERE, "csrc")
-SOURCES = ["igemm.hip", "conv_dma.hip", "conv_stream.hip", "conv_pw.hip", "conv_big.hip", "conv_pro.hip", "conv_gemm.hip", "rowchain.hip", "elementwise.hip", "attention.hip", "sampler.hip", "temporal.hip", "codesize.hip", "probe.hip", "capi.hip"]
+SOURCES = ["igemm.hip", "conv_dma.hip", "conv_stream.hip", "conv_pw.hip", "conv_big.hip", "conv_pro.hip", "conv_gemm.hip", "conv_small.hip", "rowchain.hip", "elementwise.hip", "attention.hip", "sampler.hip", "temporal.hip", "codesize.hip", "probe.hip", "capi.hip"]
 LIB = os.path.join(HERE, "libimagen_hip.so")
 STAMP = os.path.join(HERE, ".libimagen_hip.stamp")
 

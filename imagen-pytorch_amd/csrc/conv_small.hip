@@ -1,0 +1,361 @@
+// conv_small.hip — the 3x3 convolutions of the SMALL maps (ninth igemm family, gfx950): the 8^2 / 16^2 (/ 32^2) levels, 64 - 1024 input
+// channels, i.e. a few thousand output pixels against a reduction of K = 576 .. 9216.
+//
+// Why it exists (round 5, profiles/r05_graph_profile.txt): on the wave-specialised kernel (and on the all-DMA family's 64-pixel tiles)
+// these launches take 11 - 19 us for 0.3 - 1.8 GFLOP — [128 -> 128 @8^2 x 16 images] is 16 workgroups walking 36 barrier-synchronised K
+// chunks one after the other, [384 -> 256 @8^2] 64 workgroups walking 108.  The time is the LENGTH of the serial K loop, not its work, and
+// every tile shape of those kernels that adds workgroups shortens nothing.  Splitting K over workgroups would add a seam (partials through
+// HBM + a second pass: MI355X_MICROARCH.md prices it at 5 - 13 us, the whole launch).  This kernel splits K INSIDE the workgroup:
+//   * one workgroup of 8 waves per (32 output pixels of one image) x (32 NT output channels) tile, NT = 1 | 2 | 4;  wave w owns cout
+//     fragment w % NT and the K slice w / NT of 8 / NT slices — each wave runs a private, barrier-free K loop of 1/8 .. 1/2 of the
+//     reduction on ONE 32 x 32 accumulator fragment (v_mfma_f32_32x32x16_f16), then the 8 / NT partial fragments of a cout fragment are
+//     summed through LDS (4 KB each);
+//   * A operand (weights): 16-byte loads straight from the packed buffer (imagen_pack_igemm_weights order: a lane's fragment is
+//     contiguous, a K = 16 step is two consecutive group rows) into a register ring 8 steps deep, scalar base + one per-lane offset
+//     (rowchain.hip's weight stream): every workgroup streams its 32 NT x K slice out of L2, 18 - 221 KB;
+//   * B operand (pixels): the (TH + 2) x (TW + 2) halo tile of the image is staged ONCE into LDS as [position][Cin] fp16, with the Block
+//     prologue (ChanRMSNorm statistics from the producers' sums of squares | explicit mu / rs, per-channel affine, SiLU) applied on the
+//     way and zeros outside the image, one barrier; a tap is then an address offset.  Pitch 2 Cin + 16 bytes (16 x odd), and the lane ->
+//     pixel assignment follows the hardware's ds_read_b128 service groups ({0-3, 12-15, 20-27} / {4-11, 16-19, 28-31} per half-wave:
+//     MI355X_MICROARCH.md, LDS) so that each group's 16 positions are distinct mod 16 for every tap: conflict-free fragment reads;
+//   * epilogue: the waves of K slice 0 own the summed fragments and run conv_epilogue.h as a (1 x NT)-wave workgroup — every epilogue of
+//     the contract, the all-cout ones (ssq_out / post_pa / GlobalContext partials) where 32 NT covers Cout; the other waves have left
+//     (s_barrier counts live waves).
+// Contract: ImagenIgemmParams with KH = KW = 3, stride 1, pad 1, G = 4 packing; C1 % 8 == 0, C1 + C2 == Cin_pad (a multiple of 32);
+// output tiles of 32 pixels as 4 x 8, 2 x 16 or 1 x 32 (partial tiles at the map's edge are masked).
+#include <cstdio>
+#include "common.h"
+#include "conv_epilogue.h"
+
+namespace {
+
+constexpr int CS_THREADS = 512;
+constexpr int CS_RING = 8;          // weight fragments in flight per wave
+#ifndef CS_MINW
+#define CS_MINW 4                   // minimum waves per SIMD the register allocation leaves room for (4: two workgroups per CU — one stages while the other multiplies)
+#endif
+#ifndef CS_BATCH
+#define CS_BATCH 6                  // staged 16-byte pieces in flight per thread and round (8 spills under CS_MINW 4)
+#endif
+
+__host__ __device__ inline int cs_row_positions(int TW) { return TW == 8 ? 12 : TW + 2; }   // staged positions per halo row (8-wide tiles: 2 unused, so that rows 0 / 2 and 1 / 3 complement each other mod 16)
+__host__ __device__ inline int cs_pitch(int Cin_pad) { return 2 * Cin_pad + 16; }
+__host__ __device__ inline size_t cs_tile_bytes(int TH, int TW, int Cin_pad) { return (size_t)(TH + 2) * cs_row_positions(TW) * cs_pitch(Cin_pad); }
+
+template <int NT>
+struct CsEp {   // conv_epilogue.h scratch of a (1 x NT)-wave workgroup, floats
+  static constexpr int BN = 32 * NT;
+  static constexpr int PAR = 4 * BN + NT * 32 + 8 + (BN + 4);
+  static constexpr int RED = NT * 32;
+};
+
+template <int NT>
+__host__ __device__ inline size_t cs_lds_bytes(int TH, int TW, int Cin_pad, bool pro) {
+  size_t body = cs_tile_bytes(TH, TW, Cin_pad) + (pro ? (size_t)2 * Cin_pad * sizeof(float) : 0);
+  const size_t partials = (size_t)(8 / NT - 1) * NT * 4096;   // the K-split partial fragments alias the (dead) halo tile
+  if (partials > body) body = partials;
+  return ((body + 15) & ~(size_t)15) + (size_t)(CsEp<NT>::PAR + CsEp<NT>::RED) * sizeof(float);
+}
+
+// NT: 32-cout fragments per workgroup tile.  PRO: the input-side prologue (statistics / affine / SiLU).  GEN: generic epilogue (conv_epilogue.h).
+template <int NT, bool PRO, bool GEN>
+__global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const ImagenIgemmParams p, unsigned code_bytes) {
+  constexpr int KS = 8 / NT;        // K slices
+  constexpr int BN = 32 * NT;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned warm = imagen_code_warm(code_bytes, threadIdx.x, CS_THREADS);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wn = wave % NT, ks = wave / NT;
+
+  const int TH = p.TH, TW = p.TW;
+  const int P = cs_row_positions(TW), pitch = cs_pitch(p.Cin_pad);
+  const int HW_ = TW + 2, HH = TH + 2;                 // halo tile (used positions)
+  const size_t tile_bytes = cs_tile_bytes(TH, TW, p.Cin_pad);
+  float* const aff = reinterpret_cast<float*>(smem + tile_bytes);   // [pa Cin_pad | ps Cin_pad] of the tile's batch row (PRO)
+
+  // ---- tile of this workgroup: contiguous ranges of the tile list per XCD (blockIdx goes round-robin over the 8 XCDs, each with its own L2).
+  //      The list is ordered so that a range shares what is larger: cout slab fastest (the slabs of a pixel tile stage the same halo tile,
+  //      every XCD streams all weights) where the map outweighs the weights, pixel tile fastest (an XCD streams ONE slab's weights and
+  //      stages the whole map) where the weights outweigh the map — [384 -> 256 @8^2 x 16]: 1.8 MB of weights against 0.8 MB of pixels
+  const int tilesX = (p.OW + TW - 1) / TW, tilesY = (p.OH + TH - 1) / TH, tilesN = (p.Cout + BN - 1) / BN;
+  ClTile tc;
+  {
+    const int nwg = gridDim.x, bid = blockIdx.x;
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
+    int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+    const int npix = p.B * tilesY * tilesX;
+    const bool slab_major = p.Cout * 9 > p.B * p.OH * p.OW;   // weight bytes (18 Cin Cout) > map bytes (2 Cin B OH OW)
+    int nt;
+    if (slab_major) { nt = t / npix; t -= nt * npix; }
+    else { nt = t % tilesN; t /= tilesN; }
+    const int tx = t % tilesX;
+    t /= tilesX;
+    const int ty = t % tilesY;
+    tc.b = t / tilesY;
+    tc.oy0 = ty * TH;
+    tc.ox0 = tx * TW;
+    tc.n0 = nt * BN;
+  }
+
+  // ---- stage the halo tile: pieces (position, 8-channel group) dealt round-robin to the threads, 8 in flight per thread and round
+  const int ppr = p.Cin_pad >> 3;                       // pieces per position
+  const int npieces = HH * HW_ * ppr;
+  const float inv_ppr = 1.0f / (float)ppr, inv_w = 1.0f / (float)HW_;
+  const f16* x1 = reinterpret_cast<const f16*>(p.x1) + (size_t)tc.b * p.bs1;
+  const f16* x2 = p.x2 ? reinterpret_cast<const f16*>(p.x2) + (size_t)tc.b * p.bs2 : x1;
+  if constexpr (PRO) {   // the per-channel affine of this batch row -> LDS (absent factors: neutral constants), requested before everything else
+    for (int i = tid; i < p.Cin_pad; i += CS_THREADS) {
+      aff[i] = p.pa ? p.pa[(size_t)tc.b * p.pstride + i] : 1.0f;
+      aff[p.Cin_pad + i] = p.ps ? p.ps[(size_t)tc.b * p.pstride + i] : 0.0f;
+    }
+  }
+  const bool use_rs = p.rs != nullptr, use_ssq = !use_rs && p.ssq_a != nullptr, use_ssqb = use_ssq && p.ssq_b != nullptr;
+  const bool use_mu = p.mu != nullptr, use_silu = p.act_in == IMAGEN_ACT_SILU;
+  const float* q1_base = use_rs ? p.rs : (use_ssq ? p.ssq_a : nullptr);
+  const float* q2_base = use_mu ? p.mu : (use_ssqb ? p.ssq_b : nullptr);
+  const int sp0 = tc.b * (p.H * p.W);
+
+  // the weight stream of this wave: cout fragment tc.n0 / 32 + wn, K = 16 steps [s0, s1) of NS = 18 per 32-channel chunk (9 taps x 2)
+  const int NS = (p.Cin_pad >> 5) * 18;
+  const int s0 = __builtin_amdgcn_readfirstlane((NS * ks) / KS), s1 = __builtin_amdgcn_readfirstlane((NS * (ks + 1)) / KS);
+  const int nsteps = s1 - s0;
+  const char* wbase = reinterpret_cast<const char*>(p.w) + ((size_t)(tc.n0 >> 5) + wn) * 512;
+  const unsigned w_lane = ((unsigned)half * (unsigned)p.Cout_pad + (unsigned)l31) * 16u;
+  const size_t w_step = (size_t)p.Cout_pad * 32;       // two group rows per K = 16 step
+  auto weight_frag = [&](int s) __attribute__((always_inline)) -> f16x8 {
+    return *reinterpret_cast<const f16x8*>(wbase + (size_t)s * w_step + w_lane);
+  };
+  f16x8 ring[CS_RING];
+
+  bool ring_filled = false;
+  for (int base = 0; base < npieces; base += CS_BATCH * CS_THREADS) {
+    uint4 raw[CS_BATCH];
+    float q1[CS_BATCH], q2[CS_BATCH];
+    int dst[CS_BATCH], ch[CS_BATCH];
+    unsigned okmask = 0;
+#pragma unroll
+    for (int k = 0; k < CS_BATCH; ++k) {
+      const int i = base + tid + k * CS_THREADS;
+      const bool in = i < npieces;
+      const int ii = in ? i : 0;
+      const int pos = (int)(((float)ii + 0.5f) * inv_ppr);
+      const int cg = ii - pos * ppr;
+      const int hy = (int)(((float)pos + 0.5f) * inv_w);
+      const int hx = pos - hy * HW_;
+      const int gy = tc.oy0 - 1 + hy, gx = tc.ox0 - 1 + hx;
+      const int c = cg * 8;
+      const bool from1 = c < p.C1;
+      // (bitwise, not short-circuit: one straight-line address computation per piece; Cin_pad == C1 + C2, so every staged channel exists)
+      const bool ok = in & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
+      const int gp = ok ? gy * p.W + gx : 0;
+      const int eoff = ok ? (from1 ? gp * p.ld1 + c : gp * p.ld2 + (c - p.C1)) : 0;
+      const f16* bp = (from1 | !ok) ? x1 : x2;
+      raw[k] = *reinterpret_cast<const uint4*>(bp + eoff);
+      if constexpr (PRO) {
+        q1[k] = q1_base ? q1_base[sp0 + gp] : 1.0f;
+        q2[k] = q2_base ? q2_base[sp0 + gp] : 0.0f;
+      }
+      okmask |= (ok ? 1u : 0u) << k;
+      dst[k] = in ? (hy * P + hx) * pitch + cg * 16 : -1;
+      ch[k] = c;
+    }
+    if (!ring_filled) {   // (behind the first round's requests: loads return in order, and the weights are the coldest of them)
+      ring_filled = true;
+#pragma unroll
+      for (int i = 0; i < CS_RING; ++i) ring[i] = weight_frag(s0 + (i < nsteps ? i : nsteps - 1));
+      if constexpr (PRO) __syncthreads();   // the affine table
+    }
+#pragma unroll
+    for (int k = 0; k < CS_BATCH; ++k) {
+      uint4 ow = raw[k];
+      if constexpr (PRO) {
+        const f16x8 in = __builtin_bit_cast(f16x8, raw[k]);
+        const int cg8 = ch[k];
+        const float4 a0 = *reinterpret_cast<const float4*>(aff + cg8), a1 = *reinterpret_cast<const float4*>(aff + cg8 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(aff + p.Cin_pad + cg8), b1 = *reinterpret_cast<const float4*>(aff + p.Cin_pad + cg8 + 4);
+        const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, sh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        // ChanRMSNorm statistics straight from the producers' per-pixel sums of squares: 1 / max(sqrt(q), 1e-12) (ip.py:328)
+        const float q = q1[k] + (use_ssqb ? p.ssq_wb * q2[k] : 0.0f);
+        const float rs = use_rs ? q1[k] : (use_ssq ? __builtin_amdgcn_rsqf(fmaxf(q, 1e-24f)) : 1.0f);
+        const float mu = use_mu ? q2[k] : 0.0f;
+        float v[8], e[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = ((float)in[j] - mu) * rs * a[j] + sh[j];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = __builtin_amdgcn_exp2f(-1.4426950408889634f * v[j]);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) e[j] = __builtin_amdgcn_rcpf(1.0f + e[j]);
+        f16x8 o;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] = (f16)(use_silu ? v[j] * e[j] : v[j]);
+        ow = __builtin_bit_cast(uint4, o);
+      }
+      if (!(okmask & (1u << k))) ow = make_uint4(0, 0, 0, 0);   // outside the image / past the input channels: zero padding
+      if (dst[k] >= 0) *reinterpret_cast<uint4*>(smem + dst[k]) = ow;
+    }
+  }
+  __syncthreads();
+  imagen_code_warm_sink(warm);
+
+  // ---- lane -> pixel of the tile: hardware service group g (0 | 1) and rank r (0 .. 15) of the lane inside its half-wave
+  int g, r;
+  if (l31 < 4) { g = 0; r = l31; }
+  else if (l31 < 12) { g = 1; r = l31 - 4; }
+  else if (l31 < 16) { g = 0; r = l31 - 8; }
+  else if (l31 < 20) { g = 1; r = l31 - 8; }
+  else if (l31 < 28) { g = 0; r = l31 - 12; }
+  else { g = 1; r = l31 - 16; }
+  int pix_y[1], pix_x[1];
+  if (TW == 8) { pix_y[0] = 2 * (r >> 3) + g; pix_x[0] = r & 7; }        // 4 x 8: rows 0, 2 | rows 1, 3
+  else if (TW == 16) { pix_y[0] = g; pix_x[0] = r; }                      // 2 x 16: row 0 | row 1
+  else { pix_y[0] = 0; pix_x[0] = 16 * g + r; }                           // 1 x 32: left | right half
+  const char* xl = smem + (pix_y[0] * P + pix_x[0]) * pitch + half * 16;
+
+  // ---- the K loop of this wave: step s = (chunk, tap, j): channels 32 chunk + 16 j (+ 8 half), tap (dy, dx) = a position offset
+  f32x16 acc[1][1];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) acc[0][0][i] = 0.f;
+  int chunk = s0 / 18, rem = s0 - chunk * 18;
+  auto b_frag = [&]() __attribute__((always_inline)) -> f16x8 {
+    const int tap = rem >> 1;
+    const int dy = (tap * 11) >> 5;                     // tap / 3 for tap < 9
+    const int dx = tap - 3 * dy;
+    const int off = (dy * P + dx) * pitch + chunk * 64 + (rem & 1) * 32;
+    if (++rem == 18) { rem = 0; ++chunk; }
+    return *reinterpret_cast<const f16x8*>(xl + off);
+  };
+  // (the B fragment of a step is requested one step ahead: its LDS latency then sits behind the previous step's MFMA)
+  f16x8 bcur = b_frag();
+  int sb = 0;
+  for (; sb + CS_RING < nsteps; sb += CS_RING) {   // straight-line body: 8 steps, each followed by the request of the step 8 ahead (clamped to the last one)
+#pragma unroll
+    for (int i = 0; i < CS_RING; ++i) {
+      const f16x8 bnext = b_frag();
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[i], bcur, acc[0][0], 0, 0, 0);
+      const int sn = sb + i + CS_RING;
+      ring[i] = weight_frag(s0 + (sn < nsteps ? sn : nsteps - 1));
+      bcur = bnext;
+      __builtin_amdgcn_sched_barrier(0);   // pins the request here (the scheduler otherwise sinks look-ahead loads to their use)
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < CS_RING; ++i) {   // the last (up to 8) steps are in the ring
+    if (sb + i < nsteps) {
+      f16x8 bnext = bcur;
+      if (sb + i + 1 < nsteps) bnext = b_frag();
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[i], bcur, acc[0][0], 0, 0, 0);
+      bcur = bnext;
+    }
+  }
+
+  // ---- K-split: the partial fragments of slices 1 .. KS - 1 are added into slice 0's through LDS (the halo tile is dead behind the barrier)
+  if constexpr (KS > 1) {
+    __syncthreads();
+    if (ks > 0) {
+      f32x4* dstp = reinterpret_cast<f32x4*>(smem + (size_t)((ks - 1) * NT + wn) * 4096);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) dstp[q * 64 + lane] = f32x4{acc[0][0][4 * q], acc[0][0][4 * q + 1], acc[0][0][4 * q + 2], acc[0][0][4 * q + 3]};
+    }
+    __syncthreads();
+    if (ks > 0) return;
+#pragma unroll 2   // (not all 7: 28 partial quads in registers at once are the kernel's register peak)
+    for (int k = 1; k < KS; ++k) {
+      const f32x4* src = reinterpret_cast<const f32x4*>(smem + (size_t)((k - 1) * NT + wn) * 4096);
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 v = src[q * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[0][0][4 * q + e] += v[e];
+      }
+    }
+  }
+
+  // ---- epilogue: the NT live waves as a (1 x NT)-wave workgroup of conv_epilogue.h (its scratch sits behind everything else)
+  const size_t body = cs_lds_bytes<NT>(TH, TW, p.Cin_pad, PRO) - (size_t)(CsEp<NT>::PAR + CsEp<NT>::RED) * sizeof(float);
+  float* ep_par = reinterpret_cast<float*>(smem + body);
+  float* ep_red = ep_par + CsEp<NT>::PAR;
+  cl_epilogue<1, 1, 1, NT, GEN>(p, tc, acc, pix_y, pix_x, ep_red, ep_par, 0, wn, half, l31);
+}
+
+template <int NT, bool PRO, bool GEN>
+int cs_launch(const ImagenIgemmParams& p, hipStream_t s) {
+  auto kern = conv_small_kernel<NT, PRO, GEN>;
+  const size_t lds = cs_lds_bytes<NT>(p.TH, p.TW, p.Cin_pad, PRO);
+  IMAGEN_CHECK(lds <= 160 * 1024, "conv_small: %zu bytes of LDS (Cin_pad %d)", lds, p.Cin_pad);
+  static bool attr_done[16] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  if (dev < 0 || dev >= 16 || !attr_done[dev]) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) { imagen_set_error("conv_small: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
+    if (dev >= 0 && dev < 16) attr_done[dev] = true;
+  }
+  static const unsigned code_bytes = [] {
+    char name[160];
+    snprintf(name, sizeof(name), "_ZN12_GLOBAL__N_117conv_small_kernelILi%dELb%dELb%dEEEv17ImagenIgemmParamsj", NT, PRO ? 1 : 0, GEN ? 1 : 0);
+    return imagen_kernel_code_bytes(name);
+  }();
+  const int total = p.B * ((p.OH + p.TH - 1) / p.TH) * ((p.OW + p.TW - 1) / p.TW) * ((p.Cout + 32 * NT - 1) / (32 * NT));
+  hipLaunchKernelGGL(kern, dim3(total), dim3(CS_THREADS), lds, s, p, code_bytes);
+  return imagen_hip_status("conv_small launch");
+}
+
+template <int NT>
+int cs_dispatch(const ImagenIgemmParams& p, hipStream_t s) {
+  const bool pro = p.mu || p.rs || p.pa || p.ps || p.ssq_a || p.act_in != IMAGEN_ACT_NONE;
+  const bool plain = p.act_out == IMAGEN_ACT_NONE && p.out_mode == IMAGEN_OUT_NHWC && !p.addend && !p.res;
+  if (pro) return plain ? cs_launch<NT, true, false>(p, s) : cs_launch<NT, true, true>(p, s);
+  return plain ? cs_launch<NT, false, false>(p, s) : cs_launch<NT, false, true>(p, s);
+}
+
+constexpr int kCsNT[3] = {1, 2, 4};
+
+}  // namespace
+
+int imagen_conv_small_num_configs() { return 3; }
+
+int imagen_conv_small_config_info(int idx, int* tile_pixels, int* tile_cout, int* kgroups) {
+  if (idx < 0 || idx >= 3) return -1;
+  if (tile_pixels) *tile_pixels = 32;
+  if (tile_cout) *tile_cout = 32 * kCsNT[idx];
+  if (kgroups) *kgroups = 4;
+  return 0;
+}
+
+long imagen_conv_small_lds_bytes(int idx, int KH, int KW, int TH, int TW) {
+  if (idx < 0 || idx >= 3 || KH != 3 || KW != 3 || TH * TW != 32 || (TW != 8 && TW != 16 && TW != 32)) return -1;
+  return (long)cs_lds_bytes<1>(TH, TW, 256, true);   // (a typical layer: the real figure grows with Cin and is checked at launch)
+}
+
+int launch_conv_small(const ImagenIgemmParams* pp, int idx, hipStream_t s) {
+  const ImagenIgemmParams& p = *pp;
+  IMAGEN_CHECK(idx >= 0 && idx < 3, "conv_small: bad cfg index %d", idx);
+  IMAGEN_CHECK(p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.OH == p.H && p.OW == p.W, "conv_small: 3x3 stride-1 pad-1 convolutions only");
+  IMAGEN_CHECK(p.TH * p.TW == 32 && (p.TW == 8 || p.TW == 16 || p.TW == 32), "conv_small: 4x8 / 2x16 / 1x32 tiles (got %dx%d)", p.TH, p.TW);
+  IMAGEN_CHECK(p.C1 % 8 == 0 && p.C1 > 0 && p.C2 % 8 == 0 && p.Cin_pad == p.C1 + p.C2 && p.Cin_pad % 32 == 0 && (p.C2 == 0 || p.x2),
+               "conv_small: inputs in 8-channel groups, Cin_pad = C1 + C2 in 32-channel chunks (got %d + %d, padded %d)", p.C1, p.C2, p.Cin_pad);
+  IMAGEN_CHECK(p.ld1 % 8 == 0 && p.bs1 % 8 == 0 && (p.C2 == 0 || (p.ld2 % 8 == 0 && p.bs2 % 8 == 0)) && ((size_t)p.x1 & 15) == 0 && ((size_t)p.x2 & 15) == 0,
+               "conv_small: input rows must be 16-byte aligned");
+  const int NT = kCsNT[idx];
+  IMAGEN_CHECK(p.Cout_pad % (32 * NT) == 0, "conv_small: Cout_pad %d not a multiple of %d", p.Cout_pad, 32 * NT);
+  IMAGEN_CHECK(p.act_in == IMAGEN_ACT_NONE || p.act_in == IMAGEN_ACT_SILU, "conv_small: input activation none | SiLU");
+  IMAGEN_CHECK(!p.mu || p.rs, "conv_small: mu needs rs");
+  IMAGEN_CHECK(p.pstride == 0 || p.pstride >= p.Cin_pad || (!p.pa && !p.ps), "conv_small: per-batch affine rows shorter than Cin_pad");
+  IMAGEN_CHECK(p.out_mode == IMAGEN_OUT_NCHW_F32 || p.Cout % 4 == 0, "conv_small: Cout %d must be a multiple of 4", p.Cout);
+  IMAGEN_CHECK(p.out_mode != IMAGEN_OUT_PIXEL_SHUFFLE || p.Cout % 16 == 0, "conv_small: pixel-shuffle needs Cout %% 16 == 0");
+  IMAGEN_CHECK(!(p.addend && p.res), "conv_small: addend and residual are mutually exclusive");
+  IMAGEN_CHECK(!p.addend || p.gate, "conv_small: addend requires gate");
+  const bool full = p.ssq_out || p.post_pa || p.gca_part;
+  IMAGEN_CHECK(!full || p.Cout <= 32 * NT, "conv_small: ssq_out / post_pa / gca_part need one tile over all %d couts", p.Cout);
+  IMAGEN_CHECK(!p.post_pa || (p.post_ps && p.out_mode == IMAGEN_OUT_NHWC && !p.addend && !p.res && !p.ssq_out && p.act_out == IMAGEN_ACT_NONE),
+               "conv_small: post_pa needs post_ps and a plain NHWC output");
+  IMAGEN_CHECK(!p.gca_part || (p.gca_wk && !p.post_pa && p.out_mode == IMAGEN_OUT_NHWC && !p.addend && !p.res && p.act_out == IMAGEN_ACT_NONE),
+               "conv_small: gca_part needs gca_wk and a plain NHWC output");
+  switch (NT) {
+    case 1: return cs_dispatch<1>(p, s);
+    case 2: return cs_dispatch<2>(p, s);
+    default: return cs_dispatch<4>(p, s);
+  }
+}

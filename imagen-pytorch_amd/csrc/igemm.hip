@@ -1049,7 +1049,13 @@ int imagen_conv_gemm_config_info(int idx, int* tile_pixels, int* tile_cout, int*
 long imagen_conv_gemm_lds_bytes(int idx, int KH, int KW, int TH, int TW);
 int launch_conv_gemm(const ImagenIgemmParams* p, int idx, hipStream_t s);
 static inline int cfg_base_gemm() { return cfg_base_pro() + imagen_conv_pro_num_configs(); }
-static inline int cfg_end() { return cfg_base_gemm() + imagen_conv_gemm_num_configs(); }
+// kernel family 8 (conv_small.hip): the 3x3 convolutions of the small maps (32 pixels x 32 | 64 | 128 couts per workgroup, K split over its waves)
+int imagen_conv_small_num_configs();
+int imagen_conv_small_config_info(int idx, int* tile_pixels, int* tile_cout, int* kgroups);
+long imagen_conv_small_lds_bytes(int idx, int KH, int KW, int TH, int TW);
+int launch_conv_small(const ImagenIgemmParams* p, int idx, hipStream_t s);
+static inline int cfg_base_small() { return cfg_base_gemm() + imagen_conv_gemm_num_configs(); }
+static inline int cfg_end() { return cfg_base_small() + imagen_conv_small_num_configs(); }
 
 int launch_igemm(const ImagenIgemmParams* pp, hipStream_t s) {
   const ImagenIgemmParams& p = *pp;
@@ -1057,7 +1063,8 @@ int launch_igemm(const ImagenIgemmParams* pp, hipStream_t s) {
   IMAGEN_CHECK(p.x1 && p.w && p.y, "igemm: null x1/w/y");
   IMAGEN_CHECK(!p.addend || p.gate, "igemm: addend requires gate");
   IMAGEN_CHECK(p.cfg >= kNumCfgs || (p.TW > 0 && (p.TW & (p.TW - 1)) == 0), "igemm: tile width %d is not a power of two", p.TW);
-  IMAGEN_CHECK(!p.gca_part || p.cfg >= kNumCfgs, "igemm: gca_part is implemented by the kernel families 2, 3, 5 and 7 only (cfg %d)", p.cfg);
+  IMAGEN_CHECK(!p.gca_part || p.cfg >= kNumCfgs, "igemm: gca_part is implemented by the kernel families 2, 3, 5, 7 and 8 only (cfg %d)", p.cfg);
+  if (p.cfg >= cfg_base_small()) return launch_conv_small(pp, p.cfg - cfg_base_small(), s);
   if (p.cfg >= cfg_base_gemm()) return launch_conv_gemm(pp, p.cfg - cfg_base_gemm(), s);
   if (p.cfg >= cfg_base_pro()) return launch_conv_pro(pp, p.cfg - cfg_base_pro(), s);
   if (p.cfg >= cfg_base_big()) return launch_conv_big(pp, p.cfg - cfg_base_big(), s);
@@ -1089,6 +1096,7 @@ extern "C" int imagen_igemm_num_configs(void) { return cfg_end(); }
 
 extern "C" int imagen_igemm_config_family(int cfg) {   // 0: wave-specialised persistent kernel (this file), 2: all-DMA kernel (conv_dma.hip), 3: streaming kernel (conv_stream.hip)
   if (cfg < 0 || cfg >= imagen_igemm_num_configs()) return -1;
+  if (cfg >= cfg_base_small()) return 8; // 8: small-map 3x3 convolution with the K split over the waves of a workgroup (conv_small.hip)
   if (cfg >= cfg_base_gemm()) return 7;  // 7: tiled pointwise GEMM (conv_gemm.hip)
   if (cfg >= cfg_base_pro()) return 6;   // 6: streaming kernel with the prologue on register-staged rows (conv_pro.hip)
   if (cfg >= cfg_base_big()) return 5;   // 5: big-tile all-DMA kernel (conv_big.hip)
@@ -1100,6 +1108,7 @@ extern "C" int imagen_igemm_config_ring(int cfg) {   // weight look-ahead ring d
 }
 
 extern "C" int imagen_igemm_config_info(int cfg, int* tile_pixels, int* tile_cout, int* kgroups) {
+  if (cfg >= cfg_base_small()) return imagen_conv_small_config_info(cfg - cfg_base_small(), tile_pixels, tile_cout, kgroups);
   if (cfg >= cfg_base_gemm()) return imagen_conv_gemm_config_info(cfg - cfg_base_gemm(), tile_pixels, tile_cout, kgroups);
   if (cfg >= cfg_base_pro()) return imagen_conv_pro_config_info(cfg - cfg_base_pro(), tile_pixels, tile_cout, kgroups);
   if (cfg >= cfg_base_big()) return imagen_conv_big_config_info(cfg - cfg_base_big(), tile_pixels, tile_cout, kgroups);
@@ -1123,6 +1132,7 @@ static constexpr int ksc_of(int G, int ks) {   // the launch_cfg dispatch, as a 
 }
 
 extern "C" int imagen_igemm_stage_slots(int cfg, int KH, int KW) {
+  if (cfg >= cfg_base_small()) return (KH == 3 && KW == 3) ? 1 << 20 : 0;
   if (cfg >= cfg_base_gemm()) return (KH == 1 && KW == 1) ? 1 << 20 : 0;
   if (cfg >= cfg_base_pro()) return (KH == 3 && KW == 3) ? 1 << 20 : 0;
   if (cfg >= cfg_base_big()) return (KH == 3 && KW == 3) ? 1 << 20 : 0;
@@ -1135,6 +1145,7 @@ extern "C" int imagen_igemm_stage_slots(int cfg, int KH, int KW) {
 
 // dynamic LDS bytes of a launch of `cfg` with a KH x KW kernel (at `stride`) and a TH x TW output tile; -1: the combination is not launchable
 extern "C" long imagen_igemm_lds_bytes(int cfg, int KH, int KW, int stride, int TH, int TW) {
+  if (cfg >= cfg_base_small()) return stride == 1 ? imagen_conv_small_lds_bytes(cfg - cfg_base_small(), KH, KW, TH, TW) : -1;
   if (cfg >= cfg_base_gemm()) return stride == 1 ? imagen_conv_gemm_lds_bytes(cfg - cfg_base_gemm(), KH, KW, TH, TW) : -1;
   if (cfg >= cfg_base_pro()) return stride == 1 ? imagen_conv_pro_lds_bytes(cfg - cfg_base_pro(), KH, KW, TH, TW) : -1;
   if (cfg >= cfg_base_big()) return stride == 1 ? imagen_conv_big_lds_bytes(cfg - cfg_base_big(), KH, KW, TH, TW) : -1;

@@ -334,6 +334,39 @@ def pw_cfg(kchunks: int, Cout: int) -> Optional[int]:
     return best
 
 
+CONV_SMALL = int(_os.environ.get("IMAGEN_CONV_SMALL", "1"))   # A/B switch: conv_small.hip (family 8) for the 3x3 convs of the small maps
+SMALL_MAX_ROWS = int(_os.environ.get("IMAGEN_CONV_SMALL_ROWS", "4096"))   # ... of at most this many output pixels per launch (16 images of 8^2 / 16^2)
+
+
+def small_cfg(Cout: int, full_cout: bool) -> Optional[int]:
+    """Tile cfg id of the small-map family (family 8: 32 pixels x 32 | 64 | 128 couts per workgroup, K split over its waves): the 32-cout
+    tile (most workgroups), or the narrowest tile over all Cout where the epilogue needs every channel of a pixel; None if there is none."""
+    fam8 = sorted((c[1], i) for i, c in enumerate(cfg_table()) if c[3] == 8)
+    if not fam8:
+        return None
+    if not full_cout:
+        return fam8[0][1]
+    return next((i for bn, i in fam8 if bn >= Cout), None)
+
+
+def small_tile(OH: int, OW: int) -> Optional[tuple]:
+    """The 32-pixel output tile of family 8 for an OH x OW map: 4 x 8, 2 x 16 or 1 x 32, dividing the map."""
+    if OW == 8 and OH % 4 == 0:
+        return 4, 8
+    if OW == 16 and OH % 2 == 0:
+        return 2, 16
+    if OW % 32 == 0:
+        return 1, 32
+    return None
+
+
+def small_lds_bytes(th: int, tw: int, Cin_pad: int, bn: int) -> int:
+    """conv_small.hip's cs_lds_bytes (halo tile + affine table | K-split partials, + epilogue scratch)."""
+    body = (th + 2) * (12 if tw == 8 else tw + 2) * (2 * Cin_pad + 16) + 8 * Cin_pad
+    nt = bn // 32
+    return max(body, (8 // nt - 1) * nt * 4096) + 16 + 4 * (4 * bn + nt * 32 + 8 + bn + 4 + nt * 32)
+
+
 def gemm_cfg() -> Optional[int]:
     """Tile cfg id of the tiled pointwise GEMM (family 7), None if the library has none."""
     return next((i for i, c in enumerate(cfg_table()) if c[3] == 7), None)
@@ -487,6 +520,18 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
     C2 = x2.C if x2 is not None else 0
     assert x1.C + C2 == pw.Cin, f"{label}: input channels {x1.C}+{C2} != weight Cin {pw.Cin}"
     want_gca = gca is not None and out_mode == OUT_NHWC and act_out == ACT_NONE and addend is None and res is None and post is None
+    if cfg is None and CONV_SMALL and KH == 3 and KW == 3 and stride == 1 and pad == 1 and pw.G == 4 and x1.B * OH * OW <= SMALL_MAX_ROWS:
+        # family 8: the 3x3 convs of the small maps, any prologue of the contract (statistics / affine / SiLU), any epilogue; the all-cout
+        # epilogues (ssq_out / post / GlobalContext partials) where a 32 | 64 | 128-cout tile covers Cout
+        full = (ssq_out is not None or post is not None or want_gca) and out_mode == OUT_NHWC
+        tile = small_tile(OH, OW)
+        sc = small_cfg(pw.Cout, full and pw.Cout <= 128)   # (wider layers: the 32-cout tile, statistics / post left to the caller's fallback as on family 0)
+        if (tile is not None and sc is not None and x1.C % 8 == 0 and C2 % 8 == 0 and x1.C + C2 == pw.Cin_pad
+                and x1.ld % 8 == 0 and x1.bs % 8 == 0 and (x2 is None or (x2.ld % 8 == 0 and x2.bs % 8 == 0))
+                and act_in in (ACT_NONE, ACT_SILU) and (mu is None or rs is not None) and (pstride == 0 or pstride >= pw.Cin_pad)
+                and (out_mode == OUT_NCHW_F32 or pw.Cout % 4 == 0)
+                and small_lds_bytes(tile[0], tile[1], pw.Cin_pad, cfg_table()[sc][1]) <= MAX_LDS_BYTES):
+            cfg = (sc, tile[0], tile[1])
     if cfg is None and CONV_PRO and KH == 3 and KW == 3 and stride == 1 and pad == 1 and pw.G == 4 and pro_cfg(pw.Cout) is not None:
         # family 6: exactly 32 output channels from 32 | 32 + 32 input channels, or 64 from two or three 32-channel chunks (64 | 64 + 32 | 32 + 32):
         # the ssq-statistics SiLU prologue on register-staged rows (CONV_PRO = 2: raw inputs too), plain / post (/ ssq_out, 32 couts) epilogue
@@ -604,7 +649,7 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
     p.gca_part_t, p.gca_chunks = None, 0
     chunks = math.ceil(OH / th) * math.ceil(OW / tw)
     fam = cfg_table()[cid][3]
-    if want_gca and pw.Cout <= cfg_table()[cid][1] and ((fam in (2, 5, 7) and x1.B * chunks <= GCA_EPILOGUE_MAX_TILES)
+    if want_gca and pw.Cout <= cfg_table()[cid][1] and ((fam in (2, 5, 7, 8) and x1.B * chunks <= GCA_EPILOGUE_MAX_TILES)
                                                         or (fam == 3 and STREAM_GCA and chunks <= 1024)):   # (GCA_FINAL / GCA_TAIL merge up to 1024 chunks per image)
         part = torch.empty(x1.B, chunks, pw.Cout + 2, dtype=torch.float32, device=x1.t.device)
         p.gca_wk, p.gca_part, p.gca_bk = gca["wk"].data_ptr(), part.data_ptr(), gca["bk"]

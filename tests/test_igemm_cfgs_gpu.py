@@ -275,6 +275,48 @@ def test_conv_gemm_family(ops, dev):
         assert tab[r["cfg"][0]][3] != 7 and r["err"] < TOL, r
 
 
+def test_conv_small_family(ops, dev):
+    """The small-map 3x3 family (csrc/conv_small.hip): 32-pixel tiles as 4 x 8 / 2 x 16 / 1 x 32, the K loop split over the 8 / 4 / 2 waves of a
+    cout fragment (even and uneven splits: 2, 3, 8, 12 and 16 channel chunks), every prologue (none, per-pixel scale, ssq statistics over a
+    concat, LayerNorm statistics; shared and per-batch affine), every epilogue incl. the all-cout ones on the 64- / 128-cout tiles (ssq_out,
+    post_pa, GlobalContext partials), several cout tiles, couts below the tile, ragged maps; and the planner's own pick on the benchmark's
+    8^2 / 16^2 layers."""
+    tab = ops.cfg_table()
+    fam8 = {tab[i][1]: i for i in range(len(tab)) if tab[i][3] == 8}
+    if not fam8:
+        pytest.skip("the library holds no small-map family")
+    raw = dict(prologue="none", act_in="none")
+    cases = [
+        dict(B=2, H=8, W=8, C1=128, Cout=128, cfg=(fam8[32], 4, 8), prologue="ssq", affine=False),                          # 8^2: four cout tiles, 8 K slices
+        dict(B=2, H=8, W=8, C1=256, C2=128, Cout=256, cfg=(fam8[32], 4, 8), prologue="ssq", affine=True),                   # the 384 -> 256 concat Block, per-batch scale / shift
+        dict(raw, B=2, H=8, W=8, C1=128, Cout=128, cfg=(fam8[128], 4, 8), gca=True, ssq_out=True),                           # all couts in one tile: GlobalContext partials + ssq_out (2 K slices)
+        dict(raw, B=2, H=8, W=8, C1=128, Cout=128, cfg=(fam8[128], 4, 8), epilogue="post"),                                  # the next Block's prologue applied by the producer
+        dict(B=2, H=16, W=16, C1=128, C2=64, Cout=128, cfg=(fam8[128], 2, 16), prologue="ssq", affine=False, epilogue="post"),   # 16^2 concat Block, 2 x 16 tiles
+        dict(raw, B=2, H=16, W=16, C1=64, Cout=64, cfg=(fam8[64], 2, 16), gca=True),                                          # 64-cout tile, 4 K slices
+        dict(B=2, H=16, W=16, C1=64, Cout=64, cfg=(fam8[64], 2, 16), prologue="ssq", affine=False, ssq_out=True),
+        dict(B=2, H=10, W=20, C1=96, Cout=72, cfg=(fam8[32], 2, 16), prologue="rs"),                                           # ragged both ways, 3 chunks (54 steps over 8 slices), couts below the last tile
+        dict(B=2, H=6, W=40, C1=64, C2=32, Cout=96, cfg=(fam8[32], 1, 32), prologue="ln", affine=True),                       # 1 x 32 tiles, LayerNorm statistics
+        dict(raw, B=2, H=8, W=8, C1=512, Cout=64, cfg=(fam8[64], 4, 8), epilogue="addend"),                                   # 16 chunks; gate * addend
+        dict(raw, B=2, H=12, W=8, C1=64, Cout=128, cfg=(fam8[32], 4, 8), epilogue="res"),
+        dict(raw, B=2, H=8, W=16, C1=64, Cout=3, cfg=(fam8[32], 2, 16), epilogue="nchw"),
+        dict(raw, B=2, H=8, W=8, C1=64, Cout=64, cfg=(fam8[32], 4, 8), epilogue="shuffle", act_out="silu"),
+        dict(raw, B=3, H=8, W=8, C1=32, Cout=32, cfg=(fam8[32], 4, 8), bias=False),                                            # one chunk: 18 steps over 8 slices
+        dict(raw, B=4, H=16, W=16, C1=32, Cout=96, cfg=(fam8[32], 2, 16)),                                                     # the map outweighs the weights: cout slab fastest in the tile order
+    ]
+    for kw in cases:
+        r = run_case(ops, dev, K=3, G=4, **kw)
+        assert r["err"] < TOL and r.get("err_ssq", 0.0) < 2e-3 and r.get("err_gca", 0.0) < 2e-3, (kw, r)
+    if not EMULATED:
+        # the planner takes the benchmark's small maps (16 rows of 8^2 / 16^2) by itself, with the tile the epilogue needs ...
+        r = run_case(ops, dev, B=16, H=8, W=8, C1=256, C2=128, Cout=256, K=3, prologue="ssq", affine=True)
+        assert tab[r["cfg"][0]][3] == 8 and tab[r["cfg"][0]][1] == 32 and r["err"] < TOL, r
+        r = run_case(ops, dev, B=16, H=16, W=16, C1=128, Cout=128, K=3, gca=True, **raw)
+        assert tab[r["cfg"][0]][3] == 8 and tab[r["cfg"][0]][1] == 128 and r["err"] < TOL and r["err_gca"] < 2e-3, r
+        # ... and leaves the larger maps where they were
+        r = run_case(ops, dev, B=16, H=32, W=32, C1=128, Cout=128, K=3, **raw)
+        assert tab[r["cfg"][0]][3] != 8 and r["err"] < TOL, r
+
+
 def test_act_prep(ops, dev):
     """ACT_PREP: the Block prologue as its own pass (ssq statistics over a two-tensor concat, per-channel gain, SiLU; and the
     LayerNorm form with a per-(batch, channel) affine) vs fp32 torch."""

@@ -11,7 +11,7 @@ mkdir -p $OUT
 TAG=""; DEFS=""
 if [ -n "${1:-}" ]; then TAG="_$1"; shift; DEFS="$*"; fi       # any other name: the remaining arguments are the -D flags of that variant
 LIB=$P/libimagen_emul$TAG.so
-TUS="igemm conv_dma conv_stream conv_pw conv_big conv_pro conv_gemm rowchain elementwise sampler temporal attention capi codesize probe"
+TUS="igemm conv_dma conv_stream conv_pw conv_big conv_pro conv_gemm conv_small rowchain elementwise sampler temporal attention capi codesize probe"
 SRCS="$(for t in $TUS; do echo $P/csrc/$t.hip; done) $P/csrc/conv_epilogue.h $P/csrc/gca_device.h $P/csrc/common.h $ROOT/include/imagen_hip.h $ROOT/tools/emul/emul_runtime.cpp $ROOT/tools/emul/hip/hip_runtime.h $ROOT/tools/emul/build_emul_lib.sh"
 if [ -f "$LIB" ]; then
   fresh=1
