@@ -291,7 +291,7 @@ def roofline_leg(imagen, batch: int, device, pmc=None):
             lib.imagen_event_destroy(e0)
             lib.imagen_event_destroy(e1)
     tab = ops.cfg_table()
-    fam_name = {0: "igemm_kernel", 2: "conv_dma_kernel", 3: "conv_stream_kernel", 4: "conv_pw_kernel", 5: "conv_big_kernel", 6: "conv_pro_kernel"}
+    fam_name = {0: "igemm_kernel", 2: "conv_dma_kernel", 3: "conv_stream_kernel", 4: "conv_pw_kernel", 5: "conv_big_kernel", 6: "conv_pro_kernel", 7: "conv_gemm_kernel", 8: "conv_small_kernel"}
 
     def describe(bound):
         cands = {k: v for k, v in groups.items() if k[0] == bound}

@@ -42,6 +42,18 @@ __host__ __device__ inline int cs_row_positions(int TW) { return TW == 8 ? 12 : 
 __host__ __device__ inline int cs_pitch(int Cin_pad) { return 2 * Cin_pad + 16; }
 __host__ __device__ inline size_t cs_tile_bytes(int TH, int TW, int Cin_pad) { return (size_t)(TH + 2) * cs_row_positions(TW) * cs_pitch(Cin_pad); }
 
+// -DCS_TRACE (tools/small_bench.py --trace, a throw-away variant library: never in the product build): thread 0 of every workgroup stamps
+// s_memtime at the phase boundaries into a buffer handed over by imagen_debug_conv_small_trace()
+#ifdef CS_TRACE
+__device__ unsigned long long* g_cs_trace = nullptr;
+#define CS_STAMP(i)                                                                                                        \
+  do {                                                                                                                     \
+    if (threadIdx.x == 0 && g_cs_trace) g_cs_trace[(size_t)blockIdx.x * 8 + (i)] = __builtin_amdgcn_s_memtime();           \
+  } while (0)
+#else
+#define CS_STAMP(i) ((void)0)
+#endif
+
 template <int NT>
 struct CsEp {   // conv_epilogue.h scratch of a (1 x NT)-wave workgroup, floats
   static constexpr int BN = 32 * NT;
@@ -63,6 +75,7 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
   constexpr int KS = 8 / NT;        // K slices
   constexpr int BN = 32 * NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  CS_STAMP(0);
   const unsigned warm = imagen_code_warm(code_bytes, threadIdx.x, CS_THREADS);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -196,8 +209,10 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
       if (dst[k] >= 0) *reinterpret_cast<uint4*>(smem + dst[k]) = ow;
     }
   }
+  CS_STAMP(1);
   __syncthreads();
   imagen_code_warm_sink(warm);
+  CS_STAMP(2);
 
   // ---- lane -> pixel of the tile: hardware service group g (0 | 1) and rank r (0 .. 15) of the lane inside its half-wave
   int g, r;
@@ -250,6 +265,7 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
     }
   }
 
+  CS_STAMP(3);
   // ---- K-split: the partial fragments of slices 1 .. KS - 1 are added into slice 0's through LDS (the halo tile is dead behind the barrier)
   if constexpr (KS > 1) {
     __syncthreads();
@@ -272,11 +288,13 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
     }
   }
 
+  CS_STAMP(4);
   // ---- epilogue: the NT live waves as a (1 x NT)-wave workgroup of conv_epilogue.h (its scratch sits behind everything else)
   const size_t body = cs_lds_bytes<NT>(TH, TW, p.Cin_pad, PRO) - (size_t)(CsEp<NT>::PAR + CsEp<NT>::RED) * sizeof(float);
   float* ep_par = reinterpret_cast<float*>(smem + body);
   float* ep_red = ep_par + CsEp<NT>::PAR;
   cl_epilogue<1, 1, 1, NT, GEN>(p, tc, acc, pix_y, pix_x, ep_red, ep_par, 0, wn, half, l31);
+  CS_STAMP(5);
 }
 
 template <int NT, bool PRO, bool GEN>
@@ -313,6 +331,10 @@ int cs_dispatch(const ImagenIgemmParams& p, hipStream_t s) {
 constexpr int kCsNT[3] = {1, 2, 4};
 
 }  // namespace
+
+#ifdef CS_TRACE
+extern "C" int imagen_debug_conv_small_trace(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cs_trace), &buf, sizeof(buf)); }
+#endif
 
 int imagen_conv_small_num_configs() { return 3; }
 

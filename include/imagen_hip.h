@@ -108,7 +108,7 @@ typedef struct ImagenIgemmParams {
    * pixel (ChanRMSNorm -> scale/shift -> SiLU of the NEXT Block, ip.py:671-691, applied by the producer so that the consuming
    * conv stages its input with no arithmetic at all) */
   const float* post_pa; const float* post_ps;
-  /* optional GlobalContext partials of the OUTPUT (plain NHWC mode, Cout <= tile couts, the kernel families 2, 3 and 5): with
+  /* optional GlobalContext partials of the OUTPUT (plain NHWC mode, Cout <= tile couts, the kernel families 2, 3, 5, 7 and 8): with
    * logit[q] = y[q, :] . gca_wk + gca_bk (ip.py:965-966), every output tile writes (max logit, sum exp, sum exp * y[q, c]) over its
    * pixels to gca_part[b][tile][Cout + 2] (tile = ty * tilesX + tx): exactly the rows GCA_PARTIAL produces with chunks = tiles per
    * image, ready for GCA_FINAL — the separate pass over the tensor disappears. */
@@ -497,7 +497,9 @@ int imagen_igemm_stage_slots(int cfg, int KH, int KW);
  * 6 = streaming kernel with the Block prologue on register-staged rows (3x3 stride 1 to exactly 32 channels from one or two 32-channel
  *     inputs, raw or with the ssq-statistics prologue, plain / post_pa / ssq_out epilogue; weights in registers, 8 x 16 tiles),
  * 7 = tiled pointwise GEMM (1x1 stride 1, inputs in 32-channel chunks, raw or with the (x - mu) * rs * pa + ps prologue, every epilogue;
- *     128-pixel x 128-cout workgroup tiles, K loop with both operands register-staged two chunks ahead). */
+ *     128-pixel x 128-cout workgroup tiles, K loop with both operands register-staged two chunks ahead),
+ * 8 = small-map 3x3 convolution (stride 1, pad 1, G = 4 packing, C1 + C2 == Cin_pad; 4x8 / 2x16 / 1x32 tiles of 32 pixels x 32 | 64 | 128 couts,
+ *     the K loop split over the waves of the workgroup; every prologue and epilogue of the contract). */
 int imagen_igemm_config_family(int cfg);
 int imagen_igemm_config_ring(int cfg);   /* weight look-ahead ring depth in stages (family 2; 0 for the others) */
 /* dynamic LDS bytes of a launch of `cfg` with a KHxKW kernel at `stride` and a THxTW output tile; -1 = not launchable */

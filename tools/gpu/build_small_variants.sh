@@ -13,3 +13,4 @@ build() {   # tag flags...
   echo "built $P/libimagen_hip_$tag.so"
 }
 build cs18 -DCS_MINW=1 -DCS_BATCH=8      # one workgroup per CU, 8 staged pieces in flight
+build cstrace -DCS_TRACE                 # s_memtime stamps at the phase boundaries (tools/small_bench.py --trace)

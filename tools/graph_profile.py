@@ -79,7 +79,7 @@ MULTI = {"quantile"}        # op kinds that launch several kernels
 
 def matches(kind, kname):
     if kind == "igemm":
-        return kname in ("igemm_kernel", "conv_dma_kernel", "conv_stream_kernel", "conv_pw_kernel", "conv_big_kernel", "conv_pro_kernel", "conv_gemm_kernel")
+        return kname in ("igemm_kernel", "conv_dma_kernel", "conv_stream_kernel", "conv_pw_kernel", "conv_big_kernel", "conv_pro_kernel", "conv_gemm_kernel", "conv_small_kernel")
     return kname.startswith(kind)
 
 
