@@ -62,8 +62,8 @@ struct CsEp {   // conv_epilogue.h scratch of a (1 x NT)-wave workgroup, floats
 };
 
 template <int NT>
-__host__ __device__ inline size_t cs_lds_bytes(int TH, int TW, int Cin_pad, bool pro) {
-  size_t body = cs_tile_bytes(TH, TW, Cin_pad) + (pro ? (size_t)2 * Cin_pad * sizeof(float) : 0);
+__host__ __device__ inline size_t cs_lds_bytes(int TH, int TW, int Cin_pad) {
+  size_t body = cs_tile_bytes(TH, TW, Cin_pad);
   const size_t partials = (size_t)(8 / NT - 1) * NT * 4096;   // the K-split partial fragments alias the (dead) halo tile
   if (partials > body) body = partials;
   return ((body + 15) & ~(size_t)15) + (size_t)(CsEp<NT>::PAR + CsEp<NT>::RED) * sizeof(float);
@@ -76,7 +76,7 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
   constexpr int BN = 32 * NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   CS_STAMP(0);
-  const unsigned warm = imagen_code_warm(code_bytes, threadIdx.x, CS_THREADS);
+  const ImagenWarm warm = imagen_code_warm(code_bytes, threadIdx.x, CS_THREADS);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
@@ -85,8 +85,6 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
   const int TH = p.TH, TW = p.TW;
   const int P = cs_row_positions(TW), pitch = cs_pitch(p.Cin_pad);
   const int HW_ = TW + 2, HH = TH + 2;                 // halo tile (used positions)
-  const size_t tile_bytes = cs_tile_bytes(TH, TW, p.Cin_pad);
-  float* const aff = reinterpret_cast<float*>(smem + tile_bytes);   // [pa Cin_pad | ps Cin_pad] of the tile's batch row (PRO)
 
   // ---- tile of this workgroup: contiguous ranges of the tile list per XCD (blockIdx goes round-robin over the 8 XCDs, each with its own L2).
   //      The list is ordered so that a range shares what is larger: cout slab fastest (the slabs of a pixel tile stage the same halo tile,
@@ -112,28 +110,64 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
     tc.n0 = nt * BN;
   }
 
-  // ---- stage the halo tile: pieces (position, 8-channel group) dealt round-robin to the threads, 8 in flight per thread and round
-  const int ppr = p.Cin_pad >> 3;                       // pieces per position
-  const int npieces = HH * HW_ * ppr;
-  const float inv_ppr = 1.0f / (float)ppr, inv_w = 1.0f / (float)HW_;
-  const f16* x1 = reinterpret_cast<const f16*>(p.x1) + (size_t)tc.b * p.bs1;
-  const f16* x2 = p.x2 ? reinterpret_cast<const f16*>(p.x2) + (size_t)tc.b * p.bs2 : x1;
-  if constexpr (PRO) {   // the per-channel affine of this batch row -> LDS (absent factors: neutral constants), requested before everything else
-    for (int i = tid; i < p.Cin_pad; i += CS_THREADS) {
-      aff[i] = p.pa ? p.pa[(size_t)tc.b * p.pstride + i] : 1.0f;
-      aff[p.Cin_pad + i] = p.ps ? p.ps[(size_t)tc.b * p.pstride + i] : 0.0f;
+  // ---- the epilogue's per-channel operands (bias, post_pa / post_ps, gca_wk): requested first, parked in LDS before the staging barrier
+  //      (conv_epilogue.h then runs PRELOADED: no dependent global round trip at the end of the kernel)
+  float* const ep_par = reinterpret_cast<float*>(smem + cs_lds_bytes<NT>(TH, TW, p.Cin_pad) - (size_t)(CsEp<NT>::PAR + CsEp<NT>::RED) * sizeof(float));
+  float* const ep_red = ep_par + CsEp<NT>::PAR;
+  // (every load of the staging phase is unconditional and global: absent operands read the head of the weight buffer and are replaced by their
+  // neutral constant afterwards — a conditional or generic-address load makes the compiler's vmcnt bookkeeping fall back to full drains,
+  // which would wait for the weight ring, the coldest request of the phase)
+  const float* const fw = reinterpret_cast<const float*>(p.w);
+  float epv[4];
+  {
+    const int co = min(tc.n0 + tid, p.Cout_pad - 1);   // (the bias is padded to Cout_pad by the host; post_pa / post_ps / gca_wk are not)
+    const int cc = min(co, p.Cout - 1);
+    epv[0] = (p.bias ? p.bias : fw)[p.bias ? co : 0];
+    epv[1] = (p.post_pa ? p.post_pa + (size_t)tc.b * p.post_pstride : fw)[p.post_pa ? cc : 0];
+    epv[2] = (p.post_pa ? p.post_ps + (size_t)tc.b * p.post_pstride : fw)[p.post_pa ? cc : 0];
+    epv[3] = (p.gca_part ? p.gca_wk : fw)[p.gca_part ? cc : 0];
+    if (!p.bias) epv[0] = 0.0f;
+    if (co >= p.Cout) epv[1] = epv[2] = epv[3] = 0.0f;
+  }
+
+  // ---- stage the halo tile.  A thread owns ONE 8-channel group (its affine stays in registers, its address arithmetic is a multiply) and
+  //      walks the positions slot, slot + nslots, ...: 512 / (Cin / 8) positions per round of the workgroup, CS_BATCH rounds in flight
+  const int ppr = p.Cin_pad >> 3;                       // 8-channel groups per position
+  const int npos = HH * HW_;
+  const float inv_w = 1.0f / (float)HW_;
+  const int nslots = CS_THREADS / ppr;
+  const int slot = (int)(((float)tid + 0.5f) * (1.0f / (float)ppr));
+  const int cg = tid - slot * ppr;
+  const bool active = slot < nslots;
+  const int c = cg * 8;
+  const bool from1 = c < p.C1;
+  const f16* bp = from1 ? reinterpret_cast<const f16*>(p.x1) + (size_t)tc.b * p.bs1 + c : reinterpret_cast<const f16*>(p.x2) + (size_t)tc.b * p.bs2 + (c - p.C1);
+  const int ld = from1 ? p.ld1 : p.ld2;
+  float a[8], sh[8];
+  if constexpr (PRO) {
+    const float4* qa = reinterpret_cast<const float4*>(p.pa ? p.pa + (size_t)tc.b * p.pstride + c : fw);
+    const float4* qs = reinterpret_cast<const float4*>(p.ps ? p.ps + (size_t)tc.b * p.pstride + c : fw);
+    const float4 a0 = qa[0], a1 = qa[1], b0 = qs[0], b1 = qs[1];
+    a[0] = a0.x; a[1] = a0.y; a[2] = a0.z; a[3] = a0.w; a[4] = a1.x; a[5] = a1.y; a[6] = a1.z; a[7] = a1.w;
+    sh[0] = b0.x; sh[1] = b0.y; sh[2] = b0.z; sh[3] = b0.w; sh[4] = b1.x; sh[5] = b1.y; sh[6] = b1.z; sh[7] = b1.w;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {   // absent factors: neutral constants
+      a[j] = p.pa ? a[j] : 1.0f;
+      sh[j] = p.ps ? sh[j] : 0.0f;
     }
   }
   const bool use_rs = p.rs != nullptr, use_ssq = !use_rs && p.ssq_a != nullptr, use_ssqb = use_ssq && p.ssq_b != nullptr;
   const bool use_mu = p.mu != nullptr, use_silu = p.act_in == IMAGEN_ACT_SILU;
-  const float* q1_base = use_rs ? p.rs : (use_ssq ? p.ssq_a : nullptr);
-  const float* q2_base = use_mu ? p.mu : (use_ssqb ? p.ssq_b : nullptr);
+  const float* q1_base = use_rs ? p.rs : (use_ssq ? p.ssq_a : fw);          // rs | ssq_a | (loaded, unused)
+  const float* q2_base = use_mu ? p.mu : (use_ssqb ? p.ssq_b : fw);        // mu | ssq_b | (loaded, unused)
+  const int q1_on = (use_rs || use_ssq) ? 1 : 0, q2_on = (use_mu || use_ssqb) ? 1 : 0;
   const int sp0 = tc.b * (p.H * p.W);
 
-  // the weight stream of this wave: cout fragment tc.n0 / 32 + wn, K = 16 steps [s0, s1) of NS = 18 per 32-channel chunk (9 taps x 2)
-  const int NS = (p.Cin_pad >> 5) * 18;
-  const int s0 = __builtin_amdgcn_readfirstlane((NS * ks) / KS), s1 = __builtin_amdgcn_readfirstlane((NS * (ks + 1)) / KS);
-  const int nsteps = s1 - s0;
+  // the weight stream of this wave: cout fragment tc.n0 / 32 + wn, the (channel chunk, tap) units [u0, u1) of NU = 9 per 32-channel chunk —
+  // a unit is two K = 16 steps (channels 0-15 and 16-31 of the chunk at one tap), four consecutive group rows of the packed buffer
+  const int NU = (p.Cin_pad >> 5) * 9;
+  const int u0 = __builtin_amdgcn_readfirstlane((NU * ks) / KS), u1 = __builtin_amdgcn_readfirstlane((NU * (ks + 1)) / KS);
+  const int nun = u1 - u0;
   const char* wbase = reinterpret_cast<const char*>(p.w) + ((size_t)(tc.n0 >> 5) + wn) * 512;
   const unsigned w_lane = ((unsigned)half * (unsigned)p.Cout_pad + (unsigned)l31) * 16u;
   const size_t w_step = (size_t)p.Cout_pad * 32;       // two group rows per K = 16 step
@@ -143,52 +177,51 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
   f16x8 ring[CS_RING];
 
   bool ring_filled = false;
-  for (int base = 0; base < npieces; base += CS_BATCH * CS_THREADS) {
+  for (int base = 0; base < npos; base += CS_BATCH * nslots) {
     uint4 raw[CS_BATCH];
     float q1[CS_BATCH], q2[CS_BATCH];
-    int dst[CS_BATCH], ch[CS_BATCH];
+    int dst[CS_BATCH];
     unsigned okmask = 0;
 #pragma unroll
     for (int k = 0; k < CS_BATCH; ++k) {
-      const int i = base + tid + k * CS_THREADS;
-      const bool in = i < npieces;
-      const int ii = in ? i : 0;
-      const int pos = (int)(((float)ii + 0.5f) * inv_ppr);
-      const int cg = ii - pos * ppr;
-      const int hy = (int)(((float)pos + 0.5f) * inv_w);
-      const int hx = pos - hy * HW_;
+      const int pos = base + slot + k * nslots;
+      const bool in = active & (pos < npos);
+      const int pp = in ? pos : 0;
+      const int hy = (int)(((float)pp + 0.5f) * inv_w);
+      const int hx = pp - hy * HW_;
       const int gy = tc.oy0 - 1 + hy, gx = tc.ox0 - 1 + hx;
-      const int c = cg * 8;
-      const bool from1 = c < p.C1;
       // (bitwise, not short-circuit: one straight-line address computation per piece; Cin_pad == C1 + C2, so every staged channel exists)
       const bool ok = in & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
       const int gp = ok ? gy * p.W + gx : 0;
-      const int eoff = ok ? (from1 ? gp * p.ld1 + c : gp * p.ld2 + (c - p.C1)) : 0;
-      const f16* bp = (from1 | !ok) ? x1 : x2;
-      raw[k] = *reinterpret_cast<const uint4*>(bp + eoff);
+      raw[k] = *reinterpret_cast<const uint4*>(bp + gp * ld);
       if constexpr (PRO) {
-        q1[k] = q1_base ? q1_base[sp0 + gp] : 1.0f;
-        q2[k] = q2_base ? q2_base[sp0 + gp] : 0.0f;
+        q1[k] = q1_base[(sp0 + gp) * q1_on];
+        q2[k] = q2_base[(sp0 + gp) * q2_on];
       }
       okmask |= (ok ? 1u : 0u) << k;
       dst[k] = in ? (hy * P + hx) * pitch + cg * 16 : -1;
-      ch[k] = c;
     }
     if (!ring_filled) {   // (behind the first round's requests: loads return in order, and the weights are the coldest of them)
       ring_filled = true;
 #pragma unroll
-      for (int i = 0; i < CS_RING; ++i) ring[i] = weight_frag(s0 + (i < nsteps ? i : nsteps - 1));
-      if constexpr (PRO) __syncthreads();   // the affine table
+      for (int i = 0; i < CS_RING / 2; ++i) {
+        const int u = u0 + (i < nun ? i : nun - 1);
+        ring[2 * i] = weight_frag(2 * u);
+        ring[2 * i + 1] = weight_frag(2 * u + 1);
+      }
+      imagen_code_warm_sink(warm);   // (the kernel's first requests: back by now — their four registers are free for the transform)
+      if (tid < BN) {   // (the next-oldest requests, exact count)
+        ep_par[tid] = epv[0];
+        ep_par[BN + tid] = epv[1];
+        ep_par[2 * BN + tid] = epv[2];
+        ep_par[3 * BN + tid] = epv[3];
+      }
     }
 #pragma unroll
     for (int k = 0; k < CS_BATCH; ++k) {
       uint4 ow = raw[k];
       if constexpr (PRO) {
         const f16x8 in = __builtin_bit_cast(f16x8, raw[k]);
-        const int cg8 = ch[k];
-        const float4 a0 = *reinterpret_cast<const float4*>(aff + cg8), a1 = *reinterpret_cast<const float4*>(aff + cg8 + 4);
-        const float4 b0 = *reinterpret_cast<const float4*>(aff + p.Cin_pad + cg8), b1 = *reinterpret_cast<const float4*>(aff + p.Cin_pad + cg8 + 4);
-        const float a[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w}, sh[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
         // ChanRMSNorm statistics straight from the producers' per-pixel sums of squares: 1 / max(sqrt(q), 1e-12) (ip.py:328)
         const float q = q1[k] + (use_ssqb ? p.ssq_wb * q2[k] : 0.0f);
         const float rs = use_rs ? q1[k] : (use_ssq ? __builtin_amdgcn_rsqf(fmaxf(q, 1e-24f)) : 1.0f);
@@ -205,13 +238,12 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
         for (int j = 0; j < 8; ++j) o[j] = (f16)(use_silu ? v[j] * e[j] : v[j]);
         ow = __builtin_bit_cast(uint4, o);
       }
-      if (!(okmask & (1u << k))) ow = make_uint4(0, 0, 0, 0);   // outside the image / past the input channels: zero padding
+      if (!(okmask & (1u << k))) ow = make_uint4(0, 0, 0, 0);   // outside the image: zero padding
       if (dst[k] >= 0) *reinterpret_cast<uint4*>(smem + dst[k]) = ow;
     }
   }
   CS_STAMP(1);
   __syncthreads();
-  imagen_code_warm_sink(warm);
   CS_STAMP(2);
 
   // ---- lane -> pixel of the tile: hardware service group g (0 | 1) and rank r (0 .. 15) of the lane inside its half-wave
@@ -228,40 +260,56 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
   else { pix_y[0] = 0; pix_x[0] = 16 * g + r; }                           // 1 x 32: left | right half
   const char* xl = smem + (pix_y[0] * P + pix_x[0]) * pitch + half * 16;
 
-  // ---- the K loop of this wave: step s = (chunk, tap, j): channels 32 chunk + 16 j (+ 8 half), tap (dy, dx) = a position offset
+  // ---- the K loop of this wave, a unit (two MFMAs) per turn: the unit's tap is a position offset, its chunk a channel offset; the B fragments
+  //      of a unit are requested one unit ahead (their LDS latency sits behind the previous unit's MFMAs), its weights four units ahead
   f32x16 acc[1][1];
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[0][0][i] = 0.f;
-  int chunk = s0 / 18, rem = s0 - chunk * 18;
-  auto b_frag = [&]() __attribute__((always_inline)) -> f16x8 {
-    const int tap = rem >> 1;
+  int chunk = u0 / 9, tap = u0 - chunk * 9;
+  auto unit_off = [&]() __attribute__((always_inline)) -> int {
     const int dy = (tap * 11) >> 5;                     // tap / 3 for tap < 9
     const int dx = tap - 3 * dy;
-    const int off = (dy * P + dx) * pitch + chunk * 64 + (rem & 1) * 32;
-    if (++rem == 18) { rem = 0; ++chunk; }
-    return *reinterpret_cast<const f16x8*>(xl + off);
+    const int off = (dy * P + dx) * pitch + chunk * 64;
+    if (++tap == 9) { tap = 0; ++chunk; }
+    return off;
   };
-  // (the B fragment of a step is requested one step ahead: its LDS latency then sits behind the previous step's MFMA)
-  f16x8 bcur = b_frag();
-  int sb = 0;
-  for (; sb + CS_RING < nsteps; sb += CS_RING) {   // straight-line body: 8 steps, each followed by the request of the step 8 ahead (clamped to the last one)
+  f16x8 b0, b1;
+  {
+    const int off = unit_off();
+    b0 = *reinterpret_cast<const f16x8*>(xl + off);
+    b1 = *reinterpret_cast<const f16x8*>(xl + off + 32);
+  }
+  constexpr int RU = CS_RING / 2;   // units in the ring
+  int ub = 0;
+  for (; ub + RU < nun; ub += RU) {   // straight-line body: RU units, each followed by the request of the unit RU ahead (clamped to the last one)
 #pragma unroll
-    for (int i = 0; i < CS_RING; ++i) {
-      const f16x8 bnext = b_frag();
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[i], bcur, acc[0][0], 0, 0, 0);
-      const int sn = sb + i + CS_RING;
-      ring[i] = weight_frag(s0 + (sn < nsteps ? sn : nsteps - 1));
-      bcur = bnext;
-      __builtin_amdgcn_sched_barrier(0);   // pins the request here (the scheduler otherwise sinks look-ahead loads to their use)
+    for (int i = 0; i < RU; ++i) {
+      const int off = unit_off();
+      const f16x8 n0 = *reinterpret_cast<const f16x8*>(xl + off), n1 = *reinterpret_cast<const f16x8*>(xl + off + 32);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[2 * i], b0, acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[2 * i + 1], b1, acc[0][0], 0, 0, 0);
+      const int un = ub + i + RU;
+      const int u = u0 + (un < nun ? un : nun - 1);
+      ring[2 * i] = weight_frag(2 * u);
+      ring[2 * i + 1] = weight_frag(2 * u + 1);
+      b0 = n0;
+      b1 = n1;
+      __builtin_amdgcn_sched_barrier(0);   // pins the requests here (the scheduler otherwise sinks look-ahead loads to their use)
     }
   }
 #pragma unroll
-  for (int i = 0; i < CS_RING; ++i) {   // the last (up to 8) steps are in the ring
-    if (sb + i < nsteps) {
-      f16x8 bnext = bcur;
-      if (sb + i + 1 < nsteps) bnext = b_frag();
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[i], bcur, acc[0][0], 0, 0, 0);
-      bcur = bnext;
+  for (int i = 0; i < RU; ++i) {   // the last (up to RU) units are in the ring
+    if (ub + i < nun) {
+      f16x8 n0 = b0, n1 = b1;
+      if (ub + i + 1 < nun) {
+        const int off = unit_off();
+        n0 = *reinterpret_cast<const f16x8*>(xl + off);
+        n1 = *reinterpret_cast<const f16x8*>(xl + off + 32);
+      }
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[2 * i], b0, acc[0][0], 0, 0, 0);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[2 * i + 1], b1, acc[0][0], 0, 0, 0);
+      b0 = n0;
+      b1 = n1;
     }
   }
 
@@ -289,18 +337,15 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
   }
 
   CS_STAMP(4);
-  // ---- epilogue: the NT live waves as a (1 x NT)-wave workgroup of conv_epilogue.h (its scratch sits behind everything else)
-  const size_t body = cs_lds_bytes<NT>(TH, TW, p.Cin_pad, PRO) - (size_t)(CsEp<NT>::PAR + CsEp<NT>::RED) * sizeof(float);
-  float* ep_par = reinterpret_cast<float*>(smem + body);
-  float* ep_red = ep_par + CsEp<NT>::PAR;
-  cl_epilogue<1, 1, 1, NT, GEN>(p, tc, acc, pix_y, pix_x, ep_red, ep_par, 0, wn, half, l31);
+  // ---- epilogue: the NT live waves as a (1 x NT)-wave workgroup of conv_epilogue.h (its scratch sits behind everything else; operands preloaded)
+  cl_epilogue<1, 1, 1, NT, GEN, true>(p, tc, acc, pix_y, pix_x, ep_red, ep_par, 0, wn, half, l31);
   CS_STAMP(5);
 }
 
 template <int NT, bool PRO, bool GEN>
 int cs_launch(const ImagenIgemmParams& p, hipStream_t s) {
   auto kern = conv_small_kernel<NT, PRO, GEN>;
-  const size_t lds = cs_lds_bytes<NT>(p.TH, p.TW, p.Cin_pad, PRO);
+  const size_t lds = cs_lds_bytes<NT>(p.TH, p.TW, p.Cin_pad);
   IMAGEN_CHECK(lds <= 160 * 1024, "conv_small: %zu bytes of LDS (Cin_pad %d)", lds, p.Cin_pad);
   static bool attr_done[16] = {};
   int dev = 0;
@@ -348,7 +393,7 @@ int imagen_conv_small_config_info(int idx, int* tile_pixels, int* tile_cout, int
 
 long imagen_conv_small_lds_bytes(int idx, int KH, int KW, int TH, int TW) {
   if (idx < 0 || idx >= 3 || KH != 3 || KW != 3 || TH * TW != 32 || (TW != 8 && TW != 16 && TW != 32)) return -1;
-  return (long)cs_lds_bytes<1>(TH, TW, 256, true);   // (a typical layer: the real figure grows with Cin and is checked at launch)
+  return (long)cs_lds_bytes<1>(TH, TW, 256);   // (a typical layer: the real figure grows with Cin and is checked at launch)
 }
 
 int launch_conv_small(const ImagenIgemmParams* pp, int idx, hipStream_t s) {

@@ -12,5 +12,5 @@ build() {   # tag flags...
   hipcc --offload-arch=gfx950 -shared -fPIC -o $P/libimagen_hip_$tag.so $OBJS /tmp/conv_small_$tag.o -L$TL -Wl,-rpath,$TL -Wl,-rpath,/opt/rocm/lib
   echo "built $P/libimagen_hip_$tag.so"
 }
-build cs18 -DCS_MINW=1 -DCS_BATCH=8      # one workgroup per CU, 8 staged pieces in flight
+#build cs18 -DCS_MINW=1 -DCS_BATCH=8      # one workgroup per CU, 8 staged pieces in flight
 build cstrace -DCS_TRACE                 # s_memtime stamps at the phase boundaries (tools/small_bench.py --trace)
