@@ -55,38 +55,20 @@ unsigned imagen_kernel_code_bytes(const char* mangled);
 // threads of the workgroup at once).  Consecutive launches of the denoiser step run different kernels, so a kernel otherwise
 // starts with a serial chain of instruction-cache misses to HBM; after this single parallel round trip they are L2 hits.  `code_bytes`
 // comes from the launcher (0 = skip); the last KiB is left out so the range never leaves the function by more than it started
-// behind its entry.  Returns values that the caller must "use" (imagen_code_warm_sink) once its own first loads have landed.
-// Round 5: four UNCONDITIONAL global loads per thread (offsets past the code re-read its first line), the values kept apart until the sink —
-// the loop over a volatile generic pointer of rounds 2-4 compiled to `flat_load_dword; s_waitcnt vmcnt(0)` inside the loop: every kernel
-// started with one blocking round trip to HBM in its first two waves, before its own first request (found in conv_small.hip's listing).
-// Four rounds cover 128 KB of code at 256 threads, 256 KB at 512 (the largest instantiation of the library is ~70 KB).
-struct ImagenWarm { unsigned v[4]; };
-__device__ __forceinline__ ImagenWarm imagen_code_warm(unsigned code_bytes, int tid, int nthreads) {
-  ImagenWarm w;
-#ifdef IMAGEN_BLOCKING_WARM   // (A/B library of call J only: rounds 2-4's loop)
-  w.v[0] = w.v[1] = w.v[2] = w.v[3] = 0;
+// behind its entry.  Returns a value that the caller must "use" (imagen_code_warm_sink) once its own first loads have landed.
+// (The loop compiles to a load + s_waitcnt vmcnt(0) per round — the first two waves of a workgroup block on it.  Round 5, call J, replaced it by
+// four non-blocking global loads sunk later: unet1 2.170 ms per step against 2.151 with the blocking loop — the waves that run ahead only meet
+// the instruction misses the wait would have covered.  The loop stays.)
+__device__ __forceinline__ unsigned imagen_code_warm(unsigned code_bytes, int tid, int nthreads) {
+  unsigned v = 0;
   if (code_bytes > 1024u) {
-    const char* pcb = reinterpret_cast<const char*>(__builtin_amdgcn_s_getpc());
+    const char* pc = reinterpret_cast<const char*>(__builtin_amdgcn_s_getpc());
     for (unsigned off = (unsigned)tid * 128u; off + 1024u < code_bytes; off += (unsigned)nthreads * 128u)
-      w.v[0] ^= *reinterpret_cast<const volatile unsigned*>(pcb + off);
+      v ^= *reinterpret_cast<const volatile unsigned*>(pc + off);
   }
-  return w;
-#endif
-  const size_t pc = (size_t)__builtin_amdgcn_s_getpc();
-  const unsigned stride = (unsigned)nthreads * 128u;
-#pragma unroll
-  for (int r = 0; r < 4; ++r) {
-    const unsigned off = (unsigned)tid * 128u + (unsigned)r * stride;
-    w.v[r] = IMAGEN_CODE_LOAD(pc, (code_bytes > 1024u && off + 1024u < code_bytes) ? off : 0u);
-  }
-  return w;
+  return v;
 }
-__device__ __forceinline__ void imagen_code_warm_sink(const ImagenWarm& w) {
-  IMAGEN_SINK(w.v[0]);
-  IMAGEN_SINK(w.v[1]);
-  IMAGEN_SINK(w.v[2]);
-  IMAGEN_SINK(w.v[3]);
-}
+__device__ __forceinline__ void imagen_code_warm_sink(unsigned v) { IMAGEN_SINK(v); }
 
 // 16-byte output pieces from the MFMA accumulator layout.  A lane of a 32x32 fragment holds channel quads 8q + 4*half + {0..3} of
 // its pixel (lanes l and l + 32 share the pixel), i.e. 8-byte pieces at 16-byte stride.  Quads q and q + 2 are exchanged between the

@@ -217,7 +217,7 @@ __global__ __launch_bounds__(512, 1) void conv_big_kernel(const ImagenIgemmParam
   // ================================================================================================ pipeline
   // Instruction warm-up (common.h) and L2 warm-up of the weights (conv_dma.hip: the workgroups of an XCD — blockIdx % 8 by observation; only
   // speed depends on it — each touch their share of the packed weights once, one dword per 128-byte line, into a sink nobody reads)
-  const ImagenWarm warm = imagen_code_warm((unsigned)p.launcher_word << 8, tid, 512);
+  const unsigned warm = imagen_code_warm((unsigned)p.launcher_word << 8, tid, 512);
   {
     const size_t wbytes = (size_t)(NC * 36) * wrow;
     const unsigned nloc = (gridDim.x + 7) >> 3, lw = blockIdx.x >> 3;

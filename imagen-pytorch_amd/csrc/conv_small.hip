@@ -34,6 +34,9 @@ constexpr int CS_RING = 8;          // weight fragments in flight per wave
 #ifndef CS_MINW
 #define CS_MINW 4                   // minimum waves per SIMD the register allocation leaves room for (4: two workgroups per CU — one stages while the other multiplies)
 #endif
+#ifndef CS_TOUCH
+#define CS_TOUCH 6                  // dword requests per lane that pull the rest of the wave's weight slab into L2 while the first ring fill is under way
+#endif
 #ifndef CS_BATCH
 #define CS_BATCH 6                  // staged 16-byte pieces in flight per thread and round (8 spills under CS_MINW 4)
 #endif
@@ -66,7 +69,7 @@ __host__ __device__ inline size_t cs_lds_bytes(int TH, int TW, int Cin_pad) {
   size_t body = cs_tile_bytes(TH, TW, Cin_pad);
   const size_t partials = (size_t)(8 / NT - 1) * NT * 4096;   // the K-split partial fragments alias the (dead) halo tile
   if (partials > body) body = partials;
-  return ((body + 15) & ~(size_t)15) + (size_t)(CsEp<NT>::PAR + CsEp<NT>::RED) * sizeof(float);
+  return ((body + 15) & ~(size_t)15) + (size_t)(CsEp<NT>::PAR + CsEp<NT>::RED) * sizeof(float) + 256;   // (+ the touch sink)
 }
 
 // NT: 32-cout fragments per workgroup tile.  PRO: the input-side prologue (statistics / affine / SiLU).  GEN: generic epilogue (conv_epilogue.h).
@@ -76,7 +79,7 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
   constexpr int BN = 32 * NT;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   CS_STAMP(0);
-  const ImagenWarm warm = imagen_code_warm(code_bytes, threadIdx.x, CS_THREADS);
+  const unsigned warm = imagen_code_warm(code_bytes, threadIdx.x, CS_THREADS);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
@@ -112,7 +115,7 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
 
   // ---- the epilogue's per-channel operands (bias, post_pa / post_ps, gca_wk): requested first, parked in LDS before the staging barrier
   //      (conv_epilogue.h then runs PRELOADED: no dependent global round trip at the end of the kernel)
-  float* const ep_par = reinterpret_cast<float*>(smem + cs_lds_bytes<NT>(TH, TW, p.Cin_pad) - (size_t)(CsEp<NT>::PAR + CsEp<NT>::RED) * sizeof(float));
+  float* const ep_par = reinterpret_cast<float*>(smem + cs_lds_bytes<NT>(TH, TW, p.Cin_pad) - 256 - (size_t)(CsEp<NT>::PAR + CsEp<NT>::RED) * sizeof(float));
   float* const ep_red = ep_par + CsEp<NT>::PAR;
   // (every load of the staging phase is unconditional and global: absent operands read the head of the weight buffer and are replaced by their
   // neutral constant afterwards — a conditional or generic-address load makes the compiler's vmcnt bookkeeping fall back to full drains,
@@ -175,6 +178,7 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
     return *reinterpret_cast<const f16x8*>(wbase + (size_t)s * w_step + w_lane);
   };
   f16x8 ring[CS_RING];
+  const unsigned touch_sink = __builtin_amdgcn_readfirstlane(IMAGEN_LDS_BASE(smem) + (unsigned)(cs_lds_bytes<NT>(TH, TW, p.Cin_pad) - 256));
 
   bool ring_filled = false;
   for (int base = 0; base < npos; base += CS_BATCH * nslots) {
@@ -209,7 +213,18 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
         ring[2 * i] = weight_frag(2 * u);
         ring[2 * i + 1] = weight_frag(2 * u + 1);
       }
-      imagen_code_warm_sink(warm);   // (the kernel's first requests: back by now — their four registers are free for the transform)
+      // the REST of the wave's weight slab, one dword per 128-byte line (a K = 16 step is 8 lines), into an LDS sink nobody reads: the ring's
+      // refills then come out of L2.  (Call J's timeline: 285 cycles per step whatever the instruction count — every refill was a cold round
+      // trip of ~2300 cycles, HBM and page walk, with 8 KB in flight per wave.)  Up to CS_TOUCH x 8 steps behind the first fill; longer
+      // slabs stream their tail as before.  Direct-to-LDS requests carry no destination register; the compiler does not count them, so
+      // its waits of this phase also cover a few of the ring's requests — issued within the same hundred cycles.
+#pragma unroll
+      for (int t = 0; t < CS_TOUCH; ++t) {
+        const int li = lane + 64 * t;
+        const int st = min(CS_RING + (li >> 3), 2 * nun - 1);
+        IMAGEN_WARM_DMA4(wbase + (size_t)(2 * u0 + st) * w_step + (size_t)((li >> 2) & 1) * p.Cout_pad * 16 + (li & 3) * 128, touch_sink);
+      }
+      imagen_code_warm_sink(warm);
       if (tid < BN) {   // (the next-oldest requests, exact count)
         ep_par[tid] = epv[0];
         ep_par[BN + tid] = epv[1];

@@ -119,7 +119,7 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
   const int tid = threadIdx.x;
   const bool producer = tid >= 256;   // wave-uniform role
   const int rtid = tid & 255;         // thread index inside the role
-  const ImagenWarm warm = imagen_code_warm((unsigned)p.launcher_word << 8, tid, 512);   // (code size / 256, set by the launcher)
+  const unsigned warm = imagen_code_warm((unsigned)p.launcher_word << 8, tid, 512);   // (code size / 256, set by the launcher)
 
   // ---- the tile list of this workgroup
   const int tilesX = (p.OW + p.TW - 1) / p.TW;
@@ -889,7 +889,7 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
   }
   lds_barrier();   // phase 0 staged
   imagen_code_warm_sink(warm);
-  IMAGEN_SINK(warm_ep);
+  imagen_code_warm_sink(warm_ep);
   int cur = 0;
   while (true) {
     const int t_next = t_cursor + t_step;

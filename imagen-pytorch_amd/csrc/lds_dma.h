@@ -15,7 +15,6 @@
 #define IMAGEN_WAIT_VM_STORES(n) ((void)(n), emul::wait_vm(0))   // (the allowance counts the lane's output STORES behind its copies; the emulation queues copies only)
 #define IMAGEN_OPAQUE(v) ((void)0)
 #define IMAGEN_SINK(v) ((void)(v))
-#define IMAGEN_CODE_LOAD(pc, off) 0u                     // (the instruction warm-up reads the kernel's own code: nothing to emulate)
 #else
 __device__ __forceinline__ void imagen_dma16(const void* gsrc, unsigned lds_dst) {
   asm volatile("s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %0, off" ::"v"(gsrc), "s"(lds_dst) : "memory");
@@ -50,8 +49,6 @@ __device__ __forceinline__ void imagen_wait_vm_le12(int n) {   // s_waitcnt vmcn
 #define IMAGEN_WAIT_VM_STORES(n) imagen_wait_vm_le12(n)
 #define IMAGEN_OPAQUE(v) asm volatile("" : "+v"(v))      // makes a value opaque to the optimiser (nothing derived from it is hoisted)
 #define IMAGEN_SINK(v) asm volatile("" ::"v"(v))         // "uses" a value (keeps the loads that produced it alive)
-// one dword of the kernel's own code as a GLOBAL load (a generic-address load is a flat_load: it counts on lgkmcnt too, and every LDS wait behind it waits for it)
-#define IMAGEN_CODE_LOAD(pc, off) (*reinterpret_cast<const unsigned __attribute__((address_space(1)))*>((size_t)(pc) + (off)))   // (NOT volatile: a volatile access is followed by a full vmcnt(0))
 #endif
 // s_waitcnt vmcnt(n) only (gfx9 encoding: vmcnt[3:0] | expcnt[6:4] | lgkmcnt[11:8] | vmcnt[15:14]) + a compiler-level fence; both builds
 #define IMAGEN_WAIT_VM(n)                                                                     \

@@ -1065,7 +1065,7 @@ template <int MODE, int RB>
 __global__ __launch_bounds__(kThreads, ROWCHAIN_MINW) void rowchain_kernel(const ImagenRowchainParams p, unsigned code_bytes) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   // the kernel's own code range read as data, one parallel round trip (common.h: consecutive launches of a step run different kernels)
-  const ImagenWarm warm = imagen_code_warm(code_bytes, threadIdx.x, kThreads);
+  const unsigned warm = imagen_code_warm(code_bytes, threadIdx.x, kThreads);
   const int row0 = blockIdx.x * 32 * RB;
   if (MODE == IMAGEN_CHAIN_FF) chain_ff<RB>(p, smem, row0);
   else if (MODE == IMAGEN_CHAIN_XATTN) chain_xattn<RB>(p, smem, row0);

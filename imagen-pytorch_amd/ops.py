@@ -362,9 +362,9 @@ def small_tile(OH: int, OW: int) -> Optional[tuple]:
 
 def small_lds_bytes(th: int, tw: int, Cin_pad: int, bn: int) -> int:
     """conv_small.hip's cs_lds_bytes (halo tile + affine table | K-split partials, + epilogue scratch)."""
-    body = (th + 2) * (12 if tw == 8 else tw + 2) * (2 * Cin_pad + 16) + 8 * Cin_pad
+    body = (th + 2) * (12 if tw == 8 else tw + 2) * (2 * Cin_pad + 16)
     nt = bn // 32
-    return max(body, (8 // nt - 1) * nt * 4096) + 16 + 4 * (4 * bn + nt * 32 + 8 + bn + 4 + nt * 32)
+    return max(body, (8 // nt - 1) * nt * 4096) + 16 + 4 * (4 * bn + nt * 32 + 8 + bn + 4 + nt * 32) + 256
 
 
 def gemm_cfg() -> Optional[int]:
