@@ -21,6 +21,13 @@
 //   * epilogue: the waves of K slice 0 own the summed fragments and run conv_epilogue.h as a (1 x NT)-wave workgroup — every epilogue of
 //     the contract, the all-cout ones (ssq_out / post_pa / GlobalContext partials) where 32 NT covers Cout; the other waves have left
 //     (s_barrier counts live waves).
+// Measured (round 5, calls I - L, tools/small_bench.py: cold operands, rocprofv3 durations + an s_memtime phase timeline): a launch is two cold
+// round trips (kernel arguments, then the halo tile: ~2300 cycles each behind a flushed L2 / TLB) + the K loop + ~4k cycles of K-split sum and
+// epilogue.  The K loop runs at ~285 cycles per K = 16 step per wave whatever its instruction count: 8 KB in flight per wave against that
+// latency.  Touching the rest of the slab into L2 first (one dword per line, direct-to-LDS sink) halved the K loop and cost the staging phase
+// the same 5k cycles — the address path takes a line per clock, a touch is as expensive there as the load it prepares — so it is not kept.
+// [384 -> 256 @8^2 x 16]: 20.0 -> 12.8 us, [256 -> 256 @8^2]: 15.6 -> 12.0, [192 -> 128 @16^2]: 15.1 -> 13.5; the 32^2 maps and the 512- / 1024-
+// channel layers of C2 lose (32-pixel tiles stream every weight byte through each pixel tile's CU: 75 - 94 us against 33 - 48), the planner keeps them away.
 // Contract: ImagenIgemmParams with KH = KW = 3, stride 1, pad 1, G = 4 packing; C1 % 8 == 0, C1 + C2 == Cin_pad (a multiple of 32);
 // output tiles of 32 pixels as 4 x 8, 2 x 16 or 1 x 32 (partial tiles at the map's edge are masked).
 #include <cstdio>
@@ -33,9 +40,6 @@ constexpr int CS_THREADS = 512;
 constexpr int CS_RING = 8;          // weight fragments in flight per wave
 #ifndef CS_MINW
 #define CS_MINW 4                   // minimum waves per SIMD the register allocation leaves room for (4: two workgroups per CU — one stages while the other multiplies)
-#endif
-#ifndef CS_TOUCH
-#define CS_TOUCH 6                  // dword requests per lane that pull the rest of the wave's weight slab into L2 while the first ring fill is under way
 #endif
 #ifndef CS_BATCH
 #define CS_BATCH 6                  // staged 16-byte pieces in flight per thread and round (8 spills under CS_MINW 4)
@@ -69,7 +73,7 @@ __host__ __device__ inline size_t cs_lds_bytes(int TH, int TW, int Cin_pad) {
   size_t body = cs_tile_bytes(TH, TW, Cin_pad);
   const size_t partials = (size_t)(8 / NT - 1) * NT * 4096;   // the K-split partial fragments alias the (dead) halo tile
   if (partials > body) body = partials;
-  return ((body + 15) & ~(size_t)15) + (size_t)(CsEp<NT>::PAR + CsEp<NT>::RED) * sizeof(float) + 256;   // (+ the touch sink)
+  return ((body + 15) & ~(size_t)15) + (size_t)(CsEp<NT>::PAR + CsEp<NT>::RED) * sizeof(float);
 }
 
 // NT: 32-cout fragments per workgroup tile.  PRO: the input-side prologue (statistics / affine / SiLU).  GEN: generic epilogue (conv_epilogue.h).
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
 
   // ---- the epilogue's per-channel operands (bias, post_pa / post_ps, gca_wk): requested first, parked in LDS before the staging barrier
   //      (conv_epilogue.h then runs PRELOADED: no dependent global round trip at the end of the kernel)
-  float* const ep_par = reinterpret_cast<float*>(smem + cs_lds_bytes<NT>(TH, TW, p.Cin_pad) - 256 - (size_t)(CsEp<NT>::PAR + CsEp<NT>::RED) * sizeof(float));
+  float* const ep_par = reinterpret_cast<float*>(smem + cs_lds_bytes<NT>(TH, TW, p.Cin_pad) - (size_t)(CsEp<NT>::PAR + CsEp<NT>::RED) * sizeof(float));
   float* const ep_red = ep_par + CsEp<NT>::PAR;
   // (every load of the staging phase is unconditional and global: absent operands read the head of the weight buffer and are replaced by their
   // neutral constant afterwards — a conditional or generic-address load makes the compiler's vmcnt bookkeeping fall back to full drains,
@@ -178,7 +182,6 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
     return *reinterpret_cast<const f16x8*>(wbase + (size_t)s * w_step + w_lane);
   };
   f16x8 ring[CS_RING];
-  const unsigned touch_sink = __builtin_amdgcn_readfirstlane(IMAGEN_LDS_BASE(smem) + (unsigned)(cs_lds_bytes<NT>(TH, TW, p.Cin_pad) - 256));
 
   bool ring_filled = false;
   for (int base = 0; base < npos; base += CS_BATCH * nslots) {
@@ -205,24 +208,13 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
       okmask |= (ok ? 1u : 0u) << k;
       dst[k] = in ? (hy * P + hx) * pitch + cg * 16 : -1;
     }
-    if (!ring_filled) {   // (behind the first round's requests: loads return in order, and the weights are the coldest of them)
+    if (!ring_filled) {   // the first ring fill, behind the first round's requests (loads return in order: in front, it would hold them back — call L)
       ring_filled = true;
 #pragma unroll
       for (int i = 0; i < CS_RING / 2; ++i) {
         const int u = u0 + (i < nun ? i : nun - 1);
         ring[2 * i] = weight_frag(2 * u);
         ring[2 * i + 1] = weight_frag(2 * u + 1);
-      }
-      // the REST of the wave's weight slab, one dword per 128-byte line (a K = 16 step is 8 lines), into an LDS sink nobody reads: the ring's
-      // refills then come out of L2.  (Call J's timeline: 285 cycles per step whatever the instruction count — every refill was a cold round
-      // trip of ~2300 cycles, HBM and page walk, with 8 KB in flight per wave.)  Up to CS_TOUCH x 8 steps behind the first fill; longer
-      // slabs stream their tail as before.  Direct-to-LDS requests carry no destination register; the compiler does not count them, so
-      // its waits of this phase also cover a few of the ring's requests — issued within the same hundred cycles.
-#pragma unroll
-      for (int t = 0; t < CS_TOUCH; ++t) {
-        const int li = lane + 64 * t;
-        const int st = min(CS_RING + (li >> 3), 2 * nun - 1);
-        IMAGEN_WARM_DMA4(wbase + (size_t)(2 * u0 + st) * w_step + (size_t)((li >> 2) & 1) * p.Cout_pad * 16 + (li & 3) * 128, touch_sink);
       }
       imagen_code_warm_sink(warm);
       if (tid < BN) {   // (the next-oldest requests, exact count)

@@ -335,7 +335,9 @@ def pw_cfg(kchunks: int, Cout: int) -> Optional[int]:
 
 
 CONV_SMALL = int(_os.environ.get("IMAGEN_CONV_SMALL", "1"))   # A/B switch: conv_small.hip (family 8) for the 3x3 convs of the small maps
-SMALL_MAX_ROWS = int(_os.environ.get("IMAGEN_CONV_SMALL_ROWS", "4096"))   # ... of at most this many output pixels per launch (16 images of 8^2 / 16^2)
+SMALL_MAX_ROWS = int(_os.environ.get("IMAGEN_CONV_SMALL_ROWS", "4096"))   # ... of at most this many output pixels per launch (16 images of 8^2 / 16^2; call H: the 32^2 maps lose 1.3 ms per unet2 step)
+SMALL_MAX_STREAM_MB = 128   # ... whose pixel tiles together stream at most this much weight data out of L2 (every 32-pixel tile reads all of its slab: README unet1's
+                            # layers 38 - 57 MB; C2's 512 -> 512 @16^2 and 1024 -> 1024 @8^2 604 MB — 75 / 86 us against 33 / 48 on the wave-specialised kernel, call J)
 
 
 def small_cfg(Cout: int, full_cout: bool) -> Optional[int]:
@@ -364,7 +366,7 @@ def small_lds_bytes(th: int, tw: int, Cin_pad: int, bn: int) -> int:
     """conv_small.hip's cs_lds_bytes (halo tile + affine table | K-split partials, + epilogue scratch)."""
     body = (th + 2) * (12 if tw == 8 else tw + 2) * (2 * Cin_pad + 16)
     nt = bn // 32
-    return max(body, (8 // nt - 1) * nt * 4096) + 16 + 4 * (4 * bn + nt * 32 + 8 + bn + 4 + nt * 32) + 256
+    return max(body, (8 // nt - 1) * nt * 4096) + 16 + 4 * (4 * bn + nt * 32 + 8 + bn + 4 + nt * 32)
 
 
 def gemm_cfg() -> Optional[int]:
@@ -530,7 +532,8 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
                 and x1.ld % 8 == 0 and x1.bs % 8 == 0 and (x2 is None or (x2.ld % 8 == 0 and x2.bs % 8 == 0))
                 and act_in in (ACT_NONE, ACT_SILU) and (mu is None or rs is not None) and (pstride == 0 or pstride >= pw.Cin_pad)
                 and (out_mode == OUT_NCHW_F32 or pw.Cout % 4 == 0)
-                and small_lds_bytes(tile[0], tile[1], pw.Cin_pad, cfg_table()[sc][1]) <= MAX_LDS_BYTES):
+                and small_lds_bytes(tile[0], tile[1], pw.Cin_pad, cfg_table()[sc][1]) <= MAX_LDS_BYTES
+                and (x1.B * OH * OW // 32) * pw.Cout_pad * pw.Cin_pad * 18 <= SMALL_MAX_STREAM_MB << 20):
             cfg = (sc, tile[0], tile[1])
     if cfg is None and CONV_PRO and KH == 3 and KW == 3 and stride == 1 and pad == 1 and pw.G == 4 and pro_cfg(pw.Cout) is not None:
         # family 6: exactly 32 output channels from 32 | 32 + 32 input channels, or 64 from two or three 32-channel chunks (64 | 64 + 32 | 32 + 32):

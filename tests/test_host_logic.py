@@ -382,3 +382,31 @@ def test_family7_respects_the_launcher_k_limit():
     plan = ops.Plan("twice")
     ops.igemm(plan, ops.new_act(1, 1, 64, 64, "cpu"), w, ops.new_act(1, 1, 64, 32, "cpu"), pa=pa)
     assert len(plan.twice) == 1 and not hasattr(ops, "_TWICE")
+
+
+def test_family8_routing_rules():
+    """The small-map 3x3 family (conv_small.hip) takes a launch only where it measured faster (round 5, calls H - L): at most 4096 output pixels, at
+    most 128 MB of weight data streamed by the launch's pixel tiles together; the 32-cout tile unless the epilogue needs every channel of a pixel
+    (then the narrowest tile over all couts, Cout <= 128).  Dry plans on CPU memory."""
+    from imagen_pytorch_amd import ops
+
+    tab = ops.cfg_table()
+
+    def pick(B, H, C1, Cout, C2=0, **kw):
+        w = ops.pack_weight(torch.randn(Cout, C1 + C2, 3, 3) * 0.01, None, "cpu", G=4)
+        x1, x2 = ops.new_act(B, H, H, C1, "cpu"), (ops.new_act(B, H, H, C2, "cpu") if C2 else None)
+        p = ops.igemm(ops.Plan("fam8"), x1, w, ops.new_act(B, H, H, Cout, "cpu"), x2=x2, **kw)
+        return tab[p.cfg], (p.TH, p.TW), p
+
+    ssq = lambda B, H: dict(ssq_a=torch.ones(B * H * H), pa=torch.ones(1, 1), act_in=ops.ACT_SILU)
+    assert pick(16, 8, 256, 256, C2=128)[:2] == ((32, 32, 4, 8), (4, 8))                       # README unet1's widest small-map layer: 54 MB of weight stream
+    assert pick(16, 16, 128, 128)[:2] == ((32, 32, 4, 8), (2, 16))
+    t, sh, p = pick(16, 16, 128, 128, gca=dict(wk=torch.ones(128), bk=0.0))                   # GlobalContext partials: one tile over all 128 couts
+    assert t == (32, 128, 4, 8) and p.gca_chunks == 8 and p.gca_part_t is not None
+    t, sh, p = pick(16, 8, 64, 64, ssq_out=torch.empty(16 * 64))
+    assert t == (32, 64, 4, 8) and p.ssq_emitted
+    t, sh, p = pick(16, 8, 256, 256, ssq_out=torch.empty(16 * 64))                             # wider than any tile: the 32-cout tile, statistics left to the caller
+    assert t == (32, 32, 4, 8) and not p.ssq_emitted
+    assert pick(16, 32, 128, 128)[0][3] != 8                                                   # 16384 pixels: the 32^2 maps stay where they were
+    assert pick(16, 16, 512, 512)[0][3] != 8 and pick(16, 8, 1024, 1024)[0][3] != 8            # C2's layers: 604 MB of weight stream
+    assert pick(4, 16, 512, 512)[0][3] != 8 and pick(2, 16, 512, 512)[0][3] == 8               # ... 151 MB at a quarter of the rows: still not; 75 MB at an eighth: taken
