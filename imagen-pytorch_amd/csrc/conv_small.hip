@@ -41,6 +41,10 @@ constexpr int CS_RING = 8;          // weight fragments in flight per wave
 #ifndef CS_MINW
 #define CS_MINW 4                   // minimum waves per SIMD the register allocation leaves room for (4: two workgroups per CU — one stages while the other multiplies)
 #endif
+#ifndef CS_PHASES
+#define CS_PHASES 4                 // the pixel tiles that share a weight slab start their K walk at 0, 1/4, 1/2, 3/4 of the slice (wrapping): behind the
+                                    // first quarter a wave meets lines a neighbour pulled into L2 a quarter earlier (1: every tile walks from the start)
+#endif
 #ifndef CS_BATCH
 #define CS_BATCH 6                  // staged 16-byte pieces in flight per thread and round (8 spills under CS_MINW 4)
 #endif
@@ -175,6 +179,13 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
   const int NU = (p.Cin_pad >> 5) * 9;
   const int u0 = __builtin_amdgcn_readfirstlane((NU * ks) / KS), u1 = __builtin_amdgcn_readfirstlane((NU * (ks + 1)) / KS);
   const int nun = u1 - u0;
+  // the walk of this wave: units u0 + (i + rot) mod nun, i = 0 .. nun - 1.  All pixel tiles of an image batch read the same slab, in lockstep when
+  // they all start at its head: every ring refill is then a cold miss for every one of them (call J: ~2300 cycles against ~500 out of L2)
+  const int rot = __builtin_amdgcn_readfirstlane(nun >= 2 * CS_PHASES ? (((tc.b * tilesY + tc.oy0 / TH) * tilesX + tc.ox0 / TW) % CS_PHASES) * nun / CS_PHASES : 0);
+  auto walk = [&](int i) __attribute__((always_inline)) -> int {   // i < nun
+    const int x = i + rot;
+    return u0 + (x >= nun ? x - nun : x);
+  };
   const char* wbase = reinterpret_cast<const char*>(p.w) + ((size_t)(tc.n0 >> 5) + wn) * 512;
   const unsigned w_lane = ((unsigned)half * (unsigned)p.Cout_pad + (unsigned)l31) * 16u;
   const size_t w_step = (size_t)p.Cout_pad * 32;       // two group rows per K = 16 step
@@ -212,7 +223,7 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
       ring_filled = true;
 #pragma unroll
       for (int i = 0; i < CS_RING / 2; ++i) {
-        const int u = u0 + (i < nun ? i : nun - 1);
+        const int u = walk(i < nun ? i : nun - 1);
         ring[2 * i] = weight_frag(2 * u);
         ring[2 * i + 1] = weight_frag(2 * u + 1);
       }
@@ -272,12 +283,20 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
   f32x16 acc[1][1];
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[0][0][i] = 0.f;
-  int chunk = u0 / 9, tap = u0 - chunk * 9;
+  int uabs = walk(0);
+  int chunk = uabs / 9, tap = uabs - chunk * 9;
   auto unit_off = [&]() __attribute__((always_inline)) -> int {
     const int dy = (tap * 11) >> 5;                     // tap / 3 for tap < 9
     const int dx = tap - 3 * dy;
     const int off = (dy * P + dx) * pitch + chunk * 64;
-    if (++tap == 9) { tap = 0; ++chunk; }
+    if (++uabs == u1) {                                 // the walk wraps to the head of the slice
+      uabs = u0;
+      chunk = u0 / 9;
+      tap = u0 - chunk * 9;
+    } else if (++tap == 9) {
+      tap = 0;
+      ++chunk;
+    }
     return off;
   };
   f16x8 b0, b1;
@@ -296,7 +315,7 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[2 * i], b0, acc[0][0], 0, 0, 0);
       acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[2 * i + 1], b1, acc[0][0], 0, 0, 0);
       const int un = ub + i + RU;
-      const int u = u0 + (un < nun ? un : nun - 1);
+      const int u = walk(un < nun ? un : nun - 1);
       ring[2 * i] = weight_frag(2 * u);
       ring[2 * i + 1] = weight_frag(2 * u + 1);
       b0 = n0;

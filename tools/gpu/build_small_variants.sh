@@ -14,3 +14,4 @@ build() {   # tag flags...
 }
 #build cs18 -DCS_MINW=1 -DCS_BATCH=8      # one workgroup per CU, 8 staged pieces in flight
 build cstrace -DCS_TRACE                 # s_memtime stamps at the phase boundaries (tools/small_bench.py --trace)
+build csph1 -DCS_PHASES=1                # every pixel tile walks its K slice from the head (the A/B of the phase-shifted walk)
