@@ -34,6 +34,10 @@ constexpr int kDh = 64;
 #define ROWCHAIN_MINW 1       // minimum waves per SIMD the register allocation leaves room for (4: two 512-thread workgroups per CU)
 #endif
 constexpr int kRing = ROWCHAIN_RING;
+#ifndef ROWCHAIN_PHASES
+#define ROWCHAIN_PHASES 4
+#endif
+constexpr int kPhases = ROWCHAIN_PHASES;
 
 // -DROWCHAIN_TRACE (tools/chain_bench.py --trace, a throw-away variant library: never in the product build): thread 0 of every workgroup
 // stamps s_memtime at the phase boundaries into a buffer handed over by imagen_debug_rowchain_trace()
@@ -108,7 +112,11 @@ struct Part {
   int wk, kpart;        // K split: wk parts, this wave's part (kpart >= wk: idle)
   int s0, s1;           // this wave's K steps [s0, s1)
   int T;
+  int rot;              // the wave walks them as s0 + (i + rot) mod (s1 - s0): see make_part
 };
+
+// rotation of a wave's walk over n K steps: the row tile's phase (0 .. kPhases - 1) x n / kPhases; short slices walk from the head
+__device__ __forceinline__ int phase_rot(int n) { return n >= 2 * kPhases ? (int)(blockIdx.x % kPhases) * n / kPhases : 0; }
 
 __device__ __forceinline__ Part make_part(int T, int ksteps, int wave) {
   Part q;
@@ -131,6 +139,10 @@ __device__ __forceinline__ Part make_part(int T, int ksteps, int wave) {
     q.s0 = q.kpart < wk ? q.kpart * per : 0;
     q.s1 = q.kpart < wk ? q.s0 + per : 0;
   }
+  // phase-shifted walk (conv_small.hip, call M: K loop 10.3k -> 6.6k cycles): every row tile streams the same weights, in lockstep when they all
+  // start at the head of the slice — each ring refill is then a cold miss for all of them.  Neighbouring tiles start at 0, 1/4, 1/2, 3/4
+  // of it instead (wrapping): behind the first quarter a wave meets lines a neighbour pulled into L2 a quarter earlier.
+  q.rot = phase_rot(q.s1 - q.s0);
   return q;
 }
 
@@ -171,13 +183,18 @@ __device__ __forceinline__ f16x8 weight_frag(const WeightStream& ws, int s, int 
   return *reinterpret_cast<const f16x8*>(ub + ws.lane_off);
 }
 
+__device__ __forceinline__ int walk_step(int i, int rot, int n) {   // i < n
+  const int x = i + rot;
+  return x >= n ? x - n : x;
+}
+
 template <int NT>
-__device__ __forceinline__ void ring_fill(f16x8 (&ring)[kRing], const WeightStream& ws, int s0, int n) {
+__device__ __forceinline__ void ring_fill(f16x8 (&ring)[kRing], const WeightStream& ws, int s0, int n, int rot) {
   constexpr int D = kRing / NT;
   if (n <= 0) return;
 #pragma unroll
   for (int i = 0; i < D; ++i) {
-    const int s = s0 + (i < n ? i : n - 1);
+    const int s = s0 + walk_step(i < n ? i : n - 1, rot, n);
 #pragma unroll
     for (int t = 0; t < NT; ++t) ring[i * NT + t] = weight_frag(ws, s, t);
   }
@@ -185,7 +202,7 @@ __device__ __forceinline__ void ring_fill(f16x8 (&ring)[kRing], const WeightStre
 
 // acc[t][j] += W[cout tiles tile0 + t][K steps s0 .. s0 + n) . X[rows of row block j]: the ring holds steps s0 .. s0 + D - 1 on entry
 template <int NT, int RB>
-__device__ __forceinline__ void gemm_run(f32x16 (*acc)[RB], f16x8 (&ring)[kRing], const WeightStream& ws, int s0, int n, const char* xs, int pitch,
+__device__ __forceinline__ void gemm_run(f32x16 (*acc)[RB], f16x8 (&ring)[kRing], const WeightStream& ws, int s0, int n, int rot, const char* xs, int pitch,
                                          int lane) {
   constexpr int D = kRing / NT;
   if (n <= 0) return;
@@ -197,12 +214,12 @@ __device__ __forceinline__ void gemm_run(f32x16 (*acc)[RB], f16x8 (&ring)[kRing]
       const int s = sb + i;
       f16x8 b[RB];
 #pragma unroll
-      for (int j = 0; j < RB; ++j) b[j] = *reinterpret_cast<const f16x8*>(xl + (size_t)j * 32 * pitch + (s0 + s) * 32);
+      for (int j = 0; j < RB; ++j) b[j] = *reinterpret_cast<const f16x8*>(xl + (size_t)j * 32 * pitch + (s0 + walk_step(s, rot, n)) * 32);
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
         for (int j = 0; j < RB; ++j) acc[t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ring[i * NT + t], b[j], acc[t][j], 0, 0, 0);
-      const int sn = s0 + (s + D < n ? s + D : n - 1);
+      const int sn = s0 + walk_step(s + D < n ? s + D : n - 1, rot, n);
 #pragma unroll
       for (int t = 0; t < NT; ++t) ring[i * NT + t] = weight_frag(ws, sn, t);
       __builtin_amdgcn_sched_barrier(0);   // pins the request here (the scheduler otherwise sinks look-ahead loads to their use)
@@ -213,7 +230,7 @@ __device__ __forceinline__ void gemm_run(f32x16 (*acc)[RB], f16x8 (&ring)[kRing]
     if (sb + i < n) {
       f16x8 b[RB];
 #pragma unroll
-      for (int j = 0; j < RB; ++j) b[j] = *reinterpret_cast<const f16x8*>(xl + (size_t)j * 32 * pitch + (s0 + sb + i) * 32);
+      for (int j = 0; j < RB; ++j) b[j] = *reinterpret_cast<const f16x8*>(xl + (size_t)j * 32 * pitch + (s0 + walk_step(sb + i, rot, n)) * 32);
 #pragma unroll
       for (int t = 0; t < NT; ++t)
 #pragma unroll
@@ -423,8 +440,8 @@ __device__ __forceinline__ void ln_res_out_rows(const ImagenRowchainParams& p, i
 // (stage_run); the owners' accumulators stay in acc (first q.nt tiles)
 __device__ __forceinline__ void stage_fill(f16x8 (&ring)[kRing], const Part& q, const void* w, int cout_pad, int lane) {
   const WeightStream ws = weight_stream(w, cout_pad, q.tile0, lane);
-  if (q.nt == 2) ring_fill<2>(ring, ws, q.s0, q.s1 - q.s0);
-  else ring_fill<1>(ring, ws, q.s0, q.s1 - q.s0);
+  if (q.nt == 2) ring_fill<2>(ring, ws, q.s0, q.s1 - q.s0, q.rot);
+  else ring_fill<1>(ring, ws, q.s0, q.s1 - q.s0, q.rot);
 }
 
 template <int RB>
@@ -432,8 +449,8 @@ __device__ __forceinline__ void stage_run(f32x16 (&acc)[2][RB], f16x8 (&ring)[kR
                                           char* scratch, int lane) {
   const WeightStream ws = weight_stream(w, cout_pad, q.tile0, lane);
   acc_zero<2, RB>(acc);
-  if (q.nt == 2) gemm_run<2, RB>(acc, ring, ws, q.s0, q.s1 - q.s0, xs, pitch, lane);
-  else gemm_run<1, RB>(acc, ring, ws, q.s0, q.s1 - q.s0, xs, pitch, lane);
+  if (q.nt == 2) gemm_run<2, RB>(acc, ring, ws, q.s0, q.s1 - q.s0, q.rot, xs, pitch, lane);
+  else gemm_run<1, RB>(acc, ring, ws, q.s0, q.s1 - q.s0, q.rot, xs, pitch, lane);
   ksplit_reduce<RB>(acc[0], q, scratch, lane);
 }
 
@@ -768,6 +785,7 @@ __device__ __forceinline__ void chain_xattn(const ImagenRowchainParams& p, char*
   qq.kpart = 0;
   qq.s0 = 0;
   qq.s1 = C >> 4;
+  qq.rot = phase_rot(qq.s1);
   RC_STAMP(0);
   stage_fill(ring, qq, p.w0, p.w_cout_pad0, lane);
   {
@@ -782,7 +800,7 @@ __device__ __forceinline__ void chain_xattn(const ImagenRowchainParams& p, char*
   {
     const WeightStream ws = weight_stream(p.w0, p.w_cout_pad0, qq.tile0, lane);
     acc_zero<2, RB>(acc);
-    gemm_run<2, RB>(acc, ring, ws, 0, qq.s1, P1, pitch1, lane);
+    gemm_run<2, RB>(acc, ring, ws, 0, qq.s1, qq.rot, P1, pitch1, lane);
   }
   RC_STAMP(3);
   // ---- the attention of head `wave`, wave-local.  Q^ of every row block first (the fp32 accumulators are dead after it); the key tiles are
@@ -869,7 +887,8 @@ __device__ __forceinline__ void chain_qkv(const ImagenRowchainParams& p, char* s
   // ---- y = a [Wq | Wkv]^T: 20 cout tiles — every wave two (q head `wave`), waves 0-3 one of the k | v tiles on top
   f16x8 ring[kRing];
   WeightStream ws = weight_stream(p.w0, p.w_cout_pad0, 2 * wave, lane);
-  ring_fill<2>(ring, ws, 0, C >> 4);
+  const int rotq = phase_rot(C >> 4);
+  ring_fill<2>(ring, ws, 0, C >> 4, rotq);
   {
     RowPieces<RB> xr;
     load_row_pieces<RB>(xr, p.x, p.ld_x, row0 + r, C, li);
@@ -878,10 +897,10 @@ __device__ __forceinline__ void chain_qkv(const ImagenRowchainParams& p, char* s
   __syncthreads();
   f32x16 acc[2][RB];
   acc_zero<2, RB>(acc);
-  gemm_run<2, RB>(acc, ring, ws, 0, C >> 4, P1, pitch1, lane);
+  gemm_run<2, RB>(acc, ring, ws, 0, C >> 4, rotq, P1, pitch1, lane);
   if (wave < 4) {   // (requested before the first two tiles are stored)
     ws = weight_stream(p.w0, p.w_cout_pad0, 16 + wave, lane);
-    ring_fill<1>(ring, ws, 0, C >> 4);
+    ring_fill<1>(ring, ws, 0, C >> 4, rotq);
   }
 #pragma unroll
   for (int t = 0; t < 2; ++t)
@@ -889,7 +908,7 @@ __device__ __forceinline__ void chain_qkv(const ImagenRowchainParams& p, char* s
     for (int j = 0; j < RB; ++j) store_tile<IMAGEN_ACT_NONE>(acc[t][j], P0, pitch0, 2 * wave + t, j, lane);
   if (wave < 4) {
     acc_zero<1, RB>(acc);
-    gemm_run<1, RB>(acc, ring, ws, 0, C >> 4, P1, pitch1, lane);
+    gemm_run<1, RB>(acc, ring, ws, 0, C >> 4, rotq, P1, pitch1, lane);
 #pragma unroll
     for (int j = 0; j < RB; ++j) store_tile<IMAGEN_ACT_NONE>(acc[0][j], P0, pitch0, 16 + wave, j, lane);
   }
