@@ -28,7 +28,8 @@
 // the same 5k cycles — the address path takes a line per clock, a touch is as expensive there as the load it prepares — so it is not kept.
 // [384 -> 256 @8^2 x 16]: 20.0 -> 12.8 us, [256 -> 256 @8^2]: 15.6 -> 12.0, [192 -> 128 @16^2]: 15.1 -> 13.5; the 32^2 maps and the 512- / 1024-
 // channel layers of C2 lose (32-pixel tiles stream every weight byte through each pixel tile's CU: 75 - 94 us against 33 - 48), the planner keeps them away.
-// Contract: ImagenIgemmParams with KH = KW = 3, stride 1, pad 1, G = 4 packing; C1 % 8 == 0, C1 + C2 == Cin_pad (a multiple of 32);
+// Contract: ImagenIgemmParams with KH = KW = 3, stride 1, pad 1, G = 4 packing — or KH = KW = 1, pad 0, any G >= 2 (one tap, no halo: the 1x1
+// res_conv / upsample GEMMs of the same maps; the packed rows of a 1x1 layer are consecutive 8-channel groups for every G); C1 % 8 == 0, C1 + C2 == Cin_pad (a multiple of 32);
 // output tiles of 32 pixels as 4 x 8, 2 x 16 or 1 x 32 (partial tiles at the map's edge are masked).
 #include <cstdio>
 #include "common.h"
@@ -95,7 +96,8 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
 
   const int TH = p.TH, TW = p.TW;
   const int P = cs_row_positions(TW), pitch = cs_pitch(p.Cin_pad);
-  const int HW_ = TW + 2, HH = TH + 2;                 // halo tile (used positions)
+  const int pad = p.pad, ntaps = p.KH * p.KW;          // 3x3 pad 1 | 1x1 pad 0 (the same kernel: one tap, no halo)
+  const int HW_ = TW + 2 * pad, HH = TH + 2 * pad;     // halo tile (used positions)
 
   // ---- tile of this workgroup: contiguous ranges of the tile list per XCD (blockIdx goes round-robin over the 8 XCDs, each with its own L2).
   //      The list is ordered so that a range shares what is larger: cout slab fastest (the slabs of a pixel tile stage the same halo tile,
@@ -108,7 +110,7 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7;
     int t = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
     const int npix = p.B * tilesY * tilesX;
-    const bool slab_major = p.Cout * 9 > p.B * p.OH * p.OW;   // weight bytes (18 Cin Cout) > map bytes (2 Cin B OH OW)
+    const bool slab_major = p.Cout * ntaps > p.B * p.OH * p.OW;   // weight bytes (2 taps Cin Cout) > map bytes (2 Cin B OH OW)
     int nt;
     if (slab_major) { nt = t / npix; t -= nt * npix; }
     else { nt = t % tilesN; t /= tilesN; }
@@ -139,6 +141,20 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
     epv[3] = (p.gca_part ? p.gca_wk : fw)[p.gca_part ? cc : 0];
     if (!p.bias) epv[0] = 0.0f;
     if (co >= p.Cout) epv[1] = epv[2] = epv[3] = 0.0f;
+  }
+
+  // ---- the generic epilogue's per-pixel operands (gate * addend | residual: 64 bytes per pixel and cout fragment) are touched NOW by the lanes that
+  //      will read them, one dword each, so that the reads at the end of the kernel are L2 hits instead of a third cold round trip
+  unsigned ep_touch = 0;
+  if constexpr (GEN) {
+    const f16* eop = p.addend ? reinterpret_cast<const f16*>(p.addend) + (size_t)tc.b * p.bs_add : (p.res ? reinterpret_cast<const f16*>(p.res) + (size_t)tc.b * p.bs_res : nullptr);
+    if (eop && ks == 0) {
+      const int eld = p.addend ? p.ld_add : p.ld_res;
+      const int l = lane & 31;                             // (any pixel of the tile per lane: the whole tile x this wave's cout fragment gets covered)
+      const int ty = l / TW, tx = l - ty * TW;
+      const int oy = min(tc.oy0 + ty, p.OH - 1), ox = min(tc.ox0 + tx, p.OW - 1);
+      ep_touch = *reinterpret_cast<const unsigned*>(eop + (size_t)(oy * p.OW + ox) * eld + min(tc.n0 + wn * 32 + 16 * half, p.Cout - 2));
+    }
   }
 
   // ---- stage the halo tile.  A thread owns ONE 8-channel group (its affine stays in registers, its address arithmetic is a multiply) and
@@ -176,7 +192,7 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
 
   // the weight stream of this wave: cout fragment tc.n0 / 32 + wn, the (channel chunk, tap) units [u0, u1) of NU = 9 per 32-channel chunk —
   // a unit is two K = 16 steps (channels 0-15 and 16-31 of the chunk at one tap), four consecutive group rows of the packed buffer
-  const int NU = (p.Cin_pad >> 5) * 9;
+  const int NU = (p.Cin_pad >> 5) * ntaps;
   const int u0 = __builtin_amdgcn_readfirstlane((NU * ks) / KS), u1 = __builtin_amdgcn_readfirstlane((NU * (ks + 1)) / KS);
   const int nun = u1 - u0;
   // the walk of this wave: units u0 + (i + rot) mod nun, i = 0 .. nun - 1.  All pixel tiles of an image batch read the same slab, in lockstep when
@@ -207,7 +223,7 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
       const int pp = in ? pos : 0;
       const int hy = (int)(((float)pp + 0.5f) * inv_w);
       const int hx = pp - hy * HW_;
-      const int gy = tc.oy0 - 1 + hy, gx = tc.ox0 - 1 + hx;
+      const int gy = tc.oy0 - pad + hy, gx = tc.ox0 - pad + hx;
       // (bitwise, not short-circuit: one straight-line address computation per piece; Cin_pad == C1 + C2, so every staged channel exists)
       const bool ok = in & ((unsigned)gy < (unsigned)p.H) & ((unsigned)gx < (unsigned)p.W);
       const int gp = ok ? gy * p.W + gx : 0;
@@ -228,6 +244,7 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
         ring[2 * i + 1] = weight_frag(2 * u + 1);
       }
       imagen_code_warm_sink(warm);
+      IMAGEN_SINK(ep_touch);
       if (tid < BN) {   // (the next-oldest requests, exact count)
         ep_par[tid] = epv[0];
         ep_par[BN + tid] = epv[1];
@@ -284,16 +301,16 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
 #pragma unroll
   for (int i = 0; i < 16; ++i) acc[0][0][i] = 0.f;
   int uabs = walk(0);
-  int chunk = uabs / 9, tap = uabs - chunk * 9;
+  int chunk = uabs / ntaps, tap = uabs - chunk * ntaps;
   auto unit_off = [&]() __attribute__((always_inline)) -> int {
     const int dy = (tap * 11) >> 5;                     // tap / 3 for tap < 9
     const int dx = tap - 3 * dy;
     const int off = (dy * P + dx) * pitch + chunk * 64;
     if (++uabs == u1) {                                 // the walk wraps to the head of the slice
       uabs = u0;
-      chunk = u0 / 9;
-      tap = u0 - chunk * 9;
-    } else if (++tap == 9) {
+      chunk = u0 / ntaps;
+      tap = u0 - chunk * ntaps;
+    } else if (++tap == ntaps) {
       tap = 0;
       ++chunk;
     }
@@ -418,14 +435,15 @@ int imagen_conv_small_config_info(int idx, int* tile_pixels, int* tile_cout, int
 }
 
 long imagen_conv_small_lds_bytes(int idx, int KH, int KW, int TH, int TW) {
-  if (idx < 0 || idx >= 3 || KH != 3 || KW != 3 || TH * TW != 32 || (TW != 8 && TW != 16 && TW != 32)) return -1;
+  if (idx < 0 || idx >= 3 || KH != KW || (KH != 3 && KH != 1) || TH * TW != 32 || (TW != 8 && TW != 16 && TW != 32)) return -1;
   return (long)cs_lds_bytes<1>(TH, TW, 256);   // (a typical layer: the real figure grows with Cin and is checked at launch)
 }
 
 int launch_conv_small(const ImagenIgemmParams* pp, int idx, hipStream_t s) {
   const ImagenIgemmParams& p = *pp;
   IMAGEN_CHECK(idx >= 0 && idx < 3, "conv_small: bad cfg index %d", idx);
-  IMAGEN_CHECK(p.KH == 3 && p.KW == 3 && p.stride == 1 && p.pad == 1 && p.OH == p.H && p.OW == p.W, "conv_small: 3x3 stride-1 pad-1 convolutions only");
+  IMAGEN_CHECK(((p.KH == 3 && p.KW == 3 && p.pad == 1) || (p.KH == 1 && p.KW == 1 && p.pad == 0)) && p.stride == 1 && p.OH == p.H && p.OW == p.W,
+               "conv_small: 3x3 pad-1 | 1x1 pad-0 stride-1 convolutions only");
   IMAGEN_CHECK(p.TH * p.TW == 32 && (p.TW == 8 || p.TW == 16 || p.TW == 32), "conv_small: 4x8 / 2x16 / 1x32 tiles (got %dx%d)", p.TH, p.TW);
   IMAGEN_CHECK(p.C1 % 8 == 0 && p.C1 > 0 && p.C2 % 8 == 0 && p.Cin_pad == p.C1 + p.C2 && p.Cin_pad % 32 == 0 && (p.C2 == 0 || p.x2),
                "conv_small: inputs in 8-channel groups, Cin_pad = C1 + C2 in 32-channel chunks (got %d + %d, padded %d)", p.C1, p.C2, p.Cin_pad);

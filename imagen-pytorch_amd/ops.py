@@ -334,7 +334,7 @@ def pw_cfg(kchunks: int, Cout: int) -> Optional[int]:
     return best
 
 
-CONV_SMALL = int(_os.environ.get("IMAGEN_CONV_SMALL", "1"))   # A/B switch: conv_small.hip (family 8) for the 3x3 convs of the small maps
+CONV_SMALL = int(_os.environ.get("IMAGEN_CONV_SMALL", "2"))   # A/B switch: conv_small.hip (family 8) for the 3x3 convs of the small maps (2: their 1x1 res_conv / upsample GEMMs too)
 SMALL_MAX_ROWS = int(_os.environ.get("IMAGEN_CONV_SMALL_ROWS", "4096"))   # ... of at most this many output pixels per launch (16 images of 8^2 / 16^2; call H: the 32^2 maps lose 1.3 ms per unet2 step)
 SMALL_MAX_STREAM_MB = 128   # ... whose pixel tiles together stream at most this much weight data out of L2 (every 32-pixel tile reads all of its slab: README unet1's
                             # layers 38 - 57 MB; C2's 512 -> 512 @16^2 and 1024 -> 1024 @8^2 604 MB — 75 / 86 us against 33 / 48 on the wave-specialised kernel, call J)
@@ -522,9 +522,12 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
     C2 = x2.C if x2 is not None else 0
     assert x1.C + C2 == pw.Cin, f"{label}: input channels {x1.C}+{C2} != weight Cin {pw.Cin}"
     want_gca = gca is not None and out_mode == OUT_NHWC and act_out == ACT_NONE and addend is None and res is None and post is None
-    if cfg is None and CONV_SMALL and KH == 3 and KW == 3 and stride == 1 and pad == 1 and pw.G == 4 and x1.B * OH * OW <= SMALL_MAX_ROWS:
-        # family 8: the 3x3 convs of the small maps, any prologue of the contract (statistics / affine / SiLU), any epilogue; the all-cout
-        # epilogues (ssq_out / post / GlobalContext partials) where a 32 | 64 | 128-cout tile covers Cout
+    small_3x3 = KH == 3 and KW == 3 and pad == 1 and pw.G == 4
+    small_1x1 = KH == 1 and KW == 1 and pad == 0 and pw.G >= 2 and OH > 1 and CONV_SMALL >= 2   # (spatial maps only: the token linears keep their kernels)
+    if cfg is None and CONV_SMALL and stride == 1 and (small_3x3 or small_1x1) and x1.B * OH * OW <= SMALL_MAX_ROWS:
+        # family 8: the 3x3 convs (and, CONV_SMALL >= 2, the 1x1 res_conv / upsample GEMMs) of the small maps, any prologue of the contract
+        # (statistics / affine / SiLU), any epilogue; the all-cout epilogues (ssq_out / post / GlobalContext partials) where a 32 | 64 | 128-cout
+        # tile covers Cout
         full = (ssq_out is not None or post is not None or want_gca) and out_mode == OUT_NHWC
         tile = small_tile(OH, OW)
         sc = small_cfg(pw.Cout, full and pw.Cout <= 128)   # (wider layers: the 32-cout tile, statistics / post left to the caller's fallback as on family 0)
@@ -533,7 +536,7 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
                 and act_in in (ACT_NONE, ACT_SILU) and (mu is None or rs is not None) and (pstride == 0 or pstride >= pw.Cin_pad)
                 and (out_mode == OUT_NCHW_F32 or pw.Cout % 4 == 0)
                 and small_lds_bytes(tile[0], tile[1], pw.Cin_pad, cfg_table()[sc][1]) <= MAX_LDS_BYTES
-                and (x1.B * OH * OW // 32) * pw.Cout_pad * pw.Cin_pad * 18 <= SMALL_MAX_STREAM_MB << 20):
+                and (x1.B * OH * OW // 32) * pw.Cout_pad * pw.Cin_pad * 2 * KH * KW <= SMALL_MAX_STREAM_MB << 20):
             cfg = (sc, tile[0], tile[1])
     if cfg is None and CONV_PRO and KH == 3 and KW == 3 and stride == 1 and pad == 1 and pw.G == 4 and pro_cfg(pw.Cout) is not None:
         # family 6: exactly 32 output channels from 32 | 32 + 32 input channels, or 64 from two or three 32-channel chunks (64 | 64 + 32 | 32 + 32):

@@ -306,7 +306,21 @@ def test_conv_small_family(ops, dev):
     for kw in cases:
         r = run_case(ops, dev, K=3, G=4, **kw)
         assert r["err"] < TOL and r.get("err_ssq", 0.0) < 2e-3 and r.get("err_gca", 0.0) < 2e-3, (kw, r)
+    # the same kernel with one tap and no halo: the 1x1 res_conv (gate * addend epilogue over a concat) and upsample (SiLU + pixel shuffle) GEMMs of the
+    # small maps, every packing (G = 4 | 8 | 16 by the channel count), the LayerNorm prologue, a plain output with statistics
+    cases_1x1 = [
+        dict(raw, B=2, H=8, W=8, C1=256, C2=128, Cout=256, cfg=(fam8[32], 4, 8), epilogue="addend"),
+        dict(raw, B=2, H=16, W=16, C1=128, C2=64, Cout=128, cfg=(fam8[32], 2, 16), epilogue="addend"),
+        dict(raw, B=2, H=8, W=8, C1=256, Cout=512, cfg=(fam8[32], 4, 8), epilogue="shuffle", act_out="silu"),
+        dict(raw, B=2, H=6, W=40, C1=96, Cout=64, cfg=(fam8[64], 1, 32), epilogue="res", ssq_out=True),
+        dict(B=2, H=8, W=8, C1=64, Cout=96, cfg=(fam8[32], 4, 8), prologue="ln", affine=True, act_in="none"),
+    ]
+    for kw in cases_1x1:
+        r = run_case(ops, dev, K=1, **kw)
+        assert r["err"] < TOL and r.get("err_ssq", 0.0) < 2e-3, (kw, r)
     if not EMULATED:
+        r = run_case(ops, dev, B=16, H=8, W=8, C1=256, C2=128, Cout=256, K=1, epilogue="addend", **raw)    # README unet1's res_conv of the 8^2 level
+        assert tab[r["cfg"][0]][3] == 8 and r["err"] < TOL, r
         # the planner takes the benchmark's small maps (16 rows of 8^2 / 16^2) by itself, with the tile the epilogue needs ...
         r = run_case(ops, dev, B=16, H=8, W=8, C1=256, C2=128, Cout=256, K=3, prologue="ssq", affine=True)
         assert tab[r["cfg"][0]][3] == 8 and tab[r["cfg"][0]][1] == 32 and r["err"] < TOL, r
