@@ -239,7 +239,7 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
       ring_filled = true;
 #pragma unroll
       for (int i = 0; i < CS_RING / 2; ++i) {
-        const int u = walk(i < nun ? i : nun - 1);
+        const int u = walk(i < nun ? i : (nun > 0 ? nun - 1 : 0));   // (a 1x1 layer with fewer chunks than K slices leaves waves without a unit: they request unit u0 — in range — and multiply nothing)
         ring[2 * i] = weight_frag(2 * u);
         ring[2 * i + 1] = weight_frag(2 * u + 1);
       }

@@ -313,7 +313,8 @@ def test_conv_small_family(ops, dev):
         dict(raw, B=2, H=16, W=16, C1=128, C2=64, Cout=128, cfg=(fam8[32], 2, 16), epilogue="addend"),
         dict(raw, B=2, H=8, W=8, C1=256, Cout=512, cfg=(fam8[32], 4, 8), epilogue="shuffle", act_out="silu"),
         dict(raw, B=2, H=6, W=40, C1=96, Cout=64, cfg=(fam8[64], 1, 32), epilogue="res", ssq_out=True),
-        dict(B=2, H=8, W=8, C1=64, Cout=96, cfg=(fam8[32], 4, 8), prologue="ln", affine=True, act_in="none"),
+        dict(B=2, H=8, W=8, C1=64, Cout=96, cfg=(fam8[32], 4, 8), prologue="ln", affine=True, act_in="none"),   # 2 chunks over 8 K slices: waves without a unit
+        dict(raw, B=2, H=8, W=8, C1=32, Cout=32, cfg=(fam8[32], 4, 8)),                                          # one chunk: seven of the eight waves idle
     ]
     for kw in cases_1x1:
         r = run_case(ops, dev, K=1, **kw)
