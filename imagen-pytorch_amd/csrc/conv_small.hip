@@ -38,7 +38,9 @@
 namespace {
 
 constexpr int CS_THREADS = 512;
-constexpr int CS_RING = 8;          // weight fragments in flight per wave
+#ifndef CS_RING
+#define CS_RING 8                   // weight fragments in flight per wave (call P: 16, with one workgroup per CU for the registers, is no faster)
+#endif
 #ifndef CS_MINW
 #define CS_MINW 4                   // minimum waves per SIMD the register allocation leaves room for (4: two workgroups per CU — one stages while the other multiplies)
 #endif
