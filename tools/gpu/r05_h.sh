@@ -2,6 +2,7 @@
 # Round 5, call H: conv_small.hip (igemm family 8, the small-map 3x3 convs with the K loop split over the waves of a workgroup) on hardware:
 # its tests, the whole-Unet parity with it routed, the step A/B (off | 8^2 + 16^2 | + 32^2), C2 / C4 with and without it, per-kernel durations.
 #   gpurun --timeout 1500 -- 'bash tools/gpu/r05_h.sh'
+# (IMAGEN_CONV_SMALL_ROWS was an environment knob of ops.SMALL_MAX_ROWS at the commit this call ran on; the limit is a module constant since.)
 set -u
 cd "$(dirname "$0")/../.."
 R=$PWD
