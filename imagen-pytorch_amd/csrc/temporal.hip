@@ -177,6 +177,19 @@ __global__ __launch_bounds__(256) void temporal_attention_mfma_kernel(const Imag
       ta_split(kx[s], kh[s], kl[s]);
     }
   }
+  // The null value is an fp32 parameter and the same vector for every pixel: its fp16 part rides the MFMA as V^T column 0, the remainder
+  // nv - fp16(nv) is added behind it on the VALU with the null key's fp32 weight (32 FMAs per row block).  Dropped, it is a coherent
+  // bias of the whole map — a first frame under the causal mask gives the null key about half its weight — and the C5 denoiser's
+  // distance to the oracle moved 1.00e-3 -> 1.05e-3 when this kernel replaced the fp32 vector kernel in round 4 (plan interpreter with
+  // the null value rounded to fp16: 1.008e-3 -> 1.044e-3, round-5 session 2).
+  float nvlo[2][16];   // [db][4 qd + e]: dim 32 db + 8 qd + 4 half + e, the accumulator layout of O^T below
+#pragma unroll
+  for (int db = 0; db < 2; ++db)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      const float nv = p.null_kv[64 + 32 * db + 8 * (e >> 2) + 4 * half + (e & 3)];
+      nvlo[db][e] = nv - (float)(f16)nv;
+    }
   float qsc[4][8];   // q_scale * scale of this lane's dims
 #pragma unroll
   for (int s = 0; s < 4; ++s)
@@ -246,6 +259,8 @@ __global__ __launch_bounds__(256) void temporal_attention_mfma_kernel(const Imag
       pl[e >> 3][e & 7] = (f16)(w - (float)wh);
     }
     den += __shfl_xor(den, 32);
+    // the null key is key 0 = register 0 of the half-0 lane of the row
+    const float w_null = __shfl(sacc[0] > -1.0e38f ? __expf(sacc[0] - mx) : 0.f, l31);
     // ---- O^T[d][row] += V^T . P   (k-step s covers the keys of accumulator registers 8 s .. 8 s + 7)
     f32x16 oacc[2];
 #pragma unroll
@@ -264,6 +279,10 @@ __global__ __launch_bounds__(256) void temporal_attention_mfma_kernel(const Imag
         oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pl[s], oacc[db], 0, 0, 0);
         oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], oacc[db], 0, 0, 0);
       }
+#pragma unroll
+    for (int db = 0; db < 2; ++db)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) oacc[db][e] += w_null * nvlo[db][e];
     if (rok) {
       const float inv = 1.0f / den;
       f16* o = obase + (size_t)i * ostride + h * 64;

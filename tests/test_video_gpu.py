@@ -125,6 +125,37 @@ def test_temporal_attention_kernel(Fr, causal):
     assert nerr(hip, ref) < 2e-3
 
 
+def test_temporal_attention_null_value_is_not_rounded():
+    """The null value of the temporal attention is an fp32 parameter shared by every pixel: rounding it to fp16 (as V^T column 0 of the MFMA
+    kernel did in round 4) is not noise but ONE error vector in every row, weighted by the null key's softmax weight — about a half in the
+    first frame of a causal clip.  Normwise it hides under the 2.8e-4 fp16 rounding of the output; averaged over the pixels it does not:
+    the mean error of the first frame's output channels has to be the averaged-down rounding noise, not (null value - fp16(null value)) / 2.
+    (On the C5 denoiser that bias was worth 1.00e-3 -> 1.05e-3 of distance to the oracle.)"""
+    from imagen_pytorch_amd import ops
+
+    R, Fr, P, heads = 2, 4, 256, 2
+    keep = {}
+
+    def build(plan, dev):
+        rows = R * Fr * P
+        qkv = ops.new_act(1, 1, rows, heads * 64 + 128, dev)
+        qkv.t.copy_(torch.randn(qkv.t.shape).half())
+        o = ops.new_act(1, 1, rows, heads * 64, dev, zero=True)
+        null_kv = torch.randn(2, 64) * 4.0 + 0.37          # (fp16 spacing of 2^-9 .. 2^-8 over most of the vector)
+        keep["nv"] = null_kv[1].clone()
+        ops.temporal_attention(plan, qkv, null_kv.to(dev), torch.ones(64).to(dev), torch.ones(64).to(dev),
+                               torch.zeros(heads, Fr, Fr + 1).to(dev), o, B=R, F=Fr, P=P, heads=heads, causal=True, scale=1.0)
+        return o.t
+
+    hip, ref = _both(build)
+    assert nerr(hip, ref) < 1e-3
+    d = (hip - ref).reshape(R, Fr, P, heads, 64)[:, 0].mean(dim=(0, 1, 2))      # first frame: keys = null + itself, weights ~ 1/2 each
+    lost = keep["nv"] - keep["nv"].half().float()
+    assert lost.norm() > 1e-3                                                  # the case does exercise the rounding
+    # the kernel that rounds the null value shows d ~ lost / 2 (ratio ~ 0.5); the averaged-down output rounding alone is ~ 0.05 of |lost|
+    assert float(d.norm() / lost.norm()) < 0.15, float(d.norm() / lost.norm())
+
+
 @pytest.mark.parametrize("causal", [True, False])
 def test_temporal_peg_kernel_vs_oracle(causal):
     """TEMPORAL_PEG alone against the ORACLE's temporal_peg (oracle/unet3d_oracle.py, iv.py:1413-1414: F.pad + depthwise Conv3d (3, 1, 1) +
