@@ -48,6 +48,16 @@ def _w2d(mod):
     return SimpleNamespace(weight=w, bias=None if mod.bias is None else mod.bias.detach().float())
 
 
+# Split-precision weights (engine.py, SPLIT_*) on the video path's OUTPUT stage: `final_conv` and block1 of `final_res_block` — the two convs
+# whose weight rounding reaches the output unattenuated (plan interpreter, BASELINE C5: cond 1.008e-3 -> 0.970e-3, null 0.921e-3 -> 0.901e-3;
+# block1 of the two outer down levels on top of them buys nothing).  A video clip puts R * F frames through every conv, so the image path's
+# executed-FLOP bound (SPLIT_SMALL_FLOPS) never admits them: the output stage gets its own, wider, bound; two launches per step grow by
+# ~20 us each (1 % of the C5 step).
+SPLIT_OUTPUT_STAGE = 1
+SPLIT_OUTPUT_MAX_K = 640          # taps * input channels of the unsplit weight (dim 64: 576)
+SPLIT_OUTPUT_FLOPS = 4.0e10       # 2 * pixels * Cout * (2 K) of the split launch (C5: 1.9e10)
+
+
 class UnetEngine3D(UnetEngine):
 
     def enable_time_table(self, coef, step_ptr):
@@ -287,18 +297,21 @@ class UnetEngine3D(UnetEngine):
         extra = (self.fin2 if self.fin2 is not None else self.img) if self.lowres else None
         cw = _w2d(u.final_conv)
 
+        kh_ = cw.weight.shape[-1]
+        split = extra is None and self._split_output(x.C, kh_ * kh_, cw.weight.shape[0], x.rows)
+
         def make():
             w = cw.weight
             co, ci, kh, kw = w.shape
             if extra is None:
-                return ops.pack_weight(w, cw.bias, self.dev)
+                return ops.pack_weight(w, cw.bias, self.dev, split=split)
             wp = torch.zeros(co, x.C + 8, kh, kw)
             wp[:, : x.C] = w[:, : x.C]
             wp[:, x.C + u.channels: x.C + 2 * u.channels] = w[:, x.C:]      # packed frame = [x | lowres | zero pad]
             return ops.pack_weight(wp, cw.bias, self.dev)
 
         out4 = self.out_full.view(self.R * self.F, u.channels_out, self.S, self.S)
-        ops.igemm(plan, x, self.W.get("final_conv", make), out4, x2=extra, out_mode=OUT_NCHW_F32, label="final_conv")
+        ops.igemm(plan, x, self.W.get("final_conv|split" if split else "final_conv", make), out4, x2=extra, out_mode=OUT_NCHW_F32, label="final_conv")
         plan.keep.append(self.out_full)
         if self.F != self.Fx:
             # out[:, :, len(pre):][:, :, :-len(post)] (iv.py:1933-1939): frames [Fpre, Fpre + Fx) of every clip; fp32 moved as fp16 pairs
@@ -338,6 +351,11 @@ class UnetEngine3D(UnetEngine):
             if fin2 is not None:
                 fin2[:, at_fin:at_fin + n] = packed
 
+    def _split_output(self, Cin: int, taps: int, Cout: int, pixels: int) -> bool:
+        """A split-precision weight for a launch of the output stage (SPLIT_OUTPUT_* above)?"""
+        return bool(SPLIT_OUTPUT_STAGE and Cin % 8 == 0 and taps * Cin <= SPLIT_OUTPUT_MAX_K
+                    and 4.0 * pixels * Cout * taps * Cin <= SPLIT_OUTPUT_FLOPS)
+
     def _temporal_conv(self, plan, x: Act, conv, name: str, f: int) -> Act:
         """Causal Conv1d(k = 3) over the frames of every pixel (iv.py:436-449) as three accumulating 1x1 GEMMs on frame-shifted views."""
         R = self.R
@@ -370,7 +388,9 @@ class UnetEngine3D(UnetEngine):
             in_scale[C1:] = s
         sx = self._ssq_of(plan, x, name + ".block1.stat_x")
         ss = self._ssq_of(plan, skip, name + ".block1.stat_skip") if skip is not None else None
-        w1 = W.conv(name + ".block1", rb.block1.project.spatial_conv)
+        # (the output stage's block1 — no skip input, batch-shared affine — takes a split-precision weight: _split_output)
+        w1 = W.conv(name + ".block1", rb.block1.project.spatial_conv,
+                    split=name == "final_res_block" and skip is None and self._split_output(Cin, 9, Cout, R * f * H * Wd))
         pa1 = W.f32(name + ".block1.pa", lambda: _pad_vec(rb.block1.norm.gamma.detach().float().flatten().cpu() * math.sqrt(Cin)
                                                          * (in_scale if in_scale is not None else 1.0), w1.Cin_pad))
         off = self._blk_off[self._blk_index[id(rb)]]

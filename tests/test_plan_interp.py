@@ -243,6 +243,9 @@ def test_unet3d_plan_readme_structure_vs_oracle(reference_weights):
     assert ref_c.abs().mean() > 0.05
     e_c, e_n = nerr(out[:B], ref_c), nerr(out[B:], ref_n)
     assert e_c < 5e-3 and e_n < 5e-3, (e_c, e_n)
+    # the output stage reads its input twice against split-precision weights (engine3d.SPLIT_OUTPUT_STAGE): final_conv and block1 of final_res_block
+    split = {label for _, p, label in eng.step_plan.ops if label in ("final_conv", "final_res_block.block1") and p.x2 == p.x1 and p.C2 == p.C1 > 0}
+    assert split == {"final_conv", "final_res_block.block1"}, split
 
 
 def test_unet_plan_without_text_mask(reference_weights):
