@@ -388,9 +388,13 @@ def _tap3d(act, rows):
     return t.reshape(rows, f, *t.shape[1:]).permute(0, 2, 1, 3, 4)
 
 
-C5_TOL = 1.15e-3   # measured on MI355X in rounds 4 and 5: cond 1.05e-3, null 1.06e-3, CFG-3 combination 2.81e-3 (round 3: 9.9e-4 / 9.5e-4 / 2.7e-3).  ABOVE
-                   # north_star's 1e-3: the fp32-P temporal attention of round 5 did not move it; tools/parity_budget.py's ablations on the image
-                   # unet say even fp32 weights everywhere buy 8 % — what is left is fp16 storage of the activations
+C5_TOL = 1.0e-3    # north_star's bar.  Measured on MI355X, round 5 (calls Q, R): cond 9.64e-4, null 9.76e-4 (rounds 4 / 5 before: 1.05e-3 / 1.06e-3,
+                   # asserted at 1.5e-3 / 1.15e-3).  Two causes, both found with the plan interpreter: the MFMA temporal attention of round 4
+                   # rounded the fp32 null value to fp16 — one coherent error vector in every row, 1.05 -> 1.00e-3 (csrc/temporal.hip,
+                   # test_temporal_attention_null_value_is_not_rounded above) — and the output stage's weights (final_conv, block1 of
+                   # final_res_block) were fp16-rounded on the video path while the image path splits them: 1.00 -> 0.964e-3
+                   # (engine3d.SPLIT_OUTPUT_STAGE).  The run is deterministic (same kernels, same draws): the 2.4 % headroom is not a noise margin.
+C5_CFG_TOL = 3.1e-3   # the CFG-3 combination 3 e_cond - 2 e_null of two in-tolerance forwards (bound 5e-3; measured 2.77e-3, 2.7-2.8e-3 in every round)
 
 
 def test_unet3d_forward_vs_oracle_c5():
@@ -428,4 +432,4 @@ def test_unet3d_forward_vs_oracle_c5():
     from conftest import record_parity
     record_parity("unet3d_forward_vs_oracle_c5", cond=e, null=e_null, cfg3=e_cfg, taps=rep, tol=C5_TOL)
     assert {"mid_peg", "mid_tattn"} <= set(rep)
-    assert e < C5_TOL and e_null < C5_TOL and e_cfg < 2.7 * C5_TOL, (e, e_null, e_cfg, rep)
+    assert e < C5_TOL and e_null < C5_TOL and e_cfg < C5_CFG_TOL, (e, e_null, e_cfg, rep)

@@ -11,7 +11,7 @@ averaging) or noise.  (Found with the arithmetic this tool automates, round 5: t
 fp16 — 5e-5 normwise on the op, invisible beside the output rounding, 4 % of the C5 denoiser's distance to the oracle.)
 
     python tools/op_audit.py --config c5 [--frames 16 --size 64] [--null] [--emul] [--top 30] [--json out.json]
-    python tools/op_audit.py --config u1 --size 64 --null
+    python tools/op_audit.py --config u1 --size 64 --null          (u2: README unet2 with its low-res conditioning, --size 256)
 """
 from __future__ import annotations
 
@@ -31,6 +31,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 
 README_U1 = dict(dim=32, cond_dim=512, dim_mults=(1, 2, 4, 8), num_resnet_blocks=3, layer_attns=(False, True, True, True),
                  layer_cross_attns=(False, True, True, True))
+README_U2 = dict(dim=32, cond_dim=512, dim_mults=(1, 2, 4, 8), num_resnet_blocks=(2, 4, 8, 8), layer_attns=(False, False, False, True),
+                 layer_cross_attns=(False, False, False, True), lowres_cond=True)
 
 
 def emulate_cuda():
@@ -72,7 +74,7 @@ def pointer_fields(p):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--config", choices=("c5", "u1"), default="c5")
+    ap.add_argument("--config", choices=("c5", "u1", "u2"), default="c5", help="BASELINE C5's Unet3D(dim 64) | README unet1 | README unet2 (lowres_cond)")
     ap.add_argument("--frames", type=int, default=16)
     ap.add_argument("--size", type=int, default=64)
     ap.add_argument("--null", action="store_true", help="the unconditional row (cond_drop_prob = 1) instead of the conditional one")
@@ -114,7 +116,7 @@ def main():
     else:
         from imagen_pytorch_amd import Unet
         from imagen_pytorch_amd.engine import UnetEngine
-        kw = README_U1
+        kw = README_U1 if args.config == "u1" else README_U2
         u = Unet(**kw).eval()
         torch.nn.init.normal_(u.final_conv.weight, std=0.05)
         torch.nn.init.normal_(u.final_conv.bias, std=0.05)
@@ -125,17 +127,20 @@ def main():
         make = lambda d, dry: UnetEngine(u, 1, 1, args.size, d, dry=dry)
         x_in = x
 
+    lowres = bool(kw.get("lowres_cond"))
+    lnt = torch.full((1,), 0.5) if lowres else None
+    low = torch.randn(1, 3, args.size, args.size) if lowres else None
     ops.KEEP_REFERENCE_WEIGHTS = True
     eng_i = make("cpu", True)
-    eng_i.set_conditioning(text_embeds=te, text_mask=mask, keep=keep, lowres_noise_times=None)
+    eng_i.set_conditioning(text_embeds=te, text_mask=mask, keep=keep, lowres_noise_times=lnt)
     if not args.emul:
         ops.KEEP_REFERENCE_WEIGHTS = False
     eng_k = make(dev, args.emul)          # (under emulation both engines are dry: the launches below go through imagen_launch by hand)
     if args.emul:
-        eng_k.set_conditioning(text_embeds=te, text_mask=mask, keep=keep, lowres_noise_times=None)
+        eng_k.set_conditioning(text_embeds=te, text_mask=mask, keep=keep, lowres_noise_times=lnt)
     else:
         eng_k.dry = True                  # set_conditioning must not run the static plan itself: it is audited launch by launch below
-        eng_k.set_conditioning(text_embeds=te.to(dev), text_mask=mask.to(dev), keep=keep, lowres_noise_times=None)
+        eng_k.set_conditioning(text_embeds=te.to(dev), text_mask=mask.to(dev), keep=keep, lowres_noise_times=lnt)
     n_tok = te.shape[1]
     plans = [("static", eng_k._static_plans[n_tok][0], eng_i._static_plans[n_tok][0]), ("step", eng_k.step_plan, eng_i.step_plan)]
 
@@ -168,6 +173,9 @@ def main():
     eng_i.times.copy_(t)
     eng_k.x_in.copy_(x_in.to(dev))
     eng_k.times.copy_(t.to(dev))
+    if lowres:
+        eng_i.lowres_in.copy_(low)
+        eng_k.lowres_in.copy_(low.to(dev))
     st_job = _abi.STRUCTS["ImagenKvPrepParams"]
     K_MULTI = _abi.ENUMS["IMAGEN_OP_KV_PREP_MULTI"]
     rows = []
