@@ -68,8 +68,13 @@ def storage_of(mem, addr):
     return None, None
 
 
-def pointer_fields(p):
-    return [getattr(p, name) for name, ct in p._fields_ if ct is ctypes.c_void_p and getattr(p, name)]
+# GlobalContext partials are (reference logit, sum of exponentials, weighted sums) per tile: a kernel may pick another reference logit than
+# the interpreter's and still describe the same softmax pooling — compared where they are merged (GCA_FINAL / GCA_TAIL), not element by element
+OPAQUE_FIELDS = ("gca_part", "part")
+
+
+def pointer_fields(p, opaque=False):
+    return [getattr(p, name) for name, ct in p._fields_ if ct is ctypes.c_void_p and getattr(p, name) and (name in OPAQUE_FIELDS) == opaque]
 
 
 def main():
@@ -188,10 +193,11 @@ def main():
                 for j in range(si.n):
                     ptrs += pointer_fields(st_job.from_address(si.jobs + j * ctypes.sizeof(st_job)))
             touched = {}
-            for a in ptrs:
+            for a in ptrs + pointer_fields(si, opaque=True):
                 base, _ = storage_of(it.mem, a)
                 if base is not None and base in twin:
                     touched[base] = whole(twin[base][1]).clone()
+            opaque = {storage_of(it.mem, a)[0] for a in pointer_fields(si, opaque=True)}
             _abi.check(lib.imagen_launch(kind, ctypes.addressof(sk), ctypes.sizeof(sk), h), f"{pname}[{idx}] {label}")
             if not args.emul:
                 torch.cuda.synchronize()
@@ -206,6 +212,9 @@ def main():
                 if n == 0:
                     continue
                 got = whole(tk).to("cpu")
+                if base in opaque:
+                    whole(ti).copy_(got)
+                    continue
                 if before.dtype.is_floating_point:
                     a, b = got.float()[changed], after.float()[changed]
                     d = a - b
