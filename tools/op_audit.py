@@ -108,7 +108,7 @@ def main():
     if args.config == "c5":
         from imagen_pytorch_amd import Unet3D
         from imagen_pytorch_amd.engine3d import UnetEngine3D
-        from oracle.make_golden import derandomise_unet3d
+        from test_video_gpu import _derandomise_unet3d as derandomise_unet3d   # (the C5 test's own weights: dirac + dense temporal convs)
         kw = dict(dim=64, dim_mults=(1, 2, 4, 8))
         u = Unet3D(**kw).eval()
         derandomise_unet3d(u)
@@ -205,9 +205,8 @@ def main():
             for base, before in touched.items():
                 tk, ti = twin[base]
                 after = whole(ti)
-                changed = after != before
-                if before.dtype.is_floating_point:
-                    changed |= after.isnan() != before.isnan()
+                bits = {2: torch.int16, 4: torch.int32, 1: torch.uint8, 8: torch.int64}[before.element_size()]
+                changed = after.view(bits) != before.view(bits)      # bit patterns: uninitialised NaN garbage nobody wrote is not a change
                 n = int(changed.sum())
                 if n == 0:
                     continue
