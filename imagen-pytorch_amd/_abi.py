@@ -109,6 +109,7 @@ OP_STRUCT = {
     ENUMS["IMAGEN_OP_GCA_TAIL"]: STRUCTS["ImagenGcaTailParams"],
     ENUMS["IMAGEN_OP_STEP_SLICE"]: STRUCTS["ImagenStepSliceParams"],
     ENUMS["IMAGEN_OP_ROWCHAIN"]: STRUCTS["ImagenRowchainParams"],
+    ENUMS["IMAGEN_OP_LINEAR_F32"]: STRUCTS["ImagenLinearF32Params"],
 }
 STRUCT_KIND = {v: k for k, v in OP_STRUCT.items()}
 

@@ -49,6 +49,7 @@ extern "C" size_t imagen_sizeof(int kind) {
     case IMAGEN_OP_GCA_TAIL: return sizeof(ImagenGcaTailParams);
     case IMAGEN_OP_STEP_SLICE: return sizeof(ImagenStepSliceParams);
     case IMAGEN_OP_ROWCHAIN: return sizeof(ImagenRowchainParams);
+    case IMAGEN_OP_LINEAR_F32: return sizeof(ImagenLinearF32Params);
     default: return 0;
   }
 }
@@ -91,6 +92,7 @@ extern "C" int imagen_launch(int kind, const void* params, size_t params_bytes, 
     case IMAGEN_OP_GCA_TAIL: return launch_gca_tail(static_cast<const ImagenGcaTailParams*>(params), s);
     case IMAGEN_OP_STEP_SLICE: return launch_step_slice(static_cast<const ImagenStepSliceParams*>(params), s);
     case IMAGEN_OP_ROWCHAIN: return launch_rowchain(static_cast<const ImagenRowchainParams*>(params), s);
+    case IMAGEN_OP_LINEAR_F32: return launch_linear_f32(static_cast<const ImagenLinearF32Params*>(params), s);
     default: imagen_set_error("imagen_launch: unknown op kind %d", kind); return -1;
   }
 }

@@ -103,6 +103,7 @@ int launch_gate_residual(const ImagenGateResidualParams* p, hipStream_t s);
 int launch_ln_residual(const ImagenLnResidualParams* p, hipStream_t s);
 int launch_time_embed(const ImagenTimeEmbedParams* p, hipStream_t s);
 int launch_scale_shift(const ImagenScaleShiftParams* p, hipStream_t s);
+int launch_linear_f32(const ImagenLinearF32Params* p, hipStream_t s);
 int launch_pack_image(const ImagenPackImageParams* p, hipStream_t s);
 int launch_cfg_x0(const ImagenCfgX0Params* p, hipStream_t s);
 int launch_quantile(const ImagenQuantileParams* p, hipStream_t s);

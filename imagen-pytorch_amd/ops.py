@@ -1104,11 +1104,41 @@ def time_embed(plan: Plan, *, times, coef, step_ptr, freqs, w, bias, hid: Act, l
     return p
 
 
-def scale_shift(plan: Plan, ss: Act, gamma_s, idx_scale, idx_shift, pa, ps, label: str = ""):
+def scale_shift(plan: Plan, ss, gamma_s, idx_scale, idx_shift, pa, ps, label: str = ""):
+    """ss: the batched time-MLP output — an fp16 Act (an IGEMM's rows) or a 2-D fp32 tensor [rows, width] (LINEAR_F32's rows)."""
     p = STRUCTS["ImagenScaleShiftParams"]()
-    p.ss, p.gamma_s, p.idx_scale, p.idx_shift, p.pa, p.ps = ss.ptr, gamma_s.data_ptr(), idx_scale.data_ptr(), idx_shift.data_ptr(), pa.data_ptr(), ps.data_ptr()
-    p.B, p.total_c, p.ld_ss = ss.rows, gamma_s.numel(), ss.ld
-    plan.add(p, label or "scale_shift", [ss.t, gamma_s, idx_scale, idx_shift, pa, ps])
+    if isinstance(ss, Act):
+        p.ss, p.B, p.ld_ss, p.ss_f32, keep = ss.ptr, ss.rows, ss.ld, 0, ss.t
+    else:
+        assert ss.dtype == torch.float32 and ss.ndim == 2 and ss.is_contiguous()
+        p.ss, p.B, p.ld_ss, p.ss_f32, keep = ss.data_ptr(), ss.shape[0], ss.shape[1], 1, ss
+    p.gamma_s, p.idx_scale, p.idx_shift, p.pa, p.ps = gamma_s.data_ptr(), idx_scale.data_ptr(), idx_shift.data_ptr(), pa.data_ptr(), ps.data_ptr()
+    p.total_c = gamma_s.numel()
+    plan.add(p, label or "scale_shift", [keep, gamma_s, idx_scale, idx_shift, pa, ps])
+    return p
+
+
+def linear_f32(plan: Plan, x, wt: torch.Tensor, bias: Optional[torch.Tensor], y: torch.Tensor, *, res: Optional[Act] = None,
+               act_in: int = ACT_NONE, label: str = ""):
+    """LINEAR_F32 (include/imagen_hip.h): y[r, :] = bias + f(x[r, :]) @ wt (+ res[r, :]), fp32 end to end.  x: an fp16 Act of rows or a 2-D fp32
+    tensor; wt: fp32 [K, Cout] (the module's weight transposed); y: 2-D fp32 [rows, Cout]; res: fp16 Act of rows."""
+    p = STRUCTS["ImagenLinearF32Params"]()
+    assert wt.dtype == torch.float32 and wt.ndim == 2 and wt.is_contiguous() and y.dtype == torch.float32 and y.ndim == 2 and y.is_contiguous()
+    K, Cout = wt.shape
+    if isinstance(x, Act):
+        assert x.C == K, f"{label}: {x.C} input channels, weight has {K}"
+        p.x, p.rows, p.ld_x, p.x_f32, keep = x.ptr, x.rows, x.ld, 0, x.t
+    else:
+        assert x.dtype == torch.float32 and x.ndim == 2 and x.is_contiguous() and x.shape[1] == K
+        p.x, p.rows, p.ld_x, p.x_f32, keep = x.data_ptr(), x.shape[0], x.shape[1], 1, x
+    assert tuple(y.shape) == (p.rows, Cout), f"{label}: output {tuple(y.shape)} for {p.rows} rows of {Cout}"
+    assert bias is None or (bias.dtype == torch.float32 and bias.numel() == Cout)
+    p.wt, p.bias, p.y = wt.data_ptr(), (bias.data_ptr() if bias is not None else None), y.data_ptr()
+    p.K, p.Cout, p.ld_y, p.act_in = K, Cout, Cout, act_in
+    if res is not None:
+        assert res.rows == p.rows and res.C == Cout
+        p.res, p.ld_res = res.ptr, res.ld
+    plan.add(p, label or "linear_f32", [keep, wt, bias, y, res.t if res is not None else None])
     return p
 
 

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define IMAGEN_ABI_VERSION 8 /* 8: ROWCHAIN, the latency probes;  3: head_dim in the attention / QNORM / KV_PREP params; 4: DDPM_UPDATE x0_thr; 5: GCA_TAIL; 6: ACT_PREP self_stat, STEP_SLICE;
+#define IMAGEN_ABI_VERSION 9 /* 9: LINEAR_F32, SCALE_SHIFT ss_f32;  8: ROWCHAIN, the latency probes;  3: head_dim in the attention / QNORM / KV_PREP params; 4: DDPM_UPDATE x0_thr; 5: GCA_TAIL; 6: ACT_PREP self_stat, STEP_SLICE;
                                * 7: every launch carries sizeof(its params struct) (a stale mirror of a struct fails loudly), ImagenIgemmParams.dbg -> launcher_word, kernel families 6 and 7, ImagenAttentionParams.softmax_mode */
 
 typedef void* imagen_stream_t; /* hipStream_t */
@@ -66,7 +66,8 @@ enum ImagenOpKind {
   IMAGEN_OP_GCA_TAIL = 27,     /* ResnetBlock tail in ONE launch: GlobalContext finalisation + h*gate + res (+ statistics, + the next Block's activated input) */
   IMAGEN_OP_STEP_SLICE = 28,   /* copy the current step's rows of up to four per-step tables (the timestep-only conditioning, computed for all steps at once) into the buffers the step's kernels read */
   IMAGEN_OP_ROWCHAIN = 29,     /* a chain of row-local token layers (attention out-projection + LayerNorm + FeedForward | a whole cross-attention | LayerNorm + q/k/v projection + K^/V^T rows) in ONE launch */
-  IMAGEN_OP_KIND_COUNT = 30
+  IMAGEN_OP_LINEAR_F32 = 30,   /* a Linear on per-sample vectors in fp32 end to end (the timestep-conditioning chain: to_time_cond, the ResnetBlocks' time MLPs) */
+  IMAGEN_OP_KIND_COUNT = 31
 };
 
 /* ------------------------------------------------------------------------------------------------
@@ -313,7 +314,22 @@ typedef struct ImagenScaleShiftParams {
   const void* ss; const float* gamma_s; const int32_t* idx_scale; const int32_t* idx_shift;
   float* pa; float* ps;
   int32_t B, total_c, ld_ss;
+  int32_t ss_f32;   /* 1: ss holds fp32 rows (LINEAR_F32's output), 0: fp16 rows (an IGEMM's) */
 } ImagenScaleShiftParams;
+
+/* LINEAR_F32 — nn.Linear on PER-SAMPLE vectors, fp32 end to end: to_time_cond (ip.py:1207-1210, 1575-1576: t = Linear(time_hiddens) + the text /
+ * low-res hiddens) and the time MLPs of all ResnetBlocks (ip.py:715-718, 738-741: SiLU -> Linear, batched into one matrix).  These layers see
+ * ONE row per sample and what they produce — the (scale, shift) of every Block — multiplies every pixel of that sample: an fp16 rounding of
+ * the row (of t, of SiLU(t) as an MFMA operand, of the scale / shift rows) is not noise that averages over pixels but one error vector for
+ * the whole map.  Plan interpreter, README unet1, null rows of three draws: 0.957 / 1.012 / 0.91e-3 with fp16 rows -> 0.890 / 0.951 / 0.893e-3
+ * with fp32 rows; the FLOPs are nothing (K, Cout <= a few thousand, R rows; once per request for all steps in table mode).
+ *   y[r, o] = bias[o] + sum_k f(x[r, k]) * wt[k, o]  (+ res[r, o]);   f = identity | SiLU (act_in);  fp32 accumulation, k ascending
+ * x: fp16 rows (x_f32 = 0) or fp32 rows (1), ld_x elements apart;  wt: the module's weight TRANSPOSED, fp32 [K][Cout] (coalesced over o);
+ * bias: fp32 [Cout] or null;  res: fp16 rows (ld_res) or null;  y: fp32 rows (ld_y). */
+typedef struct ImagenLinearF32Params {
+  const void* x; const float* wt; const float* bias; const void* res; float* y;
+  int32_t rows, K, Cout, ld_x, ld_res, ld_y, x_f32, act_in;
+} ImagenLinearF32Params;
 
 /* PACK_IMAGE — x (+ lowres_cond_img) fp32 NCHW -> fp16 NHWC [B,H,W,Cpad] (ip.py:1550-1551 concat). */
 typedef struct ImagenPackImageParams {

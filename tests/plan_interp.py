@@ -294,9 +294,21 @@ class Interpreter:
         hid = F.silu(feats @ w.t() + m.view(p.bias, f32)[:p.out_dim])
         m.strided(p.hid, f16, (p.B, p.out_dim), (p.ld_hid, 1)).copy_(hid.half())
 
+    def linear_f32(self, p):
+        """LINEAR_F32: y = bias + f(x) @ wt (+ res), fp32 rows in (or fp16), fp32 rows out."""
+        m = self.mem
+        x = m.strided(p.x, f32 if p.x_f32 else f16, (p.rows, p.K), (p.ld_x, 1)).float()
+        wt = m.strided(p.wt, f32, (p.K, p.Cout), (p.Cout, 1))
+        v = _act(x, p.act_in) @ wt
+        if p.bias:
+            v = v + m.view(p.bias, f32)[:p.Cout]
+        if p.res:
+            v = v + m.strided(p.res, f16, (p.rows, p.Cout), (p.ld_res, 1)).float()
+        m.strided(p.y, f32, (p.rows, p.Cout), (p.ld_y, 1)).copy_(v)
+
     def scale_shift(self, p):
         m = self.mem
-        ss = m.strided(p.ss, f16, (p.B, p.ld_ss), (p.ld_ss, 1)).float()
+        ss = m.strided(p.ss, f32 if p.ss_f32 else f16, (p.B, p.ld_ss), (p.ld_ss, 1)).float()
         isc = m.view(p.idx_scale, i32)[:p.total_c].long()
         ish = m.view(p.idx_shift, i32)[:p.total_c].long()
         m.view(p.pa, f32)[:p.B * p.total_c].copy_((m.view(p.gamma_s, f32)[:p.total_c] * (ss[:, isc] + 1.0)).reshape(-1))
@@ -613,4 +625,5 @@ Interpreter.DISPATCH = {
     K["IMAGEN_OP_ACT_PREP"]: Interpreter.act_prep,
     K["IMAGEN_OP_STEP_SLICE"]: Interpreter.step_slice,
     K["IMAGEN_OP_ROWCHAIN"]: Interpreter.rowchain,
+    K["IMAGEN_OP_LINEAR_F32"]: Interpreter.linear_f32,
 }

@@ -538,6 +538,37 @@ def test_time_embed_scale_shift_pack_copy(ops, dev):
     assert torch.equal(dst[:, 2:7].cpu(), src.cpu().expand(3, 5, 64)) and dst[:, :2].abs().sum() == 0
 
 
+@pytest.mark.parametrize("rows,K,Cout,x32,act,res", [(16, 128, 300, False, False, True), (5, 128, 2048, True, True, False), (37, 200, 519, True, True, True),
+                                                    (1, 512, 64, False, True, False)])
+def test_linear_f32_time_chain(ops, dev, rows, K, Cout, x32, act, res):
+    """LINEAR_F32 (the timestep-conditioning chain in fp32, ip.py:1575-1576, 738-741) against fp64 torch: fp32 rows out at fp32 accuracy —
+    partial row blocks, a ragged last k chunk, a Cout that is no multiple of the 256-channel workgroup, fp16 / fp32 rows in, SiLU, the fp16
+    residual rows — and SCALE_SHIFT reading the fp32 rows."""
+    torch.manual_seed(rows + K)
+    x = torch.randn(rows, K) * 2
+    w, b = torch.randn(Cout, K) / K ** 0.5, torch.randn(Cout)
+    r = h16(torch.randn(rows, Cout)) if res else None
+    xin = x if x32 else h16(x)
+    ref = F.linear(F.silu(xin.double()) if act else xin.double(), w.double(), b.double()) + (r.double() if res else 0)
+    y = torch.full((rows, Cout), float("nan"), device=dev)
+    xa = xin.to(dev).contiguous() if x32 else ops.Act(xin.half().to(dev), 1, 1, rows, K, K, rows * K)
+    ra = ops.Act(r.half().to(dev), 1, 1, rows, Cout, Cout, rows * Cout) if res else None
+    plan = ops.Plan()
+    ops.linear_f32(plan, xa, w.t().contiguous().to(dev), b.to(dev), y, res=ra, act_in=ops.ACT_SILU if act else ops.ACT_NONE)
+    _run(plan)
+    assert nerr(y, ref.float()) < 2e-6, nerr(y, ref.float())
+    if Cout >= 300:     # the fp32 rows as SCALE_SHIFT's input
+        C = 100
+        gam = torch.randn(C)
+        isc, ish = torch.arange(0, C).int(), (torch.arange(0, C) + C).int()
+        pa, ps = torch.empty(rows, C, device=dev), torch.empty(rows, C, device=dev)
+        plan = ops.Plan()
+        ops.scale_shift(plan, y, gam.to(dev), isc.to(dev), ish.to(dev), pa, ps)
+        _run(plan)
+        yc = y.cpu()
+        assert torch.equal(pa.cpu(), gam * (yc[:, :C] + 1)) and torch.equal(ps.cpu(), yc[:, C:2 * C])
+
+
 # ------------------------------------------------------------------------------------------------ sampler
 
 @pytest.mark.parametrize("n", [3 * 64 * 64, 3 * 256 * 256, 1000])
