@@ -1090,7 +1090,8 @@ class UnetEngine:
         # long schedules, small-memory parts) the per-step chain stays: same results, nine small launches per step.
         selfs_, crosses_, ws_, wc_ = self._ctx_weights()
         proj_c = (ws_.Cout if selfs_ else 0) + (wc_.Cout if crosses_ else 0)
-        tt_bytes = rows_all * (2 * 4 * self.total_c + (2 + 4 * bool(TIME_CHAIN_F32)) * (3 * self.Tc + 2 * self.total_c) + self.ntt * (2 * 2 * self.cond_dim + 2 * proj_c + 8))   # (fp32 t / ss rows: counted generously)
+        chain_bytes = (8 * self.Tc + 8 * self.total_c) if TIME_CHAIN_F32 else 2 * (3 * self.Tc + 2 * self.total_c)   # hid, t_const, t, ss rows (fp32 t / ss: LINEAR_F32)
+        tt_bytes = rows_all * (2 * 4 * self.total_c + chain_bytes + self.ntt * (2 * 2 * self.cond_dim + 2 * proj_c + 8))
         self.time_table_bytes = tt_bytes
         if tt_bytes > TIME_TABLE_MAX_BYTES:
             return None
