@@ -410,3 +410,35 @@ def test_family8_routing_rules():
     assert pick(16, 32, 128, 128)[0][3] != 8                                                   # 16384 pixels: the 32^2 maps stay where they were
     assert pick(16, 16, 512, 512)[0][3] != 8 and pick(16, 8, 1024, 1024)[0][3] != 8            # C2's layers: 604 MB of weight stream
     assert pick(4, 16, 512, 512)[0][3] != 8 and pick(2, 16, 512, 512)[0][3] == 8               # ... 151 MB at a quarter of the rows: still not; 75 MB at an eighth: taken
+
+
+def test_time_chain_runs_in_fp32(monkeypatch):
+    """The timestep-conditioning chain of the image planner (to_time_cond, the batched time MLPs) is two LINEAR_F32 launches with fp32 rows between
+    them and SCALE_SHIFT reading fp32 rows — per step AND in the per-request time table — and the table estimate of BASELINE C2 stays under the
+    default cap with the fp32 rows counted (engine.TIME_CHAIN_F32; 0 restores the fp16 GEMMs of rounds 1-5)."""
+    from imagen_pytorch_amd import Unet, _abi, engine
+    from imagen_pytorch_amd.engine import UnetEngine
+
+    K = _abi.ENUMS
+    kw = dict(dim=32, cond_dim=64, dim_mults=(1, 2), num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True), attn_heads=2)
+    u = Unet(**kw).eval()
+
+    def chain(plan, prefix=""):
+        by = {label: (kind, p) for kind, p, label in plan.ops}
+        return by[prefix + "to_time_cond"], by[prefix + "time_mlps"], by[prefix + "scale_shift"]
+
+    eng = UnetEngine(u, 4, 2, 16, "cpu", dry=True)
+    (k1, p1), (k2, p2), (k3, p3) = chain(eng.step_plan)
+    assert k1 == k2 == K["IMAGEN_OP_LINEAR_F32"] and k3 == K["IMAGEN_OP_SCALE_SHIFT"]
+    assert p1.x_f32 == 0 and p1.res and p1.act_in == 0 and p2.x_f32 == 1 and p2.x == p1.y and p2.act_in == K["IMAGEN_ACT_SILU"] and p3.ss_f32 == 1 and p3.ss == p2.y
+    eng.set_conditioning(text_embeds=torch.randn(2, 8, 768), text_mask=None, keep=torch.ones(4, dtype=torch.bool), lowres_noise_times=None)
+    coef, step = torch.zeros(7, 8), torch.zeros(1, dtype=torch.int32)
+    assert eng.enable_time_table(coef, step) is not None
+    (k1, p1), (k2, p2), (k3, p3) = chain(eng._tt_plan, "tt.")
+    assert k1 == k2 == K["IMAGEN_OP_LINEAR_F32"] and p1.rows == p2.rows == 7 * 4 and p3.ss_f32 == 1 and p3.B == 7 * 4
+    assert not any(label in ("to_time_cond", "time_mlps", "scale_shift") for _, _, label in eng.step_plan_tt.ops)
+
+    monkeypatch.setattr(engine, "TIME_CHAIN_F32", 0)
+    old = UnetEngine(Unet(**kw).eval(), 4, 2, 16, "cpu", dry=True)
+    (k1, _), (k2, _), (_, p3) = chain(old.step_plan)
+    assert k1 == k2 == K["IMAGEN_OP_IGEMM"] and p3.ss_f32 == 0
