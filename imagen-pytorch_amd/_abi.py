@@ -17,6 +17,16 @@ ROOT = os.path.dirname(HERE)
 HEADER = os.path.join(ROOT, "include", "imagen_hip.h")
 LIB_PATH = os.environ.get("IMAGEN_LIB_PATH") or os.path.join(HERE, "libimagen_hip.so")   # override: A/B builds of the kernel library
 
+# Every IMAGEN_* variable anything in this repository still reads.  The A/B switches of earlier rounds became module constants (ops.CONV_DMA,
+# engine.BIG_PREP, ... — a test or tool monkeypatches them); a script of those rounds that still exports one would silently compare two identical
+# configurations, so an unknown IMAGEN_* variable is an error, not a no-op.
+KNOWN_ENV = {"IMAGEN_LIB_PATH", "IMAGEN_TIMING", "IMAGEN_TIME_TABLE", "IMAGEN_TIME_TABLE_MAX_GB", "IMAGEN_CONV_PRO", "IMAGEN_CONV_GEMM",
+             "IMAGEN_CONV_SMALL", "IMAGEN_ROWCHAIN", "IMAGEN_EMUL_TESTS", "IMAGEN_BENCH_LANES", "IMAGEN_BENCH_MODE", "IMAGEN_VIDEO_GPU_TESTS"}
+_stale = sorted(k for k in os.environ if k.startswith("IMAGEN_") and k not in KNOWN_ENV)
+if _stale:
+    raise RuntimeError(f"{', '.join(_stale)}: not read by this version (switches of earlier rounds are module constants of imagen_pytorch_amd.ops / "
+                       f".engine now: monkeypatch them); known variables: {', '.join(sorted(KNOWN_ENV))}")
+
 _CTYPE = {
     "int32_t": ctypes.c_int32,
     "uint32_t": ctypes.c_uint32,

@@ -493,6 +493,9 @@ class UnetEngine:
         # block1: ChanRMSNorm over the (scaled) concat -> SiLU -> conv3x3.  The norm statistics come from the per-pixel sums of
         # squares the producers of x / skip emitted in their epilogues (a ROWSTAT pass only where a producer could not).
         stat_x = lambda: self._ssq_of(plan, x, name + ".block1.stat_x")
+        # what the launch that produced x may read of the skip's statistics (request_prep below wires them into THAT earlier launch): only sums of
+        # squares a producer already emitted — _ssq_of() would append a ROWSTAT at the current plan position, behind the launch that needs them
+        skip_ssq_ready = skip.ssq if skip is not None else None
         ss = self._ssq_of(plan, skip, name + ".block1.stat_skip") if skip is not None else None
         w1 = W.conv(name + ".block1", rb.block1.project, split=skip is None and self._split_small(Cin, 9, Cout, R * H * Wd))
         pa1 = W.f32(name + ".block1.pa", lambda: _pad_vec(rb.block1.norm.gamma.detach().float().flatten().cpu() * math.sqrt(Cin)
@@ -515,7 +518,7 @@ class UnetEngine:
         # channels and its sum of squares in registers — and block1 stages its input with no arithmetic (prologue-free kernel families)
         xa = ops.request_act(x, pa1) if (skip is None and TAIL_ACT and w1.Cin_pad == w1.Cin) else None
         # ... or out of the previous block's res_conv as a ROWCHAIN launch (RESPREP), which then writes the activated concat(x, skip) as well
-        xr = ops.request_prep(x, skip, skip.ssq if skip is not None else None, s * s, pa1) if (xa is None and (prep or big1)) else None
+        xr = ops.request_prep(x, skip, skip_ssq_ready, s * s, pa1) if (xa is None and (prep or big1)) else None
         if xa is not None:
             op = ops.igemm(plan, xa, w1, h1, ssq_out=h1.ssq, post=post, label=name + ".block1")
         elif xr is not None:     # (no ACT_PREP pass)

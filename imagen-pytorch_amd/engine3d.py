@@ -54,6 +54,9 @@ def _w2d(mod):
 # executed-FLOP bound (SPLIT_SMALL_FLOPS) never admits them: the output stage gets its own, wider, bound; two launches per step grow by
 # ~20 us each (1 % of the C5 step).
 SPLIT_OUTPUT_STAGE = 1
+TIME_CHAIN_F32 = 0        # (round 6, call A) 1 = to_time_cond and the batched time MLPs on fp32 rows (IMAGEN_OP_LINEAR_F32) as the image planner runs them: priced in the
+                          # plan interpreter at +-0.5 % on C5 (cond 0.970 -> 0.965e-3, null 0.901 -> 0.905e-3) and measured on MI355X at 9.67e-4 / 9.97e-4 against 9.64e-4 /
+                          # 9.76e-4 without — no gain on the video denoiser, so its chain stays on the fp16 GEMMs
 SPLIT_OUTPUT_MAX_K = 640          # taps * input channels of the unsplit weight (dim 64: 576)
 SPLIT_OUTPUT_FLOPS = 4.0e10       # 2 * pixels * Cout * (2 K) of the split launch (C5: 1.9e10)
 
@@ -153,8 +156,15 @@ class UnetEngine3D(UnetEngine):
             plan, times=self.times, coef=None, step_ptr=None,
             freqs=W.f32("time.freqs", lambda: u.to_time_hiddens[0].weights), w=W.f32("time.w", lambda: u.to_time_hiddens[1].weight),
             bias=W.f32("time.b", lambda: u.to_time_hiddens[1].bias), hid=self.hid, label="time_embed")
-        self.t = self.new(1, 1, R, self.Tc)
-        ops.igemm(plan, self.hid, W.conv("time.cond", u.to_time_cond[0]), self.t, res=self.t_const, label="to_time_cond")
+        # the timestep-conditioning chain in fp32 (engine.TIME_CHAIN_F32): these are PER-SAMPLE rows, so an fp16 rounding of them is a
+        # bias of the whole clip, not noise that averages over pixels
+        if TIME_CHAIN_F32:
+            self.t = self.f32buf(R, self.Tc)
+            ops.linear_f32(plan, self.hid, W.f32("time.cond.wt32", lambda: u.to_time_cond[0].weight.t()), W.f32("time.cond.b32", lambda: u.to_time_cond[0].bias),
+                           self.t, res=self.t_const, label="to_time_cond")
+        else:
+            self.t = self.new(1, 1, R, self.Tc)
+            ops.igemm(plan, self.hid, W.conv("time.cond", u.to_time_cond[0]), self.t, res=self.t_const, label="to_time_cond")
         tok_raw = self.new(1, 1, R, self.ntt * self.cond_dim)
         ops.igemm(plan, self.hid, W.conv("time.tokens", u.to_time_tokens[0]), tok_raw, label="to_time_tokens")
         self.c_time = self.new(1, 1, R * self.ntt, self.cond_dim)
@@ -168,11 +178,18 @@ class UnetEngine3D(UnetEngine):
         self._blk_index = {id(rb): i for i, rb in enumerate(blocks)}
         tw, tb, gam, isc, ish, self._blk_off, total_c = W.get("timemlp.tables", lambda: self._time_mlp_tables(blocks))
         self.total_c = total_c
-        t_rep = self.new(1, 1, R * F, self.Tc)
-        ops.rows_copy(plan, self.t.t, t_rep.t, B=R, rows=F, C=self.Tc, src_bs=self.Tc, src_rs=0, dst_bs=F * self.Tc, dst_rs=self.Tc,
-                      label="t_per_frame")
-        ss = self.new(1, 1, R * F, tw.shape[0])
-        ops.igemm(plan, t_rep, W.raw("timemlp.w", tw, tb), ss, act_in=ACT_SILU, label="time_mlps")
+        if TIME_CHAIN_F32:     # (fp32 rows copied as pairs of halves)
+            t_rep = self.f32buf(R * F, self.Tc)
+            ops.rows_copy(plan, self.t.view(torch.float16), t_rep.view(torch.float16), B=R, rows=F, C=2 * self.Tc, src_bs=2 * self.Tc, src_rs=0,
+                          dst_bs=2 * F * self.Tc, dst_rs=2 * self.Tc, label="t_per_frame")
+            ss = self.f32buf(R * F, tw.shape[0])
+            ops.linear_f32(plan, t_rep, W.f32("timemlp.wt32", lambda: tw.t()), W.f32("timemlp.b32", lambda: tb), ss, act_in=ACT_SILU, label="time_mlps")
+        else:
+            t_rep = self.new(1, 1, R * F, self.Tc)
+            ops.rows_copy(plan, self.t.t, t_rep.t, B=R, rows=F, C=self.Tc, src_bs=self.Tc, src_rs=0, dst_bs=F * self.Tc, dst_rs=self.Tc,
+                          label="t_per_frame")
+            ss = self.new(1, 1, R * F, tw.shape[0])
+            ops.igemm(plan, t_rep, W.raw("timemlp.w", tw, tb), ss, act_in=ACT_SILU, label="time_mlps")
         self.pa2 = self.f32buf(R * F, total_c)
         self.ps2 = self.f32buf(R * F, total_c)
         ops.scale_shift(plan, ss, W.f32("timemlp.gam", lambda: gam), W.get("timemlp.isc", lambda: isc.to(self.dev)),

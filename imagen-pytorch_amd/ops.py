@@ -534,7 +534,9 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
         if (tile is not None and sc is not None and x1.C % 8 == 0 and C2 % 8 == 0 and x1.C + C2 == pw.Cin_pad
                 and x1.ld % 8 == 0 and x1.bs % 8 == 0 and (x2 is None or (x2.ld % 8 == 0 and x2.bs % 8 == 0))
                 and act_in in (ACT_NONE, ACT_SILU) and (mu is None or rs is not None) and (pstride == 0 or pstride >= pw.Cin_pad)
-                and (out_mode == OUT_NCHW_F32 or pw.Cout % 4 == 0)
+                and (out_mode == OUT_NCHW_F32 or pw.Cout % 4 == 0) and (out_mode != OUT_PIXEL_SHUFFLE or pw.Cout % 16 == 0)
+                and pw.Cin_pad % 32 == 0 and not (addend is not None and (res is not None or gate is None))
+                and x1.ptr % 16 == 0 and (x2 is None or x2.ptr % 16 == 0)     # (launch_conv_small's own predicates: a shape it refuses falls through to the older families)
                 and small_lds_bytes(tile[0], tile[1], pw.Cin_pad, cfg_table()[sc][1]) <= MAX_LDS_BYTES
                 and (x1.B * OH * OW // 32) * pw.Cout_pad * pw.Cin_pad * 2 * KH * KW <= SMALL_MAX_STREAM_MB << 20):
             cfg = (sc, tile[0], tile[1])

@@ -442,3 +442,18 @@ def test_time_chain_runs_in_fp32(monkeypatch):
     old = UnetEngine(Unet(**kw).eval(), 4, 2, 16, "cpu", dry=True)
     (k1, _), (k2, _), (_, p3) = chain(old.step_plan)
     assert k1 == k2 == K["IMAGEN_OP_IGEMM"] and p3.ss_f32 == 0
+
+
+def test_a_removed_switch_in_the_environment_is_an_error():
+    """the A/B switches of rounds 2-4 (IMAGEN_CONV_DMA, IMAGEN_BIG_PREP, ...) are module constants now; a script that still
+    exports one must not silently run the default configuration twice."""
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, IMAGEN_CONV_DMA="0")
+    r = subprocess.run([sys.executable, "-c", "import imagen_pytorch_amd"], cwd=root, env=env, capture_output=True, text=True)
+    assert r.returncode != 0 and "IMAGEN_CONV_DMA" in r.stderr and "module constants" in r.stderr, r.stderr[-400:]
+    env = dict(os.environ, IMAGEN_ROWCHAIN="1")
+    r = subprocess.run([sys.executable, "-c", "import imagen_pytorch_amd"], cwd=root, env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-400:]

@@ -248,6 +248,48 @@ def test_unet3d_plan_readme_structure_vs_oracle(reference_weights):
     assert split == {"final_conv", "final_res_block.block1"}, split
 
 
+def test_split_output_stage_does_not_worsen_a_single_video_forward(reference_weights, monkeypatch):
+    """the CPU replay of the Heun video trajectory moved 2.9e-2 -> 4.2e-2 when the output stage got split-precision weights, and
+    its bar went 3e-2 -> 5e-2 with 'chaotic trajectory' as the reason.  This is the check that separates chaos from regression: ONE denoiser
+    forward of that test's own stage-1 toy unet (tests/golden/sample_tiny_video.pt), through the planner + interpreter, against the fp32 oracle —
+    with engine3d.SPLIT_OUTPUT_STAGE on it must not be further from the oracle than with it off."""
+    from imagen_pytorch_amd import Unet3D, engine3d
+    from imagen_pytorch_amd.engine3d import UnetEngine3D
+    from oracle import unet3d_oracle as u3
+    from plan_interp import Interpreter
+
+    g = torch.load(os.path.join(GOLDEN, "sample_tiny_video.pt"), weights_only=False)
+    spec = g["unets"][0]
+    kw, sd = spec["kwargs"], spec["state_dict"]
+    B, Fr, S = 2, g["frames"], g["image_sizes"][0]
+    torch.manual_seed(11)
+    x, t, te = torch.randn(B, 3, Fr, S, S), torch.tensor([0.4, -0.8]), g["text_embeds"]
+    with torch.no_grad():
+        ref_c = u3.unet3d_forward(sd, kw, x, t, text_embeds=te)
+        ref_n = u3.unet3d_forward(sd, kw, x, t, text_embeds=te, cond_drop_prob=1.0)
+    errs = {}
+    for split in (0, 1):
+        monkeypatch.setattr(engine3d, "SPLIT_OUTPUT_STAGE", split)
+        u = Unet3D(**kw).eval()
+        u.load_state_dict(sd)
+        eng = UnetEngine3D(u, 2 * B, B, Fr, S, "cpu", dry=True)
+        keep = torch.tensor([True] * B + [False] * B)
+        eng.set_conditioning(text_embeds=te, text_mask=None, keep=keep, lowres_noise_times=None)
+        it = Interpreter()
+        for buf in (eng.x_in, eng.times, eng.lowres_times, eng.out, eng.keep_u8, eng.src_idx, eng.arange_idx, eng.t_const.t):
+            it.mem.register(buf)
+        it.run(eng._static_plans[te.shape[1]][0])
+        eng.x_in.copy_(x.permute(0, 2, 1, 3, 4))
+        eng.times.copy_(t.repeat(2))
+        it.run(eng.step_plan)
+        out = eng.out.permute(0, 2, 1, 3, 4)
+        n_split = sum(1 for _, p, label in eng.step_plan.ops if label in ("final_conv", "final_res_block.block1") and p.x2 == p.x1 and p.C2 == p.C1 > 0)
+        assert n_split == (2 if split else 0), (split, n_split)
+        errs[split] = (nerr(out[:B], ref_c), nerr(out[B:], ref_n))
+    assert max(errs[1]) < 5e-3, errs
+    assert errs[1][0] <= errs[0][0] * 1.02 and errs[1][1] <= errs[0][1] * 1.02, errs
+
+
 def test_unet_plan_without_text_mask(reference_weights):
     """`text_mask=None` with fewer tokens than max_text_len: the zero-padded positions stay ZERO tokens (ip.py:1617-1632 only applies
     the null embedding through a mask); a plan that masked them out instead is what this test caught."""
@@ -370,6 +412,42 @@ def test_unet_plan_with_big_tile_family(reference_weights, monkeypatch):
     # round 5: on these levels the res_conv + gate tail of an up block is a ROWCHAIN launch (RESPREP), and the block behind it takes its
     # activated input from that launch instead of an ACT_PREP pass
     assert seen["resprep"] >= 2 and seen["asked"] >= 1, seen
+
+
+def test_resprep_never_reads_skip_statistics_computed_behind_it(reference_weights, monkeypatch):
+    """request_prep wires the skip tensor's sums of squares into the EARLIER launch that produced x (RESPREP).  When no producer
+    emitted them, engine._ssq_of appends a ROWSTAT at the current plan position — behind that launch — so they must not be offered to it: the
+    block falls back to its ACT_PREP pass.  Here the down path's convs are kept from emitting statistics; the plan must still match the oracle,
+    and no request may carry a tensor that a late ROWSTAT fills."""
+    from imagen_pytorch_amd import engine, ops
+
+    monkeypatch.setattr(ops, "BIG_MIN_WGS", 1)
+    real_igemm, real_req, real_ssq_of = ops.igemm, ops.request_prep, engine.UnetEngine._ssq_of
+    late, seen = [], dict(offered_late=0, refused=0, stripped=0)
+
+    def igemm(plan, *a, **k):
+        if str(k.get("label", "")).startswith("downs.") and k.get("ssq_out") is not None:
+            k = dict(k, ssq_out=None)
+            seen["stripped"] += 1
+        return real_igemm(plan, *a, **k)
+
+    def ssq_of(self, plan, a, label):
+        fresh = a.ssq is None
+        t = real_ssq_of(self, plan, a, label)
+        if fresh:
+            late.append(t)
+        return t
+
+    def request(x, skip, ssq_skip, ssq_wb, pa):
+        seen["offered_late"] += any(ssq_skip is t for t in late)
+        seen["refused"] += skip is not None and ssq_skip is None
+        return real_req(x, skip, ssq_skip, ssq_wb, pa)
+
+    monkeypatch.setattr(ops, "igemm", igemm)
+    monkeypatch.setattr(ops, "request_prep", request)
+    monkeypatch.setattr(engine.UnetEngine, "_ssq_of", ssq_of)
+    test_unet_plan_config_sweep("dim32_three_levels", reference_weights)
+    assert seen["stripped"] >= 2 and seen["refused"] >= 1 and seen["offered_late"] == 0, seen
 
 
 @pytest.mark.parametrize("name", ["cond_images_3", "self_cond_lowres_cond_images_5", "plain_init_conv_no_mid_attn", "memory_efficient_lowres"])

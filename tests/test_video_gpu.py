@@ -397,8 +397,10 @@ C5_TOL = 1.0e-3    # north_star's bar.  Measured on MI355X, round 5 (calls Q, R)
 C5_CFG_TOL = 3.1e-3   # the CFG-3 combination 3 e_cond - 2 e_null of two in-tolerance forwards (bound 5e-3; measured 2.77e-3, 2.7-2.8e-3 in every round)
 
 
-def test_unet3d_forward_vs_oracle_c5():
-    """BASELINE config C5's own denoiser — Unet3D(dim=64, dim_mults=(1, 2, 4, 8)) on one 16 x 64 x 64 clip, the CFG batch of 2 rows the
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_unet3d_forward_vs_oracle_c5(seed):
+    """(seed 0 is the case every round measured; seeds 1 / 2 are two more weight / input draws of the same configuration: VERDICT round 5.)
+    BASELINE config C5's own denoiser — Unet3D(dim=64, dim_mults=(1, 2, 4, 8)) on one 16 x 64 x 64 clip, the CFG batch of 2 rows the
     sampler runs — against oracle/unet3d_oracle.py (iv.py:1650-1941), temporal layers de-identity-initialised, stage by stage: the taps
     'mid_peg' / 'mid_tattn' compare the two temporal kernels in place with the oracle's temporal_peg / temporal_attention."""
     from imagen_pytorch_amd import Unet3D
@@ -406,9 +408,9 @@ def test_unet3d_forward_vs_oracle_c5():
 
     dev = gpu_device()
     kw = dict(dim=64, dim_mults=(1, 2, 4, 8))
-    torch.manual_seed(0)
+    torch.manual_seed(seed)
     u = Unet3D(**kw).eval()
-    _derandomise_unet3d(u)
+    _derandomise_unet3d(u, seed=1234 + seed)
     sd = {k: v.clone() for k, v in u.state_dict().items()}
     x, t = torch.randn(1, 3, 16, 64, 64), torch.tensor([0.3])
     te = torch.randn(1, 24, 768)
@@ -430,6 +432,6 @@ def test_unet3d_forward_vs_oracle_c5():
     e_cfg = nerr(cfg, ref_null + (ref - ref_null) * 3.0)
     print(f"c5 Unet3D(dim=64) 16x64x64 vs oracle: cond {e:.2e} null {e_null:.2e} cfg3 {e_cfg:.2e}")
     from conftest import record_parity
-    record_parity("unet3d_forward_vs_oracle_c5", cond=e, null=e_null, cfg3=e_cfg, taps=rep, tol=C5_TOL)
+    record_parity("unet3d_forward_vs_oracle_c5" + (f"-seed{seed}" if seed else ""), cond=e, null=e_null, cfg3=e_cfg, taps=rep, tol=C5_TOL)
     assert {"mid_peg", "mid_tattn"} <= set(rep)
     assert e < C5_TOL and e_null < C5_TOL and e_cfg < C5_CFG_TOL, (e, e_null, e_cfg, rep)
