@@ -21,7 +21,7 @@ LIB_PATH = os.environ.get("IMAGEN_LIB_PATH") or os.path.join(HERE, "libimagen_hi
 # engine.BIG_PREP, ... — a test or tool monkeypatches them); a script of those rounds that still exports one would silently compare two identical
 # configurations, so an unknown IMAGEN_* variable is an error, not a no-op.
 KNOWN_ENV = {"IMAGEN_LIB_PATH", "IMAGEN_TIMING", "IMAGEN_TIME_TABLE", "IMAGEN_TIME_TABLE_MAX_GB", "IMAGEN_CONV_PRO", "IMAGEN_CONV_GEMM",
-             "IMAGEN_CONV_SMALL", "IMAGEN_ROWCHAIN", "IMAGEN_GCA_EPILOGUE_FINAL", "IMAGEN_EMUL_TESTS", "IMAGEN_BENCH_LANES", "IMAGEN_BENCH_MODE", "IMAGEN_VIDEO_GPU_TESTS"}
+             "IMAGEN_CONV_SMALL", "IMAGEN_ROWCHAIN", "IMAGEN_EMUL_TESTS", "IMAGEN_BENCH_LANES", "IMAGEN_BENCH_MODE", "IMAGEN_VIDEO_GPU_TESTS"}
 _stale = sorted(k for k in os.environ if k.startswith("IMAGEN_") and k not in KNOWN_ENV)
 if _stale:
     raise RuntimeError(f"{', '.join(_stale)}: not read by this version (switches of earlier rounds are module constants of imagen_pytorch_amd.ops / "

@@ -354,7 +354,7 @@ __global__ __launch_bounds__(512, 1) void conv_big_kernel(const ImagenIgemmParam
   imagen_code_warm_sink(warm);
   float* const ep_par = reinterpret_cast<float*>(smem + EPP0);
   float* const ep_red = ep_par + (4 * BN + NQ * PXW + 8 + WM * (BN + 4));
-  cl_epilogue<MI, NI, WM, WN, GEN, true, !GEN>(p, tc, acc, pix_y, pix_x, ep_red, ep_par, wm, wn, half, l31, smem + STG0, reinterpret_cast<float*>(smem));
+  cl_epilogue<MI, NI, WM, WN, GEN, true, !GEN>(p, tc, acc, pix_y, pix_x, ep_red, ep_par, wm, wn, half, l31, smem + STG0);
 }
 
 struct CbCfg { int WM, WN, KS, TW, WR, HR; };
@@ -386,12 +386,6 @@ int cb_launch_gen(const ImagenIgemmParams& p, hipStream_t s) {
                "conv_big: ssq_out needs NHWC output and one workgroup covering all %d output channels (tile has %d)", p.Cout, BN);
   constexpr size_t lds = (size_t)cb_lds_bytes(WM, WN, KS, TW, WR, HR);
   static_assert(lds <= 160 * 1024, "conv_big: LDS image too large");
-  const int tiles_img = ((p.OW + TW - 1) / TW) * ((p.OH + TH - 1) / TH);
-  if (p.gca_gate) {   // the image's last tile finalises the GlobalContext gate (gca_device.h)
-    IMAGEN_CHECK(p.gca_part && p.gca_ticket && p.gca_w1t && p.gca_b1 && p.gca_w2t && p.gca_b2, "conv_big: gca_gate needs gca_part, gca_ticket and the squeeze MLP");
-    IMAGEN_CHECK(gca_epilogue_final_ok(64 * WM * WN, p.Cout, p.gca_hidden, tiles_img), "conv_big: gca_gate: Cout %d / hidden %d / %d tiles per image out of range", p.Cout, p.gca_hidden, tiles_img);
-    IMAGEN_CHECK((size_t)(gca_epilogue_final_lds_floats(64 * WM * WN, p.Cout, p.gca_hidden, tiles_img) + 4) * sizeof(float) <= lds, "conv_big: gca_gate: LDS");
-  }
   auto kern = conv_big_kernel<WM, WN, KS, TW, WR, HR, GEN>;
   static bool attr_done[16] = {};
   int dev = 0;

@@ -278,7 +278,7 @@ __global__ __launch_bounds__(256, (MI * NI <= 2 ? 3 : 2)) void conv_dma_kernel(c
   CD_WAIT_VM(0);   // stray look-ahead DMAs must not outlive the workgroup's LDS allocation
   __syncthreads();
 
-  cl_epilogue<MI, NI, WM, WN, GEN>(p, tc, acc, pix_y, pix_x, ep_red, reinterpret_cast<float*>(smem), wm, wn, half, l31, nullptr, reinterpret_cast<float*>(smem));
+  cl_epilogue<MI, NI, WM, WN, GEN>(p, tc, acc, pix_y, pix_x, ep_red, reinterpret_cast<float*>(smem), wm, wn, half, l31);
 }
 
 template <int MI, int NI, int WM, int WN, int TW, int RW, int PF, bool GEN>
@@ -300,14 +300,7 @@ int cd_launch_gen(const ImagenIgemmParams& p, hipStream_t s) {
   IMAGEN_CHECK(!p.gca_part || (p.gca_wk && !GEN && !p.post_pa && p.Cout <= BN), "conv_dma: gca_part needs gca_wk, a plain NHWC output and one tile covering all %d couts", p.Cout);
   IMAGEN_CHECK(!p.ssq_out || (p.out_mode == IMAGEN_OUT_NHWC && p.Cout <= BN),
                "conv_dma: ssq_out needs NHWC output and one workgroup covering all %d output channels (tile has %d)", p.Cout, BN);
-  size_t lds = (size_t)2 * NJ * 4096 + (size_t)4 * RW * (NI * 2048) + (size_t)(4 * 32 * MI) * sizeof(float) + 16;
-  const int tilesX = (p.OW + TW - 1) / TW, tilesY = (p.OH + TH - 1) / TH;
-  if (p.gca_gate) {   // the image's last tile finalises the GlobalContext gate (gca_device.h)
-    IMAGEN_CHECK(p.gca_part && p.gca_ticket && p.gca_w1t && p.gca_b1 && p.gca_w2t && p.gca_b2, "conv_dma: gca_gate needs gca_part, gca_ticket and the squeeze MLP");
-    IMAGEN_CHECK(gca_epilogue_final_ok(64 * WM * WN, p.Cout, p.gca_hidden, tilesX * tilesY), "conv_dma: gca_gate: Cout %d / hidden %d / %d tiles per image out of range", p.Cout, p.gca_hidden, tilesX * tilesY);
-    const size_t fin = (size_t)(gca_epilogue_final_lds_floats(64 * WM * WN, p.Cout, p.gca_hidden, tilesX * tilesY) + 4) * sizeof(float);
-    if (fin > lds) lds = fin;
-  }
+  const size_t lds = (size_t)2 * NJ * 4096 + (size_t)4 * RW * (NI * 2048) + (size_t)(4 * 32 * MI) * sizeof(float) + 16;
   IMAGEN_CHECK(lds <= 160 * 1024, "conv_dma: LDS tile %zu bytes too large", lds);
   auto kern = conv_dma_kernel<MI, NI, WM, WN, TW, RW, PF, GEN>;
   static bool attr_done[16] = {};
@@ -318,6 +311,7 @@ int cd_launch_gen(const ImagenIgemmParams& p, hipStream_t s) {
     if (e != hipSuccess) { imagen_set_error("conv_dma: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
     attr_done[dev] = true;
   }
+  const int tilesX = (p.OW + TW - 1) / TW, tilesY = (p.OH + TH - 1) / TH;
   const int total = p.B * tilesX * tilesY * ((p.Cout + BN - 1) / BN);
   hipLaunchKernelGGL(kern, dim3(total), dim3(256), lds, s, p);
   return imagen_hip_status("conv_dma launch");

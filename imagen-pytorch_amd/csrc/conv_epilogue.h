@@ -3,7 +3,6 @@
 // / pixel-shuffle / fp32-NCHW / output-side Block prologue (post_pa) / per-pixel sum of squares, as documented at ImagenIgemmParams.
 #pragma once
 #include "common.h"
-#include "gca_device.h"
 
 struct ClTile { int b, oy0, ox0, n0; };
 
@@ -62,12 +61,10 @@ __device__ __forceinline__ void cl_copy_out(const ImagenIgemmParams& p, const Cl
   }
 }
 
-// fin_lds: with p.gca_gate, gca_epilogue_final_lds_floats(64 WM WN, Cout, gca_hidden, tiles per image) + 4 floats of LDS that are dead once the
-// partial rows are stored (one-tile workgroups: the base of their staging memory), 16-byte aligned; nullptr in kernels that cannot finalise
 template <int MI, int NI, int WM, int WN, bool GEN, bool PRELOADED = false, bool STG = false>
 __device__ __forceinline__ void cl_epilogue(const ImagenIgemmParams& p, const ClTile& tc, f32x16 (&acc)[NI][MI], const int (&pix_y)[MI],
                                             const int (&pix_x)[MI], float* ep_red, float* ep_par, int wm, int wn, int half, int l31,
-                                            char* stg = nullptr, float* fin_lds = nullptr) {
+                                            char* stg = nullptr) {
   constexpr int PXW = 32 * MI;
   constexpr int BN = 32 * NI * WN;
   constexpr int STG_PITCH = 2 * BN + 16;
@@ -287,31 +284,18 @@ __device__ __forceinline__ void cl_epilogue(const ImagenIgemmParams& p, const Cl
       const int tilesX = (p.OW + p.TW - 1) / p.TW, tilesY = (p.OH + p.TH - 1) / p.TH;
       float* out = p.gca_part + ((size_t)(b * tilesY + tc.oy0 / p.TH) * tilesX + tc.ox0 / p.TW) * (p.Cout + 2);
       const int i = threadIdx.x;
-      const bool fin = p.gca_gate != nullptr && fin_lds != nullptr;   // the image's last tile finalises the gate (gca_device.h): rows stored write-through
       if (i < BN && n0 + i < p.Cout) {
         float t = 0.0f;
 #pragma unroll
         for (int w = 0; w < WM; ++w) t += gs[w * (BN + 4) + i];
-        if (fin) imagen_st_wt_f32(out + 2 + n0 + i, t);
-        else out[2 + n0 + i] = t;
+        out[2 + n0 + i] = t;
       }
       if (i == 0) {
         float t = 0.0f;
 #pragma unroll
         for (int w = 0; w < WM; ++w) t += gs[w * (BN + 4) + BN];
-        if (fin) {
-          imagen_st_wt_f32(out, mx);
-          imagen_st_wt_f32(out + 1, t);
-        } else {
-          out[0] = mx;
-          out[1] = t;
-        }
-      }
-      if (fin) {
-        const int rows = tilesX * tilesY;
-        if (gca_ticket_is_last(p.gca_ticket + b, (unsigned)rows, reinterpret_cast<int*>(fin_lds), i == 0))
-          gca_epilogue_final<64 * WM * WN>(p.gca_part + (size_t)b * rows * (p.Cout + 2), rows, p.Cout, p.gca_hidden, p.gca_w1t, p.gca_b1, p.gca_w2t, p.gca_b2,
-                                           p.gca_gate + (size_t)b * p.Cout, fin_lds + 4, i);
+        out[0] = mx;
+        out[1] = t;
       }
     }
   } else {

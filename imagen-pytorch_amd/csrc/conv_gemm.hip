@@ -213,21 +213,13 @@ __global__ __launch_bounds__(256, 3) void conv_gemm_kernel(const ImagenIgemmPara
   // ---- epilogue (its scratch aliases the ring: every wave is behind the last step's barrier, the stray write of that step included)
   float* ep_par = reinterpret_cast<float*>(smem);
   float* ep_red = ep_par + CG_EP_PAR;
-  cl_epilogue<MI, NI, WM, WN, GEN>(p, tc, acc, pix_y, pix_x, ep_red, ep_par, wm, wn, half, l31, nullptr, reinterpret_cast<float*>(smem));
+  cl_epilogue<MI, NI, WM, WN, GEN>(p, tc, acc, pix_y, pix_x, ep_red, ep_par, wm, wn, half, l31);
 }
 
 template <bool PRO, bool GEN>
 int cg_launch(const ImagenIgemmParams& p, hipStream_t s) {
   auto kern = conv_gemm_kernel<PRO, GEN>;
-  size_t lds = cg_lds_bytes(p.Cin_pad, PRO);
-  const int tiles_img = ((p.OW + p.TW - 1) / p.TW) * ((p.OH + p.TH - 1) / p.TH);
-  if (p.gca_gate) {   // the image's last tile finalises the GlobalContext gate (gca_device.h)
-    IMAGEN_CHECK(p.gca_part && p.gca_ticket && p.gca_w1t && p.gca_b1 && p.gca_w2t && p.gca_b2, "conv_gemm: gca_gate needs gca_part, gca_ticket and the squeeze MLP");
-    IMAGEN_CHECK(gca_epilogue_final_ok(256, p.Cout, p.gca_hidden, tiles_img), "conv_gemm: gca_gate: Cout %d / hidden %d / %d tiles per image out of range", p.Cout, p.gca_hidden, tiles_img);
-    const size_t fin = (size_t)(gca_epilogue_final_lds_floats(256, p.Cout, p.gca_hidden, tiles_img) + 4) * sizeof(float);
-    if (fin > lds) lds = fin;
-    IMAGEN_CHECK(lds <= 160 * 1024, "conv_gemm: LDS");
-  }
+  const size_t lds = cg_lds_bytes(p.Cin_pad, PRO);
   static bool attr_done[16] = {};
   int dev = 0;
   (void)hipGetDevice(&dev);

@@ -383,21 +383,14 @@ __global__ __launch_bounds__(CS_THREADS, CS_MINW) void conv_small_kernel(const I
 
   CS_STAMP(4);
   // ---- epilogue: the NT live waves as a (1 x NT)-wave workgroup of conv_epilogue.h (its scratch sits behind everything else; operands preloaded)
-  cl_epilogue<1, 1, 1, NT, GEN, true>(p, tc, acc, pix_y, pix_x, ep_red, ep_par, 0, wn, half, l31, nullptr, reinterpret_cast<float*>(smem));
+  cl_epilogue<1, 1, 1, NT, GEN, true>(p, tc, acc, pix_y, pix_x, ep_red, ep_par, 0, wn, half, l31);
   CS_STAMP(5);
 }
 
 template <int NT, bool PRO, bool GEN>
 int cs_launch(const ImagenIgemmParams& p, hipStream_t s) {
   auto kern = conv_small_kernel<NT, PRO, GEN>;
-  size_t lds = cs_lds_bytes<NT>(p.TH, p.TW, p.Cin_pad);
-  const int tiles_img = ((p.OH + p.TH - 1) / p.TH) * ((p.OW + p.TW - 1) / p.TW);
-  if (p.gca_gate) {   // the image's last tile finalises the GlobalContext gate (gca_device.h)
-    IMAGEN_CHECK(p.gca_part && p.gca_ticket && p.gca_w1t && p.gca_b1 && p.gca_w2t && p.gca_b2, "conv_small: gca_gate needs gca_part, gca_ticket and the squeeze MLP");
-    IMAGEN_CHECK(gca_epilogue_final_ok(64 * NT, p.Cout, p.gca_hidden, tiles_img), "conv_small: gca_gate: Cout %d / hidden %d / %d tiles per image out of range", p.Cout, p.gca_hidden, tiles_img);
-    const size_t fin = (size_t)(gca_epilogue_final_lds_floats(64 * NT, p.Cout, p.gca_hidden, tiles_img) + 4) * sizeof(float);
-    if (fin > lds) lds = fin;
-  }
+  const size_t lds = cs_lds_bytes<NT>(p.TH, p.TW, p.Cin_pad);
   IMAGEN_CHECK(lds <= 160 * 1024, "conv_small: %zu bytes of LDS (Cin_pad %d)", lds, p.Cin_pad);
   static bool attr_done[16] = {};
   int dev = 0;

@@ -445,7 +445,6 @@ int launch_conv_stream(const ImagenIgemmParams* pp, int idx, hipStream_t s) {
   IMAGEN_CHECK(!(p.addend && p.res), "conv_stream: addend and residual are mutually exclusive");
   IMAGEN_CHECK(!p.gca_part || (p.gca_wk && !p.post_pa && p.out_mode == IMAGEN_OUT_NHWC && !p.addend && !p.res && p.act_out == IMAGEN_ACT_NONE),
                "conv_stream: gca_part needs gca_wk and a plain NHWC output");
-  IMAGEN_CHECK(!p.gca_gate, "conv_stream: a persistent workgroup cannot finalise the GlobalContext gate (its staging memory is never dead): gca_gate is for the kernel families 2, 5, 7 and 8");
   IMAGEN_CHECK(!p.ssq_out || p.out_mode == IMAGEN_OUT_NHWC, "conv_stream: ssq_out needs NHWC output");
   const bool plain = p.act_out == IMAGEN_ACT_NONE && p.out_mode == IMAGEN_OUT_NHWC && !p.addend && !p.res;
   const int key = (p.C2 ? 4 : 0) | (pro ? 2 : 0) | (plain ? 0 : 1);

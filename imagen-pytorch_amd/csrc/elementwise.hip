@@ -326,9 +326,8 @@ __global__ __launch_bounds__(256) void gca_partial_kernel(const ImagenGcaPartial
 __global__ __launch_bounds__(256) void gca_partial_online_kernel(const ImagenGcaPartialParams p, int chunk_px) {
   __shared__ float s_m[256];
   __shared__ float s_se[256];
-  __shared__ __attribute__((aligned(16))) float s_pool[4096 + 4];   // the merge scratch, then the finalisation's (gca_epilogue_final with a ticket: launcher-checked)
-  float* const s_acc = s_pool;          // [256 * 8]
-  float* const s_fin = s_pool + 2048;   // chunks == 1: ctx [C] | hid [hidden] | kGcaScratchFloats (C + hidden <= 1024 checked by the launcher)
+  __shared__ float s_acc[256 * 8];
+  __shared__ float s_fin[2048];   // chunks == 1: ctx [C] | hid [hidden] | kGcaScratchFloats (C + hidden <= 1024 checked by the launcher)
   const int b = blockIdx.y, ch = blockIdx.x;
   const int p0 = ch * chunk_px;
   const int npx = min(chunk_px, p.HW - p0);
@@ -405,13 +404,6 @@ __global__ __launch_bounds__(256) void gca_partial_online_kernel(const ImagenGca
       const float inv = 1.0f / S;
 #pragma unroll
       for (int j = 0; j < 8; ++j) s_fin[threadIdx.x * 8 + j] = tot[j] * inv;
-    } else if (p.ticket) {   // (the image's last chunk finalises the gate below: rows stored write-through)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) imagen_st_wt_f32(out + 2 + threadIdx.x * 8 + j, tot[j]);
-      if (threadIdx.x == 0) {
-        imagen_st_wt_f32(out, M);
-        imagen_st_wt_f32(out + 1, S);
-      }
     } else {
 #pragma unroll
       for (int j = 0; j < 8; ++j) out[2 + threadIdx.x * 8 + j] = tot[j];
@@ -422,15 +414,9 @@ __global__ __launch_bounds__(256) void gca_partial_online_kernel(const ImagenGca
     }
   }
   if (p.w1t == nullptr) return;   // partials only: a GCA_FINAL launch follows
-  if (p.chunks == 1) {            // one chunk per image: the whole image was this workgroup's, the squeeze MLP runs here
-    __syncthreads();
-    gca_mlp(s_fin, s_fin + p.C, s_fin + p.C + p.hidden, p.C, p.hidden, p.w1t, p.b1, p.w2t, p.b2, p.gate + (size_t)b * p.C);
-    return;
-  }
-  // several chunks and a ticket (launcher-checked): the workgroup that stored the image's last row merges all of them and runs the squeeze MLP
-  if (gca_ticket_is_last(p.ticket + b, (unsigned)p.chunks, reinterpret_cast<int*>(s_pool), threadIdx.x == 0))
-    gca_epilogue_final<256>(p.part + (size_t)b * p.chunks * (p.C + 2), p.chunks, p.C, p.hidden, p.w1t, p.b1, p.w2t, p.b2, p.gate + (size_t)b * p.C, s_pool + 4,
-                            (int)threadIdx.x);
+  // one chunk per image (launcher-checked): the whole image was this workgroup's, the squeeze MLP runs here
+  __syncthreads();
+  gca_mlp(s_fin, s_fin + p.C, s_fin + p.C + p.hidden, p.C, p.hidden, p.w1t, p.b1, p.w2t, p.b2, p.gate + (size_t)b * p.C);
 }
 
 // One workgroup per image: merge the chunk partials and run the squeeze MLP (gca_device.h, shared with the fused igemm epilogue).
@@ -1024,16 +1010,9 @@ int launch_gca_partial(const ImagenGcaPartialParams* p, hipStream_t s) {
   if (p->w1t) {
     IMAGEN_CHECK((groups & (groups - 1)) == 0 && groups <= 64, "gca: in-kernel finalisation needs a power-of-two C/8 (C = %d)", p->C);
     IMAGEN_CHECK(p->b1 && p->w2t && p->b2 && p->gate && p->hidden > 0, "gca: incomplete finalisation parameters");
-    if (p->chunks == 1) {
-      IMAGEN_CHECK(p->C + p->hidden + p->chunks + kGcaScratchFloats <= 2048, "gca: finalisation scratch too large (C %d hidden %d chunks %d)", p->C,
-                   p->hidden, p->chunks);
-    } else {   // several chunks per image: the last one to arrive (ticket) finalises
-      IMAGEN_CHECK(p->ticket, "gca: in-kernel finalisation over %d chunks per image needs the ticket words", p->chunks);
-      IMAGEN_CHECK(gca_epilogue_final_ok(256, p->C, p->hidden, p->chunks) && gca_epilogue_final_lds_floats(256, p->C, p->hidden, p->chunks) <= 4096,
-                   "gca: in-kernel finalisation: C %d / hidden %d / %d chunks out of range", p->C, p->hidden, p->chunks);
-    }
-  } else {
-    IMAGEN_CHECK(!p->ticket, "gca: ticket without the squeeze MLP");
+    IMAGEN_CHECK(p->chunks == 1, "gca: in-kernel finalisation needs one chunk per image (got %d)", p->chunks);
+    IMAGEN_CHECK(p->C + p->hidden + p->chunks + kGcaScratchFloats <= 2048, "gca: finalisation scratch too large (C %d hidden %d chunks %d)", p->C,
+                 p->hidden, p->chunks);
   }
   if ((groups & (groups - 1)) == 0 && groups <= 64) {
     hipLaunchKernelGGL(gca_partial_online_kernel, dim3(p->chunks, p->B), dim3(256), 0, s, *p, chunk_px);

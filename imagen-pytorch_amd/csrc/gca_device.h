@@ -157,10 +157,6 @@ constexpr int kGcaEpiP = 4;    // prefetched chunk-row elements per thread
 constexpr int kGcaEpiS = 4;    // chunk statistics per thread
 
 __host__ __device__ constexpr int gca_epilogue_final_lds_floats(int NT, int C, int hidden, int chunks) { return 4 * NT + 2 * C + 2 * hidden + chunks + 64; }
-// the shapes gca_epilogue_final<NT> takes (launchers check; ops.gca_epilogue_final_ok mirrors it)
-__host__ __device__ constexpr bool gca_epilogue_final_ok(int NT, int C, int hidden, int chunks) {
-  return C >= 8 && C <= NT && (C & (C - 1)) == 0 && hidden >= 4 && hidden <= 4 * NT && (hidden & (hidden - 1)) == 0 && chunks >= 1 && chunks <= kGcaEpiS * NT;
-}
 
 template <int NT, class Emit>
 __device__ __forceinline__ void gca_epi_matvec(const float4 (&w)[kGcaEpiW], const float* wt, int n_in, int n_out, const float* in, float4* red, int t, Emit emit) {

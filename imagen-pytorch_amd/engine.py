@@ -549,13 +549,7 @@ class UnetEngine:
                             b1=W.f32(name + ".gca.b1", lambda: g.net[0].bias),
                             w2t=W.f32(name + ".gca.w2t", lambda: g.net[2].weight.reshape(Cout, hidden).t()),
                             b2=W.f32(name + ".gca.b2", lambda: g.net[2].bias), gate=gate)
-        # identity block: GlobalContext finalisation + h2 * gate + x (+ statistics) as ONE launch (GCA_TAIL) where its shapes allow
-        fused_tail = (TAIL_FUSED and rb.res_conv is None and x.ld == x.C and x.bs == H * Wd * x.C
-                      and ops.gca_tail_ok(Cout, (hidden if rb.gca is not None else None)))
         gca_ep = dict(wk=gca_args["wk"], bk=gca_args["bk"]) if rb.gca is not None else None   # GlobalContext partials from block2's epilogue
-        # ... whose last tile per image also finalises the gate (ops.GCA_EPILOGUE_FINAL): always behind a res_conv tail, behind a fused tail in mode 2
-        if gca_ep is not None and (ops.GCA_EPILOGUE_FINAL >= 2 or (ops.GCA_EPILOGUE_FINAL and not fused_tail)):
-            gca_ep["final"] = gca_args
         if op.post_applied:     # h1 already holds silu(norm(h1) * (scale + 1) + shift)
             op2 = ops.igemm(plan, h1, W.conv(name + ".block2", rb.block2.project, split=SPLIT_BLOCK2 and self._split_small(Cout, 9, Cout, R * H * Wd)), h2,
                             gca=gca_ep, label=name + ".block2")
@@ -572,12 +566,13 @@ class UnetEngine:
             else:
                 op2 = ops.igemm(plan, h1, w2, h2, ssq_a=self._ssq_of(plan, h1, name + ".block2.stat"), pa=pa2, ps=ps2, pstride=self.total_c,
                                 act_in=ACT_SILU, gca=gca_ep, label=name + ".block2")
+        # identity block: GlobalContext finalisation + h2 * gate + x (+ statistics) as ONE launch (GCA_TAIL) where its shapes allow
+        fused_tail = (TAIL_FUSED and rb.res_conv is None and x.ld == x.C and x.bs == H * Wd * x.C
+                      and ops.gca_tail_ok(Cout, (hidden if rb.gca is not None else None)))
         tail_part, tail_chunks, gate_ready = None, 0, False
         if rb.gca is not None:
             wide = ops.GCA_FINAL_SPLIT and ops.gca_final_is_wide(Cout, hidden)   # (a fused tail would stream 1-4 MB of MLP weights in EVERY workgroup)
-            if op2.gca_gate_ready:           # block2's last tile per image wrote the gate itself
-                gate_ready = True
-            elif op2.gca_part_t is not None:   # the partials came out of block2's epilogue: only the merge + squeeze MLP is left
+            if op2.gca_part_t is not None:   # the partials came out of block2's epilogue: only the merge + squeeze MLP is left
                 if fused_tail and op2.gca_chunks <= 1024 and not wide:
                     tail_part, tail_chunks = op2.gca_part_t, op2.gca_chunks
                 else:
@@ -588,7 +583,7 @@ class UnetEngine:
                 chunks = ops.gca_chunks(H * Wd, R, Cout)
                 part = self.f32buf(R, chunks, Cout + 2)
                 gate_ready = ops.gca(plan, h2, gca_args["wk"], gca_args["bk"], gca_args["w1t"], gca_args["b1"], gca_args["w2t"], gca_args["b2"], part,
-                                     gate, chunks, label=name + ".gca", final=(not fused_tail) or wide, ticket=ops.GCA_EPILOGUE_FINAL >= 2)
+                                     gate, chunks, label=name + ".gca", final=(not fused_tail) or wide)
                 if not gate_ready:
                     tail_part, tail_chunks = part, chunks
         out = self.new(R, H, Wd, Cout)

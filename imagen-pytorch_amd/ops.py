@@ -653,9 +653,8 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
         keep.append(ssq_out)
         emitted = True
     # gca: dict(wk=fp32 [Cout], bk=float): GlobalContext partials of the output from the epilogue (kernel family 2, one tile over
-    # all Cout); `p.gca_part_t` ([B, chunks, Cout + 2], chunks = tiles per image = `p.gca_chunks`) then feeds GCA_FINAL directly.
-    # gca["final"] = dict(w1t, b1, w2t, b2, gate): the image's last tile also merges the rows and runs the squeeze MLP (`p.gca_gate_ready`): no GCA_FINAL
-    p.gca_part_t, p.gca_chunks, p.gca_gate_ready = None, 0, False
+    # all Cout); `p.gca_part_t` ([B, chunks, Cout + 2], chunks = tiles per image = `p.gca_chunks`) then feeds GCA_FINAL directly
+    p.gca_part_t, p.gca_chunks = None, 0
     chunks = math.ceil(OH / th) * math.ceil(OW / tw)
     fam = cfg_table()[cid][3]
     if want_gca and pw.Cout <= cfg_table()[cid][1] and ((fam in (2, 5, 7, 8) and x1.B * chunks <= GCA_EPILOGUE_MAX_TILES)
@@ -664,15 +663,6 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
         p.gca_wk, p.gca_part, p.gca_bk = gca["wk"].data_ptr(), part.data_ptr(), gca["bk"]
         keep += [gca["wk"], part]
         p.gca_part_t, p.gca_chunks = part, chunks
-        fin = gca.get("final")
-        if fin is not None and GCA_EPILOGUE_FINAL and fam in (2, 5, 7, 8):
-            hidden = fin["w1t"].shape[1]
-            if gca_epilogue_final_ok(epilogue_threads(cid), pw.Cout, hidden, chunks):
-                ticket = torch.zeros(x1.B, dtype=torch.int32, device=x1.t.device)    # one word per image: counts its tiles, left at zero by the launch
-                p.gca_w1t, p.gca_b1, p.gca_w2t, p.gca_b2 = fin["w1t"].data_ptr(), fin["b1"].data_ptr(), fin["w2t"].data_ptr(), fin["b2"].data_ptr()
-                p.gca_gate, p.gca_ticket, p.gca_hidden = fin["gate"].data_ptr(), ticket.data_ptr(), hidden
-                keep += [fin["w1t"], fin["b1"], fin["w2t"], fin["b2"], fin["gate"], ticket]
-                p.gca_gate_ready = True
     plan.add(p, label or "igemm", keep)
     p.ssq_emitted = emitted
     p.post_applied = posted
@@ -815,22 +805,6 @@ def gca_final(plan: Plan, part: torch.Tensor, w1t, b1, w2t, b2, gate: torch.Tens
 
 
 GCA_FINAL_SPLIT = 1   # (module constant; round 4, call V) the finalisation of wide blocks as two many-workgroup launches
-GCA_EPILOGUE_FINAL = int(_os.environ.get("IMAGEN_GCA_EPILOGUE_FINAL", "2"))   # A/B switch (round 6): the workgroup that writes an image's LAST GlobalContext partial row — a conv epilogue's or a GCA_PARTIAL workgroup's — merges
-                         # the rows and runs the squeeze MLP itself (csrc/gca_device.h: ticket + gca_epilogue_final): no GCA_FINAL launch behind the blocks whose
-                         # tail is a res_conv (1), and the fused tails of the identity blocks read the ready gate instead of deriving it in every workgroup (2)
-
-
-def epilogue_threads(cid: int) -> int:
-    """Threads of the workgroup that runs conv_epilogue.h for tile configuration `cid` (families 2, 5, 7, 8: the in-launch GlobalContext finalisation)."""
-    tp, bn, _, fam = cfg_table()[cid]
-    return {2: 256, 5: tp * bn // 64, 7: 256, 8: 2 * bn}[fam]
-
-
-def gca_epilogue_final_ok(threads: int, C: int, hidden: int, chunks: int) -> bool:
-    """csrc/gca_device.h gca_epilogue_final_ok: power-of-two C in [8, threads], power-of-two hidden in [4, 4 threads], at most 4 threads rows per image;
-    wide blocks keep the two-phase GCA_FINAL (one workgroup would stream 1-4 MB of squeeze-MLP weights alone)."""
-    return (_pow2(C) and 8 <= C <= threads and _pow2(hidden) and 4 <= hidden <= 4 * threads and 1 <= chunks <= 4 * threads
-            and not (GCA_FINAL_SPLIT and gca_final_is_wide(C, hidden)))
 
 
 def gca_final_is_wide(C: int, hidden: int) -> bool:
@@ -840,11 +814,11 @@ def gca_final_is_wide(C: int, hidden: int) -> bool:
 
 
 def gca(plan: Plan, h: Act, wk, bk: float, w1t, b1, w2t, b2, part: torch.Tensor, gate: torch.Tensor, chunks: int, label: str = "",
-        final: bool = True, ticket: bool = False) -> bool:
+        final: bool = True) -> bool:
     """GlobalContext gate of h.  w1t: [C, hidden] (net.0.weight transposed), w2t: [hidden, C] (net.2.weight transposed), fp32.
     One launch when the in-kernel finalisation applies (power-of-two C/8, scratch fits), else GCA_PARTIAL + GCA_FINAL.
     final=False: the caller finalises (GCA_TAIL merges `part` itself) — only the partial pass is emitted, unless one workgroup covers the
-    image and finalises in place, or (ticket=True) the last chunk's workgroup may.  Returns True when `gate` has been written by the ops emitted here."""
+    image and finalises in place.  Returns True when `gate` has been written by the ops emitted here."""
     C = h.C
     hidden = w1t.shape[1]
     assert tuple(w1t.shape) == (C, w2t.shape[0]) and w2t.shape[1] == C
@@ -856,18 +830,11 @@ def gca(plan: Plan, h: Act, wk, bk: float, w1t, b1, w2t, b2, part: torch.Tensor,
               and C + hidden + chunks + GCA_SCRATCH <= 2048
               and not (GCA_FINAL_SPLIT and gca_final_is_wide(C, hidden)))   # (a wide block's MLP: many workgroups, GCA_FINAL phases 1 / 2)
     keep = [h.t, wk, part]
-    # several chunks per image: the workgroup that writes the image's last row finalises (ticket), where the online kernel and its scratch apply
-    ticketed = (not single and (final or ticket) and GCA_EPILOGUE_FINAL and (groups & (groups - 1)) == 0 and groups <= 64
-                and gca_epilogue_final_ok(256, C, hidden, chunks) and 4 * 256 + 2 * C + 2 * hidden + chunks + 64 <= 4096)
-    if single or ticketed:
+    if single:
         p.w1t, p.b1, p.w2t, p.b2, p.gate, p.hidden = w1t.data_ptr(), b1.data_ptr(), w2t.data_ptr(), b2.data_ptr(), gate.data_ptr(), hidden
         keep += [w1t, b1, w2t, b2, gate]
-    if ticketed:
-        ticket = torch.zeros(h.B, dtype=torch.int32, device=gate.device)
-        p.ticket = ticket.data_ptr()
-        keep.append(ticket)
-    plan.add(p, (label or "gca") + (".fused" if single else ".partial+final" if ticketed else ".partial"), keep)
-    if single or ticketed:
+    plan.add(p, (label or "gca") + (".fused" if single else ".partial"), keep)
+    if single:
         return True
     if not final:
         return False

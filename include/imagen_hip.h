@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define IMAGEN_ABI_VERSION 10 /* 10: the GlobalContext finalisation inside the launch that emits the partial rows (ImagenIgemmParams.gca_gate .. gca_ticket, ImagenGcaPartialParams.ticket);  9: LINEAR_F32, SCALE_SHIFT ss_f32;  8: ROWCHAIN, the latency probes;  3: head_dim in the attention / QNORM / KV_PREP params; 4: DDPM_UPDATE x0_thr; 5: GCA_TAIL; 6: ACT_PREP self_stat, STEP_SLICE;
+#define IMAGEN_ABI_VERSION 9 /* 9: LINEAR_F32, SCALE_SHIFT ss_f32;  8: ROWCHAIN, the latency probes;  3: head_dim in the attention / QNORM / KV_PREP params; 4: DDPM_UPDATE x0_thr; 5: GCA_TAIL; 6: ACT_PREP self_stat, STEP_SLICE;
                                * 7: every launch carries sizeof(its params struct) (a stale mirror of a struct fails loudly), ImagenIgemmParams.dbg -> launcher_word, kernel families 6 and 7, ImagenAttentionParams.softmax_mode */
 
 typedef void* imagen_stream_t; /* hipStream_t */
@@ -114,11 +114,6 @@ typedef struct ImagenIgemmParams {
    * pixels to gca_part[b][tile][Cout + 2] (tile = ty * tilesX + tx): exactly the rows GCA_PARTIAL produces with chunks = tiles per
    * image, ready for GCA_FINAL — the separate pass over the tensor disappears. */
   const float* gca_wk; float* gca_part;
-  /* optional GlobalContext finalisation inside this launch (with gca_part; kernel families 2, 5, 7 and 8): the workgroup that writes the LAST partial
-   * row of image b — found by a ticket on gca_ticket[b], a zeroed uint32 per image that the launch leaves zeroed again — merges the image's rows and
-   * writes gca_gate[b, :Cout] = sigmoid(W2 silu(W1 ctx + b1) + b2) exactly as GCA_FINAL would (ip.py:965-970; gca_w1t: [Cout][gca_hidden] = net.0.weight
-   * transposed, gca_w2t: [gca_hidden][Cout]): no GCA_FINAL launch follows.  Cout and gca_hidden powers of two, 8 <= Cout <= threads of the workgroup. */
-  const float* gca_w1t; const float* gca_b1; const float* gca_w2t; const float* gca_b2; float* gca_gate; uint32_t* gca_ticket;
   int32_t B, H, W;     /* input batch / spatial dims */
   int32_t C1, ld1, bs1; /* channels, pixel stride, batch stride (elements) of x1 */
   int32_t C2, ld2, bs2;
@@ -138,7 +133,6 @@ typedef struct ImagenIgemmParams {
   int32_t launcher_word; /* pass 0: private to the launcher (it stores the kernel's code size here for the in-kernel instruction warm-up) */
   float ssq_wb;        /* weight of ssq_b (skip_connect_scale^2 for the concatenated skip tensor) */
   float gca_bk;        /* bias of the GlobalContext logit (to_k.bias) */
-  int32_t gca_hidden;  /* width of the squeeze MLP (with gca_gate) */
 } ImagenIgemmParams;
 
 /* ACT_PREP — the IGEMM prologue (Block: ChanRMSNorm -> scale/shift -> SiLU, ip.py:683-690) materialised once:
@@ -248,9 +242,6 @@ typedef struct ImagenGcaPartialParams {
   /* optional in-kernel finalisation (replaces the GCA_FINAL launch) when ONE chunk covers the image (small feature maps): the
    * workgroup of image b pools into LDS, runs the squeeze MLP and writes gate[b][C] */
   const float* w1t; const float* b1; const float* w2t; const float* b2; float* gate;
-  /* ... or, with several chunks per image, by the workgroup that writes the image's LAST chunk row: ticket[b] (a zeroed uint32 per image, left zeroed)
-   * counts the rows; that workgroup merges them and runs the squeeze MLP (GCA_FINAL's contract), so no GCA_FINAL launch follows.  NULL: partials only. */
-  uint32_t* ticket;
   int32_t B, HW, C, ld, chunks, hidden; float bk;
 } ImagenGcaPartialParams;
 typedef struct ImagenGcaFinalParams {

@@ -195,11 +195,6 @@ class Interpreter:
                         part[:, iy * tx + ix, 0] = mx
                         part[:, iy * tx + ix, 1] = e.sum(1)
                         part[:, iy * tx + ix, 2:] = torch.einsum("bp,bpc->bc", e, t)
-                if p.gca_gate:   # the image's last tile finalises the gate (GCA_FINAL's contract; the ticket words stay zero)
-                    w = torch.exp(part[:, :, 0] - part[:, :, 0].max(dim=1, keepdim=True).values)
-                    ctx = torch.einsum("bk,bkc->bc", w, part[:, :, 2:]) / (w * part[:, :, 1]).sum(1, keepdim=True)
-                    m.view(p.gca_gate, f32)[:B * Co].copy_(self._gca_gate(ctx, p.gca_w1t, p.gca_b1, p.gca_w2t, p.gca_b2, Co, p.gca_hidden).reshape(-1))
-                    assert int(m.view(p.gca_ticket, torch.int32)[:B].abs().sum()) == 0, "gca_ticket must be zero between launches"
 
     # ------------------------------------------------------------------------------------------------ statistics / glue
     def _rows(self, addr, rows, rpb, C, ld, bs):

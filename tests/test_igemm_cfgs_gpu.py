@@ -275,41 +275,6 @@ def test_conv_gemm_family(ops, dev):
         assert tab[r["cfg"][0]][3] != 7 and r["err"] < TOL, r
 
 
-def test_gca_gate_finalised_by_the_last_tile(ops, dev):
-    """Round 6 (ImagenIgemmParams.gca_gate, csrc/gca_device.h): the workgroup that writes an image's LAST GlobalContext partial row — found by a ticket —
-    merges the rows and runs the squeeze MLP, in every family that emits the rows (2 all-DMA, 5 big tile incl. the K-split configuration whose epilogue
-    runs on half the workgroup, 7 tiled GEMM, 8 small maps with 64 .. 256 live threads): gate vs fp32 torch, many tiles per image and one, ragged maps,
-    three images, and the launch repeated (a graph replay: the tickets are back at zero)."""
-    tab = ops.cfg_table()
-    raw = dict(prologue="none", act_in="none", gca="final")
-    fam2 = [i for i, c in enumerate(tab) if c[3] == 2]
-    fam5 = [i for i, c in enumerate(tab) if c[3] == 5]
-    fam8 = {tab[i][1]: i for i in range(len(tab)) if tab[i][3] == 8}
-    cases = []
-    for i in fam2:
-        tp, bn = tab[i][0], tab[i][1]
-        if (tp, bn) in ((64, 128), (256, 64), (128, 32), (64, 256)):
-            H, W = (40, 36) if tp >= 128 else (20, 24)
-            (th, tw), = _shapes(ops, i, 3, 1, H, W)
-            cases.append(dict(raw, B=3, H=H, W=W, C1=64, Cout=bn, K=3, G=4, cfg=(i, th, tw)))
-    for i in fam5:
-        (th, tw), = _shapes(ops, i, 3, 1, 40, 36)
-        cases.append(dict(raw, B=2, H=40, W=36, C1=96, Cout=128, K=3, G=4, cfg=(i, th, tw)))
-    if fam5:
-        (th, tw), = _shapes(ops, fam5[-1], 3, 1, 8, 16)
-        cases.append(dict(raw, B=3, H=8, W=16, C1=128, Cout=128, K=3, G=4, cfg=(fam5[-1], th, tw)))          # one tile per image: the only row is the last
-    if ops.gemm_cfg() is not None:
-        cases.append(dict(raw, B=2, H=16, W=16, C1=128, Cout=128, K=1, cfg=(ops.gemm_cfg(), 8, 16)))
-    if fam8:
-        cases += [dict(raw, B=2, H=8, W=8, C1=128, Cout=128, K=3, G=4, cfg=(fam8[128], 4, 8), ssq_out=True),
-                  dict(raw, B=3, H=16, W=16, C1=64, Cout=64, K=3, G=4, cfg=(fam8[64], 2, 16)),
-                  dict(raw, B=2, H=8, W=16, C1=32, Cout=32, K=3, G=4, cfg=(fam8[32], 2, 16))]
-    assert len(cases) >= 8 or EMULATED
-    for kw in cases:
-        r = run_case(ops, dev, **kw)
-        assert r["err"] < TOL and r["err_gca"] < 2e-3 and r["err_gate"] < 1e-3, (kw, r)
-
-
 def test_conv_small_family(ops, dev):
     """The small-map 3x3 family (csrc/conv_small.hip): 32-pixel tiles as 4 x 8 / 2 x 16 / 1 x 32, the K loop split over the 8 / 4 / 2 waves of a
     cout fragment (even and uneven splits: 2, 3, 8, 12 and 16 channel chunks), every prologue (none, per-pixel scale, ssq statistics over a

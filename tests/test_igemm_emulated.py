@@ -43,9 +43,6 @@ def test_emulated_igemm_matches_contract(tmp_path):
             assert r["err_ssq"] < 2e-3, (name, r["err_ssq"])
         if "err_gca" in r:
             assert r["err_gca"] < 2e-3, (name, r["err_gca"])
-        if "err_gate" in r:    # round 6: the gate finalised by the image's last tile (twice: the tickets return to zero)
-            assert r["err_gate"] < 1e-3, (name, r["err_gate"])
-    assert sum("err_gate" in r for r in product.values()) >= 3
 
 
 @pytest.mark.skipif(not os.path.exists(CLANG), reason="host clang of the ROCm toolchain not present")

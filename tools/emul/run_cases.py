@@ -47,9 +47,6 @@ CASES = {
     "dma_256x32_ssq": dict(B=1, H=20, W=36, C1=32, Cout=32, K=3, G=4, cfg="dma:256x32", prologue="none", act_in="none", ssq_out=True),
     # the big-tile all-DMA family (conv_big.hip): cfg = "big:<n>" = the n-th configuration of family 5 (0: 256 px, 1: 128 px with the K split,
     # 2: ... three halo buffers, 3: 256 px with a 3-stage ring); several tiles per image and partial tiles, 4 / 6 / 3 chunks, 256 couts = two tile columns
-    "dma_64x128_gca_final": dict(B=3, H=16, W=24, C1=64, Cout=128, K=3, G=4, cfg="dma:64x128", prologue="none", act_in="none", gca="final"),   # round 6: the image's last tile finalises the gate
-    "big0_gca_final": dict(B=2, H=32, W=16, C1=128, Cout=128, K=3, G=4, cfg="big:0", prologue="none", act_in="none", gca="final"),
-    "big2_gca_final": dict(B=2, H=16, W=32, C1=128, Cout=128, K=3, G=4, cfg="big:2", prologue="none", act_in="none", gca="final"),
     "big0_gca": dict(B=2, H=32, W=16, C1=128, Cout=128, K=3, G=4, cfg="big:0", prologue="none", act_in="none", gca=True),
     "big0_post_ragged": dict(B=1, H=20, W=36, C1=96, Cout=128, K=3, G=4, cfg="big:0", prologue="none", act_in="none", epilogue="post"),
     "big1_ssq": dict(B=2, H=16, W=16, C1=128, Cout=128, K=3, G=4, cfg="big:1", prologue="none", act_in="none", ssq_out=True),
