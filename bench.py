@@ -173,10 +173,42 @@ def calibration_leg(device):
         lat[name] = round(v.value, 1)
         del chain
     out["dependent_load_ns"] = lat
+    # ... and the same HBM chase while a copy kernel on a second stream keeps every memory channel busy (round 6): the idle chase reads the same on
+    # boxes whose sampling step differs by 14 % — what the denoiser's dependent round trips pay is the LOADED latency
+    try:
+        import threading
+        nbytes, hops = 2 << 30, 6000
+        nodes = nbytes // 128
+        perm = torch.randperm(nodes, device=device, generator=torch.Generator(device=device).manual_seed(11))
+        chain = torch.zeros(nodes, 32, dtype=torch.int32, device=device)
+        chain[perm, 0] = perm.roll(-1).to(torch.int32)
+        del perm
+        src = torch.empty(n, dtype=torch.uint8, device=device).fill_(1)
+        dst = torch.empty(n, dtype=torch.uint8, device=device)
+        side = torch.cuda.Stream(device=device)
+        torch.cuda.synchronize()
+        v2, rc = ctypes.c_float(), []
+        th = threading.Thread(target=lambda: rc.append(lib.imagen_probe_copy(dst.data_ptr(), src.data_ptr(), n, 120, side.cuda_stream, ctypes.byref(v2))))
+        th.start()
+        time.sleep(0.003)                                    # (the copy launches are queued by now: ~50 ms of saturated HBM)
+        _abi.check(lib.imagen_probe_latency(chain.data_ptr(), hops, word.data_ptr(), h, ctypes.byref(v)), "probe_latency (loaded)")
+        th.join()
+        torch.cuda.synchronize()
+        out["dependent_load_ns_under_copy"] = {"hbm_2GiB": round(v.value, 1), "copy_GBs_meanwhile": round(v2.value, 1)}
+        del chain, src, dst
+    except Exception as e:  # noqa: BLE001 — a probe must never cost the line
+        out["dependent_load_ns_under_copy"] = {"error": f"{type(e).__name__}: {e}"}
     _abi.check(lib.imagen_probe_launch_chain(300, 20, word.data_ptr(), h, ctypes.byref(v)), "probe_launch_chain")
     out["graph_dependent_launch_us"] = round(v.value, 3)
     out.update(smi_sample(("sclk", "mclk")))
     return out
+
+
+def _mhz(text):
+    """'1200Mhz' -> 1200.0 (None if unreadable)."""
+    import re
+    m = re.search(r"([0-9.]+)\s*mhz", str(text or ""), flags=re.I)
+    return float(m.group(1)) if m else None
 
 
 def smi_sample(clocks=("sclk", "mclk", "fclk", "socclk"), extra=False):
@@ -637,6 +669,11 @@ def main():
                                  "note": "one sample() call at a time (no overlap between batches; round-over-round comparisons use THIS "
                                          "figure): the median of three passes after the timed region",
                                  "rocm_smi_under_load": dict(under_load)}
+            # the one reading that has ordered the pool's boxes so far (socclk 1200 MHz under load on the fast kind, ~130 MHz on the slow one):
+            # the sequential figure is quoted WITH it, so that two rounds' lines are compared at equal box class
+            mhz = _mhz(under_load.get("socclk"))
+            rec["sequential"]["value_at_socclk"] = {"socclk_mhz_under_load": mhz, "value": rec["sequential"]["value"],
+                                                    "box_class": None if mhz is None else ("fast" if mhz >= 600 else "slow")}
             try:
                 rec["sequential"]["in_graph_step_ms"] = stage_replay_leg(imagen)
             except Exception as e:  # noqa: BLE001
@@ -645,6 +682,9 @@ def main():
         if world == 1:
             try:
                 rec["calibration"] = calibration_leg(device)
+                ul = (rec.get("sequential") or {}).get("rocm_smi_under_load") or {}
+                rec["calibration"]["under_load"] = {"socclk_mhz": _mhz(ul.get("socclk")), "sclk_mhz": _mhz(ul.get("sclk")), "fclk_mhz": _mhz(ul.get("fclk")),
+                                                    "power": next((v for k, v in ul.items() if "power" in k.lower()), None)}
                 log("calibration probes done")
             except Exception as e:  # noqa: BLE001
                 rec["calibration"] = None
