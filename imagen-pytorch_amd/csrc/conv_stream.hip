@@ -239,7 +239,7 @@ __global__ __launch_bounds__(64 * CS_NW, NCH == 1 ? 4 : 2) void conv_stream_kern
   // store instructions of the plain / post epilogue of conv_epilogue.h per wave (a lower bound is what the wait needs): one 16-byte piece
   // per pair of channel quads when Cout is a multiple of 8, else one 8-byte store per quad below Cout
   const int quads = GEN ? 0 : ((p.Cout & 7) == 0 ? 1 + (p.Cout > 8 ? 1 : 0) : min((p.Cout + 7) >> 3, 4));
-  const bool lean_ok = !GEN && p.Cout == 32 && !p.gca_part;   // the lean epilogue writes all four channel quads (GlobalContext partials: conv_epilogue.h)
+  const bool lean_ok = !GEN && p.Cout == 32;   // the lean epilogue writes all four channel quads
 
   while (true) {
     float sa_c[CS_NJ], sb_c[CS_NJ];
@@ -443,8 +443,7 @@ int launch_conv_stream(const ImagenIgemmParams* pp, int idx, hipStream_t s) {
   IMAGEN_CHECK(!p.post_pa || (p.post_ps && p.out_mode == IMAGEN_OUT_NHWC && !p.addend && !p.res && !p.ssq_out && p.act_out == IMAGEN_ACT_NONE && p.Cout % 4 == 0),
                "conv_stream: post_pa needs post_ps and a plain NHWC output");
   IMAGEN_CHECK(!(p.addend && p.res), "conv_stream: addend and residual are mutually exclusive");
-  IMAGEN_CHECK(!p.gca_part || (p.gca_wk && !p.post_pa && p.out_mode == IMAGEN_OUT_NHWC && !p.addend && !p.res && p.act_out == IMAGEN_ACT_NONE),
-               "conv_stream: gca_part needs gca_wk and a plain NHWC output");
+  IMAGEN_CHECK(!p.gca_part, "conv_stream: no GlobalContext partials from this family (its eight-wave epilogue with three barriers per tile cost more than the pass it replaced: round 4, call F) — families 2, 5, 7, 8 emit them");
   IMAGEN_CHECK(!p.ssq_out || p.out_mode == IMAGEN_OUT_NHWC, "conv_stream: ssq_out needs NHWC output");
   const bool plain = p.act_out == IMAGEN_ACT_NONE && p.out_mode == IMAGEN_OUT_NHWC && !p.addend && !p.res;
   const int key = (p.C2 ? 4 : 0) | (pro ? 2 : 0) | (plain ? 0 : 1);

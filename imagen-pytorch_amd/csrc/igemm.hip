@@ -1063,7 +1063,7 @@ int launch_igemm(const ImagenIgemmParams* pp, hipStream_t s) {
   IMAGEN_CHECK(p.x1 && p.w && p.y, "igemm: null x1/w/y");
   IMAGEN_CHECK(!p.addend || p.gate, "igemm: addend requires gate");
   IMAGEN_CHECK(p.cfg >= kNumCfgs || (p.TW > 0 && (p.TW & (p.TW - 1)) == 0), "igemm: tile width %d is not a power of two", p.TW);
-  IMAGEN_CHECK(!p.gca_part || p.cfg >= kNumCfgs, "igemm: gca_part is implemented by the kernel families 2, 3, 5, 7 and 8 only (cfg %d)", p.cfg);
+  IMAGEN_CHECK(!p.gca_part || p.cfg >= kNumCfgs, "igemm: gca_part is implemented by the kernel families 2, 5, 7 and 8 only (cfg %d)", p.cfg);
   if (p.cfg >= cfg_base_small()) return launch_conv_small(pp, p.cfg - cfg_base_small(), s);
   if (p.cfg >= cfg_base_gemm()) return launch_conv_gemm(pp, p.cfg - cfg_base_gemm(), s);
   if (p.cfg >= cfg_base_pro()) return launch_conv_pro(pp, p.cfg - cfg_base_pro(), s);

@@ -286,7 +286,6 @@ def launchable_shapes(cfg: int, OH: int, OW: int, KH: int, KW: int, stride: int)
 GCA_EPILOGUE_MAX_TILES = 1024
 CONV_DMA = 1       # (module constant since round 5; tests monkeypatch it) the all-DMA kernel family for prologue-free single-input 3x3 convs
 CONV_STREAM = 1    # (module constant) the streaming kernel family (conv_stream.hip) for the 32-channel 3x3 convs
-STREAM_GCA = 0     # (module constant: measured slower in round 4, call F; the epilogue path is the shared conv_epilogue.h code, tested by monkeypatching) the streaming family emits the GlobalContext partials of its output too (0: a GCA_PARTIAL pass / family 2)
 STREAM_MIN_TILES = 512   # ... of launches with at least this many 16x16 tiles (persistent workgroups need a few tiles each)
 
 
@@ -560,7 +559,7 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
         no_pro = mu is None and rs is None and pa is None and ps is None and ssq_a is None and act_in == ACT_NONE
         ssq_pro = mu is None and rs is None and pa is not None and ssq_a is not None and act_in in (ACT_NONE, ACT_SILU)
         tiles16 = x1.B * math.ceil(OH / 16) * math.ceil(OW / 16)
-        gca_here = want_gca and tiles16 <= GCA_EPILOGUE_MAX_TILES and not STREAM_GCA   # (STREAM_GCA = 0: the other families emit the GlobalContext partials of such layers)
+        gca_here = want_gca and tiles16 <= GCA_EPILOGUE_MAX_TILES   # (a layer whose epilogue emits the GlobalContext partials goes to family 2: the persistent streaming kernel measured slower with them, round 4 call F)
         if (pw.Cout <= 32 and x1.C == 32 and C2 in (0, 32) and pw.Cin_pad == x1.C + C2 and x1.ld % 8 == 0 and (x2 is None or x2.ld % 8 == 0)
                 and (no_pro or ssq_pro) and not gca_here and tiles16 >= STREAM_MIN_TILES
                 and stream_cfg() is not None):
@@ -657,8 +656,7 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
     p.gca_part_t, p.gca_chunks = None, 0
     chunks = math.ceil(OH / th) * math.ceil(OW / tw)
     fam = cfg_table()[cid][3]
-    if want_gca and pw.Cout <= cfg_table()[cid][1] and ((fam in (2, 5, 7, 8) and x1.B * chunks <= GCA_EPILOGUE_MAX_TILES)
-                                                        or (fam == 3 and STREAM_GCA and chunks <= 1024)):   # (GCA_FINAL / GCA_TAIL merge up to 1024 chunks per image)
+    if want_gca and pw.Cout <= cfg_table()[cid][1] and fam in (2, 5, 7, 8) and x1.B * chunks <= GCA_EPILOGUE_MAX_TILES:
         part = torch.empty(x1.B, chunks, pw.Cout + 2, dtype=torch.float32, device=x1.t.device)
         p.gca_wk, p.gca_part, p.gca_bk = gca["wk"].data_ptr(), part.data_ptr(), gca["bk"]
         keep += [gca["wk"], part]

@@ -109,7 +109,7 @@ typedef struct ImagenIgemmParams {
    * pixel (ChanRMSNorm -> scale/shift -> SiLU of the NEXT Block, ip.py:671-691, applied by the producer so that the consuming
    * conv stages its input with no arithmetic at all) */
   const float* post_pa; const float* post_ps;
-  /* optional GlobalContext partials of the OUTPUT (plain NHWC mode, Cout <= tile couts, the kernel families 2, 3, 5, 7 and 8): with
+  /* optional GlobalContext partials of the OUTPUT (plain NHWC mode, Cout <= tile couts, the kernel families 2, 5, 7 and 8): with
    * logit[q] = y[q, :] . gca_wk + gca_bk (ip.py:965-966), every output tile writes (max logit, sum exp, sum exp * y[q, c]) over its
    * pixels to gca_part[b][tile][Cout + 2] (tile = ty * tilesX + tx): exactly the rows GCA_PARTIAL produces with chunks = tiles per
    * image, ready for GCA_FINAL — the separate pass over the tensor disappears. */
