@@ -595,18 +595,9 @@ __global__ __launch_bounds__(256) void gca_final_split_kernel(const ImagenGcaFin
 // ------------------------------------------------------------------------------------------------ gca_tail
 // The tail of an identity ResnetBlock in one launch (ImagenGcaTailParams): workgroup (slab, b) finalises the GlobalContext gate of image b
 // in LDS, then streams its slab of rows: out = h * gate + res (+ per-row statistics, + the next Block's activated input).  One lane = 8
-// channels of a row; a row = C / 8 consecutive lanes (a power of two <= 64: the reductions are shuffles inside the wave).  The rows of the
-// first `pf` passes (h and res: one 16-byte piece per thread, pass and tensor) are requested as direct-to-LDS copies BEFORE the finalisation
-// (round 6): the gate takes ~7 us to derive (one global round trip + eight workgroup barriers: 18.8 us per tail at 64^2 against 11.3 with a
-// ready gate, call B), and on the <= 64^2 maps a workgroup's whole slab is one to four passes — its reads now ride under that time instead of
-// starting behind it.  The copies cost no registers (the kernel sits at its 128-VGPR cap); each thread reads back its own pieces.
-#ifndef IMAGEN_TAIL_PF_MAX
-#define IMAGEN_TAIL_PF_MAX 3                    // (build knob of the A/B library: 1 = only the first pass ahead of the gate, as rounds 3-5 had it)
-#endif
-constexpr int kTailPfMax = IMAGEN_TAIL_PF_MAX;  // passes staged in LDS (2 x 16 KB each)
-constexpr int kTailPfBytes = 2 * kGcaFastThreads * 16;
-__global__ __launch_bounds__(kGcaFastThreads) void gca_tail_kernel(const ImagenGcaTailParams p, int pf) {
-  extern __shared__ __attribute__((aligned(16))) char smem[];   // pf x [h rows | res rows], lane-linear (16 bytes per thread)
+// channels of a row; a row = C / 8 consecutive lanes (a power of two <= 64: the reductions are shuffles inside the wave).  The first
+// pass's loads are issued BEFORE the finalisation — its ~5 dependent round trips then overlap the first rows' HBM latency.
+__global__ __launch_bounds__(kGcaFastThreads) void gca_tail_kernel(const ImagenGcaTailParams p) {
   __shared__ float s_gate[1024];
   const int t = threadIdx.x, b = blockIdx.y;
   const int C = p.C, lpr = C >> 3;                         // lanes per row
@@ -619,16 +610,10 @@ __global__ __launch_bounds__(kGcaFastThreads) void gca_tail_kernel(const ImagenG
   f16* ob = reinterpret_cast<f16*>(p.out) + (size_t)b * p.HW * p.ld_out + g * 8;
   f16* ab = p.act_out ? reinterpret_cast<f16*>(p.act_out) + (size_t)b * p.HW * p.ld_act + g * 8 : nullptr;
   int r = r_begin + sub;
-  {
-    const unsigned lds_w = IMAGEN_LDS_BASE(smem) + (unsigned)__builtin_amdgcn_readfirstlane(t >> 6) * 1024u;
-#pragma unroll
-    for (int q = 0; q < kTailPfMax; ++q) {
-      const int rq = r + q * rpp;
-      if (q < pf && rq < r_end) {
-        IMAGEN_DMA16(hb + (size_t)rq * p.ld_h, lds_w + (unsigned)(q * kTailPfBytes));
-        IMAGEN_DMA16(rb + (size_t)rq * p.ld_res, lds_w + (unsigned)(q * kTailPfBytes + kTailPfBytes / 2));
-      }
-    }
+  f16x8 hv = {}, rv = {};
+  if (r < r_end) {
+    hv = *reinterpret_cast<const f16x8*>(hb + (size_t)r * p.ld_h);
+    rv = *reinterpret_cast<const f16x8*>(rb + (size_t)r * p.ld_res);
   }
   // ---- the gate of image b -> LDS
   if (p.part) {
@@ -646,25 +631,12 @@ __global__ __launch_bounds__(kGcaFastThreads) void gca_tail_kernel(const ImagenG
   const float gt[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
   const float pa[8] = {pa0.x, pa0.y, pa0.z, pa0.w, pa1.x, pa1.y, pa1.z, pa1.w};
   const float inv_c = 1.0f / (float)C;
-  IMAGEN_WAIT_VM(0);    // this wave's staged pieces have landed (nobody else reads them; the finalisation's own waits usually covered it)
-  f16x8 hv = {}, rv = {};
-  if (r < r_end) {
-    hv = *reinterpret_cast<const f16x8*>(smem + t * 16);
-    rv = *reinterpret_cast<const f16x8*>(smem + kTailPfBytes / 2 + t * 16);
-  }
-  int q = 0;
   while (r < r_end) {   // (rows are dealt to whole lane groups: the loop condition is uniform inside a group)
     const int rn = r + rpp;
-    ++q;
     f16x8 hn = {}, rnx = {};
-    if (rn < r_end) {   // next pass: staged in LDS, or in flight while this one is reduced and stored
-      if (q < pf) {
-        hn = *reinterpret_cast<const f16x8*>(smem + q * kTailPfBytes + t * 16);
-        rnx = *reinterpret_cast<const f16x8*>(smem + q * kTailPfBytes + kTailPfBytes / 2 + t * 16);
-      } else {
-        hn = *reinterpret_cast<const f16x8*>(hb + (size_t)rn * p.ld_h);
-        rnx = *reinterpret_cast<const f16x8*>(rb + (size_t)rn * p.ld_res);
-      }
+    if (rn < r_end) {   // next pass in flight while this one is reduced and stored
+      hn = *reinterpret_cast<const f16x8*>(hb + (size_t)rn * p.ld_h);
+      rnx = *reinterpret_cast<const f16x8*>(rb + (size_t)rn * p.ld_res);
     }
     f16x8 o;
     float vr[8], ssq = 0.f, sum = 0.f;
@@ -1079,20 +1051,7 @@ int launch_gca_tail(const ImagenGcaTailParams* p, hipStream_t s) {
                "gca_tail: row strides must be multiples of 8 (act_out needs act_pa)");
   IMAGEN_CHECK(!p->mu_out == !p->rs_out, "gca_tail: mu_out and rs_out come together");
   IMAGEN_CHECK(p->slabs >= 1 && p->slabs <= 65535, "gca_tail: slabs %d", p->slabs);
-  // passes of a workgroup's slab that are staged in LDS ahead of the gate derivation (>= 1: the first pass always is)
-  const int lpr = p->C >> 3, rpp = kGcaFastThreads / lpr;
-  const int per = (p->HW + p->slabs - 1) / p->slabs;
-  int pf = (per + rpp - 1) / rpp;
-  pf = pf < 1 ? 1 : (pf > kTailPfMax ? kTailPfMax : pf);
-  static bool attr_done[16] = {};
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  if (dev < 0 || dev >= 16 || !attr_done[dev]) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gca_tail_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, kTailPfMax * kTailPfBytes);
-    if (e != hipSuccess) { imagen_set_error("gca_tail: hipFuncSetAttribute: %s", hipGetErrorString(e)); return (int)e; }
-    if (dev >= 0 && dev < 16) attr_done[dev] = true;
-  }
-  hipLaunchKernelGGL(gca_tail_kernel, dim3(p->slabs, p->B), dim3(kGcaFastThreads), (size_t)pf * kTailPfBytes, s, *p, pf);
+  hipLaunchKernelGGL(gca_tail_kernel, dim3(p->slabs, p->B), dim3(kGcaFastThreads), 0, s, *p);
   return imagen_hip_status("gca_tail");
 }
 

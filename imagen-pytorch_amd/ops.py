@@ -335,8 +335,9 @@ def pw_cfg(kchunks: int, Cout: int) -> Optional[int]:
 
 CONV_SMALL = int(_os.environ.get("IMAGEN_CONV_SMALL", "2"))   # A/B switch: conv_small.hip (family 8) for the 3x3 convs of the small maps (2: their 1x1 res_conv / upsample GEMMs too)
 SMALL_MAX_ROWS = 4096   # ... of at most this many output pixels per launch (16 images of 8^2 / 16^2; call H: with the 32^2 maps, 16384, unet2 loses 1.3 ms per step)
-SMALL_MAX_STREAM_MB = 128   # ... whose pixel tiles together stream at most this much weight data out of L2 (every 32-pixel tile reads all of its slab: README unet1's
-                            # layers 38 - 57 MB; C2's 512 -> 512 @16^2 and 1024 -> 1024 @8^2 604 MB — 75 / 86 us against 33 / 48 on the wave-specialised kernel, call J)
+SMALL_MAX_STREAM_MB = 64    # ... whose pixel tiles together stream at most this much weight data out of L2 (every 32-pixel tile reads all of its slab: README unet1's
+                            # layers 38 - 57 MB; C2's 512 -> 512 @16^2 and 1024 -> 1024 @8^2 604 MB — 75 / 86 us against 33 / 48 on the wave-specialised kernel, round 5 call J;
+                            # C2's 1x1 res_conv / upsample GEMMs of 100 - 134 MB — 60 us each here: 5.36 -> 5.11 ms per C2 step with them back on families 0 / 7, round 6 call D)
 
 
 def small_cfg(Cout: int, full_cout: bool) -> Optional[int]:

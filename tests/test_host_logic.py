@@ -386,7 +386,7 @@ def test_family7_respects_the_launcher_k_limit():
 
 def test_family8_routing_rules():
     """The small-map 3x3 family (conv_small.hip) takes a launch only where it measured faster (round 5, calls H - L): at most 4096 output pixels, at
-    most 128 MB of weight data streamed by the launch's pixel tiles together; the 32-cout tile unless the epilogue needs every channel of a pixel
+    most 64 MB of weight data streamed by the launch's pixel tiles together; the 32-cout tile unless the epilogue needs every channel of a pixel
     (then the narrowest tile over all couts, Cout <= 128).  Dry plans on CPU memory."""
     from imagen_pytorch_amd import ops
 
@@ -409,7 +409,8 @@ def test_family8_routing_rules():
     assert t == (32, 32, 4, 8) and not p.ssq_emitted
     assert pick(16, 32, 128, 128)[0][3] != 8                                                   # 16384 pixels: the 32^2 maps stay where they were
     assert pick(16, 16, 512, 512)[0][3] != 8 and pick(16, 8, 1024, 1024)[0][3] != 8            # C2's layers: 604 MB of weight stream
-    assert pick(4, 16, 512, 512)[0][3] != 8 and pick(2, 16, 512, 512)[0][3] == 8               # ... 151 MB at a quarter of the rows: still not; 75 MB at an eighth: taken
+    assert pick(4, 16, 512, 512)[0][3] != 8 and pick(2, 16, 512, 512)[0][3] != 8               # ... 151 MB at a quarter of the rows, 75 MB at an eighth: still not
+    assert pick(1, 16, 512, 512)[0][3] == 8                                                    # ... 38 MB: taken (the limit is 64 MB since round 6, call D: C2's 100 - 134 MB 1x1 GEMMs lost 2x on it)
 
 
 def test_time_chain_runs_in_fp32(monkeypatch):
