@@ -669,11 +669,10 @@ def main():
                                  "note": "one sample() call at a time (no overlap between batches; round-over-round comparisons use THIS "
                                          "figure): the median of three passes after the timed region",
                                  "rocm_smi_under_load": dict(under_load)}
-            # the one reading that has ordered the pool's boxes so far (socclk 1200 MHz under load on the fast kind, ~130 MHz on the slow one):
-            # the sequential figure is quoted WITH it, so that two rounds' lines are compared at equal box class
-            mhz = _mhz(under_load.get("socclk"))
-            rec["sequential"]["value_at_socclk"] = {"socclk_mhz_under_load": mhz, "value": rec["sequential"]["value"],
-                                                    "box_class": None if mhz is None else ("fast" if mhz >= 600 else "slow")}
+            # the readings a line is compared by (filled in once the calibration leg has run: rec["sequential"]["box"]).  Round 5 read socclk under load
+            # as the separator of the pool's two kinds of box (1200 vs ~130 MHz on one pair); round 6's pairs contradict it (1200 MHz: 7.57 ms per step
+            # pair, 107 MHz: 7.36 ms) — the MFMA loop figure (2044 vs 2176 TFLOP/s) and the chase under a copy (1272 vs 1248 ns) ordered THOSE two, so
+            # the line carries the raw readings and no class
             try:
                 rec["sequential"]["in_graph_step_ms"] = stage_replay_leg(imagen)
             except Exception as e:  # noqa: BLE001
@@ -685,6 +684,11 @@ def main():
                 ul = (rec.get("sequential") or {}).get("rocm_smi_under_load") or {}
                 rec["calibration"]["under_load"] = {"socclk_mhz": _mhz(ul.get("socclk")), "sclk_mhz": _mhz(ul.get("sclk")), "fclk_mhz": _mhz(ul.get("fclk")),
                                                     "power": next((v for k, v in ul.items() if "power" in k.lower()), None)}
+                if rec.get("sequential"):
+                    cal = rec["calibration"]
+                    rec["sequential"]["box"] = {"value": rec["sequential"]["value"], "mfma_f16_loop_TFLOPs": cal.get("mfma_f16_loop_TFLOPs"),
+                                                "hbm_chase_under_copy_ns": (cal.get("dependent_load_ns_under_copy") or {}).get("hbm_2GiB"),
+                                                "socclk_mhz_under_load": cal["under_load"]["socclk_mhz"], "power_under_load": cal["under_load"]["power"]}
                 log("calibration probes done")
             except Exception as e:  # noqa: BLE001
                 rec["calibration"] = None

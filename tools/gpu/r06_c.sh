@@ -17,7 +17,7 @@ timeout 900 python bench.py --steps 6 --warmup 6 --no-cpu-baseline --no-pmc > $O
 tail -n 4 $OUT/bench_n1.err; python - <<PY
 import json
 r = json.load(open("$OUT/bench_n1.json"))
-print({k: r[k] for k in ("value", "ms_per_step")}, r["sequential"]["value"], r["sequential"]["value_at_socclk"], r["sequential"].get("in_graph_step_ms"))
+print({k: r[k] for k in ("value", "ms_per_step")}, r["sequential"]["value"], r["sequential"].get("box"), r["sequential"].get("in_graph_step_ms"))
 print(r["calibration"])
 print(r["roofline"])
 PY
