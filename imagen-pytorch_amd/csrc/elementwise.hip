@@ -432,6 +432,17 @@ __global__ __launch_bounds__(256) void gca_final_kernel(const ImagenGcaFinalPara
 // gate depends on — their slice of both weight matrices (<= 8 float4 each), the chunk statistics and their partial rows — before
 // the first wait, and all arithmetic runs out of registers and LDS.  Needs power-of-two C and hidden (launcher-checked).
 constexpr int kGcaFastThreads = 1024;
+// -DGCA_TRACE (tools/gca_bench.py --trace, a throw-away variant library: never in the product build): thread 0 of every workgroup stamps s_memtime
+// at the phase boundaries of the gate derivation into a buffer handed over by imagen_debug_gca_trace()
+#ifdef GCA_TRACE
+__device__ unsigned long long* g_gca_trace = nullptr;
+#define GCA_STAMP(i)                                                                                                                              \
+  do {                                                                                                                                            \
+    if (threadIdx.x == 0 && g_gca_trace) g_gca_trace[((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 16 + (i)] = __builtin_amdgcn_s_memtime();    \
+  } while (0)
+#else
+#define GCA_STAMP(i) ((void)0)
+#endif
 constexpr int kGcaFastW = 8;    // prefetched float4 per thread and weight matrix (larger matrices: a second, loop-carried pass); the fused tail kernel takes 6
 constexpr int kGcaFastP = 8;    // prefetched partial-row elements per thread
 
@@ -454,6 +465,9 @@ __device__ __forceinline__ void gca_fast_matvec(const float4 (&w)[W], const floa
     const float x = in[row];
     a.x += q.x * x; a.y += q.y * x; a.z += q.z * x; a.w += q.w * x;
   }
+  // (round 6, calls F / G: one thread per output column adds up its rpp = 1024 / nvec partials in a serial walk over LDS — 3.5k of the 20k cycles of a
+  // derivation at C = 128, 9.3k at C = 32.  Per-wave shuffle sums + an unrolled 16-wave final sum cut the derivation by 15-25 % launched alone
+  // (profiles/r06_g_gca_phase_timeline.json) and the sampling step by nothing (7.749 / 7.732 vs 7.749 / 7.750 ms): not kept.)
   red[t] = a;
   __syncthreads();
   for (int o = t; o < n_out; o += kGcaFastThreads) {
@@ -487,6 +501,7 @@ __device__ __forceinline__ void gca_final_fast_body(const float* part_base, cons
   const int t = threadIdx.x, lane = t & 63, wave = t >> 6;
   const int stride = C + 2;
   const float* part = part_base + (size_t)b * chunks * stride;
+  GCA_STAMP(1);
   // ---- every global load the gate depends on, before the first wait — in the order of use (vmcnt retires in issue order)
   float2 ms = make_float2(-3.0e38f, 0.f);
   if (t < chunks) ms = *reinterpret_cast<const float2*>(part + (size_t)t * stride);
@@ -501,11 +516,13 @@ __device__ __forceinline__ void gca_final_fast_body(const float* part_base, cons
   float4 w1[W], w2[W];
   gca_fast_prefetch<W>(w1, w1t, C, hidden);
   gca_fast_prefetch<W>(w2, w2t, hidden, C);
+  GCA_STAMP(2);
   // ---- softmax merge weights of the chunks
   float m = ms.x;
   for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off));
   if (lane == 0) s_sc[wave] = m;
   __syncthreads();
+  GCA_STAMP(3);
   float M = s_sc[0];
 #pragma unroll
   for (int w = 1; w < kGcaFastThreads / 64; ++w) M = fmaxf(M, s_sc[w]);
@@ -519,6 +536,7 @@ __device__ __forceinline__ void gca_final_fast_body(const float* part_base, cons
 #pragma unroll
   for (int w = 0; w < kGcaFastThreads / 64; ++w) S += s_sc[16 + w];
   const float inv_S = 1.0f / S;
+  GCA_STAMP(4);
   s_b1[t] = bias1;   // (parked in LDS: the weight registers leave no room to carry them)
   s_b2[t] = bias2;
   // ---- ctx[c] = sum_i part[i][2 + c] * wgt[i] / S
@@ -538,16 +556,20 @@ __device__ __forceinline__ void gca_final_fast_body(const float* part_base, cons
     s_ctx[t] = v * inv_S;
   }
   __syncthreads();
+  GCA_STAMP(5);
   // ---- squeeze MLP out of the prefetched registers
   gca_fast_matvec<W>(w1, w1t, C, hidden, s_ctx, s_red, [&](int o, float v) __attribute__((always_inline)) { s_hid[o] = silu_f(v + s_b1[o]); });
+  GCA_STAMP(6);
   gca_fast_matvec<W>(w2, w2t, hidden, C, s_hid, s_red, [&](int o, float v) __attribute__((always_inline)) {
     const float g = sigmoid_f(v + s_b2[o]);
     gate_a[o] = g;
     if (gate_b) gate_b[o] = g;
   });
+  GCA_STAMP(7);
 }
 
 __global__ __launch_bounds__(kGcaFastThreads) void gca_final_fast_kernel(const ImagenGcaFinalParams p) {
+  GCA_STAMP(0);
   gca_final_fast_body<kGcaFastW>(p.part, p.w1t, p.b1, p.w2t, p.b2, blockIdx.x, p.C, p.hidden, p.chunks, p.gate + (size_t)blockIdx.x * p.C, nullptr);
 }
 
@@ -598,6 +620,7 @@ __global__ __launch_bounds__(256) void gca_final_split_kernel(const ImagenGcaFin
 // channels of a row; a row = C / 8 consecutive lanes (a power of two <= 64: the reductions are shuffles inside the wave).  The first
 // pass's loads are issued BEFORE the finalisation — its ~5 dependent round trips then overlap the first rows' HBM latency.
 __global__ __launch_bounds__(kGcaFastThreads) void gca_tail_kernel(const ImagenGcaTailParams p) {
+  GCA_STAMP(0);
   __shared__ float s_gate[1024];
   const int t = threadIdx.x, b = blockIdx.y;
   const int C = p.C, lpr = C >> 3;                         // lanes per row
@@ -675,6 +698,7 @@ __global__ __launch_bounds__(kGcaFastThreads) void gca_tail_kernel(const ImagenG
     rv = rnx;
     r = rn;
   }
+  GCA_STAMP(8);
 }
 
 // ------------------------------------------------------------------------------------------------ embeddings / affine
@@ -950,6 +974,10 @@ __global__ __launch_bounds__(256) void step_slice_kernel(const ImagenStepSlicePa
 }
 
 }  // namespace
+
+#ifdef GCA_TRACE
+extern "C" int imagen_debug_gca_trace(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_gca_trace), &buf, sizeof(buf)); }
+#endif
 
 int launch_step_slice(const ImagenStepSliceParams* p, hipStream_t s) {
   IMAGEN_CHECK(p->step_ptr && p->words0 > 0 && p->src0 && p->dst0, "step_slice: null step_ptr / first segment");
