@@ -118,6 +118,7 @@ LN_STATS_FUSED = 1   # (module constant; call B) LayerNorm statistics from the p
 #  * SPLIT_SMALL: block1 of the 32-channel ResnetBlocks and the final conv of stages whose launches are latency-bound (<= SPLIT_SMALL_FLOPS
 #    executed FLOPs): the layers next to the output, whose weight rounding reaches it unattenuated (0.99e-3 -> 0.94e-3).
 TIME_TABLE_MAX_BYTES = int(float(os.environ.get("IMAGEN_TIME_TABLE_MAX_GB", "4")) * (1 << 30))   # per stage and lane (enable_time_table)
+TIME_TABLE_CHUNK_BYTES = 256 << 20   # intermediates of the batched all-steps pass: it runs in chunks of steps that need at most this much
 SPLIT_STATIC = 1
 SPLIT_SMALL = 1
 SPLIT_SMALL_MAX_K = 320        # taps * input channels of the unsplit weight
@@ -1089,60 +1090,81 @@ class UnetEngine:
             return self.step_plan_tt
         rows_all = NR * R
         # footprint of the tables and of the batched pass's intermediates, per stage and lane (fp32 scale / shift rows, fp16 hiddens, time
-        # tokens and K / V projections): 1.1 GB for the README super-resolution unet at batch 8, 1000 steps.  Above the cap (large batches,
-        # long schedules, small-memory parts) the per-step chain stays: same results, nine small launches per step.
+        # tokens and K / V projections).  Above the cap (large batches, long schedules, small-memory parts) the per-step chain stays: same
+        # results, nine small launches per step.
         selfs_, crosses_, ws_, wc_ = self._ctx_weights()
         proj_c = (ws_.Cout if selfs_ else 0) + (wc_.Cout if crosses_ else 0)
         chain_bytes = (8 * self.Tc + 8 * self.total_c) if TIME_CHAIN_F32 else 2 * (3 * self.Tc + 2 * self.total_c)   # hid, t_const, t, ss rows (fp32 t / ss: LINEAR_F32)
-        tt_bytes = rows_all * (2 * 4 * self.total_c + chain_bytes + self.ntt * (2 * 2 * self.cond_dim + 2 * proj_c + 8))
+        # per row of the coefficient table: what STAYS for the life of the request (the four tables STEP_SLICE reads) and what the batched pass needs
+        # while it runs (hiddens, time tokens, the time MLPs' output — as large as both scale / shift tables together).  The pass runs in chunks of
+        # steps over ONE set of intermediates sized for a chunk (round 6, 1000 steps x 16 rows: BASELINE C2 3.98 -> 2.42 GiB per stage and lane in 8 chunks, README unet2 1.88 -> 1.24 in 4, unet1 1.44 -> 1.20 in 2)
+        table_row = 2 * 4 * self.total_c + self.ntt * 2 * proj_c
+        work_row = chain_bytes + self.ntt * (2 * 2 * self.cond_dim + 8)
+        nchunks = max(1, min(NR, -(-rows_all * work_row // TIME_TABLE_CHUNK_BYTES)))
+        steps_c = -(-NR // nchunks)                 # steps per chunk
+        nchunks = -(-NR // steps_c)
+        nmax = steps_c * R
+        tt_bytes = rows_all * table_row + nmax * work_row
         self.time_table_bytes = tt_bytes
+        self.time_table_layout = dict(chunks=nchunks, steps_per_chunk=steps_c, work_bytes_unchunked=rows_all * work_row, table_bytes=rows_all * table_row)
         if tt_bytes > TIME_TABLE_MAX_BYTES:
             return None
         tt = Plan("unet-time-table")
         times_all = coef[:, 6].to(self.dev).float().repeat_interleave(R).contiguous()       # the log-SNR every step's time_embed reads
-        tc_all = self.new(1, 1, rows_all, self.Tc)
-        ops.rows_copy(tt, self.t_const.t, tc_all.t, B=NR, rows=R, C=self.Tc, src_bs=0, src_rs=self.Tc, dst_bs=R * self.Tc, dst_rs=self.Tc,
+        pre = lambda a, n: Act(a.t, 1, 1, n, a.C, a.ld, n * a.ld, a.off)                      # the first n rows of a row tensor
+        rows_of = lambda a, r0, n: Act(a.t, 1, 1, n, a.C, a.ld, n * a.ld, a.off + r0 * a.ld)  # rows [r0, r0 + n)
+        tc_all = self.new(1, 1, nmax, self.Tc)               # the conditioning rows of one step, repeated: the same for every chunk
+        ops.rows_copy(tt, self.t_const.t, tc_all.t, B=steps_c, rows=R, C=self.Tc, src_bs=0, src_rs=self.Tc, dst_bs=R * self.Tc, dst_rs=self.Tc,
                       label="tt.t_const")
-        hid = self.new(1, 1, rows_all, self.Tc)
-        ops.time_embed(tt, times=times_all, coef=None, step_ptr=None, freqs=W.f32("time.freqs", lambda: u.to_time_hiddens[0].weights),
-                       w=W.f32("time.w", lambda: u.to_time_hiddens[1].weight), bias=W.f32("time.b", lambda: u.to_time_hiddens[1].bias), hid=hid,
-                       label="tt.time_embed")
-        if TIME_CHAIN_F32:
-            t_all = self.f32buf(rows_all, self.Tc)
-            ops.linear_f32(tt, hid, W.f32("time.cond.wt32", lambda: u.to_time_cond[0].weight.t()), W.f32("time.cond.b32", lambda: u.to_time_cond[0].bias),
-                           t_all, res=tc_all, label="tt.to_time_cond")
-        else:
-            t_all = self.new(1, 1, rows_all, self.Tc)
-            ops.igemm(tt, hid, W.conv("time.cond", u.to_time_cond[0], split=SPLIT_STATIC), t_all, res=tc_all, label="tt.to_time_cond")
-        tok_raw = self.new(1, 1, rows_all, self.ntt * self.cond_dim)
-        ops.igemm(tt, hid, W.conv("time.tokens", u.to_time_tokens[0], split=SPLIT_STATIC), tok_raw, label="tt.to_time_tokens")
-        n_tok_rows = rows_all * self.ntt
-        c_time = self.new(1, 1, n_tok_rows, self.cond_dim)
-        tok_rows = Act(tok_raw.t, 1, 1, n_tok_rows, self.cond_dim, self.cond_dim, n_tok_rows * self.cond_dim)
-        ops.ln_residual(tt, tok_rows, W.f32("norm_cond.w", lambda: u.norm_cond.weight), c_time, beta=W.f32("norm_cond.b", lambda: u.norm_cond.bias),
-                        eps=1e-5, label="tt.norm_cond(time)")
+        hid = self.new(1, 1, nmax, self.Tc)
+        t_all = self.f32buf(nmax, self.Tc) if TIME_CHAIN_F32 else self.new(1, 1, nmax, self.Tc)
+        tok_raw = self.new(1, 1, nmax, self.ntt * self.cond_dim)
+        c_time = self.new(1, 1, nmax * self.ntt, self.cond_dim)
         tw, tb, gam, isc, ish, _, total_c = W.get("timemlp.tables", lambda: self._time_mlp_tables(self._all_resnet_blocks()))
-        if TIME_CHAIN_F32:
-            ss = self.f32buf(rows_all, tw.shape[0])
-            ops.linear_f32(tt, t_all, W.f32("timemlp.wt32", lambda: tw.t()), W.f32("timemlp.b32", lambda: tb), ss, act_in=ACT_SILU, label="tt.time_mlps")
-        else:
-            ss = self.new(1, 1, rows_all, tw.shape[0])
-            ops.igemm(tt, t_all, W.raw("timemlp.w", tw, tb, split=SPLIT_STATIC), ss, act_in=ACT_SILU, label="tt.time_mlps")
+        ss = self.f32buf(nmax, tw.shape[0]) if TIME_CHAIN_F32 else self.new(1, 1, nmax, tw.shape[0])
         tab_pa, tab_ps = self.f32buf(rows_all, total_c), self.f32buf(rows_all, total_c)
-        ops.scale_shift(tt, ss, W.f32("timemlp.gam", lambda: gam), W.get("timemlp.isc", lambda: isc.to(self.dev)),
-                        W.get("timemlp.ish", lambda: ish.to(self.dev)), tab_pa, tab_ps, label="tt.scale_shift")
         segments = [(tab_pa, self.pa2), (tab_ps, self.ps2)]
-        selfs, crosses, ws, wc = self._ctx_weights()
+        selfs, crosses, ws, wc = selfs_, crosses_, ws_, wc_
+        n_tok_rows = rows_all * self.ntt
+        tab_self = tab_cross = mu = rs = None
         if selfs:
-            mu, rs = self.f32buf(n_tok_rows), self.f32buf(n_tok_rows)
-            ops.rowstat(tt, c_time, mode=1, rs=rs, mu=mu, eps=1e-5, label="tt.ctx.ln")
+            mu, rs = self.f32buf(nmax * self.ntt), self.f32buf(nmax * self.ntt)
             tab_self = self.new(1, 1, n_tok_rows, ws.Cout)
-            ops.igemm(tt, c_time, ws, tab_self, mu=mu, rs=rs, label="tt.ctx.self")
             segments.append((tab_self.t, self._dyn_proj["self"].t))
         if crosses:
             tab_cross = self.new(1, 1, n_tok_rows, wc.Cout)
-            ops.igemm(tt, c_time, wc, tab_cross, label="tt.ctx.cross")
             segments.append((tab_cross.t, self._dyn_proj["cross"].t))
+        for ch in range(nchunks):
+            r0 = ch * nmax
+            n = min(nmax, rows_all - r0)
+            tag = "tt." if nchunks == 1 else f"tt{ch}."
+            ops.time_embed(tt, times=times_all[r0:r0 + n], coef=None, step_ptr=None, freqs=W.f32("time.freqs", lambda: u.to_time_hiddens[0].weights),
+                           w=W.f32("time.w", lambda: u.to_time_hiddens[1].weight), bias=W.f32("time.b", lambda: u.to_time_hiddens[1].bias), hid=pre(hid, n),
+                           label=tag + "time_embed")
+            if TIME_CHAIN_F32:
+                ops.linear_f32(tt, pre(hid, n), W.f32("time.cond.wt32", lambda: u.to_time_cond[0].weight.t()), W.f32("time.cond.b32", lambda: u.to_time_cond[0].bias),
+                               t_all[:n], res=pre(tc_all, n), label=tag + "to_time_cond")
+            else:
+                ops.igemm(tt, pre(hid, n), W.conv("time.cond", u.to_time_cond[0], split=SPLIT_STATIC), pre(t_all, n), res=pre(tc_all, n), label=tag + "to_time_cond")
+            ops.igemm(tt, pre(hid, n), W.conv("time.tokens", u.to_time_tokens[0], split=SPLIT_STATIC), pre(tok_raw, n), label=tag + "to_time_tokens")
+            tok_rows = Act(tok_raw.t, 1, 1, n * self.ntt, self.cond_dim, self.cond_dim, n * self.ntt * self.cond_dim)
+            ct = pre(c_time, n * self.ntt)
+            ops.ln_residual(tt, tok_rows, W.f32("norm_cond.w", lambda: u.norm_cond.weight), ct, beta=W.f32("norm_cond.b", lambda: u.norm_cond.bias),
+                            eps=1e-5, label=tag + "norm_cond(time)")
+            if TIME_CHAIN_F32:
+                ops.linear_f32(tt, t_all[:n], W.f32("timemlp.wt32", lambda: tw.t()), W.f32("timemlp.b32", lambda: tb), ss[:n], act_in=ACT_SILU, label=tag + "time_mlps")
+                ss_c = ss[:n]
+            else:
+                ops.igemm(tt, pre(t_all, n), W.raw("timemlp.w", tw, tb, split=SPLIT_STATIC), pre(ss, n), act_in=ACT_SILU, label=tag + "time_mlps")
+                ss_c = pre(ss, n)
+            ops.scale_shift(tt, ss_c, W.f32("timemlp.gam", lambda: gam), W.get("timemlp.isc", lambda: isc.to(self.dev)),
+                            W.get("timemlp.ish", lambda: ish.to(self.dev)), tab_pa[r0:r0 + n], tab_ps[r0:r0 + n], label=tag + "scale_shift")
+            if selfs:
+                ops.rowstat(tt, ct, mode=1, rs=rs[:n * self.ntt], mu=mu[:n * self.ntt], eps=1e-5, label=tag + "ctx.ln")
+                ops.igemm(tt, ct, ws, rows_of(tab_self, r0 * self.ntt, n * self.ntt), mu=mu[:n * self.ntt], rs=rs[:n * self.ntt], label=tag + "ctx.self")
+            if crosses:
+                ops.igemm(tt, ct, wc, rows_of(tab_cross, r0 * self.ntt, n * self.ntt), label=tag + "ctx.cross")
+        tt.keep += [tab_pa, tab_ps, times_all, hid, t_all, tok_raw, c_time, ss, tc_all.t, mu, rs] + ([tab_self.t] if selfs else []) + ([tab_cross.t] if crosses else [])
         # the step plan with the chain replaced by the copy of the current step's rows
         one = Plan("slice")
         ops.step_slice(one, segments, step_ptr, label="time_table_rows")

@@ -522,6 +522,33 @@ def _dry_engines(monkeypatch):
     monkeypatch.setattr(engine, "UnetEngine", functools.partial(engine.UnetEngine, dry=True))
 
 
+def test_time_table_pass_in_chunks(reference_weights, monkeypatch):
+    """Round 6: the batched all-steps pass of the per-request time table runs in chunks of steps over ONE set of intermediates (the time MLPs' output
+    alone is as large as both scale / shift tables).  Five steps in chunks of 2 + 2 + 1 and in five chunks of one: the tables are what the
+    single-pass plan fills (the same kernels on fewer rows per launch), so the step plan still equals the per-step chain."""
+    from imagen_pytorch_amd import engine
+
+    seen = []
+    real = engine.UnetEngine.enable_time_table
+
+    def spy(self, coef, step_ptr):
+        out = real(self, coef, step_ptr)
+        seen.append(dict(self.time_table_layout))
+        return out
+
+    monkeypatch.setattr(engine.UnetEngine, "enable_time_table", spy)
+    test_time_table_plan_equals_per_step_chain("memory_efficient_lowres", reference_weights)
+    assert seen[-1]["chunks"] == 1
+    work = seen[-1]["work_bytes_unchunked"]
+    monkeypatch.setattr(engine, "TIME_TABLE_CHUNK_BYTES", work // 3 + 1)       # 3 chunks: 2 + 2 + 1 steps
+    test_time_table_plan_equals_per_step_chain("memory_efficient_lowres", reference_weights)
+    assert (seen[-1]["chunks"], seen[-1]["steps_per_chunk"]) == (3, 2), seen[-1]
+    monkeypatch.setattr(engine, "TIME_TABLE_CHUNK_BYTES", 1)                   # one step per chunk
+    test_time_table_plan_equals_per_step_chain("four_time_tokens_init_dim", reference_weights)
+    assert (seen[-1]["chunks"], seen[-1]["steps_per_chunk"]) == (5, 1), seen[-1]
+
+
+
 def test_sampler_stage_plan_without_time_table(reference_weights, monkeypatch):
     """The per-step conditioning chain inside the sampling plan (IMAGEN_TIME_TABLE=0; also what inpainting and the step-level API run)."""
     from imagen_pytorch_amd import imagen as _im
