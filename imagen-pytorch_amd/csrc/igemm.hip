@@ -31,6 +31,7 @@ constexpr int stage_slots(int TP, int G, int KSC) {
   if (KSC == 18 && G == 4) return TP == 64 ? 2 : TP == 128 ? 3 : 6;   // 3x3: 10x10 | 10x18 | 18x18 halo tiles
   if (KSC == 2 && G == 4) return TP / 64;                             // 1x1
   if (KSC == 8 && G == 4) return TP == 64 ? 4 : 6;                    // 2x2 stride-2 downsample: 4x the output pixels
+  if (KSC == 6 && G == 4) return TP == 64 ? 3 : TP == 128 ? 4 : 5;    // 3x1 (the causal temporal conv of Imagen-Video over rows = frames): 10x8 (one frame: 3x64) | 18x8 | 18x16 halo tiles
   if (KSC == 4 && G == 8) return TP / 32;                             // 1x1, 64-channel chunks
   if (KSC == 8 && G == 16) return TP / 16;                            // 1x1, 128-channel chunks
   return 4;                                                           // generic k-loop (8-channel chunks, 15x15 cross-embed conv, ...)
@@ -231,7 +232,7 @@ __global__ __launch_bounds__(512, (MI * NI <= 2 ? 4 : 2)) void igemm_kernel(cons
       S.b = tl.b;
       S.chunk = chunk;
       const int b = tl.b;
-      const int iy0 = tl.oy0 * p.stride - p.pad, ix0 = tl.ox0 * p.stride - p.pad;
+      const int iy0 = tl.oy0 * p.stride - p.pad, ix0 = tl.ox0 * p.stride - (p.pad_x1 ? p.pad_x1 - 1 : p.pad);
       const int cc = chunk * KC + my_cg * 8;
       const bool from1 = cc < p.C1;
       const bool chan_ok = from1 || (cc - p.C1 < p.C2);
@@ -1000,6 +1001,7 @@ int launch_cfg(const ImagenIgemmParams& p, hipStream_t s) {
     if (ks == 18) return launch_ksc<MI, NI, WM, WN, G, (G == 4 ? 18 : 0)>(p, s);
     if (ks == 2) return launch_ksc<MI, NI, WM, WN, G, (G == 4 ? 2 : 0)>(p, s);
     if (ks == 8) return launch_ksc<MI, NI, WM, WN, G, (G == 4 ? 8 : 0)>(p, s);
+    if (ks == 6) return launch_ksc<MI, NI, WM, WN, G, (G == 4 ? 6 : 0)>(p, s);   // three taps (round 6: the generic loop looks one step ahead for its weight fragment)
   }
   if (G == 8 && ks == 4) return launch_ksc<MI, NI, WM, WN, G, (G == 8 ? 4 : 0)>(p, s);
   if (G == 16 && ks == 8) return launch_ksc<MI, NI, WM, WN, G, (G == 16 ? 8 : 0)>(p, s);
@@ -1063,6 +1065,8 @@ int launch_igemm(const ImagenIgemmParams* pp, hipStream_t s) {
   IMAGEN_CHECK(p.x1 && p.w && p.y, "igemm: null x1/w/y");
   IMAGEN_CHECK(!p.addend || p.gate, "igemm: addend requires gate");
   IMAGEN_CHECK(p.cfg >= kNumCfgs || (p.TW > 0 && (p.TW & (p.TW - 1)) == 0), "igemm: tile width %d is not a power of two", p.TW);
+  IMAGEN_CHECK(!p.pad_x1 || p.cfg < kNumCfgs, "igemm: pad_x1 (an x padding of its own) is implemented by kernel family 0 only (cfg %d)", p.cfg);
+  IMAGEN_CHECK(p.pad_x1 >= 0, "igemm: pad_x1 %d", p.pad_x1);
   IMAGEN_CHECK(!p.gca_part || p.cfg >= kNumCfgs, "igemm: gca_part is implemented by the kernel families 2, 5, 7 and 8 only (cfg %d)", p.cfg);
   if (p.cfg >= cfg_base_small()) return launch_conv_small(pp, p.cfg - cfg_base_small(), s);
   if (p.cfg >= cfg_base_gemm()) return launch_conv_gemm(pp, p.cfg - cfg_base_gemm(), s);
@@ -1124,7 +1128,7 @@ extern "C" int imagen_igemm_config_info(int cfg, int* tile_pixels, int* tile_cou
 }
 
 static constexpr int ksc_of(int G, int ks) {   // the launch_cfg dispatch, as a function
-  if (G == 4 && (ks == 18 || ks == 2 || ks == 8)) return ks;
+  if (G == 4 && (ks == 18 || ks == 2 || ks == 8 || ks == 6)) return ks;
   if (G == 8 && ks == 4) return ks;
   if (G == 16 && ks == 8) return ks;
   if (G == 1 && ks == 113) return ks;

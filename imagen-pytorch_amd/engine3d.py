@@ -54,6 +54,7 @@ def _w2d(mod):
 # executed-FLOP bound (SPLIT_SMALL_FLOPS) never admits them: the output stage gets its own, wider, bound; two launches per step grow by
 # ~20 us each (1 % of the C5 step).
 SPLIT_OUTPUT_STAGE = 1
+TEMPORAL_CONV_FUSED = 1   # (round 6) the causal temporal Conv1d as one (3 x 1)-tap launch (ABI 10: ImagenIgemmParams.pad_x1) instead of three 1x1 GEMMs
 TIME_CHAIN_F32 = 0        # (round 6, call A) 1 = to_time_cond and the batched time MLPs on fp32 rows (IMAGEN_OP_LINEAR_F32) as the image planner runs them: priced in the
                           # plan interpreter at +-0.5 % on C5 (cond 0.970 -> 0.965e-3, null 0.901 -> 0.905e-3) and measured on MI355X at 9.67e-4 / 9.97e-4 against 9.64e-4 /
                           # 9.76e-4 without — no gain on the video denoiser, so its chain stays on the fp16 GEMMs
@@ -374,13 +375,21 @@ class UnetEngine3D(UnetEngine):
                     and 4.0 * pixels * Cout * taps * Cin <= SPLIT_OUTPUT_FLOPS)
 
     def _temporal_conv(self, plan, x: Act, conv, name: str, f: int) -> Act:
-        """Causal Conv1d(k = 3) over the frames of every pixel (iv.py:436-449) as three accumulating 1x1 GEMMs on frame-shifted views."""
+        """Causal Conv1d(k = 3) over the frames of every pixel (iv.py:436-449).  TEMPORAL_CONV_FUSED: ONE launch — in the (clip, frame, pixel) view it is
+        a 3 x 1 window over rows = frames with two zero rows in front (ops.igemm(causal_rows=True), kernel family 0): one fp32 accumulation
+        instead of three launches that pass their partial sums through fp16 (rounds 1-5: three accumulating 1x1 GEMMs on frame-shifted views,
+        144 of the 320 launches of a C5 step)."""
         R = self.R
         C, P = x.C, x.H * x.W
         w = conv.weight.detach().float()                       # (C_out, C_in, 3): tap k multiplies frame f - 2 + k
         K = w.shape[-1]
         y = self.new(x.B, x.H, x.W, w.shape[0])
         Co = w.shape[0]
+        if TEMPORAL_CONV_FUSED and C % 8 == 0:
+            pw = self.W.raw(f"{name}.taps", w.unsqueeze(-1), conv.bias.detach().float())       # (C_out, C_in, 3, 1)
+            ops.igemm(plan, Act(x.t, R, f, P, C, C, f * P * C, x.off), pw, Act(y.t, R, f, P, Co, Co, f * P * Co, y.off), causal_rows=True,
+                      label=f"{name}.taps")
+            return y
         for shift in range(min(K, f)):                         # shift 0: the current frame (with the bias), 1: f-1, 2: f-2
             tap = K - 1 - shift
             pw = self.W.raw(f"{name}.tap{tap}", w[:, :, tap], conv.bias.detach().float() if shift == 0 else None)

@@ -504,7 +504,7 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
           pstride: int = 0, act_in: int = ACT_NONE, act_out: int = ACT_NONE, addend: Optional[Act] = None, gate=None,
           res: Optional[Act] = None, out_mode: int = OUT_NHWC, stride: int = 1, pad: Optional[int] = None,
           cfg: Optional[tuple] = None, ssq_a=None, ssq_b=None, ssq_wb: float = 1.0, ssq_out=None, post: Optional[dict] = None,
-          gca: Optional[dict] = None, label: str = ""):
+          gca: Optional[dict] = None, causal_rows: bool = False, label: str = ""):
     """... ssq_a / ssq_b: producers' per-pixel sums of squares of x1 / x2 (ChanRMSNorm statistics without a separate pass);
     ssq_out: emit the per-pixel sum of squares of the output — honoured only when the chosen tile covers all Cout
     (`p.ssq_emitted` tells the caller, who otherwise falls back to a ROWSTAT op)."""
@@ -519,9 +519,16 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
     H, W = x1.H, x1.W
     OH = (H + 2 * pad - KH) // stride + 1
     OW = (W + 2 * pad - KW) // stride + 1
+    pad_x1 = 0
+    if causal_rows:   # a KH x 1 window that ends at its own row (Imagen-Video's causal Conv1d over frames in the (clip, frame, pixel) view): KH - 1 zero
+        # rows before the image, none behind it, no x padding — one launch of kernel family 0 (ImagenIgemmParams.pad_x1)
+        assert KW == 1 and stride == 1 and cfg is None, f"{label}: causal_rows is a KH x 1 stride-1 window"
+        pad, pad_x1, OH, OW = KH - 1, 1, H, W
     C2 = x2.C if x2 is not None else 0
     assert x1.C + C2 == pw.Cin, f"{label}: input channels {x1.C}+{C2} != weight Cin {pw.Cin}"
     want_gca = gca is not None and out_mode == OUT_NHWC and act_out == ACT_NONE and addend is None and res is None and post is None
+    if causal_rows:
+        cfg = pick_cfg(pw.G, pw.Cout, OH, OW, x1.B, KH, KW, stride, full_cout=ssq_out is not None and out_mode == OUT_NHWC, family=0)
     small_3x3 = KH == 3 and KW == 3 and pad == 1 and pw.G == 4
     small_1x1 = KH == 1 and KW == 1 and pad == 0 and pw.G >= 2 and OH > 1 and CONV_SMALL >= 2   # (spatial maps only: the token linears keep their kernels)
     if cfg is None and CONV_SMALL and stride == 1 and (small_3x3 or small_1x1) and x1.B * OH * OW <= SMALL_MAX_ROWS:
@@ -608,6 +615,7 @@ def igemm(plan: Plan, x1: Act, pw: PackedWeight, y, *, x2: Optional[Act] = None,
     p.w, p.bias = pw.w.data_ptr(), ptr(pw.bias)
     p.B, p.H, p.W = x1.B, H, W
     p.KH, p.KW, p.stride, p.pad = KH, KW, stride, pad
+    p.pad_x1 = pad_x1
     p.OH, p.OW = OH, OW
     p.Cin_pad, p.Cout, p.Cout_pad = pw.Cin_pad, pw.Cout, pw.Cout_pad
     p.pstride = pstride

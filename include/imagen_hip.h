@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define IMAGEN_ABI_VERSION 9 /* 9: LINEAR_F32, SCALE_SHIFT ss_f32;  8: ROWCHAIN, the latency probes;  3: head_dim in the attention / QNORM / KV_PREP params; 4: DDPM_UPDATE x0_thr; 5: GCA_TAIL; 6: ACT_PREP self_stat, STEP_SLICE;
+#define IMAGEN_ABI_VERSION 10 /* 10: ImagenIgemmParams.pad_x1 (a KH x KW window with its own x padding: the causal temporal conv of Imagen-Video as ONE (3 x 1)-tap launch);  9: LINEAR_F32, SCALE_SHIFT ss_f32;  8: ROWCHAIN, the latency probes;  3: head_dim in the attention / QNORM / KV_PREP params; 4: DDPM_UPDATE x0_thr; 5: GCA_TAIL; 6: ACT_PREP self_stat, STEP_SLICE;
                                * 7: every launch carries sizeof(its params struct) (a stale mirror of a struct fails loudly), ImagenIgemmParams.dbg -> launcher_word, kernel families 6 and 7, ImagenAttentionParams.softmax_mode */
 
 typedef void* imagen_stream_t; /* hipStream_t */
@@ -78,7 +78,8 @@ enum ImagenOpKind {
  *
  *   in(p, c)  = concat(x1[.., :C1], x2[.., :C2])                       (x2 optional)
  *   a(p, c)   = act_in( (in - mu[p]) * rs[p] * pa[b, c] + ps[b, c] )   (each factor optional), 0 outside the image
- *   acc(q, o) = sum_{ky,kx,c} a(q*stride - pad + (ky,kx), c) * W[o][ky][kx][c]
+ *   acc(q, o) = sum_{ky,kx,c} a(q*stride - (pad, pad_x) + (ky,kx), c) * W[o][ky][kx][c]      (pad_x = pad unless pad_x1 != 0; OH / OW as given: rows / columns
+ *               past the input are zero, so pad is the padding BEFORE the image and a causal window simply has none behind it)
  *   v         = act_out(acc + bias[o]);  v += addend(q,o) * gate[b,o]  |  v += res(q,o)      (addend and res exclude each other)
  *   y         = v   (NHWC fp16 | pixel-shuffle NHWC fp16 | NCHW fp32);   ssq_out[q] = sum_o fp16(v)^2   (optional)
  *   or, with post_pa:  y = silu(v / max(||v||_2 over o, 1e-12) * post_pa[b,o] + post_ps[b,o])        (the next Block's prologue)
@@ -127,6 +128,8 @@ typedef struct ImagenIgemmParams {
   int32_t ld_add, bs_add, ld_res, bs_res;
   int32_t gate_stride;
   int32_t ldy, bsy;    /* output pixel / batch strides (elements) */
+  int32_t pad_x1;      /* 0: the x padding equals `pad`; else x padding + 1 (kernel family 0 only).  Imagen-Video's causal Conv1d over frames
+                        * (iv.py:436-449) in the (clip, frame, pixel) view: KH = 3, KW = 1, pad = 2, pad_x1 = 1, OH = frames */
   int32_t out_mode;
   int32_t TH, TW;      /* output tile (TH*TW must equal the tile's pixel count) */
   int32_t cfg;         /* tile configuration id, see imagen_igemm_config_info */

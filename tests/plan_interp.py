@@ -149,7 +149,13 @@ class Interpreter:
         a = _act(a, p.act_in).half().float()
         wref, bias = ops.REFERENCE_WEIGHTS[p.w]
         assert wref.shape[1] >= C and wref.shape[2:] == (p.KH, p.KW) and wref.shape[0] == p.Cout
-        acc = F.conv2d(a.permute(0, 3, 1, 2), wref[:, :C], None, stride=p.stride, padding=p.pad)[:, :, :p.OH, :p.OW]
+        if p.pad_x1:   # an x padding of its own; rows / columns past the input are zero (OH / OW as given)
+            px = p.pad_x1 - 1
+            need_h, need_w = (p.OH - 1) * p.stride + p.KH, (p.OW - 1) * p.stride + p.KW
+            ap = F.pad(a.permute(0, 3, 1, 2), (px, max(0, need_w - px - a.shape[2]), p.pad, max(0, need_h - p.pad - a.shape[1])))
+            acc = F.conv2d(ap, wref[:, :C], None, stride=p.stride)[:, :, :p.OH, :p.OW]
+        else:
+            acc = F.conv2d(a.permute(0, 3, 1, 2), wref[:, :C], None, stride=p.stride, padding=p.pad)[:, :, :p.OH, :p.OW]
         assert acc.shape[2:] == (p.OH, p.OW), (acc.shape, p.OH, p.OW)
         v = acc.permute(0, 2, 3, 1)                                   # (B, OH, OW, Cout)
         if p.bias:

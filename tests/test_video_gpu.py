@@ -11,6 +11,7 @@ import sys
 
 import pytest
 import torch
+import torch.nn.functional as F
 
 from conftest import gpu_device
 
@@ -89,6 +90,43 @@ def test_igemm_view_patterns_of_the_video_planner():
 
     hip, ref = _both(build)
     assert ref.abs().sum() > 0 and nerr(hip, ref) < 2e-3
+
+
+@pytest.mark.parametrize("f,P,C,Co", [(6, 64, 32, 32), (16, 40, 64, 96), (1, 64, 32, 32), (2, 24, 128, 64), (5, 72, 64, 64)])
+def test_causal_temporal_conv_in_one_launch(f, P, C, Co):
+    """Round 6 (ABI 10, ImagenIgemmParams.pad_x1): Imagen-Video's causal Conv1d(k = 3) over the frames of every pixel (iv.py:436-449) as ONE igemm
+    launch — a 3 x 1 window over rows = frames in the (clip, frame, pixel) view, two zero rows in front of every clip, none behind, no x padding
+    (ops.igemm(causal_rows=True), kernel family 0) — against torch's conv1d on identical fp16 inputs and against the plan interpreter: clips of 1, 2
+    (fewer frames than taps), 5, 6 and 16 frames, pixel counts that do not fill the tiles, three channel widths; the rows of one clip must never see
+    the previous clip's last frames."""
+    from imagen_pytorch_amd import ops
+    from imagen_pytorch_amd.ops import Act
+
+    R = 3
+    g = torch.Generator().manual_seed(f * 131 + P)
+    x_ref = (torch.randn(R, f, P, C, generator=g) * 0.8).half()
+    w = torch.randn(Co, C, 3, generator=g) / (3 * C) ** 0.5
+    bias = torch.randn(Co, generator=g) * 0.1
+
+    def build(plan, dev):
+        ops.KEEP_REFERENCE_WEIGHTS = dev.type == "cpu"
+        try:
+            x = ops.new_act(R * f, 1, P, C, dev)
+            x.t.copy_(x_ref.reshape(x.t.shape))
+            y = ops.new_act(R * f, 1, P, Co, dev)
+            y.t.fill_(float("nan"))
+            pw = ops.pack_weight(w.unsqueeze(-1), bias, dev)
+            p = ops.igemm(plan, Act(x.t, R, f, P, C, C, f * P * C, 0), pw, Act(y.t, R, f, P, Co, Co, f * P * Co, 0), causal_rows=True)
+            assert ops.cfg_table()[p.cfg][3] == 0 and (p.KH, p.KW, p.pad, p.pad_x1, p.OH, p.OW) == (3, 1, 2, 1, f, P)
+            return y.t
+        finally:
+            ops.KEEP_REFERENCE_WEIGHTS = False
+
+    hip, interp = _both(build)
+    xt = x_ref.float().permute(0, 2, 3, 1).reshape(R * P, C, f)                       # (clip x pixel, channel, frame)
+    ref = F.conv1d(F.pad(xt, (2, 0)), w.half().float(), bias).reshape(R, P, Co, f).permute(0, 3, 1, 2)
+    e_hip, e_int = nerr(hip.reshape(ref.shape), ref), nerr(interp.reshape(ref.shape), ref)
+    assert e_hip < 1e-3 and e_int < 1e-3, (e_hip, e_int)
 
 
 @pytest.mark.parametrize("causal", [True, False])
