@@ -45,6 +45,34 @@ __device__ __forceinline__ void cb_static_for(F&& f) {
 #define CB_BARRIER IMAGEN_BARRIER
 #define CB_WAIT_VM IMAGEN_WAIT_VM
 
+// -DCB_TRACE (tools/conv_bench.py --trace, a throw-away variant library: never in the product build): thread 0 of every workgroup keeps s_memtime
+// at the phase boundaries in registers (a store inside the pipeline would shift the counted vmcnt waits) and writes them, the constant-clock time
+// of entry and exit and the hardware ids of its CU behind the epilogue, into a buffer handed over by imagen_debug_conv_big_trace() (eight
+// slots of 4096 workgroups: the launcher numbers the launches, so that back-to-back launches can be told apart).
+#ifdef CB_TRACE
+__device__ unsigned long long* g_cb_trace = nullptr;
+#define CB_TRACE_DECL()                                  \
+  unsigned long long cb_t[8] = {};                       \
+  const unsigned cb_slot = (p.launcher_word >> 16) & 7;  \
+  const unsigned long long cb_r0 = __builtin_amdgcn_s_memrealtime()
+#define CB_STAMP(i) (cb_t[i] = __builtin_amdgcn_s_memtime())
+#define CB_TRACE_FLUSH()                                                                       \
+  do {                                                                                         \
+    if (threadIdx.x == 0 && g_cb_trace) {                                                      \
+      unsigned long long* o = g_cb_trace + ((size_t)cb_slot * 4096 + blockIdx.x) * 16;        \
+      for (int i = 0; i < 8; ++i) o[i] = cb_t[i];                                              \
+      o[8] = cb_r0;                                                                            \
+      o[9] = __builtin_amdgcn_s_memrealtime();                                                 \
+      o[10] = __builtin_amdgcn_s_getreg((3 << 11) | 20);  /* XCC_ID */                         \
+      o[11] = __builtin_amdgcn_s_getreg((31 << 11) | 4);  /* HW_ID */                          \
+    }                                                                                          \
+  } while (0)
+#else
+#define CB_TRACE_DECL() ((void)0)
+#define CB_STAMP(i) ((void)0)
+#define CB_TRACE_FLUSH() ((void)0)
+#endif
+
 constexpr int cb_halo_pieces(int TH, int TW) { return (((TH + 2) * (TW + 2) * 4 + 63) / 64 + 7) / 8; }   // DMA instructions per wave and halo tile
 constexpr int cb_scratch_floats(int WM, int WN) { return 4 * 64 * WN + WM * WN * 64 + 8 + WM * (64 * WN + 4) + WM * WN * 64; }   // ep_par + ep_red
 // LDS image: [pipeline: HR halo buffers | WR weight stages] [epilogue operands + scratch (ep_par, ep_red)] [warm-up sink]; after the loop
@@ -89,6 +117,8 @@ __global__ __launch_bounds__(512, 1) void conv_big_kernel(const ImagenIgemmParam
   constexpr int PXW = 32 * MI;
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
+  CB_TRACE_DECL();
+  CB_STAMP(0);
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -217,7 +247,10 @@ __global__ __launch_bounds__(512, 1) void conv_big_kernel(const ImagenIgemmParam
   // ================================================================================================ pipeline
   // Instruction warm-up (common.h) and L2 warm-up of the weights (conv_dma.hip: the workgroups of an XCD — blockIdx % 8 by observation; only
   // speed depends on it — each touch their share of the packed weights once, one dword per 128-byte line, into a sink nobody reads)
-  const unsigned warm = imagen_code_warm((unsigned)p.launcher_word << 8, tid, 512);
+  CB_STAMP(1);
+  // (round 6, call M: the warm-up as two non-blocking loads per thread BEHIND the first stage's copies — one round trip instead of two — moved
+  // ~1000 cycles from this phase into the wait for the first stage: 4650 against 5040 cycles for both, the step unchanged.  The blocking loop stays.)
+  const unsigned warm = imagen_code_warm(((unsigned)p.launcher_word & 0xffffu) << 8, tid, 512);
   {
     const size_t wbytes = (size_t)(NC * 36) * wrow;
     const unsigned nloc = (gridDim.x + 7) >> 3, lw = blockIdx.x >> 3;
@@ -258,8 +291,10 @@ __global__ __launch_bounds__(512, 1) void conv_big_kernel(const ImagenIgemmParam
     for (int i = 0; i < KD; ++i) dma_weight_piece(i);
     weight_stage_issued();
   }
+  CB_STAMP(2);
   CB_WAIT_VM((HR - 2) * NJ + (WR - 2) * KD);
   CB_BARRIER();
+  CB_STAMP(3);
   unsigned wcur = 0, hcur = 0;   // ring / halo byte offsets of the phase being multiplied
   cb_static_for<2>([&](auto kc) __attribute__((always_inline)) {
     constexpr int k = decltype(kc)::value;
@@ -329,6 +364,7 @@ __global__ __launch_bounds__(512, 1) void conv_big_kernel(const ImagenIgemmParam
       hcur = hnext;
     });
   }
+  CB_STAMP(4);
   CB_WAIT_VM(0);   // the look-ahead copies must not outlive the pipeline's LDS image (the epilogue scratch aliases it)
   __syncthreads();
 
@@ -352,9 +388,12 @@ __global__ __launch_bounds__(512, 1) void conv_big_kernel(const ImagenIgemmParam
         for (int r = 0; r < 16; ++r) acc[ni][mi][r] += red[((wq * 4 + ni * MI + mi) * 16 + r) * 64 + lane];
   }
   imagen_code_warm_sink(warm);
+  CB_STAMP(5);
   float* const ep_par = reinterpret_cast<float*>(smem + EPP0);
   float* const ep_red = ep_par + (4 * BN + NQ * PXW + 8 + WM * (BN + 4));
   cl_epilogue<MI, NI, WM, WN, GEN, true, !GEN>(p, tc, acc, pix_y, pix_x, ep_red, ep_par, wm, wn, half, l31, smem + STG0);
+  CB_STAMP(6);
+  CB_TRACE_FLUSH();
 }
 
 struct CbCfg { int WM, WN, KS, TW, WR, HR; };
@@ -406,6 +445,10 @@ int cb_launch_gen(const ImagenIgemmParams& p, hipStream_t s) {
   }();
   ImagenIgemmParams q = p;
   q.launcher_word = (int)code_q;
+#ifdef CB_TRACE
+  static unsigned launch_no = 0;
+  q.launcher_word |= (int)((launch_no++ & 7u) << 16);
+#endif
   hipLaunchKernelGGL(kern, dim3(total), dim3(512), lds, s, q);
   return imagen_hip_status("conv_big launch");
 }
@@ -417,6 +460,10 @@ int cb_launch(const ImagenIgemmParams& p, hipStream_t s) {
 }
 
 }  // namespace
+
+#ifdef CB_TRACE
+extern "C" int imagen_debug_conv_big_trace(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(g_cb_trace), &buf, sizeof(buf)); }
+#endif
 
 int imagen_conv_big_num_configs() { return kNumCbCfgs; }
 

@@ -132,6 +132,15 @@ __global__ __launch_bounds__(256) void temporal_attention_mfma_kernel(const Imag
   const f16* base = reinterpret_cast<const f16*>(p.qkv) + ((size_t)b * F * p.P + px) * p.ld;
   const size_t fstride = (size_t)p.P * p.ld;
   const int inner = p.heads * 64;
+  const int rows = p.heads * F;
+  f16x8 qraw[4];   // the query rows of a 32-row block as loaded (row r0 + l31 = (head, frame), dims 16 s + 8 half ..)
+  auto q_fetch = [&](int r0) __attribute__((always_inline)) {
+    const int r = r0 + l31;
+    const int h = r < rows ? r / F : 0, i = r < rows ? r - h * F : 0;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) qraw[s] = *reinterpret_cast<const f16x8*>(base + (size_t)i * fstride + h * 64 + 16 * s + 8 * half);
+  };
+  q_fetch(0);      // (in flight behind the V^T gather and the K^ rows)
 
   // ---- V^T: lane d gathers column d of the J value rows (null value first); keys J..31 are zero
   {
@@ -173,7 +182,7 @@ __global__ __launch_bounds__(256) void temporal_attention_mfma_kernel(const Imag
     for (int s = 0; s < 4; ++s) {
       const int d0 = 16 * s + 8 * half;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) kx[s][j] *= inv * p.k_scale[d0 + j];
+      for (int j = 0; j < 8; ++j) kx[s][j] *= inv * (p.k_scale[d0 + j] * p.q_scale[d0 + j] * p.scale);   // (q_scale * scale ride on K^: Q^ is the unit row)
       ta_split(kx[s], kh[s], kl[s]);
     }
   }
@@ -190,17 +199,12 @@ __global__ __launch_bounds__(256) void temporal_attention_mfma_kernel(const Imag
       const float nv = p.null_kv[64 + 32 * db + 8 * (e >> 2) + 4 * half + (e & 3)];
       nvlo[db][e] = nv - (float)(f16)nv;
     }
-  float qsc[4][8];   // q_scale * scale of this lane's dims
-#pragma unroll
-  for (int s = 0; s < 4; ++s)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) qsc[s][j] = p.q_scale[16 * s + 8 * half + j] * p.scale;
-
   f16* obase = reinterpret_cast<f16*>(p.o) + ((size_t)b * F * p.P + px) * p.ld_o;
   const size_t ostride = (size_t)p.P * p.ld_o;
-  const int rows = p.heads * F;
   for (int r0 = 0; r0 < rows; r0 += 32) {
-    // ---- Q^ fragments of row r0 + l31 = (head, frame) (B operand: lane = row, the same dims)
+    // ---- Q^ fragments of row r0 + l31 = (head, frame) (B operand: lane = row, the same dims); the rows of the NEXT block are requested
+    //      as soon as this block's are in fp32 registers: a wave is one of two per SIMD (244 registers), the loads of one block at a time
+    //      left the kernel at 2 TB/s (profiles/r06_k_c5_kernel_stats.csv)
     const int r = r0 + l31;
     const bool rok = r < rows;
     const int h = rok ? r / F : 0, i = rok ? r - h * F : 0;
@@ -210,19 +214,19 @@ __global__ __launch_bounds__(256) void temporal_attention_mfma_kernel(const Imag
       float ssq = 0.f;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        const f16x8 v = *reinterpret_cast<const f16x8*>(base + (size_t)i * fstride + h * 64 + 16 * s + 8 * half);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          qx[s][j] = rok ? (float)v[j] : 0.f;
+          qx[s][j] = rok ? (float)qraw[s][j] : 0.f;
           ssq += qx[s][j] * qx[s][j];
         }
       }
+      if (r0 + 32 < rows) q_fetch(r0 + 32);
       ssq += __shfl_xor(ssq, 32);
       const float inv = 1.0f / fmaxf(sqrtf(ssq), 1e-12f);
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
 #pragma unroll
-        for (int j = 0; j < 8; ++j) qx[s][j] *= inv * qsc[s][j];
+        for (int j = 0; j < 8; ++j) qx[s][j] *= inv;
         ta_split(qx[s], qh[s], ql[s]);
       }
     }
