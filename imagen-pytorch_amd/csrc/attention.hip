@@ -126,12 +126,17 @@ __global__ __launch_bounds__(256) void attention_kernel(const ImagenAttentionPar
     const float alpha = exp2f(m_run - m_new);
     m_run = m_new;
     float psum = 0.f;
-    f16x8 pf[2];
+    // P enters the PV product as fp16 hi + lo pairs (round 6; the contract keeps P in fp32): this kernel serves the once-per-request
+    // Perceiver attention pooling of the text tokens, whose bare-fp16 P was the most COHERENT deviation of a denoiser from its contract (one
+    // vector on every row: profiles/r05_t_op_audit_c5_null_row.txt), and the sites of fewer than 256 query rows, where the MFMAs are free
+    f16x8 pf[2], pl[2];
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const float e = exp2f(sacc[r] - m_new);
       psum += e;
-      pf[r >> 3][r & 7] = (f16)e;
+      const f16 eh = (f16)e;
+      pf[r >> 3][r & 7] = eh;
+      pl[r >> 3][r & 7] = (f16)(e - (float)eh);
     }
     l_run = l_run * alpha + psum;
 #pragma unroll
@@ -149,6 +154,7 @@ __global__ __launch_bounds__(256) void attention_kernel(const ImagenAttentionPar
         const uint2 hi = *reinterpret_cast<const uint2*>(vrow + 16);
         uint4 packed = make_uint4(lo.x, lo.y, hi.x, hi.y);
         const f16x8 vf = *reinterpret_cast<const f16x8*>(&packed);
+        oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pl[s], oacc[db], 0, 0, 0);
         oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vf, pf[s], oacc[db], 0, 0, 0);
       }
     }
@@ -314,7 +320,7 @@ __global__ __launch_bounds__(512, MINW) void attention_kernel_w8(const ImagenAtt
         m_run = m_new;
       }
       float psum = 0.f;
-      f16x8 pf[4];
+      f16x8 pf[4];   // (fp16 P: hi + lo pairs as in attention_kernel above spill inside this tiling's loop at its 128-register budget — round 6, not kept)
 #pragma unroll
       for (int h2 = 0; h2 < 2; ++h2)
 #pragma unroll

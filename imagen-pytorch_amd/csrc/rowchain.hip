@@ -733,12 +733,19 @@ __device__ __forceinline__ void attn_tile(Softmax& st, const KvTile& kv, const f
   const float alpha = exp2f(st.m_run - m_new);
   st.m_run = m_new;
   float psum = 0.f;
-  f16x8 pf[2];
+  // The softmax weights enter the PV product as fp16 hi + lo pairs (round 6): the contract keeps P in fp32, and a bare fp16 P was the one
+  // rounding of this chain the contract does not have — 3.4-3.8e-4 per chain launch against the interpreter from identical inputs
+  // (profiles/r05_t_op_audit_c5_null_row.txt), every other launch of the denoiser at ~5e-6.  Four more MFMAs per 32-key tile.
+  f16x8 pf[2], pl[2];
 #pragma unroll
   for (int r = 0; r < 16; ++r) {
     const float e = exp2f(sacc[r] - m_new);
     psum += e;
-    pf[r >> 3][r & 7] = (f16)e;
+    const f16 eh = (f16)e;
+    pf[r >> 3][r & 7] = eh;
+#ifndef ROWCHAIN_P16
+    pl[r >> 3][r & 7] = (f16)(e - (float)eh);
+#endif
   }
   st.l_run = st.l_run * alpha + psum;
 #pragma unroll
@@ -748,7 +755,12 @@ __device__ __forceinline__ void attn_tile(Softmax& st, const KvTile& kv, const f
 #pragma unroll
   for (int s = 0; s < 2; ++s)     // O^T[d][row] += V^T . P (k-step s covers the keys of accumulator registers 8 s .. 8 s + 7)
 #pragma unroll
-    for (int db = 0; db < 2; ++db) st.oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kv.v[s][db], pf[s], st.oacc[db], 0, 0, 0);
+    for (int db = 0; db < 2; ++db) {
+#ifndef ROWCHAIN_P16
+      st.oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kv.v[s][db], pl[s], st.oacc[db], 0, 0, 0);
+#endif
+      st.oacc[db] = __builtin_amdgcn_mfma_f32_32x32x16_f16(kv.v[s][db], pf[s], st.oacc[db], 0, 0, 0);
+    }
 }
 
 // o[row][hd * 64 + 32 db + 8 g + 4 half + e] -> the P0 row tile (the B operand of the out-projection)
