@@ -510,6 +510,7 @@ def main():
                          "8.90 / 8.00 / 7.50 ms per DDPM step pair at 3 / 4 / 6 lanes on one box); batches are handed out dynamically")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-merged", action="store_true", help="skip the informational merged-requests leg (six requests as two merged batches of 24)")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic / mfma_busy_frac = null)")
     ap.add_argument("--cpu-baseline-only", action="store_true", help="time the CPU baseline leg only (no GPU needed) and print its JSON")
     ap.add_argument("--config", choices=("c3", "c2", "c4", "c5"), default="c3",
@@ -678,6 +679,41 @@ def main():
             except Exception as e:  # noqa: BLE001
                 rec["sequential"]["in_graph_step_error"] = f"{type(e).__name__}: {e}"
             log("sequential passes done")
+        if world == 1 and args.mode == "lanes" and headline and not args.no_merged:
+            # the same 48 images in flight as six requests MERGED three by three into two batches of 24 (Imagen.sample_requests: every row keeps its
+            # request's noise), one lane each — informational, never the headline: the metric's requests are batch 8, and `value` above runs them as such
+            try:
+                import threading
+                M, L = 3, 2
+                reqs = lambda first: [dict(text_embeds=text_embeds, seed=5000 + first + j) for j in range(M)]
+                errs = []
+
+                def merged_lane(lane, first, **kw):
+                    try:
+                        with imagen.lane(0x40 + lane), torch.cuda.device(device):
+                            imagen.sample_requests(reqs(first), cond_scale=3.0, **kw)
+                    except BaseException as e:   # noqa: BLE001
+                        errs.append(e)
+
+                def merged_round(first, **kw):
+                    th = [threading.Thread(target=merged_lane, args=(l, first + M * l), kwargs=kw) for l in range(L)]
+                    [t.start() for t in th]
+                    [t.join() for t in th]
+                    if errs:
+                        raise errs[0]
+                merged_round(0, max_steps=8)            # stages, time tables and graphs of the two batch-24 lanes
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                merged_round(M * L)
+                torch.cuda.synchronize()
+                dtm = time.perf_counter() - t1
+                rec["merged_requests"] = {"value": round(B * M * L / dtm, 4), "unit": "images/s", "requests": M * L, "merged_per_batch": M, "lanes": L,
+                                          "images_in_flight": B * M * L, "seconds": round(dtm, 2),
+                                          "note": "informational: six batch-8 requests sampled as two merged batches of 24 (one set of launches per "
+                                                  "denoiser step for three requests), every row with its own request's Philox key"}
+                log("merged-requests leg done")
+            except Exception as e:  # noqa: BLE001
+                rec["merged_requests_error"] = f"{type(e).__name__}: {e}"
         if world == 1:
             try:
                 rec["calibration"] = calibration_leg(device)

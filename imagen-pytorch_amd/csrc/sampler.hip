@@ -191,8 +191,13 @@ __global__ __launch_bounds__(256) void ddpm_update_kernel(const ImagenDdpmUpdate
   } else {
     const int bs = (int)(i4 / p.n_per_sample);
     const uint32_t within = (uint32_t)((i4 - (size_t)bs * p.n_per_sample) >> 2);
-    const uint32_t k0 = p.seed_ptr ? p.seed_ptr[0] : p.seed_lo, k1 = p.seed_ptr ? p.seed_ptr[1] : p.seed_hi;
-    philox_normal4(within, (uint32_t)step, p.stream_id, (uint32_t)(p.sample_offset + bs), k0, k1, z);
+    uint32_t k0, k1, sidx;
+    if (p.row_keys) {   // merged requests: every row has the key and the sample index of its own request
+      k0 = p.row_keys[4 * bs], k1 = p.row_keys[4 * bs + 1], sidx = p.row_keys[4 * bs + 2];
+    } else {
+      k0 = p.seed_ptr ? p.seed_ptr[0] : p.seed_lo, k1 = p.seed_ptr ? p.seed_ptr[1] : p.seed_hi, sidx = (uint32_t)(p.sample_offset + bs);
+    }
+    philox_normal4(within, (uint32_t)step, p.stream_id, sidx, k0, k1, z);
   }
   const bool last = step + 1 >= p.total_steps;
 #pragma unroll

@@ -1223,9 +1223,15 @@ def quantile(plan: Plan, absx0, out, scratch, *, B, n, q: float, label: str = ""
 
 def ddpm_update(plan: Plan, x, x0, quant, coef, noise, final_out, step_ptr, *, B, n_per_sample, dynamic_threshold: bool,
                 total_steps: int, seed: int, stream_id: int, sample_offset: int = 0, seed_ptr: Optional[torch.Tensor] = None,
-                advance: bool = True, x0_thr: Optional[torch.Tensor] = None, label: str = ""):
+                advance: bool = True, x0_thr: Optional[torch.Tensor] = None, row_keys: Optional[torch.Tensor] = None, label: str = ""):
+    """row_keys: device int32 [B, 4] = (Philox key lo, key hi, global sample index, 0) per row — overrides seed / seed_ptr / sample_offset
+    (requests merged into one batch: every row draws the noise of its own request)."""
     p = STRUCTS["ImagenDdpmUpdateParams"]()
     p.x0_thr = ptr(x0_thr)
+    p.row_keys = ptr(row_keys)
+    if row_keys is not None:
+        assert row_keys.dtype == torch.int32 and tuple(row_keys.shape) == (B, 4) and row_keys.is_contiguous()
+        plan.keep.append(row_keys)
     p.x, p.x0, p.quant, p.coef, p.noise, p.final_out, p.step_ptr = (x.data_ptr(), x0.data_ptr(), ptr(quant), coef.data_ptr(), ptr(noise),
                                                                    ptr(final_out), step_ptr.data_ptr())
     p.B, p.n_per_sample, p.dynamic_threshold, p.total_steps = B, n_per_sample, int(dynamic_threshold), total_steps

@@ -31,7 +31,7 @@
 extern "C" {
 #endif
 
-#define IMAGEN_ABI_VERSION 10 /* 10: ImagenIgemmParams.pad_x1 (a KH x KW window with its own x padding: the causal temporal conv of Imagen-Video as ONE (3 x 1)-tap launch);  9: LINEAR_F32, SCALE_SHIFT ss_f32;  8: ROWCHAIN, the latency probes;  3: head_dim in the attention / QNORM / KV_PREP params; 4: DDPM_UPDATE x0_thr; 5: GCA_TAIL; 6: ACT_PREP self_stat, STEP_SLICE;
+#define IMAGEN_ABI_VERSION 11 /* 11: ImagenDdpmUpdateParams.row_keys (per-row Philox key + sample index: requests merged into one batch draw their own noise);  10: ImagenIgemmParams.pad_x1 (a KH x KW window with its own x padding: the causal temporal conv of Imagen-Video as ONE (3 x 1)-tap launch);  9: LINEAR_F32, SCALE_SHIFT ss_f32;  8: ROWCHAIN, the latency probes;  3: head_dim in the attention / QNORM / KV_PREP params; 4: DDPM_UPDATE x0_thr; 5: GCA_TAIL; 6: ACT_PREP self_stat, STEP_SLICE;
                                * 7: every launch carries sizeof(its params struct) (a stale mirror of a struct fails loudly), ImagenIgemmParams.dbg -> launcher_word, kernel families 6 and 7, ImagenAttentionParams.softmax_mode */
 
 typedef void* imagen_stream_t; /* hipStream_t */
@@ -368,6 +368,9 @@ typedef struct ImagenDdpmUpdateParams {
   int32_t no_advance; /* != 0: leave *step_ptr alone (inpainting: a LINCOMB re-noising step of the same table row follows, ip.py:2268-2275) */
   float* x0_thr;      /* optional: the thresholded x0 of this step (ip.py:2094-2107), same layout as x0 — the next step's self-conditioning
                        * input of a Unet(self_cond=True) (ip.py:2249, 1541-1543) */
+  const uint32_t* row_keys; /* optional device [B][4]: {Philox key lo, key hi, global sample index, 0} of every row; overrides seed_ptr / seed_lo /
+                             * seed_hi and sample_offset + row.  Several sample() requests merged into one batch (Imagen.sample_requests) then draw,
+                             * row by row, exactly the noise each would draw alone (its own seed, its own sample indices) */
 } ImagenDdpmUpdateParams;
 
 /* RANDN — out[b, i] ~ N(0,1), Philox4x32-10 counter (i/4, tag, stream_id, sample_offset + b), key = seed.

@@ -61,7 +61,7 @@ def test_emulated_whole_library_runs_gpu_tests():
     """The emulation covers the whole library (capi.hip with recorded graph capture, attention, elementwise, sampler): a slice of the
     `-m gpu` tests — sampler kernels, hipGraph capture / replay, the quantile, the combine_upsample_fmaps forwards — runs on it in a child pytest (IMAGEN_EMUL_TESTS=1, tests/conftest.py)."""
     env = dict(os.environ, IMAGEN_LIB_PATH=_lib(""), IMAGEN_EMUL_TESTS="1")
-    sel = ("test_conv_pro_family or test_conv_gemm_family or graph_capture_replay or ddpm_step_vs_formula or lincomb_masked or quantile_exact or time_embed_scale_shift "
+    sel = ("test_conv_pro_family or test_conv_gemm_family or graph_capture_replay or ddpm_step_vs_formula or ddpm_step_row_keys or lincomb_masked or quantile_exact or time_embed_scale_shift "
            "or upsample_combiner or test_act_prep or clamp_the_step or temporal_attention_kernel or temporal_peg or (test_global_context and 1024) "
            "or 512-103-True-extreme-False-64 or 512-103-True-extreme-True-64 or linear_f32 or null_value_is_not_rounded")   # round 4: the GEMM family, the MFMA temporal attention, the two-phase GlobalContext finalisation, the bounded-logit attention
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(ROOT, "tests", "test_kernels_gpu.py"), os.path.join(ROOT, "tests", "test_model_gpu.py"),

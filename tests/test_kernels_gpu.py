@@ -630,6 +630,42 @@ def test_ddpm_step_vs_formula(ops, dev):
             assert nerr(final, (ref.clamp(-1, 1) + 1) * 0.5) < 1e-5
 
 
+def test_ddpm_step_row_keys_draw_each_request_its_own_noise(ops, dev):
+    """ABI 11, ImagenDdpmUpdateParams.row_keys: (Philox key, global sample index) per row.  A uniform table reproduces the seed_ptr / sample_offset
+    path bit for bit; rows keyed as a second request (its own seed, indices restarting at 0) get exactly what that request draws alone."""
+    torch.manual_seed(12)
+    B, n, T = 5, 3 * 16 * 16, 4
+    x, x0 = torch.randn(B, n), torch.randn(B, n)
+    coef = torch.zeros(T, 8)
+    coef[:, 0], coef[:, 2], coef[:, 3], coef[:, 4], coef[:, 5] = 0.8, 0.85, 0.5, 0.3, 1.0
+
+    def run(rows, **kw):
+        xd, step = x[rows].clone().to(dev), torch.tensor([1], dtype=torch.int32, device=dev)
+        plan = ops.Plan()
+        ops.ddpm_update(plan, xd, x0[rows].to(dev), None, coef.to(dev), None, None, step, B=len(rows), n_per_sample=n, dynamic_threshold=False,
+                        total_steps=T, seed=0, stream_id=1, **kw)
+        _run(plan)
+        return xd.cpu()
+
+    def key_rows(spans):
+        k = torch.zeros(sum(c for _, c, _ in spans), 4, dtype=torch.int32)
+        r = 0
+        for sd, c, i0 in spans:
+            k[r:r + c, 0], k[r:r + c, 1], k[r:r + c, 2] = sd & 0x7FFFFFFF, (sd >> 31) & 0x7FFFFFFF, torch.arange(i0, i0 + c, dtype=torch.int32)
+            r += c
+        return k.to(dev)
+
+    sa, sb = 1234567, (7 << 31) | 99
+    seed_dev = lambda sd: torch.tensor([sd & 0x7FFFFFFF, (sd >> 31) & 0x7FFFFFFF], dtype=torch.int32, device=dev)
+    all_rows = list(range(B))
+    alone = run(all_rows, seed_ptr=seed_dev(sa), sample_offset=3)
+    assert torch.equal(run(all_rows, row_keys=key_rows([(sa, B, 3)])), alone)
+    merged = run(all_rows, row_keys=key_rows([(sa, 3, 0), (sb, 2, 0)]))
+    assert torch.equal(merged[:3], run([0, 1, 2], seed_ptr=seed_dev(sa)))
+    assert torch.equal(merged[3:], run([3, 4], seed_ptr=seed_dev(sb)))
+    assert not torch.equal(merged[3:], alone[3:])
+
+
 def test_lincomb_masked_blend_and_counter(ops, dev):
     """LINCOMB: out = mask ? w0*t0 + w1*t1 + w4*z : mask_else, in place, row picked by the device counter; `advance` bumps it,
     a DDPM_UPDATE with advance=False leaves it alone (the inpainting step sequence of Imagen._stage)."""

@@ -421,6 +421,32 @@ def test_sample_philox_determinism_and_sharding():
     assert nerr(hi, a[2:]) < 1e-5
 
 
+def test_merged_requests_match_separate_calls():
+    """Imagen.sample_requests (serving extension): three requests of different batch sizes, prompt lengths and seeds sampled as ONE batch.  Every row
+    draws the noise of its own request (ABI 11: ImagenDdpmUpdateParams.row_keys; one RANDN span per request for the initial image and the low-res
+    augmentation), so each request gets the images its own sample() call produces — up to the rounding of a different batch's tile configuration —
+    and not the ones another seed would give."""
+    from imagen_pytorch_amd import Imagen, Unet
+
+    dev = gpu_device()
+    g = _load("sample_tiny_cascade.pt")
+    unets = [Unet(**spec["kwargs"]).eval() for spec in g["unets"]]
+    imagen = Imagen(unets, image_sizes=g["image_sizes"], timesteps=6, text_embed_dim=32, cond_drop_prob=0.1).to(dev)
+    for u, spec in zip(imagen.unets, g["unets"]):
+        u.load_state_dict(spec["state_dict"])
+    gen = torch.Generator().manual_seed(5)
+    reqs = [dict(text_embeds=torch.randn(b, L, 32, generator=gen).to(dev), seed=sd) for b, L, sd in ((2, 9, 41), (3, 7, (5 << 31) | 42), (1, 9, 43))]
+    alone = [imagen.sample(cond_scale=3.0, use_tqdm=False, **r) for r in reqs]
+    merged = imagen.sample_requests(reqs, cond_scale=3.0)
+    assert [tuple(m.shape) for m in merged] == [tuple(a.shape) for a in alone]
+    for m, a in zip(merged, alone):
+        assert nerr(m, a) < 2e-3, nerr(m, a)
+    swapped = imagen.sample_requests([dict(reqs[0], seed=43), reqs[1], dict(reqs[2], seed=41)], cond_scale=3.0)
+    assert nerr(swapped[1], alone[1]) < 2e-3 and nerr(swapped[0], alone[0]) > 0.05 and nerr(swapped[2], alone[2]) > 0.05
+    with pytest.raises(NotImplementedError):
+        imagen.sample_requests(reqs, cond_scale=3.0, init_images=torch.zeros(6, 3, 16, 16, device=dev))
+
+
 def test_pipelined_and_lane_sampling_match_sequential():
     """Overlapped sampling: (a) sample_pipelined (one worker thread + lane per cascade stage, stage s of batch k concurrent with
     stage s+1 of batch k-1) and (b) whole cascades on two lanes from two threads give, per batch, bit-identical images to
