@@ -286,8 +286,8 @@ def roofline_leg(imagen, batch: int, device, pmc=None):
     seen = set()
     stage_no = -1
     for key, st in imagen._stages.items():
-        if key[:3] in seen:      # one engine per (stage, batch, size): lanes hold copies of the same plan
-            continue
+        if key[:3] in seen or key[1] != batch:      # one engine per (stage, batch, size): lanes hold copies of the same plan; the merged-requests
+            continue                                # leg's batch-24 stages are not the metric's workload
         seen.add(key[:3])
         stage_no = key[0]
         plan = st["plan"]
