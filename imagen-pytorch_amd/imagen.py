@@ -289,6 +289,8 @@ class Imagen(nn.Module):
                   'noise_fn', 'start_image_or_video', 'conditioning', 'return_pil_images', 'return_all_unet_outputs', 'sample_offset'):
             if common.get(k) is not None or any(r.get(k) is not None for r in requests):
                 _out_of_scope(f"sample_requests(..., {k}=...)")
+        if type(self)._run_stage is not Imagen._run_stage:
+            _out_of_scope(f"{type(self).__name__}.sample_requests (its sampler's noise launches take one key per batch)")
         if not requests:
             return []
         embeds, masks, seeds, sizes = [], [], [], []
@@ -704,7 +706,7 @@ class Imagen(nn.Module):
         use_one_unet_in_gpu=True,
         *,
         noise_fn: Optional[Callable] = None,   # extension: injectable Gaussian noise (parity tests), tags as in oracle/sampler_oracle.py
-        seed: Optional[int] = None,            # extension: Philox seed of this call
+        seed: Optional[int] = None,            # extension: Philox seed of this call (sample_requests passes [(seed, rows), ...]: one key per merged request)
         sample_offset: int = 0,                # extension: global index of sample 0 (batch sharding)
         use_graph: bool = True,
         max_steps: Optional[int] = None,

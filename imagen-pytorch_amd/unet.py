@@ -7,6 +7,7 @@ from __future__ import annotations
 
 from functools import partial
 from pathlib import Path
+import sys
 import torch
 from torch import nn
 
@@ -93,8 +94,7 @@ class Unet(nn.Module):
         assert attn_heads > 1, 'you need to have more than 1 attention head, ideally at least 4 or 8'
         if dim < 128 and not _printed_dim_hint:
             _printed_dim_hint = True
-            import sys as _sys
-            print('The base dimension of your u-net should ideally be no smaller than 128 (reference hint, ip.py:1168)', file=_sys.stderr)
+            print('The base dimension of your u-net should ideally be no smaller than 128 (reference hint, ip.py:1168)', file=sys.stderr)
 
         # constructor kwargs are kept for cast_model_parameters / persistence (ip.py:1173-1175)
         ctor_kwargs = dict(locals())

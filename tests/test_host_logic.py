@@ -458,3 +458,39 @@ def test_a_removed_switch_in_the_environment_is_an_error():
     env = dict(os.environ, IMAGEN_ROWCHAIN="1")
     r = subprocess.run([sys.executable, "-c", "import imagen_pytorch_amd"], cwd=root, env=env, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-400:]
+
+
+def test_merged_request_seed_spans_and_guards():
+    """Imagen.sample_requests, host side (the sampling itself is a -m gpu test): one Philox span per request with sample indices restarting at 0, a
+    single seed is one span at the shard's offset; options the merged path does not cover raise before anything is launched, and so does the
+    ElucidatedImagen sampler (its noise launches take one key per batch)."""
+    from imagen_pytorch_amd import ElucidatedImagen, Imagen, Unet
+    from imagen_pytorch_amd.imagen import _seed_spans
+
+    assert _seed_spans(7, 8, sample_offset=16) == [(7, 0, 8, 16)]
+    assert _seed_spans([(41, 2), ((5 << 31) | 42, 3), (43, 1)], 6) == [(41, 0, 2, 0), ((5 << 31) | 42, 2, 3, 0), (43, 5, 1, 0)]
+    with pytest.raises(AssertionError):
+        _seed_spans([(1, 2), (2, 2)], 5)
+    kw = dict(dim=8, cond_dim=16, dim_mults=(1, 2), num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True), attn_heads=2)
+    imagen = Imagen([Unet(**kw)], image_sizes=(16,), timesteps=4, text_embed_dim=32)
+    reqs = [dict(text_embeds=torch.randn(2, 5, 32), seed=1), dict(text_embeds=torch.randn(1, 7, 32), seed=2)]
+    for bad in (dict(init_images=torch.zeros(3, 3, 16, 16)), dict(inpaint_images=torch.zeros(3, 3, 16, 16)), dict(noise_fn=lambda *a: None)):
+        with pytest.raises(NotImplementedError):
+            imagen.sample_requests(reqs, **bad)
+    with pytest.raises(AssertionError):
+        imagen.sample_requests([dict(reqs[0], cond_scale=2.0), reqs[1]])
+    assert imagen.sample_requests([]) == []
+    edm = ElucidatedImagen([Unet(**kw)], image_sizes=(16,), num_sample_steps=4, text_embed_dim=32)
+    with pytest.raises(NotImplementedError):
+        edm.sample_requests(reqs)
+
+
+def test_first_small_unet_of_a_process_can_be_recast():
+    """Regression (round 6): the first dim < 128 Unet of a process printed the reference's hint through a function-local `import sys as _sys`, which
+    `dict(locals())` then kept among the constructor kwargs — Imagen's cast_model_parameters re-constructed it with an unknown keyword."""
+    import subprocess
+    code = ("import torch\nfrom imagen_pytorch_amd import Imagen, Unet\n"
+            "u = Unet(dim=8, cond_dim=16, dim_mults=(1, 2), num_resnet_blocks=1, layer_attns=(False, True), layer_cross_attns=(False, True), attn_heads=2)\n"
+            "assert '_sys' not in u._locals\nImagen([u], image_sizes=(16,), timesteps=4, text_embed_dim=32)\nprint('ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, timeout=300)
+    assert r.returncode == 0 and r.stdout.decode().strip().endswith("ok"), r.stdout.decode()[-1500:]
